@@ -1,0 +1,675 @@
+/*
+ * ndp_oracle.c -- CPU fp64 restatement of the ndp_nmpc_qd control step.
+ * TEST INFRASTRUCTURE ONLY -- see ndp_oracle.h for the scope and the
+ * "parity unpinned" statement.  Reference citations are relative to
+ * /root/reference/ndp_nmpc/scripts/.
+ */
+#include "ndp_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NX ORC_NX
+#define NU ORC_NU
+
+/* ------------------------------------------------------------------ config */
+
+void orc_default_cfg(orc_cfg *c)
+{
+    memset(c, 0, sizeof(*c));
+    c->N = 20;                 /* params/nmpc_params.py:9  */
+    c->n_rti = 1;              /* SQP_RTI: one iteration per update() call */
+    c->dt = 2.0 / 20.0;        /* params/nmpc_params.py:10,12 */
+    c->mass = 1.4844;          /* params/fhnp_params.py:9  */
+    c->g = 9.81;               /* params/fhnp_params.py:12 */
+    /* nmpc_body_rate_ctl.py:48 with params/nmpc_params.py:28-35 */
+    const double Qd[10] = {300, 300, 400, 10, 10, 10, 0, 10, 10, 100};
+    const double Rd[4] = {10, 10, 10, 5};
+    memcpy(c->Qd, Qd, sizeof(Qd));
+    memcpy(c->Rd, Rd, sizeof(Rd));
+    for (int i = 0; i < 3; ++i) {
+        c->lbu[i] = -6.0;      /* w_min  nmpc_params.py:19-20 */
+        c->ubu[i] = 6.0;
+        c->lbv[i] = -20.0;     /* v_min  nmpc_params.py:24-25 */
+        c->ubv[i] = 20.0;
+    }
+    c->lbu[3] = 0.0;           /* c_min  nmpc_params.py:22 */
+    c->ubu[3] = 9.81 / 0.36;   /* c_max  fhnp_params.py:19 */
+    c->use_fd = 0;
+    c->mu0 = 10.0;
+    c->thr0 = 0.1;
+    c->tol = 1e-8;
+    c->tau = 0.995;
+    c->iter_max = 50;
+}
+
+/* ---------------------------------------------------------------- dynamics */
+
+/* nmpc_body_rate_ctl.py:147-158; NDP: ndp_nmpc_body_rate_ctl.py:151-162 */
+void orc_dynamics(const orc_cfg *c, const double *x, const double *u, const double *fd, double *xd)
+{
+    const double vx = x[3], vy = x[4], vz = x[5];
+    const double qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    const double wx = u[0], wy = u[1], wz = u[2], cc = u[3];
+    xd[0] = vx;
+    xd[1] = vy;
+    xd[2] = vz;
+    xd[3] = 2.0 * (qx * qz + qw * qy) * cc;
+    xd[4] = 2.0 * (qy * qz - qw * qx) * cc;
+    xd[5] = (1.0 - 2.0 * qx * qx - 2.0 * qy * qy) * cc - c->g;
+    if (c->use_fd && fd) {
+        xd[3] += fd[0] / c->mass;
+        xd[4] += fd[1] / c->mass;
+        xd[5] += fd[2] / c->mass;
+    }
+    xd[6] = (-wx * qx - wy * qy - wz * qz) * 0.5;
+    xd[7] = (wx * qw + wz * qy - wy * qz) * 0.5;
+    xd[8] = (wy * qw - wz * qx + wx * qz) * 0.5;
+    xd[9] = (wz * qw + wy * qx - wx * qy) * 0.5;
+}
+
+/* SURVEY Appendix A.2 (derivatives of the expressions above) */
+void orc_jacobians(const double *x, const double *u, double *A, double *B)
+{
+    const double qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    const double wx = u[0], wy = u[1], wz = u[2], cc = u[3];
+    memset(A, 0, sizeof(double) * NX * NX);
+    memset(B, 0, sizeof(double) * NX * NU);
+#define A_(i, j) A[(i)*NX + (j)]
+#define B_(i, j) B[(i)*NU + (j)]
+    A_(0, 3) = 1.0; A_(1, 4) = 1.0; A_(2, 5) = 1.0;
+    A_(3, 6) = 2 * cc * qy;  A_(3, 7) = 2 * cc * qz;  A_(3, 8) = 2 * cc * qw; A_(3, 9) = 2 * cc * qx;
+    A_(4, 6) = -2 * cc * qx; A_(4, 7) = -2 * cc * qw; A_(4, 8) = 2 * cc * qz; A_(4, 9) = 2 * cc * qy;
+    A_(5, 7) = -4 * cc * qx; A_(5, 8) = -4 * cc * qy;
+    A_(6, 7) = -0.5 * wx; A_(6, 8) = -0.5 * wy; A_(6, 9) = -0.5 * wz;
+    A_(7, 6) = 0.5 * wx;  A_(7, 8) = 0.5 * wz;  A_(7, 9) = -0.5 * wy;
+    A_(8, 6) = 0.5 * wy;  A_(8, 7) = -0.5 * wz; A_(8, 9) = 0.5 * wx;
+    A_(9, 6) = 0.5 * wz;  A_(9, 7) = 0.5 * wy;  A_(9, 8) = -0.5 * wx;
+    B_(3, 3) = 2.0 * (qx * qz + qw * qy);
+    B_(4, 3) = 2.0 * (qy * qz - qw * qx);
+    B_(5, 3) = 1.0 - 2.0 * qx * qx - 2.0 * qy * qy;
+    B_(6, 0) = -0.5 * qx; B_(6, 1) = -0.5 * qy; B_(6, 2) = -0.5 * qz;
+    B_(7, 0) = 0.5 * qw;  B_(7, 1) = -0.5 * qz; B_(7, 2) = 0.5 * qy;
+    B_(8, 0) = 0.5 * qz;  B_(8, 1) = 0.5 * qw;  B_(8, 2) = -0.5 * qx;
+    B_(9, 0) = -0.5 * qy; B_(9, 1) = 0.5 * qx;  B_(9, 2) = 0.5 * qw;
+#undef A_
+#undef B_
+}
+
+/* one stage of the variational ODE: K = A(xs) S + [0 | B(xs)], S is 10 x 14 */
+static void vde_stage(const orc_cfg *c, const double *xs, const double *u, const double *fd,
+                      const double *S, double *k, double *K)
+{
+    double A[NX * NX], B[NX * NU];
+    orc_dynamics(c, xs, u, fd, k);
+    orc_jacobians(xs, u, A, B);
+    for (int i = 0; i < NX; ++i)
+        for (int j = 0; j < NX + NU; ++j) {
+            double s = 0.0;
+            for (int l = 0; l < NX; ++l) s += A[i * NX + l] * S[l * (NX + NU) + j];
+            if (j >= NX) s += B[i * NU + (j - NX)];
+            K[i * (NX + NU) + j] = s;
+        }
+}
+
+/* acados sim_erk: classical RK4 tableau, num_stages=4, num_steps=1 (options
+ * not set by nmpc_body_rate_ctl.py:71-80, so acados defaults), forward
+ * sensitivities from the variational equation with the same tableau.       */
+void orc_rk4_sens(const orc_cfg *c, const double *x, const double *u, const double *fd,
+                  double *xn, double *A, double *B)
+{
+    enum { NS = NX + NU };
+    const double h = c->dt;
+    double S0[NX * NS], St[NX * NS], xs[NX];
+    double k1[NX], k2[NX], k3[NX], k4[NX];
+    double K1[NX * NS], K2[NX * NS], K3[NX * NS], K4[NX * NS];
+    memset(S0, 0, sizeof(S0));
+    for (int i = 0; i < NX; ++i) S0[i * NS + i] = 1.0;
+
+    vde_stage(c, x, u, fd, S0, k1, K1);
+    for (int i = 0; i < NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
+    for (int i = 0; i < NX * NS; ++i) St[i] = S0[i] + 0.5 * h * K1[i];
+    vde_stage(c, xs, u, fd, St, k2, K2);
+    for (int i = 0; i < NX; ++i) xs[i] = x[i] + 0.5 * h * k2[i];
+    for (int i = 0; i < NX * NS; ++i) St[i] = S0[i] + 0.5 * h * K2[i];
+    vde_stage(c, xs, u, fd, St, k3, K3);
+    for (int i = 0; i < NX; ++i) xs[i] = x[i] + h * k3[i];
+    for (int i = 0; i < NX * NS; ++i) St[i] = S0[i] + h * K3[i];
+    vde_stage(c, xs, u, fd, St, k4, K4);
+
+    for (int i = 0; i < NX; ++i)
+        xn[i] = x[i] + h / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+    for (int i = 0; i < NX; ++i)
+        for (int j = 0; j < NS; ++j) {
+            const int ij = i * NS + j;
+            const double s = S0[ij] + h / 6.0 * (K1[ij] + 2.0 * K2[ij] + 2.0 * K3[ij] + K4[ij]);
+            if (j < NX) A[i * NX + j] = s;
+            else B[i * NU + (j - NX)] = s;
+        }
+}
+
+/* -------------------------------------------------------------------- cost */
+
+/* NONLINEAR_LS residual and Gauss-Newton blocks.
+ * y = [p, v, qwr, qe + q_r,xyz, u]  (nmpc_body_rate_ctl.py:164-180,194-195)
+ * yref = [xr, ur], p = xr[6:10]    (nmpc_body_rate_ctl.py:96-100)
+ * => residual = [p-pr, v-vr, 0, qe, u-ur]; d(qe)/dq = E(q_r)
+ * scale = dt for stages 0..N-1, 1 for the terminal stage (acados scales the
+ * stage cost by the shooting interval; the terminal cost is unscaled).      */
+void orc_cost_stage(const orc_cfg *c, double scale, const double *x, const double *u,
+                    const double *xr, const double *ur,
+                    double *Q, double *q, double *Rdiag, double *r)
+{
+    const double qwr = xr[6], qxr = xr[7], qyr = xr[8], qzr = xr[9];
+    const double qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    double E[3][4] = {{-qxr, qwr, -qzr, qyr}, {-qyr, qzr, qwr, -qxr}, {-qzr, -qyr, qxr, qwr}};
+    double qe[3];
+    /* nmpc_body_rate_ctl.py:164-166 */
+    qe[0] = qwr * qx - qw * qxr + qyr * qz - qy * qzr;
+    qe[1] = qwr * qy - qw * qyr - qxr * qz + qx * qzr;
+    qe[2] = qxr * qy - qx * qyr + qwr * qz - qw * qzr;
+    memset(Q, 0, sizeof(double) * NX * NX);
+    memset(q, 0, sizeof(double) * NX);
+    for (int i = 0; i < 6; ++i) {
+        Q[i * NX + i] = scale * c->Qd[i];
+        q[i] = scale * c->Qd[i] * (x[i] - xr[i]);
+    }
+    /* row 6 (qwr - yref[6] = 0) has zero Jacobian and zero weight */
+    for (int a = 0; a < 4; ++a) {
+        double g = 0.0;
+        for (int m = 0; m < 3; ++m) g += E[m][a] * c->Qd[7 + m] * qe[m];
+        q[6 + a] = scale * g;
+        for (int b = 0; b < 4; ++b) {
+            double s = 0.0;
+            for (int m = 0; m < 3; ++m) s += E[m][a] * c->Qd[7 + m] * E[m][b];
+            Q[(6 + a) * NX + 6 + b] = scale * s;
+        }
+    }
+    if (u) {
+        for (int i = 0; i < NU; ++i) {
+            Rdiag[i] = scale * c->Rd[i];
+            r[i] = scale * c->Rd[i] * (u[i] - ur[i]);
+        }
+    }
+}
+
+/* ----------------------------------------------------------------- Riccati */
+
+typedef struct {
+    double K[ORC_NMAX][NU * NX];
+    double kff[ORC_NMAX][NU];
+} ric_gain;
+
+static int chol4(double *L) /* in: SPD 4x4 row-major (lower used); out: lower factor */
+{
+    for (int j = 0; j < NU; ++j) {
+        double d = L[j * NU + j];
+        for (int l = 0; l < j; ++l) d -= L[j * NU + l] * L[j * NU + l];
+        if (!(d > 0.0)) return 1;
+        d = sqrt(d);
+        L[j * NU + j] = d;
+        for (int i = j + 1; i < NU; ++i) {
+            double s = L[i * NU + j];
+            for (int l = 0; l < j; ++l) s -= L[i * NU + l] * L[j * NU + l];
+            L[i * NU + j] = s / d;
+        }
+    }
+    return 0;
+}
+
+static void chol4_solve(const double *L, double *v) /* v <- (L L^T)^-1 v */
+{
+    for (int i = 0; i < NU; ++i) {
+        double s = v[i];
+        for (int l = 0; l < i; ++l) s -= L[i * NU + l] * v[l];
+        v[i] = s / L[i * NU + i];
+    }
+    for (int i = NU - 1; i >= 0; --i) {
+        double s = v[i];
+        for (int l = i + 1; l < NU; ++l) s -= L[l * NU + i] * v[l];
+        v[i] = s / L[i * NU + i];
+    }
+}
+
+/* Backward Riccati recursion + forward rollout of
+ *   min sum 1/2 dx'Q dx + q'dx + 1/2 du'R du + r'du  s.t. dx+ = A dx + B du + b
+ * Qe/qe/Re/re are the effective (barrier-augmented) blocks.                 */
+static int riccati_solve(int N, const double *A, const double *B, const double *b,
+                         const double *Qe, const double *qe, const double *Re, const double *re,
+                         const double *dx0, double *dx, double *du, ric_gain *G)
+{
+    double P[NX * NX], p[NX];
+    memcpy(P, Qe + (size_t)N * NX * NX, sizeof(P));
+    memcpy(p, qe + (size_t)N * NX, sizeof(p));
+    for (int k = N - 1; k >= 0; --k) {
+        const double *Ak = A + (size_t)k * NX * NX, *Bk = B + (size_t)k * NX * NU;
+        const double *bk = b + (size_t)k * NX;
+        double Pb[NX], PA[NX * NX], PB[NX * NU];
+        for (int i = 0; i < NX; ++i) {
+            double s = p[i];
+            for (int l = 0; l < NX; ++l) s += P[i * NX + l] * bk[l];
+            Pb[i] = s;
+        }
+        for (int i = 0; i < NX; ++i) {
+            for (int j = 0; j < NX; ++j) {
+                double s = 0.0;
+                for (int l = 0; l < NX; ++l) s += P[i * NX + l] * Ak[l * NX + j];
+                PA[i * NX + j] = s;
+            }
+            for (int j = 0; j < NU; ++j) {
+                double s = 0.0;
+                for (int l = 0; l < NX; ++l) s += P[i * NX + l] * Bk[l * NU + j];
+                PB[i * NU + j] = s;
+            }
+        }
+        double Lam[NU * NU], Hux[NU * NX], hu[NU], Hxx[NX * NX], hx[NX];
+        for (int i = 0; i < NU; ++i) {
+            for (int j = 0; j < NU; ++j) {
+                double s = (i == j) ? Re[k * NU + i] : 0.0;
+                for (int l = 0; l < NX; ++l) s += Bk[l * NU + i] * PB[l * NU + j];
+                Lam[i * NU + j] = s;
+            }
+            for (int j = 0; j < NX; ++j) {
+                double s = 0.0;
+                for (int l = 0; l < NX; ++l) s += Bk[l * NU + i] * PA[l * NX + j];
+                Hux[i * NX + j] = s;
+            }
+            double s = re[k * NU + i];
+            for (int l = 0; l < NX; ++l) s += Bk[l * NU + i] * Pb[l];
+            hu[i] = s;
+        }
+        for (int i = 0; i < NX; ++i) {
+            for (int j = 0; j < NX; ++j) {
+                double s = Qe[(size_t)k * NX * NX + i * NX + j];
+                for (int l = 0; l < NX; ++l) s += Ak[l * NX + i] * PA[l * NX + j];
+                Hxx[i * NX + j] = s;
+            }
+            double s = qe[k * NX + i];
+            for (int l = 0; l < NX; ++l) s += Ak[l * NX + i] * Pb[l];
+            hx[i] = s;
+        }
+        if (chol4(Lam)) return 4;
+        /* K = -Lam^-1 Hux, kff = -Lam^-1 hu */
+        for (int j = 0; j < NX; ++j) {
+            double col[NU];
+            for (int i = 0; i < NU; ++i) col[i] = Hux[i * NX + j];
+            chol4_solve(Lam, col);
+            for (int i = 0; i < NU; ++i) G->K[k][i * NX + j] = -col[i];
+        }
+        double kf[NU];
+        memcpy(kf, hu, sizeof(kf));
+        chol4_solve(Lam, kf);
+        for (int i = 0; i < NU; ++i) G->kff[k][i] = -kf[i];
+        /* P = Hxx + Hux' K (symmetrised), p = hx + Hux' kff */
+        for (int i = 0; i < NX; ++i) {
+            for (int j = 0; j < NX; ++j) {
+                double s = Hxx[i * NX + j];
+                for (int l = 0; l < NU; ++l) s += Hux[l * NX + i] * G->K[k][l * NX + j];
+                P[i * NX + j] = s;
+            }
+            double s = hx[i];
+            for (int l = 0; l < NU; ++l) s += Hux[l * NX + i] * G->kff[k][l];
+            p[i] = s;
+        }
+        for (int i = 0; i < NX; ++i)
+            for (int j = i + 1; j < NX; ++j) {
+                const double s = 0.5 * (P[i * NX + j] + P[j * NX + i]);
+                P[i * NX + j] = s;
+                P[j * NX + i] = s;
+            }
+    }
+    memcpy(dx, dx0, sizeof(double) * NX);
+    for (int k = 0; k < N; ++k) {
+        const double *Ak = A + (size_t)k * NX * NX, *Bk = B + (size_t)k * NX * NU;
+        const double *xk = dx + (size_t)k * NX;
+        double *uk = du + (size_t)k * NU, *xn = dx + (size_t)(k + 1) * NX;
+        for (int i = 0; i < NU; ++i) {
+            double s = G->kff[k][i];
+            for (int l = 0; l < NX; ++l) s += G->K[k][i * NX + l] * xk[l];
+            uk[i] = s;
+        }
+        for (int i = 0; i < NX; ++i) {
+            double s = b[(size_t)k * NX + i];
+            for (int l = 0; l < NX; ++l) s += Ak[i * NX + l] * xk[l];
+            for (int l = 0; l < NU; ++l) s += Bk[i * NU + l] * uk[l];
+            xn[i] = s;
+        }
+    }
+    return 0;
+}
+
+void orc_qp_riccati(int N, const double *A, const double *B, const double *b,
+                    const double *Q, const double *q, const double *Rd, const double *r,
+                    const double *dx0, double *dx, double *du)
+{
+    ric_gain *G = (ric_gain *)malloc(sizeof(ric_gain));
+    riccati_solve(N, A, B, b, Q, q, Rd, r, dx0, dx, du, G);
+    free(G);
+}
+
+/* --------------------------------------------------- interior-point method */
+
+/* Bounded step variables, in the order the QP uses them:
+ *   du_k[0..3], k=0..N-1              (idxbu = 0..3, nmpc_body_rate_ctl.py:56-58)
+ *   dv_k[0..2] = dx_k[3..5], k=1..N-1 (idxbx = 3,4,5, nmpc_body_rate_ctl.py:59-61;
+ *                                      lbx/ubx apply to intermediate stages only,
+ *                                      stage 0 is the x0 equality)             */
+typedef struct {
+    double lo, hi;      /* bounds on the step variable */
+    double tl, tu, ll, lu; /* slacks and multipliers */
+    double dtl, dtu, dll, dlu;
+    int stage, idx;     /* idx<4: u index, else 4+(v index) */
+} ipm_con;
+
+static double con_value(const ipm_con *cn, const double *dx, const double *du)
+{
+    return cn->idx < NU ? du[cn->stage * NU + cn->idx] : dx[cn->stage * NX + 3 + (cn->idx - NU)];
+}
+
+/* Primal-dual Mehrotra predictor-corrector in "absolute" form: every Newton
+ * system is the equality-constrained QP with Hessian diag += Gamma and
+ * gradient += gamma, solved by the Riccati recursion (what HPIPM does with
+ * d_ocp_qp_fact_solve_kkt_step).  All linear residuals (stationarity,
+ * dynamics, slack definitions) contract by (1-alpha) per iteration, so they
+ * are tracked by the scalar rho.                                             */
+int orc_qp_solve(const orc_cfg *c, int N, const double *A, const double *B, const double *b,
+                 const double *Q, const double *q, const double *Rd, const double *r,
+                 const double *dx0, const double *lu, const double *uu,
+                 const double *lv, const double *uv,
+                 double *dx, double *du, orc_stats *st)
+{
+    const int m = NU * N + 3 * (N - 1);
+    ipm_con *cn = (ipm_con *)calloc((size_t)m, sizeof(ipm_con));
+    double *Qe = (double *)malloc(sizeof(double) * (size_t)(N + 1) * NX * NX);
+    double *qe = (double *)malloc(sizeof(double) * (size_t)(N + 1) * NX);
+    double *Re = (double *)malloc(sizeof(double) * (size_t)N * NU);
+    double *re = (double *)malloc(sizeof(double) * (size_t)N * NU);
+    double *zx = (double *)calloc((size_t)(N + 1) * NX, sizeof(double));
+    double *zu = (double *)calloc((size_t)N * NU, sizeof(double));
+    double *nx_ = (double *)malloc(sizeof(double) * (size_t)(N + 1) * NX);
+    double *nu_ = (double *)malloc(sizeof(double) * (size_t)N * NU);
+    ric_gain *G = (ric_gain *)malloc(sizeof(ric_gain));
+    int status = 0, iters = 0, n = 0;
+
+    for (int k = 0; k < N; ++k)
+        for (int i = 0; i < NU; ++i, ++n) {
+            cn[n].stage = k; cn[n].idx = i;
+            cn[n].lo = lu[k * NU + i]; cn[n].hi = uu[k * NU + i];
+        }
+    for (int k = 1; k < N; ++k)
+        for (int i = 0; i < 3; ++i, ++n) {
+            cn[n].stage = k; cn[n].idx = NU + i;
+            cn[n].lo = lv[k * 3 + i]; cn[n].hi = uv[k * 3 + i];
+        }
+
+    /* cold start (qp_solver_warm_start left at 0, nmpc_body_rate_ctl.py:73-74) */
+    double norm0 = 1.0, mu = 0.0;
+    for (int i = 0; i < m; ++i) {
+        cn[i].tl = fmax(-cn[i].lo, c->thr0);
+        cn[i].tu = fmax(cn[i].hi, c->thr0);
+        cn[i].ll = c->mu0 / cn[i].tl;
+        cn[i].lu = c->mu0 / cn[i].tu;
+        mu += cn[i].ll * cn[i].tl + cn[i].lu * cn[i].tu;
+        norm0 = fmax(norm0, fmax(cn[i].ll, cn[i].lu));
+        norm0 = fmax(norm0, fmax(fabs(-cn[i].lo - cn[i].tl), fabs(cn[i].hi - cn[i].tu)));
+    }
+    mu /= (2.0 * m);
+    for (int i = 0; i < (N + 1) * NX; ++i) norm0 = fmax(norm0, fabs(q[i]));
+    for (int i = 0; i < N * NU; ++i) norm0 = fmax(norm0, fabs(r[i]));
+    for (int i = 0; i < N * NX; ++i) norm0 = fmax(norm0, fabs(b[i]));
+    for (int i = 0; i < NX; ++i) norm0 = fmax(norm0, fabs(dx0[i]));
+    double rho = 1.0;
+
+    for (;;) {
+        if (mu <= c->tol && rho * norm0 <= c->tol) break;
+        if (iters >= c->iter_max) { status = 4; break; }
+        ++iters;
+        double sigma_mu = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            /* barrier-augmented blocks */
+            memcpy(Qe, Q, sizeof(double) * (size_t)(N + 1) * NX * NX);
+            memcpy(qe, q, sizeof(double) * (size_t)(N + 1) * NX);
+            memcpy(Re, Rd, sizeof(double) * (size_t)N * NU);
+            memcpy(re, r, sizeof(double) * (size_t)N * NU);
+            for (int i = 0; i < m; ++i) {
+                ipm_con *cc = &cn[i];
+                const double sl = pass ? sigma_mu - cc->dll * cc->dtl : 0.0;
+                const double su = pass ? sigma_mu - cc->dlu * cc->dtu : 0.0;
+                const double gl = cc->ll / cc->tl, gu = cc->lu / cc->tu;
+                const double Gam = gl + gu;
+                const double gam = -sl / cc->tl - cc->ll - gl * cc->lo + su / cc->tu + cc->lu - gu * cc->hi;
+                if (cc->idx < NU) {
+                    Re[cc->stage * NU + cc->idx] += Gam;
+                    re[cc->stage * NU + cc->idx] += gam;
+                } else {
+                    const int j = 3 + cc->idx - NU;
+                    Qe[(size_t)cc->stage * NX * NX + j * NX + j] += Gam;
+                    qe[cc->stage * NX + j] += gam;
+                }
+            }
+            if (riccati_solve(N, A, B, b, Qe, qe, Re, re, dx0, nx_, nu_, G)) { status = 4; goto done; }
+            /* slack / multiplier steps and the largest feasible step length */
+            double alpha = 1.0;
+            for (int i = 0; i < m; ++i) {
+                ipm_con *cc = &cn[i];
+                const double zn = con_value(cc, nx_, nu_);
+                const double sl = pass ? sigma_mu - cc->dll * cc->dtl : 0.0;
+                const double su = pass ? sigma_mu - cc->dlu * cc->dtu : 0.0;
+                const double dtl = zn - cc->lo - cc->tl, dtu = cc->hi - zn - cc->tu;
+                const double dll = sl / cc->tl - cc->ll - cc->ll / cc->tl * dtl;
+                const double dlu = su / cc->tu - cc->lu - cc->lu / cc->tu * dtu;
+                cc->dtl = dtl; cc->dtu = dtu; cc->dll = dll; cc->dlu = dlu;
+                if (dtl < 0.0) alpha = fmin(alpha, -cc->tl / dtl);
+                if (dtu < 0.0) alpha = fmin(alpha, -cc->tu / dtu);
+                if (dll < 0.0) alpha = fmin(alpha, -cc->ll / dll);
+                if (dlu < 0.0) alpha = fmin(alpha, -cc->lu / dlu);
+            }
+            if (pass == 0) {
+                double mu_aff = 0.0;
+                for (int i = 0; i < m; ++i) {
+                    const ipm_con *cc = &cn[i];
+                    mu_aff += (cc->ll + alpha * cc->dll) * (cc->tl + alpha * cc->dtl)
+                            + (cc->lu + alpha * cc->dlu) * (cc->tu + alpha * cc->dtu);
+                }
+                mu_aff /= (2.0 * m);
+                const double s = mu_aff / mu;
+                sigma_mu = s * s * s * mu;
+            } else {
+                if (alpha < 1.0) alpha *= c->tau;
+                for (int i = 0; i < (N + 1) * NX; ++i) zx[i] += alpha * (nx_[i] - zx[i]);
+                for (int i = 0; i < N * NU; ++i) zu[i] += alpha * (nu_[i] - zu[i]);
+                mu = 0.0;
+                for (int i = 0; i < m; ++i) {
+                    ipm_con *cc = &cn[i];
+                    cc->tl += alpha * cc->dtl; cc->tu += alpha * cc->dtu;
+                    cc->ll += alpha * cc->dll; cc->lu += alpha * cc->dlu;
+                    mu += cc->ll * cc->tl + cc->lu * cc->tu;
+                }
+                mu /= (2.0 * m);
+                rho *= (1.0 - alpha);
+            }
+        }
+        if (!(mu == mu)) { status = 1; break; }
+    }
+done:
+    memcpy(dx, zx, sizeof(double) * (size_t)(N + 1) * NX);
+    memcpy(du, zu, sizeof(double) * (size_t)N * NU);
+    if (st) {
+        st->status = status;
+        st->ipm_iters = iters;
+        st->mu = mu;
+        st->n_active = 0;
+        for (int i = 0; i < m; ++i)
+            st->n_active += (cn[i].ll > 1e-6) + (cn[i].lu > 1e-6);
+    }
+    free(cn); free(Qe); free(qe); free(Re); free(re); free(zx); free(zu); free(nx_); free(nu_); free(G);
+    return status;
+}
+
+/* ------------------------------------------------------------- SQP-RTI step */
+
+void orc_reset(const orc_cfg *c, const double *xr, const double *ur, double *X, double *U)
+{
+    /* nmpc_body_rate_ctl.py:86-91 */
+    memcpy(X, xr, sizeof(double) * (size_t)(c->N + 1) * NX);
+    memcpy(U, ur, sizeof(double) * (size_t)c->N * NU);
+}
+
+void orc_linearize(const orc_cfg *c, const double *x0, const double *xr, const double *ur,
+                   const double *f, const double *X, const double *U,
+                   double *A, double *B, double *b, double *Q, double *q, double *Rd, double *r,
+                   double *dx0, double *lu, double *uu, double *lv, double *uv)
+{
+    const int N = c->N;
+    for (int k = 0; k < N; ++k) {
+        const double *xk = X + (size_t)k * NX, *uk = U + (size_t)k * NU;
+        double xn[NX], fdk[3] = {0, 0, 0};
+        /* p_k = [xr_k[6:10], f[k,:]]  ndp_nmpc_body_rate_ctl.py:97-99 */
+        if (c->use_fd && f) { fdk[0] = f[k * 3]; fdk[1] = f[k * 3 + 1]; fdk[2] = f[k * 3 + 2]; }
+        orc_rk4_sens(c, xk, uk, fdk, xn, A + (size_t)k * NX * NX, B + (size_t)k * NX * NU);
+        for (int i = 0; i < NX; ++i) b[k * NX + i] = xn[i] - X[(size_t)(k + 1) * NX + i];
+        orc_cost_stage(c, c->dt, xk, uk, xr + (size_t)k * NX, ur + (size_t)k * NU,
+                       Q + (size_t)k * NX * NX, q + (size_t)k * NX, Rd + (size_t)k * NU, r + (size_t)k * NU);
+        for (int i = 0; i < NU; ++i) {
+            lu[k * NU + i] = c->lbu[i] - uk[i];
+            uu[k * NU + i] = c->ubu[i] - uk[i];
+        }
+        for (int i = 0; i < 3; ++i) {
+            lv[k * 3 + i] = c->lbv[i] - xk[3 + i];
+            uv[k * 3 + i] = c->ubv[i] - xk[3 + i];
+        }
+    }
+    /* terminal: yref_N = xr_N, W_e = Q unscaled (nmpc_body_rate_ctl.py:53,101-104) */
+    orc_cost_stage(c, 1.0, X + (size_t)N * NX, NULL, xr + (size_t)N * NX, NULL,
+                   Q + (size_t)N * NX * NX, q + (size_t)N * NX, NULL, NULL);
+    for (int i = 0; i < 3; ++i) { lv[N * 3 + i] = -1e30; uv[N * 3 + i] = 1e30; }
+    /* solve_for_x0: lbx_0 = ubx_0 = x0 (nmpc_body_rate_ctl.py:107) */
+    for (int i = 0; i < NX; ++i) dx0[i] = x0[i] - X[i];
+}
+
+int orc_step(const orc_cfg *c, const double *x0, const double *xr, const double *ur,
+             const double *f, double *X, double *U, double *u0, orc_stats *st)
+{
+    const int N = c->N;
+    double *w = (double *)malloc(sizeof(double) *
+        ((size_t)N * (NX * NX + NX * NU + NX + NU + NU + NU + NU) + (size_t)(N + 1) * (NX * NX + NX + 3 + 3 + NX) + NX + (size_t)N * NU));
+    double *A = w, *B = A + (size_t)N * NX * NX, *b = B + (size_t)N * NX * NU;
+    double *Rd = b + (size_t)N * NX, *r = Rd + (size_t)N * NU, *lu = r + (size_t)N * NU, *uu = lu + (size_t)N * NU;
+    double *Q = uu + (size_t)N * NU, *q = Q + (size_t)(N + 1) * NX * NX;
+    double *lv = q + (size_t)(N + 1) * NX, *uv = lv + (size_t)(N + 1) * 3;
+    double *dx = uv + (size_t)(N + 1) * 3, *dx0 = dx + (size_t)(N + 1) * NX, *du = dx0 + NX;
+    orc_stats acc = {0, 0, 0, 0.0};
+    for (int it = 0; it < c->n_rti; ++it) {
+        orc_stats s1;
+        orc_linearize(c, x0, xr, ur, f, X, U, A, B, b, Q, q, Rd, r, dx0, lu, uu, lv, uv);
+        orc_qp_solve(c, N, A, B, b, Q, q, Rd, r, dx0, lu, uu, lv, uv, dx, du, &s1);
+        /* full step, no line search */
+        for (int i = 0; i < (N + 1) * NX; ++i) X[i] += dx[i];
+        for (int i = 0; i < N * NU; ++i) U[i] += du[i];
+        acc.ipm_iters += s1.ipm_iters;
+        acc.n_active = s1.n_active;
+        acc.mu = s1.mu;
+        if (s1.status && !acc.status) acc.status = s1.status;
+    }
+    for (int i = 0; i < NU; ++i) {
+        u0[i] = U[i];
+        if (!(u0[i] == u0[i])) acc.status = 1;
+    }
+    if (st) *st = acc;
+    free(w);
+    return acc.status;
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int orc_step_batch(const orc_cfg *c, int B, const double *x0, const double *xr, const double *ur,
+                   const double *f, double *X, double *U, double *u0, int *status, int *ipm_iters,
+                   int nthreads)
+{
+    const int N = c->N;
+    int worst = 0;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads) reduction(max : worst)
+#endif
+    for (int i = 0; i < B; ++i) {
+        orc_stats s;
+        orc_step(c, x0 + (size_t)i * NX, xr + (size_t)i * (N + 1) * NX, ur + (size_t)i * N * NU,
+                 f ? f + (size_t)i * (N + 1) * 3 : NULL, X + (size_t)i * (N + 1) * NX,
+                 U + (size_t)i * N * NU, u0 + (size_t)i * NU, &s);
+        if (status) status[i] = s.status;
+        if (ipm_iters) ipm_iters[i] = s.ipm_iters;
+        if (s.status > worst) worst = s.status;
+    }
+    return worst;
+}
+
+/* --------------------------------------------------------------------- MLP */
+
+static void dense_relu(const float *W, const float *bias, int nout, int nin, const float *in, float *out, int relu)
+{
+    for (int o = 0; o < nout; ++o) {
+        float s = bias[o];
+        for (int i = 0; i < nin; ++i) s += W[o * nin + i] * in[i];
+        out[o] = (relu && s < 0.0f) ? 0.0f : s;
+    }
+}
+
+/* nn_net.py:7-18: Linear(6,128) ReLU Linear(128,64) ReLU Linear(64,128) ReLU Linear(128,3) */
+void orc_mlp_forward(const float *blob, int rows, const float *in, float *out)
+{
+    const float *W1 = blob, *b1 = W1 + 128 * 6;
+    const float *W2 = b1 + 128, *b2 = W2 + 64 * 128;
+    const float *W3 = b2 + 64, *b3 = W3 + 128 * 64;
+    const float *W4 = b3 + 128, *b4 = W4 + 3 * 128;
+    for (int rI = 0; rI < rows; ++rI) {
+        float h1[128], h2[64], h3[128];
+        dense_relu(W1, b1, 128, 6, in + (size_t)rI * 6, h1, 1);
+        dense_relu(W2, b2, 64, 128, h1, h2, 1);
+        dense_relu(W3, b3, 128, 64, h2, h3, 1);
+        dense_relu(W4, b4, 3, 128, h3, out + (size_t)rI * 3, 0);
+    }
+}
+
+void orc_downwash(const float *blob, int N, double r_horiz, const double *other,
+                  const double *ego_ref, const double *ego_xy, float *f_out)
+{
+    const int rows = N + 1;
+    /* gate: ndp_nmpc_leader_node.py:65-68 (other.x[0] xy vs ego ODOMETRY xy) */
+    if (ego_xy) {
+        const double dx = other[0] - ego_xy[0], dy = other[1] - ego_xy[1];
+        if (!(dx * dx + dy * dy < r_horiz * r_horiz)) {
+            memset(f_out, 0, sizeof(float) * (size_t)rows * 3); /* :75-76 */
+            return;
+        }
+    }
+    float in[(ORC_NMAX + 1) * 6];
+    /* downwash_nn.py:22-23: (other - ego)[:, 0:6] in fp64, then cast to fp32 */
+    for (int k = 0; k < rows; ++k)
+        for (int j = 0; j < 6; ++j)
+            in[k * 6 + j] = (float)(other[k * NX + j] - ego_ref[k * NX + j]);
+    orc_mlp_forward(blob, rows, in, f_out);
+}
+
+void orc_downwash_batch(const float *blob, int B, int N, double r_horiz, const double *other,
+                        const double *ego_ref, const double *ego_xy, float *f_out, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+    for (int i = 0; i < B; ++i)
+        orc_downwash(blob, N, r_horiz, other + (size_t)i * (N + 1) * NX, ego_ref + (size_t)i * (N + 1) * NX,
+                     ego_xy ? ego_xy + (size_t)i * 2 : NULL, f_out + (size_t)i * (N + 1) * 3);
+}

@@ -1,0 +1,118 @@
+/*
+ * ndp_oracle.h -- CPU fp64 restatement of the ndp_nmpc_qd control step.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED (NMPC half): the reference's NMPC arithmetic lives in
+ * acados / HPIPM / BLASFEO / CasADi-generated C, none of which is vendored in
+ * /root/reference, pinned to a version (README.md:24) or installed in the
+ * build image, and the reference has no tests or golden vectors.  This file
+ * restates the *published algorithm* those options select
+ * (nmpc_body_rate_ctl.py:71-80: SQP_RTI, ERK, GAUSS_NEWTON, HPIPM) and is
+ * pinned instead by independent cross-checks in tests/ (finite differences,
+ * dense KKT solves, an active-set QP solver, analytic hover answers).
+ * The MLP half IS pinned: tests/golden/mlp_golden.npz was produced by
+ * importing the reference's nn_net.py + shipped SN=4 weights.
+ */
+#ifndef NDP_ORACLE_H
+#define NDP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NX 10
+#define ORC_NU 4
+#define ORC_NMAX 64
+
+typedef struct {
+    int N;          /* shooting intervals          nmpc_params.py:9  */
+    int n_rti;      /* SQP-RTI iterations per call (reference: 1)    */
+    double dt;      /* T_horizon / N_node          nmpc_params.py:12 */
+    double mass;    /* fhnp_params.py:9  */
+    double g;       /* fhnp_params.py:12 */
+    double Qd[10];  /* diag of Q   nmpc_body_rate_ctl.py:48 */
+    double Rd[4];   /* diag of R   nmpc_body_rate_ctl.py:49 */
+    double lbu[4], ubu[4]; /* nmpc_body_rate_ctl.py:56-58 */
+    double lbv[3], ubv[3]; /* nmpc_body_rate_ctl.py:59-61, stages 1..N-1 */
+    int use_fd;     /* 1 = NDP variant (ndp_nmpc_body_rate_ctl.py:155-157) */
+    /* interior point (HPIPM-like Mehrotra predictor-corrector) */
+    double mu0, thr0, tol, tau;
+    int iter_max;
+} orc_cfg;
+
+typedef struct {
+    int status;       /* 0 ok, 1 NaN, 4 QP failure (acados status ints) */
+    int ipm_iters;    /* summed over rti iterations */
+    int n_active;     /* bounds active at the last QP solution */
+    double mu;        /* final complementarity */
+} orc_stats;
+
+void orc_default_cfg(orc_cfg *c);
+
+/* a1: continuous dynamics, nmpc_body_rate_ctl.py:147-158 */
+void orc_dynamics(const orc_cfg *c, const double *x, const double *u, const double *fd, double *xdot);
+/* analytic Jacobians of a1, row-major A[10][10], B[10][4] */
+void orc_jacobians(const double *x, const double *u, double *A, double *B);
+/* ERK4, one step of h, with forward sensitivities (acados sim_erk) */
+void orc_rk4_sens(const orc_cfg *c, const double *x, const double *u, const double *fd,
+                  double *xn, double *A, double *B);
+/* a2: residual y - yref and J_x^T W J_x, J_x^T W r; nmpc_body_rate_ctl.py:164-180 */
+void orc_cost_stage(const orc_cfg *c, double scale, const double *x, const double *u,
+                    const double *xr, const double *ur,
+                    double *Q /*10x10*/, double *q /*10*/, double *Rdiag /*4*/, double *r /*4*/);
+
+/* box-constrained OCP-QP in the step variables; dense per-stage row-major blocks.
+ * A[N][10][10] B[N][10][4] b[N][10] Q[N+1][10][10] q[N+1][10] Rd[N][4] r[N][4]
+ * lu/uu[N][4] bounds on du_k (k=0..N-1); lv/uv[N+1][3] bounds on dv_k (used k=1..N-1)
+ * out: dx[N+1][10], du[N][4]                                                   */
+int orc_qp_solve(const orc_cfg *c, int N, const double *A, const double *B, const double *b,
+                 const double *Q, const double *q, const double *Rd, const double *r,
+                 const double *dx0, const double *lu, const double *uu,
+                 const double *lv, const double *uv,
+                 double *dx, double *du, orc_stats *st);
+
+/* unconstrained (equality-only) Riccati solve of the same QP, for cross-checks */
+void orc_qp_riccati(int N, const double *A, const double *B, const double *b,
+                    const double *Q, const double *q, const double *Rd, const double *r,
+                    const double *dx0, double *dx, double *du);
+
+/* linearise at (X,U): fills the QP blocks above (a5 steps 2-3) */
+void orc_linearize(const orc_cfg *c, const double *x0, const double *xr, const double *ur,
+                   const double *f, const double *X, const double *U,
+                   double *A, double *B, double *b, double *Q, double *q, double *Rd, double *r,
+                   double *dx0, double *lu, double *uu, double *lv, double *uv);
+
+/* a4: reset -- X[k]=xr[k], U[k]=ur[k]   nmpc_body_rate_ctl.py:86-91 */
+void orc_reset(const orc_cfg *c, const double *xr, const double *ur, double *X, double *U);
+
+/* a5/a6: update() -- one (or n_rti) SQP-RTI iterations, iterate updated in place.
+ * x0[10] xr[(N+1)*10] ur[N*4] f[(N+1)*3] or NULL; X[(N+1)*10] U[N*4]; u0[4]   */
+int orc_step(const orc_cfg *c, const double *x0, const double *xr, const double *ur,
+             const double *f, double *X, double *U, double *u0, orc_stats *st);
+
+/* batch of independent instances, OpenMP over the batch (nthreads<=0: all cores) */
+int orc_step_batch(const orc_cfg *c, int B, const double *x0, const double *xr, const double *ur,
+                   const double *f, double *X, double *U, double *u0, int *status, int *ipm_iters,
+                   int nthreads);
+int orc_num_threads(void);
+
+/* a7: MLP 6-128-64-128-3, fp32 (nn_net.py:7-18). blob = W1(128x6) b1 W2(64x128) b2
+ * W3(128x64) b3 W4(3x128) b4, row-major [out][in], 17859 floats.                */
+#define ORC_MLP_NPARAM 17859
+void orc_mlp_forward(const float *blob, int rows, const float *in /*rows x 6*/, float *out /*rows x 3*/);
+
+/* a7+a8: DownwashNN.update + the gate at ndp_nmpc_leader_node.py:65-76.
+ * other[(N+1)*10], ego_ref[(N+1)*10] fp64; ego_xy[2] = ego odometry xy, or NULL = no gate.
+ * f_out[(N+1)*3] fp32.                                                          */
+void orc_downwash(const float *blob, int N, double r_horiz, const double *other,
+                  const double *ego_ref, const double *ego_xy, float *f_out);
+void orc_downwash_batch(const float *blob, int B, int N, double r_horiz, const double *other,
+                        const double *ego_ref, const double *ego_xy, float *f_out, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

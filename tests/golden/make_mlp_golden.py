@@ -1,0 +1,57 @@
+"""Generates the downwash-MLP fixtures by IMPORTING the reference (run in the build
+container only; /root/reference does not exist on the GPU box).
+
+Outputs (committed):
+  ndp_nmpc_qd_amd/weights/downwash_sn4.bin   flat little-endian fp32 blob of the shipped
+      state dict (downwash_nn.py:15), order W1 b1 W2 b2 W3 b3 W4 b4, each W row-major [out][in]
+  tests/golden/mlp_golden.npz                inputs/outputs of the reference network:
+      z[n,6] fp32 -> f[n,3] fp32 (eager torch CPU; TorchScript is bit-identical on CPU),
+      plus DownwashNN.update-shaped cases other/ego[c,21,10] fp64 -> f_update[c,21,3] fp32
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference/ndp_nmpc/scripts/dnwash_nn_est"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+sys.path.insert(0, REF)
+from nn_net import net  # noqa: E402  (the reference's nn.Sequential)
+
+sd = torch.load(os.path.join(REF, "nn_model", "128-64-128_WBias_SN=4_epoch=20000_test_loss=1.0221.pkl"),
+                map_location="cpu", weights_only=True)
+net.load_state_dict(sd)
+net.eval()
+
+blob = np.concatenate([sd[k].detach().numpy().astype("<f4").ravel()
+                       for k in ("0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias", "6.weight", "6.bias")])
+assert blob.size == 17859
+os.makedirs(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights"), exist_ok=True)
+blob.tofile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"))
+
+rng = np.random.Generator(np.random.PCG64(20231213))
+kat = np.array([[0, 0, 0.7, 0, 0, 0], [0, 0, -0.7, 0, 0, 0], [0.5, 0.5, 1.0, 0.1, -0.1, 0],
+                [0, 0, 0, 0, 0, 0], [0, 1.0, 0, 0, 0, 0]], dtype=np.float32)
+env = np.concatenate([rng.uniform(-1.5, 1.5, (507, 3)), rng.uniform(-3, 3, (507, 3))], axis=1).astype(np.float32)
+z = np.concatenate([kat, env], axis=0)
+with torch.no_grad():
+    f = net(torch.from_numpy(z)).numpy()
+    f_script = torch.jit.script(net)(torch.from_numpy(z)).numpy()
+assert np.array_equal(f, f_script)
+
+# DownwashNN.update semantics (downwash_nn.py:22-28) on full [21,10] windows
+C = 8
+ego = rng.normal(0, 1.0, (C, 21, 10))
+other = ego + np.concatenate([rng.uniform(-1.5, 1.5, (C, 21, 3)), rng.uniform(-2, 2, (C, 21, 3)),
+                              rng.normal(0, 0.1, (C, 21, 4))], axis=2)
+f_update = np.zeros((C, 21, 3), dtype=np.float32)
+with torch.no_grad():
+    for c in range(C):
+        inp = (other[c] - ego[c])[:, 0:6]
+        f_update[c] = net(torch.from_numpy(inp).to(torch.float32)).numpy()
+
+np.savez_compressed(os.path.join(HERE, "mlp_golden.npz"), z=z, f=f, other=other, ego=ego, f_update=f_update)
+print("blob", blob.size, "golden rows", z.shape[0], "kat f:\n", f[:5])

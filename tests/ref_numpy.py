@@ -1,0 +1,171 @@
+"""Independent numpy restatements used ONLY to pin the C oracle (tests).
+
+Everything here is written straight from the reference's symbolic expressions
+(nmpc_body_rate_ctl.py:147-180) and from textbook definitions (dense KKT
+systems, finite differences), sharing no code with oracle/ndp_oracle.c.
+"""
+import numpy as np
+
+NX, NU = 10, 4
+G = 9.81
+MASS = 1.4844
+
+
+def f_dyn(x, u, fd=None):
+    """nmpc_body_rate_ctl.py:147-158 (+ ndp_nmpc_body_rate_ctl.py:155-157)."""
+    vx, vy, vz, qw, qx, qy, qz = x[3:10]
+    wx, wy, wz, c = u
+    ds = np.array([
+        vx, vy, vz,
+        2 * (qx * qz + qw * qy) * c,
+        2 * (qy * qz - qw * qx) * c,
+        (1 - 2 * qx ** 2 - 2 * qy ** 2) * c - G,
+        (-wx * qx - wy * qy - wz * qz) * 0.5,
+        (wx * qw + wz * qy - wy * qz) * 0.5,
+        (wy * qw - wz * qx + wx * qz) * 0.5,
+        (wz * qw + wy * qx - wx * qy) * 0.5,
+    ])
+    if fd is not None:
+        ds[3:6] += np.asarray(fd) / MASS
+    return ds
+
+
+def rk4(x, u, fd=None, h=0.1):
+    k1 = f_dyn(x, u, fd)
+    k2 = f_dyn(x + 0.5 * h * k1, u, fd)
+    k3 = f_dyn(x + 0.5 * h * k2, u, fd)
+    k4 = f_dyn(x + h * k3, u, fd)
+    return x + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+
+
+def cost_y(x, u, qr):
+    """cost_y_expr, nmpc_body_rate_ctl.py:164-180,194."""
+    qw, qx, qy, qz = x[6:10]
+    qwr, qxr, qyr, qzr = qr
+    qe_x = qwr * qx - qw * qxr + qyr * qz - qy * qzr
+    qe_y = qwr * qy - qw * qyr - qxr * qz + qx * qzr
+    qe_z = qxr * qy - qx * qyr + qwr * qz - qw * qzr
+    sy = np.array([x[0], x[1], x[2], x[3], x[4], x[5], qwr, qe_x + qxr, qe_y + qyr, qe_z + qzr])
+    return sy if u is None else np.concatenate([sy, u])
+
+
+def fd_jac(fun, z, eps=1e-6):
+    z = np.asarray(z, dtype=np.float64)
+    f0 = fun(z)
+    J = np.zeros((f0.size, z.size))
+    for i in range(z.size):
+        d = np.zeros_like(z)
+        d[i] = eps
+        J[:, i] = (fun(z + d) - fun(z - d)) / (2 * eps)
+    return J
+
+
+def gn_blocks(x, u, xr, ur, W, scale):
+    """Gauss-Newton H = s J'WJ, g = s J'W(y - yref) with J by finite differences."""
+    qr = xr[6:10]
+    if u is None:
+        fun = lambda z: cost_y(z, None, qr)  # noqa: E731
+        z0, yref = x, xr
+    else:
+        fun = lambda z: cost_y(z[:NX], z[NX:], qr)  # noqa: E731
+        z0, yref = np.concatenate([x, u]), np.concatenate([xr, ur])
+    J = fd_jac(fun, z0)
+    res = fun(z0) - yref
+    return scale * J.T @ W @ J, scale * J.T @ W @ res
+
+
+def kkt_solve(qp, fixed=None):
+    """Dense KKT solve of the equality-constrained QP (+ optional variables pinned to values).
+
+    Variable order: dx_0..dx_N (10 each), du_0..du_{N-1} (4 each).
+    fixed: list of (var_index, value).  Returns dx, du, multipliers of the pinned variables
+    (sign: lam > 0 means the pin pushes the variable up, i.e. it is a LOWER bound multiplier).
+    """
+    A, B, b, Q, q, Rd, r, dx0 = (qp[k] for k in ("A", "B", "b", "Q", "q", "Rd", "r", "dx0"))
+    N = A.shape[0]
+    nz = (N + 1) * NX + N * NU
+    xo = lambda k: k * NX  # noqa: E731
+    uo = lambda k: (N + 1) * NX + k * NU  # noqa: E731
+    H = np.zeros((nz, nz))
+    g = np.zeros(nz)
+    for k in range(N + 1):
+        H[xo(k):xo(k) + NX, xo(k):xo(k) + NX] = Q[k]
+        g[xo(k):xo(k) + NX] = q[k]
+    for k in range(N):
+        H[uo(k):uo(k) + NU, uo(k):uo(k) + NU] = np.diag(Rd[k])
+        g[uo(k):uo(k) + NU] = r[k]
+    fixed = fixed or []
+    ne = (N + 1) * NX + len(fixed)
+    E = np.zeros((ne, nz))
+    e = np.zeros(ne)
+    E[0:NX, xo(0):xo(0) + NX] = np.eye(NX)
+    e[0:NX] = dx0
+    for k in range(N):
+        rows = slice((k + 1) * NX, (k + 2) * NX)
+        E[rows, xo(k + 1):xo(k + 1) + NX] = np.eye(NX)
+        E[rows, xo(k):xo(k) + NX] = -A[k]
+        E[rows, uo(k):uo(k) + NU] = -B[k]
+        e[rows] = b[k]
+    for i, (vi, val) in enumerate(fixed):
+        E[(N + 1) * NX + i, vi] = 1.0
+        e[(N + 1) * NX + i] = val
+    KKT = np.block([[H, E.T], [E, np.zeros((ne, ne))]])
+    sol = np.linalg.solve(KKT, np.concatenate([-g, e]))
+    z = sol[:nz]
+    mult = -sol[nz + (N + 1) * NX:]  # H z + g + E' nu = 0 -> pin multiplier = -nu
+    dx = z[:(N + 1) * NX].reshape(N + 1, NX)
+    du = z[(N + 1) * NX:].reshape(N, NU)
+    return dx, du, mult
+
+
+def bound_table(qp):
+    """[(var_index, lo, hi)] of the QP's box constraints (du all stages; dv stages 1..N-1)."""
+    N = qp["A"].shape[0]
+    out = []
+    for k in range(N):
+        for i in range(NU):
+            out.append(((N + 1) * NX + k * NU + i, qp["lu"][k, i], qp["uu"][k, i]))
+    for k in range(1, N):
+        for i in range(3):
+            out.append((k * NX + 3 + i, qp["lv"][k, i], qp["uv"][k, i]))
+    return out
+
+
+def active_set_solve(qp, max_iter=200):
+    """Textbook primal-feasible-agnostic active-set iteration on the dense KKT system:
+    pin violated variables to the violated bound, release pins whose multiplier has the
+    wrong sign, until the KKT conditions of the box-constrained QP hold exactly."""
+    table = bound_table(qp)
+    active = {}  # var -> ('lo'|'hi')
+    for _ in range(max_iter):
+        fixed = [(v, (lo if active[v] == "lo" else hi)) for (v, lo, hi) in table if v in active]
+        dx, du, mult = kkt_solve(qp, fixed)
+        z = np.concatenate([dx.ravel(), du.ravel()])
+        changed = False
+        # release wrong-signed pins (most negative first)
+        worst, worst_v = -1e-10, None
+        i = 0
+        for (v, lo, hi) in table:
+            if v in active:
+                lam = mult[i] if active[v] == "lo" else -mult[i]
+                if lam < worst:
+                    worst, worst_v = lam, v
+                i += 1
+        if worst_v is not None:
+            del active[worst_v]
+            changed = True
+        else:
+            viol, vv, side = 1e-10, None, None
+            for (v, lo, hi) in table:
+                if v in active:
+                    continue
+                if lo - z[v] > viol:
+                    viol, vv, side = lo - z[v], v, "lo"
+                if z[v] - hi > viol:
+                    viol, vv, side = z[v] - hi, v, "hi"
+            if vv is not None:
+                active[vv] = side
+                changed = True
+        if not changed:
+            return dx, du, active
+    raise RuntimeError("active set did not converge")
