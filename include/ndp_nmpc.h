@@ -1,0 +1,134 @@
+/*
+ * ndp_nmpc.h -- C-ABI of the MI355X-native batched NMPC + downwash control step.
+ *
+ * Drop-in boundary for the hot path of Li-Jinjie/ndp_nmpc_qd.  In the reference this
+ * boundary is acados_template's ctypes binding of the generated solver
+ * (AcadosOcpSolver.set / get / solve_for_x0, used at
+ *  ndp_nmpc/scripts/nmpc_ctl/nmpc_body_rate_ctl.py:84-112 and
+ *  ndp_nmpc/scripts/ndp_nmpc_ctl/ndp_nmpc_body_rate_ctl.py:82-112)
+ * plus torch's CUDA module call in dnwash_nn_est/downwash_nn.py:21-29.
+ * Each entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *  - plain C, no C++ types, no exceptions across the boundary;
+ *  - every function returns 0 on success, >0 = solver status of the worst instance
+ *    (acados ints: 1 NaN, 4 QP failure), <0 = API misuse or HIP error
+ *    (text via ndp_last_error);
+ *  - host arrays are row-major, batch-major: x0[B][10], xr[B][N+1][10], ur[B][N][4],
+ *    f[B][N+1][3] (fp32), other[B][N+1][10], ego_xy[B][2], u0[B][4];
+ *    state order [px,py,pz,vx,vy,vz,qw,qx,qy,qz] (nmpc_body_rate_ctl.py:130),
+ *    control order [wx,wy,wz,c] (:144);
+ *  - the caller owns every pointer for the duration of the call only; the library owns
+ *    device memory and the persistent SQP iterate (the warm start acados keeps);
+ *  - a handle is internally serialised (mutex): update / reset / get may be called from
+ *    different threads, as rospy does (nmpc_node.py:94,152,237);
+ *  - *_device variants take device pointers (HBM-resident inputs) and a hipStream_t
+ *    passed as void*; they enqueue work and do not synchronise.
+ */
+#ifndef NDP_NMPC_H
+#define NDP_NMPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDP_NX 10
+#define NDP_NU 4
+#define NDP_MLP_NPARAM 17859 /* 6-128-64-128-3 with biases, nn_net.py:7-18 */
+
+#define NDP_QP_AUTO 0       /* exact early exit when no bound is active, else interior point */
+#define NDP_QP_IPM_ALWAYS 1 /* always run the interior-point loop (what HPIPM does) */
+
+typedef struct ndp_cfg {
+    int32_t batch;      /* B: independent OCP instances in this handle            */
+    int32_t N;          /* shooting intervals        params/nmpc_params.py:9      */
+    int32_t n_rti;      /* SQP-RTI iterations per step (reference: 1)             */
+    int32_t use_fd;     /* 1 = NDP model, disturbance force in p (ndp_...ctl.py:146-162) */
+    int32_t qp_mode;    /* NDP_QP_*                                               */
+    int32_t iter_max;   /* interior-point iteration cap (acados default 50)       */
+    int32_t device;     /* HIP device ordinal                                     */
+    int32_t reserved;
+    double dt;          /* T_horizon / N_node        params/nmpc_params.py:10,12  */
+    double mass;        /* params/fhnp_params.py:9   */
+    double gravity;     /* params/fhnp_params.py:12  */
+    double r_horiz;     /* params/downwash_params.py:10 */
+    double Qd[10];      /* diag(Q)   nmpc_body_rate_ctl.py:48 */
+    double Rd[4];       /* diag(R)   nmpc_body_rate_ctl.py:49 */
+    double lbu[4], ubu[4]; /* nmpc_body_rate_ctl.py:56-58 */
+    double lbv[3], ubv[3]; /* nmpc_body_rate_ctl.py:59-61 (stages 1..N-1) */
+    double mu0, thr0, tol, tau; /* interior-point constants */
+} ndp_cfg;
+
+typedef struct ndp_handle ndp_handle;
+
+/* Fills cfg with the reference constants (the params package), batch = 1, N = 20. */
+int ndp_default_cfg(ndp_cfg *cfg);
+
+/* Replaces AcadosOcpSolver(ocp, json_file, build=...) (nmpc_body_rate_ctl.py:84):
+ * allocates device state for cfg->batch instances.  Fails (<0) when no HIP device is usable. */
+int ndp_create(const ndp_cfg *cfg, ndp_handle **out);
+int ndp_destroy(ndp_handle *h);
+const char *ndp_last_error(const ndp_handle *h); /* h may be NULL: last create error */
+
+/* Replaces nn_model.load_state_dict(torch.load(...)) (downwash_nn.py:14-16).
+ * blob: W1[128][6] b1 W2[64][128] b2 W3[128][64] b3 W4[3][128] b4, fp32, n = NDP_MLP_NPARAM. */
+int ndp_set_mlp_weights(ndp_handle *h, const float *blob, size_t n);
+
+/* Replaces NMPCBodyRateController.reset (nmpc_body_rate_ctl.py:86-91):
+ * iterate x_k := xr[k] (k=0..N), u_k := ur[k] (k=0..N-1), for every instance. */
+int ndp_reset(ndp_handle *h, const double *xr, const double *ur);
+int ndp_reset_device(ndp_handle *h, const void *d_xr, const void *d_ur, void *stream);
+
+/* Replaces update(x0, xr, ur[, f]) = 2N+2 solver.set calls + solver.solve_for_x0(x0)
+ * (nmpc_body_rate_ctl.py:93-112; ndp_nmpc_body_rate_ctl.py:91-112), batched.
+ *   f      : [B][N+1][3] fp32 disturbance force, or NULL            (NDP: p_k[4:7])
+ *   other  : [B][N+1][10] neighbour reference window, or NULL.  When given (and f is NULL,
+ *            use_fd = 1) the force is predicted on the device exactly as
+ *            NDPLeaderNode.sub_xf_pred_callback does (ndp_nmpc_leader_node.py:60-76):
+ *            f = MLP((other - xr)[:, 0:6]) if |other[0].xy - ego_xy|^2 < r_horiz^2 else 0
+ *   ego_xy : [B][2] ego odometry xy for that gate, or NULL = gate always open
+ *   u0     : [B][4] out, u_0 after the full step
+ * Returns the worst per-instance status (0 = all converged). */
+int ndp_step(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
+             const double *other, const double *ego_xy, double *u0);
+int ndp_step_device(ndp_handle *h, const void *d_x0, const void *d_xr, const void *d_ur, const void *d_f,
+                    const void *d_other, const void *d_ego_xy, void *d_u0, void *stream);
+
+/* Replaces DownwashNN.update(other_pred_x, ego_pred_x) (downwash_nn.py:21-29), batched, with the
+ * optional r_horiz gate.  f_out: [B][N+1][3] fp32. */
+int ndp_downwash(ndp_handle *h, const double *other, const double *ego_ref, const double *ego_xy, float *f_out);
+int ndp_downwash_device(ndp_handle *h, const void *d_other, const void *d_ego_ref, const void *d_ego_xy,
+                        void *d_f_out, void *stream);
+
+/* Replaces solver.get(i,"x"/"u") / solver.set(i,"x"/"u") (nmpc_node.py:237; nmpc_body_rate_ctl.py:88-91):
+ * whole iterate of every instance, X[B][N+1][10], U[B][N][4]. */
+int ndp_get_iterate(ndp_handle *h, double *X, double *U);
+int ndp_set_iterate(ndp_handle *h, const double *X, const double *U);
+
+/* Replaces solver.status (nmpc_body_rate_ctl.py:109): per-instance status of the last step and the
+ * interior-point iterations it took (0 = early exit).  Either pointer may be NULL. */
+int ndp_get_status(ndp_handle *h, int32_t *status, int32_t *ipm_iters);
+
+/* Device views for callers that keep everything in HBM (bench, multi-GPU driver). */
+void *ndp_device_iterate_x(ndp_handle *h);
+void *ndp_device_iterate_u(ndp_handle *h);
+void *ndp_device_force(ndp_handle *h);   /* [B][N+1][3] fp32 written by the fused downwash */
+int ndp_synchronize(ndp_handle *h);
+
+/* Per-kernel timing of the calls issued on the library's own stream since the last reset,
+ * measured with HIP events: name is "rti" or "mlp".  Returns <0 if nothing was timed. */
+int ndp_timing_enable(ndp_handle *h, int on);
+int ndp_timing_read(ndp_handle *h, const char *name, double *total_ms, int64_t *launches);
+
+/* Test hook: number of doubles of the LDS image dump, and a step that also dumps it (B = 1 use). */
+int ndp_debug_lds_doubles(int N);
+int ndp_step_debug(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
+                   double *u0, double *lds_dump);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

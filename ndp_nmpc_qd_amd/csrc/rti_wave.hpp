@@ -1,0 +1,757 @@
+// rti_wave.hpp -- one SQP-RTI control step of one quadrotor OCP, executed by ONE 64-lane wavefront.
+//
+// Replaces, for a batch of independent instances, what the reference reaches through
+// NMPCBodyRateController.update / NDPNMPCBodyRateController.update
+// (ndp_nmpc/scripts/nmpc_ctl/nmpc_body_rate_ctl.py:93-112, ndp_nmpc_ctl/ndp_nmpc_body_rate_ctl.py:91-112):
+// the acados-generated SQP_RTI / ERK / GAUSS_NEWTON / HPIPM solver configured at nmpc_body_rate_ctl.py:36-80.
+//
+// The program is written SPMD-style against a small "wave backend" W (per-lane value types vd/vi/vb,
+// LDS access, cross-lane reads, the 16x16x4 f64 matrix instruction).  The product instantiates it with
+// the gfx950 backend (wave_gfx950.hpp: v_mfma_f64_16x16x4_f64, v_readlane, LDS); tests instantiate the
+// same text with a host lock-step emulator so the algorithm can be checked without a GPU.
+// Control flow is wave-uniform everywhere; per-lane decisions are selects / predicated stores.
+//
+// Design:
+//  * everything of one instance lives in that wave's LDS slice (~38 KB at N=20) for the whole step;
+//  * linearisation (RK4 + forward sensitivities) is lane-parallel over (stage, sensitivity column);
+//  * the Riccati recursion runs in homogeneous coordinates z~ = [x(10), 1, 0, u(4)] so that one
+//    16x16 f64 MFMA tile carries the Hessian AND the gradient: per stage
+//        W = P~ M~ (3 mfma), H~ = M~' W + C~ (3), G = Lam^-1 H~ux (1), P~ = H~ - H~xu G (1), K~' (1)
+//    with every operand already in the register layout the previous instruction produced it in;
+//  * bounds are handled by a Mehrotra predictor-corrector interior-point loop around that recursion
+//    (same algorithm as oracle/ndp_oracle.c), with an exact early exit when the equality-constrained
+//    minimiser is strictly inside the box.
+#pragma once
+
+#ifndef NDP_HD
+#define NDP_HD inline
+#endif
+
+namespace ndp {
+
+enum { NX = 10, NU = 4 };
+enum { QP_AUTO = 0, QP_IPM_ALWAYS = 1 };
+enum { MB_STRIDE = 86, CB_STRIDE = 47, KT_STRIDE = 48 };
+// stage block MB_k: 6x8 [d(p,v)+/d(q,u)] | 4x7 [dq+/d(q,w)] | b(10)
+enum { MB_PV = 0, MB_Q = 48, MB_B = 76 };
+// cost block CB_k: Qq(4x4) | qe(10) | re(4) | dex(6) | deu(4) | qbv(3) | rb(4)
+enum { CB_QQ = 0, CB_QE = 16, CB_RE = 26, CB_DEX = 30, CB_DEU = 36, CB_QBV = 40, CB_RB = 43 };
+// constants area
+enum { KC_ZERO = 0, KC_ONE = 1, KC_H = 2, KC_QD = 4, KC_RD = 14, KC_LBU = 18, KC_UBU = 22, KC_LBV = 26, KC_UBV = 29, KC_SIZE = 32 };
+
+struct RtiParams {
+    int N, n_rti, use_fd, qp_mode, iter_max;
+    double dt, inv_mass, g;
+    double Qd[10], Rd[4], lbu[4], ubu[4], lbv[3], ubv[3];
+    double mu0, thr0, tol, tau;
+};
+
+struct RtiIo {            // global-memory views of ONE instance
+    const double *x0;     // [10]
+    const double *xr;     // [(N+1)*10]
+    const double *ur;     // [N*4]
+    const float *f;       // [(N+1)*3] or null
+    double *X, *U;        // persistent iterate, updated in place
+    double *u0;           // [4]
+    int *status, *iters;  // per-instance
+    double *dbg;          // optional dump area (tests), or null
+};
+
+struct LdsMap {
+    int KC, XI, UI, ZX, ZU, CX, CU, MB, CB, KT, TXR, TUR, TF, total;
+};
+
+NDP_HD LdsMap make_map(int N)
+{
+    LdsMap m;
+    int o = 0;
+    m.KC = o; o += KC_SIZE;
+    m.XI = o; o += (N + 1) * NX;
+    m.UI = o; o += N * NU;
+    m.ZX = o; o += (N + 1) * NX;
+    m.ZU = o; o += N * NU;
+    m.CX = o; o += (N + 1) * NX;
+    m.CU = o; o += N * NU;
+    m.MB = o; o += N * MB_STRIDE;
+    m.CB = o; o += (N + 1) * CB_STRIDE;
+    m.KT = o; o += N * KT_STRIDE;
+    m.total = o;
+    // staged inputs alias the gain storage, which is dead until the first backward sweep
+    m.TXR = m.KT;
+    m.TUR = m.TXR + (N + 1) * NX;
+    m.TF = m.TUR + N * NU;
+    return m;
+}
+
+NDP_HD int lds_doubles(int N) { return make_map(N).total; }
+
+template <class W, int NSLOT>
+struct RtiWave {
+    using vd = typename W::vd;
+    using vi = typename W::vi;
+    using vb = typename W::vb;
+    using vd4 = typename W::vd4;
+
+    struct Tables {
+        vi mk_off[3], mk_mul[3];  // M~ as B operand / M~' as A operand: element (4c+g, j)
+        vi ma_off[4], ma_mul[4];  // M~ as A operand: element (j, 4c+g)
+        vi c_off[4], c_mul[4];    // C~ in accumulator layout: element (g+4r, j)
+        vi kt_off[3];
+        vb kt_pred;               // j < 4
+        vb col0;                  // j == 0
+    };
+
+    struct Slots {                // box constraints, 64 per slot
+        vb valid[NSLOT];
+        vi zoff[NSLOT];           // where the bounded step variable lives in ZX/ZU
+        vi ioff[NSLOT];           // where the iterate value lives in XI/UI
+        vi de_off[NSLOT], ge_off[NSLOT], gb_off[NSLOT];
+        vi lb_off[NSLOT], ub_off[NSLOT], dw_off[NSLOT];
+        vd lo[NSLOT], hi[NSLOT], tl[NSLOT], tu[NSLOT], ll[NSLOT], lu[NSLOT];
+        vd dtl[NSLOT], dtu[NSLOT], dll[NSLOT], dlu[NSLOT];
+    };
+
+    // ---------------------------------------------------------------- index tables
+    // element (r, c) of M~_k = [[A b 0 B], [0 1 0 0], [0 0 0 0]] -> LDS offset (+ k * mul)
+    static NDP_HD void m_entry(const LdsMap &m, vi r, vi c, vi &off, vi &mul)
+    {
+        vb isP = r < 3, isPV = r < 6, isQ = (r >= 6) && (r < 10);
+        vb colq = (c >= 6) && (c < 10), colu = c >= 12;
+        vi colpos = W::sel(colq, c - 6, c - 8);
+        vb var_pv = isPV && (colq || colu);
+        vb var_q = isQ && (colq || (colu && (c < 15)));
+        vb var_b = (r < 10) && (c == 10);
+        vb one = (isPV && (c == r)) || ((r == 10) && (c == 10));
+        vb hh = isP && (c == r + 3);
+        vi rel = W::sel(var_pv, r * 8 + colpos + int(MB_PV),
+                 W::sel(var_q, (r - 6) * 7 + colpos + int(MB_Q), r + int(MB_B)));
+        vb isvar = var_pv || var_q || var_b;
+        vi kc = W::sel(one, vi(m.KC + KC_ONE), W::sel(hh, vi(m.KC + KC_H), vi(m.KC + KC_ZERO)));
+        off = W::sel(isvar, rel + m.MB, kc);
+        mul = W::sel(isvar, vi(int(MB_STRIDE)), vi(0));
+    }
+
+    // element (row, col) of C~_k = [[Q q 0 0], [q' 0 0 r'], [0], [0 r 0 R]] -> LDS offset (+ k * mul)
+    static NDP_HD void c_entry(const LdsMap &m, vi row, vi col, vi &off, vi &mul)
+    {
+        vb rx = row < 10, cx = col < 10, ru = row >= 12, cu = col >= 12;
+        vb dgx = rx && (row == col) && (row < 6);
+        vb qq = (row >= 6) && rx && (col >= 6) && cx;
+        vb gx = (rx && (col == 10)) || ((row == 10) && cx);
+        vi gxi = W::sel(rx, row, col);
+        vb dgu = ru && (col == row);
+        vb gu = (ru && (col == 10)) || ((row == 10) && cu);
+        vi gui = W::sel(ru, row - 12, col - 12);
+        vi rel = W::sel(dgx, row + int(CB_DEX),
+                 W::sel(qq, (row - 6) * 4 + (col - 6) + int(CB_QQ),
+                 W::sel(gx, gxi + int(CB_QE),
+                 W::sel(dgu, row - 12 + int(CB_DEU), gui + int(CB_RE)))));
+        vb isvar = dgx || qq || gx || dgu || gu;
+        off = W::sel(isvar, rel + m.CB, vi(m.KC + KC_ZERO));
+        mul = W::sel(isvar, vi(int(CB_STRIDE)), vi(0));
+    }
+
+    static NDP_HD void build_tables(const LdsMap &m, Tables &T)
+    {
+        vi lane = W::lane();
+        vi g = lane >> 4, j = lane & 15;
+        for (int c = 0; c < 3; ++c) m_entry(m, g + 4 * c, j, T.mk_off[c], T.mk_mul[c]);
+        for (int c = 0; c < 4; ++c) m_entry(m, j, g + 4 * c, T.ma_off[c], T.ma_mul[c]);
+        for (int r = 0; r < 4; ++r) c_entry(m, g + 4 * r, j, T.c_off[r], T.c_mul[r]);
+        for (int c = 0; c < 3; ++c) T.kt_off[c] = (g + 4 * c) * 4 + j + m.KT;
+        T.kt_pred = j < 4;
+        T.col0 = j == 0;
+    }
+
+    // ---------------------------------------------------------------- inputs
+    static NDP_HD void stage_inputs(const RtiParams &P, const LdsMap &m, const RtiIo &io, double *lds, bool first)
+    {
+        const int N = P.N;
+        vi lane = W::lane();
+        const int nx = (N + 1) * NX, nu = N * NU, nf = (N + 1) * 3;
+        for (int t = 0; t < nx; t += 64) {
+            vi i = lane + t;
+            vb p = i < nx;
+            W::stp(lds, i + m.TXR, W::gld(io.xr, i, p), p);
+            if (first) W::stp(lds, i + m.XI, W::gld(io.X, i, p), p);
+        }
+        for (int t = 0; t < nu; t += 64) {
+            vi i = lane + t;
+            vb p = i < nu;
+            W::stp(lds, i + m.TUR, W::gld(io.ur, i, p), p);
+            if (first) W::stp(lds, i + m.UI, W::gld(io.U, i, p), p);
+        }
+        for (int t = 0; t < nf; t += 64) {
+            vi i = lane + t;
+            vb p = i < nf;
+            vd v = (P.use_fd && io.f) ? W::gldf(io.f, i, p) : vd(0.0);
+            W::stp(lds, i + m.TF, v, p);
+        }
+        if (first) {
+            // constants area (lane-indexable copies of the uniform parameters)
+            vb p = lane < KC_SIZE;
+            vd v = 0.0;
+            v = W::sel(lane == KC_ONE, vd(1.0), v);
+            v = W::sel(lane == KC_H, vd(P.dt), v);
+            for (int i = 0; i < 10; ++i) v = W::sel(lane == KC_QD + i, vd(P.Qd[i]), v);
+            for (int i = 0; i < 4; ++i) v = W::sel(lane == KC_RD + i, vd(P.Rd[i]), v);
+            for (int i = 0; i < 4; ++i) v = W::sel(lane == KC_LBU + i, vd(P.lbu[i]), v);
+            for (int i = 0; i < 4; ++i) v = W::sel(lane == KC_UBU + i, vd(P.ubu[i]), v);
+            for (int i = 0; i < 3; ++i) v = W::sel(lane == KC_LBV + i, vd(P.lbv[i]), v);
+            for (int i = 0; i < 3; ++i) v = W::sel(lane == KC_UBV + i, vd(P.ubv[i]), v);
+            W::stp(lds, lane + m.KC, v, p);
+        }
+        W::sync();
+    }
+
+    // ---------------------------------------------------------------- Gauss-Newton cost blocks
+    // residual [p-pr, v-vr, 0, E(qr) q, u-ur]; nmpc_body_rate_ctl.py:164-180
+    static NDP_HD void build_cost(const RtiParams &P, const LdsMap &m, double *lds)
+    {
+        const int N = P.N;
+        vi lane = W::lane();
+        // (a) quaternion block, one lane per (stage, row a)
+        for (int t = 0; t < 4 * (N + 1); t += 64) {
+            vi task = lane + t;
+            vb p = task < 4 * (N + 1);
+            vi k = W::sel(p, task >> 2, vi(0));
+            vi a = task & 3;
+            vd s = W::sel(k < N, vd(P.dt), vd(1.0));
+            vi xr = k * NX + m.TXR + 6;
+            vd qwr = W::ld(lds, xr), qxr = W::ld(lds, xr + 1), qyr = W::ld(lds, xr + 2), qzr = W::ld(lds, xr + 3);
+            vi xi = k * NX + m.XI + 6;
+            vd q0 = W::ld(lds, xi), q1 = W::ld(lds, xi + 1), q2 = W::ld(lds, xi + 2), q3 = W::ld(lds, xi + 3);
+            // E = [[-qx, qw,-qz, qy], [-qy, qz, qw,-qx], [-qz,-qy, qx, qw]] (of q_r)
+            vd E0[4] = {-qxr, qwr, -qzr, qyr};
+            vd E1[4] = {-qyr, qzr, qwr, -qxr};
+            vd E2[4] = {-qzr, -qyr, qxr, qwr};
+            vd ea0 = W::sel(a == 0, E0[0], W::sel(a == 1, E0[1], W::sel(a == 2, E0[2], E0[3])));
+            vd ea1 = W::sel(a == 0, E1[0], W::sel(a == 1, E1[1], W::sel(a == 2, E1[2], E1[3])));
+            vd ea2 = W::sel(a == 0, E2[0], W::sel(a == 1, E2[1], W::sel(a == 2, E2[2], E2[3])));
+            vd w0 = ea0 * (s * P.Qd[7]), w1 = ea1 * (s * P.Qd[8]), w2 = ea2 * (s * P.Qd[9]);
+            vd qi[4] = {q0, q1, q2, q3};
+            vd grad = 0.0;
+            vi cb = k * int(CB_STRIDE) + m.CB;
+            for (int b = 0; b < 4; ++b) {
+                vd h = w0 * E0[b] + w1 * E1[b] + w2 * E2[b];
+                W::stp(lds, cb + a * 4 + (int(CB_QQ) + b), h, p);
+                grad = grad + h * qi[b];
+            }
+            W::stp(lds, cb + a + (int(CB_QE) + 6), grad, p);
+        }
+        // (b) position / velocity rows, one lane per (stage, i<6)
+        for (int t = 0; t < 6 * (N + 1); t += 64) {
+            vi task = lane + t;
+            vb p = task < 6 * (N + 1);
+            vi k = W::sel(p, W::div6(task), vi(0));
+            vi i = W::sel(p, task - k * 6, vi(0));
+            vd s = W::sel(k < N, vd(P.dt), vd(1.0));
+            vd de = s * W::ld(lds, i + (m.KC + KC_QD));
+            vd grad = de * (W::ld(lds, k * NX + i + m.XI) - W::ld(lds, k * NX + i + m.TXR));
+            vi cb = k * int(CB_STRIDE) + m.CB;
+            W::stp(lds, cb + i + int(CB_DEX), de, p);
+            W::stp(lds, cb + i + int(CB_QE), grad, p);
+            W::stp(lds, cb + i + (int(CB_QBV) - 3), grad, p && (i >= 3));
+        }
+        // (c) control rows, one lane per (stage<N, i<4)
+        for (int t = 0; t < 4 * N; t += 64) {
+            vi task = lane + t;
+            vb p = task < 4 * N;
+            vi k = W::sel(p, task >> 2, vi(0));
+            vi i = task & 3;
+            vi ti = k * NU + i;
+            vd de = P.dt * W::ld(lds, i + (m.KC + KC_RD));
+            vd grad = de * (W::ld(lds, ti + m.UI) - W::ld(lds, ti + m.TUR));
+            vi cb = k * int(CB_STRIDE) + m.CB;
+            W::stp(lds, cb + i + int(CB_DEU), de, p);
+            W::stp(lds, cb + i + int(CB_RE), grad, p);
+            W::stp(lds, cb + i + int(CB_RB), grad, p);
+        }
+    }
+
+    // ---------------------------------------------------------------- linearisation
+    // q-dot = 1/2 Omega(w) q   (nmpc_body_rate_ctl.py:154-157)
+    static NDP_HD void qdot(const vd q[4], const vd w[3], vd o[4])
+    {
+        o[0] = (-w[0] * q[1] - w[1] * q[2] - w[2] * q[3]) * 0.5;
+        o[1] = (w[0] * q[0] + w[2] * q[2] - w[1] * q[3]) * 0.5;
+        o[2] = (w[1] * q[0] - w[2] * q[1] + w[0] * q[3]) * 0.5;
+        o[3] = (w[2] * q[0] + w[1] * q[1] - w[0] * q[2]) * 0.5;
+    }
+    // thrust direction R(q) e3   (nmpc_body_rate_ctl.py:151-153)
+    static NDP_HD void thrust_dir(const vd q[4], vd o[3])
+    {
+        o[0] = (q[1] * q[3] + q[0] * q[2]) * 2.0;
+        o[1] = (q[2] * q[3] - q[0] * q[1]) * 2.0;
+        o[2] = 1.0 - (q[1] * q[1] + q[2] * q[2]) * 2.0;
+    }
+    // directional derivative of R(q) e3 along s
+    static NDP_HD void thrust_dir_tan(const vd q[4], const vd s[4], vd o[3])
+    {
+        o[0] = (s[1] * q[3] + q[1] * s[3] + s[0] * q[2] + q[0] * s[2]) * 2.0;
+        o[1] = (s[2] * q[3] + q[2] * s[3] - s[0] * q[1] - q[0] * s[1]) * 2.0;
+        o[2] = (q[1] * s[1] + q[2] * s[2]) * -4.0;
+    }
+
+    // tangent of the ODE at attitude qs: input tangent (dw, dc); state tangent s = (sp, sv, sq); sp does not feed back
+    static NDP_HD void tan_rhs(const vd qs[4], const vd w[3], vd c, const vd sv[3], const vd sq[4], const vd dw[3], vd dc,
+                               vd kp[3], vd kv[3], vd kq[4])
+    {
+        vd td[3], tt[3], a[4], b[4];
+        thrust_dir(qs, td);
+        thrust_dir_tan(qs, sq, tt);
+        qdot(sq, w, a);
+        qdot(qs, dw, b);
+        for (int i = 0; i < 3; ++i) {
+            kp[i] = sv[i];
+            kv[i] = tt[i] * c + td[i] * dc;
+        }
+        for (int i = 0; i < 4; ++i) kq[i] = a[i] + b[i];
+    }
+
+    // ERK4 (one step of dt) + forward sensitivities -> stage blocks MB_k (acados sim_erk defaults)
+    static NDP_HD void linearize(const RtiParams &P, const LdsMap &m, double *lds)
+    {
+        const int N = P.N;
+        const double h = P.dt, hh = 0.5 * P.dt, h6 = P.dt / 6.0;
+        vi lane = W::lane();
+        // sensitivity columns: col 0..3 = d/dq, 4..6 = d/dw, 7 = d/dc; one lane per (stage, column)
+        for (int t = 0; t < 8 * N; t += 64) {
+            vi task = lane + t;
+            vb p = task < 8 * N;
+            vi k = W::sel(p, task >> 3, vi(0));
+            vi col = task & 7;
+            vi xi = k * NX + m.XI + 6, ui = k * NU + m.UI;
+            vd q1[4] = {W::ld(lds, xi), W::ld(lds, xi + 1), W::ld(lds, xi + 2), W::ld(lds, xi + 3)};
+            vd w[3] = {W::ld(lds, ui), W::ld(lds, ui + 1), W::ld(lds, ui + 2)};
+            vd c = W::ld(lds, ui + 3);
+            // attitude at the four RK nodes (the only state the Jacobians depend on)
+            vd k1[4], k2[4], k3[4], q2[4], q3[4], q4[4];
+            qdot(q1, w, k1);
+            for (int i = 0; i < 4; ++i) q2[i] = q1[i] + k1[i] * hh;
+            qdot(q2, w, k2);
+            for (int i = 0; i < 4; ++i) q3[i] = q1[i] + k2[i] * hh;
+            qdot(q3, w, k3);
+            for (int i = 0; i < 4; ++i) q4[i] = q1[i] + k3[i] * h;
+            // seeds
+            vd sq0[4], dw[3], zero3[3] = {0.0, 0.0, 0.0};
+            for (int i = 0; i < 4; ++i) sq0[i] = W::sel(col == i, vd(1.0), vd(0.0));
+            for (int i = 0; i < 3; ++i) dw[i] = W::sel(col == 4 + i, vd(1.0), vd(0.0));
+            vd dc = W::sel(col == 7, vd(1.0), vd(0.0));
+            vd Kp[4][3], Kv[4][3], Kq[4][4], sv[3], sq[4];
+            tan_rhs(q1, w, c, zero3, sq0, dw, dc, Kp[0], Kv[0], Kq[0]);
+            for (int i = 0; i < 3; ++i) sv[i] = Kv[0][i] * hh;
+            for (int i = 0; i < 4; ++i) sq[i] = sq0[i] + Kq[0][i] * hh;
+            tan_rhs(q2, w, c, sv, sq, dw, dc, Kp[1], Kv[1], Kq[1]);
+            for (int i = 0; i < 3; ++i) sv[i] = Kv[1][i] * hh;
+            for (int i = 0; i < 4; ++i) sq[i] = sq0[i] + Kq[1][i] * hh;
+            tan_rhs(q3, w, c, sv, sq, dw, dc, Kp[2], Kv[2], Kq[2]);
+            for (int i = 0; i < 3; ++i) sv[i] = Kv[2][i] * h;
+            for (int i = 0; i < 4; ++i) sq[i] = sq0[i] + Kq[2][i] * h;
+            tan_rhs(q4, w, c, sv, sq, dw, dc, Kp[3], Kv[3], Kq[3]);
+            vi mb = k * int(MB_STRIDE) + m.MB + col;
+            for (int i = 0; i < 3; ++i) {
+                vd sp = (Kp[0][i] + (Kp[1][i] + Kp[2][i]) * 2.0 + Kp[3][i]) * h6;
+                vd svn = (Kv[0][i] + (Kv[1][i] + Kv[2][i]) * 2.0 + Kv[3][i]) * h6;
+                W::stp(lds, mb + (int(MB_PV) + i * 8), sp, p);
+                W::stp(lds, mb + (int(MB_PV) + (3 + i) * 8), svn, p);
+            }
+            for (int i = 0; i < 4; ++i) {
+                vd sqn = sq0[i] + (Kq[0][i] + (Kq[1][i] + Kq[2][i]) * 2.0 + Kq[3][i]) * h6;
+                W::stp(lds, mb + (int(MB_Q) + i * 7), sqn, p && (col < 7));
+            }
+        }
+        // nominal step and dynamics defect b_k = phi(x_k,u_k) - x_{k+1}; one lane per stage
+        for (int t = 0; t < N; t += 64) {
+            vi task = lane + t;
+            vb p = task < N;
+            vi k = W::sel(p, task, vi(0));
+            vi xi = k * NX + m.XI, ui = k * NU + m.UI, fi = k * 3 + m.TF;
+            vd x[10];
+            for (int i = 0; i < 10; ++i) x[i] = W::ld(lds, xi + i);
+            vd w[3] = {W::ld(lds, ui), W::ld(lds, ui + 1), W::ld(lds, ui + 2)};
+            vd c = W::ld(lds, ui + 3);
+            // disturbance acceleration f/m (ndp_nmpc_body_rate_ctl.py:155-157) and gravity
+            vd acc[3] = {W::ld(lds, fi) * P.inv_mass, W::ld(lds, fi + 1) * P.inv_mass, W::ld(lds, fi + 2) * P.inv_mass - P.g};
+            vd kv[4][3], kq[4][4], vs[4][3], qs[4], td[3];
+            for (int i = 0; i < 4; ++i) qs[i] = x[6 + i];
+            const double cs[4] = {0.0, hh, hh, h};
+            for (int s = 0; s < 4; ++s) {
+                if (s > 0) {
+                    for (int i = 0; i < 4; ++i) qs[i] = x[6 + i] + kq[s - 1][i] * cs[s];
+                    for (int i = 0; i < 3; ++i) vs[s][i] = x[3 + i] + kv[s - 1][i] * cs[s];
+                } else {
+                    for (int i = 0; i < 3; ++i) vs[0][i] = x[3 + i];
+                }
+                thrust_dir(qs, td);
+                for (int i = 0; i < 3; ++i) kv[s][i] = td[i] * c + acc[i];
+                qdot(qs, w, kq[s]);
+            }
+            vi mb = k * int(MB_STRIDE) + m.MB + int(MB_B), xn = xi + NX;
+            for (int i = 0; i < 3; ++i) {
+                vd pn = x[i] + (vs[0][i] + (vs[1][i] + vs[2][i]) * 2.0 + vs[3][i]) * h6;
+                vd vn = x[3 + i] + (kv[0][i] + (kv[1][i] + kv[2][i]) * 2.0 + kv[3][i]) * h6;
+                W::stp(lds, mb + i, pn - W::ld(lds, xn + i), p);
+                W::stp(lds, mb + (3 + i), vn - W::ld(lds, xn + (3 + i)), p);
+            }
+            for (int i = 0; i < 4; ++i) {
+                vd qn = x[6 + i] + (kq[0][i] + (kq[1][i] + kq[2][i]) * 2.0 + kq[3][i]) * h6;
+                W::stp(lds, mb + (6 + i), qn - W::ld(lds, xn + (6 + i)), p);
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- Riccati sweep (MFMA)
+    // inverse of the SPD 4x4 block Lam = H~uu via LDL'; all values wave-uniform.  Returns false if not PD.
+    static NDP_HD bool inv4(const double L[4][4], double inv[4][4])
+    {
+        const double d0 = L[0][0];
+        const double e0 = 1.0 / d0;
+        const double l10 = L[1][0] * e0, l20 = L[2][0] * e0, l30 = L[3][0] * e0;
+        const double d1 = L[1][1] - l10 * L[1][0];
+        const double e1 = 1.0 / d1;
+        const double t21 = L[2][1] - l20 * L[1][0], t31 = L[3][1] - l30 * L[1][0];
+        const double l21 = t21 * e1, l31 = t31 * e1;
+        const double d2 = L[2][2] - l20 * L[2][0] - l21 * t21;
+        const double e2 = 1.0 / d2;
+        const double t32 = L[3][2] - l30 * L[2][0] - l31 * t21;
+        const double l32 = t32 * e2;
+        const double d3 = L[3][3] - l30 * L[3][0] - l31 * t31 - l32 * t32;
+        const double e3 = 1.0 / d3;
+        // M = L^-1 (unit lower)
+        const double m10 = -l10, m21 = -l21, m32 = -l32;
+        const double m20 = -l20 - l21 * m10, m31 = -l31 - l32 * m21;
+        const double m30 = -l30 - l31 * m10 - l32 * m20;
+        const double a3 = m30 * e3, b3 = m31 * e3, c3 = m32 * e3;
+        const double a2 = m20 * e2, b2 = m21 * e2;
+        const double a1 = m10 * e1;
+        inv[0][0] = e0 + m10 * a1 + m20 * a2 + m30 * a3;
+        inv[1][0] = a1 + m21 * a2 + m31 * a3;
+        inv[2][0] = a2 + m32 * a3;
+        inv[3][0] = a3;
+        inv[1][1] = e1 + m21 * b2 + m31 * b3;
+        inv[2][1] = b2 + m32 * b3;
+        inv[3][1] = b3;
+        inv[2][2] = e2 + m32 * c3;
+        inv[3][2] = c3;
+        inv[3][3] = e3;
+        inv[0][1] = inv[1][0]; inv[0][2] = inv[2][0]; inv[0][3] = inv[3][0];
+        inv[1][2] = inv[2][1]; inv[1][3] = inv[3][1]; inv[2][3] = inv[3][2];
+        return (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
+    }
+
+    // backward: P~_N = C~_N; P~_k = H~xx - H~xu Lam^-1 H~ux with H~ = M~' P~ M~ + C~.  Stores K~' per stage.
+    // forward: z~_0 = [dx0,1,0]; du = K~ z~; z~+ = M~ [z~; du].  Writes ZX[1..N], ZU[0..N-1].
+    static NDP_HD bool riccati_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, double *lds)
+    {
+        const int N = P.N;
+        bool ok = true;
+        vd4 Pt;
+        vi lane = W::lane();
+        vi g = lane >> 4, j = lane & 15;
+        // terminal block has no control part: keep columns 12..15 exactly zero
+        for (int c = 0; c < 3; ++c) Pt.r[c] = W::sel(j < 12, W::ld(lds, T.c_off[c] + T.c_mul[c] * N), vd(0.0));
+        Pt.r[3] = 0.0;
+        for (int k = N - 1; k >= 0; --k) {
+            vd mk0 = W::ld(lds, T.mk_off[0] + T.mk_mul[0] * k);
+            vd mk1 = W::ld(lds, T.mk_off[1] + T.mk_mul[1] * k);
+            vd mk2 = W::ld(lds, T.mk_off[2] + T.mk_mul[2] * k);
+            vd4 H;
+            for (int r = 0; r < 4; ++r) H.r[r] = W::ld(lds, T.c_off[r] + T.c_mul[r] * k);
+            vd4 Wm = W::zero4();
+            Wm = W::mfma(Pt.r[0], mk0, Wm);
+            Wm = W::mfma(Pt.r[1], mk1, Wm);
+            Wm = W::mfma(Pt.r[2], mk2, Wm);
+            H = W::mfma(mk0, Wm.r[0], H);
+            H = W::mfma(mk1, Wm.r[1], H);
+            H = W::mfma(mk2, Wm.r[2], H);
+            // Lam[a][b] = H~[12+a][12+b] sits in accumulator register 3 of lane 16a + 12 + b
+            double L[4][4], inv[4][4];
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b <= a; ++b) L[a][b] = W::readlane(H.r[3], 16 * a + 12 + b);
+            ok = inv4(L, inv) && ok;
+            vd linv = 0.0;
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) linv = W::sel(lane == 16 * a + b, vd(inv[a][b]), linv);
+            vd hux = H.r[3];
+            vd4 G = W::mfma(linv, hux, W::zero4());
+            vd4 Kt = W::mfma(hux, -linv, W::zero4());
+            vd4 Pn = W::mfma(-hux, G.r[0], H);
+            for (int c = 0; c < 3; ++c) W::stp(lds, T.kt_off[c] + k * int(KT_STRIDE), Kt.r[c], T.kt_pred);
+            Pt.r[0] = Pn.r[0]; Pt.r[1] = Pn.r[1]; Pt.r[2] = Pn.r[2];
+        }
+        W::sync();
+        // forward rollout; z~ index 4c+g lives in chunk c of the lanes with j == 0
+        vd zc[3];
+        for (int c = 0; c < 3; ++c) {
+            vi idx = g + 4 * c;
+            vd v = W::ldp(lds, idx + m.ZX, T.col0 && (idx < 10));
+            zc[c] = W::sel(T.col0 && (idx == 10), vd(1.0), v);
+        }
+        for (int k = 0; k < N; ++k) {
+            vd kt0 = W::ldp(lds, T.kt_off[0] + k * int(KT_STRIDE), T.kt_pred);
+            vd kt1 = W::ldp(lds, T.kt_off[1] + k * int(KT_STRIDE), T.kt_pred);
+            vd kt2 = W::ldp(lds, T.kt_off[2] + k * int(KT_STRIDE), T.kt_pred);
+            vd ma0 = W::ld(lds, T.ma_off[0] + T.ma_mul[0] * k);
+            vd ma1 = W::ld(lds, T.ma_off[1] + T.ma_mul[1] * k);
+            vd ma2 = W::ld(lds, T.ma_off[2] + T.ma_mul[2] * k);
+            vd ma3 = W::ld(lds, T.ma_off[3] + T.ma_mul[3] * k);
+            vd4 du = W::zero4(), xn = W::zero4();
+            du = W::mfma(kt0, zc[0], du);
+            xn = W::mfma(ma0, zc[0], xn);
+            du = W::mfma(kt1, zc[1], du);
+            xn = W::mfma(ma1, zc[1], xn);
+            du = W::mfma(kt2, zc[2], du);
+            xn = W::mfma(ma2, zc[2], xn);
+            xn = W::mfma(ma3, du.r[0], xn);
+            W::stp(lds, g + (k * NU + m.ZU), du.r[0], T.col0);
+            for (int c = 0; c < 3; ++c) {
+                zc[c] = xn.r[c];
+                vi idx = g + 4 * c;
+                W::stp(lds, idx + ((k + 1) * NX + m.ZX), xn.r[c], T.col0 && (idx < 10));
+            }
+        }
+        W::sync();
+        return ok;
+    }
+
+    // ---------------------------------------------------------------- box constraints / interior point
+    // order: du_k[0..3] k=0..N-1 (idxbu), then dv_k[0..2] k=1..N-1 (idxbx = 3,4,5; nmpc_body_rate_ctl.py:56-61)
+    static NDP_HD void build_slots(const RtiParams &P, const LdsMap &m, Slots &S)
+    {
+        const int N = P.N, nu = 4 * N, mcon = 7 * N - 3;
+        vi lane = W::lane();
+        for (int s = 0; s < NSLOT; ++s) {
+            vi n = lane + 64 * s;
+            S.valid[s] = n < mcon;
+            vb isu = n < nu;
+            vi nv = W::sel(isu, vi(0), n - nu);
+            vi kv = W::div3(nv);
+            vi iv = nv - kv * 3;
+            vi k = W::sel(isu, n >> 2, kv + 1);
+            k = W::sel(S.valid[s], k, vi(0));
+            vi i = W::sel(isu, n & 3, iv);
+            vi cb = k * int(CB_STRIDE) + m.CB;
+            S.zoff[s] = W::sel(isu, k * NU + i + m.ZU, k * NX + i + (m.ZX + 3));
+            S.ioff[s] = W::sel(isu, k * NU + i + m.UI, k * NX + i + (m.XI + 3));
+            S.de_off[s] = cb + W::sel(isu, i + int(CB_DEU), i + (int(CB_DEX) + 3));
+            S.ge_off[s] = cb + W::sel(isu, i + int(CB_RE), i + (int(CB_QE) + 3));
+            S.gb_off[s] = cb + W::sel(isu, i + int(CB_RB), i + int(CB_QBV));
+            S.lb_off[s] = W::sel(isu, i + (m.KC + KC_LBU), i + (m.KC + KC_LBV));
+            S.ub_off[s] = W::sel(isu, i + (m.KC + KC_UBU), i + (m.KC + KC_UBV));
+            S.dw_off[s] = W::sel(isu, i + (m.KC + KC_RD), i + (m.KC + KC_QD + 3));
+        }
+    }
+
+    static NDP_HD void load_bounds(const LdsMap &, Slots &S, const double *lds)
+    {
+        for (int s = 0; s < NSLOT; ++s) {
+            vd cur = W::ld(lds, S.ioff[s]);
+            S.lo[s] = W::ld(lds, S.lb_off[s]) - cur;
+            S.hi[s] = W::ld(lds, S.ub_off[s]) - cur;
+        }
+    }
+
+    static NDP_HD bool strictly_inside(const Slots &S, const double *lds)
+    {
+        vb okv = W::lane() >= 0;
+        for (int s = 0; s < NSLOT; ++s) {
+            vd z = W::ld(lds, S.zoff[s]);
+            okv = okv && (!S.valid[s] || ((z > S.lo[s]) && (z < S.hi[s])));
+        }
+        return W::all(okv);
+    }
+
+    static NDP_HD double absmax(const double *lds, int off, int n)
+    {
+        vi lane = W::lane();
+        vd mx = 0.0;
+        for (int t = 0; t < n; t += 64) {
+            vi i = lane + t;
+            mx = W::vmax(mx, W::vabs(W::ldp(lds, i + off, i < n)));
+        }
+        return W::wave_max(mx);
+    }
+
+    // Mehrotra predictor-corrector in absolute form; every Newton system is one riccati_sweep with
+    // diag += Gamma, grad += gamma on the bounded variables (same algorithm as oracle orc_qp_solve).
+    static NDP_HD int ipm(const RtiParams &P, const LdsMap &m, const Tables &T, Slots &S, double *lds, int &iters_out)
+    {
+        const int N = P.N, mcon = 7 * N - 3;
+        const int nzx = (N + 1) * NX, nzu = N * NU;
+        const double inv2m = 1.0 / (2.0 * mcon);
+        vi lane = W::lane();
+        int status = 0, iters = 0;
+        // cold start at dz = 0
+        vd musum = 0.0, nrm = 1.0;
+        for (int s = 0; s < NSLOT; ++s) {
+            vb v = S.valid[s];
+            S.tl[s] = W::sel(v, W::vmax(-S.lo[s], vd(P.thr0)), vd(1.0));
+            S.tu[s] = W::sel(v, W::vmax(S.hi[s], vd(P.thr0)), vd(1.0));
+            S.ll[s] = W::sel(v, P.mu0 / S.tl[s], vd(0.0));
+            S.lu[s] = W::sel(v, P.mu0 / S.tu[s], vd(0.0));
+            S.dtl[s] = 0.0; S.dtu[s] = 0.0; S.dll[s] = 0.0; S.dlu[s] = 0.0;
+            musum = musum + S.ll[s] * S.tl[s] + S.lu[s] * S.tu[s];
+            nrm = W::vmax(nrm, W::vmax(S.ll[s], S.lu[s]));
+            vd rdl = W::vabs(-S.lo[s] - S.tl[s]), rdu = W::vabs(S.hi[s] - S.tu[s]);
+            nrm = W::vmax(nrm, W::sel(v, W::vmax(rdl, rdu), vd(0.0)));
+        }
+        double mu = W::wave_sum(musum) * inv2m;
+        double norm0 = W::wave_max(nrm);
+        for (int k = 0; k <= N; ++k) norm0 = fmax_u(norm0, absmax(lds, m.CB + k * CB_STRIDE + CB_QE, 10));
+        for (int k = 0; k < N; ++k) {
+            norm0 = fmax_u(norm0, absmax(lds, m.CB + k * CB_STRIDE + CB_RB, 4));
+            norm0 = fmax_u(norm0, absmax(lds, m.MB + k * MB_STRIDE + MB_B, 10));
+        }
+        norm0 = fmax_u(norm0, absmax(lds, m.ZX, 10));
+        double rho = 1.0;
+        for (int t = 0; t < nzx + nzu; t += 64) {   // CX and CU are contiguous
+            vi i = lane + t;
+            W::stp(lds, i + m.CX, vd(0.0), i < nzx + nzu);
+        }
+        W::sync();
+        bool ok = true;
+        for (;;) {
+            if (mu <= P.tol && rho * norm0 <= P.tol) break;
+            if (iters >= P.iter_max) { status = 4; break; }
+            ++iters;
+            double sigma_mu = 0.0;
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int s = 0; s < NSLOT; ++s) {
+                    vd sl = pass ? vd(sigma_mu) - S.dll[s] * S.dtl[s] : vd(0.0);
+                    vd su = pass ? vd(sigma_mu) - S.dlu[s] * S.dtu[s] : vd(0.0);
+                    vd gl = S.ll[s] / S.tl[s], gu = S.lu[s] / S.tu[s];
+                    vd Gam = gl + gu;
+                    vd gam = -sl / S.tl[s] - S.ll[s] - gl * S.lo[s] + su / S.tu[s] + S.lu[s] - gu * S.hi[s];
+                    vd dbase = P.dt * W::ld(lds, S.dw_off[s]);
+                    W::stp(lds, S.de_off[s], dbase + Gam, S.valid[s]);
+                    W::stp(lds, S.ge_off[s], W::ld(lds, S.gb_off[s]) + gam, S.valid[s]);
+                }
+                W::sync();
+                ok = riccati_sweep(P, m, T, lds) && ok;
+                vd amin = 1.0;
+                for (int s = 0; s < NSLOT; ++s) {
+                    vb v = S.valid[s];
+                    vd zn = W::ld(lds, S.zoff[s]);
+                    vd sl = pass ? vd(sigma_mu) - S.dll[s] * S.dtl[s] : vd(0.0);
+                    vd su = pass ? vd(sigma_mu) - S.dlu[s] * S.dtu[s] : vd(0.0);
+                    vd dtl = zn - S.lo[s] - S.tl[s], dtu = S.hi[s] - zn - S.tu[s];
+                    vd dll = sl / S.tl[s] - S.ll[s] - S.ll[s] / S.tl[s] * dtl;
+                    vd dlu = su / S.tu[s] - S.lu[s] - S.lu[s] / S.tu[s] * dtu;
+                    dtl = W::sel(v, dtl, vd(0.0)); dtu = W::sel(v, dtu, vd(0.0));
+                    dll = W::sel(v, dll, vd(0.0)); dlu = W::sel(v, dlu, vd(0.0));
+                    S.dtl[s] = dtl; S.dtu[s] = dtu; S.dll[s] = dll; S.dlu[s] = dlu;
+                    amin = W::vmin(amin, W::sel(dtl < 0.0, -S.tl[s] / dtl, vd(1.0)));
+                    amin = W::vmin(amin, W::sel(dtu < 0.0, -S.tu[s] / dtu, vd(1.0)));
+                    amin = W::vmin(amin, W::sel(dll < 0.0, -S.ll[s] / dll, vd(1.0)));
+                    amin = W::vmin(amin, W::sel(dlu < 0.0, -S.lu[s] / dlu, vd(1.0)));
+                }
+                double alpha = W::wave_min(amin);
+                if (pass == 0) {
+                    vd acc = 0.0;
+                    for (int s = 0; s < NSLOT; ++s)
+                        acc = acc + (S.ll[s] + S.dll[s] * alpha) * (S.tl[s] + S.dtl[s] * alpha)
+                                  + (S.lu[s] + S.dlu[s] * alpha) * (S.tu[s] + S.dtu[s] * alpha);
+                    const double mu_aff = W::wave_sum(acc) * inv2m;
+                    const double r = mu_aff / mu;
+                    sigma_mu = r * r * r * mu;
+                } else {
+                    if (alpha < 1.0) alpha *= P.tau;
+                    for (int t = 0; t < nzx + nzu; t += 64) {   // (ZX,ZU) and (CX,CU) are laid out alike
+                        vi i = lane + t;
+                        vb p = i < nzx + nzu;
+                        vd cur = W::ldp(lds, i + m.CX, p), nw = W::ldp(lds, i + m.ZX, p);
+                        W::stp(lds, i + m.CX, cur + (nw - cur) * alpha, p);
+                    }
+                    vd acc = 0.0;
+                    for (int s = 0; s < NSLOT; ++s) {
+                        S.tl[s] = S.tl[s] + S.dtl[s] * alpha; S.tu[s] = S.tu[s] + S.dtu[s] * alpha;
+                        S.ll[s] = S.ll[s] + S.dll[s] * alpha; S.lu[s] = S.lu[s] + S.dlu[s] * alpha;
+                        acc = acc + S.ll[s] * S.tl[s] + S.lu[s] * S.tu[s];
+                    }
+                    mu = W::wave_sum(acc) * inv2m;
+                    rho *= (1.0 - alpha);
+                }
+            }
+            if (!(mu == mu)) { status = 1; break; }
+        }
+        if (!ok && status == 0) status = 4;
+        iters_out += iters;
+        return status;
+    }
+
+    static NDP_HD double fmax_u(double a, double b) { return a > b ? a : b; }
+
+    // ---------------------------------------------------------------- the control step
+    static NDP_HD void run(const RtiParams &P, const RtiIo &io, double *lds)
+    {
+        const int N = P.N;
+        const LdsMap m = make_map(N);
+        const int nzx = (N + 1) * NX, nzu = N * NU;
+        Tables T;
+        build_tables(m, T);
+        Slots S;
+        build_slots(P, m, S);
+        vi lane = W::lane();
+        int status = 0, iters = 0;
+        vd x0v = W::gld(io.x0, lane, lane < NX);
+        for (int it = 0; it < P.n_rti; ++it) {
+            stage_inputs(P, m, io, lds, it == 0);
+            build_cost(P, m, lds);
+            linearize(P, m, lds);
+            // solve_for_x0: dx_0 = x0 - x_0  (nmpc_body_rate_ctl.py:107)
+            W::stp(lds, lane + m.ZX, x0v - W::ldp(lds, lane + m.XI, lane < NX), lane < NX);
+            load_bounds(m, S, lds);
+            W::sync();
+            if (io.dbg && it == 0) {   // test hook: dump the linearisation + cost blocks
+                for (int t = 0; t < m.KT; t += 64) {
+                    vi i = lane + t;
+                    W::gst(io.dbg, i, W::ldp(lds, i, i < m.KT), i < m.KT);
+                }
+            }
+            bool done = false;
+            int st = 0;
+            if (P.qp_mode == QP_AUTO) {
+                // equality-constrained minimiser strictly inside the box => it IS the QP solution (all multipliers 0)
+                bool ok = riccati_sweep(P, m, T, lds);
+                if (!ok) st = 4;
+                done = strictly_inside(S, lds) || !ok;
+                if (done) {
+                    for (int t = 0; t < nzx + nzu; t += 64) {
+                        vi i = lane + t;
+                        vb p = i < nzx + nzu;
+                        W::stp(lds, i + m.CX, W::ldp(lds, i + m.ZX, p), p);
+                    }
+                    W::sync();
+                }
+            }
+            if (!done) st = ipm(P, m, T, S, lds, iters);
+            if (st && !status) status = st;
+            // full step, no line search; XI|UI and CX|CU are laid out alike
+            for (int t = 0; t < nzx + nzu; t += 64) {
+                vi i = lane + t;
+                vb p = i < nzx + nzu;
+                W::stp(lds, i + m.XI, W::ldp(lds, i + m.XI, p) + W::ldp(lds, i + m.CX, p), p);
+            }
+            W::sync();
+        }
+        // write back: iterate, u0 = u_0 after the step (nmpc_body_rate_ctl.py:107,112), status
+        for (int t = 0; t < nzx; t += 64) {
+            vi i = lane + t;
+            vb p = i < nzx;
+            W::gst(io.X, i, W::ldp(lds, i + m.XI, p), p);
+        }
+        for (int t = 0; t < nzu; t += 64) {
+            vi i = lane + t;
+            vb p = i < nzu;
+            W::gst(io.U, i, W::ldp(lds, i + m.UI, p), p);
+        }
+        vd u0 = W::ldp(lds, lane + m.UI, lane < NU);
+        W::gst(io.u0, lane, u0, lane < NU);
+        if (W::any((lane < NU) && !(u0 == u0))) status = 1;
+        W::gsti(io.status, status);
+        W::gsti(io.iters, iters);
+    }
+};
+
+}  // namespace ndp

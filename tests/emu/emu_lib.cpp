@@ -1,0 +1,34 @@
+// emu_lib.cpp -- runs the product's wave program (rti_wave.hpp) on the host wave emulator.
+// TEST INFRASTRUCTURE ONLY: built by tests/emu/Makefile into tests/emu/libndp_emu.so, loaded by tests/.
+#include <vector>
+
+#include "wave_emu.hpp"
+#include "../../ndp_nmpc_qd_amd/csrc/cfg_params.hpp"
+
+extern "C" {
+
+int emu_default_cfg(ndp_cfg *c) { ndp::fill_default_cfg(c); return 0; }
+
+int emu_lds_doubles(int N) { return ndp::lds_doubles(N); }
+
+// One instance, one emulated wave.  counters: [mfma, lds_ld, lds_st, readlane]
+int emu_rti_step(const ndp_cfg *cfg, const double *x0, const double *xr, const double *ur, const float *f,
+                 double *X, double *U, double *u0, int *status, int *iters, double *lds_dump, long *counters)
+{
+    ndp::RtiParams P = ndp::to_params(*cfg);
+    const int n = ndp::lds_doubles(P.N);
+    std::vector<double> lds((size_t)n, 0.0 / 0.0);   // NaN-poisoned: any read of unwritten LDS shows up
+    emu::Wave::lds_limit() = n;
+    emu::stats() = emu::Stats();
+    ndp::RtiIo io{x0, xr, ur, f, X, U, u0, status, iters, lds_dump};
+    const int ns = ndp::slots_for(P.N);
+    if (ns <= 3) ndp::RtiWave<emu::Wave, 3>::run(P, io, lds.data());
+    else if (ns <= 5) ndp::RtiWave<emu::Wave, 5>::run(P, io, lds.data());
+    else return -1;
+    if (counters) {
+        counters[0] = emu::stats().mfma; counters[1] = emu::stats().lds_ld;
+        counters[2] = emu::stats().lds_st; counters[3] = emu::stats().readlane;
+    }
+    return 0;
+}
+}

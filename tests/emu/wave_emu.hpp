@@ -1,0 +1,127 @@
+// wave_emu.hpp -- host lock-step emulation of a 64-lane wavefront (TEST INFRASTRUCTURE ONLY).
+//
+// Lets tests/ run the exact text of ndp_nmpc_qd_amd/csrc/rti_wave.hpp on the CPU: every per-lane
+// value is an array of 64 elements, every operation is applied to all lanes, and the matrix
+// instruction follows the gfx950 register maps documented for v_mfma_f64_16x16x4_f64
+// (A: lane l holds A[l&15][l>>4]; B: lane l holds B[l>>4][l&15]; C/D: register r of lane l holds
+// D[(l>>4)+4r][l&15]).  Never linked into the product library.
+#pragma once
+#include <cmath>
+#include <cstring>
+
+#define NDP_HD inline
+
+namespace emu {
+
+struct vb { bool v[64]; };
+struct vi {
+    int v[64];
+    vi() {}
+    vi(int s) { for (int l = 0; l < 64; ++l) v[l] = s; }
+};
+struct vd {
+    double v[64];
+    vd() {}
+    vd(double s) { for (int l = 0; l < 64; ++l) v[l] = s; }
+};
+struct vd4 { vd r[4]; };
+
+#define EMU_BIN(T, R, op) \
+    inline R operator op(const T &a, const T &b) { R o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[l] op b.v[l]; return o; }
+EMU_BIN(vd, vd, +) EMU_BIN(vd, vd, -) EMU_BIN(vd, vd, *) EMU_BIN(vd, vd, /)
+EMU_BIN(vd, vb, <) EMU_BIN(vd, vb, >) EMU_BIN(vd, vb, <=) EMU_BIN(vd, vb, >=) EMU_BIN(vd, vb, ==)
+EMU_BIN(vi, vi, +) EMU_BIN(vi, vi, -) EMU_BIN(vi, vi, *) EMU_BIN(vi, vi, &) EMU_BIN(vi, vi, >>)
+EMU_BIN(vi, vb, <) EMU_BIN(vi, vb, >) EMU_BIN(vi, vb, <=) EMU_BIN(vi, vb, >=) EMU_BIN(vi, vb, ==)
+EMU_BIN(vb, vb, &&) EMU_BIN(vb, vb, ||)
+#undef EMU_BIN
+// mixed scalar forms (the implicit constructors make the right-hand conversions; these cover scalar-on-the-left)
+inline vd operator+(double a, const vd &b) { return vd(a) + b; }
+inline vd operator-(double a, const vd &b) { return vd(a) - b; }
+inline vd operator*(double a, const vd &b) { return vd(a) * b; }
+inline vd operator/(double a, const vd &b) { return vd(a) / b; }
+inline vd operator+(const vd &a, double b) { return a + vd(b); }
+inline vd operator-(const vd &a, double b) { return a - vd(b); }
+inline vd operator*(const vd &a, double b) { return a * vd(b); }
+inline vd operator/(const vd &a, double b) { return a / vd(b); }
+inline vb operator<(const vd &a, double b) { return a < vd(b); }
+inline vb operator>(const vd &a, double b) { return a > vd(b); }
+inline vi operator+(const vi &a, int b) { return a + vi(b); }
+inline vi operator-(const vi &a, int b) { return a - vi(b); }
+inline vi operator*(const vi &a, int b) { return a * vi(b); }
+inline vi operator&(const vi &a, int b) { return a & vi(b); }
+inline vi operator>>(const vi &a, int b) { return a >> vi(b); }
+inline vi operator+(int a, const vi &b) { return vi(a) + b; }
+inline vi operator*(int a, const vi &b) { return vi(a) * b; }
+inline vb operator<(const vi &a, int b) { return a < vi(b); }
+inline vb operator>(const vi &a, int b) { return a > vi(b); }
+inline vb operator<=(const vi &a, int b) { return a <= vi(b); }
+inline vb operator>=(const vi &a, int b) { return a >= vi(b); }
+inline vb operator==(const vi &a, int b) { return a == vi(b); }
+inline vd operator-(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = -a.v[l]; return o; }
+inline vb operator!(const vb &a) { vb o; for (int l = 0; l < 64; ++l) o.v[l] = !a.v[l]; return o; }
+
+struct Stats { long mfma = 0, lds_ld = 0, lds_st = 0, readlane = 0; };
+inline Stats &stats() { static thread_local Stats s; return s; }
+
+struct Wave {
+    using vd = emu::vd;
+    using vi = emu::vi;
+    using vb = emu::vb;
+    using vd4 = emu::vd4;
+
+    static int &lds_limit() { static thread_local int n = 0; return n; }
+    static void chk(int i) { if (i < 0 || i >= lds_limit()) __builtin_trap(); }
+
+    static vi lane() { vi o; for (int l = 0; l < 64; ++l) o.v[l] = l; return o; }
+    static vd sel(const vb &p, const vd &a, const vd &b) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = p.v[l] ? a.v[l] : b.v[l]; return o; }
+    static vi sel(const vb &p, const vi &a, const vi &b) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = p.v[l] ? a.v[l] : b.v[l]; return o; }
+    static vd vmin(const vd &a, const vd &b) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = std::fmin(a.v[l], b.v[l]); return o; }
+    static vd vmax(const vd &a, const vd &b) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = std::fmax(a.v[l], b.v[l]); return o; }
+    static vd vabs(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = std::fabs(a.v[l]); return o; }
+    static vi div3(const vi &a) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[l] / 3; return o; }
+    static vi div6(const vi &a) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[l] / 6; return o; }
+
+    // LDS
+    static vd ld(const double *lds, const vi &off) { vd o; stats().lds_ld++; for (int l = 0; l < 64; ++l) { chk(off.v[l]); o.v[l] = lds[off.v[l]]; } return o; }
+    static vd ldp(const double *lds, const vi &off, const vb &p) { vd o; stats().lds_ld++; for (int l = 0; l < 64; ++l) { if (p.v[l]) { chk(off.v[l]); o.v[l] = lds[off.v[l]]; } else o.v[l] = 0.0; } return o; }
+    static void stp(double *lds, const vi &off, const vd &val, const vb &p) { stats().lds_st++; for (int l = 0; l < 64; ++l) if (p.v[l]) { chk(off.v[l]); lds[off.v[l]] = val.v[l]; } }
+    static void sync() {}
+
+    // global memory
+    static vd gld(const double *g, const vi &off, const vb &p) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = p.v[l] ? g[off.v[l]] : 0.0; return o; }
+    static vd gldf(const float *g, const vi &off, const vb &p) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = p.v[l] ? (double)g[off.v[l]] : 0.0; return o; }
+    static void gst(double *g, const vi &off, const vd &val, const vb &p) { for (int l = 0; l < 64; ++l) if (p.v[l]) g[off.v[l]] = val.v[l]; }
+    static void gsti(int *g, int val) { if (g) *g = val; }
+
+    // cross-lane
+    static double readlane(const vd &a, int l) { stats().readlane++; return a.v[l]; }
+    static double wave_min(const vd &a) { double m = a.v[0]; for (int l = 1; l < 64; ++l) m = std::fmin(m, a.v[l]); return m; }
+    static double wave_max(const vd &a) { double m = a.v[0]; for (int l = 1; l < 64; ++l) m = std::fmax(m, a.v[l]); return m; }
+    static double wave_sum(const vd &a)
+    {   // xor-butterfly order, as the device reduction
+        double t[64];
+        std::memcpy(t, a.v, sizeof(t));
+        for (int s = 32; s >= 1; s >>= 1) { double u[64]; for (int l = 0; l < 64; ++l) u[l] = t[l] + t[l ^ s]; std::memcpy(t, u, sizeof(t)); }
+        return t[0];
+    }
+    static bool all(const vb &p) { for (int l = 0; l < 64; ++l) if (!p.v[l]) return false; return true; }
+    static bool any(const vb &p) { for (int l = 0; l < 64; ++l) if (p.v[l]) return true; return false; }
+
+    // v_mfma_f64_16x16x4_f64: D = A(16x4) * B(4x16) + C
+    static vd4 zero4() { vd4 z; for (int r = 0; r < 4; ++r) z.r[r] = vd(0.0); return z; }
+    static vd4 mfma(const vd &a, const vd &b, const vd4 &c)
+    {
+        stats().mfma++;
+        vd4 d;
+        for (int r = 0; r < 4; ++r)
+            for (int l = 0; l < 64; ++l) {
+                const int row = (l >> 4) + 4 * r, col = l & 15;
+                double acc = c.r[r].v[l];
+                for (int k = 0; k < 4; ++k) acc = std::fma(a.v[row + 16 * k], b.v[col + 16 * k], acc);
+                d.r[r].v[l] = acc;
+            }
+        return d;
+    }
+};
+
+}  // namespace emu

@@ -1,0 +1,169 @@
+"""Runs the PRODUCT's wave program (ndp_nmpc_qd_amd/csrc/rti_wave.hpp) on a host lock-step wave
+emulator (tests/emu) and compares it with the CPU oracle.  No GPU needed: this is the CPU-side check
+of the device algorithm (index tables, MFMA operand layouts, Riccati in homogeneous coordinates,
+interior point).  The emulator follows the documented gfx950 register maps of
+v_mfma_f64_16x16x4_f64; tests/test_gpu_parity.py repeats the comparison on real hardware.
+"""
+import numpy as np
+import pytest
+
+from ndp_nmpc_qd_amd import synth
+from tests.emu import emu as E
+
+# parity bar on controls (BASELINE.json north_star): |du| <= 1e-5 * max(1, |u|); fp64 path sits far inside
+RTOL_U = 1e-5
+
+
+def _assert_u(u, uo, tol=RTOL_U):
+    assert np.all(np.abs(u - uo) <= tol * np.maximum(1.0, np.abs(uo))), (u, uo)
+
+
+def _run_pair(oracle, b, i, N=20, n_rti=1, use_fd=False, f=None, qp_mode=0, X0=None, U0=None):
+    cfg = E.default_cfg(N=N, n_rti=n_rti, use_fd=use_fd, qp_mode=qp_mode)
+    cfgo = oracle.default_cfg(N=N, n_rti=n_rti, use_fd=use_fd)
+    X = (b["xr"][i] if X0 is None else X0).copy()
+    U = (b["ur"][i] if U0 is None else U0).copy()
+    Xo, Uo = X.copy(), U.copy()
+    fi = None if f is None else f[i]
+    u0, st, it, _, cnt = E.rti_step(cfg, b["x0"][i], b["xr"][i], b["ur"][i], fi, X, U)
+    u0o, sto = oracle.step(cfgo, b["x0"][i], b["xr"][i], b["ur"][i], fi, Xo, Uo)
+    return (u0, st, it, X, U, cnt), (u0o, sto, Xo, Uo)
+
+
+@pytest.mark.parametrize("qp_mode", [0, 1])
+def test_nominal_batch_matches_oracle(oracle, qp_mode):
+    b = synth.make_batch(6, seed=synth.SEED0 + 2)
+    for i in range(6):
+        (u0, st, it, X, U, cnt), (u0o, sto, Xo, Uo) = _run_pair(oracle, b, i, qp_mode=qp_mode)
+        assert st == 0 and sto.status == 0
+        _assert_u(u0, u0o, 1e-8)
+        np.testing.assert_allclose(X, Xo, atol=1e-8)
+        np.testing.assert_allclose(U, Uo, atol=1e-8)
+        if qp_mode == 0:
+            assert it == 0 and cnt["mfma"] == 16 * 20      # one sweep: 9 backward + 7 forward MFMAs per stage
+        else:
+            assert it == sto.ipm_iters                      # same algorithm, same iteration count
+
+
+@pytest.mark.parametrize("seed,scale", [(2, 1.0), (3, 2.0), (4, 3.0), (9, 2.0)])
+def test_active_bounds_match_oracle(oracle, seed, scale):
+    b = synth.make_batch(1, seed=seed, pos_sigma=scale, vel_sigma=2 * scale, quat_sigma=0.2)
+    (u0, st, it, X, U, _), (u0o, sto, Xo, Uo) = _run_pair(oracle, b, 0)
+    assert sto.n_active > 0 and it > 0          # the early exit was refused, interior point ran
+    assert st == 0 and sto.status == 0
+    assert it == sto.ipm_iters
+    _assert_u(u0, u0o, 1e-7)
+    np.testing.assert_allclose(U, Uo, atol=1e-6)
+    np.testing.assert_allclose(X, Xo, atol=1e-6)
+    assert np.all(U[:, :3] <= 6 + 1e-7) and np.all(U[:, :3] >= -6 - 1e-7)
+    assert np.all(U[:, 3] >= -1e-7) and np.all(U[:, 3] <= 9.81 / 0.36 + 1e-7)
+
+
+def test_iterate_outside_bounds_is_pulled_back(oracle):
+    """reset() with a reference that violates the input box (infeasible start for the step variables)."""
+    b = synth.make_batch(1, seed=5)
+    U0 = b["ur"][0].copy()
+    U0[:, 0] = 7.5       # > w_max
+    U0[3, 3] = -1.0      # < c_min
+    (u0, st, it, X, U, _), (u0o, sto, Xo, Uo) = _run_pair(oracle, b, 0, U0=U0)
+    assert st == 0 and sto.status == 0 and it > 0
+    _assert_u(u0, u0o, 1e-7)
+    assert U[:, 0].max() <= 6 + 1e-6 and U[3, 3] >= -1e-6
+
+
+def test_ndp_force_and_fp32_promotion(oracle):
+    """update(x0, xr, ur, f): f is fp32 and is promoted to fp64 in p."""
+    b = synth.make_batch(3, seed=7)
+    f = np.random.default_rng(1).normal(0, 2.0, (3, 21, 3)).astype(np.float32)
+    for i in range(3):
+        (u0, st, it, X, U, _), (u0o, sto, Xo, Uo) = _run_pair(oracle, b, i, use_fd=True, f=f)
+        assert st == 0
+        _assert_u(u0, u0o, 1e-8)
+        np.testing.assert_allclose(X, Xo, atol=1e-8)
+    # f must actually matter
+    (u0n, *_), _ = _run_pair(oracle, b, 0, use_fd=False, f=None)
+    (u0f, *_), _ = _run_pair(oracle, b, 0, use_fd=True, f=f)
+    assert np.abs(u0n - u0f).max() > 1e-3
+
+
+def test_hover_known_answers(oracle):
+    xr, ur = synth.hover_reference()
+    b = dict(x0=xr[None, 0], xr=xr[None], ur=ur[None])
+    (u0, st, it, X, U, _), _ = _run_pair(oracle, b, 0)
+    np.testing.assert_allclose(u0, [0, 0, 0, 9.81], atol=1e-12)
+    np.testing.assert_allclose(X, xr, atol=1e-12)
+    xr, ur = synth.hover_reference(quirk_b1=True)
+    b = dict(x0=xr[None, 0], xr=xr[None], ur=ur[None])
+    (u0, st, it, X, U, _), (u0o, *_ ) = _run_pair(oracle, b, 0)
+    assert abs(u0[3] - 9.79359713) < 1e-6
+    _assert_u(u0, u0o, 1e-9)
+
+
+def test_two_rti_iterations_and_long_horizon(oracle):
+    """BASELINE config 5 shape: N=40 (0.1 s interval kept), 2 RTI iterations per step."""
+    b = synth.make_batch(2, N=40, seed=11)
+    for i in range(2):
+        (u0, st, it, X, U, _), (u0o, sto, Xo, Uo) = _run_pair(oracle, b, i, N=40, n_rti=2)
+        assert st == 0 and sto.status == 0
+        _assert_u(u0, u0o, 1e-8)
+        np.testing.assert_allclose(X, Xo, atol=1e-7)
+
+
+def test_persistent_iterate_across_calls(oracle):
+    """No shift between calls; second update() starts from the stored iterate."""
+    b = synth.make_batch(1, seed=21)
+    cfg, cfgo = E.default_cfg(), oracle.default_cfg()
+    X, U = b["xr"][0].copy(), b["ur"][0].copy()
+    Xo, Uo = X.copy(), U.copy()
+    for _ in range(3):
+        u0, st, *_ = E.rti_step(cfg, b["x0"][0], b["xr"][0], b["ur"][0], None, X, U)
+        u0o, _ = oracle.step(cfgo, b["x0"][0], b["xr"][0], b["ur"][0], None, Xo, Uo)
+        _assert_u(u0, u0o, 1e-8)
+    np.testing.assert_allclose(X, Xo, atol=1e-8)
+
+
+def test_lds_image_matches_oracle_linearisation(oracle):
+    """The stage blocks the kernel keeps in LDS are the oracle's A_k, B_k, b_k, Q_k, q_k, r_k."""
+    b = synth.make_batch(1, seed=31)
+    N = 20
+    rng = np.random.default_rng(0)
+    X = b["xr"][0] + rng.normal(0, 0.05, (N + 1, 10))
+    U = b["ur"][0] + rng.normal(0, 0.2, (N, 4))
+    f = rng.normal(0, 1.5, (N + 1, 3)).astype(np.float32)
+    cfg, cfgo = E.default_cfg(use_fd=True), oracle.default_cfg(use_fd=True)
+    qp = oracle.linearize(cfgo, b["x0"][0], b["xr"][0], b["ur"][0], f, X, U)
+    _, _, _, lds, _ = E.rti_step(cfg, b["x0"][0], b["xr"][0], b["ur"][0], f, X.copy(), U.copy(), dump=True)
+    KC = 0
+    XI = KC + 32
+    MB = XI + 3 * ((N + 1) * 10 + N * 4)
+    CB = MB + N * 86
+    for k in range(N):
+        blk = lds[MB + k * 86: MB + (k + 1) * 86]
+        S_pv = blk[0:48].reshape(6, 8)
+        S_q = blk[48:76].reshape(4, 7)
+        np.testing.assert_allclose(S_pv[:, 0:4], qp["A"][k][0:6, 6:10], atol=1e-13)
+        np.testing.assert_allclose(S_pv[:, 4:8], qp["B"][k][0:6, :], atol=1e-13)
+        np.testing.assert_allclose(S_q[:, 0:4], qp["A"][k][6:10, 6:10], atol=1e-13)
+        np.testing.assert_allclose(S_q[:, 4:7], qp["B"][k][6:10, 0:3], atol=1e-13)
+        np.testing.assert_allclose(blk[76:86], qp["b"][k], atol=1e-13)
+    for k in range(N + 1):
+        blk = lds[CB + k * 47: CB + (k + 1) * 47]
+        np.testing.assert_allclose(blk[0:16].reshape(4, 4), qp["Q"][k][6:10, 6:10], atol=1e-12)
+        np.testing.assert_allclose(blk[16:26], qp["q"][k], atol=1e-11)
+        np.testing.assert_allclose(blk[30:36], np.diag(qp["Q"][k])[0:6], atol=1e-13)
+        if k < N:
+            np.testing.assert_allclose(blk[26:30], qp["r"][k], atol=1e-12)
+            np.testing.assert_allclose(blk[36:40], qp["Rd"][k], atol=1e-13)
+
+
+def test_qp_failure_status(oracle):
+    """Infeasible box (velocity bound tighter than the fixed initial state allows) -> status 4, as the
+    reference would raise 'acados acados_ocp_solver returned status 4' (nmpc_body_rate_ctl.py:109-110)."""
+    b = synth.make_batch(1, seed=41)
+    cfg = E.default_cfg()
+    for i in range(3):
+        cfg.lbv[i], cfg.ubv[i] = -1e-3, 1e-3
+    cfg.iter_max = 15
+    X, U = b["xr"][0].copy(), b["ur"][0].copy()
+    u0, st, it, *_ = E.rti_step(cfg, b["x0"][0], b["xr"][0], b["ur"][0], None, X, U)
+    assert st in (1, 4) and it == 15
