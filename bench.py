@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- NMPC solves/s of the batched control step on N MI355X GPUs (one process per GPU).
+
+    python bench.py --gpus 1 --steps 300 --warmup 30
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric / configs[2]): per GPU batch = 1024 independent quadrotor OCPs, N = 20,
+1 SQP-RTI iteration per step + the downwash MLP (NDP controller), inputs resident in HBM.
+A "step" is one control tick of the whole batch: [all-gather of neighbour windows when N > 1] ->
+mlp_kernel (gate + MLP) -> rti_kernel (linearise, QP, full step).  Weak scaling: the per-GPU batch is fixed.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, datasheet; v_mfma_f64_16x16x4 = 2048 FLOP / 64 clk / SIMD
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_flops_per_solve(N, sweeps, downwash):
+    """N*F_lin + n_fact*N*F_ric (+ F_mlp); F_lin ~ 4.3 kFLOP, F_ric ~ 8.2 kFLOP, F_mlp = 21*35072."""
+    f = N * 4.3e3 + sweeps * N * 8.2e3
+    return f, (21 * 35072.0 if downwash else 0.0)
+
+
+def algorithmic_bytes_per_solve(N, downwash):
+    """fp64 storage: read x0, xr, ur, X, U; write X, U, u0 (+ neighbour window and ego xy with downwash)."""
+    b = 8 * (10 + 10 * (N + 1) + 4 * N + 2 * (10 * (N + 1) + 4 * N) + 4)
+    if downwash:
+        b += 8 * 10 * (N + 1) + 16
+    return b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--workload", default="ndp_downwash", choices=["ndp_downwash", "nmpc"])
+    ap.add_argument("--qp-mode", type=int, default=0, help="0 auto (exact early exit), 1 interior point always")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-passes", type=int, default=24)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import ndp_nmpc_qd_amd as ndp
+    from ndp_nmpc_qd_amd import dist as ndist
+
+    B, N = args.batch, args.horizon
+    downwash = args.workload == "ndp_downwash"
+    T = 8  # distinct control ticks cycled through (reference window slides by ts_nmpc = 0.02 s per tick)
+    ticks = []
+    for t in range(T):
+        b = ndist.make_formation_shard(B, rank, world, N=N, t0=0.02 * t)
+        ticks.append({k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur", "other", "ego_xy")})
+    host0 = ndist.make_formation_shard(B, rank, world, N=N, t0=0.0)
+
+    eng = ndp.BatchedNMPC(B, N=N, disturbance=downwash, qp_mode=args.qp_mode, device=local_rank)
+    stream = torch.cuda.current_stream()
+    u0 = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    gathered = torch.empty(world, B, N + 1, 10, dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step(i):
+        d = ticks[i % T]
+        other = None
+        if downwash:
+            if world > 1:
+                other, _ = ndist.exchange_neighbours(d["xr"], gathered)   # one RCCL all-gather over xGMI
+            else:
+                other = d["other"]
+        eng.update_device(d["x0"], d["xr"], d["ur"], u0, other=other, ego_xy=d["ego_xy"] if downwash else None,
+                          stream=stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- parity spot check against the CPU oracle (rank 0, first tick, 64 instances) before timing
+    parity = None
+    eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
+    step(0)
+    torch.cuda.synchronize()
+    if rank == 0:
+        from oracle import oracle as O
+        ns = min(64, B)
+        cfgo = O.default_cfg(N=N, use_fd=downwash)
+        f = None
+        if downwash:
+            blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
+            f = O.downwash_batch(blob, host0["other"][:ns], host0["xr"][:ns], host0["ego_xy"][:ns])
+        Xo, Uo = host0["xr"][:ns].copy(), host0["ur"][:ns].copy()
+        u_or, st_or, _ = O.step_batch(cfgo, host0["x0"][:ns], host0["xr"][:ns], host0["ur"][:ns], f, Xo, Uo)
+        u_dev = u0[:ns].cpu().numpy()
+        parity = float(np.max(np.abs(u_dev - u_or) / np.maximum(1.0, np.abs(u_or))))
+
+    # ---- warm-up, then EXACTLY --steps timed steps between barrier + synchronize
+    eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    eng.timing_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    rti_ms, rti_n = eng.timing_read("rti")
+    mlp_ms, mlp_n = eng.timing_read("mlp")
+    eng.timing_enable(False)
+    st, it = eng.status()
+    bad = int((st != 0).sum())
+    sweeps = float(np.mean(np.where(it > 0, 1 + 2 * it, 1))) if args.qp_mode == 0 else float(np.mean(2 * it))
+    if world > 1:
+        agg = torch.tensor([bad], dtype=torch.int64, device=dev)
+        dist.all_reduce(agg)
+        bad = int(agg.item())
+
+    if rank == 0:
+        total = B * world * args.steps
+        value = total / elapsed
+        f_qp, f_mlp = algorithmic_flops_per_solve(N, sweeps, downwash)
+        rti_s = rti_ms * 1e-3 / max(rti_n, 1)
+        mlp_s = mlp_ms * 1e-3 / max(mlp_n, 1) if mlp_n else 0.0
+        ach_tf = f_qp * B / rti_s / 1e12
+        abytes = algorithmic_bytes_per_solve(N, downwash)
+        out = {
+            "metric": "NMPC solves/sec (N=20, 1 RTI iter + downwash MLP) at batch",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"batch={B}/GPU independent quadrotors, N={N}, 1 RTI iter, "
+                                   + ("MLP downwash on (NDP controller)" if downwash else "no downwash (NMPC controller)")
+                                   + (", neighbour windows all-gathered over RCCL" if world > 1 else ""),
+                       "batch_per_gpu": B, "horizon": N, "n_rti": 1, "qp_mode": "auto" if args.qp_mode == 0 else "ipm_always",
+                       "parallelism": f"instances sharded x{world}"},
+            "roofline": {"kernel": "rti_kernel", "bound": "mfma", "achieved": ach_tf, "peak": F64_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach_tf / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel_us": rti_s * 1e6, "flops_per_solve": f_qp, "riccati_sweeps_per_solve": sweeps,
+                         "hbm_algorithmic_GBps": abytes * B / (rti_s + mlp_s) / 1e9,
+                         "hbm_frac": abytes * B / (rti_s + mlp_s) / 1e9 / HBM_PEAK_GBS,
+                         "mlp_kernel_us": mlp_s * 1e6,
+                         "mlp_achieved_TFLOPs": (f_mlp * B / mlp_s / 1e12) if mlp_s else None},
+            "parity_max_rel_vs_oracle": parity, "instances_not_converged": bad,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import oracle as O
+            cfgo = O.default_cfg(N=N, use_fd=downwash)
+            nthr = O.num_threads()
+            blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
+            Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
+            O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], None, Xo, Uo)       # warm the thread pool
+            Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
+            tc = time.perf_counter()
+            for _ in range(args.cpu_passes):
+                f = O.downwash_batch(blob, host0["other"], host0["xr"], host0["ego_xy"]) if downwash else None
+                O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], f, Xo, Uo)
+            tc = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": B * args.cpu_passes / tc, "unit": "solves/s", "cores": nthr, "kind": "port",
+                                   "sample": f"{args.cpu_passes} control ticks of the same batch={B} workload "
+                                             f"(oracle/ndp_oracle.c: fp64 RTI + IPM always, fp32 MLP), OpenMP over instances"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

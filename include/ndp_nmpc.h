@@ -125,6 +125,9 @@ int ndp_timing_read(ndp_handle *h, const char *name, double *total_ms, int64_t *
 
 /* Test hook: number of doubles of the LDS image dump, and a step that also dumps it (B = 1 use). */
 int ndp_debug_lds_doubles(int N);
+/* Test hook: one v_mfma_f64_16x16x4_f64 on caller-chosen per-lane operands a[64], b[64], c[4][64];
+ * d[0..255] = result registers [4][64], d[256..319] = a cross-lane checksum (readlane + wave reductions). */
+int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, double *d);
 int ndp_step_debug(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
                    double *u0, double *lds_dump);
 

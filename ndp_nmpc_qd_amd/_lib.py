@@ -1,0 +1,112 @@
+"""ctypes binding of the C-ABI in include/ndp_nmpc.h (libndp_nmpc_hip.so, HIP/gfx950).
+
+There is deliberately no fallback: if the shared library is missing, or no MI355X is
+usable, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libndp_nmpc_hip.so")
+WEIGHTS_PATH = os.path.join(_HERE, "weights", "downwash_sn4.bin")
+
+NX, NU = 10, 4
+MLP_NPARAM = 17859
+QP_AUTO, QP_IPM_ALWAYS = 0, 1
+
+
+class NdpCfg(C.Structure):
+    """include/ndp_nmpc.h: struct ndp_cfg."""
+    _fields_ = [
+        ("batch", C.c_int32), ("N", C.c_int32), ("n_rti", C.c_int32), ("use_fd", C.c_int32),
+        ("qp_mode", C.c_int32), ("iter_max", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+        ("dt", C.c_double), ("mass", C.c_double), ("gravity", C.c_double), ("r_horiz", C.c_double),
+        ("Qd", C.c_double * 10), ("Rd", C.c_double * 4),
+        ("lbu", C.c_double * 4), ("ubu", C.c_double * 4), ("lbv", C.c_double * 3), ("ubv", C.c_double * 3),
+        ("mu0", C.c_double), ("thr0", C.c_double), ("tol", C.c_double), ("tau", C.c_double),
+    ]
+
+
+EXPORTS = [
+    "ndp_default_cfg", "ndp_create", "ndp_destroy", "ndp_last_error", "ndp_set_mlp_weights", "ndp_reset",
+    "ndp_reset_device", "ndp_step", "ndp_step_device", "ndp_downwash", "ndp_downwash_device", "ndp_get_iterate",
+    "ndp_set_iterate", "ndp_get_status", "ndp_device_iterate_x", "ndp_device_iterate_u", "ndp_device_force",
+    "ndp_synchronize", "ndp_timing_enable", "ndp_timing_read", "ndp_debug_lds_doubles", "ndp_step_debug", "ndp_debug_mfma_probe",
+]
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library; raises if it has not been built (python -m ndp_nmpc_qd_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libndp_nmpc_hip.so is missing: build it with `python -m ndp_nmpc_qd_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32p = C.c_void_p, C.POINTER(C.c_int32)
+    lib.ndp_default_cfg.argtypes = [C.POINTER(NdpCfg)]
+    lib.ndp_create.argtypes = [C.POINTER(NdpCfg), C.POINTER(vp)]
+    lib.ndp_destroy.argtypes = [vp]
+    lib.ndp_last_error.argtypes = [vp]
+    lib.ndp_last_error.restype = C.c_char_p
+    lib.ndp_set_mlp_weights.argtypes = [vp, vp, C.c_size_t]
+    lib.ndp_reset.argtypes = [vp, vp, vp]
+    lib.ndp_reset_device.argtypes = [vp, vp, vp, vp]
+    lib.ndp_step.argtypes = [vp] * 8
+    lib.ndp_step_device.argtypes = [vp] * 9
+    lib.ndp_downwash.argtypes = [vp] * 5
+    lib.ndp_downwash_device.argtypes = [vp] * 6
+    lib.ndp_get_iterate.argtypes = [vp, vp, vp]
+    lib.ndp_set_iterate.argtypes = [vp, vp, vp]
+    lib.ndp_get_status.argtypes = [vp, vp, vp]
+    for name in ("ndp_device_iterate_x", "ndp_device_iterate_u", "ndp_device_force"):
+        getattr(lib, name).argtypes = [vp]
+        getattr(lib, name).restype = vp
+    lib.ndp_synchronize.argtypes = [vp]
+    lib.ndp_timing_enable.argtypes = [vp, C.c_int]
+    lib.ndp_timing_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.ndp_debug_lds_doubles.argtypes = [C.c_int]
+    lib.ndp_step_debug.argtypes = [vp] * 7
+    lib.ndp_debug_mfma_probe.argtypes = [vp] * 4
+    _lib = lib
+    return lib
+
+
+def default_cfg(**kw):
+    cfg = NdpCfg()
+    load().ndp_default_cfg(C.byref(cfg))
+    for k, v in kw.items():
+        cur = getattr(cfg, k)
+        if hasattr(cur, "__len__"):
+            for i, x in enumerate(v):
+                cur[i] = x
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+def load_weights(path=WEIGHTS_PATH):
+    w = np.fromfile(path, dtype="<f4")
+    if w.size != MLP_NPARAM:
+        raise ValueError(f"{path}: expected {MLP_NPARAM} fp32 values, found {w.size}")
+    return w
+
+
+def ptr(a):
+    """numpy array -> void* (None passes NULL)."""
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def f64(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return a

@@ -1,0 +1,178 @@
+"""BatchedNMPC: B independent quadrotor OCPs solved per call on one MI355X through the C-ABI.
+
+This is the batched form of the reference's controller objects
+(nmpc_ctl/nmpc_body_rate_ctl.py:20-112, ndp_nmpc_ctl/ndp_nmpc_body_rate_ctl.py:20-112):
+`reset(xr, ur)` seeds the persistent SQP iterate, `update(...)` runs one SQP-RTI iteration per
+instance (plus the downwash MLP when neighbour windows are given) and returns u0[B,4].
+Host arrays go through ndp_step; torch CUDA tensors go through ndp_step_device (no host copies).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .params import downwash_params as DP
+from .params import nmpc_params as CP
+
+
+class NdpError(RuntimeError):
+    pass
+
+
+class BatchedNMPC:
+    def __init__(self, batch, N=CP.N_node, disturbance=False, n_rti=1, qp_mode=_lib.QP_AUTO, device=0,
+                 dt=CP.th_pred, load_mlp=None, **cfg_overrides):
+        self._lib = _lib.load()
+        self.cfg = _lib.default_cfg(batch=int(batch), N=int(N), n_rti=int(n_rti), use_fd=int(bool(disturbance)),
+                                    qp_mode=int(qp_mode), device=int(device), dt=float(dt), r_horiz=DP.r_horiz,
+                                    **cfg_overrides)
+        self.B, self.N = int(batch), int(N)
+        self.disturbance = bool(disturbance)
+        self._h = C.c_void_p()
+        rc = self._lib.ndp_create(C.byref(self.cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise NdpError(f"ndp_create failed ({rc}): {self._lib.ndp_last_error(None).decode()}")
+        if load_mlp is None:
+            load_mlp = self.disturbance
+        if load_mlp:
+            self.set_mlp_weights(_lib.load_weights())
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ndp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise NdpError(f"{what} failed ({rc}): {self._lib.ndp_last_error(self._h).decode()}")
+        return rc
+
+    def set_mlp_weights(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        self._check(self._lib.ndp_set_mlp_weights(self._h, _lib.ptr(blob), blob.size), "ndp_set_mlp_weights")
+
+    # ------------------------------------------------------------------ reference-shaped API (host arrays)
+    def reset(self, xr, ur):
+        """nmpc_body_rate_ctl.py:86-91 for every instance."""
+        xr = _lib.f64(xr, (self.B, self.N + 1, 10))
+        ur = _lib.f64(ur, (self.B, self.N, 4))
+        self._check(self._lib.ndp_reset(self._h, _lib.ptr(xr), _lib.ptr(ur)), "ndp_reset")
+
+    def update(self, x0, xr, ur, f=None, other=None, ego_xy=None, raise_on_status=True):
+        """update(x0, xr, ur[, f]) for every instance; returns u0[B,4] float64.
+
+        f: [B,N+1,3] disturbance force (NDP).  other/ego_xy: neighbour reference windows and ego
+        odometry xy; the force is then predicted on the device (DownwashNN.update + r_horiz gate).
+        """
+        x0 = _lib.f64(x0, (self.B, 10))
+        xr = _lib.f64(xr, (self.B, self.N + 1, 10))
+        ur = _lib.f64(ur, (self.B, self.N, 4))
+        f32 = None if f is None else np.ascontiguousarray(f, dtype=np.float32).reshape(self.B, self.N + 1, 3)
+        other = _lib.f64(other, (self.B, self.N + 1, 10))
+        ego_xy = _lib.f64(ego_xy, (self.B, 2))
+        u0 = np.empty((self.B, 4), dtype=np.float64)
+        rc = self._check(self._lib.ndp_step(self._h, _lib.ptr(x0), _lib.ptr(xr), _lib.ptr(ur), _lib.ptr(f32),
+                                            _lib.ptr(other), _lib.ptr(ego_xy), _lib.ptr(u0)), "ndp_step")
+        if rc != 0 and raise_on_status:
+            # same text as nmpc_body_rate_ctl.py:109-110
+            raise Exception("acados acados_ocp_solver returned status {}. Exiting.".format(rc))
+        return u0
+
+    def update_debug(self, x0, xr, ur, f=None):
+        """B = 1 only: one step that also returns the kernel's LDS image after linearisation (tests)."""
+        x0, xr, ur = _lib.f64(x0, (1, 10)), _lib.f64(xr, (1, self.N + 1, 10)), _lib.f64(ur, (1, self.N, 4))
+        f32 = None if f is None else np.ascontiguousarray(f, dtype=np.float32).reshape(1, self.N + 1, 3)
+        u0 = np.empty((1, 4))
+        dump = np.zeros(self._lib.ndp_debug_lds_doubles(self.N))
+        self._check(self._lib.ndp_step_debug(self._h, _lib.ptr(x0), _lib.ptr(xr), _lib.ptr(ur), _lib.ptr(f32),
+                                             _lib.ptr(u0), _lib.ptr(dump)), "ndp_step_debug")
+        return u0, dump
+
+    def downwash(self, other, ego_ref, ego_xy=None):
+        """DownwashNN.update for every instance (+ optional gate); returns f[B,N+1,3] float32."""
+        other = _lib.f64(other, (self.B, self.N + 1, 10))
+        ego_ref = _lib.f64(ego_ref, (self.B, self.N + 1, 10))
+        ego_xy = _lib.f64(ego_xy, (self.B, 2))
+        f = np.empty((self.B, self.N + 1, 3), dtype=np.float32)
+        self._check(self._lib.ndp_downwash(self._h, _lib.ptr(other), _lib.ptr(ego_ref), _lib.ptr(ego_xy), _lib.ptr(f)),
+                    "ndp_downwash")
+        return f
+
+    def get_iterate(self):
+        X = np.empty((self.B, self.N + 1, 10))
+        U = np.empty((self.B, self.N, 4))
+        self._check(self._lib.ndp_get_iterate(self._h, _lib.ptr(X), _lib.ptr(U)), "ndp_get_iterate")
+        return X, U
+
+    def set_iterate(self, X=None, U=None):
+        X = _lib.f64(X, (self.B, self.N + 1, 10))
+        U = _lib.f64(U, (self.B, self.N, 4))
+        self._check(self._lib.ndp_set_iterate(self._h, _lib.ptr(X), _lib.ptr(U)), "ndp_set_iterate")
+
+    def status(self):
+        st = np.zeros(self.B, dtype=np.int32)
+        it = np.zeros(self.B, dtype=np.int32)
+        self._check(self._lib.ndp_get_status(self._h, _lib.ptr(st), _lib.ptr(it)), "ndp_get_status")
+        return st, it
+
+    # ------------------------------------------------------------------ HBM-resident API (torch CUDA tensors)
+    @staticmethod
+    def _dptr(t, dtype, shape):
+        if t is None:
+            return None
+        import torch
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype == dtype
+                and tuple(t.shape) == tuple(shape)):
+            raise ValueError(f"expected contiguous CUDA tensor {dtype} {tuple(shape)}")
+        return C.c_void_p(t.data_ptr())
+
+    def reset_device(self, xr, ur, stream=None):
+        import torch
+        self._check(self._lib.ndp_reset_device(self._h, self._dptr(xr, torch.float64, (self.B, self.N + 1, 10)),
+                                               self._dptr(ur, torch.float64, (self.B, self.N, 4)),
+                                               self._stream(stream)), "ndp_reset_device")
+
+    def update_device(self, x0, xr, ur, u0_out, f=None, other=None, ego_xy=None, stream=None):
+        """Enqueues one control step on `stream` (default: the library's stream); no synchronisation."""
+        import torch
+        B, N = self.B, self.N
+        self._check(self._lib.ndp_step_device(
+            self._h, self._dptr(x0, torch.float64, (B, 10)), self._dptr(xr, torch.float64, (B, N + 1, 10)),
+            self._dptr(ur, torch.float64, (B, N, 4)), self._dptr(f, torch.float32, (B, N + 1, 3)),
+            self._dptr(other, torch.float64, (B, N + 1, 10)), self._dptr(ego_xy, torch.float64, (B, 2)),
+            self._dptr(u0_out, torch.float64, (B, 4)), self._stream(stream)), "ndp_step_device")
+
+    def downwash_device(self, other, ego_ref, f_out, ego_xy=None, stream=None):
+        import torch
+        B, N = self.B, self.N
+        self._check(self._lib.ndp_downwash_device(
+            self._h, self._dptr(other, torch.float64, (B, N + 1, 10)), self._dptr(ego_ref, torch.float64, (B, N + 1, 10)),
+            self._dptr(ego_xy, torch.float64, (B, 2)), self._dptr(f_out, torch.float32, (B, N + 1, 3)),
+            self._stream(stream)), "ndp_downwash_device")
+
+    @staticmethod
+    def _stream(stream):
+        if stream is None:
+            return None
+        return C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+
+    def synchronize(self):
+        self._check(self._lib.ndp_synchronize(self._h), "ndp_synchronize")
+
+    def timing_enable(self, on=True):
+        self._check(self._lib.ndp_timing_enable(self._h, int(on)), "ndp_timing_enable")
+
+    def timing_read(self, name):
+        tot, n = C.c_double(0.0), C.c_int64(0)
+        rc = self._lib.ndp_timing_read(self._h, name.encode(), C.byref(tot), C.byref(n))
+        if rc < 0:
+            return 0.0, 0
+        return tot.value, n.value

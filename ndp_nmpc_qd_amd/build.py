@@ -1,0 +1,32 @@
+"""Builds the gfx950 shared library in-tree (hipcc cross-compiles without a GPU)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libndp_nmpc_hip.so")
+SOURCES = ["ndp_hip.hip"]
+HEADERS = ["rti_wave.hpp", "wave_gfx950.hpp", "cfg_params.hpp", os.path.join("..", "..", "include", "ndp_nmpc.h")]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> ndp_nmpc_qd_amd/libndp_nmpc_hip.so"""
+    if not (force or _stale()):
+        return LIB
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + \
+          [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,603 @@
+// ndp_hip.hip -- gfx950 kernels + the C-ABI of include/ndp_nmpc.h.
+//
+// Kernels
+//   rti_kernel  : one wavefront per OCP instance runs the whole SQP-RTI step (rti_wave.hpp) out of its
+//                 LDS slice; 4 waves (= 4 instances) per 256-thread workgroup, one per SIMD of a CU.
+//   mlp_kernel  : DownwashNN.update + r_horiz gate for all (instance, horizon row) pairs; the four
+//                 layers are chained through v_mfma_f32_32x32x2_f32 accumulators (no LDS round trip).
+// There is no CPU fallback: every entry point fails (<0) if HIP is unusable.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "wave_gfx950.hpp"   // defines the device qualifiers, must precede rti_wave.hpp
+#include "cfg_params.hpp"
+
+namespace ndp {
+
+// ------------------------------------------------------------------------------------------ RTI kernel
+struct BatchPtrs {
+    const double *x0, *xr, *ur;
+    const float *f;
+    double *X, *U, *u0;
+    int *status, *iters;
+    double *dbg;
+};
+
+template <int NSLOT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs bp, int B, int lds_per_wave)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int wave = (int)(threadIdx.x >> 6);
+    const int inst = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave);
+    if (inst >= B) return;
+    const int N = P.N;
+    const size_t nx = (size_t)(N + 1) * NX, nu = (size_t)N * NU, nf = (size_t)(N + 1) * 3;
+    RtiIo io;
+    io.x0 = bp.x0 + (size_t)inst * NX;
+    io.xr = bp.xr + inst * nx;
+    io.ur = bp.ur + inst * nu;
+    io.f = bp.f ? bp.f + inst * nf : nullptr;
+    io.X = bp.X + inst * nx;
+    io.U = bp.U + inst * nu;
+    io.u0 = bp.u0 + (size_t)inst * NU;
+    io.status = bp.status + inst;
+    io.iters = bp.iters + inst;
+    io.dbg = bp.dbg;
+    WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lds_per_wave);
+    RtiWave<WaveGfx950, NSLOT>::run(P, io, lds);
+}
+
+// test hook: one v_mfma_f64_16x16x4_f64 with caller-chosen per-lane operands (pins the register maps)
+__global__ void mfma_probe_kernel(const double *a, const double *b, const double *c, double *d)
+{
+    const int l = (int)threadIdx.x;
+    WaveGfx950::vd4 acc;
+    for (int r = 0; r < 4; ++r) acc.r[r] = c[r * 64 + l];
+    acc = WaveGfx950::mfma(a[l], b[l], acc);
+    for (int r = 0; r < 4; ++r) d[r * 64 + l] = acc.r[r];
+    d[256 + l] = WaveGfx950::readlane(a[l], 37) + WaveGfx950::wave_sum(b[l]) + WaveGfx950::wave_min(a[l]) + WaveGfx950::wave_max(a[l]);
+}
+
+// ------------------------------------------------------------------------------------------ MLP kernel
+// nn_net.py:7-18: Linear(6,128) ReLU Linear(128,64) ReLU Linear(64,128) ReLU Linear(128,3), fp32.
+// One wave = 32 horizon rows (columns of the MFMA tile); activations stay transposed [feature][row] in
+// the accumulators: the 32x32 f32 accumulator holds feature (r&3)+8(r>>2)+4(lane>>5) of row lane&31 in
+// register r, which is exactly the B-operand shape of the next layer's 32x32x2 step when that step
+// contracts the feature pair {f0(r), f0(r)+4}.  The weights are pre-permuted on the host into that
+// "fragment order" (one 64-float record per MFMA), so A operands are coalesced 256-byte loads.
+typedef float f16_t __attribute__((ext_vector_type(16)));
+
+enum { FR_L1 = 0, FR_L2 = FR_L1 + 12 * 64, FR_L3 = FR_L2 + 128 * 64, FR_B1 = FR_L3 + 128 * 64,
+       FR_B2 = FR_B1 + 128, FR_B3 = FR_B2 + 64, FR_W4 = FR_B3 + 128, FR_B4 = FR_W4 + 3 * 128, FR_TOTAL = FR_B4 + 4 };
+
+__device__ __forceinline__ int f0(int r) { return (r & 3) + 8 * (r >> 2); }
+
+__global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, const double *__restrict__ other,
+                                                  const double *__restrict__ ego, const double *__restrict__ ego_xy,
+                                                  float *__restrict__ fout, int rows, int np1, double r2)
+{
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int ntiles = (rows + 31) / 32;
+    // one 32-row tile per wave, no tile loop: a loop makes every weight load loop-invariant and the
+    // compiler then tries to keep all 17k weights in registers
+    const int tile = (int)blockIdx.x * 4 + wave;
+    if (tile < ntiles) {
+        const int row = tile * 32 + j;
+        const bool valid = row < rows;
+        const int rowc = valid ? row : rows - 1;
+        const int inst = rowc / np1;
+        // gate: ndp_nmpc_leader_node.py:65-68 (other.x[0] xy against ego ODOMETRY xy, strict <)
+        bool open = valid;
+        if (ego_xy) {
+            const double dx = other[(size_t)inst * np1 * NX] - ego_xy[inst * 2];
+            const double dy = other[(size_t)inst * np1 * NX + 1] - ego_xy[inst * 2 + 1];
+            open = open && (dx * dx + dy * dy < r2);
+        }
+        // downwash_nn.py:22-23: (other - ego)[:, 0:6] in fp64, cast to fp32
+        float zb[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const size_t idx = (size_t)rowc * NX + 2 * s + h;
+            zb[s] = (float)(other[idx] - ego[idx]);
+        }
+        f16_t h1[4], h2[2], h3[4];
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            f16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fr[FR_B1 + ot * 32 + f0(r) + 4 * h];
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[FR_L1 + (ot * 3 + s) * 64 + lane], zb[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1[ot][r] = fmaxf(acc[r], 0.0f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            f16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fr[FR_B2 + ot * 32 + f0(r) + 4 * h];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[FR_L2 + ((ot * 4 + it) * 16 + r) * 64 + lane], h1[it][r], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);   // keep at most one 16-record weight group in flight (register budget)
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h2[ot][r] = fmaxf(acc[r], 0.0f);
+        }
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            f16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fr[FR_B3 + ot * 32 + f0(r) + 4 * h];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[FR_L3 + ((ot * 2 + it) * 16 + r) * 64 + lane], h2[it][r], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h3[ot][r] = fmaxf(acc[r], 0.0f);
+        }
+        // last layer (128 -> 3) on the VALU: each half-wave owns 64 of the 128 features of its row
+        float o[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int feat = it * 32 + f0(r) + 4 * h;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[c] = fmaf(fr[FR_W4 + c * 128 + feat], h3[it][r], o[c]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = o[c] + __shfl_xor(o[c], 32, 64) + fr[FR_B4 + c];
+        if (valid && h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fout[(size_t)row * 3 + c] = open ? o[c] : 0.0f;   // :75-76 zeros when gated off
+        }
+    }
+}
+
+// host: blob (W1 b1 W2 b2 W3 b3 W4 b4, row-major [out][in]) -> fragment order
+static void make_fragments(const float *blob, std::vector<float> &fr)
+{
+    const float *W1 = blob, *b1 = W1 + 128 * 6, *W2 = b1 + 128, *b2 = W2 + 64 * 128;
+    const float *W3 = b2 + 64, *b3 = W3 + 128 * 64, *W4 = b3 + 128, *b4 = W4 + 3 * 128;
+    fr.assign(FR_TOTAL, 0.0f);
+    auto f0h = [](int r) { return (r & 3) + 8 * (r >> 2); };
+    for (int ot = 0; ot < 4; ++ot)
+        for (int s = 0; s < 3; ++s)
+            for (int l = 0; l < 64; ++l) fr[FR_L1 + (ot * 3 + s) * 64 + l] = W1[(ot * 32 + (l & 31)) * 6 + 2 * s + (l >> 5)];
+    for (int ot = 0; ot < 2; ++ot)
+        for (int it = 0; it < 4; ++it)
+            for (int r = 0; r < 16; ++r)
+                for (int l = 0; l < 64; ++l)
+                    fr[FR_L2 + ((ot * 4 + it) * 16 + r) * 64 + l] = W2[(ot * 32 + (l & 31)) * 128 + it * 32 + f0h(r) + 4 * (l >> 5)];
+    for (int ot = 0; ot < 4; ++ot)
+        for (int it = 0; it < 2; ++it)
+            for (int r = 0; r < 16; ++r)
+                for (int l = 0; l < 64; ++l)
+                    fr[FR_L3 + ((ot * 2 + it) * 16 + r) * 64 + l] = W3[(ot * 32 + (l & 31)) * 64 + it * 32 + f0h(r) + 4 * (l >> 5)];
+    for (int i = 0; i < 128; ++i) fr[FR_B1 + i] = b1[i];
+    for (int i = 0; i < 64; ++i) fr[FR_B2 + i] = b2[i];
+    for (int i = 0; i < 128; ++i) fr[FR_B3 + i] = b3[i];
+    for (int i = 0; i < 3 * 128; ++i) fr[FR_W4 + i] = W4[i];
+    for (int i = 0; i < 3; ++i) fr[FR_B4 + i] = b4[i];
+}
+
+}  // namespace ndp
+
+// ------------------------------------------------------------------------------------------ C-ABI
+using namespace ndp;
+
+struct ndp_handle {
+    ndp_cfg cfg;
+    RtiParams P;
+    int lds_per_wave = 0;      // doubles
+    int waves = 4;             // instances per workgroup
+    hipStream_t stream = nullptr;
+    // persistent device state
+    double *dX = nullptr, *dU = nullptr;
+    int *dStatus = nullptr, *dIters = nullptr;
+    float *dForce = nullptr, *dFrag = nullptr;
+    bool have_mlp = false;
+    // staging for the host-pointer entry points
+    double *sx0 = nullptr, *sxr = nullptr, *sur = nullptr, *sother = nullptr, *sego = nullptr, *su0 = nullptr, *sdbg = nullptr;
+    float *sf = nullptr;
+    // timing
+    bool timing = false;
+    struct Ev { hipEvent_t a, b; int kind; };
+    std::vector<Ev> events;
+    std::mutex mu;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+#define NDP_HIP(h, call)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+            return -(int)e_ - 1000;                                                        \
+        }                                                                                  \
+    } while (0)
+
+static size_t nxs(const ndp_handle *h) { return (size_t)h->cfg.batch * (h->cfg.N + 1) * NX; }
+static size_t nus(const ndp_handle *h) { return (size_t)h->cfg.batch * h->cfg.N * NU; }
+static size_t nfs(const ndp_handle *h) { return (size_t)h->cfg.batch * (h->cfg.N + 1) * 3; }
+
+extern "C" {
+
+int ndp_default_cfg(ndp_cfg *cfg)
+{
+    if (!cfg) return -1;
+    fill_default_cfg(cfg);
+    return 0;
+}
+
+const char *ndp_last_error(const ndp_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int ndp_debug_lds_doubles(int N) { return lds_doubles(N); }
+
+int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, double *d)
+{
+    double *da = nullptr, *db = nullptr, *dc = nullptr, *dd = nullptr;
+    if (hipMalloc((void **)&da, 64 * 8) != hipSuccess || hipMalloc((void **)&db, 64 * 8) != hipSuccess ||
+        hipMalloc((void **)&dc, 256 * 8) != hipSuccess || hipMalloc((void **)&dd, 320 * 8) != hipSuccess)
+        return -1;
+    (void)hipMemcpy(da, a, 64 * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, b, 64 * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dc, c, 256 * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, 0, da, db, dc, dd);
+    const hipError_t e = hipMemcpy(d, dd, 320 * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dd);
+    return e == hipSuccess ? 0 : -2;
+}
+
+int ndp_destroy(ndp_handle *h)
+{
+    if (!h) return -1;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    void *ptrs[] = {h->dX, h->dU, h->dStatus, h->dIters, h->dForce, h->dFrag, h->sx0, h->sxr, h->sur,
+                    h->sother, h->sego, h->su0, h->sdbg, h->sf};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
+{
+    if (!cfg || !out) { g_create_err = "ndp_create: null argument"; return -1; }
+    *out = nullptr;
+    if (cfg->batch < 1 || cfg->N < 2 || slots_for(cfg->N) > 5 || cfg->n_rti < 1) {
+        g_create_err = "ndp_create: need batch >= 1, 2 <= N <= 46, n_rti >= 1";
+        return -2;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= cfg->device) {
+        g_create_err = std::string("ndp_create: no usable HIP device (") + hipGetErrorString(e) + ")";
+        return -3;
+    }
+    ndp_handle *h = new (std::nothrow) ndp_handle;
+    if (!h) return -4;
+    h->cfg = *cfg;
+    h->P = to_params(*cfg);
+    h->lds_per_wave = (lds_doubles(cfg->N) + 1) & ~1;   // keep 16-byte alignment per wave slice
+    const size_t per_wave_bytes = (size_t)h->lds_per_wave * sizeof(double);
+    h->waves = 4;
+    while (h->waves > 1 && per_wave_bytes * h->waves > 160 * 1024) h->waves >>= 1;
+    auto fail = [&](const char *what, hipError_t err) {
+        g_create_err = std::string("ndp_create: ") + what + ": " + hipGetErrorString(err);
+        ndp_destroy(h);
+        return -5;
+    };
+    if ((e = hipSetDevice(cfg->device)) != hipSuccess) return fail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    const size_t B = cfg->batch;
+#define ALLOC(p, n)                                                                      \
+    if ((e = hipMalloc((void **)&(p), (n))) != hipSuccess) return fail("hipMalloc " #p, e)
+    ALLOC(h->dX, nxs(h) * 8); ALLOC(h->dU, nus(h) * 8);
+    ALLOC(h->dStatus, B * 4); ALLOC(h->dIters, B * 4);
+    ALLOC(h->dForce, nfs(h) * 4); ALLOC(h->dFrag, FR_TOTAL * 4);
+    ALLOC(h->sx0, B * NX * 8); ALLOC(h->sxr, nxs(h) * 8); ALLOC(h->sur, nus(h) * 8);
+    ALLOC(h->sother, nxs(h) * 8); ALLOC(h->sego, B * 2 * 8); ALLOC(h->su0, B * NU * 8);
+    ALLOC(h->sf, nfs(h) * 4); ALLOC(h->sdbg, (size_t)lds_doubles(cfg->N) * 8);
+#undef ALLOC
+    (void)hipMemsetAsync(h->dX, 0, nxs(h) * 8, h->stream);
+    (void)hipMemsetAsync(h->dU, 0, nus(h) * 8, h->stream);
+    (void)hipMemsetAsync(h->dStatus, 0, B * 4, h->stream);
+    (void)hipMemsetAsync(h->dIters, 0, B * 4, h->stream);
+    (void)hipMemsetAsync(h->dForce, 0, nfs(h) * 4, h->stream);
+    // allow the big dynamic-LDS launches
+    const int lds_bytes = (int)(per_wave_bytes * h->waves);
+    const void *fns[] = {(const void *)rti_kernel<3, 4>, (const void *)rti_kernel<3, 2>, (const void *)rti_kernel<3, 1>,
+                         (const void *)rti_kernel<5, 4>, (const void *)rti_kernel<5, 2>, (const void *)rti_kernel<5, 1>};
+    for (const void *fn : fns)
+        if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess)
+            return fail("hipFuncSetAttribute", e);
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
+    *out = h;
+    return 0;
+}
+
+int ndp_set_mlp_weights(ndp_handle *h, const float *blob, size_t n)
+{
+    if (!h || !blob) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (n != NDP_MLP_NPARAM) { h->err = "ndp_set_mlp_weights: expected 17859 floats"; return -2; }
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    std::vector<float> fr;
+    make_fragments(blob, fr);
+    NDP_HIP(h, hipMemcpyAsync(h->dFrag, fr.data(), FR_TOTAL * 4, hipMemcpyHostToDevice, h->stream));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    h->have_mlp = true;
+    return 0;
+}
+
+// ---- enqueue helpers (no locking, no sync) ----
+static int begin_timing(ndp_handle *h, hipStream_t s, int kind)
+{
+    if (!h->timing) return 0;
+    ndp_handle::Ev ev; ev.kind = kind;
+    NDP_HIP(h, hipEventCreate(&ev.a)); NDP_HIP(h, hipEventCreate(&ev.b));
+    NDP_HIP(h, hipEventRecord(ev.a, s));
+    h->events.push_back(ev);
+    return 0;
+}
+static int end_timing(ndp_handle *h, hipStream_t s)
+{
+    if (!h->timing) return 0;
+    NDP_HIP(h, hipEventRecord(h->events.back().b, s));
+    return 0;
+}
+
+static int launch_mlp(ndp_handle *h, const double *d_other, const double *d_ego, const double *d_ego_xy, float *d_f,
+                      hipStream_t s)
+{
+    if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }
+    const int np1 = h->cfg.N + 1, rows = h->cfg.batch * np1;
+    const int ntiles = (rows + 31) / 32;
+    const int grid = (ntiles + 3) / 4;
+    int rc = begin_timing(h, s, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mlp_kernel, dim3(grid), dim3(256), 0, s, (const float *)h->dFrag, d_other, d_ego, d_ego_xy, d_f,
+                       rows, np1, h->cfg.r_horiz * h->cfg.r_horiz);
+    NDP_HIP(h, hipGetLastError());
+    return end_timing(h, s);
+}
+
+static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, const double *d_ur, const float *d_f,
+                      double *d_u0, double *d_dbg, hipStream_t s)
+{
+    BatchPtrs bp{d_x0, d_xr, d_ur, d_f, h->dX, h->dU, d_u0, h->dStatus, h->dIters, d_dbg};
+    const int B = h->cfg.batch, W = h->waves;
+    const dim3 grid((B + W - 1) / W), block(64 * W);
+    const size_t shm = (size_t)h->lds_per_wave * sizeof(double) * W;
+    const int ns = slots_for(h->cfg.N);
+    int rc = begin_timing(h, s, 0);
+    if (rc) return rc;
+#define LAUNCH(NS, WV) hipLaunchKernelGGL((rti_kernel<NS, WV>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave)
+    if (ns <= 3) { if (W == 4) LAUNCH(3, 4); else if (W == 2) LAUNCH(3, 2); else LAUNCH(3, 1); }
+    else         { if (W == 4) LAUNCH(5, 4); else if (W == 2) LAUNCH(5, 2); else LAUNCH(5, 1); }
+#undef LAUNCH
+    NDP_HIP(h, hipGetLastError());
+    return end_timing(h, s);
+}
+
+int ndp_reset_device(ndp_handle *h, const void *d_xr, const void *d_ur, void *stream)
+{
+    if (!h || !d_xr || !d_ur) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipMemcpyAsync(h->dX, d_xr, nxs(h) * 8, hipMemcpyDeviceToDevice, s));
+    NDP_HIP(h, hipMemcpyAsync(h->dU, d_ur, nus(h) * 8, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int ndp_reset(ndp_handle *h, const double *xr, const double *ur)
+{
+    if (!h || !xr || !ur) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipMemcpyAsync(h->dX, xr, nxs(h) * 8, hipMemcpyHostToDevice, h->stream));
+    NDP_HIP(h, hipMemcpyAsync(h->dU, ur, nus(h) * 8, hipMemcpyHostToDevice, h->stream));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ndp_step_device(ndp_handle *h, const void *d_x0, const void *d_xr, const void *d_ur, const void *d_f,
+                    const void *d_other, const void *d_ego_xy, void *d_u0, void *stream)
+{
+    if (!h || !d_x0 || !d_xr || !d_ur || !d_u0) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    const float *force = (const float *)d_f;
+    if (d_other) {
+        if (d_f) { h->err = "ndp_step: pass either f or other, not both"; return -7; }
+        int rc = launch_mlp(h, (const double *)d_other, (const double *)d_xr, (const double *)d_ego_xy, h->dForce, s);
+        if (rc) return rc;
+        force = h->dForce;
+    }
+    if (force && !h->cfg.use_fd) { h->err = "ndp_step: a disturbance force needs use_fd = 1 (NDP model)"; return -8; }
+    return launch_rti(h, (const double *)d_x0, (const double *)d_xr, (const double *)d_ur, force, (double *)d_u0,
+                      nullptr, s);
+}
+
+static int worst_status(ndp_handle *h, int *out)
+{
+    std::vector<int> st(h->cfg.batch);
+    NDP_HIP(h, hipMemcpy(st.data(), h->dStatus, st.size() * 4, hipMemcpyDeviceToHost));
+    int w = 0;
+    for (int v : st) w = v > w ? v : w;
+    *out = w;
+    return 0;
+}
+
+static int step_host(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
+                     const double *other, const double *ego_xy, double *u0, double *dump)
+{
+    if (!h || !x0 || !xr || !ur || !u0) return -1;
+    std::unique_lock<std::mutex> lk(h->mu);
+    hipStream_t s = h->stream;
+    const size_t B = h->cfg.batch;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipMemcpyAsync(h->sx0, x0, B * NX * 8, hipMemcpyHostToDevice, s));
+    NDP_HIP(h, hipMemcpyAsync(h->sxr, xr, nxs(h) * 8, hipMemcpyHostToDevice, s));
+    NDP_HIP(h, hipMemcpyAsync(h->sur, ur, nus(h) * 8, hipMemcpyHostToDevice, s));
+    if (f) NDP_HIP(h, hipMemcpyAsync(h->sf, f, nfs(h) * 4, hipMemcpyHostToDevice, s));
+    if (other) NDP_HIP(h, hipMemcpyAsync(h->sother, other, nxs(h) * 8, hipMemcpyHostToDevice, s));
+    if (ego_xy) NDP_HIP(h, hipMemcpyAsync(h->sego, ego_xy, B * 2 * 8, hipMemcpyHostToDevice, s));
+    const float *force = f ? h->sf : nullptr;
+    if (other) {
+        if (f) { h->err = "ndp_step: pass either f or other, not both"; return -7; }
+        int rc = launch_mlp(h, h->sother, h->sxr, ego_xy ? h->sego : nullptr, h->dForce, s);
+        if (rc) return rc;
+        force = h->dForce;
+    }
+    if (force && !h->cfg.use_fd) { h->err = "ndp_step: a disturbance force needs use_fd = 1 (NDP model)"; return -8; }
+    int rc = launch_rti(h, h->sx0, h->sxr, h->sur, force, h->su0, dump ? h->sdbg : nullptr, s);
+    if (rc) return rc;
+    NDP_HIP(h, hipMemcpyAsync(u0, h->su0, B * NU * 8, hipMemcpyDeviceToHost, s));
+    if (dump) NDP_HIP(h, hipMemcpyAsync(dump, h->sdbg, (size_t)lds_doubles(h->cfg.N) * 8, hipMemcpyDeviceToHost, s));
+    NDP_HIP(h, hipStreamSynchronize(s));
+    int w = 0;
+    rc = worst_status(h, &w);
+    return rc ? rc : w;
+}
+
+int ndp_step(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
+             const double *other, const double *ego_xy, double *u0)
+{
+    return step_host(h, x0, xr, ur, f, other, ego_xy, u0, nullptr);
+}
+
+int ndp_step_debug(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
+                   double *u0, double *lds_dump)
+{
+    if (h && h->cfg.batch != 1) { h->err = "ndp_step_debug: batch must be 1"; return -9; }
+    return step_host(h, x0, xr, ur, f, nullptr, nullptr, u0, lds_dump);
+}
+
+int ndp_downwash_device(ndp_handle *h, const void *d_other, const void *d_ego_ref, const void *d_ego_xy,
+                        void *d_f_out, void *stream)
+{
+    if (!h || !d_other || !d_ego_ref || !d_f_out) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    return launch_mlp(h, (const double *)d_other, (const double *)d_ego_ref, (const double *)d_ego_xy, (float *)d_f_out, s);
+}
+
+int ndp_downwash(ndp_handle *h, const double *other, const double *ego_ref, const double *ego_xy, float *f_out)
+{
+    if (!h || !other || !ego_ref || !f_out) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = h->stream;
+    const size_t B = h->cfg.batch;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipMemcpyAsync(h->sother, other, nxs(h) * 8, hipMemcpyHostToDevice, s));
+    NDP_HIP(h, hipMemcpyAsync(h->sxr, ego_ref, nxs(h) * 8, hipMemcpyHostToDevice, s));
+    if (ego_xy) NDP_HIP(h, hipMemcpyAsync(h->sego, ego_xy, B * 2 * 8, hipMemcpyHostToDevice, s));
+    int rc = launch_mlp(h, h->sother, h->sxr, ego_xy ? h->sego : nullptr, h->dForce, s);
+    if (rc) return rc;
+    NDP_HIP(h, hipMemcpyAsync(f_out, h->dForce, nfs(h) * 4, hipMemcpyDeviceToHost, s));
+    NDP_HIP(h, hipStreamSynchronize(s));
+    return 0;
+}
+
+int ndp_get_iterate(ndp_handle *h, double *X, double *U)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    if (X) NDP_HIP(h, hipMemcpy(X, h->dX, nxs(h) * 8, hipMemcpyDeviceToHost));
+    if (U) NDP_HIP(h, hipMemcpy(U, h->dU, nus(h) * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ndp_set_iterate(ndp_handle *h, const double *X, const double *U)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    if (X) NDP_HIP(h, hipMemcpy(h->dX, X, nxs(h) * 8, hipMemcpyHostToDevice));
+    if (U) NDP_HIP(h, hipMemcpy(h->dU, U, nus(h) * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int ndp_get_status(ndp_handle *h, int32_t *status, int32_t *ipm_iters)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    if (status) NDP_HIP(h, hipMemcpy(status, h->dStatus, (size_t)h->cfg.batch * 4, hipMemcpyDeviceToHost));
+    if (ipm_iters) NDP_HIP(h, hipMemcpy(ipm_iters, h->dIters, (size_t)h->cfg.batch * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+void *ndp_device_iterate_x(ndp_handle *h) { return h ? h->dX : nullptr; }
+void *ndp_device_iterate_u(ndp_handle *h) { return h ? h->dU : nullptr; }
+void *ndp_device_force(ndp_handle *h) { return h ? h->dForce : nullptr; }
+
+int ndp_synchronize(ndp_handle *h)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ndp_timing_enable(ndp_handle *h, int on)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    h->events.clear();
+    h->timing = on != 0;
+    return 0;
+}
+
+int ndp_timing_read(ndp_handle *h, const char *name, double *total_ms, int64_t *launches)
+{
+    if (!h || !name) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int kind = (name[0] == 'm') ? 1 : 0;
+    double tot = 0.0;
+    int64_t n = 0;
+    for (auto &e : h->events) {
+        if (e.kind != kind) continue;
+        NDP_HIP(h, hipEventSynchronize(e.b));
+        float ms = 0.0f;
+        NDP_HIP(h, hipEventElapsedTime(&ms, e.a, e.b));
+        tot += ms;
+        ++n;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return n ? 0 : -10;
+}
+
+}  // extern "C"

@@ -23,7 +23,10 @@
 //    minimiser is strictly inside the box.
 #pragma once
 
-#ifndef NDP_HD
+#ifndef NDP_D        // wave-program functions: __device__ in the gfx950 build, plain inline under the emulator
+#define NDP_D inline
+#endif
+#ifndef NDP_HD       // layout helpers used by host and device
 #define NDP_HD inline
 #endif
 
@@ -91,6 +94,7 @@ struct RtiWave {
     using vi = typename W::vi;
     using vb = typename W::vb;
     using vd4 = typename W::vd4;
+    using lp = typename W::lds_ptr;   // pointer into this wave's LDS slice
 
     struct Tables {
         vi mk_off[3], mk_mul[3];  // M~ as B operand / M~' as A operand: element (4c+g, j)
@@ -113,7 +117,7 @@ struct RtiWave {
 
     // ---------------------------------------------------------------- index tables
     // element (r, c) of M~_k = [[A b 0 B], [0 1 0 0], [0 0 0 0]] -> LDS offset (+ k * mul)
-    static NDP_HD void m_entry(const LdsMap &m, vi r, vi c, vi &off, vi &mul)
+    static NDP_D void m_entry(const LdsMap &m, vi r, vi c, vi &off, vi &mul)
     {
         vb isP = r < 3, isPV = r < 6, isQ = (r >= 6) && (r < 10);
         vb colq = (c >= 6) && (c < 10), colu = c >= 12;
@@ -132,7 +136,7 @@ struct RtiWave {
     }
 
     // element (row, col) of C~_k = [[Q q 0 0], [q' 0 0 r'], [0], [0 r 0 R]] -> LDS offset (+ k * mul)
-    static NDP_HD void c_entry(const LdsMap &m, vi row, vi col, vi &off, vi &mul)
+    static NDP_D void c_entry(const LdsMap &m, vi row, vi col, vi &off, vi &mul)
     {
         vb rx = row < 10, cx = col < 10, ru = row >= 12, cu = col >= 12;
         vb dgx = rx && (row == col) && (row < 6);
@@ -151,7 +155,7 @@ struct RtiWave {
         mul = W::sel(isvar, vi(int(CB_STRIDE)), vi(0));
     }
 
-    static NDP_HD void build_tables(const LdsMap &m, Tables &T)
+    static NDP_D void build_tables(const LdsMap &m, Tables &T)
     {
         vi lane = W::lane();
         vi g = lane >> 4, j = lane & 15;
@@ -164,7 +168,7 @@ struct RtiWave {
     }
 
     // ---------------------------------------------------------------- inputs
-    static NDP_HD void stage_inputs(const RtiParams &P, const LdsMap &m, const RtiIo &io, double *lds, bool first)
+    static NDP_D void stage_inputs(const RtiParams &P, const LdsMap &m, const RtiIo &io, lp lds, bool first)
     {
         const int N = P.N;
         vi lane = W::lane();
@@ -206,7 +210,7 @@ struct RtiWave {
 
     // ---------------------------------------------------------------- Gauss-Newton cost blocks
     // residual [p-pr, v-vr, 0, E(qr) q, u-ur]; nmpc_body_rate_ctl.py:164-180
-    static NDP_HD void build_cost(const RtiParams &P, const LdsMap &m, double *lds)
+    static NDP_D void build_cost(const RtiParams &P, const LdsMap &m, lp lds)
     {
         const int N = P.N;
         vi lane = W::lane();
@@ -271,7 +275,7 @@ struct RtiWave {
 
     // ---------------------------------------------------------------- linearisation
     // q-dot = 1/2 Omega(w) q   (nmpc_body_rate_ctl.py:154-157)
-    static NDP_HD void qdot(const vd q[4], const vd w[3], vd o[4])
+    static NDP_D void qdot(const vd q[4], const vd w[3], vd o[4])
     {
         o[0] = (-w[0] * q[1] - w[1] * q[2] - w[2] * q[3]) * 0.5;
         o[1] = (w[0] * q[0] + w[2] * q[2] - w[1] * q[3]) * 0.5;
@@ -279,14 +283,14 @@ struct RtiWave {
         o[3] = (w[2] * q[0] + w[1] * q[1] - w[0] * q[2]) * 0.5;
     }
     // thrust direction R(q) e3   (nmpc_body_rate_ctl.py:151-153)
-    static NDP_HD void thrust_dir(const vd q[4], vd o[3])
+    static NDP_D void thrust_dir(const vd q[4], vd o[3])
     {
         o[0] = (q[1] * q[3] + q[0] * q[2]) * 2.0;
         o[1] = (q[2] * q[3] - q[0] * q[1]) * 2.0;
         o[2] = 1.0 - (q[1] * q[1] + q[2] * q[2]) * 2.0;
     }
     // directional derivative of R(q) e3 along s
-    static NDP_HD void thrust_dir_tan(const vd q[4], const vd s[4], vd o[3])
+    static NDP_D void thrust_dir_tan(const vd q[4], const vd s[4], vd o[3])
     {
         o[0] = (s[1] * q[3] + q[1] * s[3] + s[0] * q[2] + q[0] * s[2]) * 2.0;
         o[1] = (s[2] * q[3] + q[2] * s[3] - s[0] * q[1] - q[0] * s[1]) * 2.0;
@@ -294,7 +298,7 @@ struct RtiWave {
     }
 
     // tangent of the ODE at attitude qs: input tangent (dw, dc); state tangent s = (sp, sv, sq); sp does not feed back
-    static NDP_HD void tan_rhs(const vd qs[4], const vd w[3], vd c, const vd sv[3], const vd sq[4], const vd dw[3], vd dc,
+    static NDP_D void tan_rhs(const vd qs[4], const vd w[3], vd c, const vd sv[3], const vd sq[4], const vd dw[3], vd dc,
                                vd kp[3], vd kv[3], vd kq[4])
     {
         vd td[3], tt[3], a[4], b[4];
@@ -310,7 +314,7 @@ struct RtiWave {
     }
 
     // ERK4 (one step of dt) + forward sensitivities -> stage blocks MB_k (acados sim_erk defaults)
-    static NDP_HD void linearize(const RtiParams &P, const LdsMap &m, double *lds)
+    static NDP_D void linearize(const RtiParams &P, const LdsMap &m, lp lds)
     {
         const int N = P.N;
         const double h = P.dt, hh = 0.5 * P.dt, h6 = P.dt / 6.0;
@@ -403,7 +407,7 @@ struct RtiWave {
 
     // ---------------------------------------------------------------- Riccati sweep (MFMA)
     // inverse of the SPD 4x4 block Lam = H~uu via LDL'; all values wave-uniform.  Returns false if not PD.
-    static NDP_HD bool inv4(const double L[4][4], double inv[4][4])
+    static NDP_D bool inv4(const double L[4][4], double inv[4][4])
     {
         const double d0 = L[0][0];
         const double e0 = 1.0 / d0;
@@ -442,7 +446,7 @@ struct RtiWave {
 
     // backward: P~_N = C~_N; P~_k = H~xx - H~xu Lam^-1 H~ux with H~ = M~' P~ M~ + C~.  Stores K~' per stage.
     // forward: z~_0 = [dx0,1,0]; du = K~ z~; z~+ = M~ [z~; du].  Writes ZX[1..N], ZU[0..N-1].
-    static NDP_HD bool riccati_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, double *lds)
+    static NDP_D bool riccati_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, lp lds)
     {
         const int N = P.N;
         bool ok = true;
@@ -517,7 +521,7 @@ struct RtiWave {
 
     // ---------------------------------------------------------------- box constraints / interior point
     // order: du_k[0..3] k=0..N-1 (idxbu), then dv_k[0..2] k=1..N-1 (idxbx = 3,4,5; nmpc_body_rate_ctl.py:56-61)
-    static NDP_HD void build_slots(const RtiParams &P, const LdsMap &m, Slots &S)
+    static NDP_D void build_slots(const RtiParams &P, const LdsMap &m, Slots &S)
     {
         const int N = P.N, nu = 4 * N, mcon = 7 * N - 3;
         vi lane = W::lane();
@@ -543,7 +547,7 @@ struct RtiWave {
         }
     }
 
-    static NDP_HD void load_bounds(const LdsMap &, Slots &S, const double *lds)
+    static NDP_D void load_bounds(const LdsMap &, Slots &S, lp lds)
     {
         for (int s = 0; s < NSLOT; ++s) {
             vd cur = W::ld(lds, S.ioff[s]);
@@ -552,7 +556,7 @@ struct RtiWave {
         }
     }
 
-    static NDP_HD bool strictly_inside(const Slots &S, const double *lds)
+    static NDP_D bool strictly_inside(const Slots &S, lp lds)
     {
         vb okv = W::lane() >= 0;
         for (int s = 0; s < NSLOT; ++s) {
@@ -562,7 +566,7 @@ struct RtiWave {
         return W::all(okv);
     }
 
-    static NDP_HD double absmax(const double *lds, int off, int n)
+    static NDP_D double absmax(lp lds, int off, int n)
     {
         vi lane = W::lane();
         vd mx = 0.0;
@@ -575,7 +579,7 @@ struct RtiWave {
 
     // Mehrotra predictor-corrector in absolute form; every Newton system is one riccati_sweep with
     // diag += Gamma, grad += gamma on the bounded variables (same algorithm as oracle orc_qp_solve).
-    static NDP_HD int ipm(const RtiParams &P, const LdsMap &m, const Tables &T, Slots &S, double *lds, int &iters_out)
+    static NDP_D int ipm(const RtiParams &P, const LdsMap &m, const Tables &T, Slots &S, lp lds, int &iters_out)
     {
         const int N = P.N, mcon = 7 * N - 3;
         const int nzx = (N + 1) * NX, nzu = N * NU;
@@ -680,10 +684,10 @@ struct RtiWave {
         return status;
     }
 
-    static NDP_HD double fmax_u(double a, double b) { return a > b ? a : b; }
+    static NDP_D double fmax_u(double a, double b) { return a > b ? a : b; }
 
     // ---------------------------------------------------------------- the control step
-    static NDP_HD void run(const RtiParams &P, const RtiIo &io, double *lds)
+    static NDP_D void run(const RtiParams &P, const RtiIo &io, lp lds)
     {
         const int N = P.N;
         const LdsMap m = make_map(N);

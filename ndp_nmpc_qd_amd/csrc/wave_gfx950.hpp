@@ -1,0 +1,93 @@
+// wave_gfx950.hpp -- the wave backend of rti_wave.hpp on CDNA4 (gfx950): one HIP thread = one lane.
+// Per-lane values are plain registers; cross-lane traffic is v_readlane / ds_bpermute; the matrix
+// instruction is v_mfma_f64_16x16x4_f64; the LDS slice is addressed through an address_space(3)
+// pointer so every access is a ds_read/ds_write (no flat instructions).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define NDP_D __device__ __forceinline__
+#define NDP_HD __host__ __device__ inline
+
+namespace ndp {
+
+struct WaveGfx950 {
+    using vd = double;
+    using vi = int;
+    using vb = bool;
+    struct vd4 { double r[4]; };
+    typedef __attribute__((address_space(3))) double *lds_ptr;
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+
+    static NDP_D vi lane() { return (int)(threadIdx.x & 63u); }
+    static NDP_D vd sel(vb p, vd a, vd b) { return p ? a : b; }
+    static NDP_D vi sel(vb p, vi a, vi b) { return p ? a : b; }
+    static NDP_D vd vmin(vd a, vd b) { return fmin(a, b); }
+    static NDP_D vd vmax(vd a, vd b) { return fmax(a, b); }
+    static NDP_D vd vabs(vd a) { return fabs(a); }
+    static NDP_D vi div3(vi a) { return a / 3; }
+    static NDP_D vi div6(vi a) { return a / 6; }
+
+    // LDS (one wave owns its slice; DS operations of one wave execute in order)
+    static NDP_D vd ld(lds_ptr lds, vi off) { return lds[off]; }
+    static NDP_D vd ldp(lds_ptr lds, vi off, vb p) { return p ? lds[off] : 0.0; }
+    static NDP_D void stp(lds_ptr lds, vi off, vd v, vb p) { if (p) lds[off] = v; }
+    static NDP_D void sync()
+    {   // lanes exchange data through LDS: forbid the compiler to move LDS accesses across this point
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // global memory
+    static NDP_D vd gld(const double *g, vi off, vb p) { return p ? g[off] : 0.0; }
+    static NDP_D vd gldf(const float *g, vi off, vb p) { return p ? (double)g[off] : 0.0; }
+    static NDP_D void gst(double *g, vi off, vd v, vb p) { if (p) g[off] = v; }
+    static NDP_D void gsti(int *g, int v) { if (g && lane() == 0) *g = v; }
+
+    // cross-lane
+    static NDP_D double readlane(vd a, int l)
+    {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(a), l);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(a), l);
+        return __hiloint2double(hi, lo);
+    }
+    static NDP_D double uniform(vd a)
+    {
+        const int lo = __builtin_amdgcn_readfirstlane(__double2loint(a));
+        const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(a));
+        return __hiloint2double(hi, lo);
+    }
+    static NDP_D double wave_min(vd a)
+    {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) a = fmin(a, __shfl_xor(a, s, 64));
+        return uniform(a);
+    }
+    static NDP_D double wave_max(vd a)
+    {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) a = fmax(a, __shfl_xor(a, s, 64));
+        return uniform(a);
+    }
+    static NDP_D double wave_sum(vd a)
+    {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) a = a + __shfl_xor(a, s, 64);
+        return uniform(a);
+    }
+    static NDP_D bool all(vb p) { return __all((int)p) != 0; }
+    static NDP_D bool any(vb p) { return __any((int)p) != 0; }
+
+    // v_mfma_f64_16x16x4_f64: A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15], D reg r lane l = D[(l>>4)+4r][l&15]
+    static NDP_D vd4 zero4() { vd4 z; z.r[0] = z.r[1] = z.r[2] = z.r[3] = 0.0; return z; }
+    static NDP_D vd4 mfma(vd a, vd b, const vd4 &c)
+    {
+        d4_t acc = {c.r[0], c.r[1], c.r[2], c.r[3]};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        vd4 d;
+        d.r[0] = acc[0]; d.r[1] = acc[1]; d.r[2] = acc[2]; d.r[3] = acc[3];
+        return d;
+    }
+};
+
+}  // namespace ndp

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstring>
 
+#define NDP_D inline
 #define NDP_HD inline
 
 namespace emu {
@@ -68,6 +69,7 @@ struct Wave {
     using vi = emu::vi;
     using vb = emu::vb;
     using vd4 = emu::vd4;
+    using lds_ptr = double *;
 
     static int &lds_limit() { static thread_local int n = 0; return n; }
     static void chk(int i) { if (i < 0 || i >= lds_limit()) __builtin_trap(); }

@@ -1,0 +1,293 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the
+CPU oracle on identical seeded inputs, against the committed reference-generated MLP fixtures, and
+through size-independent properties at BASELINE.json's full batch size.
+
+Tolerance (BASELINE.json north_star): |du0| <= 1e-5 * max(1, |u0|) after the same number of SQP-RTI
+iterations; the fp64 device path is expected (and asserted) to sit orders of magnitude inside that.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ndp_nmpc_qd_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL_U = 1e-5
+
+
+def _assert_u(u, uo, tol=RTOL_U):
+    bad = np.abs(u - uo) > tol * np.maximum(1.0, np.abs(uo))
+    assert not bad.any(), f"{bad.sum()} control entries outside {tol}: max abs {np.abs(u - uo).max()}"
+
+
+@pytest.fixture(scope="module")
+def ndp():
+    import ndp_nmpc_qd_amd
+    return ndp_nmpc_qd_amd
+
+
+def _oracle_batch(oracle, b, N=20, n_rti=1, use_fd=False, f=None, X=None, U=None):
+    cfg = oracle.default_cfg(N=N, n_rti=n_rti, use_fd=use_fd)
+    X = b["xr"].copy() if X is None else X
+    U = b["ur"].copy() if U is None else U
+    u0, st, it = oracle.step_batch(cfg, b["x0"], b["xr"], b["ur"], f, X, U)
+    return u0, st, it, X, U
+
+
+def test_mfma_register_maps(ndp):
+    """v_mfma_f64_16x16x4_f64 operand / result layouts are what rti_wave.hpp (and the emulator) assume."""
+    from ndp_nmpc_qd_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    A, Bm, Cm = rng.integers(-9, 9, (16, 4)).astype(float), rng.integers(-9, 9, (4, 16)).astype(float), \
+        rng.integers(-9, 9, (16, 16)).astype(float)
+    a = np.array([A[l & 15, l >> 4] for l in range(64)])
+    b = np.array([Bm[l >> 4, l & 15] for l in range(64)])
+    c = np.array([[Cm[(l >> 4) + 4 * r, l & 15] for l in range(64)] for r in range(4)])
+    d = np.zeros(320)
+    assert lib.ndp_debug_mfma_probe(_lib.ptr(a), _lib.ptr(b), _lib.ptr(np.ascontiguousarray(c)), _lib.ptr(d)) == 0
+    D = A @ Bm + Cm
+    got = d[:256].reshape(4, 64)
+    for r in range(4):
+        for l in range(64):
+            assert got[r, l] == D[(l >> 4) + 4 * r, l & 15], (r, l)
+    np.testing.assert_allclose(d[256:], a[37] + b.sum() + a.min() + a.max(), atol=0)
+
+
+@pytest.mark.parametrize("qp_mode", [0, 1])
+def test_batch_matches_oracle(ndp, oracle, qp_mode):
+    B = 256
+    b = synth.make_batch(B, seed=synth.SEED0 + 2)
+    eng = ndp.BatchedNMPC(B, qp_mode=qp_mode)
+    eng.reset(b["xr"], b["ur"])
+    u0 = eng.update(b["x0"], b["xr"], b["ur"])
+    u0o, sto, ito, Xo, Uo = _oracle_batch(oracle, b)
+    st, it = eng.status()
+    assert (st == 0).all() and (sto == 0).all()
+    _assert_u(u0, u0o, 1e-8)
+    X, U = eng.get_iterate()
+    np.testing.assert_allclose(X, Xo, atol=1e-8)
+    np.testing.assert_allclose(U, Uo, atol=1e-8)
+    if qp_mode == 1:
+        assert (it == ito).all()
+    # second and third control tick from the persistent device iterate (no shift)
+    for _ in range(2):
+        u0 = eng.update(b["x0"], b["xr"], b["ur"])
+        u0o, *_ = _oracle_batch(oracle, b, X=Xo, U=Uo)
+        _assert_u(u0, u0o, 1e-8)
+
+
+def test_active_bounds_and_infeasible_start(ndp, oracle):
+    """Large initial errors (input bounds active) and iterates outside the box: interior point on the device."""
+    B = 64
+    b = synth.make_batch(B, seed=77, pos_sigma=1.5, vel_sigma=3.0, quat_sigma=0.2)
+    U0 = b["ur"].copy()
+    U0[::4, :, 0] = 7.5         # > w_max for a quarter of the instances
+    U0[1::4, 3, 3] = -1.0       # < c_min
+    eng = ndp.BatchedNMPC(B)
+    eng.set_iterate(b["xr"], U0)
+    u0 = eng.update(b["x0"], b["xr"], b["ur"], raise_on_status=False)
+    u0o, sto, ito, Xo, Uo = _oracle_batch(oracle, b, U=U0.copy())
+    st, it = eng.status()
+    assert (ito > 0).sum() > B // 2          # the case exercises the inequality path
+    assert np.array_equal(st, sto)
+    ok = sto == 0
+    assert ok.sum() > B // 2
+    assert np.array_equal(it[ok], ito[ok])
+    _assert_u(u0[ok], u0o[ok], 1e-6)
+    X, U = eng.get_iterate()
+    np.testing.assert_allclose(U[ok], Uo[ok], atol=1e-5)
+    assert U[ok][..., :3].max() <= 6 + 1e-6 and U[ok][..., 3].min() >= -1e-6
+
+
+def test_ndp_update_with_force(ndp, oracle):
+    B = 64
+    b = synth.make_batch(B, seed=5)
+    f = np.random.default_rng(3).normal(0, 2.0, (B, 21, 3)).astype(np.float32)
+    eng = ndp.BatchedNMPC(B, disturbance=True, load_mlp=False)
+    eng.reset(b["xr"], b["ur"])
+    u0 = eng.update(b["x0"], b["xr"], b["ur"], f=f)
+    u0o, *_ = _oracle_batch(oracle, b, use_fd=True, f=f)
+    _assert_u(u0, u0o, 1e-8)
+
+
+def test_downwash_mlp_against_reference_fixture(ndp, mlp_golden):
+    """DownwashNN.update-shaped fixture produced by importing the reference network (tests/golden)."""
+    other, ego, want = mlp_golden["other"], mlp_golden["ego"], mlp_golden["f_update"]
+    eng = ndp.BatchedNMPC(other.shape[0], disturbance=True)
+    f = eng.downwash(other, ego)
+    assert f.dtype == np.float32
+    tol = 1e-5 * np.maximum(1.0, np.abs(want))      # fp32 network, summation order differs from torch's
+    assert np.all(np.abs(f - want) <= tol), np.abs(f - want).max()
+    # the 512 single rows (incl. SURVEY C.1) through the same kernel: put z into the position/velocity slots
+    z, fz = mlp_golden["z"], mlp_golden["f"]
+    rows = z.shape[0]
+    Bz = (rows + 20) // 21
+    o2 = np.zeros((Bz * 21, 10))
+    o2[:rows, 0:6] = z
+    eng2 = ndp.BatchedNMPC(Bz, disturbance=True)
+    f2 = eng2.downwash(o2.reshape(Bz, 21, 10), np.zeros((Bz, 21, 10))).reshape(-1, 3)[:rows]
+    assert np.all(np.abs(f2 - fz) <= 1e-5 * np.maximum(1.0, np.abs(fz)))
+
+
+def test_fused_downwash_step_and_gate(ndp, oracle, mlp_blob):
+    """update with neighbour windows: gate (ego odometry xy, strict <) + MLP + NDP solve, all on the device."""
+    B = 128
+    b = synth.make_batch(B, seed=synth.SEED0 + 3, downwash=True)
+    eng = ndp.BatchedNMPC(B, disturbance=True)
+    eng.reset(b["xr"], b["ur"])
+    u0 = eng.update(b["x0"], b["xr"], b["ur"], other=b["other"], ego_xy=b["ego_xy"])
+    f_or = oracle.downwash_batch(mlp_blob, b["other"], b["xr"], b["ego_xy"])
+    gate_on = (np.abs(f_or).max(axis=(1, 2)) > 0)
+    assert 0.15 < gate_on.mean() < 0.6           # roughly a third of the instances pass the 1 m gate
+    u0o, *_ = _oracle_batch(oracle, b, use_fd=True, f=f_or)
+    _assert_u(u0, u0o, 1e-6)                     # force is fp32: device and oracle MLP differ by ~1e-6 relative
+    f_dev = eng.downwash(b["other"], b["xr"], b["ego_xy"])
+    assert np.array_equal(f_dev[~gate_on], np.zeros_like(f_dev[~gate_on]))
+    assert np.all(np.abs(f_dev - f_or) <= 1e-5 * np.maximum(1.0, np.abs(f_or)))
+    # exactly-on-the-rim case is gated OFF (strict <, ndp_nmpc_leader_node.py:65-68)
+    exy = b["other"][:, 0, 0:2].copy()
+    exy[0] += [0.6, 0.8]
+    exy[1] += [0.6, 0.79]
+    fr = eng.downwash(b["other"], b["xr"], exy)
+    assert np.all(fr[0] == 0) and np.abs(fr[1]).max() > 0
+
+
+def test_long_horizon_two_rti_iterations(ndp, oracle):
+    """BASELINE config 5 shape: N=40, 2 RTI iterations per call."""
+    B = 32
+    b = synth.make_batch(B, N=40, seed=11)
+    eng = ndp.BatchedNMPC(B, N=40, n_rti=2)
+    eng.reset(b["xr"], b["ur"])
+    u0 = eng.update(b["x0"], b["xr"], b["ur"])
+    u0o, sto, *_ = _oracle_batch(oracle, b, N=40, n_rti=2)
+    assert (sto == 0).all()
+    _assert_u(u0, u0o, 1e-8)
+
+
+def test_full_size_batch_1024(ndp, oracle):
+    """BASELINE configs[1]/[2] size: every one of the 1024 instances against the oracle, plus properties."""
+    B = 1024
+    b = synth.make_batch(B, seed=synth.SEED0 + 3, downwash=True)
+    eng = ndp.BatchedNMPC(B, disturbance=True)
+    eng.reset(b["xr"], b["ur"])
+    f = eng.downwash(b["other"], b["xr"], b["ego_xy"])
+    u0 = eng.update(b["x0"], b["xr"], b["ur"], other=b["other"], ego_xy=b["ego_xy"])
+    u0o, sto, ito, Xo, Uo = _oracle_batch(oracle, b, use_fd=True, f=f)
+    _assert_u(u0, u0o, 1e-8)                     # same fp32 force on both sides -> fp64-level agreement
+    X, U = eng.get_iterate()
+    # properties independent of any oracle: x0 equality holds after the full step; u0 is U[0]; inputs in the box
+    np.testing.assert_allclose(X[:, 0, :], b["x0"], atol=1e-9)
+    assert np.array_equal(u0, U[:, 0, :])
+    assert (U[..., :3] <= 6 + 1e-9).all() and (U[..., :3] >= -6 - 1e-9).all()
+    assert (U[..., 3] >= -1e-9).all() and (U[..., 3] <= 9.81 / 0.36 + 1e-9).all()
+    # permutation equivariance: instances are independent
+    perm = np.random.default_rng(0).permutation(B)
+    eng2 = ndp.BatchedNMPC(B, disturbance=True)
+    eng2.reset(b["xr"][perm], b["ur"][perm])
+    u0p = eng2.update(b["x0"][perm], b["xr"][perm], b["ur"][perm], other=b["other"][perm], ego_xy=b["ego_xy"][perm])
+    assert np.array_equal(u0p, u0[perm])
+
+
+def test_ragged_batches(ndp, oracle):
+    """Batch sizes that do not fill a 4-wave workgroup or a 32-row MLP tile."""
+    for B in (1, 3, 5, 33):
+        b = synth.make_batch(B, seed=100 + B, downwash=True)
+        eng = ndp.BatchedNMPC(B, disturbance=True)
+        eng.reset(b["xr"], b["ur"])
+        f = eng.downwash(b["other"], b["xr"], b["ego_xy"])
+        u0 = eng.update(b["x0"], b["xr"], b["ur"], other=b["other"], ego_xy=b["ego_xy"])
+        u0o, *_ = _oracle_batch(oracle, b, use_fd=True, f=f)
+        _assert_u(u0, u0o, 1e-8)
+
+
+def test_lds_image_matches_oracle_linearisation(ndp, oracle):
+    b = synth.make_batch(1, seed=31)
+    N = 20
+    rng = np.random.default_rng(0)
+    X = b["xr"] + rng.normal(0, 0.05, (1, N + 1, 10))
+    U = b["ur"] + rng.normal(0, 0.2, (1, N, 4))
+    eng = ndp.BatchedNMPC(1)
+    eng.set_iterate(X, U)
+    _, lds = eng.update_debug(b["x0"], b["xr"], b["ur"])
+    qp = oracle.linearize(oracle.default_cfg(), b["x0"][0], b["xr"][0], b["ur"][0], None, X[0], U[0])
+    MB = 32 + 3 * ((N + 1) * 10 + N * 4)
+    CB = MB + N * 86
+    for k in range(N):
+        blk = lds[MB + k * 86: MB + (k + 1) * 86]
+        np.testing.assert_allclose(blk[0:48].reshape(6, 8)[:, 0:4], qp["A"][k][0:6, 6:10], atol=1e-12)
+        np.testing.assert_allclose(blk[0:48].reshape(6, 8)[:, 4:8], qp["B"][k][0:6, :], atol=1e-12)
+        np.testing.assert_allclose(blk[48:76].reshape(4, 7)[:, 0:4], qp["A"][k][6:10, 6:10], atol=1e-12)
+        np.testing.assert_allclose(blk[76:86], qp["b"][k], atol=1e-12)
+        cb = lds[CB + k * 47: CB + (k + 1) * 47]
+        np.testing.assert_allclose(cb[16:26], qp["q"][k], atol=1e-10)
+        np.testing.assert_allclose(cb[26:30], qp["r"][k], atol=1e-10)
+
+
+def test_reference_api_drop_in(ndp, oracle, mlp_golden):
+    """The three reference classes, used exactly as nmpc_node.py / ndp_nmpc_leader_node.py use them."""
+    from ndp_nmpc_qd_amd.dnwash_nn_est import DownwashNN
+    from ndp_nmpc_qd_amd.ndp_nmpc_ctl import NDPNMPCBodyRateController
+    from ndp_nmpc_qd_amd.nmpc_ctl import NMPCBodyRateController
+    b = synth.make_batch(1, seed=9)
+    x0, xr, ur = b["x0"][0], b["xr"][0], b["ur"][0]
+    ctl = NMPCBodyRateController(is_build_acados=True)
+    assert ctl.solver.N == 20
+    ctl.reset(xr, ur)
+    u0 = ctl.update(x0, xr, ur)
+    assert isinstance(u0, np.ndarray) and u0.shape == (4,) and u0.dtype == np.float64
+    cfg = oracle.default_cfg()
+    Xo, Uo = xr.copy(), ur.copy()
+    u0o, _ = oracle.step(cfg, x0, xr, ur, None, Xo, Uo)
+    _assert_u(u0, u0o, 1e-8)
+    x1 = ctl.solver.get(1, "x")
+    np.testing.assert_allclose(x1, Xo[1], atol=1e-8)
+    x1[:] = 0                                           # caller mutates its copy (nmpc_node.py:238)
+    np.testing.assert_allclose(ctl.solver.get(1, "x"), Xo[1], atol=1e-8)
+    assert ctl.solver.status == 0
+    # hover fixed point
+    xh, uh = synth.hover_reference()
+    ctl.reset(xh, uh)
+    np.testing.assert_allclose(ctl.update(xh[0], xh, uh), [0, 0, 0, 9.81], atol=1e-10)
+    # NDP controller + DownwashNN
+    nn = DownwashNN()
+    f = nn.update(mlp_golden["other"][0], mlp_golden["ego"][0])
+    assert f.shape == (21, 3) and f.dtype == np.float32
+    assert np.all(np.abs(f - mlp_golden["f_update"][0]) <= 1e-5 * np.maximum(1, np.abs(mlp_golden["f_update"][0])))
+    nctl = NDPNMPCBodyRateController()
+    nctl.reset(xr, ur)
+    u0n = nctl.update(x0, xr, ur, f)
+    Xo, Uo = xr.copy(), ur.copy()
+    u0no, _ = oracle.step(oracle.default_cfg(use_fd=True), x0, xr, ur, f, Xo, Uo)
+    _assert_u(u0n, u0no, 1e-8)
+    assert isinstance(ctl, NMPCBodyRateController) and not isinstance(ctl, NDPNMPCBodyRateController)  # nmpc_node.py:203-208
+
+
+def test_status_raises_like_reference(ndp):
+    """Infeasible QP -> status 4 -> the reference's exception text (nmpc_body_rate_ctl.py:109-110)."""
+    b = synth.make_batch(2, seed=41)
+    eng = ndp.BatchedNMPC(2, lbv=(-1e-3,) * 3, ubv=(1e-3,) * 3, iter_max=12)
+    eng.reset(b["xr"], b["ur"])
+    with pytest.raises(Exception, match="acados acados_ocp_solver returned status"):
+        eng.update(b["x0"], b["xr"], b["ur"])
+    st, it = eng.status()
+    assert (st != 0).all() and (it == 12).all()
+
+
+def test_device_resident_path_matches_host_path(ndp):
+    import torch
+    B = 64
+    b = synth.make_batch(B, seed=3, downwash=True)
+    eng_h = ndp.BatchedNMPC(B, disturbance=True)
+    eng_h.reset(b["xr"], b["ur"])
+    u_host = eng_h.update(b["x0"], b["xr"], b["ur"], other=b["other"], ego_xy=b["ego_xy"])
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur", "other", "ego_xy")}
+    eng_d = ndp.BatchedNMPC(B, disturbance=True)
+    eng_d.reset_device(t["xr"], t["ur"])
+    u_dev = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    eng_d.update_device(t["x0"], t["xr"], t["ur"], u_dev, other=t["other"], ego_xy=t["ego_xy"])
+    eng_d.synchronize()
+    assert np.array_equal(u_dev.cpu().numpy(), u_host)
