@@ -48,6 +48,12 @@ def load():
         raise RuntimeError(
             "libndp_nmpc_hip.so is missing: build it with `python -m ndp_nmpc_qd_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch-ROCm bundles its own HIP runtime; if it is going to be used in this process it has to be
+    # the first one loaded, otherwise torch later reports "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32p = C.c_void_p, C.POINTER(C.c_int32)
     lib.ndp_default_cfg.argtypes = [C.POINTER(NdpCfg)]

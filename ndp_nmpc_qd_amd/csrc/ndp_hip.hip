@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, 
         if (ego_xy) {
             const double dx = other[(size_t)inst * np1 * NX] - ego_xy[inst * 2];
             const double dy = other[(size_t)inst * np1 * NX + 1] - ego_xy[inst * 2 + 1];
-            open = open && (dx * dx + dy * dy < r2);
+            // individually rounded mul/add (no FMA contraction): the reference evaluates this in Python doubles,
+            // and the strict '<' must agree with it at the rim
+            open = open && (__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)) < r2);
         }
         // downwash_nn.py:22-23: (other - ego)[:, 0:6] in fp64, cast to fp32
         float zb[3];

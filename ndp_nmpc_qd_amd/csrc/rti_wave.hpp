@@ -40,7 +40,7 @@ enum { MB_PV = 0, MB_Q = 48, MB_B = 76 };
 // cost block CB_k: Qq(4x4) | qe(10) | re(4) | dex(6) | deu(4) | qbv(3) | rb(4)
 enum { CB_QQ = 0, CB_QE = 16, CB_RE = 26, CB_DEX = 30, CB_DEU = 36, CB_QBV = 40, CB_RB = 43 };
 // constants area
-enum { KC_ZERO = 0, KC_ONE = 1, KC_H = 2, KC_QD = 4, KC_RD = 14, KC_LBU = 18, KC_UBU = 22, KC_LBV = 26, KC_UBV = 29, KC_SIZE = 32 };
+enum { KC_ZERO = 0, KC_ONE = 1, KC_H = 2, KC_QD = 4, KC_RD = 14, KC_LBU = 18, KC_UBU = 22, KC_LBV = 26, KC_UBV = 29, KC_SC = 32, KC_SIZE = 48 };
 
 struct RtiParams {
     int N, n_rti, use_fd, qp_mode, iter_max;
@@ -61,7 +61,7 @@ struct RtiIo {            // global-memory views of ONE instance
 };
 
 struct LdsMap {
-    int KC, XI, UI, ZX, ZU, CX, CU, MB, CB, KT, TXR, TUR, TF, total;
+    int KC, SC, XI, UI, ZX, ZU, CX, CU, MB, CB, KT, TXR, TUR, TF, total;
 };
 
 NDP_HD LdsMap make_map(int N)
@@ -69,6 +69,7 @@ NDP_HD LdsMap make_map(int N)
     LdsMap m;
     int o = 0;
     m.KC = o; o += KC_SIZE;
+    m.SC = m.KC + KC_SC;   // 16-double scratch for the 4x4 inverse
     m.XI = o; o += (N + 1) * NX;
     m.UI = o; o += N * NU;
     m.ZX = o; o += (N + 1) * NX;
@@ -103,6 +104,14 @@ struct RtiWave {
         vi kt_off[3];
         vb kt_pred;               // j < 4
         vb col0;                  // j == 0
+        // 4x4 inverse (lam_inverse): LDS scratch SC holds Lam row-major
+        vi lam_w_off;             // lanes j >= 12 publish H~[12+g][j] to SC[g*4 + j-12]
+        vb lam_w_pred;
+        vi minor_off[9];          // the 3x3 minor of (g, j&3)
+        vi own_off;               // Lam[g][j&3]
+        vd cof_sign;              // (-1)^(g + j&3)
+        vb lam_diag;              // g == j&3
+        vd eye[3];                // identity as B operand: chunk c, lane (g,j) = [j == 4c+g]
     };
 
     struct Slots {                // box constraints, 64 per slot
@@ -165,35 +174,65 @@ struct RtiWave {
         for (int c = 0; c < 3; ++c) T.kt_off[c] = (g + 4 * c) * 4 + j + m.KT;
         T.kt_pred = j < 4;
         T.col0 = j == 0;
+        vi jc = j & 3;
+        T.lam_w_off = g * 4 + (j - 12) + m.SC;
+        T.lam_w_pred = j >= 12;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                vi ra = W::sel(g <= a, vi(a + 1), vi(a));    // rows {0..3} \ {g}
+                vi cb = W::sel(jc <= b, vi(b + 1), vi(b));   // cols {0..3} \ {jc}
+                T.minor_off[3 * a + b] = ra * 4 + cb + m.SC;
+            }
+        T.own_off = g * 4 + jc + m.SC;
+        T.cof_sign = W::sel(((g + jc) & 1) == 1, vd(-1.0), vd(1.0));
+        T.lam_diag = g == jc;
+        for (int c = 0; c < 3; ++c) T.eye[c] = W::sel(j == g + 4 * c, vd(1.0), vd(0.0));
     }
 
     // ---------------------------------------------------------------- inputs
+    // largest horizon this instantiation serves (7N-3 box constraints in 64*NSLOT slots) and the number of
+    // 64-lane rounds needed to move its arrays: compile-time so that every global load is in flight at once
+    static constexpr int NMAXS = (64 * NSLOT + 3) / 7;
+    static constexpr int RX = ((NMAXS + 1) * NX + 63) / 64, RU = (NMAXS * NU + 63) / 64, RF = ((NMAXS + 1) * 3 + 63) / 64;
+
     static NDP_D void stage_inputs(const RtiParams &P, const LdsMap &m, const RtiIo &io, lp lds, bool first)
     {
         const int N = P.N;
         vi lane = W::lane();
         const int nx = (N + 1) * NX, nu = N * NU, nf = (N + 1) * 3;
-        for (int t = 0; t < nx; t += 64) {
-            vi i = lane + t;
-            vb p = i < nx;
-            W::stp(lds, i + m.TXR, W::gld(io.xr, i, p), p);
-            if (first) W::stp(lds, i + m.XI, W::gld(io.X, i, p), p);
+        const bool have_f = P.use_fd && io.f;
+        vd bxr[RX], bxi[RX], bur[RU], bui[RU], bf[RF];
+        for (int t = 0; t < RX; ++t) {
+            vi i = lane + 64 * t;
+            bxr[t] = W::gld(io.xr, i, i < nx);
+            if (first) bxi[t] = W::gld(io.X, i, i < nx);
         }
-        for (int t = 0; t < nu; t += 64) {
-            vi i = lane + t;
-            vb p = i < nu;
-            W::stp(lds, i + m.TUR, W::gld(io.ur, i, p), p);
-            if (first) W::stp(lds, i + m.UI, W::gld(io.U, i, p), p);
+        for (int t = 0; t < RU; ++t) {
+            vi i = lane + 64 * t;
+            bur[t] = W::gld(io.ur, i, i < nu);
+            if (first) bui[t] = W::gld(io.U, i, i < nu);
         }
-        for (int t = 0; t < nf; t += 64) {
-            vi i = lane + t;
-            vb p = i < nf;
-            vd v = (P.use_fd && io.f) ? W::gldf(io.f, i, p) : vd(0.0);
-            W::stp(lds, i + m.TF, v, p);
+        for (int t = 0; t < RF; ++t) {
+            vi i = lane + 64 * t;
+            bf[t] = have_f ? W::gldf(io.f, i, i < nf) : vd(0.0);
+        }
+        for (int t = 0; t < RX; ++t) {
+            vi i = lane + 64 * t;
+            W::stp(lds, i + m.TXR, bxr[t], i < nx);
+            if (first) W::stp(lds, i + m.XI, bxi[t], i < nx);
+        }
+        for (int t = 0; t < RU; ++t) {
+            vi i = lane + 64 * t;
+            W::stp(lds, i + m.TUR, bur[t], i < nu);
+            if (first) W::stp(lds, i + m.UI, bui[t], i < nu);
+        }
+        for (int t = 0; t < RF; ++t) {
+            vi i = lane + 64 * t;
+            W::stp(lds, i + m.TF, bf[t], i < nf);
         }
         if (first) {
             // constants area (lane-indexable copies of the uniform parameters)
-            vb p = lane < KC_SIZE;
+            vb p = lane < KC_SC;
             vd v = 0.0;
             v = W::sel(lane == KC_ONE, vd(1.0), v);
             v = W::sel(lane == KC_H, vd(P.dt), v);
@@ -406,47 +445,35 @@ struct RtiWave {
     }
 
     // ---------------------------------------------------------------- Riccati sweep (MFMA)
-    // inverse of the SPD 4x4 block Lam = H~uu via LDL'; all values wave-uniform.  Returns false if not PD.
-    static NDP_D bool inv4(const double L[4][4], double inv[4][4])
+    // Lam^-1 for the SPD 4x4 block Lam = H~uu, lane-parallel: lane (g, j<4) computes its own entry
+    // adj(Lam)[g][j] / det(Lam) from a 16-double LDS copy of Lam.  No sequential pivots: on gfx950 a
+    // dependent f64 VALU op costs ~32 cycles and a divide ~100, so a 4-pivot factorisation computed
+    // redundantly on every lane was ~40 % of a backward stage.  Lam = R + B'PB + barrier diagonal: R > 0 and
+    // the barrier terms only add to the diagonal, so the cofactor expansion is well conditioned here.
+    // Returns the A/B-operand register (lane (g,j): Lam^-1[g][j] for j < 4, else 0) and a PD flag.
+    static NDP_D vd lam_inverse(const Tables &T, lp lds, vd h3, bool &ok)
     {
-        const double d0 = L[0][0];
-        const double e0 = 1.0 / d0;
-        const double l10 = L[1][0] * e0, l20 = L[2][0] * e0, l30 = L[3][0] * e0;
-        const double d1 = L[1][1] - l10 * L[1][0];
-        const double e1 = 1.0 / d1;
-        const double t21 = L[2][1] - l20 * L[1][0], t31 = L[3][1] - l30 * L[1][0];
-        const double l21 = t21 * e1, l31 = t31 * e1;
-        const double d2 = L[2][2] - l20 * L[2][0] - l21 * t21;
-        const double e2 = 1.0 / d2;
-        const double t32 = L[3][2] - l30 * L[2][0] - l31 * t21;
-        const double l32 = t32 * e2;
-        const double d3 = L[3][3] - l30 * L[3][0] - l31 * t31 - l32 * t32;
-        const double e3 = 1.0 / d3;
-        // M = L^-1 (unit lower)
-        const double m10 = -l10, m21 = -l21, m32 = -l32;
-        const double m20 = -l20 - l21 * m10, m31 = -l31 - l32 * m21;
-        const double m30 = -l30 - l31 * m10 - l32 * m20;
-        const double a3 = m30 * e3, b3 = m31 * e3, c3 = m32 * e3;
-        const double a2 = m20 * e2, b2 = m21 * e2;
-        const double a1 = m10 * e1;
-        inv[0][0] = e0 + m10 * a1 + m20 * a2 + m30 * a3;
-        inv[1][0] = a1 + m21 * a2 + m31 * a3;
-        inv[2][0] = a2 + m32 * a3;
-        inv[3][0] = a3;
-        inv[1][1] = e1 + m21 * b2 + m31 * b3;
-        inv[2][1] = b2 + m32 * b3;
-        inv[3][1] = b3;
-        inv[2][2] = e2 + m32 * c3;
-        inv[3][2] = c3;
-        inv[3][3] = e3;
-        inv[0][1] = inv[1][0]; inv[0][2] = inv[2][0]; inv[0][3] = inv[3][0];
-        inv[1][2] = inv[2][1]; inv[1][3] = inv[3][1]; inv[2][3] = inv[3][2];
-        return (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
+        W::stp(lds, T.lam_w_off, h3, T.lam_w_pred);          // H~[12+g][12+b] -> SC[g*4+b]
+        W::sync();
+        vd mm[9];
+        for (int i = 0; i < 9; ++i) mm[i] = W::ld(lds, T.minor_off[i]);
+        vd own = W::ld(lds, T.own_off);
+        vd d0 = mm[4] * mm[8] - mm[5] * mm[7];
+        vd d1 = mm[3] * mm[8] - mm[5] * mm[6];
+        vd d2 = mm[3] * mm[7] - mm[4] * mm[6];
+        vd cof = (mm[0] * d0 - mm[1] * d1 + mm[2] * d2) * T.cof_sign;
+        vd det = W::quad_sum(own * cof);                      // row expansion: lanes 16g..16g+3 form one quad
+        vb pd = (det > 0.0) && (!T.lam_diag || (cof > 0.0));
+        ok = W::all(!T.kt_pred || pd) && ok;
+        return W::sel(T.kt_pred, cof * W::rcp(det), vd(0.0));
     }
 
     // backward: P~_N = C~_N; P~_k = H~xx - H~xu Lam^-1 H~ux with H~ = M~' P~ M~ + C~.  Stores K~' per stage.
     // forward: z~_0 = [dx0,1,0]; du = K~ z~; z~+ = M~ [z~; du].  Writes ZX[1..N], ZU[0..N-1].
-    static NDP_D bool riccati_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, lp lds)
+    // The LDS operands of stage k-1 (k+1 in the forward sweep) are requested before stage k's matrix
+    // instructions are issued, so their latency hides under the MFMA chain.
+    static NDP_D bool riccati_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, lp lds,
+                                    const RtiIo *io = nullptr)
     {
         const int N = P.N;
         bool ok = true;
@@ -456,35 +483,47 @@ struct RtiWave {
         // terminal block has no control part: keep columns 12..15 exactly zero
         for (int c = 0; c < 3; ++c) Pt.r[c] = W::sel(j < 12, W::ld(lds, T.c_off[c] + T.c_mul[c] * N), vd(0.0));
         Pt.r[3] = 0.0;
+        vd mk[3], cc[4];
+        for (int c = 0; c < 3; ++c) mk[c] = W::ld(lds, T.mk_off[c] + T.mk_mul[c] * (N - 1));
+        for (int r = 0; r < 4; ++r) cc[r] = W::ld(lds, T.c_off[r] + T.c_mul[r] * (N - 1));
         for (int k = N - 1; k >= 0; --k) {
-            vd mk0 = W::ld(lds, T.mk_off[0] + T.mk_mul[0] * k);
-            vd mk1 = W::ld(lds, T.mk_off[1] + T.mk_mul[1] * k);
-            vd mk2 = W::ld(lds, T.mk_off[2] + T.mk_mul[2] * k);
+            const int kn = k > 0 ? k - 1 : 0;
+            vd nmk[3], ncc[4];
+            for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, T.mk_off[c] + T.mk_mul[c] * kn);
+            for (int r = 0; r < 4; ++r) ncc[r] = W::ld(lds, T.c_off[r] + T.c_mul[r] * kn);
             vd4 H;
-            for (int r = 0; r < 4; ++r) H.r[r] = W::ld(lds, T.c_off[r] + T.c_mul[r] * k);
+            for (int r = 0; r < 4; ++r) H.r[r] = cc[r];
             vd4 Wm = W::zero4();
-            Wm = W::mfma(Pt.r[0], mk0, Wm);
-            Wm = W::mfma(Pt.r[1], mk1, Wm);
-            Wm = W::mfma(Pt.r[2], mk2, Wm);
-            H = W::mfma(mk0, Wm.r[0], H);
-            H = W::mfma(mk1, Wm.r[1], H);
-            H = W::mfma(mk2, Wm.r[2], H);
+            Wm = W::mfma(Pt.r[0], mk[0], Wm);
+            Wm = W::mfma(Pt.r[1], mk[1], Wm);
+            Wm = W::mfma(Pt.r[2], mk[2], Wm);
+            H = W::mfma(mk[0], Wm.r[0], H);
+            H = W::mfma(mk[1], Wm.r[1], H);
+            H = W::mfma(mk[2], Wm.r[2], H);
             // Lam[a][b] = H~[12+a][12+b] sits in accumulator register 3 of lane 16a + 12 + b
-            double L[4][4], inv[4][4];
-            for (int a = 0; a < 4; ++a)
-                for (int b = 0; b <= a; ++b) L[a][b] = W::readlane(H.r[3], 16 * a + 12 + b);
-            ok = inv4(L, inv) && ok;
-            vd linv = 0.0;
-            for (int a = 0; a < 4; ++a)
-                for (int b = 0; b < 4; ++b) linv = W::sel(lane == 16 * a + b, vd(inv[a][b]), linv);
             vd hux = H.r[3];
+            vd linv = lam_inverse(T, lds, hux, ok);
             vd4 G = W::mfma(linv, hux, W::zero4());
             vd4 Kt = W::mfma(hux, -linv, W::zero4());
             vd4 Pn = W::mfma(-hux, G.r[0], H);
             for (int c = 0; c < 3; ++c) W::stp(lds, T.kt_off[c] + k * int(KT_STRIDE), Kt.r[c], T.kt_pred);
-            Pt.r[0] = Pn.r[0]; Pt.r[1] = Pn.r[1]; Pt.r[2] = Pn.r[2];
+            if ((k & 3) == 0 && k > 0) {
+                // P~ re-enters the next stage as an A operand, i.e. transposed.  The antisymmetric rounding part of
+                // P~ therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
+                // re-symmetrise every 4th stage.  P~' = (P~ as A operand) x I costs three MFMAs, no LDS.
+                vd4 Tp = W::zero4();
+                Tp = W::mfma(Pn.r[0], T.eye[0], Tp);
+                Tp = W::mfma(Pn.r[1], T.eye[1], Tp);
+                Tp = W::mfma(Pn.r[2], T.eye[2], Tp);
+                for (int c = 0; c < 3; ++c) Pt.r[c] = (Pn.r[c] + Tp.r[c]) * 0.5;
+            } else {
+                Pt.r[0] = Pn.r[0]; Pt.r[1] = Pn.r[1]; Pt.r[2] = Pn.r[2];
+            }
+            for (int c = 0; c < 3; ++c) mk[c] = nmk[c];
+            for (int r = 0; r < 4; ++r) cc[r] = ncc[r];
         }
         W::sync();
+        if (io) stamp(*io, m, 6);
         // forward rollout; z~ index 4c+g lives in chunk c of the lanes with j == 0
         vd zc[3];
         for (int c = 0; c < 3; ++c) {
@@ -492,28 +531,30 @@ struct RtiWave {
             vd v = W::ldp(lds, idx + m.ZX, T.col0 && (idx < 10));
             zc[c] = W::sel(T.col0 && (idx == 10), vd(1.0), v);
         }
+        vd kt[3], ma[4];
+        for (int c = 0; c < 3; ++c) kt[c] = W::ldp(lds, T.kt_off[c], T.kt_pred);
+        for (int c = 0; c < 4; ++c) ma[c] = W::ld(lds, T.ma_off[c]);
         for (int k = 0; k < N; ++k) {
-            vd kt0 = W::ldp(lds, T.kt_off[0] + k * int(KT_STRIDE), T.kt_pred);
-            vd kt1 = W::ldp(lds, T.kt_off[1] + k * int(KT_STRIDE), T.kt_pred);
-            vd kt2 = W::ldp(lds, T.kt_off[2] + k * int(KT_STRIDE), T.kt_pred);
-            vd ma0 = W::ld(lds, T.ma_off[0] + T.ma_mul[0] * k);
-            vd ma1 = W::ld(lds, T.ma_off[1] + T.ma_mul[1] * k);
-            vd ma2 = W::ld(lds, T.ma_off[2] + T.ma_mul[2] * k);
-            vd ma3 = W::ld(lds, T.ma_off[3] + T.ma_mul[3] * k);
+            const int kn = k + 1 < N ? k + 1 : k;
+            vd nkt[3], nma[4];
+            for (int c = 0; c < 3; ++c) nkt[c] = W::ldp(lds, T.kt_off[c] + kn * int(KT_STRIDE), T.kt_pred);
+            for (int c = 0; c < 4; ++c) nma[c] = W::ld(lds, T.ma_off[c] + T.ma_mul[c] * kn);
             vd4 du = W::zero4(), xn = W::zero4();
-            du = W::mfma(kt0, zc[0], du);
-            xn = W::mfma(ma0, zc[0], xn);
-            du = W::mfma(kt1, zc[1], du);
-            xn = W::mfma(ma1, zc[1], xn);
-            du = W::mfma(kt2, zc[2], du);
-            xn = W::mfma(ma2, zc[2], xn);
-            xn = W::mfma(ma3, du.r[0], xn);
+            du = W::mfma(kt[0], zc[0], du);
+            xn = W::mfma(ma[0], zc[0], xn);
+            du = W::mfma(kt[1], zc[1], du);
+            xn = W::mfma(ma[1], zc[1], xn);
+            du = W::mfma(kt[2], zc[2], du);
+            xn = W::mfma(ma[2], zc[2], xn);
+            xn = W::mfma(ma[3], du.r[0], xn);
             W::stp(lds, g + (k * NU + m.ZU), du.r[0], T.col0);
             for (int c = 0; c < 3; ++c) {
                 zc[c] = xn.r[c];
                 vi idx = g + 4 * c;
                 W::stp(lds, idx + ((k + 1) * NX + m.ZX), xn.r[c], T.col0 && (idx < 10));
             }
+            for (int c = 0; c < 3; ++c) kt[c] = nkt[c];
+            for (int c = 0; c < 4; ++c) ma[c] = nma[c];
         }
         W::sync();
         return ok;
@@ -686,23 +727,37 @@ struct RtiWave {
 
     static NDP_D double fmax_u(double a, double b) { return a > b ? a : b; }
 
+    // debug-path phase stamps (shader clock) written behind the LDS image dump; no-op when io.dbg is null
+    static NDP_D void stamp(const RtiIo &io, const LdsMap &m, int idx)
+    {
+        if (io.dbg) {
+            vd t = W::clock();
+            W::gst(io.dbg, W::lane() * 0 + (m.KT + idx), t, W::lane() == 0);
+        }
+    }
+
     // ---------------------------------------------------------------- the control step
     static NDP_D void run(const RtiParams &P, const RtiIo &io, lp lds)
     {
         const int N = P.N;
         const LdsMap m = make_map(N);
         const int nzx = (N + 1) * NX, nzu = N * NU;
+        stamp(io, m, 0);
         Tables T;
         build_tables(m, T);
         Slots S;
         build_slots(P, m, S);
+        stamp(io, m, 1);
         vi lane = W::lane();
         int status = 0, iters = 0;
         vd x0v = W::gld(io.x0, lane, lane < NX);
         for (int it = 0; it < P.n_rti; ++it) {
             stage_inputs(P, m, io, lds, it == 0);
+            stamp(io, m, 2);
             build_cost(P, m, lds);
+            stamp(io, m, 3);
             linearize(P, m, lds);
+            stamp(io, m, 4);
             // solve_for_x0: dx_0 = x0 - x_0  (nmpc_body_rate_ctl.py:107)
             W::stp(lds, lane + m.ZX, x0v - W::ldp(lds, lane + m.XI, lane < NX), lane < NX);
             load_bounds(m, S, lds);
@@ -717,7 +772,9 @@ struct RtiWave {
             int st = 0;
             if (P.qp_mode == QP_AUTO) {
                 // equality-constrained minimiser strictly inside the box => it IS the QP solution (all multipliers 0)
-                bool ok = riccati_sweep(P, m, T, lds);
+                stamp(io, m, 5);
+                bool ok = riccati_sweep(P, m, T, lds, &io);
+                stamp(io, m, 7);
                 if (!ok) st = 4;
                 done = strictly_inside(S, lds) || !ok;
                 if (done) {
@@ -752,6 +809,7 @@ struct RtiWave {
         }
         vd u0 = W::ldp(lds, lane + m.UI, lane < NU);
         W::gst(io.u0, lane, u0, lane < NU);
+        stamp(io, m, 8);
         if (W::any((lane < NU) && !(u0 == u0))) status = 1;
         W::gsti(io.status, status);
         W::gsti(io.iters, iters);

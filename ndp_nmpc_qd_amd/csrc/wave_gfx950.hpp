@@ -44,6 +44,30 @@ struct WaveGfx950 {
     static NDP_D void gst(double *g, vi off, vd v, vb p) { if (p) g[off] = v; }
     static NDP_D void gsti(int *g, int v) { if (g && lane() == 0) *g = v; }
 
+    // 1/a: v_rcp_f64 seed + two Newton steps (a full IEEE divide is ~100 dependent cycles on gfx950)
+    static NDP_D vd rcp(vd a)
+    {
+        double r = __builtin_amdgcn_rcp(a);
+        r = __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
+        return r;
+    }
+    // sum over the 4 lanes of each aligned quad, result in all 4 (DPP quad_perm, no LDS)
+    static NDP_D vd quad_sum(vd a)
+    {
+        a = a + dpp_quad<0xB1>(a);   // quad_perm [1,0,3,2]
+        a = a + dpp_quad<0x4E>(a);   // quad_perm [2,3,0,1]
+        return a;
+    }
+    template <int CTRL>
+    static NDP_D vd dpp_quad(vd a)
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), CTRL, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), CTRL, 0xF, 0xF, true);
+        return __hiloint2double(hi, lo);
+    }
+    static NDP_D vd clock() { return (double)__builtin_amdgcn_s_memtime(); }   // shader-clock ticks (debug stamps)
+
     // cross-lane
     static NDP_D double readlane(vd a, int l)
     {

@@ -95,6 +95,16 @@ struct Wave {
     static void gst(double *g, const vi &off, const vd &val, const vb &p) { for (int l = 0; l < 64; ++l) if (p.v[l]) g[off.v[l]] = val.v[l]; }
     static void gsti(int *g, int val) { if (g) *g = val; }
 
+    static vd clock() { return vd(0.0); }
+    static vd rcp(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = 1.0 / a.v[l]; return o; }
+    static vd quad_sum(const vd &a)
+    {   // same association as the device: (x + x^1) + (x + x^1)^2
+        vd t, o;
+        for (int l = 0; l < 64; ++l) t.v[l] = a.v[l] + a.v[l ^ 1];
+        for (int l = 0; l < 64; ++l) o.v[l] = t.v[l] + t.v[l ^ 2];
+        return o;
+    }
+
     // cross-lane
     static double readlane(const vd &a, int l) { stats().readlane++; return a.v[l]; }
     static double wave_min(const vd &a) { double m = a.v[0]; for (int l = 1; l < 64; ++l) m = std::fmin(m, a.v[l]); return m; }

@@ -95,7 +95,8 @@ def test_active_bounds_and_infeasible_start(ndp, oracle):
     assert np.array_equal(st, sto)
     ok = sto == 0
     assert ok.sum() > B // 2
-    assert np.array_equal(it[ok], ito[ok])
+    ran = ok & (it > 0)                      # auto mode: 0 iterations where the exact early exit fired
+    assert ran.sum() > B // 2 and np.array_equal(it[ran], ito[ran])
     _assert_u(u0[ok], u0o[ok], 1e-6)
     X, U = eng.get_iterate()
     np.testing.assert_allclose(U[ok], Uo[ok], atol=1e-5)
@@ -147,12 +148,17 @@ def test_fused_downwash_step_and_gate(ndp, oracle, mlp_blob):
     f_dev = eng.downwash(b["other"], b["xr"], b["ego_xy"])
     assert np.array_equal(f_dev[~gate_on], np.zeros_like(f_dev[~gate_on]))
     assert np.all(np.abs(f_dev - f_or) <= 1e-5 * np.maximum(1.0, np.abs(f_or)))
-    # exactly-on-the-rim case is gated OFF (strict <, ndp_nmpc_leader_node.py:65-68)
-    exy = b["other"][:, 0, 0:2].copy()
-    exy[0] += [0.6, 0.8]
-    exy[1] += [0.6, 0.79]
-    fr = eng.downwash(b["other"], b["xr"], exy)
-    assert np.all(fr[0] == 0) and np.abs(fr[1]).max() > 0
+    # exactly-on-the-rim case is gated OFF (strict <, ndp_nmpc_leader_node.py:65-68); values exact in binary
+    oth = b["other"].copy()
+    oth[0:2, 0, 0:2] = [1.0, 2.0]
+    exy = oth[:, 0, 0:2].copy()
+    exy[0] = [1.0, 3.0]                      # d^2 == 1.0 exactly -> off
+    exy[1] = [1.0, 2.9999999999999996]       # one ulp inside -> on
+    fr = eng.downwash(oth, b["xr"], exy)
+    assert np.all(fr[0] == 0)
+    assert np.abs(fr[1]).max() > 0
+    fro = oracle.downwash_batch(mlp_blob, oth, b["xr"], exy)
+    assert np.array_equal(fr == 0, fro == 0)
 
 
 def test_long_horizon_two_rti_iterations(ndp, oracle):
@@ -213,7 +219,7 @@ def test_lds_image_matches_oracle_linearisation(ndp, oracle):
     eng.set_iterate(X, U)
     _, lds = eng.update_debug(b["x0"], b["xr"], b["ur"])
     qp = oracle.linearize(oracle.default_cfg(), b["x0"][0], b["xr"][0], b["ur"][0], None, X[0], U[0])
-    MB = 32 + 3 * ((N + 1) * 10 + N * 4)
+    MB = 48 + 3 * ((N + 1) * 10 + N * 4)
     CB = MB + N * 86
     for k in range(N):
         blk = lds[MB + k * 86: MB + (k + 1) * 86]

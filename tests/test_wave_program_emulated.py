@@ -40,7 +40,7 @@ def test_nominal_batch_matches_oracle(oracle, qp_mode):
         np.testing.assert_allclose(X, Xo, atol=1e-8)
         np.testing.assert_allclose(U, Uo, atol=1e-8)
         if qp_mode == 0:
-            assert it == 0 and cnt["mfma"] == 16 * 20      # one sweep: 9 backward + 7 forward MFMAs per stage
+            assert it == 0 and cnt["mfma"] == 16 * 20 + 3 * 4   # one sweep: (9 backward + 7 forward) per stage + 4 re-symmetrisations
         else:
             assert it == sto.ipm_iters                      # same algorithm, same iteration count
 
@@ -109,6 +109,19 @@ def test_two_rti_iterations_and_long_horizon(oracle):
         np.testing.assert_allclose(X, Xo, atol=1e-7)
 
 
+def test_riccati_symmetry_is_maintained_over_long_horizons(oracle):
+    """P~ is fed back transposed (MFMA A operand); without the periodic re-symmetrisation its antisymmetric
+    rounding part grows ~2.2x per stage and ruins N >= 40.  Longest supported horizon, both QP modes."""
+    for N in (40, 46):
+        b = synth.make_batch(3, N=N, seed=13 + N)
+        for i in range(3):
+            for mode in (0, 1):
+                (u0, st, it, X, U, _), (u0o, sto, Xo, Uo) = _run_pair(oracle, b, i, N=N, qp_mode=mode)
+                assert st == 0 and sto.status == 0
+                _assert_u(u0, u0o, 1e-9)
+                np.testing.assert_allclose(X, Xo, atol=1e-8)
+
+
 def test_persistent_iterate_across_calls(oracle):
     """No shift between calls; second update() starts from the stored iterate."""
     b = synth.make_batch(1, seed=21)
@@ -134,7 +147,7 @@ def test_lds_image_matches_oracle_linearisation(oracle):
     qp = oracle.linearize(cfgo, b["x0"][0], b["xr"][0], b["ur"][0], f, X, U)
     _, _, _, lds, _ = E.rti_step(cfg, b["x0"][0], b["xr"][0], b["ur"][0], f, X.copy(), U.copy(), dump=True)
     KC = 0
-    XI = KC + 32
+    XI = KC + 48
     MB = XI + 3 * ((N + 1) * 10 + N * 4)
     CB = MB + N * 86
     for k in range(N):
