@@ -99,14 +99,15 @@ struct RtiWave {
 
     struct Tables {
         vi mk_off[3], mk_mul[3];  // M~ as B operand / M~' as A operand: element (4c+g, j)
-        vi ma_off[4], ma_mul[4];  // M~ as A operand: element (j, 4c+g)
+        vi fw_off[3], fw_mul[3];  // forward A operand [M~x ; K~]: rows j<12 element (j, 4c+g) of M~, rows j>=12 K~[j-12][4c+g]
+        vi mu_off, mu_mul;        // M~ columns 12..15 (B~) as A operand: element (j, 12+g)
         vi c_off[4], c_mul[4];    // C~ in accumulator layout: element (g+4r, j)
-        vi kt_off[3];
-        vb kt_pred;               // j < 4
+        vi kt_off[3];             // where lanes j>=12 keep K~'[4c+g][j-12]
+        vb kt_pred;               // j >= 12
+        vb lo4;                   // j < 4
         vb col0;                  // j == 0
         // 4x4 inverse (lam_inverse): LDS scratch SC holds Lam row-major
         vi lam_w_off;             // lanes j >= 12 publish H~[12+g][j] to SC[g*4 + j-12]
-        vb lam_w_pred;
         vi minor_off[9];          // the 3x3 minor of (g, j&3)
         vi own_off;               // Lam[g][j&3]
         vd cof_sign;              // (-1)^(g + j&3)
@@ -169,14 +170,20 @@ struct RtiWave {
         vi lane = W::lane();
         vi g = lane >> 4, j = lane & 15;
         for (int c = 0; c < 3; ++c) m_entry(m, g + 4 * c, j, T.mk_off[c], T.mk_mul[c]);
-        for (int c = 0; c < 4; ++c) m_entry(m, j, g + 4 * c, T.ma_off[c], T.ma_mul[c]);
         for (int r = 0; r < 4; ++r) c_entry(m, g + 4 * r, j, T.c_off[r], T.c_mul[r]);
-        for (int c = 0; c < 3; ++c) T.kt_off[c] = (g + 4 * c) * 4 + j + m.KT;
-        T.kt_pred = j < 4;
+        T.kt_pred = j >= 12;
+        T.lo4 = j < 4;
         T.col0 = j == 0;
+        for (int c = 0; c < 3; ++c) {
+            T.kt_off[c] = (g + 4 * c) * 4 + (j & 3) + m.KT;
+            vi mo, mm;
+            m_entry(m, j, g + 4 * c, mo, mm);
+            T.fw_off[c] = W::sel(T.kt_pred, T.kt_off[c], mo);
+            T.fw_mul[c] = W::sel(T.kt_pred, vi(int(KT_STRIDE)), mm);
+        }
+        m_entry(m, j, g + 12, T.mu_off, T.mu_mul);
         vi jc = j & 3;
-        T.lam_w_off = g * 4 + (j - 12) + m.SC;
-        T.lam_w_pred = j >= 12;
+        T.lam_w_off = g * 4 + jc + m.SC;
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) {
                 vi ra = W::sel(g <= a, vi(a + 1), vi(a));    // rows {0..3} \ {g}
@@ -195,40 +202,50 @@ struct RtiWave {
     static constexpr int NMAXS = (64 * NSLOT + 3) / 7;
     static constexpr int RX = ((NMAXS + 1) * NX + 63) / 64, RU = (NMAXS * NU + 63) / 64, RF = ((NMAXS + 1) * 3 + 63) / 64;
 
-    static NDP_D void stage_inputs(const RtiParams &P, const LdsMap &m, const RtiIo &io, lp lds, bool first)
+    struct InBuf { vd xr[RX], xi[RX], ur[RU], ui[RU], f[RF]; };
+
+    // issue every global load of this instance (nothing waits here)
+    static NDP_D void issue_inputs(const RtiParams &P, const RtiIo &io, InBuf &b, bool first)
     {
         const int N = P.N;
         vi lane = W::lane();
         const int nx = (N + 1) * NX, nu = N * NU, nf = (N + 1) * 3;
         const bool have_f = P.use_fd && io.f;
-        vd bxr[RX], bxi[RX], bur[RU], bui[RU], bf[RF];
         for (int t = 0; t < RX; ++t) {
             vi i = lane + 64 * t;
-            bxr[t] = W::gld(io.xr, i, i < nx);
-            if (first) bxi[t] = W::gld(io.X, i, i < nx);
+            b.xr[t] = W::gld(io.xr, i, i < nx);
+            b.xi[t] = first ? W::gld(io.X, i, i < nx) : vd(0.0);
         }
         for (int t = 0; t < RU; ++t) {
             vi i = lane + 64 * t;
-            bur[t] = W::gld(io.ur, i, i < nu);
-            if (first) bui[t] = W::gld(io.U, i, i < nu);
+            b.ur[t] = W::gld(io.ur, i, i < nu);
+            b.ui[t] = first ? W::gld(io.U, i, i < nu) : vd(0.0);
         }
         for (int t = 0; t < RF; ++t) {
             vi i = lane + 64 * t;
-            bf[t] = have_f ? W::gldf(io.f, i, i < nf) : vd(0.0);
+            b.f[t] = have_f ? W::gldf(io.f, i, i < nf) : vd(0.0);
         }
+    }
+
+    // land them in LDS (first use of the loaded values: the wait sits here)
+    static NDP_D void commit_inputs(const RtiParams &P, const LdsMap &m, const InBuf &b, lp lds, bool first)
+    {
+        const int N = P.N;
+        vi lane = W::lane();
+        const int nx = (N + 1) * NX, nu = N * NU, nf = (N + 1) * 3;
         for (int t = 0; t < RX; ++t) {
             vi i = lane + 64 * t;
-            W::stp(lds, i + m.TXR, bxr[t], i < nx);
-            if (first) W::stp(lds, i + m.XI, bxi[t], i < nx);
+            W::stp(lds, i + m.TXR, b.xr[t], i < nx);
+            if (first) W::stp(lds, i + m.XI, b.xi[t], i < nx);
         }
         for (int t = 0; t < RU; ++t) {
             vi i = lane + 64 * t;
-            W::stp(lds, i + m.TUR, bur[t], i < nu);
-            if (first) W::stp(lds, i + m.UI, bui[t], i < nu);
+            W::stp(lds, i + m.TUR, b.ur[t], i < nu);
+            if (first) W::stp(lds, i + m.UI, b.ui[t], i < nu);
         }
         for (int t = 0; t < RF; ++t) {
             vi i = lane + 64 * t;
-            W::stp(lds, i + m.TF, bf[t], i < nf);
+            W::stp(lds, i + m.TF, b.f[t], i < nf);
         }
         if (first) {
             // constants area (lane-indexable copies of the uniform parameters)
@@ -450,10 +467,10 @@ struct RtiWave {
     // dependent f64 VALU op costs ~32 cycles and a divide ~100, so a 4-pivot factorisation computed
     // redundantly on every lane was ~40 % of a backward stage.  Lam = R + B'PB + barrier diagonal: R > 0 and
     // the barrier terms only add to the diagonal, so the cofactor expansion is well conditioned here.
-    // Returns the A/B-operand register (lane (g,j): Lam^-1[g][j] for j < 4, else 0) and a PD flag.
+    // Returns, in EVERY lane (g,j), Lam^-1[g][j&3] (callers mask the columns they need) and a PD flag.
     static NDP_D vd lam_inverse(const Tables &T, lp lds, vd h3, bool &ok)
     {
-        W::stp(lds, T.lam_w_off, h3, T.lam_w_pred);          // H~[12+g][12+b] -> SC[g*4+b]
+        W::stp(lds, T.lam_w_off, h3, T.kt_pred);             // H~[12+g][12+b] -> SC[g*4+b]
         W::sync();
         vd mm[9];
         for (int i = 0; i < 9; ++i) mm[i] = W::ld(lds, T.minor_off[i]);
@@ -464,8 +481,8 @@ struct RtiWave {
         vd cof = (mm[0] * d0 - mm[1] * d1 + mm[2] * d2) * T.cof_sign;
         vd det = W::quad_sum(own * cof);                      // row expansion: lanes 16g..16g+3 form one quad
         vb pd = (det > 0.0) && (!T.lam_diag || (cof > 0.0));
-        ok = W::all(!T.kt_pred || pd) && ok;
-        return W::sel(T.kt_pred, cof * W::rcp(det), vd(0.0));
+        ok = W::all(pd) && ok;
+        return cof * W::rcp(det);
     }
 
     // backward: P~_N = C~_N; P~_k = H~xx - H~xu Lam^-1 H~ux with H~ = M~' P~ M~ + C~.  Stores K~' per stage.
@@ -502,9 +519,11 @@ struct RtiWave {
             H = W::mfma(mk[2], Wm.r[2], H);
             // Lam[a][b] = H~[12+a][12+b] sits in accumulator register 3 of lane 16a + 12 + b
             vd hux = H.r[3];
-            vd linv = lam_inverse(T, lds, hux, ok);
+            vd li = lam_inverse(T, lds, hux, ok);
+            vd linv = W::sel(T.lo4, li, vd(0.0));             // A operand of G: Lam^-1[g][j], j < 4
+            vd nlhi = W::sel(T.kt_pred, -li, vd(0.0));        // B operand of K~': -Lam^-1[g][j-12] in columns 12..15
             vd4 G = W::mfma(linv, hux, W::zero4());
-            vd4 Kt = W::mfma(hux, -linv, W::zero4());
+            vd4 Kt = W::mfma(hux, nlhi, W::zero4());          // K~'[i][b] lands in column 12+b: rows 12..15 of the forward operand
             vd4 Pn = W::mfma(-hux, G.r[0], H);
             for (int c = 0; c < 3; ++c) W::stp(lds, T.kt_off[c] + k * int(KT_STRIDE), Kt.r[c], T.kt_pred);
             if ((k & 3) == 0 && k > 0) {
@@ -531,30 +550,30 @@ struct RtiWave {
             vd v = W::ldp(lds, idx + m.ZX, T.col0 && (idx < 10));
             zc[c] = W::sel(T.col0 && (idx == 10), vd(1.0), v);
         }
-        vd kt[3], ma[4];
-        for (int c = 0; c < 3; ++c) kt[c] = W::ldp(lds, T.kt_off[c], T.kt_pred);
-        for (int c = 0; c < 4; ++c) ma[c] = W::ld(lds, T.ma_off[c]);
+        // per stage: Y = [M~x ; K~] z~ (3 MFMAs) holds M~x z~ in rows 0..11 and du = K~ z~ in rows 12..15, i.e. du is
+        // accumulator register 3 -- exactly the B operand of the 4th MFMA, which adds B~ du to rows 0..11.
+        vd fw[3], mu;
+        for (int c = 0; c < 3; ++c) fw[c] = W::ld(lds, T.fw_off[c]);
+        mu = W::ld(lds, T.mu_off);
         for (int k = 0; k < N; ++k) {
             const int kn = k + 1 < N ? k + 1 : k;
-            vd nkt[3], nma[4];
-            for (int c = 0; c < 3; ++c) nkt[c] = W::ldp(lds, T.kt_off[c] + kn * int(KT_STRIDE), T.kt_pred);
-            for (int c = 0; c < 4; ++c) nma[c] = W::ld(lds, T.ma_off[c] + T.ma_mul[c] * kn);
-            vd4 du = W::zero4(), xn = W::zero4();
-            du = W::mfma(kt[0], zc[0], du);
-            xn = W::mfma(ma[0], zc[0], xn);
-            du = W::mfma(kt[1], zc[1], du);
-            xn = W::mfma(ma[1], zc[1], xn);
-            du = W::mfma(kt[2], zc[2], du);
-            xn = W::mfma(ma[2], zc[2], xn);
-            xn = W::mfma(ma[3], du.r[0], xn);
-            W::stp(lds, g + (k * NU + m.ZU), du.r[0], T.col0);
+            vd nfw[3], nmu;
+            for (int c = 0; c < 3; ++c) nfw[c] = W::ld(lds, T.fw_off[c] + T.fw_mul[c] * kn);
+            nmu = W::ld(lds, T.mu_off + T.mu_mul * kn);
+            vd4 Y = W::zero4();
+            Y = W::mfma(fw[0], zc[0], Y);
+            Y = W::mfma(fw[1], zc[1], Y);
+            Y = W::mfma(fw[2], zc[2], Y);
+            vd du = Y.r[3];
+            vd4 xn = W::mfma(mu, du, Y);
+            W::stp(lds, g + (k * NU + m.ZU), du, T.col0);
             for (int c = 0; c < 3; ++c) {
                 zc[c] = xn.r[c];
                 vi idx = g + 4 * c;
                 W::stp(lds, idx + ((k + 1) * NX + m.ZX), xn.r[c], T.col0 && (idx < 10));
             }
-            for (int c = 0; c < 3; ++c) kt[c] = nkt[c];
-            for (int c = 0; c < 4; ++c) ma[c] = nma[c];
+            for (int c = 0; c < 3; ++c) fw[c] = nfw[c];
+            mu = nmu;
         }
         W::sync();
         return ok;
@@ -743,16 +762,20 @@ struct RtiWave {
         const LdsMap m = make_map(N);
         const int nzx = (N + 1) * NX, nzu = N * NU;
         stamp(io, m, 0);
+        vi lane = W::lane();
+        int status = 0, iters = 0;
+        // global loads first; the index tables (pure VALU) are built while they are in flight
+        vd x0v = W::gld(io.x0, lane, lane < NX);
+        InBuf inb;
+        issue_inputs(P, io, inb, true);
         Tables T;
         build_tables(m, T);
         Slots S;
         build_slots(P, m, S);
         stamp(io, m, 1);
-        vi lane = W::lane();
-        int status = 0, iters = 0;
-        vd x0v = W::gld(io.x0, lane, lane < NX);
         for (int it = 0; it < P.n_rti; ++it) {
-            stage_inputs(P, m, io, lds, it == 0);
+            if (it > 0) issue_inputs(P, io, inb, false);
+            commit_inputs(P, m, inb, lds, it == 0);
             stamp(io, m, 2);
             build_cost(P, m, lds);
             stamp(io, m, 3);

@@ -107,6 +107,24 @@ __global__ void k_rcpfast64(double *out, unsigned long long *cyc, int iters)
     out[threadIdx.x] = x;
     if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
+// accuracy of the v_rcp_f64 seed and of 1 / 2 Newton steps against the IEEE quotient
+__global__ void k_rcp_acc(double *out)
+{
+    double worst0 = 0, worst1 = 0, worst2 = 0;
+    unsigned long long st = 0x9E3779B97F4A7C15ull * (threadIdx.x + 1);
+    for (int it = 0; it < 20000; ++it) {
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+        double x = 1e-3 + (double)(st >> 11) * (1.0 / 9007199254740992.0) * 1e6;
+        double ref = 1.0 / x;
+        double r0 = __builtin_amdgcn_rcp(x);
+        double r1 = __builtin_fma(__builtin_fma(-x, r0, 1.0), r0, r0);
+        double r2 = __builtin_fma(__builtin_fma(-x, r1, 1.0), r1, r1);
+        worst0 = fmax(worst0, fabs(r0 - ref) / ref);
+        worst1 = fmax(worst1, fabs(r1 - ref) / ref);
+        worst2 = fmax(worst2, fabs(r2 - ref) / ref);
+    }
+    out[threadIdx.x * 3] = worst0; out[threadIdx.x * 3 + 1] = worst1; out[threadIdx.x * 3 + 2] = worst2;
+}
 #define RUN(name, launch, n)                                                          \
     do {                                                                              \
         launch; hipDeviceSynchronize(); launch; hipDeviceSynchronize();               \
@@ -129,5 +147,11 @@ int main()
     RUN("v_fma_f64 8 chains", (k_fma64<8><<<1, 64>>>(o, cyc, iters)), 8);
     RUN("f64 divide (IEEE) dependent", (k_rcp64<<<1, 64>>>(o, cyc, iters)), 1);
     RUN("f64 rcp + 2 Newton dependent", (k_rcpfast64<<<1, 64>>>(o, cyc, iters)), 1);
+    double *acc; hipMalloc(&acc, 64 * 3 * 8);
+    k_rcp_acc<<<1, 64>>>(acc);
+    double h[192]; hipMemcpy(h, acc, sizeof(h), hipMemcpyDeviceToHost);
+    double w0 = 0, w1 = 0, w2 = 0;
+    for (int i = 0; i < 64; ++i) { w0 = fmax(w0, h[3 * i]); w1 = fmax(w1, h[3 * i + 1]); w2 = fmax(w2, h[3 * i + 2]); }
+    printf("v_rcp_f64 max rel err: seed %.3g, +1 Newton %.3g, +2 Newton %.3g\n", w0, w1, w2);
     return 0;
 }
