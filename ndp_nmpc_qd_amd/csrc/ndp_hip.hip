@@ -27,8 +27,22 @@ struct BatchPtrs {
     double *dbg;
 };
 
-template <int NSLOT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs bp, int B, int lds_per_wave)
+struct MlpArgs {            // fused downwash (null frag = not fused)
+    const float *frag;
+    const double *other;    // [B][N+1][10] neighbour windows
+    const double *ego_xy;   // [B][2] or null (gate always open)
+    float *force_out;       // [B][N+1][3] copy of the predicted force for callers
+    double r2;
+};
+
+__device__ __forceinline__ void mlp_tile(const float *__restrict__ fr, const float zb[3], int lane, float o[3]);
+__device__ __forceinline__ bool gate_open(const double *other_inst, const double *ego_xy_inst, double r2);
+
+// FUSED: the wave first predicts its own instance's disturbance force (gate + MLP over the N+1 <= 32 horizon rows,
+// one 32x32 f32 MFMA tile) and leaves it in the LDS staging slot the RTI program reads f from -- no second
+// launch and no trip of f through HBM.
+template <int NSLOT, int WAVES, bool FUSED>
+__global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs bp, int B, int lds_per_wave, MlpArgs ma)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = (int)(threadIdx.x >> 6);
@@ -47,7 +61,34 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
     io.status = bp.status + inst;
     io.iters = bp.iters + inst;
     io.dbg = bp.dbg;
+    io.f_in_lds = 0;
     WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lds_per_wave);
+    if (FUSED) {
+        const int lane = (int)(threadIdx.x & 63u), j = lane & 31, h = lane >> 5;
+        const int np1 = N + 1;
+        const double *oth = ma.other + inst * nx;
+        const bool open = ma.ego_xy ? gate_open(oth, ma.ego_xy + (size_t)inst * 2, ma.r2) : true;
+        const int jr = j < np1 ? j : np1 - 1;
+        float zb[3], o[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const size_t idx = (size_t)jr * NX + 2 * s + h;
+            zb[s] = (float)(oth[idx] - io.xr[idx]);       // downwash_nn.py:22-23
+        }
+        mlp_tile(ma.frag, zb, lane, o);
+        const LdsMap m = make_map(N);
+        if (j < np1 && h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = open ? o[c] : 0.0f;      // ndp_nmpc_leader_node.py:75-76
+                lds[m.TF + j * 3 + c] = (double)v;       // fp32 value promoted to fp64
+                ma.force_out[inst * nf + j * 3 + c] = v;
+            }
+        }
+        WaveGfx950::sync();
+        io.f = nullptr;
+        io.f_in_lds = 1;
+    }
     RtiWave<WaveGfx950, NSLOT>::run(P, io, lds);
 }
 
@@ -76,6 +117,86 @@ enum { FR_L1 = 0, FR_L2 = FR_L1 + 12 * 64, FR_L3 = FR_L2 + 128 * 64, FR_B1 = FR_
 
 __device__ __forceinline__ int f0(int r) { return (r & 3) + 8 * (r >> 2); }
 
+// The four layers for one 32-row tile held by one wave.  zb[s] = input feature 2s + (lane>>5) of row lane&31;
+// returns the three outputs of row lane&31 in o[] (both half-waves hold the full sums).
+__device__ __forceinline__ void mlp_tile(const float *__restrict__ fr, const float zb[3], int lane, float o[3])
+{
+    const int h = lane >> 5;
+    f16_t h1[4], h2[2], h3[4];
+    // Weight fragments are streamed in groups of 16 records (one per MFMA); group n+1 is requested before
+    // group n's MFMAs issue, so the L2 latency hides under 16 x 64 matrix-pipe cycles.  The scheduling
+    // barriers stop the compiler from hoisting every load to the top (which spills).
+    float wc[16], wn[16];
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) {
+        f16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = fr[FR_B1 + ot * 32 + f0(r) + 4 * h];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[FR_L1 + (ot * 3 + s) * 64 + lane], zb[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1[ot][r] = fmaxf(acc[r], 0.0f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wc[r] = fr[FR_L2 + r * 64 + lane];
+    // layers 2 and 3 as one stream of 16 groups: groups 0..7 = layer 2 (ot 0..1 x it 0..3), 8..15 = layer 3 (ot 0..3 x it 0..1)
+    f16_t acc;
+#pragma unroll
+    for (int gi = 0; gi < 16; ++gi) {
+        const bool l2 = gi < 8;
+        const int ot = l2 ? gi / 4 : (gi - 8) / 2, it = l2 ? gi % 4 : (gi - 8) % 2;
+        if (gi + 1 < 16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wn[r] = fr[FR_L2 + ((gi + 1) * 16 + r) * 64 + lane];   // FR_L3 follows FR_L2 contiguously
+        }
+        if (it == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fr[(l2 ? FR_B2 : FR_B3) + ot * 32 + f0(r) + 4 * h];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[r], l2 ? h1[it][r] : h2[it][r], acc, 0, 0, 0);
+        if (it == (l2 ? 3 : 1)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (l2) h2[ot][r] = fmaxf(acc[r], 0.0f);
+                else h3[ot][r] = fmaxf(acc[r], 0.0f);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wc[r] = wn[r];
+    }
+    // last layer (128 -> 3) on the VALU: each half-wave owns 64 of the 128 features of its row
+    o[0] = o[1] = o[2] = 0.0f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int feat = it * 32 + f0(r) + 4 * h;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = fmaf(fr[FR_W4 + c * 128 + feat], h3[it][r], o[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = o[c] + __shfl_xor(o[c], 32, 64) + fr[FR_B4 + c];
+}
+
+// gate of ndp_nmpc_leader_node.py:65-68: other.x[0] xy against ego ODOMETRY xy, strict '<'.  Individually rounded
+// mul/add (no FMA contraction): the reference evaluates this in Python doubles and must agree at the rim.
+__device__ __forceinline__ bool gate_open(const double *other_inst, const double *ego_xy_inst, double r2)
+{
+    const double dx = other_inst[0] - ego_xy_inst[0];
+    const double dy = other_inst[1] - ego_xy_inst[1];
+    return __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)) < r2;
+}
+
+// Standalone form (DownwashNN.update for arbitrary row counts): one 32-row tile per wave, no tile loop --
+// a loop would make every weight load loop-invariant and the compiler then tries to keep 17k weights in registers.
 __global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, const double *__restrict__ other,
                                                   const double *__restrict__ ego, const double *__restrict__ ego_xy,
                                                   float *__restrict__ fout, int rows, int np1, double r2)
@@ -83,91 +204,25 @@ __global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, 
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int ntiles = (rows + 31) / 32;
-    // one 32-row tile per wave, no tile loop: a loop makes every weight load loop-invariant and the
-    // compiler then tries to keep all 17k weights in registers
     const int tile = (int)blockIdx.x * 4 + wave;
-    if (tile < ntiles) {
-        const int row = tile * 32 + j;
-        const bool valid = row < rows;
-        const int rowc = valid ? row : rows - 1;
-        const int inst = rowc / np1;
-        // gate: ndp_nmpc_leader_node.py:65-68 (other.x[0] xy against ego ODOMETRY xy, strict <)
-        bool open = valid;
-        if (ego_xy) {
-            const double dx = other[(size_t)inst * np1 * NX] - ego_xy[inst * 2];
-            const double dy = other[(size_t)inst * np1 * NX + 1] - ego_xy[inst * 2 + 1];
-            // individually rounded mul/add (no FMA contraction): the reference evaluates this in Python doubles,
-            // and the strict '<' must agree with it at the rim
-            open = open && (__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)) < r2);
-        }
-        // downwash_nn.py:22-23: (other - ego)[:, 0:6] in fp64, cast to fp32
-        float zb[3];
+    if (tile >= ntiles) return;
+    const int row = tile * 32 + j;
+    const bool valid = row < rows;
+    const int rowc = valid ? row : rows - 1;
+    const int inst = rowc / np1;
+    bool open = valid;
+    if (ego_xy) open = open && gate_open(other + (size_t)inst * np1 * NX, ego_xy + inst * 2, r2);
+    // downwash_nn.py:22-23: (other - ego)[:, 0:6] in fp64, cast to fp32
+    float zb[3], o[3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const size_t idx = (size_t)rowc * NX + 2 * s + h;
-            zb[s] = (float)(other[idx] - ego[idx]);
-        }
-        f16_t h1[4], h2[2], h3[4];
+    for (int s = 0; s < 3; ++s) {
+        const size_t idx = (size_t)rowc * NX + 2 * s + h;
+        zb[s] = (float)(other[idx] - ego[idx]);
+    }
+    mlp_tile(fr, zb, lane, o);
+    if (valid && h == 0) {
 #pragma unroll
-        for (int ot = 0; ot < 4; ++ot) {
-            f16_t acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fr[FR_B1 + ot * 32 + f0(r) + 4 * h];
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[FR_L1 + (ot * 3 + s) * 64 + lane], zb[s], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h1[ot][r] = fmaxf(acc[r], 0.0f);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int ot = 0; ot < 2; ++ot) {
-            f16_t acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fr[FR_B2 + ot * 32 + f0(r) + 4 * h];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[FR_L2 + ((ot * 4 + it) * 16 + r) * 64 + lane], h1[it][r], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);   // keep at most one 16-record weight group in flight (register budget)
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h2[ot][r] = fmaxf(acc[r], 0.0f);
-        }
-#pragma unroll
-        for (int ot = 0; ot < 4; ++ot) {
-            f16_t acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fr[FR_B3 + ot * 32 + f0(r) + 4 * h];
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[FR_L3 + ((ot * 2 + it) * 16 + r) * 64 + lane], h2[it][r], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h3[ot][r] = fmaxf(acc[r], 0.0f);
-        }
-        // last layer (128 -> 3) on the VALU: each half-wave owns 64 of the 128 features of its row
-        float o[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int feat = it * 32 + f0(r) + 4 * h;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) o[c] = fmaf(fr[FR_W4 + c * 128 + feat], h3[it][r], o[c]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = o[c] + __shfl_xor(o[c], 32, 64) + fr[FR_B4 + c];
-        if (valid && h == 0) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) fout[(size_t)row * 3 + c] = open ? o[c] : 0.0f;   // :75-76 zeros when gated off
-        }
+        for (int c = 0; c < 3; ++c) fout[(size_t)row * 3 + c] = open ? o[c] : 0.0f;   // :75-76 zeros when gated off
     }
 }
 
@@ -329,8 +384,9 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     (void)hipMemsetAsync(h->dForce, 0, nfs(h) * 4, h->stream);
     // allow the big dynamic-LDS launches
     const int lds_bytes = (int)(per_wave_bytes * h->waves);
-    const void *fns[] = {(const void *)rti_kernel<3, 4>, (const void *)rti_kernel<3, 2>, (const void *)rti_kernel<3, 1>,
-                         (const void *)rti_kernel<5, 4>, (const void *)rti_kernel<5, 2>, (const void *)rti_kernel<5, 1>};
+    const void *fns[] = {(const void *)rti_kernel<3, 4, false>, (const void *)rti_kernel<3, 2, false>, (const void *)rti_kernel<3, 1, false>,
+                         (const void *)rti_kernel<5, 4, false>, (const void *)rti_kernel<5, 2, false>, (const void *)rti_kernel<5, 1, false>,
+                         (const void *)rti_kernel<3, 4, true>, (const void *)rti_kernel<3, 2, true>, (const void *)rti_kernel<3, 1, true>};
     for (const void *fn : fns)
         if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess)
             return fail("hipFuncSetAttribute", e);
@@ -386,22 +442,28 @@ static int launch_mlp(ndp_handle *h, const double *d_other, const double *d_ego,
 }
 
 static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, const double *d_ur, const float *d_f,
-                      double *d_u0, double *d_dbg, hipStream_t s)
+                      double *d_u0, double *d_dbg, hipStream_t s, const double *d_other = nullptr,
+                      const double *d_ego_xy = nullptr)
 {
     BatchPtrs bp{d_x0, d_xr, d_ur, d_f, h->dX, h->dU, d_u0, h->dStatus, h->dIters, d_dbg};
+    MlpArgs ma{d_other ? h->dFrag : nullptr, d_other, d_ego_xy, h->dForce, h->cfg.r_horiz * h->cfg.r_horiz};
     const int B = h->cfg.batch, W = h->waves;
     const dim3 grid((B + W - 1) / W), block(64 * W);
     const size_t shm = (size_t)h->lds_per_wave * sizeof(double) * W;
     const int ns = slots_for(h->cfg.N);
     int rc = begin_timing(h, s, 0);
     if (rc) return rc;
-#define LAUNCH(NS, WV) hipLaunchKernelGGL((rti_kernel<NS, WV>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave)
-    if (ns <= 3) { if (W == 4) LAUNCH(3, 4); else if (W == 2) LAUNCH(3, 2); else LAUNCH(3, 1); }
-    else         { if (W == 4) LAUNCH(5, 4); else if (W == 2) LAUNCH(5, 2); else LAUNCH(5, 1); }
+#define LAUNCH(NS, WV, FU) hipLaunchKernelGGL((rti_kernel<NS, WV, FU>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma)
+    if (d_other) { if (W == 4) LAUNCH(3, 4, true); else if (W == 2) LAUNCH(3, 2, true); else LAUNCH(3, 1, true); }
+    else if (ns <= 3) { if (W == 4) LAUNCH(3, 4, false); else if (W == 2) LAUNCH(3, 2, false); else LAUNCH(3, 1, false); }
+    else { if (W == 4) LAUNCH(5, 4, false); else if (W == 2) LAUNCH(5, 2, false); else LAUNCH(5, 1, false); }
 #undef LAUNCH
     NDP_HIP(h, hipGetLastError());
     return end_timing(h, s);
 }
+
+// downwash inside the RTI launch when one 32-row tile covers the horizon; otherwise mlp_kernel first
+static bool can_fuse(const ndp_handle *h) { return h->cfg.N + 1 <= 32 && slots_for(h->cfg.N) <= 3; }
 
 int ndp_reset_device(ndp_handle *h, const void *d_xr, const void *d_ur, void *stream)
 {
@@ -433,13 +495,17 @@ int ndp_step_device(ndp_handle *h, const void *d_x0, const void *d_xr, const voi
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     const float *force = (const float *)d_f;
+    if ((d_f || d_other) && !h->cfg.use_fd) { h->err = "ndp_step: a disturbance force needs use_fd = 1 (NDP model)"; return -8; }
     if (d_other) {
         if (d_f) { h->err = "ndp_step: pass either f or other, not both"; return -7; }
+        if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }
+        if (can_fuse(h))
+            return launch_rti(h, (const double *)d_x0, (const double *)d_xr, (const double *)d_ur, nullptr,
+                              (double *)d_u0, nullptr, s, (const double *)d_other, (const double *)d_ego_xy);
         int rc = launch_mlp(h, (const double *)d_other, (const double *)d_xr, (const double *)d_ego_xy, h->dForce, s);
         if (rc) return rc;
         force = h->dForce;
     }
-    if (force && !h->cfg.use_fd) { h->err = "ndp_step: a disturbance force needs use_fd = 1 (NDP model)"; return -8; }
     return launch_rti(h, (const double *)d_x0, (const double *)d_xr, (const double *)d_ur, force, (double *)d_u0,
                       nullptr, s);
 }
@@ -469,14 +535,22 @@ static int step_host(ndp_handle *h, const double *x0, const double *xr, const do
     if (other) NDP_HIP(h, hipMemcpyAsync(h->sother, other, nxs(h) * 8, hipMemcpyHostToDevice, s));
     if (ego_xy) NDP_HIP(h, hipMemcpyAsync(h->sego, ego_xy, B * 2 * 8, hipMemcpyHostToDevice, s));
     const float *force = f ? h->sf : nullptr;
+    if ((f || other) && !h->cfg.use_fd) { h->err = "ndp_step: a disturbance force needs use_fd = 1 (NDP model)"; return -8; }
+    int rc = 0;
     if (other) {
         if (f) { h->err = "ndp_step: pass either f or other, not both"; return -7; }
-        int rc = launch_mlp(h, h->sother, h->sxr, ego_xy ? h->sego : nullptr, h->dForce, s);
-        if (rc) return rc;
-        force = h->dForce;
+        if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }
+        if (can_fuse(h)) {
+            rc = launch_rti(h, h->sx0, h->sxr, h->sur, nullptr, h->su0, dump ? h->sdbg : nullptr, s, h->sother,
+                            ego_xy ? h->sego : nullptr);
+        } else {
+            rc = launch_mlp(h, h->sother, h->sxr, ego_xy ? h->sego : nullptr, h->dForce, s);
+            if (rc) return rc;
+            rc = launch_rti(h, h->sx0, h->sxr, h->sur, h->dForce, h->su0, dump ? h->sdbg : nullptr, s);
+        }
+    } else {
+        rc = launch_rti(h, h->sx0, h->sxr, h->sur, force, h->su0, dump ? h->sdbg : nullptr, s);
     }
-    if (force && !h->cfg.use_fd) { h->err = "ndp_step: a disturbance force needs use_fd = 1 (NDP model)"; return -8; }
-    int rc = launch_rti(h, h->sx0, h->sxr, h->sur, force, h->su0, dump ? h->sdbg : nullptr, s);
     if (rc) return rc;
     NDP_HIP(h, hipMemcpyAsync(u0, h->su0, B * NU * 8, hipMemcpyDeviceToHost, s));
     if (dump) NDP_HIP(h, hipMemcpyAsync(dump, h->sdbg, (size_t)lds_doubles(h->cfg.N) * 8, hipMemcpyDeviceToHost, s));

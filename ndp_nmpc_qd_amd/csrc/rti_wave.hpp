@@ -58,6 +58,7 @@ struct RtiIo {            // global-memory views of ONE instance
     double *u0;           // [4]
     int *status, *iters;  // per-instance
     double *dbg;          // optional dump area (tests), or null
+    int f_in_lds;         // 1: the caller already left f (as doubles) in the LDS staging slot TF (fused downwash)
 };
 
 struct LdsMap {
@@ -210,7 +211,7 @@ struct RtiWave {
         const int N = P.N;
         vi lane = W::lane();
         const int nx = (N + 1) * NX, nu = N * NU, nf = (N + 1) * 3;
-        const bool have_f = P.use_fd && io.f;
+        const bool have_f = P.use_fd && io.f && !io.f_in_lds;
         for (int t = 0; t < RX; ++t) {
             vi i = lane + 64 * t;
             b.xr[t] = W::gld(io.xr, i, i < nx);
@@ -766,15 +767,21 @@ struct RtiWave {
         int status = 0, iters = 0;
         // global loads first; the index tables (pure VALU) are built while they are in flight
         vd x0v = W::gld(io.x0, lane, lane < NX);
+        // fused downwash: f sits in the staging slot already; the slot is recycled by the sweep, so keep a register copy
+        vd fkeep[RF];
+        for (int t = 0; t < RF; ++t) {
+            vi i = lane + 64 * t;
+            fkeep[t] = io.f_in_lds ? W::ldp(lds, i + m.TF, i < (N + 1) * 3) : vd(0.0);
+        }
         InBuf inb;
         issue_inputs(P, io, inb, true);
         Tables T;
         build_tables(m, T);
-        Slots S;
-        build_slots(P, m, S);
         stamp(io, m, 1);
         for (int it = 0; it < P.n_rti; ++it) {
             if (it > 0) issue_inputs(P, io, inb, false);
+            if (io.f_in_lds)
+                for (int t = 0; t < RF; ++t) inb.f[t] = fkeep[t];
             commit_inputs(P, m, inb, lds, it == 0);
             stamp(io, m, 2);
             build_cost(P, m, lds);
@@ -783,7 +790,6 @@ struct RtiWave {
             stamp(io, m, 4);
             // solve_for_x0: dx_0 = x0 - x_0  (nmpc_body_rate_ctl.py:107)
             W::stp(lds, lane + m.ZX, x0v - W::ldp(lds, lane + m.XI, lane < NX), lane < NX);
-            load_bounds(m, S, lds);
             W::sync();
             if (io.dbg && it == 0) {   // test hook: dump the linearisation + cost blocks
                 for (int t = 0; t < m.KT; t += 64) {
@@ -799,6 +805,11 @@ struct RtiWave {
                 bool ok = riccati_sweep(P, m, T, lds, &io);
                 stamp(io, m, 7);
                 if (!ok) st = 4;
+                // the constraint slots are built only now: keeping ~90 more registers live across the sweep
+                // forces the MFMA accumulators into AGPRs with copies on every dependency
+                Slots S;
+                build_slots(P, m, S);
+                load_bounds(m, S, lds);
                 done = strictly_inside(S, lds) || !ok;
                 if (done) {
                     for (int t = 0; t < nzx + nzu; t += 64) {
@@ -809,7 +820,12 @@ struct RtiWave {
                     W::sync();
                 }
             }
-            if (!done) st = ipm(P, m, T, S, lds, iters);
+            if (!done) {
+                Slots S;
+                build_slots(P, m, S);
+                load_bounds(m, S, lds);
+                st = ipm(P, m, T, S, lds, iters);
+            }
             if (st && !status) status = st;
             // full step, no line search; XI|UI and CX|CU are laid out alike
             for (int t = 0; t < nzx + nzu; t += 64) {
