@@ -8,7 +8,7 @@
 Workload (BASELINE.json metric / configs[2]): per GPU batch = 1024 independent quadrotor OCPs, N = 20,
 1 SQP-RTI iteration per step + the downwash MLP (NDP controller), inputs resident in HBM.
 A "step" is one control tick of the whole batch: [all-gather of neighbour windows when N > 1] ->
-mlp_kernel (gate + MLP) -> rti_kernel (linearise, QP, full step).  Weak scaling: the per-GPU batch is fixed.
+rti_kernel (gate + MLP fused in front of linearise, QP, full step).  Weak scaling: the per-GPU batch is fixed.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -38,6 +38,18 @@ def algorithmic_bytes_per_solve(N, downwash):
     if downwash:
         b += 8 * 10 * (N + 1) + 16
     return b
+
+
+def measured_traffic(B, N, fused):
+    """HBM bytes per rti_kernel launch from the committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE runs
+    of this same command; KB units; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  None if the
+    profiled configuration differs from the one being run."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_rti_kernel_fused_b1024.json")
+    if not (fused and B == 1024 and N == 20 and os.path.exists(path)):
+        return None
+    with open(path) as fh:
+        pmc = json.load(fh)
+    return (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
 
 
 def main():
@@ -152,25 +164,32 @@ def main():
         f_qp, f_mlp = algorithmic_flops_per_solve(N, sweeps, downwash)
         rti_s = rti_ms * 1e-3 / max(rti_n, 1)
         mlp_s = mlp_ms * 1e-3 / max(mlp_n, 1) if mlp_n else 0.0
+        fused = downwash and mlp_n == 0          # gate + MLP run inside rti_kernel (one launch per step)
         ach_tf = f_qp * B / rti_s / 1e12
         abytes = algorithmic_bytes_per_solve(N, downwash)
+        # matrix-pipe occupancy estimate: every v_mfma_f64_16x16x4 / v_mfma_f32_32x32x2 holds the SIMD's pipe 64 cycles
+        # (measured, scripts/ubench); one instance per SIMD: 13 f64 MFMAs per stage and sweep (+3 per 4 stages), 268 f32 for the MLP tile
+        n_mfma = sweeps * (13 * N + 3 * (N // 4)) + (268 if fused else 0)
         out = {
             "metric": "NMPC solves/sec (N=20, 1 RTI iter + downwash MLP) at batch",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"batch={B}/GPU independent quadrotors, N={N}, 1 RTI iter, "
-                                   + ("MLP downwash on (NDP controller)" if downwash else "no downwash (NMPC controller)")
+                                   + ("MLP downwash on (NDP controller, gate+MLP fused into the RTI launch)" if fused else
+                                      "MLP downwash on (NDP controller)" if downwash else "no downwash (NMPC controller)")
                                    + (", neighbour windows all-gathered over RCCL" if world > 1 else ""),
                        "batch_per_gpu": B, "horizon": N, "n_rti": 1, "qp_mode": "auto" if args.qp_mode == 0 else "ipm_always",
                        "parallelism": f"instances sharded x{world}"},
             "roofline": {"kernel": "rti_kernel", "bound": "mfma", "achieved": ach_tf, "peak": F64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach_tf / F64_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel_us": rti_s * 1e6, "flops_per_solve": f_qp, "riccati_sweeps_per_solve": sweeps,
+                         "unit": "TFLOP/s", "frac": ach_tf / F64_MFMA_PEAK_TFLOPS, "traffic": measured_traffic(B, N, fused),
+                         "traffic_note": "HBM bytes per launch, PMC (profiles/r01_pmc_rti_kernel_fused_b1024.json); algorithmic bytes per launch = %d" % (abytes * B),
+                         "kernel_us": rti_s * 1e6, "flops_per_solve_f64": f_qp, "riccati_sweeps_per_solve": sweeps,
+                         "fused_mlp_flops_per_solve_f32": f_mlp if fused else 0.0,
+                         "mfma_pipe_busy_est": n_mfma * 64 / (rti_s * 2.4e9),
                          "hbm_algorithmic_GBps": abytes * B / (rti_s + mlp_s) / 1e9,
                          "hbm_frac": abytes * B / (rti_s + mlp_s) / 1e9 / HBM_PEAK_GBS,
-                         "mlp_kernel_us": mlp_s * 1e6,
-                         "mlp_achieved_TFLOPs": (f_mlp * B / mlp_s / 1e12) if mlp_s else None},
+                         "mlp_kernel_us": mlp_s * 1e6 if mlp_n else None},
             "parity_max_rel_vs_oracle": parity, "instances_not_converged": bad,
         }
         if not args.no_cpu_baseline and world == 1:

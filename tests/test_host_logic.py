@@ -1,0 +1,189 @@
+"""CPU tests of the host side: C-ABI exports, config constants, the `.solver` facade, synthetic inputs,
+and the multi-process neighbour exchange (gloo, world_size 2).  No compute call needs a GPU here."""
+import ctypes as C
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+from ndp_nmpc_qd_amd import _lib, synth
+from ndp_nmpc_qd_amd.params import downwash_params as DP
+from ndp_nmpc_qd_amd.params import nmpc_params as CP
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ndp_nmpc.h")).read()
+    declared = set(re.findall(r"\b(ndp_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = _lib.load()
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert declared == set(_lib.EXPORTS)
+
+
+def test_default_cfg_carries_the_reference_constants():
+    cfg = _lib.default_cfg()
+    assert (cfg.N, cfg.n_rti, cfg.use_fd, cfg.iter_max) == (CP.N_node, 1, 0, 50)
+    assert cfg.dt == CP.th_pred == 0.1 and cfg.mass == CP.mass == 1.4844 and cfg.gravity == 9.81
+    assert cfg.r_horiz == DP.r_horiz
+    assert list(cfg.Qd) == [CP.Qp_xy, CP.Qp_xy, CP.Qp_z, CP.Qv_xy, CP.Qv_xy, CP.Qv_z, 0, CP.Qq_xy, CP.Qq_xy, CP.Qq_z]
+    assert list(cfg.Rd) == [CP.Rw, CP.Rw, CP.Rw, CP.Rc]
+    assert list(cfg.lbu) == [CP.w_min] * 3 + [CP.c_min] and list(cfg.ubu) == [CP.w_max] * 3 + [CP.c_max]
+    assert list(cfg.lbv) == [CP.v_min] * 3 and list(cfg.ubv) == [CP.v_max] * 3
+    assert CP.c_max == 9.81 / 0.36
+    assert C.sizeof(_lib.NdpCfg) == 8 * 4 + 8 * (4 + 10 + 4 + 4 + 4 + 3 + 3 + 4)
+    # horizon indexing of the reference generator (nmpc_params.py:40-43): 21 states / 20 controls out of 101
+    assert CP.long_list_size == 101 and list(range(101))[CP.xr_list_index] == list(range(0, 101, 5))
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a machine without a GPU")
+def test_no_cpu_fallback():
+    import ndp_nmpc_qd_amd as ndp
+    with pytest.raises(ndp.NdpError, match="no usable HIP device"):
+        ndp.BatchedNMPC(4)
+    from ndp_nmpc_qd_amd.nmpc_ctl import NMPCBodyRateController
+    with pytest.raises(ndp.NdpError):
+        NMPCBodyRateController()
+
+
+def test_weights_blob():
+    w = _lib.load_weights()
+    assert w.dtype == np.float32 and w.size == 17859
+    assert abs(np.linalg.norm(w[:768].reshape(128, 6), 2) - 4.0) < 1e-3   # spectral norm of layer 1 (SN=4 model)
+
+
+class _FakeEngine:
+    """Records what the facade sends to the device engine."""
+    def __init__(self, N=20):
+        self.N, self.calls = N, []
+        self.X, self.U = np.zeros((1, N + 1, 10)), np.zeros((1, N, 4))
+
+    def get_iterate(self):
+        return self.X.copy(), self.U.copy()
+
+    def set_iterate(self, X, U):
+        self.calls.append(("set_iterate",))
+        self.X, self.U = X.copy(), U.copy()
+
+    def update(self, x0, xr, ur, f=None, raise_on_status=True):
+        self.calls.append(("update", x0.copy(), xr.copy(), ur.copy(), None if f is None else f.copy()))
+        self.X = self.X + 1.0
+        return np.array([[1.0, 2.0, 3.0, 4.0]])
+
+    def status(self):
+        return np.array([0], dtype=np.int32), np.array([0], dtype=np.int32)
+
+
+def test_solver_facade_marshals_like_acados_template():
+    """reset / update of the reference classes expressed through solver.set / solve_for_x0 (nmpc_body_rate_ctl.py:86-112)."""
+    from ndp_nmpc_qd_amd.ndp_nmpc_ctl.ndp_nmpc_body_rate_ctl import NDPNMPCBodyRateController
+    from ndp_nmpc_qd_amd.solver_facade import SolverFacade
+    b = synth.make_batch(1, seed=1)
+    xr, ur, x0 = b["xr"][0], b["ur"][0], b["x0"][0]
+    f = np.random.default_rng(0).normal(size=(21, 3)).astype(np.float32)
+    ctl = NDPNMPCBodyRateController.__new__(NDPNMPCBodyRateController)
+    ctl._engine = _FakeEngine()
+    ctl.solver = SolverFacade(ctl._engine, disturbance=True)
+    ctl.reset(xr, ur)
+    u0 = ctl.update(x0, xr, ur, f)
+    assert np.array_equal(u0, [1.0, 2.0, 3.0, 4.0])
+    kinds = [c[0] for c in ctl._engine.calls]
+    assert kinds == ["set_iterate", "update"]                      # reset is pushed lazily, right before the solve
+    _, x0s, xrs, urs, fs = ctl._engine.calls[1]
+    assert np.array_equal(x0s[0], x0) and np.array_equal(xrs[0], xr) and np.array_equal(urs[0], ur)
+    assert fs.dtype == np.float32 and np.array_equal(fs[0], f)
+    np.testing.assert_array_equal(ctl.solver.get(3, "x"), xr[3] + 1.0)   # iterate mirrored back after the solve
+    g = ctl.solver.get(3, "x")
+    g[:] = 0
+    assert ctl.solver.get(3, "x")[0] != 0                                  # get() returns a copy (nmpc_node.py:237-238)
+    assert ctl.solver.N == 20 and ctl.solver.status == 0
+    with pytest.raises(Exception):
+        ctl.solver.set(0, "p", np.zeros(4))                                # NDP model has 7 parameters
+    ctl.solver.set(2, "p", np.concatenate([xr[2, 6:10] + 1e-3, f[2]]))
+    with pytest.raises(Exception, match="p\\[0:4\\] == yref\\[6:10\\]"):
+        ctl.solver.solve_for_x0(x0)
+
+
+def test_synthetic_references_are_consistent():
+    b = synth.make_batch(5, seed=3, downwash=True)
+    xr, ur = b["xr"], b["ur"]
+    assert xr.shape == (5, 21, 10) and ur.shape == (5, 20, 4) and b["other"].shape == (5, 21, 10)
+    np.testing.assert_allclose(np.linalg.norm(xr[..., 6:10], axis=-1), 1.0, atol=1e-12)
+    assert (xr[..., 6] > 0).all()                                          # "ROS convention, w > 0" (pt_publisher.py:236)
+    # collective acceleration = |a + g e3| (pt_publisher.py:195-201,145) and thrust direction matches the quaternion
+    q, c = xr[:, :20, 6:10], ur[..., 3]
+    qw, qx, qy, qz = (q[..., i] for i in range(4))
+    _, _, acc, _ = synth.figure_eight(b["omega"][:, None], b["phi"][:, None], 0.1 * np.arange(20)[None, :])
+    thrust = np.stack([2 * (qx * qz + qw * qy) * c, 2 * (qy * qz - qw * qx) * c, (1 - 2 * qx ** 2 - 2 * qy ** 2) * c - 9.81], -1)
+    np.testing.assert_allclose(thrust, acc, atol=1e-12)
+    xh, uh = synth.hover_reference(quirk_b1=True)
+    assert uh[0, 3] == CP.mass * CP.gravity
+
+
+# ------------------------------------------------------------------------------------------- multi-process (gloo)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from ndp_nmpc_qd_amd import dist as ndist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, N = 6, 20
+        shard = ndist.make_formation_shard(B, rank, world, N=N)
+        xr = torch.from_numpy(shard["xr"])
+        other, gathered = ndist.exchange_neighbours(xr)
+        ok = np.array_equal(other.numpy(), shard["other"])                  # what the exchange delivers is the neighbour's window
+        ok = ok and np.array_equal(gathered[rank].numpy(), shard["xr"])
+        other2, g2 = ndist.exchange_neighbours(xr, gathered)                # steady state: reuse the gather buffer
+        ok = ok and g2.data_ptr() == gathered.data_ptr() and np.array_equal(other2.numpy(), shard["other"])
+        # the gate statistic of the synthetic formation: a sensible fraction of neighbours inside r_horiz
+        d2 = ((shard["other"][:, 0, 0:2] - shard["ego_xy"]) ** 2).sum(axis=1)
+        q.put((rank, bool(ok), float((d2 < 1.0).mean())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_neighbour_exchange_world_size_2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == [0, 1] and all(r[1] for r in res)
+
+
+def test_formation_shards_are_mutually_consistent():
+    from ndp_nmpc_qd_amd import dist as ndist
+    W, B = 4, 16
+    shards = [ndist.make_formation_shard(B, r, W) for r in range(W)]
+    for r in range(W):
+        assert np.array_equal(shards[r]["other"], shards[ndist.neighbour_rank(r, W)]["xr"])
+        assert np.array_equal(shards[r]["ego_xy"], shards[r]["x0"][:, 0:2])
+    frac = np.mean([((s["other"][:, 0, 0:2] - s["ego_xy"]) ** 2).sum(axis=1) < 1.0 for s in shards])
+    assert 0.1 < frac < 0.9
