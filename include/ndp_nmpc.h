@@ -129,7 +129,7 @@ int ndp_debug_lds_doubles(int N);
  * d[0..255] = result registers [4][64], d[256..319] = a cross-lane checksum (readlane + wave reductions). */
 int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, double *d);
 int ndp_step_debug(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
-                   double *u0, double *lds_dump);
+                   const double *other, const double *ego_xy, double *u0, double *lds_dump);
 
 #ifdef __cplusplus
 }

@@ -78,7 +78,7 @@ def load():
     lib.ndp_timing_enable.argtypes = [vp, C.c_int]
     lib.ndp_timing_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.ndp_debug_lds_doubles.argtypes = [C.c_int]
-    lib.ndp_step_debug.argtypes = [vp] * 7
+    lib.ndp_step_debug.argtypes = [vp] * 9
     lib.ndp_debug_mfma_probe.argtypes = [vp] * 4
     _lib = lib
     return lib

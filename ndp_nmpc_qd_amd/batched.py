@@ -86,14 +86,16 @@ class BatchedNMPC:
             raise Exception("acados acados_ocp_solver returned status {}. Exiting.".format(rc))
         return u0
 
-    def update_debug(self, x0, xr, ur, f=None):
+    def update_debug(self, x0, xr, ur, f=None, other=None, ego_xy=None):
         """B = 1 only: one step that also returns the kernel's LDS image after linearisation (tests)."""
         x0, xr, ur = _lib.f64(x0, (1, 10)), _lib.f64(xr, (1, self.N + 1, 10)), _lib.f64(ur, (1, self.N, 4))
         f32 = None if f is None else np.ascontiguousarray(f, dtype=np.float32).reshape(1, self.N + 1, 3)
+        other, ego_xy = _lib.f64(other, (1, self.N + 1, 10)), _lib.f64(ego_xy, (1, 2))
         u0 = np.empty((1, 4))
         dump = np.zeros(self._lib.ndp_debug_lds_doubles(self.N))
         self._check(self._lib.ndp_step_debug(self._h, _lib.ptr(x0), _lib.ptr(xr), _lib.ptr(ur), _lib.ptr(f32),
-                                             _lib.ptr(u0), _lib.ptr(dump)), "ndp_step_debug")
+                                             _lib.ptr(other), _lib.ptr(ego_xy), _lib.ptr(u0), _lib.ptr(dump)),
+                    "ndp_step_debug")
         return u0, dump
 
     def downwash(self, other, ego_ref, ego_xy=None):

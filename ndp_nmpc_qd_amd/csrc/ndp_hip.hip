@@ -35,7 +35,10 @@ struct MlpArgs {            // fused downwash (null frag = not fused)
     double r2;
 };
 
-__device__ __forceinline__ void mlp_tile(const float *__restrict__ fr, const float zb[3], int lane, float o[3]);
+typedef __attribute__((address_space(3))) float *lds_f32;
+typedef const __attribute__((address_space(3))) float *lds_cf32;
+__device__ __forceinline__ void stage_fragments(const float *__restrict__ fr, lds_f32 dst, int tid, int nthreads);
+__device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lane, float o[3]);
 __device__ __forceinline__ bool gate_open(const double *other_inst, const double *ego_xy_inst, double r2);
 
 // FUSED: the wave first predicts its own instance's disturbance force (gate + MLP over the N+1 <= 32 horizon rows,
@@ -46,8 +49,10 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = (int)(threadIdx.x >> 6);
-    const int inst = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave);
-    if (inst >= B) return;
+    const int inst_raw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave);
+    const bool active = inst_raw < B;
+    if (!FUSED && !active) return;
+    const int inst = active ? inst_raw : B - 1;   // fused: idle waves of the last workgroup still take part in the barriers
     const int N = P.N;
     const size_t nx = (size_t)(N + 1) * NX, nu = (size_t)N * NU, nf = (size_t)(N + 1) * 3;
     RtiIo io;
@@ -63,6 +68,10 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
     io.dbg = bp.dbg;
     io.f_in_lds = 0;
     WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lds_per_wave);
+    using Prog = RtiWave<WaveGfx950, NSLOT>;
+    typename Prog::InBuf inb;
+    double x0v;
+    Prog::issue_first(P, io, inb, x0v);      // every global input of the RTI step is now in flight (hidden under the MLP when fused)
     if (FUSED) {
         const int lane = (int)(threadIdx.x & 63u), j = lane & 31, h = lane >> 5;
         const int np1 = N + 1;
@@ -75,8 +84,16 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
             const size_t idx = (size_t)jr * NX + 2 * s + h;
             zb[s] = (float)(oth[idx] - io.xr[idx]);       // downwash_nn.py:22-23
         }
-        mlp_tile(ma.frag, zb, lane, o);
         const LdsMap m = make_map(N);
+        if (io.dbg && lane == 0) io.dbg[m.KT + 9] = (double)__builtin_amdgcn_s_memtime();
+        // the whole workgroup's LDS is still unused: park the weight fragments there for the MLP phase
+        lds_f32 wl = (lds_f32)smem;
+        stage_fragments(ma.frag, wl, (int)threadIdx.x, 64 * WAVES);
+        __syncthreads();
+        mlp_tile(wl, zb, lane, o);
+        __syncthreads();                              // every wave is done with the weights before LDS becomes RTI state
+        if (!active) return;
+        if (io.dbg && lane == 0) io.dbg[m.KT + 10] = (double)__builtin_amdgcn_s_memtime();
         if (j < np1 && h == 0) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -89,7 +106,7 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
         io.f = nullptr;
         io.f_in_lds = 1;
     }
-    RtiWave<WaveGfx950, NSLOT>::run(P, io, lds);
+    Prog::run(P, io, lds, inb, x0v);
 }
 
 // test hook: one v_mfma_f64_16x16x4_f64 with caller-chosen per-lane operands (pins the register maps)
@@ -113,30 +130,46 @@ __global__ void mfma_probe_kernel(const double *a, const double *b, const double
 typedef float f16_t __attribute__((ext_vector_type(16)));
 
 enum { FR_L1 = 0, FR_L2 = FR_L1 + 12 * 64, FR_L3 = FR_L2 + 128 * 64, FR_B1 = FR_L3 + 128 * 64,
-       FR_B2 = FR_B1 + 128, FR_B3 = FR_B2 + 64, FR_W4 = FR_B3 + 128, FR_B4 = FR_W4 + 3 * 128, FR_TOTAL = FR_B4 + 4 };
+       FR_B2 = FR_B1 + 128, FR_B3 = FR_B2 + 64, FR_W4 = FR_B3 + 128 /* [128 features][4]: w0 w1 w2 0 */, FR_B4 = FR_W4 + 4 * 128, FR_TOTAL = FR_B4 + 4 };
 
 __device__ __forceinline__ int f0(int r) { return (r & 3) + 8 * (r >> 2); }
 
 // The four layers for one 32-row tile held by one wave.  zb[s] = input feature 2s + (lane>>5) of row lane&31;
 // returns the three outputs of row lane&31 in o[] (both half-waves hold the full sums).
-__device__ __forceinline__ void mlp_tile(const float *__restrict__ fr, const float zb[3], int lane, float o[3])
+
+// All threads of the workgroup copy the fragment blob (FR_TOTAL floats = 70.3 KB, L2-resident) into LDS with 16-byte
+// accesses.  Streaming it per wave straight from L2 made 1024 waves fetch the same lines in lockstep (channel
+// hot-spotting: the MLP tile took 33k cycles at B = 1024 against 25k alone and a 17k matrix-pipe floor).
+__device__ __forceinline__ void stage_fragments(const float *__restrict__ fr, lds_f32 dst, int tid, int nthreads)
 {
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const f4_t *src = reinterpret_cast<const f4_t *>(fr);
+    __attribute__((address_space(3))) f4_t *d4 = (__attribute__((address_space(3))) f4_t *)dst;
+    for (int i = tid; i < FR_TOTAL / 4; i += nthreads) d4[i] = src[i];
+}
+
+__device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lane, float o[3])
+{
+    typedef float f4_t __attribute__((ext_vector_type(4)));
     const int h = lane >> 5;
     f16_t h1[4], h2[2], h3[4];
     // Weight fragments are streamed in groups of 16 records (one per MFMA); group n+1 is requested before
-    // group n's MFMAs issue, so the L2 latency hides under 16 x 64 matrix-pipe cycles.  The scheduling
-    // barriers stop the compiler from hoisting every load to the top (which spills).
-    float wc[16], wn[16];
+    // group n's MFMAs issue, so the L2 latency hides under 16 x 64 matrix-pipe cycles.  Biases are requested
+    // with the group and ADDED after its MFMAs (an accumulator initialised with them would expose their
+    // latency once per output tile).  Scheduling barriers stop the compiler from hoisting every load (spills).
+    float wc[16], wn[16], bc[16];
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bc[r] = fr[FR_B1 + ot * 32 + f0(r) + 4 * h];
         f16_t acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = fr[FR_B1 + ot * 32 + f0(r) + 4 * h];
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
         for (int s = 0; s < 3; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[FR_L1 + (ot * 3 + s) * 64 + lane], zb[s], acc, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h1[ot][r] = fmaxf(acc[r], 0.0f);
+        for (int r = 0; r < 16; ++r) h1[ot][r] = fmaxf(acc[r] + bc[r], 0.0f);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -153,7 +186,10 @@ __device__ __forceinline__ void mlp_tile(const float *__restrict__ fr, const flo
         }
         if (it == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fr[(l2 ? FR_B2 : FR_B3) + ot * 32 + f0(r) + 4 * h];
+            for (int r = 0; r < 16; ++r) {
+                bc[r] = fr[(l2 ? FR_B2 : FR_B3) + ot * 32 + f0(r) + 4 * h];
+                acc[r] = 0.0f;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -162,25 +198,36 @@ __device__ __forceinline__ void mlp_tile(const float *__restrict__ fr, const flo
         if (it == (l2 ? 3 : 1)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (l2) h2[ot][r] = fmaxf(acc[r], 0.0f);
-                else h3[ot][r] = fmaxf(acc[r], 0.0f);
+                if (l2) h2[ot][r] = fmaxf(acc[r] + bc[r], 0.0f);
+                else h3[ot][r] = fmaxf(acc[r] + bc[r], 0.0f);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) wc[r] = wn[r];
     }
-    // last layer (128 -> 3) on the VALU: each half-wave owns 64 of the 128 features of its row
+    // last layer (128 -> 3) on the VALU: each half-wave owns 64 of the 128 features of its row; weights come as one
+    // 16-byte record per feature, the records of the next 16 features requested before the current ones are used
+    const __attribute__((address_space(3))) f4_t *w4 = (const __attribute__((address_space(3))) f4_t *)(fr + FR_W4);
+    f4_t qc[16], qn[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) qc[r] = w4[f0(r) + 4 * h];
     o[0] = o[1] = o[2] = 0.0f;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
+        if (it + 1 < 4) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int feat = it * 32 + f0(r) + 4 * h;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) o[c] = fmaf(fr[FR_W4 + c * 128 + feat], h3[it][r], o[c]);
+            for (int r = 0; r < 16; ++r) qn[r] = w4[(it + 1) * 32 + f0(r) + 4 * h];
         }
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = fmaf(qc[r][c], h3[it][r], o[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) qc[r] = qn[r];
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = o[c] + __shfl_xor(o[c], 32, 64) + fr[FR_B4 + c];
@@ -201,10 +248,14 @@ __global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, 
                                                   const double *__restrict__ ego, const double *__restrict__ ego_xy,
                                                   float *__restrict__ fout, int rows, int np1, double r2)
 {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int ntiles = (rows + 31) / 32;
     const int tile = (int)blockIdx.x * 4 + wave;
+    lds_f32 wl = (lds_f32)wsm;
+    stage_fragments(fr, wl, (int)threadIdx.x, 256);
+    __syncthreads();
     if (tile >= ntiles) return;
     const int row = tile * 32 + j;
     const bool valid = row < rows;
@@ -219,7 +270,7 @@ __global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, 
         const size_t idx = (size_t)rowc * NX + 2 * s + h;
         zb[s] = (float)(other[idx] - ego[idx]);
     }
-    mlp_tile(fr, zb, lane, o);
+    mlp_tile(wl, zb, lane, o);
     if (valid && h == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) fout[(size_t)row * 3 + c] = open ? o[c] : 0.0f;   // :75-76 zeros when gated off
@@ -249,7 +300,8 @@ static void make_fragments(const float *blob, std::vector<float> &fr)
     for (int i = 0; i < 128; ++i) fr[FR_B1 + i] = b1[i];
     for (int i = 0; i < 64; ++i) fr[FR_B2 + i] = b2[i];
     for (int i = 0; i < 128; ++i) fr[FR_B3 + i] = b3[i];
-    for (int i = 0; i < 3 * 128; ++i) fr[FR_W4 + i] = W4[i];
+    for (int f = 0; f < 128; ++f)
+        for (int c = 0; c < 3; ++c) fr[FR_W4 + f * 4 + c] = W4[c * 128 + f];
     for (int i = 0; i < 3; ++i) fr[FR_B4 + i] = b4[i];
 }
 
@@ -387,6 +439,9 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     const void *fns[] = {(const void *)rti_kernel<3, 4, false>, (const void *)rti_kernel<3, 2, false>, (const void *)rti_kernel<3, 1, false>,
                          (const void *)rti_kernel<5, 4, false>, (const void *)rti_kernel<5, 2, false>, (const void *)rti_kernel<5, 1, false>,
                          (const void *)rti_kernel<3, 4, true>, (const void *)rti_kernel<3, 2, true>, (const void *)rti_kernel<3, 1, true>};
+    if ((e = hipFuncSetAttribute((const void *)mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(FR_TOTAL * sizeof(float)))) != hipSuccess)
+        return fail("hipFuncSetAttribute(mlp_kernel)", e);
     for (const void *fn : fns)
         if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess)
             return fail("hipFuncSetAttribute", e);
@@ -435,7 +490,7 @@ static int launch_mlp(ndp_handle *h, const double *d_other, const double *d_ego,
     const int grid = (ntiles + 3) / 4;
     int rc = begin_timing(h, s, 1);
     if (rc) return rc;
-    hipLaunchKernelGGL(mlp_kernel, dim3(grid), dim3(256), 0, s, (const float *)h->dFrag, d_other, d_ego, d_ego_xy, d_f,
+    hipLaunchKernelGGL(mlp_kernel, dim3(grid), dim3(256), FR_TOTAL * sizeof(float), s, (const float *)h->dFrag, d_other, d_ego, d_ego_xy, d_f,
                        rows, np1, h->cfg.r_horiz * h->cfg.r_horiz);
     NDP_HIP(h, hipGetLastError());
     return end_timing(h, s);
@@ -463,7 +518,11 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
 }
 
 // downwash inside the RTI launch when one 32-row tile covers the horizon; otherwise mlp_kernel first
-static bool can_fuse(const ndp_handle *h) { return h->cfg.N + 1 <= 32 && slots_for(h->cfg.N) <= 3; }
+static bool can_fuse(const ndp_handle *h)
+{
+    return h->cfg.N + 1 <= 32 && slots_for(h->cfg.N) <= 3 &&
+           (size_t)h->lds_per_wave * sizeof(double) * h->waves >= FR_TOTAL * sizeof(float);
+}
 
 int ndp_reset_device(ndp_handle *h, const void *d_xr, const void *d_ur, void *stream)
 {
@@ -567,10 +626,10 @@ int ndp_step(ndp_handle *h, const double *x0, const double *xr, const double *ur
 }
 
 int ndp_step_debug(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
-                   double *u0, double *lds_dump)
+                   const double *other, const double *ego_xy, double *u0, double *lds_dump)
 {
     if (h && h->cfg.batch != 1) { h->err = "ndp_step_debug: batch must be 1"; return -9; }
-    return step_host(h, x0, xr, ur, f, nullptr, nullptr, u0, lds_dump);
+    return step_host(h, x0, xr, ur, f, other, ego_xy, u0, lds_dump);
 }
 
 int ndp_downwash_device(ndp_handle *h, const void *d_other, const void *d_ego_ref, const void *d_ego_xy,

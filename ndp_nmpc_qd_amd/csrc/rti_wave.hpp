@@ -757,7 +757,25 @@ struct RtiWave {
     }
 
     // ---------------------------------------------------------------- the control step
+    // first-iteration loads, split out so a caller can put independent work between issue and use
+    static NDP_D void issue_first(const RtiParams &P, const RtiIo &io, InBuf &inb, vd &x0v)
+    {
+        vi lane = W::lane();
+        x0v = W::gld(io.x0, lane, lane < NX);
+        RtiIo g = io;
+        g.f_in_lds = 0;                       // decide on f from the pointer only (fused callers pass f = null here)
+        issue_inputs(P, g, inb, true);
+    }
+
     static NDP_D void run(const RtiParams &P, const RtiIo &io, lp lds)
+    {
+        InBuf inb;
+        vd x0v;
+        issue_first(P, io, inb, x0v);
+        run(P, io, lds, inb, x0v);
+    }
+
+    static NDP_D void run(const RtiParams &P, const RtiIo &io, lp lds, InBuf &inb, vd x0v)
     {
         const int N = P.N;
         const LdsMap m = make_map(N);
@@ -765,16 +783,13 @@ struct RtiWave {
         stamp(io, m, 0);
         vi lane = W::lane();
         int status = 0, iters = 0;
-        // global loads first; the index tables (pure VALU) are built while they are in flight
-        vd x0v = W::gld(io.x0, lane, lane < NX);
+        // the global loads are already in flight (issue_first); the index tables (pure VALU) are built under them
         // fused downwash: f sits in the staging slot already; the slot is recycled by the sweep, so keep a register copy
         vd fkeep[RF];
         for (int t = 0; t < RF; ++t) {
             vi i = lane + 64 * t;
             fkeep[t] = io.f_in_lds ? W::ldp(lds, i + m.TF, i < (N + 1) * 3) : vd(0.0);
         }
-        InBuf inb;
-        issue_inputs(P, io, inb, true);
         Tables T;
         build_tables(m, T);
         stamp(io, m, 1);
