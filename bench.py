@@ -168,8 +168,8 @@ def main():
         ach_tf = f_qp * B / rti_s / 1e12
         abytes = algorithmic_bytes_per_solve(N, downwash)
         # matrix-pipe occupancy estimate: every v_mfma_f64_16x16x4 / v_mfma_f32_32x32x2 holds the SIMD's pipe 64 cycles
-        # (measured, scripts/ubench); one instance per SIMD: 13 f64 MFMAs per stage and sweep (+3 per 4 stages), 268 f32 for the MLP tile
-        n_mfma = sweeps * (13 * N + 3 * (N // 4)) + (268 if fused else 0)
+        # (measured, scripts/ubench); one instance per SIMD: 274 f64 MFMAs per sweep at N = 20, 268 f32 for the MLP tile
+        n_mfma = sweeps * (6 + 8 * (N - 1) + N + 16 * ((N - 1) // 4) + 4 * N) + (268 if fused else 0)
         out = {
             "metric": "NMPC solves/sec (N=20, 1 RTI iter + downwash MLP) at batch",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

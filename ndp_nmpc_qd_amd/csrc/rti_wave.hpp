@@ -113,7 +113,7 @@ struct RtiWave {
         vi own_off;               // Lam[g][j&3]
         vd cof_sign;              // (-1)^(g + j&3)
         vb lam_diag;              // g == j&3
-        vd eye[3];                // identity as B operand: chunk c, lane (g,j) = [j == 4c+g]
+        vd eye[4];                // identity as B operand: chunk c, lane (g,j) = [j == 4c+g]
     };
 
     struct Slots {                // box constraints, 64 per slot
@@ -194,7 +194,7 @@ struct RtiWave {
         T.own_off = g * 4 + jc + m.SC;
         T.cof_sign = W::sel(((g + jc) & 1) == 1, vd(-1.0), vd(1.0));
         T.lam_diag = g == jc;
-        for (int c = 0; c < 3; ++c) T.eye[c] = W::sel(j == g + 4 * c, vd(1.0), vd(0.0));
+        for (int c = 0; c < 4; ++c) T.eye[c] = W::sel(j == g + 4 * c, vd(1.0), vd(0.0));
     }
 
     // ---------------------------------------------------------------- inputs
@@ -486,58 +486,68 @@ struct RtiWave {
         return cof * W::rcp(det);
     }
 
-    // backward: P~_N = C~_N; P~_k = H~xx - H~xu Lam^-1 H~ux with H~ = M~' P~ M~ + C~.  Stores K~' per stage.
+    // backward: H~_k = M~_k' P~_{k+1} M~_k + C~_k with P~_{k+1} = H~xx - H~xu Lam^-1 H~ux of stage k+1, P~_N = C~_N.
+    // P~ is never formed: the next stage needs only W' = P~ M~' = H~xx M~' - H~xu (Lam^-1 (H~ux M~')), and
+    // [H~xx ; H~ux] M~' is ONE product (the accumulator registers of H~ as A operand), which does not depend on
+    // Lam^-1 -- its three MFMAs run on the matrix pipe while the VALU inverts Lam.  Stores K~' per stage.
     // forward: z~_0 = [dx0,1,0]; du = K~ z~; z~+ = M~ [z~; du].  Writes ZX[1..N], ZU[0..N-1].
-    // The LDS operands of stage k-1 (k+1 in the forward sweep) are requested before stage k's matrix
-    // instructions are issued, so their latency hides under the MFMA chain.
+    // The LDS operands of the next stage are requested one stage ahead, so their latency hides under the MFMA chain.
     static NDP_D bool riccati_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, lp lds,
                                     const RtiIo *io = nullptr)
     {
         const int N = P.N;
         bool ok = true;
-        vd4 Pt;
         vi lane = W::lane();
         vi g = lane >> 4, j = lane & 15;
-        // terminal block has no control part: keep columns 12..15 exactly zero
-        for (int c = 0; c < 3; ++c) Pt.r[c] = W::sel(j < 12, W::ld(lds, T.c_off[c] + T.c_mul[c] * N), vd(0.0));
-        Pt.r[3] = 0.0;
-        vd mk[3], cc[4];
-        for (int c = 0; c < 3; ++c) mk[c] = W::ld(lds, T.mk_off[c] + T.mk_mul[c] * (N - 1));
-        for (int r = 0; r < 4; ++r) cc[r] = W::ld(lds, T.c_off[r] + T.c_mul[r] * (N - 1));
-        for (int k = N - 1; k >= 0; --k) {
-            const int kn = k > 0 ? k - 1 : 0;
-            vd nmk[3], ncc[4];
-            for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, T.mk_off[c] + T.mk_mul[c] * kn);
-            for (int r = 0; r < 4; ++r) ncc[r] = W::ld(lds, T.c_off[r] + T.c_mul[r] * kn);
-            vd4 H;
-            for (int r = 0; r < 4; ++r) H.r[r] = cc[r];
+        vd4 H;
+        {   // stage N-1 from the terminal block (no control part: keep columns 12..15 exactly zero)
+            vd4 Pt;
+            for (int c = 0; c < 3; ++c) Pt.r[c] = W::sel(j < 12, W::ld(lds, T.c_off[c] + T.c_mul[c] * N), vd(0.0));
+            vd mk[3];
+            for (int c = 0; c < 3; ++c) mk[c] = W::ld(lds, T.mk_off[c] + T.mk_mul[c] * (N - 1));
+            for (int r = 0; r < 4; ++r) H.r[r] = W::ld(lds, T.c_off[r] + T.c_mul[r] * (N - 1));
             vd4 Wm = W::zero4();
-            Wm = W::mfma(Pt.r[0], mk[0], Wm);
-            Wm = W::mfma(Pt.r[1], mk[1], Wm);
-            Wm = W::mfma(Pt.r[2], mk[2], Wm);
-            H = W::mfma(mk[0], Wm.r[0], H);
-            H = W::mfma(mk[1], Wm.r[1], H);
-            H = W::mfma(mk[2], Wm.r[2], H);
-            // Lam[a][b] = H~[12+a][12+b] sits in accumulator register 3 of lane 16a + 12 + b
+            for (int c = 0; c < 3; ++c) Wm = W::mfma(Pt.r[c], mk[c], Wm);
+            for (int c = 0; c < 3; ++c) H = W::mfma(mk[c], Wm.r[c], H);
+        }
+        vd mk[3], cc[4];       // operands of the NEXT stage to be formed (k-1), requested one iteration ahead
+        {
+            const int kn = N > 1 ? N - 2 : 0;
+            for (int c = 0; c < 3; ++c) mk[c] = W::ld(lds, T.mk_off[c] + T.mk_mul[c] * kn);
+            for (int r = 0; r < 4; ++r) cc[r] = W::ld(lds, T.c_off[r] + T.c_mul[r] * kn);
+        }
+        for (int k = N - 1; k >= 0; --k) {
+            const int kp = k > 1 ? k - 2 : 0;
+            vd nmk[3], ncc[4];
+            for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, T.mk_off[c] + T.mk_mul[c] * kp);
+            for (int r = 0; r < 4; ++r) ncc[r] = W::ld(lds, T.c_off[r] + T.c_mul[r] * kp);
+            // Lam[a][b] = H~[12+a][12+b] and H~ux both sit in accumulator register 3
             vd hux = H.r[3];
+            // [H~xx ; H~ux] M~_{k-1}: H~'s registers as A operand mean H~' -- equal up to rounding (see the
+            // re-symmetrisation below); rows 12..15 of the result are T = H~ux M~_{k-1}
+            vd4 Wf = W::zero4();
+            if (k > 0)
+                for (int c = 0; c < 3; ++c) Wf = W::mfma(H.r[c], mk[c], Wf);
             vd li = lam_inverse(T, lds, hux, ok);
-            vd linv = W::sel(T.lo4, li, vd(0.0));             // A operand of G: Lam^-1[g][j], j < 4
+            vd linv = W::sel(T.lo4, li, vd(0.0));             // A operand: Lam^-1[g][j], j < 4
             vd nlhi = W::sel(T.kt_pred, -li, vd(0.0));        // B operand of K~': -Lam^-1[g][j-12] in columns 12..15
-            vd4 G = W::mfma(linv, hux, W::zero4());
             vd4 Kt = W::mfma(hux, nlhi, W::zero4());          // K~'[i][b] lands in column 12+b: rows 12..15 of the forward operand
-            vd4 Pn = W::mfma(-hux, G.r[0], H);
             for (int c = 0; c < 3; ++c) W::stp(lds, T.kt_off[c] + k * int(KT_STRIDE), Kt.r[c], T.kt_pred);
-            if ((k & 3) == 0 && k > 0) {
-                // P~ re-enters the next stage as an A operand, i.e. transposed.  The antisymmetric rounding part of
-                // P~ therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
-                // re-symmetrise every 4th stage.  P~' = (P~ as A operand) x I costs three MFMAs, no LDS.
-                vd4 Tp = W::zero4();
-                Tp = W::mfma(Pn.r[0], T.eye[0], Tp);
-                Tp = W::mfma(Pn.r[1], T.eye[1], Tp);
-                Tp = W::mfma(Pn.r[2], T.eye[2], Tp);
-                for (int c = 0; c < 3; ++c) Pt.r[c] = (Pn.r[c] + Tp.r[c]) * 0.5;
-            } else {
-                Pt.r[0] = Pn.r[0]; Pt.r[1] = Pn.r[1]; Pt.r[2] = Pn.r[2];
+            if (k > 0) {
+                vd4 G = W::mfma(linv, Wf.r[3], W::zero4());  // Lam^-1 T
+                vd4 Wn = W::mfma(-hux, G.r[0], Wf);           // rows 0..11: P~ M~_{k-1}
+                vd4 Hn;
+                for (int r = 0; r < 4; ++r) Hn.r[r] = cc[r];
+                for (int c = 0; c < 3; ++c) Hn = W::mfma(mk[c], Wn.r[c], Hn);
+                if ((k & 3) == 0) {
+                    // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
+                    // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
+                    // re-symmetrise every 4th stage.  H~' = (H~ as A operand) x I costs four MFMAs, no LDS.
+                    vd4 Tp = W::zero4();
+                    for (int c = 0; c < 4; ++c) Tp = W::mfma(Hn.r[c], T.eye[c], Tp);
+                    for (int r = 0; r < 4; ++r) Hn.r[r] = (Hn.r[r] + Tp.r[r]) * 0.5;
+                }
+                H = Hn;
             }
             for (int c = 0; c < 3; ++c) mk[c] = nmk[c];
             for (int r = 0; r < 4; ++r) cc[r] = ncc[r];
