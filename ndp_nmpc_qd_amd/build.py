@@ -20,8 +20,11 @@ def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> ndp_nmpc_qd_amd/libndp_nmpc_hip.so"""
     if not (force or _stale()):
         return LIB
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
+    # -amdgpu-mfma-vgpr-form: MFMA results go straight to VGPRs.  With the default AGPR form every accumulator that is
+    # live across a basic block or feeds VALU/LDS is copied through v_accvgpr_read/write behind full-latency s_nops,
+    # which serialised the matrix pipe against the VALU in the Riccati sweep.
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form",
+           "-fPIC", "-shared", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

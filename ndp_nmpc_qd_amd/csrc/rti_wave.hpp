@@ -40,7 +40,7 @@ enum { MB_PV = 0, MB_Q = 48, MB_B = 76 };
 // cost block CB_k: Qq(4x4) | qe(10) | re(4) | dex(6) | deu(4) | qbv(3) | rb(4)
 enum { CB_QQ = 0, CB_QE = 16, CB_RE = 26, CB_DEX = 30, CB_DEU = 36, CB_QBV = 40, CB_RB = 43 };
 // constants area
-enum { KC_ZERO = 0, KC_ONE = 1, KC_H = 2, KC_QD = 4, KC_RD = 14, KC_LBU = 18, KC_UBU = 22, KC_LBV = 26, KC_UBV = 29, KC_SC = 32, KC_SIZE = 48 };
+enum { KC_ZERO = 0, KC_ONE = 1, KC_H = 2, KC_QD = 4, KC_RD = 14, KC_LBU = 18, KC_UBU = 22, KC_LBV = 26, KC_UBV = 29, KC_SC = 32, KC_DUMP = 48, KC_SIZE = 50 };
 
 struct RtiParams {
     int N, n_rti, use_fd, qp_mode, iter_max;
@@ -104,6 +104,8 @@ struct RtiWave {
         vi mu_off, mu_mul;        // M~ columns 12..15 (B~) as A operand: element (j, 12+g)
         vi c_off[4], c_mul[4];    // C~ in accumulator layout: element (g+4r, j)
         vi kt_off[3];             // where lanes j>=12 keep K~'[4c+g][j-12]
+        vi kt_st[3], kt_mul;      // the same for stores: lanes j<12 aim at the dump slot (branch-free store, stride 0)
+        vi zu_st, zu_mul, zx_st[3], zx_mul[3];   // forward-sweep result stores (lanes j==0), others to the dump slot
         vb kt_pred;               // j >= 12
         vb lo4;                   // j < 4
         vb col0;                  // j == 0
@@ -179,10 +181,20 @@ struct RtiWave {
             T.kt_off[c] = (g + 4 * c) * 4 + (j & 3) + m.KT;
             vi mo, mm;
             m_entry(m, j, g + 4 * c, mo, mm);
+            T.kt_st[c] = W::sel(T.kt_pred, T.kt_off[c], vi(m.KC + KC_DUMP));
+            T.kt_mul = W::sel(T.kt_pred, vi(int(KT_STRIDE)), vi(0));
             T.fw_off[c] = W::sel(T.kt_pred, T.kt_off[c], mo);
             T.fw_mul[c] = W::sel(T.kt_pred, vi(int(KT_STRIDE)), mm);
         }
         m_entry(m, j, g + 12, T.mu_off, T.mu_mul);
+        T.zu_st = W::sel(T.col0, g + m.ZU, vi(m.KC + KC_DUMP));
+        for (int c = 0; c < 3; ++c) {
+            vi idx = g + 4 * c;
+            vb p = T.col0 && (idx < 10);
+            T.zx_st[c] = W::sel(p, idx + m.ZX, vi(m.KC + KC_DUMP));
+            T.zx_mul[c] = W::sel(p, vi(int(NX)), vi(0));
+        }
+        T.zu_mul = W::sel(T.col0, vi(int(NU)), vi(0));
         vi jc = j & 3;
         T.lam_w_off = g * 4 + jc + m.SC;
         for (int a = 0; a < 3; ++a)
@@ -516,7 +528,7 @@ struct RtiWave {
             for (int c = 0; c < 3; ++c) mk[c] = W::ld(lds, T.mk_off[c] + T.mk_mul[c] * kn);
             for (int r = 0; r < 4; ++r) cc[r] = W::ld(lds, T.c_off[r] + T.c_mul[r] * kn);
         }
-        for (int k = N - 1; k >= 0; --k) {
+        for (int k = N - 1; k >= 1; --k) {
             const int kp = k > 1 ? k - 2 : 0;
             vd nmk[3], ncc[4];
             for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, T.mk_off[c] + T.mk_mul[c] * kp);
@@ -526,31 +538,35 @@ struct RtiWave {
             // [H~xx ; H~ux] M~_{k-1}: H~'s registers as A operand mean H~' -- equal up to rounding (see the
             // re-symmetrisation below); rows 12..15 of the result are T = H~ux M~_{k-1}
             vd4 Wf = W::zero4();
-            if (k > 0)
-                for (int c = 0; c < 3; ++c) Wf = W::mfma(H.r[c], mk[c], Wf);
+            for (int c = 0; c < 3; ++c) Wf = W::mfma(H.r[c], mk[c], Wf);
             vd li = lam_inverse(T, lds, hux, ok);
             vd linv = W::sel(T.lo4, li, vd(0.0));             // A operand: Lam^-1[g][j], j < 4
             vd nlhi = W::sel(T.kt_pred, -li, vd(0.0));        // B operand of K~': -Lam^-1[g][j-12] in columns 12..15
+            vd4 G = W::mfma(linv, Wf.r[3], W::zero4());      // Lam^-1 T
             vd4 Kt = W::mfma(hux, nlhi, W::zero4());          // K~'[i][b] lands in column 12+b: rows 12..15 of the forward operand
-            for (int c = 0; c < 3; ++c) W::stp(lds, T.kt_off[c] + k * int(KT_STRIDE), Kt.r[c], T.kt_pred);
-            if (k > 0) {
-                vd4 G = W::mfma(linv, Wf.r[3], W::zero4());  // Lam^-1 T
-                vd4 Wn = W::mfma(-hux, G.r[0], Wf);           // rows 0..11: P~ M~_{k-1}
-                vd4 Hn;
-                for (int r = 0; r < 4; ++r) Hn.r[r] = cc[r];
-                for (int c = 0; c < 3; ++c) Hn = W::mfma(mk[c], Wn.r[c], Hn);
-                if ((k & 3) == 0) {
-                    // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
-                    // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
-                    // re-symmetrise every 4th stage.  H~' = (H~ as A operand) x I costs four MFMAs, no LDS.
-                    vd4 Tp = W::zero4();
-                    for (int c = 0; c < 4; ++c) Tp = W::mfma(Hn.r[c], T.eye[c], Tp);
-                    for (int r = 0; r < 4; ++r) Hn.r[r] = (Hn.r[r] + Tp.r[r]) * 0.5;
-                }
-                H = Hn;
+            vd4 Wn = W::mfma(-hux, G.r[0], Wf);               // rows 0..11: P~ M~_{k-1}
+            vd4 Hn;
+            for (int r = 0; r < 4; ++r) Hn.r[r] = cc[r];
+            for (int c = 0; c < 3; ++c) Hn = W::mfma(mk[c], Wn.r[c], Hn);
+            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + T.kt_mul * k, Kt.r[c]);
+            if ((k & 3) == 0) {
+                // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
+                // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
+                // re-symmetrise every 4th stage.  H~' = (H~ as A operand) x I costs four MFMAs, no LDS.
+                vd4 Tp = W::zero4();
+                for (int c = 0; c < 4; ++c) Tp = W::mfma(Hn.r[c], T.eye[c], Tp);
+                for (int r = 0; r < 4; ++r) Hn.r[r] = (Hn.r[r] + Tp.r[r]) * 0.5;
             }
+            H = Hn;
             for (int c = 0; c < 3; ++c) mk[c] = nmk[c];
             for (int r = 0; r < 4; ++r) cc[r] = ncc[r];
+        }
+        {   // stage 0: only the gain is needed
+            vd hux = H.r[3];
+            vd li = lam_inverse(T, lds, hux, ok);
+            vd nlhi = W::sel(T.kt_pred, -li, vd(0.0));
+            vd4 Kt = W::mfma(hux, nlhi, W::zero4());
+            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c], Kt.r[c]);
         }
         W::sync();
         if (io) stamp(*io, m, 6);
@@ -577,11 +593,10 @@ struct RtiWave {
             Y = W::mfma(fw[2], zc[2], Y);
             vd du = Y.r[3];
             vd4 xn = W::mfma(mu, du, Y);
-            W::stp(lds, g + (k * NU + m.ZU), du, T.col0);
+            W::st(lds, T.zu_st + T.zu_mul * k, du);
             for (int c = 0; c < 3; ++c) {
                 zc[c] = xn.r[c];
-                vi idx = g + 4 * c;
-                W::stp(lds, idx + ((k + 1) * NX + m.ZX), xn.r[c], T.col0 && (idx < 10));
+                W::st(lds, T.zx_st[c] + T.zx_mul[c] * (k + 1), xn.r[c]);
             }
             for (int c = 0; c < 3; ++c) fw[c] = nfw[c];
             mu = nmu;

@@ -219,7 +219,7 @@ def test_lds_image_matches_oracle_linearisation(ndp, oracle):
     eng.set_iterate(X, U)
     _, lds = eng.update_debug(b["x0"], b["xr"], b["ur"])
     qp = oracle.linearize(oracle.default_cfg(), b["x0"][0], b["xr"][0], b["ur"][0], None, X[0], U[0])
-    MB = 48 + 3 * ((N + 1) * 10 + N * 4)
+    MB = 50 + 3 * ((N + 1) * 10 + N * 4)
     CB = MB + N * 86
     for k in range(N):
         blk = lds[MB + k * 86: MB + (k + 1) * 86]

@@ -147,7 +147,7 @@ def test_lds_image_matches_oracle_linearisation(oracle):
     qp = oracle.linearize(cfgo, b["x0"][0], b["xr"][0], b["ur"][0], f, X, U)
     _, _, _, lds, _ = E.rti_step(cfg, b["x0"][0], b["xr"][0], b["ur"][0], f, X.copy(), U.copy(), dump=True)
     KC = 0
-    XI = KC + 48
+    XI = KC + 50
     MB = XI + 3 * ((N + 1) * 10 + N * 4)
     CB = MB + N * 86
     for k in range(N):
