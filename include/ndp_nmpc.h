@@ -118,8 +118,9 @@ void *ndp_device_iterate_u(ndp_handle *h);
 void *ndp_device_force(ndp_handle *h);   /* [B][N+1][3] fp32 written by the fused downwash */
 int ndp_synchronize(ndp_handle *h);
 
-/* Per-kernel timing of the calls issued on the library's own stream since the last reset,
- * measured with HIP events: name is "rti" or "mlp".  Returns <0 if nothing was timed. */
+/* Per-kernel timing with HIP events recorded on the stream each kernel is launched on:
+ * on = n > 0 brackets every n-th launch of each kernel (n = 1: every launch), on = 0 stops and clears.
+ * ndp_timing_read: name is "rti" or "mlp"; total over the bracketed launches.  Returns <0 if nothing was timed. */
 int ndp_timing_enable(ndp_handle *h, int on);
 int ndp_timing_read(ndp_handle *h, const char *name, double *total_ms, int64_t *launches);
 

@@ -169,8 +169,9 @@ class BatchedNMPC:
     def synchronize(self):
         self._check(self._lib.ndp_synchronize(self._h), "ndp_synchronize")
 
-    def timing_enable(self, on=True):
-        self._check(self._lib.ndp_timing_enable(self._h, int(on)), "ndp_timing_enable")
+    def timing_enable(self, every=1):
+        """Bracket every `every`-th launch of each kernel with HIP events (0 / False: off)."""
+        self._check(self._lib.ndp_timing_enable(self._h, int(every)), "ndp_timing_enable")
 
     def timing_read(self, name):
         tot, n = C.c_double(0.0), C.c_int64(0)

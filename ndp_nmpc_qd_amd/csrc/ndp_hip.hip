@@ -325,7 +325,9 @@ struct ndp_handle {
     double *sx0 = nullptr, *sxr = nullptr, *sur = nullptr, *sother = nullptr, *sego = nullptr, *su0 = nullptr, *sdbg = nullptr;
     float *sf = nullptr;
     // timing
-    bool timing = false;
+    int timing = 0;            // 0 off, n > 0: bracket every n-th launch of each kernel with HIP events
+    int64_t launch_no[2] = {0, 0};
+    bool timing_open = false;
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> events;
     std::mutex mu;
@@ -467,7 +469,9 @@ int ndp_set_mlp_weights(ndp_handle *h, const float *blob, size_t n)
 // ---- enqueue helpers (no locking, no sync) ----
 static int begin_timing(ndp_handle *h, hipStream_t s, int kind)
 {
-    if (!h->timing) return 0;
+    h->timing_open = false;
+    if (!h->timing || (h->launch_no[kind]++ % h->timing) != 0) return 0;
+    h->timing_open = true;
     ndp_handle::Ev ev; ev.kind = kind;
     NDP_HIP(h, hipEventCreate(&ev.a)); NDP_HIP(h, hipEventCreate(&ev.b));
     NDP_HIP(h, hipEventRecord(ev.a, s));
@@ -476,7 +480,7 @@ static int begin_timing(ndp_handle *h, hipStream_t s, int kind)
 }
 static int end_timing(ndp_handle *h, hipStream_t s)
 {
-    if (!h->timing) return 0;
+    if (!h->timing_open) return 0;
     NDP_HIP(h, hipEventRecord(h->events.back().b, s));
     return 0;
 }
@@ -711,7 +715,8 @@ int ndp_timing_enable(ndp_handle *h, int on)
     std::lock_guard<std::mutex> lk(h->mu);
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     h->events.clear();
-    h->timing = on != 0;
+    h->timing = on > 0 ? on : 0;
+    h->launch_no[0] = h->launch_no[1] = 0;
     return 0;
 }
 

@@ -297,3 +297,112 @@ def test_device_resident_path_matches_host_path(ndp):
     eng_d.update_device(t["x0"], t["xr"], t["ur"], u_dev, other=t["other"], ego_xy=t["ego_xy"])
     eng_d.synchronize()
     assert np.array_equal(u_dev.cpu().numpy(), u_host)
+
+
+def test_fused_downwash_with_two_rti_iterations_and_ipm_always(ndp, oracle, mlp_blob):
+    """Fused gate+MLP launch: the force must survive the recycling of its LDS staging slot across RTI iterations;
+    and the interior-point path must see the same force."""
+    B = 48
+    b = synth.make_batch(B, seed=123, downwash=True)
+    f_or = oracle.downwash_batch(mlp_blob, b["other"], b["xr"], b["ego_xy"])
+    for n_rti, qp_mode in ((2, 0), (1, 1), (3, 1)):
+        eng = ndp.BatchedNMPC(B, disturbance=True, n_rti=n_rti, qp_mode=qp_mode)
+        eng.reset(b["xr"], b["ur"])
+        f_dev = eng.downwash(b["other"], b["xr"], b["ego_xy"])
+        u0 = eng.update(b["x0"], b["xr"], b["ur"], other=b["other"], ego_xy=b["ego_xy"])
+        u0o, sto, *_ = _oracle_batch(oracle, b, n_rti=n_rti, use_fd=True, f=f_dev)
+        assert (sto == 0).all()
+        _assert_u(u0, u0o, 1e-8)
+        assert np.all(np.abs(f_dev - f_or) <= 1e-5 * np.maximum(1.0, np.abs(f_or)))
+
+
+def test_minimal_and_odd_horizons(ndp, oracle):
+    for N in (2, 3, 7, 27, 31):
+        b = synth.make_batch(5, N=N, seed=200 + N, downwash=True)
+        eng = ndp.BatchedNMPC(5, N=N, disturbance=True)
+        eng.reset(b["xr"], b["ur"])
+        f = eng.downwash(b["other"], b["xr"], b["ego_xy"])
+        u0 = eng.update(b["x0"], b["xr"], b["ur"], other=b["other"], ego_xy=b["ego_xy"])
+        u0o, sto, *_ = _oracle_batch(oracle, b, N=N, use_fd=True, f=f)
+        assert (sto == 0).all()
+        _assert_u(u0, u0o, 1e-8)
+
+
+def test_nan_input_reports_status_1_for_that_instance_only(ndp, oracle):
+    B = 8
+    b = synth.make_batch(B, seed=77)
+    x0 = b["x0"].copy()
+    x0[3, 4] = np.nan
+    eng = ndp.BatchedNMPC(B)
+    eng.reset(b["xr"], b["ur"])
+    u0 = eng.update(x0, b["xr"], b["ur"], raise_on_status=False)
+    st, _ = eng.status()
+    assert st[3] != 0 and (np.delete(st, 3) == 0).all()
+    u0o, *_ = _oracle_batch(oracle, b)
+    _assert_u(np.delete(u0, 3, axis=0), np.delete(u0o, 3, axis=0), 1e-8)       # the other instances are untouched
+
+
+def test_large_batch_and_multiple_handles(ndp, oracle):
+    """More instances than SIMDs (waves run in rounds) and two live handles with different configurations."""
+    B = 4096 + 3
+    b = synth.make_batch(B, seed=5)
+    eng = ndp.BatchedNMPC(B)
+    eng2 = ndp.BatchedNMPC(16, N=10)
+    b2 = synth.make_batch(16, N=10, seed=6)
+    eng.reset(b["xr"], b["ur"])
+    eng2.reset(b2["xr"], b2["ur"])
+    u0 = eng.update(b["x0"], b["xr"], b["ur"])
+    u2 = eng2.update(b2["x0"], b2["xr"], b2["ur"])
+    idx = np.random.default_rng(0).choice(B, 256, replace=False)
+    sub = {k: np.ascontiguousarray(b[k][idx]) for k in ("x0", "xr", "ur")}
+    u0o, *_ = _oracle_batch(oracle, sub)
+    _assert_u(u0[idx], u0o, 1e-8)
+    u2o, *_ = _oracle_batch(oracle, b2, N=10)
+    _assert_u(u2, u2o, 1e-8)
+
+
+def test_concurrent_callers_like_rospy_threads(ndp, oracle):
+    """update (control timer), reset (action thread) and solver.get (viz timer) from different threads, no caller
+    locks (nmpc_node.py:94,152,237): the handle serialises; every result is one of the legal interleavings."""
+    import threading
+    from ndp_nmpc_qd_amd.nmpc_ctl import NMPCBodyRateController
+    b = synth.make_batch(1, seed=9)
+    x0, xr, ur = b["x0"][0], b["xr"][0], b["ur"][0]
+    ctl = NMPCBodyRateController()
+    ctl.reset(xr, ur)
+    errors, outs = [], []
+
+    def control():
+        try:
+            for _ in range(30):
+                outs.append(ctl.update(x0, xr, ur))
+        except Exception as e:     # noqa: BLE001
+            errors.append(e)
+
+    def action():
+        try:
+            for _ in range(10):
+                ctl.reset(xr, ur)
+        except Exception as e:     # noqa: BLE001
+            errors.append(e)
+
+    def viz():
+        try:
+            for _ in range(60):
+                x = ctl.solver.get(3, "x")
+                assert x.shape == (10,) and np.isfinite(x).all()
+        except Exception as e:     # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=f) for f in (control, action, viz)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    # every returned u0 is finite and inside the input box; the first solve after a reset equals the oracle's first step
+    U = np.array(outs)
+    assert np.isfinite(U).all() and (np.abs(U[:, :3]) <= 6 + 1e-9).all() and (U[:, 3] >= -1e-9).all()
+    ctl.reset(xr, ur)
+    u = ctl.update(x0, xr, ur)
+    Xo, Uo = xr.copy(), ur.copy()
+    uo, _ = oracle.step(oracle.default_cfg(), x0, xr, ur, None, Xo, Uo)
+    _assert_u(u, uo, 1e-8)
