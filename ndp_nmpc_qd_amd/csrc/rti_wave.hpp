@@ -587,6 +587,7 @@ struct RtiWave {
             vd nfw[3], nmu;
             for (int c = 0; c < 3; ++c) nfw[c] = W::ld(lds, T.fw_off[c] + T.fw_mul[c] * kn);
             nmu = W::ld(lds, T.mu_off + T.mu_mul * kn);
+            W::pin();   // keep the prefetch ahead of this stage's MFMAs (the scheduler otherwise sinks it behind them)
             vd4 Y = W::zero4();
             Y = W::mfma(fw[0], zc[0], Y);
             Y = W::mfma(fw[1], zc[1], Y);

@@ -32,6 +32,7 @@ struct WaveGfx950 {
     static NDP_D vd ldp(lds_ptr lds, vi off, vb p) { return p ? lds[off] : 0.0; }
     static NDP_D void stp(lds_ptr lds, vi off, vd v, vb p) { if (p) lds[off] = v; }
     static NDP_D void st(lds_ptr lds, vi off, vd v) { lds[off] = v; }
+    static NDP_D void pin() { __builtin_amdgcn_sched_barrier(0); }   // instruction-scheduling fence only
     static NDP_D void sync()
     {   // lanes exchange data through LDS: forbid the compiler to move LDS accesses across this point
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
