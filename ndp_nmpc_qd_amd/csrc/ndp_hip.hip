@@ -72,6 +72,7 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
     typename Prog::InBuf inb;
     double x0v;
     Prog::issue_first(P, io, inb, x0v);      // every global input of the RTI step is now in flight (hidden under the MLP when fused)
+    __builtin_amdgcn_sched_barrier(0);       // do not let the scheduler sink those loads behind the MLP
     if (FUSED) {
         const int lane = (int)(threadIdx.x & 63u), j = lane & 31, h = lane >> 5;
         const int np1 = N + 1;

@@ -376,24 +376,29 @@ static double con_value(const ipm_con *cn, const double *dx, const double *du)
  * d_ocp_qp_fact_solve_kkt_step).  All linear residuals (stationarity,
  * dynamics, slack definitions) contract by (1-alpha) per iteration, so they
  * are tracked by the scalar rho.                                             */
-int orc_qp_solve(const orc_cfg *c, int N, const double *A, const double *B, const double *b,
-                 const double *Q, const double *q, const double *Rd, const double *r,
-                 const double *dx0, const double *lu, const double *uu,
-                 const double *lv, const double *uv,
-                 double *dx, double *du, orc_stats *st)
+/* scratch of one QP solve; allocated once per thread by the batch driver (malloc per instance does not scale
+ * under OpenMP) */
+typedef struct {
+    ipm_con cn[7 * ORC_NMAX];
+    double Qe[(ORC_NMAX + 1) * NX * NX], qe[(ORC_NMAX + 1) * NX], Re[ORC_NMAX * NU], re[ORC_NMAX * NU];
+    double zx[(ORC_NMAX + 1) * NX], zu[ORC_NMAX * NU], nx_[(ORC_NMAX + 1) * NX], nu_[ORC_NMAX * NU];
+    ric_gain G;
+} qp_ws;
+
+static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B, const double *b,
+                       const double *Q, const double *q, const double *Rd, const double *r,
+                       const double *dx0, const double *lu, const double *uu,
+                       const double *lv, const double *uv,
+                       double *dx, double *du, orc_stats *st, qp_ws *w)
 {
     const int m = NU * N + 3 * (N - 1);
-    ipm_con *cn = (ipm_con *)calloc((size_t)m, sizeof(ipm_con));
-    double *Qe = (double *)malloc(sizeof(double) * (size_t)(N + 1) * NX * NX);
-    double *qe = (double *)malloc(sizeof(double) * (size_t)(N + 1) * NX);
-    double *Re = (double *)malloc(sizeof(double) * (size_t)N * NU);
-    double *re = (double *)malloc(sizeof(double) * (size_t)N * NU);
-    double *zx = (double *)calloc((size_t)(N + 1) * NX, sizeof(double));
-    double *zu = (double *)calloc((size_t)N * NU, sizeof(double));
-    double *nx_ = (double *)malloc(sizeof(double) * (size_t)(N + 1) * NX);
-    double *nu_ = (double *)malloc(sizeof(double) * (size_t)N * NU);
-    ric_gain *G = (ric_gain *)malloc(sizeof(ric_gain));
+    ipm_con *cn = w->cn;
+    double *Qe = w->Qe, *qe = w->qe, *Re = w->Re, *re = w->re, *zx = w->zx, *zu = w->zu, *nx_ = w->nx_, *nu_ = w->nu_;
+    ric_gain *G = &w->G;
     int status = 0, iters = 0, n = 0;
+    memset(cn, 0, sizeof(ipm_con) * (size_t)m);
+    memset(zx, 0, sizeof(double) * (size_t)(N + 1) * NX);
+    memset(zu, 0, sizeof(double) * (size_t)N * NU);
 
     for (int k = 0; k < N; ++k)
         for (int i = 0; i < NU; ++i, ++n) {
@@ -506,8 +511,19 @@ done:
         for (int i = 0; i < m; ++i)
             st->n_active += (cn[i].ll > 1e-6) + (cn[i].lu > 1e-6);
     }
-    free(cn); free(Qe); free(qe); free(Re); free(re); free(zx); free(zu); free(nx_); free(nu_); free(G);
     return status;
+}
+
+int orc_qp_solve(const orc_cfg *c, int N, const double *A, const double *B, const double *b,
+                 const double *Q, const double *q, const double *Rd, const double *r,
+                 const double *dx0, const double *lu, const double *uu,
+                 const double *lv, const double *uv,
+                 double *dx, double *du, orc_stats *st)
+{
+    qp_ws *w = (qp_ws *)malloc(sizeof(qp_ws));
+    const int rc = qp_solve_ws(c, N, A, B, b, Q, q, Rd, r, dx0, lu, uu, lv, uv, dx, du, st, w);
+    free(w);
+    return rc;
 }
 
 /* ------------------------------------------------------------- SQP-RTI step */
@@ -551,12 +567,16 @@ void orc_linearize(const orc_cfg *c, const double *x0, const double *xr, const d
     for (int i = 0; i < NX; ++i) dx0[i] = x0[i] - X[i];
 }
 
-int orc_step(const orc_cfg *c, const double *x0, const double *xr, const double *ur,
-             const double *f, double *X, double *U, double *u0, orc_stats *st)
+typedef struct {
+    double lin[ORC_NMAX * (NX * NX + NX * NU + NX + NU + NU + NU + NU) + (ORC_NMAX + 1) * (NX * NX + NX + 3 + 3 + NX) + NX + ORC_NMAX * NU];
+    qp_ws qp;
+} step_ws;
+
+static int step_ws_run(const orc_cfg *c, const double *x0, const double *xr, const double *ur,
+                       const double *f, double *X, double *U, double *u0, orc_stats *st, step_ws *ws)
 {
     const int N = c->N;
-    double *w = (double *)malloc(sizeof(double) *
-        ((size_t)N * (NX * NX + NX * NU + NX + NU + NU + NU + NU) + (size_t)(N + 1) * (NX * NX + NX + 3 + 3 + NX) + NX + (size_t)N * NU));
+    double *w = ws->lin;
     double *A = w, *B = A + (size_t)N * NX * NX, *b = B + (size_t)N * NX * NU;
     double *Rd = b + (size_t)N * NX, *r = Rd + (size_t)N * NU, *lu = r + (size_t)N * NU, *uu = lu + (size_t)N * NU;
     double *Q = uu + (size_t)N * NU, *q = Q + (size_t)(N + 1) * NX * NX;
@@ -566,7 +586,7 @@ int orc_step(const orc_cfg *c, const double *x0, const double *xr, const double 
     for (int it = 0; it < c->n_rti; ++it) {
         orc_stats s1;
         orc_linearize(c, x0, xr, ur, f, X, U, A, B, b, Q, q, Rd, r, dx0, lu, uu, lv, uv);
-        orc_qp_solve(c, N, A, B, b, Q, q, Rd, r, dx0, lu, uu, lv, uv, dx, du, &s1);
+        qp_solve_ws(c, N, A, B, b, Q, q, Rd, r, dx0, lu, uu, lv, uv, dx, du, &s1, &ws->qp);
         /* full step, no line search */
         for (int i = 0; i < (N + 1) * NX; ++i) X[i] += dx[i];
         for (int i = 0; i < N * NU; ++i) U[i] += du[i];
@@ -580,8 +600,17 @@ int orc_step(const orc_cfg *c, const double *x0, const double *xr, const double 
         if (!(u0[i] == u0[i])) acc.status = 1;
     }
     if (st) *st = acc;
-    free(w);
     return acc.status;
+}
+
+int orc_step(const orc_cfg *c, const double *x0, const double *xr, const double *ur,
+             const double *f, double *X, double *U, double *u0, orc_stats *st)
+{
+    if (c->N > ORC_NMAX) return -1;
+    step_ws *ws = (step_ws *)malloc(sizeof(step_ws));
+    const int rc = step_ws_run(c, x0, xr, ur, f, X, U, u0, st, ws);
+    free(ws);
+    return rc;
 }
 
 int orc_num_threads(void)
@@ -599,18 +628,27 @@ int orc_step_batch(const orc_cfg *c, int B, const double *x0, const double *xr, 
 {
     const int N = c->N;
     int worst = 0;
+    if (N > ORC_NMAX) return -1;
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = omp_get_max_threads();
-#pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads) reduction(max : worst)
+    if (nthreads > B) nthreads = B;
+#pragma omp parallel num_threads(nthreads) reduction(max : worst)
 #endif
-    for (int i = 0; i < B; ++i) {
-        orc_stats s;
-        orc_step(c, x0 + (size_t)i * NX, xr + (size_t)i * (N + 1) * NX, ur + (size_t)i * N * NU,
-                 f ? f + (size_t)i * (N + 1) * 3 : NULL, X + (size_t)i * (N + 1) * NX,
-                 U + (size_t)i * N * NU, u0 + (size_t)i * NU, &s);
-        if (status) status[i] = s.status;
-        if (ipm_iters) ipm_iters[i] = s.ipm_iters;
-        if (s.status > worst) worst = s.status;
+    {
+        step_ws *ws = (step_ws *)malloc(sizeof(step_ws));   /* one scratch per thread */
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int i = 0; i < B; ++i) {
+            orc_stats s;
+            step_ws_run(c, x0 + (size_t)i * NX, xr + (size_t)i * (N + 1) * NX, ur + (size_t)i * N * NU,
+                        f ? f + (size_t)i * (N + 1) * 3 : NULL, X + (size_t)i * (N + 1) * NX,
+                        U + (size_t)i * N * NU, u0 + (size_t)i * NU, &s, ws);
+            if (status) status[i] = s.status;
+            if (ipm_iters) ipm_iters[i] = s.ipm_iters;
+            if (s.status > worst) worst = s.status;
+        }
+        free(ws);
     }
     return worst;
 }
