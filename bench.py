@@ -52,6 +52,19 @@ def measured_traffic(B, N, fused):
     return (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
 
 
+def effective_cores():
+    """Host cores this process may really use: min(affinity mask, cgroup CPU quota).  OpenMP's default (all logical
+    CPUs) oversubscribes a quota-limited container and gets throttled."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,7 +75,7 @@ def main():
     ap.add_argument("--workload", default="ndp_downwash", choices=["ndp_downwash", "nmpc"])
     ap.add_argument("--qp-mode", type=int, default=0, help="0 auto (exact early exit), 1 interior point always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-passes", type=int, default=24)
+    ap.add_argument("--cpu-passes", type=int, default=200)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -195,15 +208,15 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle as O
             cfgo = O.default_cfg(N=N, use_fd=downwash)
-            nthr = O.num_threads()
+            nthr = min(O.num_threads(), effective_cores())
             blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
             Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
-            O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], None, Xo, Uo)       # warm the thread pool
+            O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], None, Xo, Uo, nthreads=nthr)       # warm the thread pool
             Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
             tc = time.perf_counter()
             for _ in range(args.cpu_passes):
-                f = O.downwash_batch(blob, host0["other"], host0["xr"], host0["ego_xy"]) if downwash else None
-                O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], f, Xo, Uo)
+                f = O.downwash_batch(blob, host0["other"], host0["xr"], host0["ego_xy"], nthreads=nthr) if downwash else None
+                O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], f, Xo, Uo, nthreads=nthr)
             tc = time.perf_counter() - tc
             out["cpu_baseline"] = {"value": B * args.cpu_passes / tc, "unit": "solves/s", "cores": nthr, "kind": "port",
                                    "sample": f"{args.cpu_passes} control ticks of the same batch={B} workload "

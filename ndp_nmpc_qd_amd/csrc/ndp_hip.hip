@@ -20,6 +20,7 @@ namespace ndp {
 
 // ------------------------------------------------------------------------------------------ RTI kernel
 struct BatchPtrs {
+    const double *kc;
     const double *x0, *xr, *ur;
     const float *f;
     double *X, *U, *u0;
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
     io.iters = bp.iters + inst;
     io.dbg = bp.dbg;
     io.f_in_lds = 0;
+    io.kc = bp.kc;
     WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lds_per_wave);
     using Prog = RtiWave<WaveGfx950, NSLOT>;
     typename Prog::InBuf inb;
@@ -321,6 +323,7 @@ struct ndp_handle {
     double *dX = nullptr, *dU = nullptr;
     int *dStatus = nullptr, *dIters = nullptr;
     float *dForce = nullptr, *dFrag = nullptr;
+    double *dKC = nullptr;     // constants block of the LDS image (fill_kc)
     bool have_mlp = false;
     // staging for the host-pointer entry points
     double *sx0 = nullptr, *sxr = nullptr, *sur = nullptr, *sother = nullptr, *sego = nullptr, *su0 = nullptr, *sdbg = nullptr;
@@ -384,7 +387,7 @@ int ndp_destroy(ndp_handle *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    void *ptrs[] = {h->dX, h->dU, h->dStatus, h->dIters, h->dForce, h->dFrag, h->sx0, h->sxr, h->sur,
+    void *ptrs[] = {h->dKC, h->dX, h->dU, h->dStatus, h->dIters, h->dForce, h->dFrag, h->sx0, h->sxr, h->sur,
                     h->sother, h->sego, h->su0, h->sdbg, h->sf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -427,7 +430,13 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     if ((e = hipMalloc((void **)&(p), (n))) != hipSuccess) return fail("hipMalloc " #p, e)
     ALLOC(h->dX, nxs(h) * 8); ALLOC(h->dU, nus(h) * 8);
     ALLOC(h->dStatus, B * 4); ALLOC(h->dIters, B * 4);
-    ALLOC(h->dForce, nfs(h) * 4); ALLOC(h->dFrag, FR_TOTAL * 4);
+    ALLOC(h->dForce, nfs(h) * 4); ALLOC(h->dFrag, FR_TOTAL * 4); ALLOC(h->dKC, KC_SC * 8);
+    {
+        double kc[KC_SC];
+        fill_kc(h->P, kc);
+        if ((e = hipMemcpyAsync(h->dKC, kc, sizeof(kc), hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail("hipMemcpy kc", e);
+        if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
+    }
     ALLOC(h->sx0, B * NX * 8); ALLOC(h->sxr, nxs(h) * 8); ALLOC(h->sur, nus(h) * 8);
     ALLOC(h->sother, nxs(h) * 8); ALLOC(h->sego, B * 2 * 8); ALLOC(h->su0, B * NU * 8);
     ALLOC(h->sf, nfs(h) * 4); ALLOC(h->sdbg, (size_t)lds_doubles(cfg->N) * 8);
@@ -505,7 +514,7 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
                       double *d_u0, double *d_dbg, hipStream_t s, const double *d_other = nullptr,
                       const double *d_ego_xy = nullptr)
 {
-    BatchPtrs bp{d_x0, d_xr, d_ur, d_f, h->dX, h->dU, d_u0, h->dStatus, h->dIters, d_dbg};
+    BatchPtrs bp{h->dKC, d_x0, d_xr, d_ur, d_f, h->dX, h->dU, d_u0, h->dStatus, h->dIters, d_dbg};
     MlpArgs ma{d_other ? h->dFrag : nullptr, d_other, d_ego_xy, h->dForce, h->cfg.r_horiz * h->cfg.r_horiz};
     const int B = h->cfg.batch, W = h->waves;
     const dim3 grid((B + W - 1) / W), block(64 * W);

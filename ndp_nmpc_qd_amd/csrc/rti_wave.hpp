@@ -59,6 +59,7 @@ struct RtiIo {            // global-memory views of ONE instance
     int *status, *iters;  // per-instance
     double *dbg;          // optional dump area (tests), or null
     int f_in_lds;         // 1: the caller already left f (as doubles) in the LDS staging slot TF (fused downwash)
+    const double *kc;     // [KC_SC] lane-indexable constants block prepared by the host (fill_kc)
 };
 
 struct LdsMap {
@@ -89,6 +90,18 @@ NDP_HD LdsMap make_map(int N)
 }
 
 NDP_HD int lds_doubles(int N) { return make_map(N).total; }
+
+// the constants area of the LDS image, written once by the host and copied by the kernel (one coalesced load
+// instead of a 30-way select chain per launch)
+NDP_HD void fill_kc(const RtiParams &P, double *kc)
+{
+    for (int i = 0; i < KC_SC; ++i) kc[i] = 0.0;
+    kc[KC_ONE] = 1.0;
+    kc[KC_H] = P.dt;
+    for (int i = 0; i < 10; ++i) kc[KC_QD + i] = P.Qd[i];
+    for (int i = 0; i < 4; ++i) { kc[KC_RD + i] = P.Rd[i]; kc[KC_LBU + i] = P.lbu[i]; kc[KC_UBU + i] = P.ubu[i]; }
+    for (int i = 0; i < 3; ++i) { kc[KC_LBV + i] = P.lbv[i]; kc[KC_UBV + i] = P.ubv[i]; }
+}
 
 template <class W, int NSLOT>
 struct RtiWave {
@@ -215,7 +228,7 @@ struct RtiWave {
     static constexpr int NMAXS = (64 * NSLOT + 3) / 7;
     static constexpr int RX = ((NMAXS + 1) * NX + 63) / 64, RU = (NMAXS * NU + 63) / 64, RF = ((NMAXS + 1) * 3 + 63) / 64;
 
-    struct InBuf { vd xr[RX], xi[RX], ur[RU], ui[RU], f[RF]; };
+    struct InBuf { vd xr[RX], xi[RX], ur[RU], ui[RU], f[RF], kc; };
 
     // issue every global load of this instance (nothing waits here)
     static NDP_D void issue_inputs(const RtiParams &P, const RtiIo &io, InBuf &b, bool first)
@@ -224,20 +237,23 @@ struct RtiWave {
         vi lane = W::lane();
         const int nx = (N + 1) * NX, nu = N * NU, nf = (N + 1) * 3;
         const bool have_f = P.use_fd && io.f && !io.f_in_lds;
+        // unconditional loads from a clamped index (a predicated load compiles to a branchy block each);
+        // lanes past the end fetch the last element and are masked at the LDS store
         for (int t = 0; t < RX; ++t) {
-            vi i = lane + 64 * t;
-            b.xr[t] = W::gld(io.xr, i, i < nx);
-            b.xi[t] = first ? W::gld(io.X, i, i < nx) : vd(0.0);
+            vi i = W::imin(lane + 64 * t, nx - 1);
+            b.xr[t] = W::gldu(io.xr, i);
+            b.xi[t] = first ? W::gldu(io.X, i) : vd(0.0);
         }
         for (int t = 0; t < RU; ++t) {
-            vi i = lane + 64 * t;
-            b.ur[t] = W::gld(io.ur, i, i < nu);
-            b.ui[t] = first ? W::gld(io.U, i, i < nu) : vd(0.0);
+            vi i = W::imin(lane + 64 * t, nu - 1);
+            b.ur[t] = W::gldu(io.ur, i);
+            b.ui[t] = first ? W::gldu(io.U, i) : vd(0.0);
         }
         for (int t = 0; t < RF; ++t) {
-            vi i = lane + 64 * t;
-            b.f[t] = have_f ? W::gldf(io.f, i, i < nf) : vd(0.0);
+            vi i = W::imin(lane + 64 * t, nf - 1);
+            b.f[t] = have_f ? W::gldfu(io.f, i) : vd(0.0);
         }
+        b.kc = first ? W::gldu(io.kc, W::imin(lane, KC_SC - 1)) : vd(0.0);
     }
 
     // land them in LDS (first use of the loaded values: the wait sits here)
@@ -260,20 +276,7 @@ struct RtiWave {
             vi i = lane + 64 * t;
             W::stp(lds, i + m.TF, b.f[t], i < nf);
         }
-        if (first) {
-            // constants area (lane-indexable copies of the uniform parameters)
-            vb p = lane < KC_SC;
-            vd v = 0.0;
-            v = W::sel(lane == KC_ONE, vd(1.0), v);
-            v = W::sel(lane == KC_H, vd(P.dt), v);
-            for (int i = 0; i < 10; ++i) v = W::sel(lane == KC_QD + i, vd(P.Qd[i]), v);
-            for (int i = 0; i < 4; ++i) v = W::sel(lane == KC_RD + i, vd(P.Rd[i]), v);
-            for (int i = 0; i < 4; ++i) v = W::sel(lane == KC_LBU + i, vd(P.lbu[i]), v);
-            for (int i = 0; i < 4; ++i) v = W::sel(lane == KC_UBU + i, vd(P.ubu[i]), v);
-            for (int i = 0; i < 3; ++i) v = W::sel(lane == KC_LBV + i, vd(P.lbv[i]), v);
-            for (int i = 0; i < 3; ++i) v = W::sel(lane == KC_UBV + i, vd(P.ubv[i]), v);
-            W::stp(lds, lane + m.KC, v, p);
-        }
+        if (first) W::stp(lds, lane + m.KC, b.kc, lane < KC_SC);   // constants area
         W::sync();
     }
 
@@ -787,7 +790,7 @@ struct RtiWave {
     static NDP_D void issue_first(const RtiParams &P, const RtiIo &io, InBuf &inb, vd &x0v)
     {
         vi lane = W::lane();
-        x0v = W::gld(io.x0, lane, lane < NX);
+        x0v = W::gldu(io.x0, W::imin(lane, NX - 1));
         RtiIo g = io;
         g.f_in_lds = 0;                       // decide on f from the pointer only (fused callers pass f = null here)
         issue_inputs(P, g, inb, true);

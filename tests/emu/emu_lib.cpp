@@ -20,7 +20,9 @@ int emu_rti_step(const ndp_cfg *cfg, const double *x0, const double *xr, const d
     std::vector<double> lds((size_t)n, 0.0 / 0.0);   // NaN-poisoned: any read of unwritten LDS shows up
     emu::Wave::lds_limit() = n;
     emu::stats() = emu::Stats();
-    ndp::RtiIo io{x0, xr, ur, f, X, U, u0, status, iters, lds_dump, 0};
+    double kc[ndp::KC_SC];
+    ndp::fill_kc(P, kc);
+    ndp::RtiIo io{x0, xr, ur, f, X, U, u0, status, iters, lds_dump, 0, kc};
     const int ns = ndp::slots_for(P.N);
     if (ns <= 3) ndp::RtiWave<emu::Wave, 3>::run(P, io, lds.data());
     else if (ns <= 5) ndp::RtiWave<emu::Wave, 5>::run(P, io, lds.data());
