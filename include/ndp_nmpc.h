@@ -124,6 +124,21 @@ int ndp_synchronize(ndp_handle *h);
 int ndp_timing_enable(ndp_handle *h, int on);
 int ndp_timing_read(ndp_handle *h, const char *name, double *total_ms, int64_t *launches);
 
+/* ---- "next" row f3: the step after the path (hover-throttle estimator + actuator command), batched.
+ * Replaces, per vehicle, HoverThrottleEstimator(ts).update(vz, throttle) -> k_throttle
+ * (hv_throttle_est/hover_throttle_estimator.py:15-53, differentiator.py:10-23, params/estimator_params.py:13-18;
+ *  called from nmpc_node.py:251-253) and nmpc_u_2_att_tgt's thrust = c * mass / k_throttle (nmpc_node.py:273-283).
+ * One estimator per instance of the handle; state lives on the device.
+ *   ndp_throttle_reset : x = [0, k_init], P = I, differentiator cleared
+ *   ndp_throttle_update: vz[B], throttle[B] (the thrust command sent last tick) -> k_throttle[B]
+ *   ndp_actuator_cmd   : u0[B][4] = [wx,wy,wz,c] -> cmd[B][4] = [wx,wy,wz, c*mass/k_throttle (0 if k == 0)] */
+int ndp_throttle_reset(ndp_handle *h);
+int ndp_throttle_update(ndp_handle *h, const double *vz, const double *throttle, double *k_throttle);
+int ndp_throttle_update_device(ndp_handle *h, const void *d_vz, const void *d_throttle, void *d_k_throttle, void *stream);
+int ndp_actuator_cmd(ndp_handle *h, const double *u0, const double *k_throttle, double *cmd);
+int ndp_actuator_cmd_device(ndp_handle *h, const void *d_u0, const void *d_k_throttle, void *d_cmd, void *stream);
+int ndp_throttle_get_state(ndp_handle *h, double *state /* [B][8]: x0 x1 P00 P01 P10 P11 vz_prev az_prev */);
+
 /* Test hook: number of doubles of the LDS image dump, and a step that also dumps it (B = 1 use). */
 int ndp_debug_lds_doubles(int N);
 /* Test hook: one v_mfma_f64_16x16x4_f64 on caller-chosen per-lane operands a[64], b[64], c[4][64];

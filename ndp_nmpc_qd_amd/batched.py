@@ -108,6 +108,29 @@ class BatchedNMPC:
                     "ndp_downwash")
         return f
 
+    # ------------------------------------------------------------------ f3: hover-throttle estimator + actuator command
+    def throttle_reset(self):
+        self._check(self._lib.ndp_throttle_reset(self._h), "ndp_throttle_reset")
+
+    def throttle_update(self, vz, throttle):
+        """HoverThrottleEstimator.update for every instance: returns k_throttle[B]."""
+        vz, throttle = _lib.f64(vz, (self.B,)), _lib.f64(throttle, (self.B,))
+        k = np.empty(self.B)
+        self._check(self._lib.ndp_throttle_update(self._h, _lib.ptr(vz), _lib.ptr(throttle), _lib.ptr(k)), "ndp_throttle_update")
+        return k
+
+    def throttle_state(self):
+        st = np.empty((self.B, 8))
+        self._check(self._lib.ndp_throttle_get_state(self._h, _lib.ptr(st)), "ndp_throttle_get_state")
+        return st
+
+    def actuator_cmd(self, u0, k_throttle):
+        """nmpc_u_2_att_tgt for every instance: [wx, wy, wz, c] -> [wx, wy, wz, thrust]."""
+        u0, k = _lib.f64(u0, (self.B, 4)), _lib.f64(k_throttle, (self.B,))
+        cmd = np.empty((self.B, 4))
+        self._check(self._lib.ndp_actuator_cmd(self._h, _lib.ptr(u0), _lib.ptr(k), _lib.ptr(cmd)), "ndp_actuator_cmd")
+        return cmd
+
     def get_iterate(self):
         X = np.empty((self.B, self.N + 1, 10))
         U = np.empty((self.B, self.N, 4))

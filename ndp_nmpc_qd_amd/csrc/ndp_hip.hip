@@ -308,6 +308,70 @@ static void make_fragments(const float *blob, std::vector<float> &fr)
     for (int i = 0; i < 3; ++i) fr[FR_B4 + i] = b4[i];
 }
 
+// ------------------------------------------------------------------------------------------ f3 kernels
+// Hover-throttle estimator (2-state Kalman filter on [f_collect, k_throttle] + Tustin differentiator), one thread
+// per vehicle.  Elementwise and HBM-bound: state is SoA ([8][B] doubles) so every access is a coalesced 512-B wave
+// load/store; 152 algorithmic bytes per vehicle and tick.  Operation order follows the reference's numpy
+// expressions (hover_throttle_estimator.py:38-51) so results agree to rounding.
+struct ThrCfg { double a1, a2, hm, g, R, Q0, Q1, mass; };
+
+__global__ __launch_bounds__(256) void throttle_kernel(ThrCfg c, double *__restrict__ st, const double *__restrict__ vz,
+                                                       const double *__restrict__ throttle, double *__restrict__ k_out, int B)
+{
+    const int v = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (v >= B) return;
+    const size_t S = (size_t)B;
+    const double vzv = vz[v], th = throttle[v];
+    const double az = __dadd_rn(__dmul_rn(c.a1, st[7 * S + v]), __dmul_rn(c.a2, vzv - st[6 * S + v]));   // differentiator.py:21
+    st[6 * S + v] = vzv;
+    st[7 * S + v] = az;
+    double x1 = st[1 * S + v];
+    if (0.1 < th && th < 1.0) {                                            // hover_throttle_estimator.py:40
+        const double z = az + c.g;
+        const double P11 = st[5 * S + v];
+        // numpy evaluates these products without fused multiply-add: keep individually rounded operations
+        const double p01 = __dmul_rn(th, P11), p10 = __dmul_rn(P11, th);
+        const double p00 = __dadd_rn(__dmul_rn(p01, th), c.Q0), p11 = __dadd_rn(P11, c.Q1);
+        const double inv = 1.0 / __dadd_rn(__dmul_rn(__dmul_rn(c.hm, p00), c.hm), c.R);
+        const double K0 = __dmul_rn(__dmul_rn(p00, c.hm), inv), K1 = __dmul_rn(__dmul_rn(p10, c.hm), inv);
+        const double x0p = __dmul_rn(th, x1);
+        const double innov = z - __dmul_rn(c.hm, x0p);
+        st[0 * S + v] = __dadd_rn(x0p, __dmul_rn(K0, innov));
+        x1 = __dadd_rn(x1, __dmul_rn(K1, innov));
+        st[1 * S + v] = x1;
+        const double i00 = 1.0 - __dmul_rn(K0, c.hm), i10 = -__dmul_rn(K1, c.hm);
+        st[2 * S + v] = __dmul_rn(i00, p00);
+        st[3 * S + v] = __dmul_rn(i00, p01);
+        st[4 * S + v] = __dadd_rn(__dmul_rn(i10, p00), p10);
+        st[5 * S + v] = __dadd_rn(__dmul_rn(i10, p01), p11);
+    }
+    k_out[v] = x1;
+}
+
+__global__ __launch_bounds__(256) void throttle_reset_kernel(double *st, double k_init, int B)
+{
+    const int v = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (v >= B) return;
+    const size_t S = (size_t)B;
+    st[0 * S + v] = 0.0; st[1 * S + v] = k_init;
+    st[2 * S + v] = 1.0; st[3 * S + v] = 0.0; st[4 * S + v] = 0.0; st[5 * S + v] = 1.0;
+    st[6 * S + v] = 0.0; st[7 * S + v] = 0.0;
+}
+
+// nmpc_u_2_att_tgt (nmpc_node.py:273-283): body rates pass through, thrust = c * mass / k_throttle (0 if k == 0)
+__global__ __launch_bounds__(256) void actuator_kernel(const double *__restrict__ u0, const double *__restrict__ k,
+                                                       double *__restrict__ cmd, double mass, int B)
+{
+    const int v = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (v >= B) return;
+    const double2 a = reinterpret_cast<const double2 *>(u0)[2 * v], b = reinterpret_cast<const double2 *>(u0)[2 * v + 1];
+    const double kk = k[v];
+    double2 o0 = a, o1 = b;
+    o1.y = kk != 0.0 ? __dmul_rn(b.y, mass) / kk : 0.0;
+    reinterpret_cast<double2 *>(cmd)[2 * v] = o0;
+    reinterpret_cast<double2 *>(cmd)[2 * v + 1] = o1;
+}
+
 }  // namespace ndp
 
 // ------------------------------------------------------------------------------------------ C-ABI
@@ -324,6 +388,8 @@ struct ndp_handle {
     int *dStatus = nullptr, *dIters = nullptr;
     float *dForce = nullptr, *dFrag = nullptr;
     double *dKC = nullptr;     // constants block of the LDS image (fill_kc)
+    double *dThr = nullptr;    // hover-throttle estimator state, SoA [8][B]
+    double *sThr = nullptr;    // staging: vz[B] throttle[B] k[B] | u0[B][4] cmd[B][4]
     bool have_mlp = false;
     // staging for the host-pointer entry points
     double *sx0 = nullptr, *sxr = nullptr, *sur = nullptr, *sother = nullptr, *sego = nullptr, *su0 = nullptr, *sdbg = nullptr;
@@ -387,7 +453,7 @@ int ndp_destroy(ndp_handle *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    void *ptrs[] = {h->dKC, h->dX, h->dU, h->dStatus, h->dIters, h->dForce, h->dFrag, h->sx0, h->sxr, h->sur,
+    void *ptrs[] = {h->dThr, h->sThr, h->dKC, h->dX, h->dU, h->dStatus, h->dIters, h->dForce, h->dFrag, h->sx0, h->sxr, h->sur,
                     h->sother, h->sego, h->su0, h->sdbg, h->sf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -431,6 +497,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     ALLOC(h->dX, nxs(h) * 8); ALLOC(h->dU, nus(h) * 8);
     ALLOC(h->dStatus, B * 4); ALLOC(h->dIters, B * 4);
     ALLOC(h->dForce, nfs(h) * 4); ALLOC(h->dFrag, FR_TOTAL * 4); ALLOC(h->dKC, KC_SC * 8);
+    ALLOC(h->dThr, B * 8 * 8); ALLOC(h->sThr, B * 11 * 8);
     {
         double kc[KC_SC];
         fill_kc(h->P, kc);
@@ -457,6 +524,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     for (const void *fn : fns)
         if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess)
             return fail("hipFuncSetAttribute", e);
+    hipLaunchKernelGGL(throttle_reset_kernel, dim3((cfg->batch + 255) / 256), dim3(256), 0, h->stream, h->dThr, 50.0, cfg->batch);
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
     *out = h;
     return 0;
@@ -703,6 +771,105 @@ int ndp_get_status(ndp_handle *h, int32_t *status, int32_t *ipm_iters)
     NDP_HIP(h, hipStreamSynchronize(h->stream));
     if (status) NDP_HIP(h, hipMemcpy(status, h->dStatus, (size_t)h->cfg.batch * 4, hipMemcpyDeviceToHost));
     if (ipm_iters) NDP_HIP(h, hipMemcpy(ipm_iters, h->dIters, (size_t)h->cfg.batch * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- f3: hover-throttle estimator + actuator command (reference constants: params/estimator_params.py:13-18)
+static ThrCfg thr_cfg(const ndp_handle *h)
+{
+    const double ts = 0.02, tau = 0.05;
+    ThrCfg c;
+    c.a1 = (2.0 * tau - ts) / (2.0 * tau + ts);
+    c.a2 = 2.0 / (2.0 * tau + ts);
+    c.hm = 1.0 / h->cfg.mass;
+    c.g = h->cfg.gravity;
+    c.R = 1.225; c.Q0 = 0.1; c.Q1 = 0.1;
+    c.mass = h->cfg.mass;
+    return c;
+}
+
+int ndp_throttle_reset(ndp_handle *h)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(throttle_reset_kernel, dim3((h->cfg.batch + 255) / 256), dim3(256), 0, h->stream, h->dThr, 50.0, h->cfg.batch);
+    NDP_HIP(h, hipGetLastError());
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ndp_throttle_update_device(ndp_handle *h, const void *d_vz, const void *d_throttle, void *d_k, void *stream)
+{
+    if (!h || !d_vz || !d_throttle || !d_k) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(throttle_kernel, dim3((h->cfg.batch + 255) / 256), dim3(256), 0, s, thr_cfg(h), h->dThr,
+                       (const double *)d_vz, (const double *)d_throttle, (double *)d_k, h->cfg.batch);
+    NDP_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int ndp_throttle_update(ndp_handle *h, const double *vz, const double *throttle, double *k)
+{
+    if (!h || !vz || !throttle || !k) return -1;
+    const size_t B = h->cfg.batch;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        NDP_HIP(h, hipSetDevice(h->cfg.device));
+        NDP_HIP(h, hipMemcpyAsync(h->sThr, vz, B * 8, hipMemcpyHostToDevice, h->stream));
+        NDP_HIP(h, hipMemcpyAsync(h->sThr + B, throttle, B * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    int rc = ndp_throttle_update_device(h, h->sThr, h->sThr + B, h->sThr + 2 * B, nullptr);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipMemcpyAsync(k, h->sThr + 2 * B, B * 8, hipMemcpyDeviceToHost, h->stream));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ndp_actuator_cmd_device(ndp_handle *h, const void *d_u0, const void *d_k, void *d_cmd, void *stream)
+{
+    if (!h || !d_u0 || !d_k || !d_cmd) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(actuator_kernel, dim3((h->cfg.batch + 255) / 256), dim3(256), 0, s, (const double *)d_u0,
+                       (const double *)d_k, (double *)d_cmd, h->cfg.mass, h->cfg.batch);
+    NDP_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int ndp_actuator_cmd(ndp_handle *h, const double *u0, const double *k, double *cmd)
+{
+    if (!h || !u0 || !k || !cmd) return -1;
+    const size_t B = h->cfg.batch;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        NDP_HIP(h, hipSetDevice(h->cfg.device));
+        NDP_HIP(h, hipMemcpyAsync(h->sThr + 2 * B, k, B * 8, hipMemcpyHostToDevice, h->stream));
+        NDP_HIP(h, hipMemcpyAsync(h->sThr + 3 * B, u0, B * 32, hipMemcpyHostToDevice, h->stream));
+    }
+    int rc = ndp_actuator_cmd_device(h, h->sThr + 3 * B, h->sThr + 2 * B, h->sThr + 7 * B, nullptr);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipMemcpyAsync(cmd, h->sThr + 7 * B, B * 32, hipMemcpyDeviceToHost, h->stream));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ndp_throttle_get_state(ndp_handle *h, double *state)
+{
+    if (!h || !state) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const size_t B = h->cfg.batch;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    std::vector<double> soa(B * 8);
+    NDP_HIP(h, hipMemcpy(soa.data(), h->dThr, B * 64, hipMemcpyDeviceToHost));
+    for (size_t v = 0; v < B; ++v)
+        for (int i = 0; i < 8; ++i) state[v * 8 + i] = soa[(size_t)i * B + v];
     return 0;
 }
 

@@ -711,3 +711,65 @@ void orc_downwash_batch(const float *blob, int B, int N, double r_horiz, const d
         orc_downwash(blob, N, r_horiz, other + (size_t)i * (N + 1) * NX, ego_ref + (size_t)i * (N + 1) * NX,
                      ego_xy ? ego_xy + (size_t)i * 2 : NULL, f_out + (size_t)i * (N + 1) * 3);
 }
+
+/* ------------------------------------------------- f3: hover-throttle estimator */
+
+void orc_thr_default_cfg(orc_thr_cfg *c)
+{
+    c->ts = 0.02;        /* params/estimator_params.py:15 */
+    c->tau = 0.05;       /* differentiator.py:17 */
+    c->mass = 1.4844;    /* params/fhnp_params.py:9 */
+    c->g = 9.81;
+    c->R = 1.225;        /* params/estimator_params.py:17 */
+    c->Q0 = 0.1;         /* params/estimator_params.py:18 */
+    c->Q1 = 0.1;
+    c->k_init = 50.0;    /* params/estimator_params.py:13 */
+}
+
+void orc_thr_reset(const orc_thr_cfg *c, int V, double *st)
+{
+    for (int v = 0; v < V; ++v) {
+        double *s = st + (size_t)v * 8;
+        s[0] = 0.0; s[1] = c->k_init;                 /* hover_throttle_estimator.py:21 */
+        s[2] = 1.0; s[3] = 0.0; s[4] = 0.0; s[5] = 1.0; /* P = I  :22 */
+        s[6] = 0.0; s[7] = 0.0;                       /* differentiator.py:12-13 */
+    }
+}
+
+void orc_thr_update(const orc_thr_cfg *c, int V, double *st, const double *vz, const double *throttle, double *k_out)
+{
+    const double a1 = (2.0 * c->tau - c->ts) / (2.0 * c->tau + c->ts);   /* differentiator.py:18-19 */
+    const double a2 = 2.0 / (2.0 * c->tau + c->ts);
+    const double hm = 1.0 / c->mass;                                      /* H = [1/mass, 0]  :31 */
+    for (int v = 0; v < V; ++v) {
+        double *s = st + (size_t)v * 8;
+        const double az = a1 * s[7] + a2 * (vz[v] - s[6]);                /* differentiator.py:21-23 */
+        s[6] = vz[v];
+        s[7] = az;
+        const double th = throttle[v];
+        if (0.1 < th && th < 1.0) {                                       /* :40 */
+            const double z = az + c->g;
+            /* P = Phi P Phi' + Q with Phi = [[0, th], [0, 1]]   :45 */
+            const double P11 = s[5];
+            const double p00 = (th * P11) * th + c->Q0, p01 = th * P11, p10 = P11 * th, p11 = P11 + c->Q1;
+            /* K = P H' inv(H P H' + R)   :46 */
+            const double inv = 1.0 / ((hm * p00) * hm + c->R);
+            const double K0 = (p00 * hm) * inv, K1 = (p10 * hm) * inv;
+            /* x = Phi x; x = x + K (z - H x)   :47-48 */
+            const double x0 = th * s[1], x1 = s[1];
+            const double innov = z - hm * x0;
+            s[0] = x0 + K0 * innov;
+            s[1] = x1 + K1 * innov;
+            /* P = (I - K H) P   :49 */
+            const double i00 = 1.0 - K0 * hm, i10 = -(K1 * hm);
+            s[2] = i00 * p00; s[3] = i00 * p01;
+            s[4] = i10 * p00 + p10; s[5] = i10 * p01 + p11;
+        }
+        k_out[v] = s[1];                                                   /* :51 */
+    }
+}
+
+void orc_att_thrust(const orc_thr_cfg *c, int V, const double *cacc, const double *k, double *thrust)
+{
+    for (int v = 0; v < V; ++v) thrust[v] = k[v] != 0.0 ? cacc[v] * c->mass / k[v] : 0.0;   /* nmpc_node.py:281 */
+}

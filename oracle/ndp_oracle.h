@@ -112,6 +112,15 @@ void orc_downwash(const float *blob, int N, double r_horiz, const double *other,
 void orc_downwash_batch(const float *blob, int B, int N, double r_horiz, const double *other,
                         const double *ego_ref, const double *ego_xy, float *f_out, int nthreads);
 
+/* f3: HoverThrottleEstimator.update (hv_throttle_est/hover_throttle_estimator.py:37-53) with its
+ * Tustin differentiator (differentiator.py:10-23), one estimator per vehicle, state = [x0,x1,P00,P01,P10,P11,
+ * vz_prev, az_prev]; and nmpc_u_2_att_tgt's thrust conversion (nmpc_node.py:273-283). */
+typedef struct { double ts, tau, mass, g, R, Q0, Q1, k_init; } orc_thr_cfg;
+void orc_thr_default_cfg(orc_thr_cfg *c);
+void orc_thr_reset(const orc_thr_cfg *c, int V, double *state /*V x 8*/);
+void orc_thr_update(const orc_thr_cfg *c, int V, double *state, const double *vz, const double *throttle, double *k_out);
+void orc_att_thrust(const orc_thr_cfg *c, int V, const double *cacc, const double *k, double *thrust);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,3 +163,33 @@ def downwash_batch(blob, other, ego_ref, ego_xy, r_horiz=1.0, nthreads=0):
     lib().orc_downwash_batch(_p(blob), C.c_int(B), C.c_int(Np1 - 1), C.c_double(r_horiz), _p(other), _p(ego_ref),
                              _p(ego_xy), _p(out), C.c_int(nthreads))
     return out
+
+
+class OrcThrCfg(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("ts", "tau", "mass", "g", "R", "Q0", "Q1", "k_init")]
+
+
+def thr_default_cfg():
+    c = OrcThrCfg()
+    lib().orc_thr_default_cfg(C.byref(c))
+    return c
+
+
+def thr_reset(cfg, V):
+    st = np.zeros((V, 8))
+    lib().orc_thr_reset(C.byref(cfg), C.c_int(V), _p(st))
+    return st
+
+
+def thr_update(cfg, state, vz, throttle):
+    vz, throttle = _f64(vz), _f64(throttle)
+    k = np.zeros(state.shape[0])
+    lib().orc_thr_update(C.byref(cfg), C.c_int(state.shape[0]), _p(state), _p(vz), _p(throttle), _p(k))
+    return k
+
+
+def att_thrust(cfg, cacc, k):
+    cacc, k = _f64(cacc), _f64(k)
+    out = np.zeros_like(k)
+    lib().orc_att_thrust(C.byref(cfg), C.c_int(k.size), _p(cacc), _p(k), _p(out))
+    return out
