@@ -107,7 +107,10 @@ def main():
     host0 = ndist.make_formation_shard(B, rank, world, N=N, t0=0.0)
 
     eng = ndp.BatchedNMPC(B, N=N, disturbance=downwash, qp_mode=args.qp_mode, device=local_rank)
-    stream = torch.cuda.current_stream()
+    # an explicit non-default stream: torch's default stream has handle 0, which the C-ABI reads as "use the
+    # library's own stream" -- with a real handle the all-gather (N > 1) and the kernel are ordered on ONE stream
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     u0 = torch.empty(B, 4, dtype=torch.float64, device=dev)
     gathered = torch.empty(world, B, N + 1, 10, dtype=torch.float64, device=dev) if world > 1 else None
 

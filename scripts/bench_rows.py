@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Measurement of the widened rows -- separate from bench.py, whose line is the headline metric.
+
+    python scripts/bench_rows.py --row throttle --batch 4194304
+
+throttle (f3): one KF + differentiator update + actuator command per vehicle and tick.  Elementwise, HBM-bound:
+algorithmic bytes per vehicle = read vz 8 + throttle 8 + state 64, write state 64 + k 8 (152 B) for the estimator,
+read u0 32 + k 8, write cmd 32 (72 B) for the actuator command.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--row", default="throttle")
+    ap.add_argument("--batch", type=int, default=1 << 22)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    a = ap.parse_args()
+    import torch
+    import ndp_nmpc_qd_amd as ndp
+    B = a.batch
+    dev = torch.device("cuda:0")
+    eng = ndp.BatchedNMPC(B, N=2, load_mlp=False)       # tiny horizon: only the estimator state matters here
+    vz = torch.randn(B, dtype=torch.float64, device=dev) * 0.1
+    th = torch.rand(B, dtype=torch.float64, device=dev) * 0.8 + 0.15
+    k = torch.empty(B, dtype=torch.float64, device=dev)
+    u0 = torch.randn(B, 4, dtype=torch.float64, device=dev)
+    cmd = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    import ctypes as C
+    lib, h = eng._lib, eng._h
+    st = torch.cuda.Stream(device=dev)       # non-default: handle 0 would mean "the library's own stream"
+    torch.cuda.set_stream(st)
+    s = C.c_void_p(st.cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    def step():
+        assert lib.ndp_throttle_update_device(h, p(vz), p(th), p(k), s) == 0
+        assert lib.ndp_actuator_cmd_device(h, p(u0), p(k), p(cmd), s) == 0
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    dev_s = e0.elapsed_time(e1) * 1e-3 / a.steps
+    bytes_per = 152 + 72
+    print(json.dumps({"row": "f3 hover-throttle estimator + actuator command", "metric": "vehicle updates/s",
+                      "value": B * a.steps / el, "batch": B, "ms_per_step": el / a.steps * 1e3, "dtype": "f64",
+                      "roofline": {"bound": "hbm", "achieved": bytes_per * B / dev_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                   "frac": bytes_per * B / dev_s / 1e9 / 8000.0, "algorithmic_bytes_per_vehicle": bytes_per}}))
+
+
+if __name__ == "__main__":
+    main()
