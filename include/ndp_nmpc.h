@@ -139,6 +139,22 @@ int ndp_actuator_cmd(ndp_handle *h, const double *u0, const double *k_throttle, 
 int ndp_actuator_cmd_device(ndp_handle *h, const void *d_u0, const void *d_k_throttle, void *d_cmd, void *stream);
 int ndp_throttle_get_state(ndp_handle *h, double *state /* [B][8]: x0 x1 P00 P01 P10 P11 vz_prev az_prev */);
 
+/* ---- "next" row f2: the step beside the path -- the follower's reference relay (nmpc_follower_node.py:44-77).
+ *   ndp_relay_formation: one formation_ref message per instance, form[B][3]; three AlphaFilters (alpha 0.8,
+ *                        y0 = first message; hv_throttle_est/alpha_filter.py:11-20) -> filtered offset, kept on the device
+ *   ndp_relay_reference: leader windows xr_lead[B][N+1][10] -> follower reference xr_out (x[:,0:3] += offset);
+ *                        the leader's ur is used unchanged (:72-74), so it needs no copy
+ *   ndp_relay_reset    : filters back to "no message seen" */
+int ndp_relay_reset(ndp_handle *h);
+int ndp_relay_formation(ndp_handle *h, const double *form, double *offset_out /* [B][3] or NULL */);
+int ndp_relay_reference(ndp_handle *h, const double *xr_lead, double *xr_out);
+int ndp_relay_reference_device(ndp_handle *h, const void *d_xr_lead, void *d_xr_out, void *stream);
+
+/* ---- "next" row f4: plant step for closed-loop rollouts on the device (dop_sim is absent from the reference).
+ * x[B][10] in/out, u[B][4], f[B][3] force or NULL; RK4 with `substeps` over dt, quaternion renormalised. */
+int ndp_plant_step(ndp_handle *h, double *x, const double *u, const double *f, double dt, int substeps);
+int ndp_plant_step_device(ndp_handle *h, void *d_x, const void *d_u, const void *d_f, double dt, int substeps, void *stream);
+
 /* Test hook: number of doubles of the LDS image dump, and a step that also dumps it (B = 1 use). */
 int ndp_debug_lds_doubles(int N);
 /* Test hook: one v_mfma_f64_16x16x4_f64 on caller-chosen per-lane operands a[64], b[64], c[4][64];

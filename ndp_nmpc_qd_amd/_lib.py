@@ -34,7 +34,8 @@ EXPORTS = [
     "ndp_reset_device", "ndp_step", "ndp_step_device", "ndp_downwash", "ndp_downwash_device", "ndp_get_iterate",
     "ndp_set_iterate", "ndp_get_status", "ndp_device_iterate_x", "ndp_device_iterate_u", "ndp_device_force",
     "ndp_synchronize", "ndp_timing_enable", "ndp_timing_read", "ndp_debug_lds_doubles", "ndp_step_debug", "ndp_debug_mfma_probe", "ndp_throttle_reset", "ndp_throttle_update",
-    "ndp_throttle_update_device", "ndp_actuator_cmd", "ndp_actuator_cmd_device", "ndp_throttle_get_state",
+    "ndp_throttle_update_device", "ndp_actuator_cmd", "ndp_actuator_cmd_device", "ndp_throttle_get_state", "ndp_relay_reset", "ndp_relay_formation",
+    "ndp_relay_reference", "ndp_relay_reference_device", "ndp_plant_step", "ndp_plant_step_device",
 ]
 
 _lib = None
@@ -87,6 +88,12 @@ def load():
     lib.ndp_actuator_cmd.argtypes = [vp] * 4
     lib.ndp_actuator_cmd_device.argtypes = [vp] * 5
     lib.ndp_throttle_get_state.argtypes = [vp, vp]
+    lib.ndp_relay_reset.argtypes = [vp]
+    lib.ndp_relay_formation.argtypes = [vp, vp, vp]
+    lib.ndp_relay_reference.argtypes = [vp, vp, vp]
+    lib.ndp_relay_reference_device.argtypes = [vp, vp, vp, vp]
+    lib.ndp_plant_step.argtypes = [vp, vp, vp, vp, C.c_double, C.c_int]
+    lib.ndp_plant_step_device.argtypes = [vp, vp, vp, vp, C.c_double, C.c_int, vp]
     _lib = lib
     return lib
 

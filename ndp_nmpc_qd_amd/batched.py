@@ -131,6 +131,33 @@ class BatchedNMPC:
         self._check(self._lib.ndp_actuator_cmd(self._h, _lib.ptr(u0), _lib.ptr(k), _lib.ptr(cmd)), "ndp_actuator_cmd")
         return cmd
 
+    # ------------------------------------------------------------------ f2: follower reference relay
+    def relay_reset(self):
+        self._check(self._lib.ndp_relay_reset(self._h), "ndp_relay_reset")
+
+    def relay_formation(self, form):
+        """One formation_ref message per instance (nmpc_follower_node.py:44-56): returns the filtered offsets [B,3]."""
+        form = _lib.f64(form, (self.B, 3))
+        off = np.empty((self.B, 3))
+        self._check(self._lib.ndp_relay_formation(self._h, _lib.ptr(form), _lib.ptr(off)), "ndp_relay_formation")
+        return off
+
+    def relay_reference(self, xr_lead):
+        """Leader windows -> follower references (nmpc_follower_node.py:58-74); ur is the leader's, unchanged."""
+        xr_lead = _lib.f64(xr_lead, (self.B, self.N + 1, 10))
+        out = np.empty_like(xr_lead)
+        self._check(self._lib.ndp_relay_reference(self._h, _lib.ptr(xr_lead), _lib.ptr(out)), "ndp_relay_reference")
+        return out
+
+    # ------------------------------------------------------------------ f4: plant step (closed-loop rollouts)
+    def plant_step(self, x, u, f=None, dt=CP.ts_nmpc, substeps=4):
+        x = _lib.f64(x, (self.B, 10)).copy()
+        u = _lib.f64(u, (self.B, 4))
+        f = _lib.f64(f, (self.B, 3))
+        self._check(self._lib.ndp_plant_step(self._h, _lib.ptr(x), _lib.ptr(u), _lib.ptr(f), float(dt), int(substeps)),
+                    "ndp_plant_step")
+        return x
+
     def get_iterate(self):
         X = np.empty((self.B, self.N + 1, 10))
         U = np.empty((self.B, self.N, 4))

@@ -372,6 +372,92 @@ __global__ __launch_bounds__(256) void actuator_kernel(const double *__restrict_
     reinterpret_cast<double2 *>(cmd)[2 * v + 1] = o1;
 }
 
+// ------------------------------------------------------------------------------------------ f2 kernels
+// AlphaFilter per instance and axis (alpha_filter.py:19; individually rounded like the Python expression)
+__global__ __launch_bounds__(256) void relay_formation_kernel(double alpha, double *__restrict__ st, const double *__restrict__ form, int B)
+{
+    const int v = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (v >= B) return;
+    const bool init = st[v * 4 + 3] != 0.0;
+    const double oma = 1.0 - alpha;
+    for (int a = 0; a < 3; ++a) {
+        const double u = form[v * 3 + a];
+        const double y = init ? st[v * 4 + a] : u;
+        st[v * 4 + a] = __dadd_rn(__dmul_rn(alpha, y), __dmul_rn(oma, u));
+    }
+    st[v * 4 + 3] = 1.0;
+}
+
+// follower reference = leader window with the filtered offset added to the positions; one thread per state row
+// (80 contiguous bytes in, 80 out: five double2 accesses), HBM-bound: 3360 B per instance at N = 20
+__global__ __launch_bounds__(256) void relay_reference_kernel(const double *__restrict__ st, const double *__restrict__ xr_lead,
+                                                              double *__restrict__ xr_out, int rows, int np1)
+{
+    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= rows) return;
+    const int inst = r / np1;
+    const double ox = st[inst * 4], oy = st[inst * 4 + 1], oz = st[inst * 4 + 2];
+    const double2 *src = reinterpret_cast<const double2 *>(xr_lead) + (size_t)r * 5;
+    double2 *dst = reinterpret_cast<double2 *>(xr_out) + (size_t)r * 5;
+    double2 a = src[0], b = src[1];
+    a.x += ox; a.y += oy; b.x += oz;
+    dst[0] = a; dst[1] = b; dst[2] = src[2]; dst[3] = src[3]; dst[4] = src[4];
+}
+
+// ------------------------------------------------------------------------------------------ f4 kernel
+// plant: the OCP's own dynamics (nmpc_body_rate_ctl.py:147-158 + f/mass), RK4 substeps, quaternion renormalised
+__device__ __forceinline__ void plant_f(const double *x, const double *u, const double *acc, double *d)
+{
+    const double qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    d[0] = x[3]; d[1] = x[4]; d[2] = x[5];
+    d[3] = 2.0 * (qx * qz + qw * qy) * u[3] + acc[0];
+    d[4] = 2.0 * (qy * qz - qw * qx) * u[3] + acc[1];
+    d[5] = (1.0 - 2.0 * qx * qx - 2.0 * qy * qy) * u[3] + acc[2];
+    d[6] = (-u[0] * qx - u[1] * qy - u[2] * qz) * 0.5;
+    d[7] = (u[0] * qw + u[2] * qy - u[1] * qz) * 0.5;
+    d[8] = (u[1] * qw - u[2] * qx + u[0] * qz) * 0.5;
+    d[9] = (u[2] * qw + u[1] * qx - u[0] * qy) * 0.5;
+}
+
+__global__ __launch_bounds__(256) void plant_kernel(double *__restrict__ x, const double *__restrict__ u, const double *__restrict__ f,
+                                                    double h, int sub, double inv_mass, double g, int B)
+{
+    const int v = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (v >= B) return;
+    double xv[10], uv[4], acc[3] = {0.0, 0.0, -g};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const double2 t = reinterpret_cast<const double2 *>(x)[(size_t)v * 5 + i];
+        xv[2 * i] = t.x; xv[2 * i + 1] = t.y;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double2 t = reinterpret_cast<const double2 *>(u)[(size_t)v * 2 + i];
+        uv[2 * i] = t.x; uv[2 * i + 1] = t.y;
+    }
+    if (f) { acc[0] = f[v * 3] * inv_mass; acc[1] = f[v * 3 + 1] * inv_mass; acc[2] = f[v * 3 + 2] * inv_mass - g; }
+    for (int s = 0; s < sub; ++s) {
+        double k1[10], k2[10], k3[10], k4[10], xs[10];
+        plant_f(xv, uv, acc, k1);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) xs[i] = xv[i] + 0.5 * h * k1[i];
+        plant_f(xs, uv, acc, k2);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) xs[i] = xv[i] + 0.5 * h * k2[i];
+        plant_f(xs, uv, acc, k3);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) xs[i] = xv[i] + h * k3[i];
+        plant_f(xs, uv, acc, k4);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) xv[i] += h / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+    }
+    const double n = sqrt(xv[6] * xv[6] + xv[7] * xv[7] + xv[8] * xv[8] + xv[9] * xv[9]);
+#pragma unroll
+    for (int i = 6; i < 10; ++i) xv[i] /= n;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) reinterpret_cast<double2 *>(x)[(size_t)v * 5 + i] = make_double2(xv[2 * i], xv[2 * i + 1]);
+}
+
 }  // namespace ndp
 
 // ------------------------------------------------------------------------------------------ C-ABI
@@ -389,6 +475,7 @@ struct ndp_handle {
     float *dForce = nullptr, *dFrag = nullptr;
     double *dKC = nullptr;     // constants block of the LDS image (fill_kc)
     double *dThr = nullptr;    // hover-throttle estimator state, SoA [8][B]
+    double *dRelay = nullptr;  // follower relay: [B][4] = filtered offset xyz + initialised flag
     double *sThr = nullptr;    // staging: vz[B] throttle[B] k[B] | u0[B][4] cmd[B][4]
     bool have_mlp = false;
     // staging for the host-pointer entry points
@@ -453,7 +540,7 @@ int ndp_destroy(ndp_handle *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    void *ptrs[] = {h->dThr, h->sThr, h->dKC, h->dX, h->dU, h->dStatus, h->dIters, h->dForce, h->dFrag, h->sx0, h->sxr, h->sur,
+    void *ptrs[] = {h->dRelay, h->dThr, h->sThr, h->dKC, h->dX, h->dU, h->dStatus, h->dIters, h->dForce, h->dFrag, h->sx0, h->sxr, h->sur,
                     h->sother, h->sego, h->su0, h->sdbg, h->sf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -498,6 +585,8 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     ALLOC(h->dStatus, B * 4); ALLOC(h->dIters, B * 4);
     ALLOC(h->dForce, nfs(h) * 4); ALLOC(h->dFrag, FR_TOTAL * 4); ALLOC(h->dKC, KC_SC * 8);
     ALLOC(h->dThr, B * 8 * 8); ALLOC(h->sThr, B * 11 * 8);
+    ALLOC(h->dRelay, B * 4 * 8);
+    (void)hipMemsetAsync(h->dRelay, 0, B * 4 * 8, h->stream);
     {
         double kc[KC_SC];
         fill_kc(h->P, kc);
@@ -870,6 +959,99 @@ int ndp_throttle_get_state(ndp_handle *h, double *state)
     NDP_HIP(h, hipMemcpy(soa.data(), h->dThr, B * 64, hipMemcpyDeviceToHost));
     for (size_t v = 0; v < B; ++v)
         for (int i = 0; i < 8; ++i) state[v * 8 + i] = soa[(size_t)i * B + v];
+    return 0;
+}
+
+// ---- f2: follower reference relay
+int ndp_relay_reset(ndp_handle *h)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipMemsetAsync(h->dRelay, 0, (size_t)h->cfg.batch * 32, h->stream));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ndp_relay_formation(ndp_handle *h, const double *form, double *offset_out)
+{
+    if (!h || !form) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const size_t B = h->cfg.batch;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipMemcpyAsync(h->sThr, form, B * 24, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(relay_formation_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, 0.8, h->dRelay, (const double *)h->sThr, (int)B);
+    NDP_HIP(h, hipGetLastError());
+    if (offset_out) {
+        std::vector<double> st(B * 4);
+        NDP_HIP(h, hipMemcpyAsync(st.data(), h->dRelay, B * 32, hipMemcpyDeviceToHost, h->stream));
+        NDP_HIP(h, hipStreamSynchronize(h->stream));
+        for (size_t v = 0; v < B; ++v)
+            for (int a = 0; a < 3; ++a) offset_out[v * 3 + a] = st[v * 4 + a];
+    } else {
+        NDP_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+int ndp_relay_reference_device(ndp_handle *h, const void *d_xr_lead, void *d_xr_out, void *stream)
+{
+    if (!h || !d_xr_lead || !d_xr_out) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    const int np1 = h->cfg.N + 1, rows = h->cfg.batch * np1;
+    hipLaunchKernelGGL(relay_reference_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, (const double *)h->dRelay,
+                       (const double *)d_xr_lead, (double *)d_xr_out, rows, np1);
+    NDP_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int ndp_relay_reference(ndp_handle *h, const double *xr_lead, double *xr_out)
+{
+    if (!h || !xr_lead || !xr_out) return -1;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        NDP_HIP(h, hipSetDevice(h->cfg.device));
+        NDP_HIP(h, hipMemcpyAsync(h->sother, xr_lead, nxs(h) * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    int rc = ndp_relay_reference_device(h, h->sother, h->sxr, nullptr);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipMemcpyAsync(xr_out, h->sxr, nxs(h) * 8, hipMemcpyDeviceToHost, h->stream));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- f4: plant step
+int ndp_plant_step_device(ndp_handle *h, void *d_x, const void *d_u, const void *d_f, double dt, int substeps, void *stream)
+{
+    if (!h || !d_x || !d_u || substeps < 1) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(plant_kernel, dim3((h->cfg.batch + 255) / 256), dim3(256), 0, s, (double *)d_x, (const double *)d_u,
+                       (const double *)d_f, dt / substeps, substeps, 1.0 / h->cfg.mass, h->cfg.gravity, h->cfg.batch);
+    NDP_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int ndp_plant_step(ndp_handle *h, double *x, const double *u, const double *f, double dt, int substeps)
+{
+    if (!h || !x || !u) return -1;
+    const size_t B = h->cfg.batch;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        NDP_HIP(h, hipSetDevice(h->cfg.device));
+        NDP_HIP(h, hipMemcpyAsync(h->sx0, x, B * 80, hipMemcpyHostToDevice, h->stream));
+        NDP_HIP(h, hipMemcpyAsync(h->su0, u, B * 32, hipMemcpyHostToDevice, h->stream));
+        if (f) NDP_HIP(h, hipMemcpyAsync(h->sThr, f, B * 24, hipMemcpyHostToDevice, h->stream));
+    }
+    int rc = ndp_plant_step_device(h, h->sx0, h->su0, f ? h->sThr : nullptr, dt, substeps, nullptr);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipMemcpyAsync(x, h->sx0, B * 80, hipMemcpyDeviceToHost, h->stream));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 

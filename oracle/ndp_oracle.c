@@ -773,3 +773,54 @@ void orc_att_thrust(const orc_thr_cfg *c, int V, const double *cacc, const doubl
 {
     for (int v = 0; v < V; ++v) thrust[v] = k[v] != 0.0 ? cacc[v] * c->mass / k[v] : 0.0;   /* nmpc_node.py:281 */
 }
+
+/* ------------------------------------------------- f2: follower reference relay */
+
+void orc_relay_formation(double alpha, int V, double *st, const double *form)
+{
+    for (int v = 0; v < V; ++v) {
+        double *s = st + (size_t)v * 4;
+        for (int a = 0; a < 3; ++a) {
+            const double u = form[v * 3 + a];
+            if (s[3] == 0.0) s[a] = u;                          /* AlphaFilter(alpha, y0=msg)  nmpc_follower_node.py:45-52 */
+            s[a] = alpha * s[a] + (1.0 - alpha) * u;            /* alpha_filter.py:19 */
+        }
+        s[3] = 1.0;
+    }
+}
+
+void orc_relay_reference(int V, int N, const double *st, const double *xr_lead, double *xr_out)
+{
+    for (int v = 0; v < V; ++v)
+        for (int k = 0; k <= N; ++k)
+            for (int i = 0; i < NX; ++i) {
+                const size_t idx = ((size_t)v * (N + 1) + k) * NX + i;
+                xr_out[idx] = i < 3 ? xr_lead[idx] + st[v * 4 + i] : xr_lead[idx];   /* nmpc_follower_node.py:66-70 */
+            }
+}
+
+/* ------------------------------------------------- f4: plant step */
+
+void orc_plant_step(const orc_cfg *c, int V, double *x, const double *u, const double *f, double dt, int sub)
+{
+    orc_cfg cc = *c;
+    cc.use_fd = f != NULL;
+    const double h = dt / sub;
+    for (int v = 0; v < V; ++v) {
+        double *xv = x + (size_t)v * NX;
+        const double *uv = u + (size_t)v * NU, *fv = f ? f + (size_t)v * 3 : NULL;
+        for (int s = 0; s < sub; ++s) {
+            double k1[NX], k2[NX], k3[NX], k4[NX], xs[NX];
+            orc_dynamics(&cc, xv, uv, fv, k1);
+            for (int i = 0; i < NX; ++i) xs[i] = xv[i] + 0.5 * h * k1[i];
+            orc_dynamics(&cc, xs, uv, fv, k2);
+            for (int i = 0; i < NX; ++i) xs[i] = xv[i] + 0.5 * h * k2[i];
+            orc_dynamics(&cc, xs, uv, fv, k3);
+            for (int i = 0; i < NX; ++i) xs[i] = xv[i] + h * k3[i];
+            orc_dynamics(&cc, xs, uv, fv, k4);
+            for (int i = 0; i < NX; ++i) xv[i] += h / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        }
+        const double n = sqrt(xv[6] * xv[6] + xv[7] * xv[7] + xv[8] * xv[8] + xv[9] * xv[9]);
+        for (int i = 6; i < 10; ++i) xv[i] /= n;
+    }
+}

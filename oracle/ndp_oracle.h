@@ -121,6 +121,16 @@ void orc_thr_reset(const orc_thr_cfg *c, int V, double *state /*V x 8*/);
 void orc_thr_update(const orc_thr_cfg *c, int V, double *state, const double *vz, const double *throttle, double *k_out);
 void orc_att_thrust(const orc_thr_cfg *c, int V, const double *cacc, const double *k, double *thrust);
 
+/* f2: follower reference relay.  AlphaFilter y = a*y + (1-a)*u with y0 = first input
+ * (hv_throttle_est/alpha_filter.py:11-20, nmpc_follower_node.py:44-56); reference x[:,0:3] += offset, u copied
+ * (nmpc_follower_node.py:58-74).  state[V][4] = [ox, oy, oz, initialised]. */
+void orc_relay_formation(double alpha, int V, double *state, const double *form /*V x 3*/);
+void orc_relay_reference(int V, int N, const double *state, const double *xr_lead, double *xr_out);
+
+/* f4: plant = a1 dynamics (+ f/mass), RK4 with `sub` substeps over dt, quaternion renormalised
+ * (no reference implementation exists: dop_sim is an empty submodule). x[V][10] in/out, u[V][4], f[V][3] or NULL. */
+void orc_plant_step(const orc_cfg *c, int V, double *x, const double *u, const double *f, double dt, int sub);
+
 #ifdef __cplusplus
 }
 #endif

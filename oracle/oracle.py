@@ -193,3 +193,23 @@ def att_thrust(cfg, cacc, k):
     out = np.zeros_like(k)
     lib().orc_att_thrust(C.byref(cfg), C.c_int(k.size), _p(cacc), _p(k), _p(out))
     return out
+
+
+def relay_formation(state, form, alpha=0.8):
+    form = _f64(form)
+    lib().orc_relay_formation(C.c_double(alpha), C.c_int(state.shape[0]), _p(state), _p(form))
+    return state[:, 0:3].copy()
+
+
+def relay_reference(state, xr_lead):
+    xr_lead = _f64(xr_lead)
+    out = np.zeros_like(xr_lead)
+    lib().orc_relay_reference(C.c_int(xr_lead.shape[0]), C.c_int(xr_lead.shape[1] - 1), _p(state), _p(xr_lead), _p(out))
+    return out
+
+
+def plant_step(cfg, x, u, f, dt, sub=4):
+    assert x.dtype == np.float64 and x.flags.c_contiguous
+    u, f = _f64(u), _f64(f)
+    lib().orc_plant_step(C.byref(cfg), C.c_int(x.shape[0]), _p(x), _p(u), _p(f), C.c_double(dt), C.c_int(sub))
+    return x
