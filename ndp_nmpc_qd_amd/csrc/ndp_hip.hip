@@ -18,6 +18,20 @@
 
 namespace ndp {
 
+// Individually rounded multiply / add.  hipcc contracts a*b+c into an FMA by default, and HIP's __dmul_rn/__dadd_rn
+// are plain operators that get re-fused; the reference evaluates the gate, the Kalman filter and the alpha filter
+// in Python/numpy doubles without fusion, so these few expressions are built from non-contractable operations.
+__device__ __forceinline__ double nc_mul(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double nc_add(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+
 // ------------------------------------------------------------------------------------------ RTI kernel
 struct BatchPtrs {
     const double *kc;
@@ -237,12 +251,12 @@ __device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lan
 }
 
 // gate of ndp_nmpc_leader_node.py:65-68: other.x[0] xy against ego ODOMETRY xy, strict '<'.  Individually rounded
-// mul/add (no FMA contraction): the reference evaluates this in Python doubles and must agree at the rim.
+// mul/add (nc_mul / nc_add): the reference evaluates this in Python doubles and must agree at the rim.
 __device__ __forceinline__ bool gate_open(const double *other_inst, const double *ego_xy_inst, double r2)
 {
     const double dx = other_inst[0] - ego_xy_inst[0];
     const double dy = other_inst[1] - ego_xy_inst[1];
-    return __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)) < r2;
+    return nc_add(nc_mul(dx, dx), nc_mul(dy, dy)) < r2;
 }
 
 // Standalone form (DownwashNN.update for arbitrary row counts): one 32-row tile per wave, no tile loop --
@@ -322,7 +336,7 @@ __global__ __launch_bounds__(256) void throttle_kernel(ThrCfg c, double *__restr
     if (v >= B) return;
     const size_t S = (size_t)B;
     const double vzv = vz[v], th = throttle[v];
-    const double az = __dadd_rn(__dmul_rn(c.a1, st[7 * S + v]), __dmul_rn(c.a2, vzv - st[6 * S + v]));   // differentiator.py:21
+    const double az = nc_add(nc_mul(c.a1, st[7 * S + v]), nc_mul(c.a2, vzv - st[6 * S + v]));   // differentiator.py:21
     st[6 * S + v] = vzv;
     st[7 * S + v] = az;
     double x1 = st[1 * S + v];
@@ -330,20 +344,20 @@ __global__ __launch_bounds__(256) void throttle_kernel(ThrCfg c, double *__restr
         const double z = az + c.g;
         const double P11 = st[5 * S + v];
         // numpy evaluates these products without fused multiply-add: keep individually rounded operations
-        const double p01 = __dmul_rn(th, P11), p10 = __dmul_rn(P11, th);
-        const double p00 = __dadd_rn(__dmul_rn(p01, th), c.Q0), p11 = __dadd_rn(P11, c.Q1);
-        const double inv = 1.0 / __dadd_rn(__dmul_rn(__dmul_rn(c.hm, p00), c.hm), c.R);
-        const double K0 = __dmul_rn(__dmul_rn(p00, c.hm), inv), K1 = __dmul_rn(__dmul_rn(p10, c.hm), inv);
-        const double x0p = __dmul_rn(th, x1);
-        const double innov = z - __dmul_rn(c.hm, x0p);
-        st[0 * S + v] = __dadd_rn(x0p, __dmul_rn(K0, innov));
-        x1 = __dadd_rn(x1, __dmul_rn(K1, innov));
+        const double p01 = nc_mul(th, P11), p10 = nc_mul(P11, th);
+        const double p00 = nc_add(nc_mul(p01, th), c.Q0), p11 = nc_add(P11, c.Q1);
+        const double inv = 1.0 / nc_add(nc_mul(nc_mul(c.hm, p00), c.hm), c.R);
+        const double K0 = nc_mul(nc_mul(p00, c.hm), inv), K1 = nc_mul(nc_mul(p10, c.hm), inv);
+        const double x0p = nc_mul(th, x1);
+        const double innov = z - nc_mul(c.hm, x0p);
+        st[0 * S + v] = nc_add(x0p, nc_mul(K0, innov));
+        x1 = nc_add(x1, nc_mul(K1, innov));
         st[1 * S + v] = x1;
-        const double i00 = 1.0 - __dmul_rn(K0, c.hm), i10 = -__dmul_rn(K1, c.hm);
-        st[2 * S + v] = __dmul_rn(i00, p00);
-        st[3 * S + v] = __dmul_rn(i00, p01);
-        st[4 * S + v] = __dadd_rn(__dmul_rn(i10, p00), p10);
-        st[5 * S + v] = __dadd_rn(__dmul_rn(i10, p01), p11);
+        const double i00 = 1.0 - nc_mul(K0, c.hm), i10 = -nc_mul(K1, c.hm);
+        st[2 * S + v] = nc_mul(i00, p00);
+        st[3 * S + v] = nc_mul(i00, p01);
+        st[4 * S + v] = nc_add(nc_mul(i10, p00), p10);
+        st[5 * S + v] = nc_add(nc_mul(i10, p01), p11);
     }
     k_out[v] = x1;
 }
@@ -367,7 +381,7 @@ __global__ __launch_bounds__(256) void actuator_kernel(const double *__restrict_
     const double2 a = reinterpret_cast<const double2 *>(u0)[2 * v], b = reinterpret_cast<const double2 *>(u0)[2 * v + 1];
     const double kk = k[v];
     double2 o0 = a, o1 = b;
-    o1.y = kk != 0.0 ? __dmul_rn(b.y, mass) / kk : 0.0;
+    o1.y = kk != 0.0 ? nc_mul(b.y, mass) / kk : 0.0;
     reinterpret_cast<double2 *>(cmd)[2 * v] = o0;
     reinterpret_cast<double2 *>(cmd)[2 * v + 1] = o1;
 }
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(256) void relay_formation_kernel(double alpha, doub
     for (int a = 0; a < 3; ++a) {
         const double u = form[v * 3 + a];
         const double y = init ? st[v * 4 + a] : u;
-        st[v * 4 + a] = __dadd_rn(__dmul_rn(alpha, y), __dmul_rn(oma, u));
+        st[v * 4 + a] = nc_add(nc_mul(alpha, y), nc_mul(oma, u));
     }
     st[v * 4 + 3] = 1.0;
 }

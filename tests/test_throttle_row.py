@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOL = 1e-12      # fp64 KF: relative tolerance on k_throttle / state (operation order follows the numpy expressions)
+TOL = 1e-12      # fp64 KF: relative tolerance on k_throttle / state (operation order follows the numpy expressions;
+                 # numpy's 2x2 matmuls go through BLAS, whose fusion choices are not specified, hence not bit-exact)
 
 
 @pytest.fixture(scope="module")
