@@ -184,8 +184,9 @@ def main():
         ach_tf = f_qp * B / rti_s / 1e12
         abytes = algorithmic_bytes_per_solve(N, downwash)
         # matrix-pipe occupancy estimate: every v_mfma_f64_16x16x4 / v_mfma_f32_32x32x2 holds the SIMD's pipe 64 cycles
-        # (measured, scripts/ubench); one instance per SIMD: 274 f64 MFMAs per sweep at N = 20, 268 f32 for the MLP tile
-        n_mfma = sweeps * (6 + 8 * (N - 1) + N + 16 * ((N - 1) // 4) + 4 * N) + (268 if fused else 0)
+        # (measured, scripts/ubench); one instance per SIMD: 274 f64 MFMAs per sweep at N = 20; the MLP tile adds 12 f32 and 192 bf16 MFMAs
+        n_f64 = sweeps * (6 + 8 * (N - 1) + N + 16 * ((N - 1) // 4) + 4 * N)
+        pipe_cycles = n_f64 * 64 + ((12 * 64 + 192 * 32) if fused else 0)   # MLP tile: 12 f32 + 192 bf16 (32 clk) MFMAs
         out = {
             "metric": "NMPC solves/sec (N=20, 1 RTI iter + downwash MLP) at batch",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -201,8 +202,8 @@ def main():
                          "unit": "TFLOP/s", "frac": ach_tf / F64_MFMA_PEAK_TFLOPS, "traffic": measured_traffic(B, N, fused),
                          "traffic_note": "HBM bytes per launch, PMC (profiles/r01_pmc_rti_kernel_fused_b1024.json); algorithmic bytes per launch = %d" % (abytes * B),
                          "kernel_us": rti_s * 1e6, "flops_per_solve_f64": f_qp, "riccati_sweeps_per_solve": sweeps,
-                         "fused_mlp_flops_per_solve_f32": f_mlp if fused else 0.0,
-                         "mfma_pipe_busy_est": n_mfma * 64 / (rti_s * 2.4e9),
+                         "fused_mlp_flops_per_solve": f_mlp if fused else 0.0,
+                         "mfma_pipe_busy_est": pipe_cycles / (rti_s * 2.4e9),
                          "hbm_algorithmic_GBps": abytes * B / (rti_s + mlp_s) / 1e9,
                          "hbm_frac": abytes * B / (rti_s + mlp_s) / 1e9 / HBM_PEAK_GBS,
                          "mlp_kernel_us": mlp_s * 1e6 if mlp_n else None},

@@ -483,8 +483,9 @@ struct RtiWave {
     // dependent f64 VALU op costs ~32 cycles and a divide ~100, so a 4-pivot factorisation computed
     // redundantly on every lane was ~40 % of a backward stage.  Lam = R + B'PB + barrier diagonal: R > 0 and
     // the barrier terms only add to the diagonal, so the cofactor expansion is well conditioned here.
-    // Returns, in EVERY lane (g,j), Lam^-1[g][j&3] (callers mask the columns they need) and a PD flag.
-    static NDP_D vd lam_inverse(const Tables &T, lp lds, vd h3, bool &ok)
+    // Returns, in EVERY lane (g,j), the cofactor adj(Lam)[g][j&3] and 1/det(Lam) separately (callers mask the columns
+    // they need): products with adj can start while the det -> reciprocal chain is still running.  Plus a PD flag.
+    static NDP_D void lam_adjugate(const Tables &T, lp lds, vd h3, bool &ok, vd &cof_out, vd &rdet_out)
     {
         W::stp(lds, T.lam_w_off, h3, T.kt_pred);             // H~[12+g][12+b] -> SC[g*4+b]
         W::sync();
@@ -498,7 +499,8 @@ struct RtiWave {
         vd det = W::quad_sum(own * cof);                      // row expansion: lanes 16g..16g+3 form one quad
         vb pd = (det > 0.0) && (!T.lam_diag || (cof > 0.0));
         ok = W::all(pd) && ok;
-        return cof * W::rcp(det);
+        cof_out = cof;
+        rdet_out = W::rcp(det);
     }
 
     // backward: H~_k = M~_k' P~_{k+1} M~_k + C~_k with P~_{k+1} = H~xx - H~xu Lam^-1 H~ux of stage k+1, P~_N = C~_N.
@@ -542,16 +544,21 @@ struct RtiWave {
             // re-symmetrisation below); rows 12..15 of the result are T = H~ux M~_{k-1}
             vd4 Wf = W::zero4();
             for (int c = 0; c < 3; ++c) Wf = W::mfma(H.r[c], mk[c], Wf);
-            vd li = lam_inverse(T, lds, hux, ok);
-            vd linv = W::sel(T.lo4, li, vd(0.0));             // A operand: Lam^-1[g][j], j < 4
-            vd nlhi = W::sel(T.kt_pred, -li, vd(0.0));        // B operand of K~': -Lam^-1[g][j-12] in columns 12..15
-            vd4 G = W::mfma(linv, Wf.r[3], W::zero4());      // Lam^-1 T
-            vd4 Kt = W::mfma(hux, nlhi, W::zero4());          // K~'[i][b] lands in column 12+b: rows 12..15 of the forward operand
-            vd4 Wn = W::mfma(-hux, G.r[0], Wf);               // rows 0..11: P~ M~_{k-1}
+            vd cof, rdet;
+            lam_adjugate(T, lds, hux, ok, cof, rdet);
+            // Lam^-1 = adj / det: the two dependent MFMAs use adj and run while det -> 1/det is still in the VALU;
+            // the scalar 1/det is applied to their (three-register) results afterwards
+            vd ladj = W::sel(T.lo4, cof, vd(0.0));            // A operand: adj[g][j], j < 4
+            vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));       // B operand of K~': -adj[g][j-12] in columns 12..15
+            vd4 G = W::mfma(ladj, Wf.r[3], W::zero4());      // adj T
+            vd4 Kt = W::mfma(hux, nahi, W::zero4());          // det * K~'[i][b], lands in column 12+b (rows 12..15 of the forward operand)
+            vd4 Wt = W::mfma(-hux, G.r[0], W::zero4());       // -det * H~xu Lam^-1 T
+            vd4 Wn;
+            for (int c = 0; c < 3; ++c) Wn.r[c] = Wf.r[c] + Wt.r[c] * rdet;   // rows 0..11: P~ M~_{k-1}
             vd4 Hn;
             for (int r = 0; r < 4; ++r) Hn.r[r] = cc[r];
             for (int c = 0; c < 3; ++c) Hn = W::mfma(mk[c], Wn.r[c], Hn);
-            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + T.kt_mul * k, Kt.r[c]);
+            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + T.kt_mul * k, Kt.r[c] * rdet);
             if ((k & 3) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
                 // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
@@ -566,10 +573,11 @@ struct RtiWave {
         }
         {   // stage 0: only the gain is needed
             vd hux = H.r[3];
-            vd li = lam_inverse(T, lds, hux, ok);
-            vd nlhi = W::sel(T.kt_pred, -li, vd(0.0));
-            vd4 Kt = W::mfma(hux, nlhi, W::zero4());
-            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c], Kt.r[c]);
+            vd cof, rdet;
+            lam_adjugate(T, lds, hux, ok, cof, rdet);
+            vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));
+            vd4 Kt = W::mfma(hux, nahi, W::zero4());
+            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c], Kt.r[c] * rdet);
         }
         W::sync();
         if (io) stamp(*io, m, 6);
