@@ -542,22 +542,32 @@ struct RtiWave {
             vd hux = H.r[3];
             // [H~xx ; H~ux] M~_{k-1}: H~'s registers as A operand mean H~' -- equal up to rounding (see the
             // re-symmetrisation below); rows 12..15 of the result are T = H~ux M~_{k-1}
+            const bool fine = io && io->dbg && k == N / 2;     // debug path only: where does one stage spend its cycles
+            if (fine) fstamp(*io, m, 0);
             vd4 Wf = W::zero4();
             for (int c = 0; c < 3; ++c) Wf = W::mfma(H.r[c], mk[c], Wf);
+            // M~'' H~xu = (H~ux M~')' = T', hence  H~' = [C~' + M~'' (H~xx M~')] - T' Lam^-1 T.
+            // The bracket does not need Lam^-1 either: six MFMAs run on the matrix pipe while the VALU inverts Lam,
+            // and only two dependent MFMAs (Lam^-1 T, then the rank-4 correction) follow it.
+            vd4 Hb;
+            for (int r = 0; r < 4; ++r) Hb.r[r] = cc[r];
+            for (int c = 0; c < 3; ++c) Hb = W::mfma(mk[c], Wf.r[c], Hb);
+            if (fine) fstamp(*io, m, 1);
             vd cof, rdet;
             lam_adjugate(T, lds, hux, ok, cof, rdet);
-            // Lam^-1 = adj / det: the two dependent MFMAs use adj and run while det -> 1/det is still in the VALU;
-            // the scalar 1/det is applied to their (three-register) results afterwards
+            if (fine) fstamp(*io, m, 2);
+            // Lam^-1 = adj / det: adj T starts as soon as the cofactors exist; 1/det (still in the VALU then) scales its
+            // single result register afterwards
             vd ladj = W::sel(T.lo4, cof, vd(0.0));            // A operand: adj[g][j], j < 4
             vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));       // B operand of K~': -adj[g][j-12] in columns 12..15
-            vd4 G = W::mfma(ladj, Wf.r[3], W::zero4());      // adj T
+            vd tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
+            vd4 G = W::mfma(ladj, tt, W::zero4());            // adj T
             vd4 Kt = W::mfma(hux, nahi, W::zero4());          // det * K~'[i][b], lands in column 12+b (rows 12..15 of the forward operand)
-            vd4 Wt = W::mfma(-hux, G.r[0], W::zero4());       // -det * H~xu Lam^-1 T
-            vd4 Wn;
-            for (int c = 0; c < 3; ++c) Wn.r[c] = Wf.r[c] + Wt.r[c] * rdet;   // rows 0..11: P~ M~_{k-1}
-            vd4 Hn;
-            for (int r = 0; r < 4; ++r) Hn.r[r] = cc[r];
-            for (int c = 0; c < 3; ++c) Hn = W::mfma(mk[c], Wn.r[c], Hn);
+            if (fine) fstamp(*io, m, 3);
+            vd gs = G.r[0] * rdet;                            // Lam^-1 T
+            vd4 Hn = W::mfma(-tt, gs, Hb);                    // - T' Lam^-1 T on top of the bracket
+            if (fine) fstamp(*io, m, 4, gs);
+            if (fine) fstamp(*io, m, 5, Hn.r[3]);
             for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + T.kt_mul * k, Kt.r[c] * rdet);
             if ((k & 3) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
@@ -783,6 +793,13 @@ struct RtiWave {
     }
 
     static NDP_D double fmax_u(double a, double b) { return a > b ? a : b; }
+
+    // fine-grained stamp: waits until `dep` (if given) is available, then reads the clock (debug path only)
+    static NDP_D void fstamp(const RtiIo &io, const LdsMap &m, int idx, vd dep = vd(0.0))
+    {
+        vd t = W::clock_after(dep);
+        W::gst(io.dbg, W::lane() * 0 + (m.KT + 16 + idx), t, W::lane() == 0);
+    }
 
     // debug-path phase stamps (shader clock) written behind the LDS image dump; no-op when io.dbg is null
     static NDP_D void stamp(const RtiIo &io, const LdsMap &m, int idx)

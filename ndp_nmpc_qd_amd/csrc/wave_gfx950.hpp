@@ -72,6 +72,15 @@ struct WaveGfx950 {
         return __hiloint2double(hi, lo);
     }
     static NDP_D vd clock() { return (double)__builtin_amdgcn_s_memtime(); }   // shader-clock ticks (debug stamps)
+    // clock read that is ordered after `dep` has been produced (debug only): the asm consumes dep, fences scheduling
+    static NDP_D vd clock_after(vd dep)
+    {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 0\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return (double)t;
+    }
 
     // cross-lane
     static NDP_D double readlane(vd a, int l)

@@ -13,6 +13,9 @@ for fused in (False, True):
         kw = dict(other=b['other'], ego_xy=b['ego_xy']) if fused else {}
         u0, d = eng.update_debug(b['x0'], b['xr'], b['ur'], **kw)
         t = d[KT:KT + 11]
+        ft = d[KT + 16:KT + 22]
         line = ' '.join(f'{n}:{int(t[i] - t[i - 1])}' for i, n in enumerate(names) if i > 0)
         extra = f' | mlp_tile:{int(t[10] - t[9])} mlp_end->start:{int(t[0] - t[10])}' if fused else ''
         print('fused' if fused else 'plain', 'rep', rep, line, 'total', int(t[8] - t[0]), extra)
+        if rep == 2:
+            print('   one backward stage: issue Wf+bracket %d | adjugate(+1/det) %d | G,Kt issue %d | Lam^-1 T ready %d | H ready %d' % tuple(int(ft[i + 1] - ft[i]) for i in range(5)))

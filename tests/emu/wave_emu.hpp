@@ -101,6 +101,7 @@ struct Wave {
     static void gsti(int *g, int val) { if (g) *g = val; }
 
     static vd clock() { return vd(0.0); }
+    static vd clock_after(const vd &) { return vd(0.0); }
     static vd rcp(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = 1.0 / a.v[l]; return o; }
     static vd quad_sum(const vd &a)
     {   // same association as the device: (x + x^1) + (x + x^1)^2
