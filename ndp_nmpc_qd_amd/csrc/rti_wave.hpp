@@ -26,6 +26,11 @@
 #ifndef NDP_D        // wave-program functions: __device__ in the gfx950 build, plain inline under the emulator
 #define NDP_D inline
 #endif
+#ifdef NDP_FINE_STAMPS
+#define NDP_FINE(x) x
+#else
+#define NDP_FINE(x)
+#endif
 #ifndef NDP_HD       // layout helpers used by host and device
 #define NDP_HD inline
 #endif
@@ -542,8 +547,9 @@ struct RtiWave {
             vd hux = H.r[3];
             // [H~xx ; H~ux] M~_{k-1}: H~'s registers as A operand mean H~' -- equal up to rounding (see the
             // re-symmetrisation below); rows 12..15 of the result are T = H~ux M~_{k-1}
-            const bool fine = io && io->dbg && k == N / 2;     // debug path only: where does one stage spend its cycles
-            if (fine) fstamp(*io, m, 0);
+            NDP_FINE(const bool fine = io && io->dbg && k == N / 2;)   // diagnostic build only (-DNDP_FINE_STAMPS): a conditional
+                                                                      // block here would split the basic block and serialise the stage
+            NDP_FINE(if (fine) fstamp(*io, m, 0);)
             vd4 Wf = W::zero4();
             for (int c = 0; c < 3; ++c) Wf = W::mfma(H.r[c], mk[c], Wf);
             // M~'' H~xu = (H~ux M~')' = T', hence  H~' = [C~' + M~'' (H~xx M~')] - T' Lam^-1 T.
@@ -552,10 +558,10 @@ struct RtiWave {
             vd4 Hb;
             for (int r = 0; r < 4; ++r) Hb.r[r] = cc[r];
             for (int c = 0; c < 3; ++c) Hb = W::mfma(mk[c], Wf.r[c], Hb);
-            if (fine) fstamp(*io, m, 1);
+            NDP_FINE(if (fine) fstamp(*io, m, 1);)
             vd cof, rdet;
             lam_adjugate(T, lds, hux, ok, cof, rdet);
-            if (fine) fstamp(*io, m, 2);
+            NDP_FINE(if (fine) fstamp(*io, m, 2);)
             // Lam^-1 = adj / det: adj T starts as soon as the cofactors exist; 1/det (still in the VALU then) scales its
             // single result register afterwards
             vd ladj = W::sel(T.lo4, cof, vd(0.0));            // A operand: adj[g][j], j < 4
@@ -563,11 +569,11 @@ struct RtiWave {
             vd tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
             vd4 G = W::mfma(ladj, tt, W::zero4());            // adj T
             vd4 Kt = W::mfma(hux, nahi, W::zero4());          // det * K~'[i][b], lands in column 12+b (rows 12..15 of the forward operand)
-            if (fine) fstamp(*io, m, 3);
+            NDP_FINE(if (fine) fstamp(*io, m, 3);)
             vd gs = G.r[0] * rdet;                            // Lam^-1 T
             vd4 Hn = W::mfma(-tt, gs, Hb);                    // - T' Lam^-1 T on top of the bracket
-            if (fine) fstamp(*io, m, 4, gs);
-            if (fine) fstamp(*io, m, 5, Hn.r[3]);
+            NDP_FINE(if (fine) fstamp(*io, m, 4, gs);)
+            NDP_FINE(if (fine) fstamp(*io, m, 5, Hn.r[3]);)
             for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + T.kt_mul * k, Kt.r[c] * rdet);
             if ((k & 3) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
