@@ -488,24 +488,32 @@ struct RtiWave {
     // dependent f64 VALU op costs ~32 cycles and a divide ~100, so a 4-pivot factorisation computed
     // redundantly on every lane was ~40 % of a backward stage.  Lam = R + B'PB + barrier diagonal: R > 0 and
     // the barrier terms only add to the diagonal, so the cofactor expansion is well conditioned here.
-    // Returns, in EVERY lane (g,j), the cofactor adj(Lam)[g][j&3] and 1/det(Lam) separately (callers mask the columns
-    // they need): products with adj can start while the det -> reciprocal chain is still running.  Plus a PD flag.
-    static NDP_D void lam_adjugate(const Tables &T, lp lds, vd h3, bool &ok, vd &cof_out, vd &rdet_out)
+    // The inverse in three phases so that the caller can interleave them with matrix instructions:
+    //   lam_gather   : publish Lam (register 3 of H~) to the LDS scratch and read this lane's 3x3 minor + own entry
+    //   lam_cofactor : signed cofactor adj(Lam)[g][j&3], in EVERY lane (callers mask the columns they need)
+    //   lam_rdet     : 1/det by row expansion (DPP quad-sum) + PD flag
+    struct LamRegs { vd mm[9], own; };
+    static NDP_D void lam_gather(const Tables &T, lp lds, vd h3, LamRegs &L)
     {
         W::stp(lds, T.lam_w_off, h3, T.kt_pred);             // H~[12+g][12+b] -> SC[g*4+b]
         W::sync();
-        vd mm[9];
-        for (int i = 0; i < 9; ++i) mm[i] = W::ld(lds, T.minor_off[i]);
-        vd own = W::ld(lds, T.own_off);
+        for (int i = 0; i < 9; ++i) L.mm[i] = W::ld(lds, T.minor_off[i]);
+        L.own = W::ld(lds, T.own_off);
+    }
+    static NDP_D vd lam_cofactor(const Tables &T, const LamRegs &L)
+    {
+        const vd *mm = L.mm;
         vd d0 = mm[4] * mm[8] - mm[5] * mm[7];
         vd d1 = mm[3] * mm[8] - mm[5] * mm[6];
         vd d2 = mm[3] * mm[7] - mm[4] * mm[6];
-        vd cof = (mm[0] * d0 - mm[1] * d1 + mm[2] * d2) * T.cof_sign;
-        vd det = W::quad_sum(own * cof);                      // row expansion: lanes 16g..16g+3 form one quad
+        return (mm[0] * d0 - mm[1] * d1 + mm[2] * d2) * T.cof_sign;
+    }
+    static NDP_D vd lam_rdet(const Tables &T, const LamRegs &L, vd cof, bool &ok)
+    {
+        vd det = W::quad_sum(L.own * cof);                    // row expansion: lanes 16g..16g+3 form one quad
         vb pd = (det > 0.0) && (!T.lam_diag || (cof > 0.0));
         ok = W::all(pd) && ok;
-        cof_out = cof;
-        rdet_out = W::rcp(det);
+        return W::rcp(det);
     }
 
     // backward: H~_k = M~_k' P~_{k+1} M~_k + C~_k with P~_{k+1} = H~xx - H~xu Lam^-1 H~ux of stage k+1, P~_N = C~_N.
@@ -547,33 +555,31 @@ struct RtiWave {
             vd hux = H.r[3];
             // [H~xx ; H~ux] M~_{k-1}: H~'s registers as A operand mean H~' -- equal up to rounding (see the
             // re-symmetrisation below); rows 12..15 of the result are T = H~ux M~_{k-1}
-            NDP_FINE(const bool fine = io && io->dbg && k == N / 2;)   // diagnostic build only (-DNDP_FINE_STAMPS): a conditional
-                                                                      // block here would split the basic block and serialise the stage
-            NDP_FINE(if (fine) fstamp(*io, m, 0);)
+            // Issue order matters (one in-order wave, asynchronous matrix pipe): Lam gather first, then the three
+            // H~ M~' MFMAs, the cofactors while those run, then the bracket MFMAs interleaved with det -> 1/det.
+            LamRegs LR;
+            lam_gather(T, lds, hux, LR);
+            W::pin();
             vd4 Wf = W::zero4();
             for (int c = 0; c < 3; ++c) Wf = W::mfma(H.r[c], mk[c], Wf);
+            W::pin();
+            vd cof = lam_cofactor(T, LR);
+            W::pin();
             // M~'' H~xu = (H~ux M~')' = T', hence  H~' = [C~' + M~'' (H~xx M~')] - T' Lam^-1 T.
-            // The bracket does not need Lam^-1 either: six MFMAs run on the matrix pipe while the VALU inverts Lam,
-            // and only two dependent MFMAs (Lam^-1 T, then the rank-4 correction) follow it.
+            // The bracket does not need Lam^-1 either; only two dependent MFMAs (Lam^-1 T, then the rank-4
+            // correction) follow the inverse.
             vd4 Hb;
             for (int r = 0; r < 4; ++r) Hb.r[r] = cc[r];
             for (int c = 0; c < 3; ++c) Hb = W::mfma(mk[c], Wf.r[c], Hb);
-            NDP_FINE(if (fine) fstamp(*io, m, 1);)
-            vd cof, rdet;
-            lam_adjugate(T, lds, hux, ok, cof, rdet);
-            NDP_FINE(if (fine) fstamp(*io, m, 2);)
-            // Lam^-1 = adj / det: adj T starts as soon as the cofactors exist; 1/det (still in the VALU then) scales its
-            // single result register afterwards
+            // Lam^-1 = adj / det: adj T starts as soon as the cofactors exist; 1/det scales its single result register
             vd ladj = W::sel(T.lo4, cof, vd(0.0));            // A operand: adj[g][j], j < 4
             vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));       // B operand of K~': -adj[g][j-12] in columns 12..15
             vd tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
             vd4 G = W::mfma(ladj, tt, W::zero4());            // adj T
             vd4 Kt = W::mfma(hux, nahi, W::zero4());          // det * K~'[i][b], lands in column 12+b (rows 12..15 of the forward operand)
-            NDP_FINE(if (fine) fstamp(*io, m, 3);)
+            vd rdet = lam_rdet(T, LR, cof, ok);
             vd gs = G.r[0] * rdet;                            // Lam^-1 T
             vd4 Hn = W::mfma(-tt, gs, Hb);                    // - T' Lam^-1 T on top of the bracket
-            NDP_FINE(if (fine) fstamp(*io, m, 4, gs);)
-            NDP_FINE(if (fine) fstamp(*io, m, 5, Hn.r[3]);)
             for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + T.kt_mul * k, Kt.r[c] * rdet);
             if ((k & 3) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
@@ -589,8 +595,10 @@ struct RtiWave {
         }
         {   // stage 0: only the gain is needed
             vd hux = H.r[3];
-            vd cof, rdet;
-            lam_adjugate(T, lds, hux, ok, cof, rdet);
+            LamRegs LR;
+            lam_gather(T, lds, hux, LR);
+            vd cof = lam_cofactor(T, LR);
+            vd rdet = lam_rdet(T, LR, cof, ok);
             vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));
             vd4 Kt = W::mfma(hux, nahi, W::zero4());
             for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c], Kt.r[c] * rdet);
