@@ -541,16 +541,22 @@ struct RtiWave {
             for (int c = 0; c < 3; ++c) H = W::mfma(mk[c], Wm.r[c], H);
         }
         vd mk[3], cc[4];       // operands of the NEXT stage to be formed (k-1), requested one iteration ahead
+        // running LDS addresses (one add per operand and stage instead of a quarter-rate integer multiply)
+        vi a_mk[3], a_cc[4], a_kt[3];
         {
             const int kn = N > 1 ? N - 2 : 0;
-            for (int c = 0; c < 3; ++c) mk[c] = W::ld(lds, T.mk_off[c] + T.mk_mul[c] * kn);
-            for (int r = 0; r < 4; ++r) cc[r] = W::ld(lds, T.c_off[r] + T.c_mul[r] * kn);
+            for (int c = 0; c < 3; ++c) { a_mk[c] = T.mk_off[c] + T.mk_mul[c] * kn; mk[c] = W::ld(lds, a_mk[c]); }
+            for (int r = 0; r < 4; ++r) { a_cc[r] = T.c_off[r] + T.c_mul[r] * kn; cc[r] = W::ld(lds, a_cc[r]); }
+            for (int c = 0; c < 3; ++c) a_kt[c] = T.kt_st[c] + T.kt_mul * (N - 1);
         }
         for (int k = N - 1; k >= 1; --k) {
-            const int kp = k > 1 ? k - 2 : 0;
             vd nmk[3], ncc[4];
-            for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, T.mk_off[c] + T.mk_mul[c] * kp);
-            for (int r = 0; r < 4; ++r) ncc[r] = W::ld(lds, T.c_off[r] + T.c_mul[r] * kp);
+            if (k >= 2) {      // prefetch stage k-2; at k = 1 there is none: re-read stage 0 (values unused)
+                for (int c = 0; c < 3; ++c) a_mk[c] = a_mk[c] - T.mk_mul[c];
+                for (int r = 0; r < 4; ++r) a_cc[r] = a_cc[r] - T.c_mul[r];
+            }
+            for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, a_mk[c]);
+            for (int r = 0; r < 4; ++r) ncc[r] = W::ld(lds, a_cc[r]);
             // Lam[a][b] = H~[12+a][12+b] and H~ux both sit in accumulator register 3
             vd hux = H.r[3];
             // [H~xx ; H~ux] M~_{k-1}: H~'s registers as A operand mean H~' -- equal up to rounding (see the
@@ -580,7 +586,7 @@ struct RtiWave {
             vd rdet = lam_rdet(T, LR, cof, ok);
             vd gs = G.r[0] * rdet;                            // Lam^-1 T
             vd4 Hn = W::mfma(-tt, gs, Hb);                    // - T' Lam^-1 T on top of the bracket
-            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + T.kt_mul * k, Kt.r[c] * rdet);
+            for (int c = 0; c < 3; ++c) { W::st(lds, a_kt[c], Kt.r[c] * rdet); a_kt[c] = a_kt[c] - T.kt_mul; }
             if ((k & 3) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
                 // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
@@ -615,13 +621,17 @@ struct RtiWave {
         // per stage: Y = [M~x ; K~] z~ (3 MFMAs) holds M~x z~ in rows 0..11 and du = K~ z~ in rows 12..15, i.e. du is
         // accumulator register 3 -- exactly the B operand of the 4th MFMA, which adds B~ du to rows 0..11.
         vd fw[3], mu;
-        for (int c = 0; c < 3; ++c) fw[c] = W::ld(lds, T.fw_off[c]);
-        mu = W::ld(lds, T.mu_off);
+        vi a_fw[3], a_mu = T.mu_off, a_zu = T.zu_st, a_zx[3];
+        for (int c = 0; c < 3; ++c) { a_fw[c] = T.fw_off[c]; fw[c] = W::ld(lds, a_fw[c]); a_zx[c] = T.zx_st[c] + T.zx_mul[c]; }
+        mu = W::ld(lds, a_mu);
         for (int k = 0; k < N; ++k) {
-            const int kn = k + 1 < N ? k + 1 : k;
             vd nfw[3], nmu;
-            for (int c = 0; c < 3; ++c) nfw[c] = W::ld(lds, T.fw_off[c] + T.fw_mul[c] * kn);
-            nmu = W::ld(lds, T.mu_off + T.mu_mul * kn);
+            if (k + 1 < N) {
+                for (int c = 0; c < 3; ++c) a_fw[c] = a_fw[c] + T.fw_mul[c];
+                a_mu = a_mu + T.mu_mul;
+            }
+            for (int c = 0; c < 3; ++c) nfw[c] = W::ld(lds, a_fw[c]);
+            nmu = W::ld(lds, a_mu);
             W::pin();   // keep the prefetch ahead of this stage's MFMAs (the scheduler otherwise sinks it behind them)
             vd4 Y = W::zero4();
             Y = W::mfma(fw[0], zc[0], Y);
@@ -629,10 +639,12 @@ struct RtiWave {
             Y = W::mfma(fw[2], zc[2], Y);
             vd du = Y.r[3];
             vd4 xn = W::mfma(mu, du, Y);
-            W::st(lds, T.zu_st + T.zu_mul * k, du);
+            W::st(lds, a_zu, du);
+            a_zu = a_zu + T.zu_mul;
             for (int c = 0; c < 3; ++c) {
                 zc[c] = xn.r[c];
-                W::st(lds, T.zx_st[c] + T.zx_mul[c] * (k + 1), xn.r[c]);
+                W::st(lds, a_zx[c], xn.r[c]);
+                a_zx[c] = a_zx[c] + T.zx_mul[c];
             }
             for (int c = 0; c < 3; ++c) fw[c] = nfw[c];
             mu = nmu;
