@@ -291,17 +291,46 @@ struct RtiWave {
     {
         const int N = P.N;
         vi lane = W::lane();
+        // Three task families, each at most a few 64-lane rounds.  Every LDS read of every round is issued before the
+        // first result is needed (one wait per family instead of one per round), then computed, then stored.
+        constexpr int RA = (4 * (NMAXS + 1) + 63) / 64, RB = (6 * (NMAXS + 1) + 63) / 64, RC = (4 * NMAXS + 63) / 64;
         // (a) quaternion block, one lane per (stage, row a)
-        for (int t = 0; t < 4 * (N + 1); t += 64) {
-            vi task = lane + t;
+        vd qr[RA][4], qi[RA][4];
+        vd xb[RB], rb[RB], wb[RB], uc[RC], rc[RC], wc[RC];
+        for (int t = 0; t < RA; ++t) {
+            vi task = lane + 64 * t;
+            vi k = W::sel(task < 4 * (N + 1), task >> 2, vi(0));
+            for (int i = 0; i < 4; ++i) {
+                qr[t][i] = W::ld(lds, k * NX + (m.TXR + 6 + i));
+                qi[t][i] = W::ld(lds, k * NX + (m.XI + 6 + i));
+            }
+        }
+        // (b) position / velocity rows, one lane per (stage, i < 6)
+        for (int t = 0; t < RB; ++t) {
+            vi task = lane + 64 * t;
+            vb p = task < 6 * (N + 1);
+            vi k = W::sel(p, W::div6(task), vi(0));
+            vi i = W::sel(p, task - k * 6, vi(0));
+            wb[t] = W::ld(lds, i + (m.KC + KC_QD));
+            xb[t] = W::ld(lds, k * NX + i + m.XI);
+            rb[t] = W::ld(lds, k * NX + i + m.TXR);
+        }
+        // (c) control rows, one lane per (stage < N, i < 4)
+        for (int t = 0; t < RC; ++t) {
+            vi task = lane + 64 * t;
+            vb p = task < 4 * N;
+            vi ti = W::sel(p, task, vi(0));
+            wc[t] = W::ld(lds, (ti & 3) + (m.KC + KC_RD));
+            uc[t] = W::ld(lds, ti + m.UI);
+            rc[t] = W::ld(lds, ti + m.TUR);
+        }
+        for (int t = 0; t < RA; ++t) {
+            vi task = lane + 64 * t;
             vb p = task < 4 * (N + 1);
             vi k = W::sel(p, task >> 2, vi(0));
             vi a = task & 3;
             vd s = W::sel(k < N, vd(P.dt), vd(1.0));
-            vi xr = k * NX + m.TXR + 6;
-            vd qwr = W::ld(lds, xr), qxr = W::ld(lds, xr + 1), qyr = W::ld(lds, xr + 2), qzr = W::ld(lds, xr + 3);
-            vi xi = k * NX + m.XI + 6;
-            vd q0 = W::ld(lds, xi), q1 = W::ld(lds, xi + 1), q2 = W::ld(lds, xi + 2), q3 = W::ld(lds, xi + 3);
+            const vd qwr = qr[t][0], qxr = qr[t][1], qyr = qr[t][2], qzr = qr[t][3];
             // E = [[-qx, qw,-qz, qy], [-qy, qz, qw,-qx], [-qz,-qy, qx, qw]] (of q_r)
             vd E0[4] = {-qxr, qwr, -qzr, qyr};
             vd E1[4] = {-qyr, qzr, qwr, -qxr};
@@ -310,39 +339,35 @@ struct RtiWave {
             vd ea1 = W::sel(a == 0, E1[0], W::sel(a == 1, E1[1], W::sel(a == 2, E1[2], E1[3])));
             vd ea2 = W::sel(a == 0, E2[0], W::sel(a == 1, E2[1], W::sel(a == 2, E2[2], E2[3])));
             vd w0 = ea0 * (s * P.Qd[7]), w1 = ea1 * (s * P.Qd[8]), w2 = ea2 * (s * P.Qd[9]);
-            vd qi[4] = {q0, q1, q2, q3};
             vd grad = 0.0;
             vi cb = k * int(CB_STRIDE) + m.CB;
             for (int b = 0; b < 4; ++b) {
                 vd h = w0 * E0[b] + w1 * E1[b] + w2 * E2[b];
                 W::stp(lds, cb + a * 4 + (int(CB_QQ) + b), h, p);
-                grad = grad + h * qi[b];
+                grad = grad + h * qi[t][b];
             }
             W::stp(lds, cb + a + (int(CB_QE) + 6), grad, p);
         }
-        // (b) position / velocity rows, one lane per (stage, i<6)
-        for (int t = 0; t < 6 * (N + 1); t += 64) {
-            vi task = lane + t;
+        for (int t = 0; t < RB; ++t) {
+            vi task = lane + 64 * t;
             vb p = task < 6 * (N + 1);
             vi k = W::sel(p, W::div6(task), vi(0));
             vi i = W::sel(p, task - k * 6, vi(0));
             vd s = W::sel(k < N, vd(P.dt), vd(1.0));
-            vd de = s * W::ld(lds, i + (m.KC + KC_QD));
-            vd grad = de * (W::ld(lds, k * NX + i + m.XI) - W::ld(lds, k * NX + i + m.TXR));
+            vd de = s * wb[t];
+            vd grad = de * (xb[t] - rb[t]);
             vi cb = k * int(CB_STRIDE) + m.CB;
             W::stp(lds, cb + i + int(CB_DEX), de, p);
             W::stp(lds, cb + i + int(CB_QE), grad, p);
             W::stp(lds, cb + i + (int(CB_QBV) - 3), grad, p && (i >= 3));
         }
-        // (c) control rows, one lane per (stage<N, i<4)
-        for (int t = 0; t < 4 * N; t += 64) {
-            vi task = lane + t;
+        for (int t = 0; t < RC; ++t) {
+            vi task = lane + 64 * t;
             vb p = task < 4 * N;
             vi k = W::sel(p, task >> 2, vi(0));
             vi i = task & 3;
-            vi ti = k * NU + i;
-            vd de = P.dt * W::ld(lds, i + (m.KC + KC_RD));
-            vd grad = de * (W::ld(lds, ti + m.UI) - W::ld(lds, ti + m.TUR));
+            vd de = P.dt * wc[t];
+            vd grad = de * (uc[t] - rc[t]);
             vi cb = k * int(CB_STRIDE) + m.CB;
             W::stp(lds, cb + i + int(CB_DEU), de, p);
             W::stp(lds, cb + i + int(CB_RE), grad, p);
@@ -922,29 +947,43 @@ struct RtiWave {
                 st = ipm(P, m, T, S, lds, iters);
             }
             if (st && !status) status = st;
-            // full step, no line search; XI|UI and CX|CU are laid out alike
-            for (int t = 0; t < nzx + nzu; t += 64) {
-                vi i = lane + t;
-                vb p = i < nzx + nzu;
-                W::stp(lds, i + m.XI, W::ldp(lds, i + m.XI, p) + W::ldp(lds, i + m.CX, p), p);
+            // full step, no line search; XI|UI and CX|CU are laid out alike.
+            // All LDS reads of the step are issued before the first add (one wait, not one per 64 elements); after the
+            // last RTI iteration the new iterate goes straight to global memory as well.
+            {
+                constexpr int RZ = RX + RU;     // rounds that cover X|U contiguously: nzx + nzu <= 64 * RZ
+                const bool last = it + 1 == P.n_rti;
+                vd xa[RZ], xc[RZ];
+                for (int t = 0; t < RZ; ++t) {
+                    vi i = W::imin(lane + 64 * t, nzx + nzu - 1);
+                    xa[t] = W::ld(lds, i + m.XI);
+                    xc[t] = W::ld(lds, i + m.CX);
+                }
+                for (int t = 0; t < RZ; ++t) {
+                    vi i = lane + 64 * t;
+                    vb p = i < nzx + nzu;
+                    vd xn = xa[t] + xc[t];
+                    W::stp(lds, i + m.XI, xn, p);
+                    if (last) {
+                        // X and U are separate global arrays: element i < nzx goes to X[i], else to U[i - nzx]
+                        W::gst(io.X, i, xn, i < nzx);
+                        W::gst(io.U, i - nzx, xn, p && (i >= nzx));
+                        if (t == (nzx >> 6)) {   // the round that holds u_0 = U[0..3] (wave-uniform test)
+                            vb pu = (i >= nzx) && (i < nzx + NU);
+                            W::gst(io.u0, i - nzx, xn, pu);
+                            if (W::any(pu && !(xn == xn))) status = 1;
+                        }
+                        if (nzx + NU > 64 * ((nzx >> 6) + 1) && t == (nzx >> 6) + 1) {   // u_0 straddles two rounds
+                            vb pu = (i >= nzx) && (i < nzx + NU);
+                            W::gst(io.u0, i - nzx, xn, pu);
+                            if (W::any(pu && !(xn == xn))) status = 1;
+                        }
+                    }
+                }
             }
             W::sync();
         }
-        // write back: iterate, u0 = u_0 after the step (nmpc_body_rate_ctl.py:107,112), status
-        for (int t = 0; t < nzx; t += 64) {
-            vi i = lane + t;
-            vb p = i < nzx;
-            W::gst(io.X, i, W::ldp(lds, i + m.XI, p), p);
-        }
-        for (int t = 0; t < nzu; t += 64) {
-            vi i = lane + t;
-            vb p = i < nzu;
-            W::gst(io.U, i, W::ldp(lds, i + m.UI, p), p);
-        }
-        vd u0 = W::ldp(lds, lane + m.UI, lane < NU);
-        W::gst(io.u0, lane, u0, lane < NU);
         stamp(io, m, 8);
-        if (W::any((lane < NU) && !(u0 == u0))) status = 1;
         W::gsti(io.status, status);
         W::gsti(io.iters, iters);
     }
