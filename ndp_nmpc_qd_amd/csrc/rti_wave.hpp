@@ -399,75 +399,108 @@ struct RtiWave {
         o[2] = (q[1] * s[1] + q[2] * s[2]) * -4.0;
     }
 
-    // tangent of the ODE at attitude qs: input tangent (dw, dc); state tangent s = (sp, sv, sq); sp does not feed back
-    static NDP_D void tan_rhs(const vd qs[4], const vd w[3], vd c, const vd sv[3], const vd sq[4], const vd dw[3], vd dc,
-                               vd kp[3], vd kv[3], vd kq[4])
+    // Scalars of the closed-form ERK4 step.  The attitude ODE q' = Z q, Z = 1/2 Omega(w), is linear with Z^2 = -sigma I
+    // (sigma = |w|^2/4), so every RK node is q_i = a_i q + b_i r with r = Z q:
+    //   (a,b) = (1,0), (1,h/2), (1-h^2 sigma/4, h/2), (1-h^2 sigma/2, h(1-h^2 sigma/4)),  q+ = A q + B r.
+    // The thrust direction is td(x) = 1/2 tdt(x,x) + e3 with tdt the symmetric bilinear form thrust_dir_tan, hence
+    //   v+ = v + c Dv + h acc,  p+ = p + h v + c Dp + h^2/2 acc,   D = sum_i beta_i td(q_i),
+    // beta_v = h/6 (1,2,2,1), beta_p = h^2/6 (1,1,1,0), and all sensitivities are tdt(q,U) + tdt(r,V) with U, V linear
+    // combinations of a few basis vectors weighted by the sums S_xy = sum_i beta_i x_i y_i below.  This is the exact
+    // derivative of the same RK4 map the oracle differentiates numerically stage by stage (acados sim_erk defaults).
+    struct RkScal {
+        vd a3, a4, b4, A, B;
+        vd Sv_aa, Sv_ab, Sv_bb, Sp_aa, Sp_ab, Sp_bb;
+    };
+    static NDP_D void rk_scalars(double h, vd sg, RkScal &K)
     {
-        vd td[3], tt[3], a[4], b[4];
-        thrust_dir(qs, td);
-        thrust_dir_tan(qs, sq, tt);
-        qdot(sq, w, a);
-        qdot(qs, dw, b);
-        for (int i = 0; i < 3; ++i) {
-            kp[i] = sv[i];
-            kv[i] = tt[i] * c + td[i] * dc;
-        }
-        for (int i = 0; i < 4; ++i) kq[i] = a[i] + b[i];
+        const double h2 = h * h, hh = 0.5 * h, h6 = h / 6.0, hp = h2 / 6.0;
+        K.a3 = 1.0 - sg * (0.25 * h2);
+        K.a4 = 1.0 - sg * (0.5 * h2);
+        K.b4 = K.a3 * h;
+        K.A = 1.0 - sg * (0.5 * h2) + sg * sg * (h2 * h2 / 24.0);
+        K.B = h - sg * (h * h2 / 6.0);
+        K.Sv_aa = (3.0 + K.a3 * K.a3 * 2.0 + K.a4 * K.a4) * h6;
+        K.Sv_ab = (2.0 * hh + K.a3 * (2.0 * hh) + K.a4 * K.b4) * h6;
+        K.Sv_bb = (4.0 * hh * hh + K.b4 * K.b4) * h6;
+        K.Sp_aa = (2.0 + K.a3 * K.a3) * hp;
+        K.Sp_ab = (hh + K.a3 * hh) * hp;
+        K.Sp_bb = (2.0 * hh * hh) * hp;
     }
 
-    // ERK4 (one step of dt) + forward sensitivities -> stage blocks MB_k (acados sim_erk defaults)
+    // ERK4 (one step of dt) + forward sensitivities -> stage blocks MB_k, in closed form (see rk_scalars)
     static NDP_D void linearize(const RtiParams &P, const LdsMap &m, lp lds)
     {
         const int N = P.N;
-        const double h = P.dt, hh = 0.5 * P.dt, h6 = P.dt / 6.0;
+        const double h = P.dt, h2 = h * h, hh = 0.5 * h, h6 = h / 6.0, hp = h2 / 6.0;
         vi lane = W::lane();
-        // sensitivity columns: col 0..3 = d/dq, 4..6 = d/dw, 7 = d/dc; one lane per (stage, column)
-        for (int t = 0; t < 8 * N; t += 64) {
+        // ---- d/dq columns: one lane per (stage, j), 4N tasks
+        for (int t = 0; t < 4 * N; t += 64) {
             vi task = lane + t;
-            vb p = task < 8 * N;
-            vi k = W::sel(p, task >> 3, vi(0));
-            vi col = task & 7;
+            vb p = task < 4 * N;
+            vi k = W::sel(p, task >> 2, vi(0));
+            vi j = task & 3;
             vi xi = k * NX + m.XI + 6, ui = k * NU + m.UI;
-            vd q1[4] = {W::ld(lds, xi), W::ld(lds, xi + 1), W::ld(lds, xi + 2), W::ld(lds, xi + 3)};
+            vd q[4] = {W::ld(lds, xi), W::ld(lds, xi + 1), W::ld(lds, xi + 2), W::ld(lds, xi + 3)};
             vd w[3] = {W::ld(lds, ui), W::ld(lds, ui + 1), W::ld(lds, ui + 2)};
             vd c = W::ld(lds, ui + 3);
-            // attitude at the four RK nodes (the only state the Jacobians depend on)
-            vd k1[4], k2[4], k3[4], q2[4], q3[4], q4[4];
-            qdot(q1, w, k1);
-            for (int i = 0; i < 4; ++i) q2[i] = q1[i] + k1[i] * hh;
-            qdot(q2, w, k2);
-            for (int i = 0; i < 4; ++i) q3[i] = q1[i] + k2[i] * hh;
-            qdot(q3, w, k3);
-            for (int i = 0; i < 4; ++i) q4[i] = q1[i] + k3[i] * h;
-            // seeds
-            vd sq0[4], dw[3], zero3[3] = {0.0, 0.0, 0.0};
-            for (int i = 0; i < 4; ++i) sq0[i] = W::sel(col == i, vd(1.0), vd(0.0));
-            for (int i = 0; i < 3; ++i) dw[i] = W::sel(col == 4 + i, vd(1.0), vd(0.0));
-            vd dc = W::sel(col == 7, vd(1.0), vd(0.0));
-            vd Kp[4][3], Kv[4][3], Kq[4][4], sv[3], sq[4];
-            tan_rhs(q1, w, c, zero3, sq0, dw, dc, Kp[0], Kv[0], Kq[0]);
-            for (int i = 0; i < 3; ++i) sv[i] = Kv[0][i] * hh;
-            for (int i = 0; i < 4; ++i) sq[i] = sq0[i] + Kq[0][i] * hh;
-            tan_rhs(q2, w, c, sv, sq, dw, dc, Kp[1], Kv[1], Kq[1]);
-            for (int i = 0; i < 3; ++i) sv[i] = Kv[1][i] * hh;
-            for (int i = 0; i < 4; ++i) sq[i] = sq0[i] + Kq[1][i] * hh;
-            tan_rhs(q3, w, c, sv, sq, dw, dc, Kp[2], Kv[2], Kq[2]);
-            for (int i = 0; i < 3; ++i) sv[i] = Kv[2][i] * h;
-            for (int i = 0; i < 4; ++i) sq[i] = sq0[i] + Kq[2][i] * h;
-            tan_rhs(q4, w, c, sv, sq, dw, dc, Kp[3], Kv[3], Kq[3]);
-            vi mb = k * int(MB_STRIDE) + m.MB + col;
-            for (int i = 0; i < 3; ++i) {
-                vd sp = (Kp[0][i] + (Kp[1][i] + Kp[2][i]) * 2.0 + Kp[3][i]) * h6;
-                vd svn = (Kv[0][i] + (Kv[1][i] + Kv[2][i]) * 2.0 + Kv[3][i]) * h6;
-                W::stp(lds, mb + (int(MB_PV) + i * 8), sp, p);
-                W::stp(lds, mb + (int(MB_PV) + (3 + i) * 8), svn, p);
-            }
+            vd r[4], e[4], z[4];
+            qdot(q, w, r);
+            RkScal K;
+            rk_scalars(h, (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) * 0.25, K);
+            for (int i = 0; i < 4; ++i) e[i] = W::sel(j == i, vd(1.0), vd(0.0));
+            qdot(e, w, z);                                   // Z e_j
+            vd Uv[4], Vv[4], Up[4], Vp[4], t1[3], t2[3];
             for (int i = 0; i < 4; ++i) {
-                vd sqn = sq0[i] + (Kq[0][i] + (Kq[1][i] + Kq[2][i]) * 2.0 + Kq[3][i]) * h6;
-                W::stp(lds, mb + (int(MB_Q) + i * 7), sqn, p && (col < 7));
+                Uv[i] = e[i] * K.Sv_aa + z[i] * K.Sv_ab; Vv[i] = e[i] * K.Sv_ab + z[i] * K.Sv_bb;
+                Up[i] = e[i] * K.Sp_aa + z[i] * K.Sp_ab; Vp[i] = e[i] * K.Sp_ab + z[i] * K.Sp_bb;
             }
+            vi mb = k * int(MB_STRIDE) + m.MB + j;
+            thrust_dir_tan(q, Uv, t1); thrust_dir_tan(r, Vv, t2);
+            for (int i = 0; i < 3; ++i) W::stp(lds, mb + (int(MB_PV) + (3 + i) * 8), (t1[i] + t2[i]) * c, p);
+            thrust_dir_tan(q, Up, t1); thrust_dir_tan(r, Vp, t2);
+            for (int i = 0; i < 3; ++i) W::stp(lds, mb + (int(MB_PV) + i * 8), (t1[i] + t2[i]) * c, p);
+            for (int i = 0; i < 4; ++i) W::stp(lds, mb + (int(MB_Q) + i * 7), e[i] * K.A + z[i] * K.B, p);
         }
-        // nominal step and dynamics defect b_k = phi(x_k,u_k) - x_{k+1}; one lane per stage
+        // ---- d/dw columns: one lane per (stage, mth rate), 3N tasks.  d q_i = eps (a_i' q + b_i' r) + b_i g,
+        //      eps = w_m/2 = d sigma/d w_m, g = Z_m q; only a_3' = -h^2/4, a_4' = -h^2/2, b_4' = -h^3/4 are non-zero
+        for (int t = 0; t < 3 * N; t += 64) {
+            vi task = lane + t;
+            vb p = task < 3 * N;
+            vi k = W::sel(p, W::div3(task), vi(0));
+            vi mm = W::sel(p, task - k * 3, vi(0));
+            vi xi = k * NX + m.XI + 6, ui = k * NU + m.UI;
+            vd q[4] = {W::ld(lds, xi), W::ld(lds, xi + 1), W::ld(lds, xi + 2), W::ld(lds, xi + 3)};
+            vd w[3] = {W::ld(lds, ui), W::ld(lds, ui + 1), W::ld(lds, ui + 2)};
+            vd c = W::ld(lds, ui + 3);
+            vd r[4], em[3], g[4];
+            qdot(q, w, r);
+            RkScal K;
+            rk_scalars(h, (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) * 0.25, K);
+            for (int i = 0; i < 3; ++i) em[i] = W::sel(mm == i, vd(1.0), vd(0.0));
+            qdot(q, em, g);                                  // Z_m q
+            vd eps = (em[0] * w[0] + em[1] * w[1] + em[2] * w[2]) * 0.5;
+            const double da3 = -0.25 * h2, da4 = -0.5 * h2, db4 = -0.25 * h * h2;
+            // sums with one primed factor; beta_v = h/6 (1,2,2,1), beta_p = h^2/6 (1,1,1,0); b_2 = b_3 = h/2
+            vd Sv_aad = (K.a3 * (2.0 * da3) + K.a4 * da4) * h6, Sv_abd = (K.a4 * db4) * h6;
+            vd Sv_bad = (K.b4 * da4 + 2.0 * hh * da3) * h6, Sv_bbd = (K.b4 * db4) * h6;
+            vd Sp_aad = K.a3 * (da3 * hp);
+            const double Sp_bad = hh * da3 * hp;            // Sp_abd = Sp_bbd = 0 (node 4 carries no position weight)
+            vd dA = sg_lin(h2, K), dB = vd(-h * h2 / 6.0);
+            vd Uv[4], Vv[4], Up[4], Vp[4], t1[3], t2[3];
+            for (int i = 0; i < 4; ++i) {
+                Uv[i] = (q[i] * Sv_aad + r[i] * Sv_abd) * eps + g[i] * K.Sv_ab;
+                Vv[i] = (q[i] * Sv_bad + r[i] * Sv_bbd) * eps + g[i] * K.Sv_bb;
+                Up[i] = (q[i] * Sp_aad) * eps + g[i] * K.Sp_ab;
+                Vp[i] = (q[i] * Sp_bad) * eps + g[i] * K.Sp_bb;
+            }
+            vi mb = k * int(MB_STRIDE) + m.MB + 4 + mm;
+            thrust_dir_tan(q, Uv, t1); thrust_dir_tan(r, Vv, t2);
+            for (int i = 0; i < 3; ++i) W::stp(lds, mb + (int(MB_PV) + (3 + i) * 8), (t1[i] + t2[i]) * c, p);
+            thrust_dir_tan(q, Up, t1); thrust_dir_tan(r, Vp, t2);
+            for (int i = 0; i < 3; ++i) W::stp(lds, mb + (int(MB_PV) + i * 8), (t1[i] + t2[i]) * c, p);
+            for (int i = 0; i < 4; ++i) W::stp(lds, mb + (int(MB_Q) + i * 7), (q[i] * dA + r[i] * dB) * eps + g[i] * K.B, p);
+        }
+        // ---- d/dc column + nominal step and dynamics defect b_k = phi(x_k,u_k) - x_{k+1}; one lane per stage
         for (int t = 0; t < N; t += 64) {
             vi task = lane + t;
             vb p = task < N;
@@ -479,32 +512,36 @@ struct RtiWave {
             vd c = W::ld(lds, ui + 3);
             // disturbance acceleration f/m (ndp_nmpc_body_rate_ctl.py:155-157) and gravity
             vd acc[3] = {W::ld(lds, fi) * P.inv_mass, W::ld(lds, fi + 1) * P.inv_mass, W::ld(lds, fi + 2) * P.inv_mass - P.g};
-            vd kv[4][3], kq[4][4], vs[4][3], qs[4], td[3];
-            for (int i = 0; i < 4; ++i) qs[i] = x[6 + i];
-            const double cs[4] = {0.0, hh, hh, h};
-            for (int s = 0; s < 4; ++s) {
-                if (s > 0) {
-                    for (int i = 0; i < 4; ++i) qs[i] = x[6 + i] + kq[s - 1][i] * cs[s];
-                    for (int i = 0; i < 3; ++i) vs[s][i] = x[3 + i] + kv[s - 1][i] * cs[s];
-                } else {
-                    for (int i = 0; i < 3; ++i) vs[0][i] = x[3 + i];
-                }
-                thrust_dir(qs, td);
-                for (int i = 0; i < 3; ++i) kv[s][i] = td[i] * c + acc[i];
-                qdot(qs, w, kq[s]);
-            }
-            vi mb = k * int(MB_STRIDE) + m.MB + int(MB_B), xn = xi + NX;
+            vd xn1[10];
+            for (int i = 0; i < 10; ++i) xn1[i] = W::ld(lds, xi + (NX + i));
+            vd q[4] = {x[6], x[7], x[8], x[9]}, r[4];
+            qdot(q, w, r);
+            RkScal K;
+            rk_scalars(h, (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) * 0.25, K);
+            vd tqq[3], tqr[3], trr[3];
+            thrust_dir_tan(q, q, tqq); thrust_dir_tan(q, r, tqr); thrust_dir_tan(r, r, trr);
+            vi mb = k * int(MB_STRIDE) + m.MB;
             for (int i = 0; i < 3; ++i) {
-                vd pn = x[i] + (vs[0][i] + (vs[1][i] + vs[2][i]) * 2.0 + vs[3][i]) * h6;
-                vd vn = x[3 + i] + (kv[0][i] + (kv[1][i] + kv[2][i]) * 2.0 + kv[3][i]) * h6;
-                W::stp(lds, mb + i, pn - W::ld(lds, xn + i), p);
-                W::stp(lds, mb + (3 + i), vn - W::ld(lds, xn + (3 + i)), p);
+                const double e3 = i == 2 ? 1.0 : 0.0;
+                vd Dv = (tqq[i] * K.Sv_aa + tqr[i] * (K.Sv_ab * 2.0) + trr[i] * K.Sv_bb) * 0.5 + e3 * h;
+                vd Dp = (tqq[i] * K.Sp_aa + tqr[i] * (K.Sp_ab * 2.0) + trr[i] * K.Sp_bb) * 0.5 + e3 * (0.5 * h2);
+                W::stp(lds, mb + (int(MB_PV) + (3 + i) * 8 + 7), Dv, p);      // column 7 = d/dc
+                W::stp(lds, mb + (int(MB_PV) + i * 8 + 7), Dp, p);
+                vd vn = x[3 + i] + Dv * c + acc[i] * h;
+                vd pn = x[i] + x[3 + i] * h + Dp * c + acc[i] * (0.5 * h2);
+                W::stp(lds, mb + (int(MB_B) + 3 + i), vn - xn1[3 + i], p);
+                W::stp(lds, mb + (int(MB_B) + i), pn - xn1[i], p);
             }
-            for (int i = 0; i < 4; ++i) {
-                vd qn = x[6 + i] + (kq[0][i] + (kq[1][i] + kq[2][i]) * 2.0 + kq[3][i]) * h6;
-                W::stp(lds, mb + (6 + i), qn - W::ld(lds, xn + (6 + i)), p);
-            }
+            for (int i = 0; i < 4; ++i) W::stp(lds, mb + (int(MB_B) + 6 + i), q[i] * K.A + r[i] * K.B - xn1[6 + i], p);
         }
+    }
+
+    // dA/dsigma of q+ = A q + B r
+    static NDP_D vd sg_lin(double h2, const RkScal &K)
+    {
+        // A = 1 - h^2 sigma/2 + h^4 sigma^2/24 and a4 = 1 - h^2 sigma/2  =>  sigma = (1 - a4) 2/h^2
+        vd sg = (1.0 - K.a4) * (2.0 / h2);
+        return sg * (h2 * h2 / 12.0) - 0.5 * h2;
     }
 
     // ---------------------------------------------------------------- Riccati sweep (MFMA)
