@@ -160,6 +160,9 @@ int ndp_debug_lds_doubles(int N);
 /* Test hook: one v_mfma_f64_16x16x4_f64 on caller-chosen per-lane operands a[64], b[64], c[4][64];
  * d[0..255] = result registers [4][64], d[256..319] = a cross-lane checksum (readlane + wave reductions). */
 int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, double *d);
+/* Profiling hook: enable = 1 makes every instance of the following steps write 16 phase stamps (shader clock);
+ * out (or NULL) receives the [B][16] stamps of the last step before the switch is applied. */
+int ndp_debug_stamps(ndp_handle *h, int enable, double *out);
 int ndp_step_debug(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
                    const double *other, const double *ego_xy, double *u0, double *lds_dump);
 

@@ -33,7 +33,7 @@ EXPORTS = [
     "ndp_default_cfg", "ndp_create", "ndp_destroy", "ndp_last_error", "ndp_set_mlp_weights", "ndp_reset",
     "ndp_reset_device", "ndp_step", "ndp_step_device", "ndp_downwash", "ndp_downwash_device", "ndp_get_iterate",
     "ndp_set_iterate", "ndp_get_status", "ndp_device_iterate_x", "ndp_device_iterate_u", "ndp_device_force",
-    "ndp_synchronize", "ndp_timing_enable", "ndp_timing_read", "ndp_debug_lds_doubles", "ndp_step_debug", "ndp_debug_mfma_probe", "ndp_throttle_reset", "ndp_throttle_update",
+    "ndp_synchronize", "ndp_timing_enable", "ndp_timing_read", "ndp_debug_lds_doubles", "ndp_step_debug", "ndp_debug_mfma_probe", "ndp_debug_stamps", "ndp_throttle_reset", "ndp_throttle_update",
     "ndp_throttle_update_device", "ndp_actuator_cmd", "ndp_actuator_cmd_device", "ndp_throttle_get_state", "ndp_relay_reset", "ndp_relay_formation",
     "ndp_relay_reference", "ndp_relay_reference_device", "ndp_plant_step", "ndp_plant_step_device",
 ]
@@ -82,6 +82,7 @@ def load():
     lib.ndp_debug_lds_doubles.argtypes = [C.c_int]
     lib.ndp_step_debug.argtypes = [vp] * 9
     lib.ndp_debug_mfma_probe.argtypes = [vp] * 4
+    lib.ndp_debug_stamps.argtypes = [vp, C.c_int, vp]
     lib.ndp_throttle_reset.argtypes = [vp]
     lib.ndp_throttle_update.argtypes = [vp] * 4
     lib.ndp_throttle_update_device.argtypes = [vp] * 5

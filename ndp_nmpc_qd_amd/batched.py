@@ -219,6 +219,12 @@ class BatchedNMPC:
     def synchronize(self):
         self._check(self._lib.ndp_synchronize(self._h), "ndp_synchronize")
 
+    def debug_stamps(self, enable=True, read=False):
+        """Whole-batch phase stamps (profiling hook): returns [B,16] of the last step when read=True."""
+        out = np.zeros((self.B, 16)) if read else None
+        self._check(self._lib.ndp_debug_stamps(self._h, int(bool(enable)), _lib.ptr(out)), "ndp_debug_stamps")
+        return out
+
     def timing_enable(self, every=1):
         """Bracket every `every`-th launch of each kernel with HIP events (0 / False: off)."""
         self._check(self._lib.ndp_timing_enable(self._h, int(every)), "ndp_timing_enable")

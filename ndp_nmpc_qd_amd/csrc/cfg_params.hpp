@@ -47,6 +47,7 @@ inline RtiParams to_params(const ndp_cfg &c)
     memcpy(p.lbu, c.lbu, sizeof(p.lbu)); memcpy(p.ubu, c.ubu, sizeof(p.ubu));
     memcpy(p.lbv, c.lbv, sizeof(p.lbv)); memcpy(p.ubv, c.ubv, sizeof(p.ubv));
     p.mu0 = c.mu0; p.thr0 = c.thr0; p.tol = c.tol; p.tau = c.tau;
+    fill_quotients(p);
     return p;
 }
 

@@ -36,11 +36,13 @@ __device__ __forceinline__ double nc_add(double a, double b)
 // ------------------------------------------------------------------------------------------ RTI kernel
 struct BatchPtrs {
     const double *kc;
+    const int *tables;      // host-built index tables (fill_tables)
     const double *x0, *xr, *ur;
     const float *f;
     double *X, *U, *u0;
     int *status, *iters;
     double *dbg;
+    double *stamps;         // [B][16] phase stamps of every instance (ndp_debug_stamps), or null
 };
 
 struct MlpArgs {            // fused downwash (null frag = not fused)
@@ -60,7 +62,7 @@ __device__ __forceinline__ bool gate_open(const double *other_inst, const double
 // FUSED: the wave first predicts its own instance's disturbance force (gate + MLP over the N+1 <= 32 horizon rows,
 // one 32x32 f32 MFMA tile) and leaves it in the LDS staging slot the RTI program reads f from -- no second
 // launch and no trip of f through HBM.
-template <int NSLOT, int WAVES, bool FUSED>
+template <int NSLOT, int WAVES, bool FUSED, int NC = 0>
 __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs bp, int B, int lds_per_wave, MlpArgs ma)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
     const bool active = inst_raw < B;
     if (!FUSED && !active) return;
     const int inst = active ? inst_raw : B - 1;   // fused: idle waves of the last workgroup still take part in the barriers
-    const int N = P.N;
+    const int N = NC ? NC : P.N;
     const size_t nx = (size_t)(N + 1) * NX, nu = (size_t)N * NU, nf = (size_t)(N + 1) * 3;
     RtiIo io;
     io.x0 = bp.x0 + (size_t)inst * NX;
@@ -84,8 +86,11 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
     io.dbg = bp.dbg;
     io.f_in_lds = 0;
     io.kc = bp.kc;
-    WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lds_per_wave);
-    using Prog = RtiWave<WaveGfx950, NSLOT>;
+    io.tables = bp.tables;
+    io.stamps = bp.stamps ? bp.stamps + (size_t)inst * 16 : nullptr;
+    const int lpw = NC ? ((lds_doubles(NC) + 1) & ~1) : lds_per_wave;
+    WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lpw);
+    using Prog = RtiWave<WaveGfx950, NSLOT, NC, true, NC ? 1 : 0>;   // the compile-time-horizon form is also the 1-iteration form
     typename Prog::InBuf inb;
     double x0v;
     Prog::issue_first(P, io, inb, x0v);      // every global input of the RTI step is now in flight (hidden under the MLP when fused)
@@ -104,14 +109,17 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
         }
         const LdsMap m = make_map(N);
         if (io.dbg && lane == 0) io.dbg[m.KT + 9] = (double)__builtin_amdgcn_s_memtime();
+        if (io.stamps && lane == 0) io.stamps[9] = (double)__builtin_amdgcn_s_memtime();
         // the whole workgroup's LDS is still unused: park the weight fragments there for the MLP phase
         lds_f32 wl = (lds_f32)smem;
         stage_fragments(ma.frag, wl, (int)threadIdx.x, 64 * WAVES);
         __syncthreads();
+        if (io.stamps && lane == 0) io.stamps[11] = (double)__builtin_amdgcn_s_memtime();
         mlp_tile(wl, zb, lane, o);
         __syncthreads();                              // every wave is done with the weights before LDS becomes RTI state
         if (!active) return;
         if (io.dbg && lane == 0) io.dbg[m.KT + 10] = (double)__builtin_amdgcn_s_memtime();
+        if (io.stamps && lane == 0) io.stamps[10] = (double)__builtin_amdgcn_s_memtime();
         if (j < np1 && h == 0) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -560,7 +568,9 @@ struct ndp_handle {
     int *dStatus = nullptr, *dIters = nullptr;
     float *dForce = nullptr, *dFrag = nullptr;
     double *dKC = nullptr;     // constants block of the LDS image (fill_kc)
+    int *dTables = nullptr;    // per-lane index tables of the Riccati sweep (fill_tables)
     double *dThr = nullptr;    // hover-throttle estimator state, SoA [8][B]
+    double *dStamps = nullptr; // [B][16] whole-batch phase stamps (ndp_debug_stamps)
     double *dRelay = nullptr;  // follower relay: [B][4] = filtered offset xyz + initialised flag
     double *sThr = nullptr;    // staging: vz[B] throttle[B] k[B] | u0[B][4] cmd[B][4]
     bool have_mlp = false;
@@ -626,7 +636,7 @@ int ndp_destroy(ndp_handle *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    void *ptrs[] = {h->dRelay, h->dThr, h->sThr, h->dKC, h->dX, h->dU, h->dStatus, h->dIters, h->dForce, h->dFrag, h->sx0, h->sxr, h->sur,
+    void *ptrs[] = {h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dX, h->dU, h->dStatus, h->dIters, h->dForce, h->dFrag, h->sx0, h->sxr, h->sur,
                     h->sother, h->sego, h->su0, h->sdbg, h->sf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -677,6 +687,10 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         double kc[KC_SC];
         fill_kc(h->P, kc);
         if ((e = hipMemcpyAsync(h->dKC, kc, sizeof(kc), hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail("hipMemcpy kc", e);
+        ALLOC(h->dTables, TB_WORDS * 4);
+        std::vector<int> tb(TB_WORDS);
+        fill_tables(cfg->N, tb.data());
+        if ((e = hipMemcpyAsync(h->dTables, tb.data(), TB_WORDS * 4, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail("hipMemcpy tables", e);
         if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
     }
     ALLOC(h->sx0, B * NX * 8); ALLOC(h->sxr, nxs(h) * 8); ALLOC(h->sur, nus(h) * 8);
@@ -692,7 +706,8 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     const int lds_bytes = (int)(per_wave_bytes * h->waves);
     const void *fns[] = {(const void *)rti_kernel<3, 4, false>, (const void *)rti_kernel<3, 2, false>, (const void *)rti_kernel<3, 1, false>,
                          (const void *)rti_kernel<5, 4, false>, (const void *)rti_kernel<5, 2, false>, (const void *)rti_kernel<5, 1, false>,
-                         (const void *)rti_kernel<3, 4, true>, (const void *)rti_kernel<3, 2, true>, (const void *)rti_kernel<3, 1, true>};
+                         (const void *)rti_kernel<3, 4, true>, (const void *)rti_kernel<3, 2, true>, (const void *)rti_kernel<3, 1, true>,
+                         (const void *)rti_kernel<3, 4, false, 20>, (const void *)rti_kernel<3, 4, true, 20>};
     if ((e = hipFuncSetAttribute((const void *)mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(FR_TOTAL * sizeof(float)))) != hipSuccess)
         return fail("hipFuncSetAttribute(mlp_kernel)", e);
@@ -757,7 +772,7 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
                       double *d_u0, double *d_dbg, hipStream_t s, const double *d_other = nullptr,
                       const double *d_ego_xy = nullptr)
 {
-    BatchPtrs bp{h->dKC, d_x0, d_xr, d_ur, d_f, h->dX, h->dU, d_u0, h->dStatus, h->dIters, d_dbg};
+    BatchPtrs bp{h->dKC, h->dTables, d_x0, d_xr, d_ur, d_f, h->dX, h->dU, d_u0, h->dStatus, h->dIters, d_dbg, h->dStamps};
     MlpArgs ma{d_other ? h->dFrag : nullptr, d_other, d_ego_xy, h->dForce, h->cfg.r_horiz * h->cfg.r_horiz};
     const int B = h->cfg.batch, W = h->waves;
     const dim3 grid((B + W - 1) / W), block(64 * W);
@@ -766,7 +781,10 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     int rc = begin_timing(h, s, 0);
     if (rc) return rc;
 #define LAUNCH(NS, WV, FU) hipLaunchKernelGGL((rti_kernel<NS, WV, FU>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma)
-    if (d_other) { if (W == 4) LAUNCH(3, 4, true); else if (W == 2) LAUNCH(3, 2, true); else LAUNCH(3, 1, true); }
+    if (h->cfg.N == 20 && h->cfg.n_rti == 1 && W == 4) {   // the reference configuration (params/nmpc_params.py:9, 1 RTI iteration): compile-time instantiation
+        if (d_other) hipLaunchKernelGGL((rti_kernel<3, 4, true, 20>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma);
+        else hipLaunchKernelGGL((rti_kernel<3, 4, false, 20>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma);
+    } else if (d_other) { if (W == 4) LAUNCH(3, 4, true); else if (W == 2) LAUNCH(3, 2, true); else LAUNCH(3, 1, true); }
     else if (ns <= 3) { if (W == 4) LAUNCH(3, 4, false); else if (W == 2) LAUNCH(3, 2, false); else LAUNCH(3, 1, false); }
     else { if (W == 4) LAUNCH(5, 4, false); else if (W == 2) LAUNCH(5, 2, false); else LAUNCH(5, 1, false); }
 #undef LAUNCH
@@ -1138,6 +1156,26 @@ int ndp_plant_step(ndp_handle *h, double *x, const double *u, const double *f, d
     std::lock_guard<std::mutex> lk(h->mu);
     NDP_HIP(h, hipMemcpyAsync(x, h->sx0, B * 80, hipMemcpyDeviceToHost, h->stream));
     NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// test/profiling hook: every instance writes its phase stamps (shader clock) to [B][16] doubles
+int ndp_debug_stamps(ndp_handle *h, int enable, double *out)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    NDP_HIP(h, hipDeviceSynchronize());
+    const size_t bytes = (size_t)h->cfg.batch * 16 * 8;
+    if (out && h->dStamps) NDP_HIP(h, hipMemcpy(out, h->dStamps, bytes, hipMemcpyDeviceToHost));
+    if (enable && !h->dStamps) {
+        NDP_HIP(h, hipMalloc((void **)&h->dStamps, bytes));
+        NDP_HIP(h, hipMemset(h->dStamps, 0, bytes));
+    } else if (!enable && h->dStamps) {
+        (void)hipFree(h->dStamps);
+        h->dStamps = nullptr;
+    }
     return 0;
 }
 

@@ -52,7 +52,17 @@ struct RtiParams {
     double dt, inv_mass, g;
     double Qd[10], Rd[4], lbu[4], ubu[4], lbv[3], ubv[3];
     double mu0, thr0, tol, tau;
+    // host-evaluated quotients (an f64 divide is a ~30-instruction VALU sequence on the device, even for uniforms)
+    double h_6, h2_6, h4_24, h3_6, h4_12, two_over_h2, inv2m;
 };
+
+NDP_HD void fill_quotients(RtiParams &p)
+{
+    const double h = p.dt, h2 = h * h;
+    p.h_6 = h / 6.0; p.h2_6 = h2 / 6.0; p.h4_24 = h2 * h2 / 24.0; p.h3_6 = h * h2 / 6.0; p.h4_12 = h2 * h2 / 12.0;
+    p.two_over_h2 = 2.0 / h2;
+    p.inv2m = 1.0 / (2.0 * (7 * p.N - 3));
+}
 
 struct RtiIo {            // global-memory views of ONE instance
     const double *x0;     // [10]
@@ -65,6 +75,8 @@ struct RtiIo {            // global-memory views of ONE instance
     double *dbg;          // optional dump area (tests), or null
     int f_in_lds;         // 1: the caller already left f (as doubles) in the LDS staging slot TF (fused downwash)
     const double *kc;     // [KC_SC] lane-indexable constants block prepared by the host (fill_kc)
+    double *stamps = nullptr;   // optional [16] per-instance phase stamps (whole-batch profiling), or null
+    const int *tables = nullptr;   // [TB_WORDS] host-built index tables (fill_tables), read when RtiWave<..., HT = true>
 };
 
 struct LdsMap {
@@ -108,8 +120,15 @@ NDP_HD void fill_kc(const RtiParams &P, double *kc)
     for (int i = 0; i < 3; ++i) { kc[KC_LBV + i] = P.lbv[i]; kc[KC_UBV + i] = P.ubv[i]; }
 }
 
-template <class W, int NSLOT>
+// NC > 0: the horizon is a compile-time constant (every LDS offset folds into the DS instruction's immediate, every
+// task-range predicate into a constant lane mask); NC = 0: horizon read from RtiParams at run time.
+// HT: the per-lane index tables come from a host-built block (RtiIo::tables, fill_tables) instead of ~900 integer
+// VALU instructions per launch.
+// NR > 0: compile-time number of RTI iterations per step (NR = 1 removes the iteration loop, which otherwise makes the
+// compiler hoist every address computation of the loop body in front of it and spill them).
+template <class W, int NSLOT, int NC = 0, bool HT = false, int NR = 0>
 struct RtiWave {
+    static NDP_D int horizon(const RtiParams &P) { return NC ? NC : P.N; }
     using vd = typename W::vd;
     using vi = typename W::vi;
     using vb = typename W::vb;
@@ -148,7 +167,7 @@ struct RtiWave {
 
     // ---------------------------------------------------------------- index tables
     // element (r, c) of M~_k = [[A b 0 B], [0 1 0 0], [0 0 0 0]] -> LDS offset (+ k * mul)
-    static NDP_D void m_entry(const LdsMap &m, vi r, vi c, vi &off, vi &mul)
+    static NDP_HD void m_entry(const LdsMap &m, vi r, vi c, vi &off, vi &mul)
     {
         vb isP = r < 3, isPV = r < 6, isQ = (r >= 6) && (r < 10);
         vb colq = (c >= 6) && (c < 10), colu = c >= 12;
@@ -167,7 +186,7 @@ struct RtiWave {
     }
 
     // element (row, col) of C~_k = [[Q q 0 0], [q' 0 0 r'], [0], [0 r 0 R]] -> LDS offset (+ k * mul)
-    static NDP_D void c_entry(const LdsMap &m, vi row, vi col, vi &off, vi &mul)
+    static NDP_HD void c_entry(const LdsMap &m, vi row, vi col, vi &off, vi &mul)
     {
         vb rx = row < 10, cx = col < 10, ru = row >= 12, cu = col >= 12;
         vb dgx = rx && (row == col) && (row < 6);
@@ -186,15 +205,26 @@ struct RtiWave {
         mul = W::sel(isvar, vi(int(CB_STRIDE)), vi(0));
     }
 
-    static NDP_D void build_tables(const LdsMap &m, Tables &T)
+    // lane-derived predicates and constants of the tables (cheap: a handful of compares)
+    static NDP_HD void lane_preds(Tables &T)
     {
+        vi lane = W::lane();
+        vi g = lane >> 4, j = lane & 15, jc = j & 3;
+        T.kt_pred = j >= 12;
+        T.lo4 = j < 4;
+        T.col0 = j == 0;
+        T.cof_sign = W::sel(((g + jc) & 1) == 1, vd(-1.0), vd(1.0));
+        T.lam_diag = g == jc;
+        for (int c = 0; c < 4; ++c) T.eye[c] = W::sel(j == g + 4 * c, vd(1.0), vd(0.0));
+    }
+
+    static NDP_HD void build_tables(const LdsMap &m, Tables &T)
+    {
+        lane_preds(T);
         vi lane = W::lane();
         vi g = lane >> 4, j = lane & 15;
         for (int c = 0; c < 3; ++c) m_entry(m, g + 4 * c, j, T.mk_off[c], T.mk_mul[c]);
         for (int r = 0; r < 4; ++r) c_entry(m, g + 4 * r, j, T.c_off[r], T.c_mul[r]);
-        T.kt_pred = j >= 12;
-        T.lo4 = j < 4;
-        T.col0 = j == 0;
         for (int c = 0; c < 3; ++c) {
             T.kt_off[c] = (g + 4 * c) * 4 + (j & 3) + m.KT;
             vi mo, mm;
@@ -222,9 +252,31 @@ struct RtiWave {
                 T.minor_off[3 * a + b] = ra * 4 + cb + m.SC;
             }
         T.own_off = g * 4 + jc + m.SC;
-        T.cof_sign = W::sel(((g + jc) & 1) == 1, vd(-1.0), vd(1.0));
-        T.lam_diag = g == jc;
-        for (int c = 0; c < 4; ++c) T.eye[c] = W::sel(j == g + 4 * c, vd(1.0), vd(0.0));
+    }
+
+    // the integer fields of Tables in a fixed order: f(index, field).  Used by the host to serialise the tables
+    // (fill_tables) and by the device to read them back (load_tables).
+    enum { TB_FIELDS = 48 };
+    template <class F>
+    static NDP_HD void for_each_int(Tables &T, F &&f)
+    {
+        int i = 0;
+        for (int c = 0; c < 3; ++c) { f(i++, T.mk_off[c]); f(i++, T.mk_mul[c]); f(i++, T.fw_off[c]); f(i++, T.fw_mul[c]); }
+        for (int r = 0; r < 4; ++r) { f(i++, T.c_off[r]); f(i++, T.c_mul[r]); }
+        for (int c = 0; c < 3; ++c) { f(i++, T.kt_off[c]); f(i++, T.kt_st[c]); f(i++, T.zx_st[c]); f(i++, T.zx_mul[c]); }
+        f(i++, T.mu_off); f(i++, T.mu_mul); f(i++, T.kt_mul); f(i++, T.zu_st); f(i++, T.zu_mul);
+        f(i++, T.lam_w_off); f(i++, T.own_off);
+        for (int a = 0; a < 9; ++a) f(i++, T.minor_off[a]);
+    }
+    // block layout [field / 4][lane][field % 4]: the four fields of a group are one 16-byte load per lane, a
+    // contiguous 1 KB per wave
+    static NDP_HD int tb_word(int field, int lane) { return ((field >> 2) * 64 + lane) * 4 + (field & 3); }
+
+    static NDP_D void load_tables(const int *g, Tables &T)
+    {
+        lane_preds(T);
+        vi lane = W::lane();
+        for_each_int(T, [&](int i, vi &fld) { fld = W::gldi(g, lane * 4 + ((i >> 2) * 256 + (i & 3))); });
     }
 
     // ---------------------------------------------------------------- inputs
@@ -238,7 +290,7 @@ struct RtiWave {
     // issue every global load of this instance (nothing waits here)
     static NDP_D void issue_inputs(const RtiParams &P, const RtiIo &io, InBuf &b, bool first)
     {
-        const int N = P.N;
+        const int N = horizon(P);
         vi lane = W::lane();
         const int nx = (N + 1) * NX, nu = N * NU, nf = (N + 1) * 3;
         const bool have_f = P.use_fd && io.f && !io.f_in_lds;
@@ -264,7 +316,7 @@ struct RtiWave {
     // land them in LDS (first use of the loaded values: the wait sits here)
     static NDP_D void commit_inputs(const RtiParams &P, const LdsMap &m, const InBuf &b, lp lds, bool first)
     {
-        const int N = P.N;
+        const int N = horizon(P);
         vi lane = W::lane();
         const int nx = (N + 1) * NX, nu = N * NU, nf = (N + 1) * 3;
         for (int t = 0; t < RX; ++t) {
@@ -289,7 +341,7 @@ struct RtiWave {
     // residual [p-pr, v-vr, 0, E(qr) q, u-ur]; nmpc_body_rate_ctl.py:164-180
     static NDP_D void build_cost(const RtiParams &P, const LdsMap &m, lp lds)
     {
-        const int N = P.N;
+        const int N = horizon(P);
         vi lane = W::lane();
         // Three task families, each at most a few 64-lane rounds.  Every LDS read of every round is issued before the
         // first result is needed (one wait per family instead of one per round), then computed, then stored.
@@ -411,14 +463,14 @@ struct RtiWave {
         vd a3, a4, b4, A, B;
         vd Sv_aa, Sv_ab, Sv_bb, Sp_aa, Sp_ab, Sp_bb;
     };
-    static NDP_D void rk_scalars(double h, vd sg, RkScal &K)
+    static NDP_D void rk_scalars(const RtiParams &P, vd sg, RkScal &K)
     {
-        const double h2 = h * h, hh = 0.5 * h, h6 = h / 6.0, hp = h2 / 6.0;
+        const double h = P.dt, h2 = h * h, hh = 0.5 * h, h6 = P.h_6, hp = P.h2_6;
         K.a3 = 1.0 - sg * (0.25 * h2);
         K.a4 = 1.0 - sg * (0.5 * h2);
         K.b4 = K.a3 * h;
-        K.A = 1.0 - sg * (0.5 * h2) + sg * sg * (h2 * h2 / 24.0);
-        K.B = h - sg * (h * h2 / 6.0);
+        K.A = 1.0 - sg * (0.5 * h2) + sg * sg * P.h4_24;
+        K.B = h - sg * P.h3_6;
         K.Sv_aa = (3.0 + K.a3 * K.a3 * 2.0 + K.a4 * K.a4) * h6;
         K.Sv_ab = (2.0 * hh + K.a3 * (2.0 * hh) + K.a4 * K.b4) * h6;
         K.Sv_bb = (4.0 * hh * hh + K.b4 * K.b4) * h6;
@@ -430,8 +482,8 @@ struct RtiWave {
     // ERK4 (one step of dt) + forward sensitivities -> stage blocks MB_k, in closed form (see rk_scalars)
     static NDP_D void linearize(const RtiParams &P, const LdsMap &m, lp lds)
     {
-        const int N = P.N;
-        const double h = P.dt, h2 = h * h, hh = 0.5 * h, h6 = h / 6.0, hp = h2 / 6.0;
+        const int N = horizon(P);
+        const double h = P.dt, h2 = h * h, hh = 0.5 * h, h6 = P.h_6, hp = P.h2_6;
         vi lane = W::lane();
         // ---- d/dq columns: one lane per (stage, j), 4N tasks
         for (int t = 0; t < 4 * N; t += 64) {
@@ -446,7 +498,7 @@ struct RtiWave {
             vd r[4], e[4], z[4];
             qdot(q, w, r);
             RkScal K;
-            rk_scalars(h, (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) * 0.25, K);
+            rk_scalars(P, (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) * 0.25, K);
             for (int i = 0; i < 4; ++i) e[i] = W::sel(j == i, vd(1.0), vd(0.0));
             qdot(e, w, z);                                   // Z e_j
             vd Uv[4], Vv[4], Up[4], Vp[4], t1[3], t2[3];
@@ -475,7 +527,7 @@ struct RtiWave {
             vd r[4], em[3], g[4];
             qdot(q, w, r);
             RkScal K;
-            rk_scalars(h, (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) * 0.25, K);
+            rk_scalars(P, (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) * 0.25, K);
             for (int i = 0; i < 3; ++i) em[i] = W::sel(mm == i, vd(1.0), vd(0.0));
             qdot(q, em, g);                                  // Z_m q
             vd eps = (em[0] * w[0] + em[1] * w[1] + em[2] * w[2]) * 0.5;
@@ -485,7 +537,7 @@ struct RtiWave {
             vd Sv_bad = (K.b4 * da4 + 2.0 * hh * da3) * h6, Sv_bbd = (K.b4 * db4) * h6;
             vd Sp_aad = K.a3 * (da3 * hp);
             const double Sp_bad = hh * da3 * hp;            // Sp_abd = Sp_bbd = 0 (node 4 carries no position weight)
-            vd dA = sg_lin(h2, K), dB = vd(-h * h2 / 6.0);
+            vd dA = sg_lin(P, K), dB = vd(-P.h3_6);
             vd Uv[4], Vv[4], Up[4], Vp[4], t1[3], t2[3];
             for (int i = 0; i < 4; ++i) {
                 Uv[i] = (q[i] * Sv_aad + r[i] * Sv_abd) * eps + g[i] * K.Sv_ab;
@@ -517,7 +569,7 @@ struct RtiWave {
             vd q[4] = {x[6], x[7], x[8], x[9]}, r[4];
             qdot(q, w, r);
             RkScal K;
-            rk_scalars(h, (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) * 0.25, K);
+            rk_scalars(P, (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) * 0.25, K);
             vd tqq[3], tqr[3], trr[3];
             thrust_dir_tan(q, q, tqq); thrust_dir_tan(q, r, tqr); thrust_dir_tan(r, r, trr);
             vi mb = k * int(MB_STRIDE) + m.MB;
@@ -537,11 +589,11 @@ struct RtiWave {
     }
 
     // dA/dsigma of q+ = A q + B r
-    static NDP_D vd sg_lin(double h2, const RkScal &K)
+    static NDP_D vd sg_lin(const RtiParams &P, const RkScal &K)
     {
         // A = 1 - h^2 sigma/2 + h^4 sigma^2/24 and a4 = 1 - h^2 sigma/2  =>  sigma = (1 - a4) 2/h^2
-        vd sg = (1.0 - K.a4) * (2.0 / h2);
-        return sg * (h2 * h2 / 12.0) - 0.5 * h2;
+        vd sg = (1.0 - K.a4) * P.two_over_h2;
+        return sg * P.h4_12 - 0.5 * (P.dt * P.dt);
     }
 
     // ---------------------------------------------------------------- Riccati sweep (MFMA)
@@ -587,7 +639,7 @@ struct RtiWave {
     static NDP_D bool riccati_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, lp lds,
                                     const RtiIo *io = nullptr)
     {
-        const int N = P.N;
+        const int N = horizon(P);
         bool ok = true;
         vi lane = W::lane();
         vi g = lane >> 4, j = lane & 15;
@@ -719,7 +771,7 @@ struct RtiWave {
     // order: du_k[0..3] k=0..N-1 (idxbu), then dv_k[0..2] k=1..N-1 (idxbx = 3,4,5; nmpc_body_rate_ctl.py:56-61)
     static NDP_D void build_slots(const RtiParams &P, const LdsMap &m, Slots &S)
     {
-        const int N = P.N, nu = 4 * N, mcon = 7 * N - 3;
+        const int N = horizon(P), nu = 4 * N, mcon = 7 * N - 3;
         vi lane = W::lane();
         for (int s = 0; s < NSLOT; ++s) {
             vi n = lane + 64 * s;
@@ -777,9 +829,9 @@ struct RtiWave {
     // diag += Gamma, grad += gamma on the bounded variables (same algorithm as oracle orc_qp_solve).
     static NDP_D int ipm(const RtiParams &P, const LdsMap &m, const Tables &T, Slots &S, lp lds, int &iters_out)
     {
-        const int N = P.N, mcon = 7 * N - 3;
+        const int N = horizon(P);
         const int nzx = (N + 1) * NX, nzu = N * NU;
-        const double inv2m = 1.0 / (2.0 * mcon);
+        const double inv2m = P.inv2m;
         vi lane = W::lane();
         int status = 0, iters = 0;
         // cold start at dz = 0
@@ -896,6 +948,10 @@ struct RtiWave {
             vd t = W::clock();
             W::gst(io.dbg, W::lane() * 0 + (m.KT + idx), t, W::lane() == 0);
         }
+        if (io.stamps) {
+            vd t = W::clock();
+            W::gst(io.stamps, W::lane() * 0 + idx, t, W::lane() == 0);
+        }
     }
 
     // ---------------------------------------------------------------- the control step
@@ -919,7 +975,7 @@ struct RtiWave {
 
     static NDP_D void run(const RtiParams &P, const RtiIo &io, lp lds, InBuf &inb, vd x0v)
     {
-        const int N = P.N;
+        const int N = horizon(P);
         const LdsMap m = make_map(N);
         const int nzx = (N + 1) * NX, nzu = N * NU;
         stamp(io, m, 0);
@@ -933,9 +989,11 @@ struct RtiWave {
             fkeep[t] = io.f_in_lds ? W::ldp(lds, i + m.TF, i < (N + 1) * 3) : vd(0.0);
         }
         Tables T;
-        build_tables(m, T);
+        if (HT) load_tables(io.tables, T);      // in flight while the inputs are committed and the cost / dynamics blocks built
+        else build_tables(m, T);
         stamp(io, m, 1);
-        for (int it = 0; it < P.n_rti; ++it) {
+        const int n_rti = NR ? NR : P.n_rti;
+        for (int it = 0; it < n_rti; ++it) {
             if (it > 0) issue_inputs(P, io, inb, false);
             if (io.f_in_lds)
                 for (int t = 0; t < RF; ++t) inb.f[t] = fkeep[t];
@@ -989,7 +1047,7 @@ struct RtiWave {
             // last RTI iteration the new iterate goes straight to global memory as well.
             {
                 constexpr int RZ = RX + RU;     // rounds that cover X|U contiguously: nzx + nzu <= 64 * RZ
-                const bool last = it + 1 == P.n_rti;
+                const bool last = it + 1 == n_rti;
                 vd xa[RZ], xc[RZ];
                 for (int t = 0; t < RZ; ++t) {
                     vi i = W::imin(lane + 64 * t, nzx + nzu - 1);
@@ -1025,5 +1083,36 @@ struct RtiWave {
         W::gsti(io.iters, iters);
     }
 };
+
+// ---------------------------------------------------------------- host-built index tables
+// One-lane scalar backend: runs build_tables for a single lane on the host so that the serialised tables are
+// produced by the very code the in-kernel path (HT = false, used by the emulator tests) executes.
+struct LaneW {
+    using vd = double;
+    using vi = int;
+    using vb = bool;
+    struct vd4 { double r[4]; };
+    using lds_ptr = double *;
+    // host-only on purpose (no device attribute): only fill_tables, a host function, instantiates code that calls them
+    static int &cur() { static thread_local int l = 0; return l; }
+    static vi lane() { return cur(); }
+    static vd sel(vb p, vd a, vd b) { return p ? a : b; }
+    static vi sel(vb p, vi a, vi b) { return p ? a : b; }
+};
+
+enum { TB_WORDS = 48 * 64 };
+
+inline void fill_tables(int N, int *out /* [TB_WORDS] */)
+{
+    using Prog = RtiWave<LaneW, 1>;
+    const LdsMap m = make_map(N);
+    for (int i = 0; i < TB_WORDS; ++i) out[i] = 0;
+    for (int lane = 0; lane < 64; ++lane) {
+        LaneW::cur() = lane;
+        typename Prog::Tables T;
+        Prog::build_tables(m, T);
+        Prog::for_each_int(T, [&](int i, int &fld) { out[Prog::tb_word(i, lane)] = fld; });
+    }
+}
 
 }  // namespace ndp

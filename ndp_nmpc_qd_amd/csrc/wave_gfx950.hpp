@@ -45,6 +45,7 @@ struct WaveGfx950 {
     static NDP_D vd gldf(const float *g, vi off, vb p) { return p ? (double)g[off] : 0.0; }
     static NDP_D vd gldu(const double *g, vi off) { return g[off]; }
     static NDP_D vd gldfu(const float *g, vi off) { return (double)g[off]; }
+    static NDP_D vi gldi(const int *g, vi off) { return g[off]; }
     static NDP_D vi imin(vi a, vi b) { return a < b ? a : b; }
     static NDP_D void gst(double *g, vi off, vd v, vb p) { if (p) g[off] = v; }
     static NDP_D void gsti(int *g, int v) { if (g && lane() == 0) *g = v; }

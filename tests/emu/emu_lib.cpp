@@ -23,9 +23,15 @@ int emu_rti_step(const ndp_cfg *cfg, const double *x0, const double *xr, const d
     double kc[ndp::KC_SC];
     ndp::fill_kc(P, kc);
     ndp::RtiIo io{x0, xr, ur, f, X, U, u0, status, iters, lds_dump, 0, kc};
+    std::vector<int> tb(ndp::TB_WORDS);
+    ndp::fill_tables(P.N, tb.data());
+    io.tables = tb.data();
     const int ns = ndp::slots_for(P.N);
-    if (ns <= 3) ndp::RtiWave<emu::Wave, 3>::run(P, io, lds.data());
-    else if (ns <= 5) ndp::RtiWave<emu::Wave, 5>::run(P, io, lds.data());
+    // horizon 20 and the 5-slot form run as the product does (host-built tables; N = 20 also compile-time horizon);
+    // the other horizons build the tables in the wave program
+    if (P.N == 20 && P.n_rti == 1) ndp::RtiWave<emu::Wave, 3, 20, true, 1>::run(P, io, lds.data());
+    else if (ns <= 3) ndp::RtiWave<emu::Wave, 3>::run(P, io, lds.data());
+    else if (ns <= 5) ndp::RtiWave<emu::Wave, 5, 0, true>::run(P, io, lds.data());
     else return -1;
     if (counters) {
         counters[0] = emu::stats().mfma; counters[1] = emu::stats().lds_ld;

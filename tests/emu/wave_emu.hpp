@@ -97,6 +97,7 @@ struct Wave {
     static void gst(double *g, const vi &off, const vd &val, const vb &p) { for (int l = 0; l < 64; ++l) if (p.v[l]) g[off.v[l]] = val.v[l]; }
     static vd gldu(const double *g, const vi &off) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = g[off.v[l]]; return o; }
     static vd gldfu(const float *g, const vi &off) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)g[off.v[l]]; return o; }
+    static vi gldi(const int *g, const vi &off) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = g[off.v[l]]; return o; }
     static vi imin(const vi &a, const vi &b) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return o; }
     static void gsti(int *g, int val) { if (g) *g = val; }
 
