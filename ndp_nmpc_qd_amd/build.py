@@ -24,7 +24,8 @@ def build(force=False, verbose=False):
     # live across a basic block or feeds VALU/LDS is copied through v_accvgpr_read/write behind full-latency s_nops,
     # which serialised the matrix pipe against the VALU in the Riccati sweep.
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form",
-           "-fPIC", "-shared", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-fPIC", "-shared", "-o", LIB] + os.environ.get("NDP_EXTRA_HIPCC_FLAGS", "").split() \
+          + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

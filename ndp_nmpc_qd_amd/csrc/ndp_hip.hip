@@ -158,75 +158,94 @@ typedef float f16_t __attribute__((ext_vector_type(16)));
 // Fragment blob (built on the host by make_fragments, parked in LDS during the MLP phase), in float units:
 //   FR_L1  12 x 64 f32     layer-1 A operands for v_mfma_f32_32x32x2_f32 (K = 6 inputs)
 //   FR_B1/B2/B3, FR_W4 ([128 features][4]: w0 w1 w2 0), FR_B4
-//   FR_BF  layers 2 and 3 as bf16 triples: 32 records (16 per layer) x 3 splits (hi, mid, lo) x 64 lanes x 8 bf16
+//   FR_HF  layers 2 and 3 as fp16 pairs: 32 records (16 per layer) x 2 splits (hi, lo * 2^11) x 64 lanes x 8 halves
+// The blob is moved by LDS-DMA in 1-KB pieces (one global_load_lds_dwordx4 per wave): its size is a multiple of 256 floats.
 enum { FR_L1 = 0, FR_B1 = FR_L1 + 12 * 64, FR_B2 = FR_B1 + 128, FR_B3 = FR_B2 + 64, FR_W4 = FR_B3 + 128,
-       FR_B4 = FR_W4 + 4 * 128, FR_BF = FR_B4 + 4, FR_REC = 3 * 64 * 8 / 2 /* floats per record */,
-       FR_TOTAL = FR_BF + 32 * FR_REC };
-static_assert(FR_BF % 4 == 0 && FR_W4 % 4 == 0 && FR_TOTAL % 4 == 0, "16-byte alignment of the LDS image");
+       FR_B4 = FR_W4 + 4 * 128, FR_HF = FR_B4 + 4, FR_REC = 2 * 64 * 8 / 2 /* floats per record */,
+       FR_USED = FR_HF + 32 * FR_REC, FR_CHUNKS = (FR_USED + 255) / 256, FR_TOTAL = FR_CHUNKS * 256 };
+static_assert(FR_HF % 4 == 0 && FR_W4 % 4 == 0, "16-byte alignment of the LDS image");
 
 __device__ __forceinline__ int f0(int r) { return (r & 3) + 8 * (r >> 2); }
 
 // The four layers for one 32-row tile held by one wave.  zb[s] = input feature 2s + (lane>>5) of row lane&31;
 // returns the three outputs of row lane&31 in o[] (both half-waves hold the full sums).
 
-// All threads of the workgroup copy the fragment blob (FR_TOTAL floats = 70.3 KB, L2-resident) into LDS with 16-byte
-// accesses.  Streaming it per wave straight from L2 made 1024 waves fetch the same lines in lockstep (channel
-// hot-spotting: the MLP tile took 33k cycles at B = 1024 against 25k alone and a 17k matrix-pipe floor).
+// The workgroup copies the fragment blob (FR_TOTAL floats, L2-resident) into LDS by LDS-DMA: each wave issues one
+// global_load_lds_dwordx4 per 1-KB piece (64 lanes x 16 B, lane-linear destination), nothing passes through VGPRs and
+// all pieces are in flight at once; the caller's __syncthreads() (which waits vmcnt(0)) retires them.  Through
+// registers (global_load_dwordx4 + ds_write_b128 per thread and pass) the same copy took 7.5k cycles per workgroup.
+// Streaming the weights per wave straight from L2 instead made 1024 waves fetch the same lines in lockstep (channel
+// hot-spotting: the MLP tile took 33k cycles at B = 1024 against 25k alone).
 __device__ __forceinline__ void stage_fragments(const float *__restrict__ fr, lds_f32 dst, int tid, int nthreads)
 {
-    typedef float f4_t __attribute__((ext_vector_type(4)));
-    const f4_t *src = reinterpret_cast<const f4_t *>(fr);
-    __attribute__((address_space(3))) f4_t *d4 = (__attribute__((address_space(3))) f4_t *)dst;
-    for (int i = tid; i < FR_TOTAL / 4; i += nthreads) d4[i] = src[i];
+    const int wave = tid >> 6, lane = tid & 63, nw = nthreads >> 6;
+    for (int c = wave; c < FR_CHUNKS; c += nw)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fr + c * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void *)(dst + c * 256), 16, 0, 0);
 }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-struct Split3 { bf16x8 hi, mid, lo; };
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+struct Split2 { h16x8 hi, lo; };
+#define NDP_LO_SCALE 2048.0f            // 2^11: the low parts are carried scaled so that they stay fp16-normal
+#define NDP_LO_INV (1.0f / 2048.0f)
+#define NDP_H16_CAP 65000.0f            // activations are capped below the fp16 overflow threshold (see split2)
 
-// x = hi + mid + lo with three bf16 terms (8 + 8 + 8 significand bits = fp32's 24): the subtractions are exact
-__device__ __forceinline__ void split3(const f16_t &v, int s, Split3 &o)
+// x = hi + lo / 2^11 with two fp16 terms (11 + 11 significand bits; fp32 has 24): hi = fp16(x), the residual
+// x - hi is exact in fp32 and lo = fp16(residual * 2^11).  Relative error of the pair 2^-22.
+__device__ __forceinline__ void split2(const f16_t &v, int s, Split2 &o)
 {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float x = v[8 * s + j];
-        const __bf16 h = (__bf16)x;
+        const _Float16 h = (_Float16)x;
         const float r = x - (float)h;
-        const __bf16 m = (__bf16)r;
-        const float r2 = r - (float)m;
-        o.hi[j] = h; o.mid[j] = m; o.lo[j] = (__bf16)r2;
+        o.hi[j] = h;
+        o.lo[j] = (_Float16)(r * NDP_LO_SCALE);
     }
 }
 
-// one (output tile, 16-deep k-step): W x = sum of the six split products that matter (the dropped ones are
-// below 2^-24 of the result), each a v_mfma_f32_32x32x16_bf16 -- 16x the f32 MFMA rate, so 6 products still run
-// 2.7x faster than the exact f32 form; measured error on the reference fixture 3.9e-6 (bar 1e-5).
-__device__ __forceinline__ f16_t mm6(const Split3 &w, const Split3 &x, f16_t acc)
+// post-ReLU activations of one 32x32 tile: cap at NDP_H16_CAP if any element of the wave's tile exceeds it (inputs
+// ~1000x outside the training envelope; the reference would return a finite meaningless force there, so do we --
+// an fp16 overflow would turn it into NaN).  One v_max chain + one wave vote per tile; the cap itself never runs
+// on in-envelope data.
+__device__ __forceinline__ void cap_tile(f16_t &v)
 {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, x.hi, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.lo, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.mid, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.hi, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.mid, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.hi, acc, 0, 0, 0);
-    return acc;
+    float m = v[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, v[r]);
+    if (__any(m > NDP_H16_CAP)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fminf(v[r], NDP_H16_CAP);
+    }
 }
 
-__device__ __forceinline__ void load_w(lds_cf32 fr, int rec, int lane, Split3 &w)
+// one (output tile, 16-deep k-step): W x = W_hi x_hi + (W_hi x_lo + W_lo x_hi) / 2^11; the dropped W_lo x_lo term is
+// below 2^-22 of the result.  Three v_mfma_f32_32x32x16_f16 (products exact in the fp32 accumulators), the cross terms
+// in their own accumulator.  16x the f32 MFMA rate per instruction, so the three still run 5x faster than the exact
+// f32 form; measured error on the reference fixture 3.7e-6 (bar 1e-5).
+__device__ __forceinline__ void mm3(const Split2 &w, const Split2 &x, f16_t &acc_hi, f16_t &acc_lo)
 {
-    const __attribute__((address_space(3))) bf16x8 *p = (const __attribute__((address_space(3))) bf16x8 *)(fr + FR_BF) + rec * 192 + lane;
-    w.hi = p[0]; w.mid = p[64]; w.lo = p[128];
+    acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.lo, x.hi, acc_lo, 0, 0, 0);
+    acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi, x.lo, acc_lo, 0, 0, 0);
+    acc_hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi, x.hi, acc_hi, 0, 0, 0);
+}
+
+__device__ __forceinline__ void load_w(lds_cf32 fr, int rec, int lane, Split2 &w)
+{
+    const __attribute__((address_space(3))) h16x8 *p = (const __attribute__((address_space(3))) h16x8 *)(fr + FR_HF) + rec * 128 + lane;
+    w.hi = p[0]; w.lo = p[64];
 }
 
 // The four layers for one 32-row tile held by one wave.  zb[s] = input feature 2s + (lane>>5) of row lane&31;
 // returns the three outputs of row lane&31 in o[] (both half-waves hold the full sums).
 // Activations stay transposed [feature][row] in the accumulators.  Registers 8s..8s+7 of a 32x32 accumulator,
-// converted to bf16, ARE the B operand of k-step s of the next layer (feature 16s + 8(j>>2) + 4(lane>>5) + (j&3) in
+// converted to fp16 pairs, ARE the B operand of k-step s of the next layer (feature 16s + 8(j>>2) + 4(lane>>5) + (j&3) in
 // element j); the weights are stored in that k order.
 __device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lane, float o[3])
 {
     typedef float f4_t __attribute__((ext_vector_type(4)));
     const int h = lane >> 5;
-    Split3 x1[4][2], x2[2][2];
+    Split2 x1[4][2], x2[2][2];
     f16_t h3[4];
     float bc[16];
     // layer 1 (6 -> 128): exact f32 MFMA, K = 2 per instruction
@@ -242,14 +261,15 @@ __device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lan
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[FR_L1 + (ot * 3 + s) * 64 + lane], zb[s], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r] + bc[r], 0.0f);
-        split3(acc, 0, x1[ot][0]);
-        split3(acc, 1, x1[ot][1]);
+        cap_tile(acc);
+        split2(acc, 0, x1[ot][0]);
+        split2(acc, 1, x1[ot][1]);
     }
     // layers 2 (128 -> 64) and 3 (64 -> 128) as one stream of 32 weight records, the next record requested before
     // the current record's six MFMAs issue
-    Split3 wc, wn;
+    Split2 wc, wn;
     load_w(fr, 0, lane, wc);
-    f16_t acc;
+    f16_t acc, accl;
 #pragma unroll
     for (int rec = 0; rec < 32; ++rec) {
         const bool l2 = rec < 16;
@@ -262,14 +282,16 @@ __device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lan
             for (int r = 0; r < 16; ++r) {
                 bc[r] = fr[(l2 ? FR_B2 : FR_B3) + ot * 32 + f0(r) + 4 * h];
                 acc[r] = 0.0f;
+                accl[r] = 0.0f;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        acc = mm6(wc, l2 ? x1[it][s] : x2[it][s], acc);
+        mm3(wc, l2 ? x1[it][s] : x2[it][s], acc, accl);
         if (last) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r] + bc[r], 0.0f);
-            if (l2) { split3(acc, 0, x2[ot][0]); split3(acc, 1, x2[ot][1]); }
+            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(fmaf(accl[r], NDP_LO_INV, acc[r]) + bc[r], 0.0f);
+            cap_tile(acc);
+            if (l2) { split2(acc, 0, x2[ot][0]); split2(acc, 1, x2[ot][1]); }
             else h3[ot] = acc;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -347,17 +369,33 @@ __global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, 
 }
 
 // host: blob (W1 b1 W2 b2 W3 b3 W4 b4, row-major [out][in]) -> fragment order
-static uint16_t bf16_rn(float x)
-{   // round-to-nearest-even f32 -> bf16 (the weights are finite)
+static uint16_t f16_rn(float x)
+{   // round-to-nearest-even f32 -> fp16 bits, subnormals included (the weights and their residuals are finite and small)
     uint32_t u;
     memcpy(&u, &x, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const uint32_t ax = u & 0x7FFFFFFFu;
+    if (ax >= 0x47800000u) return (uint16_t)(sign | 0x7C00u);               // >= 65536: inf (never for these data)
+    if (ax < 0x33000000u) return sign;                                       // < 2^-25: 0
+    const int e = (int)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x7FFFFFu) | 0x800000u;                               // 24-bit significand
+    const int shift = e < -14 ? 13 + (-14 - e) : 13;                         // bits to drop (subnormal: more)
+    const uint32_t keep = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    uint32_t r = keep + ((rem > half || (rem == half && (keep & 1u))) ? 1u : 0u);
+    // normal: r has the hidden bit at position 10; adding the exponent field lets a mantissa carry roll into it
+    const uint32_t bits = e < -14 ? r : (uint32_t)((e + 15 - 1) << 10) + r;
+    return (uint16_t)(sign | bits);
 }
-static float bf16_f32(uint16_t b)
+static float f16_f32(uint16_t b)
 {
-    const uint32_t u = (uint32_t)b << 16;
+    const uint32_t sign = (uint32_t)(b & 0x8000u) << 16, ex = (b >> 10) & 0x1Fu, mant = b & 0x3FFu;
     float x;
+    if (ex == 0) {
+        x = (float)mant * 5.9604644775390625e-08f;                           // 2^-24
+        uint32_t u; memcpy(&u, &x, 4); u |= sign; memcpy(&x, &u, 4);
+        return x;
+    }
+    const uint32_t u = sign | ((ex + 112u) << 23) | (mant << 13);
     memcpy(&x, &u, 4);
     return x;
 }
@@ -377,8 +415,8 @@ static void make_fragments(const float *blob, std::vector<float> &fr)
         for (int c = 0; c < 3; ++c) fr[FR_W4 + f * 4 + c] = W4[c * 128 + f];
     for (int i = 0; i < 3; ++i) fr[FR_B4 + i] = b4[i];
     // layers 2, 3: record = (out tile, in tile, k-step); lane (r = l&31, h = l>>5) element j holds
-    // W[ot*32 + r][it*32 + 16 s + 8 (j>>2) + 4 h + (j&3)] split into hi + mid + lo
-    uint16_t *bf = reinterpret_cast<uint16_t *>(fr.data() + FR_BF);
+    // W[ot*32 + r][it*32 + 16 s + 8 (j>>2) + 4 h + (j&3)] split into hi + lo / 2^11
+    uint16_t *hf = reinterpret_cast<uint16_t *>(fr.data() + FR_HF);
     for (int rec = 0; rec < 32; ++rec) {
         const bool l2 = rec < 16;
         const int q = l2 ? rec : rec - 16;
@@ -389,15 +427,12 @@ static void make_fragments(const float *blob, std::vector<float> &fr)
             for (int j = 0; j < 8; ++j) {
                 const int kin = it * 32 + 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
                 const float w = W[(ot * 32 + (l & 31)) * nin + kin];
-                const uint16_t hi = bf16_rn(w);
-                const float r1 = w - bf16_f32(hi);
-                const uint16_t mid = bf16_rn(r1);
-                const float r2 = r1 - bf16_f32(mid);
-                const uint16_t lo = bf16_rn(r2);
-                uint16_t *rp = bf + (size_t)rec * 3 * 512;
+                const uint16_t hi = f16_rn(w);
+                const float r1 = w - f16_f32(hi);
+                const uint16_t lo = f16_rn(r1 * NDP_LO_SCALE);
+                uint16_t *rp = hf + (size_t)rec * 2 * 512;
                 rp[0 * 512 + l * 8 + j] = hi;
-                rp[1 * 512 + l * 8 + j] = mid;
-                rp[2 * 512 + l * 8 + j] = lo;
+                rp[1 * 512 + l * 8 + j] = lo;
             }
     }
 }

@@ -26,6 +26,9 @@
 #ifndef NDP_D        // wave-program functions: __device__ in the gfx950 build, plain inline under the emulator
 #define NDP_D inline
 #endif
+#ifndef NDP_EXP
+#define NDP_EXP 0
+#endif
 #ifdef NDP_FINE_STAMPS
 #define NDP_FINE(x) x
 #else
@@ -643,6 +646,7 @@ struct RtiWave {
         bool ok = true;
         vi lane = W::lane();
         vi g = lane >> 4, j = lane & 15;
+        vb okv = lane >= 0;        // per-lane positive-definiteness flags, reduced once after the sweep
         vd4 H;
         {   // stage N-1 from the terminal block (no control part: keep columns 12..15 exactly zero)
             vd4 Pt;
@@ -669,39 +673,89 @@ struct RtiWave {
                 for (int c = 0; c < 3; ++c) a_mk[c] = a_mk[c] - T.mk_mul[c];
                 for (int r = 0; r < 4; ++r) a_cc[r] = a_cc[r] - T.c_mul[r];
             }
+#if NDP_EXP == 6
+            for (int c = 0; c < 3; ++c) nmk[c] = mk[c] * 0.5;
+            for (int r = 0; r < 4; ++r) ncc[r] = cc[r] * 0.5;
+#else
             for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, a_mk[c]);
             for (int r = 0; r < 4; ++r) ncc[r] = W::ld(lds, a_cc[r]);
+#endif
             // Lam[a][b] = H~[12+a][12+b] and H~ux both sit in accumulator register 3
             vd hux = H.r[3];
             // [H~xx ; H~ux] M~_{k-1}: H~'s registers as A operand mean H~' -- equal up to rounding (see the
             // re-symmetrisation below); rows 12..15 of the result are T = H~ux M~_{k-1}
-            // Issue order matters (one in-order wave, asynchronous matrix pipe): Lam gather first, then the three
-            // H~ M~' MFMAs, the cofactors while those run, then the bracket MFMAs interleaved with det -> 1/det.
+            // Issue order matters: one in-order wave, an asynchronous matrix pipe that takes one MFMA per 64 cycles, and
+            // ~32 cycles per DEPENDENT f64 VALU op.  The inverse (cofactors -> det -> 1/det, ~20 dependent ops) is cut
+            // into pieces of one or two ops and each piece is issued right behind an MFMA, so it runs while that MFMA
+            // occupies the pipe; every pin() keeps the compiler from regrouping them.
+            //   M~'' H~xu = (H~ux M~')' = T', hence  H~' = [C~' + M~'' (H~xx M~')] - T' Lam^-1 T:
+            // the bracket needs no Lam^-1, only two dependent MFMAs (adj T, then the rank-4 correction) follow it.
             LamRegs LR;
+#if NDP_EXP == 1
+            for (int i = 0; i < 9; ++i) LR.mm[i] = hux * (0.1 * i);
+            LR.own = hux;
+#else
             lam_gather(T, lds, hux, LR);
+#endif
             W::pin();
             vd4 Wf = W::zero4();
             for (int c = 0; c < 3; ++c) Wf = W::mfma(H.r[c], mk[c], Wf);
             W::pin();
-            vd cof = lam_cofactor(T, LR);
+            const vd *mm = LR.mm;
+            vd d0 = mm[4] * mm[8] - mm[5] * mm[7];
+            vd d1 = mm[3] * mm[8] - mm[5] * mm[6];
+            vd d2 = mm[3] * mm[7] - mm[4] * mm[6];
             W::pin();
-            // M~'' H~xu = (H~ux M~')' = T', hence  H~' = [C~' + M~'' (H~xx M~')] - T' Lam^-1 T.
-            // The bracket does not need Lam^-1 either; only two dependent MFMAs (Lam^-1 T, then the rank-4
-            // correction) follow the inverse.
             vd4 Hb;
             for (int r = 0; r < 4; ++r) Hb.r[r] = cc[r];
-            for (int c = 0; c < 3; ++c) Hb = W::mfma(mk[c], Wf.r[c], Hb);
-            // Lam^-1 = adj / det: adj T starts as soon as the cofactors exist; 1/det scales its single result register
+            Hb = W::mfma(mk[0], Wf.r[0], Hb);
+            W::pin();
+            vd cof = (mm[0] * d0 - mm[1] * d1 + mm[2] * d2) * T.cof_sign;
+            W::pin();
+            Hb = W::mfma(mk[1], Wf.r[1], Hb);
+            W::pin();
+            vd dq = LR.own * cof;                             // row expansion of det: lanes 16g..16g+3 form one quad
+            dq = dq + W::quad_swap1(dq);
             vd ladj = W::sel(T.lo4, cof, vd(0.0));            // A operand: adj[g][j], j < 4
             vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));       // B operand of K~': -adj[g][j-12] in columns 12..15
+            W::pin();
+            Hb = W::mfma(mk[2], Wf.r[2], Hb);
+            W::pin();
+            vd det = dq + W::quad_swap2(dq);
+            vd r0 = W::rcp_seed(det);
+            W::pin();
             vd tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
+#if NDP_EXP == 5
+            vd4 G; for (int r = 0; r < 4; ++r) G.r[r] = ladj * tt;
+#else
             vd4 G = W::mfma(ladj, tt, W::zero4());            // adj T
+#endif
+            W::pin();
+            vd e0 = W::fma(-det, r0, vd(1.0));
+            vd r1 = W::fma(e0, r0, r0);
+            W::pin();
+#if NDP_EXP == 5
+            vd4 Kt; for (int r = 0; r < 4; ++r) Kt.r[r] = hux * nahi;
+#else
             vd4 Kt = W::mfma(hux, nahi, W::zero4());          // det * K~'[i][b], lands in column 12+b (rows 12..15 of the forward operand)
-            vd rdet = lam_rdet(T, LR, cof, ok);
+#endif
+            W::pin();
+#if NDP_EXP == 2
+            vd rdet = r1;
+#else
+            vd e1 = W::fma(-det, r1, vd(1.0));
+            vd rdet = W::fma(e1, r1, r1);                     // 1/det: v_rcp_f64 seed + two Newton steps
+#endif
+            okv = okv && (det > 0.0) && (!T.lam_diag || (cof > 0.0));
+#if NDP_EXP == 3
+            vd gs = G.r[0];
+#else
             vd gs = G.r[0] * rdet;                            // Lam^-1 T
+#endif
+            W::pin();
             vd4 Hn = W::mfma(-tt, gs, Hb);                    // - T' Lam^-1 T on top of the bracket
             for (int c = 0; c < 3; ++c) { W::st(lds, a_kt[c], Kt.r[c] * rdet); a_kt[c] = a_kt[c] - T.kt_mul; }
-            if ((k & 3) == 0) {
+            if (NDP_EXP != 4 && (k & 3) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
                 // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
                 // re-symmetrise every 4th stage.  H~' = (H~ as A operand) x I costs four MFMAs, no LDS.
@@ -723,6 +777,7 @@ struct RtiWave {
             vd4 Kt = W::mfma(hux, nahi, W::zero4());
             for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c], Kt.r[c] * rdet);
         }
+        ok = W::all(okv) && ok;
         W::sync();
         if (io) stamp(*io, m, 6);
         // forward rollout; z~ index 4c+g lives in chunk c of the lanes with j == 0

@@ -58,6 +58,11 @@ struct WaveGfx950 {
         r = __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
         return r;
     }
+    // the pieces of rcp / quad_sum, for callers that interleave them with matrix instructions
+    static NDP_D vd rcp_seed(vd a) { return __builtin_amdgcn_rcp(a); }
+    static NDP_D vd fma(vd a, vd b, vd c) { return __builtin_fma(a, b, c); }
+    static NDP_D vd quad_swap1(vd a) { return dpp_quad<0xB1>(a); }   // lane ^ 1
+    static NDP_D vd quad_swap2(vd a) { return dpp_quad<0x4E>(a); }   // lane ^ 2
     // sum over the 4 lanes of each aligned quad, result in all 4 (DPP quad_perm, no LDS)
     static NDP_D vd quad_sum(vd a)
     {

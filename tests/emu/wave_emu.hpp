@@ -104,6 +104,10 @@ struct Wave {
     static vd clock() { return vd(0.0); }
     static vd clock_after(const vd &) { return vd(0.0); }
     static vd rcp(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = 1.0 / a.v[l]; return o; }
+    static vd rcp_seed(const vd &a) { return rcp(a); }
+    static vd fma(const vd &a, const vd &b, const vd &c) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = std::fma(a.v[l], b.v[l], c.v[l]); return o; }
+    static vd quad_swap1(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[l ^ 1]; return o; }
+    static vd quad_swap2(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[l ^ 2]; return o; }
     static vd quad_sum(const vd &a)
     {   // same association as the device: (x + x^1) + (x + x^1)^2
         vd t, o;
