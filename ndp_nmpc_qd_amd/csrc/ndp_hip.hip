@@ -204,20 +204,10 @@ __device__ __forceinline__ void split2(const f16_t &v, int s, Split2 &o)
     }
 }
 
-// post-ReLU activations of one 32x32 tile: cap at NDP_H16_CAP if any element of the wave's tile exceeds it (inputs
-// ~1000x outside the training envelope; the reference would return a finite meaningless force there, so do we --
-// an fp16 overflow would turn it into NaN).  One v_max chain + one wave vote per tile; the cap itself never runs
-// on in-envelope data.
-__device__ __forceinline__ void cap_tile(f16_t &v)
-{
-    float m = v[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) m = fmaxf(m, v[r]);
-    if (__any(m > NDP_H16_CAP)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = fminf(v[r], NDP_H16_CAP);
-    }
-}
+// ReLU of a hidden layer that feeds an fp16 split, capped at NDP_H16_CAP: one v_med3_f32, the price of a plain
+// v_max_f32.  The cap only acts on inputs ~1000x outside the training envelope, where the reference returns a finite
+// meaningless force; uncapped, the fp16 conversion would overflow to inf and turn that into NaN.
+__device__ __forceinline__ float relu_cap(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, NDP_H16_CAP); }
 
 // one (output tile, 16-deep k-step): W x = W_hi x_hi + (W_hi x_lo + W_lo x_hi) / 2^11; the dropped W_lo x_lo term is
 // below 2^-22 of the result.  Three v_mfma_f32_32x32x16_f16 (products exact in the fp32 accumulators), the cross terms
@@ -255,13 +245,12 @@ __device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lan
         for (int r = 0; r < 16; ++r) bc[r] = fr[FR_B1 + ot * 32 + f0(r) + 4 * h];
         f16_t acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[r] = bc[r];        // the bias rides in the accumulator
 #pragma unroll
         for (int s = 0; s < 3; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[FR_L1 + (ot * 3 + s) * 64 + lane], zb[s], acc, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r] + bc[r], 0.0f);
-        cap_tile(acc);
+        for (int r = 0; r < 16; ++r) acc[r] = relu_cap(acc[r]);
         split2(acc, 0, x1[ot][0]);
         split2(acc, 1, x1[ot][1]);
     }
@@ -280,8 +269,7 @@ __device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lan
         if (first) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                bc[r] = fr[(l2 ? FR_B2 : FR_B3) + ot * 32 + f0(r) + 4 * h];
-                acc[r] = 0.0f;
+                acc[r] = fr[(l2 ? FR_B2 : FR_B3) + ot * 32 + f0(r) + 4 * h];   // the bias rides in the accumulator
                 accl[r] = 0.0f;
             }
         }
@@ -289,8 +277,10 @@ __device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lan
         mm3(wc, l2 ? x1[it][s] : x2[it][s], acc, accl);
         if (last) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(fmaf(accl[r], NDP_LO_INV, acc[r]) + bc[r], 0.0f);
-            cap_tile(acc);
+            for (int r = 0; r < 16; ++r) {
+                const float v = fmaf(accl[r], NDP_LO_INV, acc[r]);
+                acc[r] = l2 ? relu_cap(v) : fmaxf(v, 0.0f);
+            }
             if (l2) { split2(acc, 0, x2[ot][0]); split2(acc, 1, x2[ot][1]); }
             else h3[ot] = acc;
         }
