@@ -150,6 +150,21 @@ int ndp_relay_formation(ndp_handle *h, const double *form, double *offset_out /*
 int ndp_relay_reference(ndp_handle *h, const double *xr_lead, double *xr_out);
 int ndp_relay_reference_device(ndp_handle *h, const void *d_xr_lead, void *d_xr_out, void *stream);
 
+/* ---- "next" row f1: the step before the path -- reference window generation, batched.
+ * Replaces, per vehicle, NMPCRefPublisher.reset(traj_coeff, ros_t) + get_nmpc_pts(ros_t)
+ * (pt_pub/pt_publisher.py:57-103): trajectory point from the piecewise polynomials (pt_pub/base_pt_publisher.py:81-133,
+ * polym_optimizer.py:104-139), differential flatness (pt_publisher.py:188-248), x/u packing (:115-146), and the
+ * 0.1 s node spacing of params/nmpc_params.py:40-43.  Past the end of the trajectory every node hovers at final_pt.
+ *   ndp_ref_set_trajectory: the arrays of TrajCoefficients.msg for every instance, all with n_seg segments:
+ *       coeff_x/y/z[B][n_seg*8] (minimum snap), coeff_yaw[B][n_seg*4] (minimum acceleration),
+ *       time_cum[B][n_seg+1], time_seg[B][n_seg], final_pt[B][3]
+ *   ndp_ref_window        : t[B] = trajectory time of node 0 ((ros_t - start_ros_t).to_sec()) ->
+ *       xr[B][N+1][10], ur[B][N][4], node k at t + k*dt.  The device form writes buffers that ndp_step_device reads. */
+int ndp_ref_set_trajectory(ndp_handle *h, int n_seg, const double *coeff_x, const double *coeff_y, const double *coeff_z,
+                           const double *coeff_yaw, const double *time_cum, const double *time_seg, const double *final_pt);
+int ndp_ref_window(ndp_handle *h, const double *t, double *xr, double *ur);
+int ndp_ref_window_device(ndp_handle *h, const void *d_t, void *d_xr, void *d_ur, void *stream);
+
 /* ---- "next" row f4: plant step for closed-loop rollouts on the device (dop_sim is absent from the reference).
  * x[B][10] in/out, u[B][4], f[B][3] force or NULL; RK4 with `substeps` over dt, quaternion renormalised. */
 int ndp_plant_step(ndp_handle *h, double *x, const double *u, const double *f, double dt, int substeps);

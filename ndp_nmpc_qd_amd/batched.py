@@ -149,6 +149,32 @@ class BatchedNMPC:
         self._check(self._lib.ndp_relay_reference(self._h, _lib.ptr(xr_lead), _lib.ptr(out)), "ndp_relay_reference")
         return out
 
+    # ------------------------------------------------------------------ f1: reference window generation
+    def ref_set_trajectory(self, coeff_x, coeff_y, coeff_z, coeff_yaw, time_cum, time_seg, final_pt):
+        """TrajCoefficients of every instance (NMPCRefPublisher.reset, pt_pub/pt_publisher.py:57-60); all instances
+        carry the same number of segments: coeff_x/y/z[B,n_seg*8], coeff_yaw[B,n_seg*4], time_cum[B,n_seg+1], ..."""
+        time_seg = _lib.f64(time_seg)
+        n_seg = time_seg.shape[1]
+        cx, cy, cz = (_lib.f64(np.reshape(c, (self.B, n_seg * 8)), (self.B, n_seg * 8)) for c in (coeff_x, coeff_y, coeff_z))
+        cyaw = _lib.f64(np.reshape(coeff_yaw, (self.B, n_seg * 4)), (self.B, n_seg * 4))
+        time_cum, final_pt = _lib.f64(time_cum, (self.B, n_seg + 1)), _lib.f64(final_pt, (self.B, 3))
+        self._check(self._lib.ndp_ref_set_trajectory(self._h, n_seg, _lib.ptr(cx), _lib.ptr(cy), _lib.ptr(cz), _lib.ptr(cyaw),
+                                                     _lib.ptr(time_cum), _lib.ptr(_lib.f64(time_seg, (self.B, n_seg))),
+                                                     _lib.ptr(final_pt)), "ndp_ref_set_trajectory")
+
+    def ref_window(self, t):
+        """get_nmpc_pts for every instance at trajectory times t[B]: returns xr[B,N+1,10], ur[B,N,4]."""
+        t = _lib.f64(t, (self.B,))
+        xr, ur = np.empty((self.B, self.N + 1, 10)), np.empty((self.B, self.N, 4))
+        self._check(self._lib.ndp_ref_window(self._h, _lib.ptr(t), _lib.ptr(xr), _lib.ptr(ur)), "ndp_ref_window")
+        return xr, ur
+
+    def ref_window_device(self, t, xr_out, ur_out, stream=None):
+        import torch
+        self._check(self._lib.ndp_ref_window_device(
+            self._h, self._dptr(t, torch.float64, (self.B,)), self._dptr(xr_out, torch.float64, (self.B, self.N + 1, 10)),
+            self._dptr(ur_out, torch.float64, (self.B, self.N, 4)), self._stream(stream)), "ndp_ref_window_device")
+
     # ------------------------------------------------------------------ f4: plant step (closed-loop rollouts)
     def plant_step(self, x, u, f=None, dt=CP.ts_nmpc, substeps=4):
         x = _lib.f64(x, (self.B, 10)).copy()

@@ -577,6 +577,111 @@ __global__ __launch_bounds__(256) void plant_kernel(double *__restrict__ x, cons
     for (int i = 0; i < 5; ++i) reinterpret_cast<double2 *>(x)[(size_t)v * 5 + i] = make_double2(xv[2 * i], xv[2 * i + 1]);
 }
 
+// ------------------------------------------------------------------------------------------ f1 kernel
+// Reference window generation (the step before the path): per vehicle a piecewise polynomial trajectory
+// (TrajCoefficients.msg) is evaluated at the N+1 node times t + k*dt and pushed through the differential-flatness map;
+// what NMPCRefPublisher.get_nmpc_pts returns (pt_pub/pt_publisher.py:79-103, base_pt_publisher.py:81-133,
+// diff_flatness :188-248, traj_full_pt_2_x_u :115-146).  One thread per (vehicle, node): reads its segment's 28
+// coefficients (224 contiguous bytes, shared by the neighbouring nodes of the vehicle), writes 80 + 32 contiguous bytes.
+struct RefCfg { int B, N, n_seg; double dt, mass, g; };
+
+// sum_i [i (i-1) .. (i-d+1) t^(i-d)] / tseg^d * c[i]  (get_poly_params + _get_output_value), powers by repeated products
+template <int NC_, int D>
+__device__ __forceinline__ double poly_eval(const double *__restrict__ c, const double *tp, double inv_scale_den)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int i = D; i < NC_; ++i) {
+        double f = 1.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) f *= (double)(i - j);
+        acc += f * tp[i - D] / inv_scale_den * c[i];
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void ref_window_kernel(RefCfg cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
+                                                         const double *__restrict__ tseg, const double *__restrict__ fpt,
+                                                         const double *__restrict__ tq, double *__restrict__ xr, double *__restrict__ ur)
+{
+    const int row = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int np1 = cf.N + 1;
+    if (row >= cf.B * np1) return;
+    const int b = row / np1, k = row - b * np1;
+    const double t = tq[b] + k * cf.dt;
+    const double *tc = tcum + (size_t)b * (cf.n_seg + 1);
+    double pvaj[12], yaw = 0.0, yawd = 0.0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pvaj[i] = 0.0;
+    if (t >= tc[cf.n_seg]) {                              // base_pt_publisher.py:93-94: hover at final_pt after the end
+        for (int i = 0; i < 3; ++i) pvaj[i] = fpt[(size_t)b * 3 + i];
+    } else {
+        int idx = 0;                                      // :100: first i with time_cum[i] > t, minus one
+        while (idx < cf.n_seg && !(tc[idx] > t)) ++idx;
+        idx = idx > 0 ? idx - 1 : 0;
+        const double ts_ = tseg[(size_t)b * cf.n_seg + idx];
+        const double s = (t - tc[idx]) / ts_;             // :102-103
+        const double *c = coeff + ((size_t)b * cf.n_seg + idx) * 28;
+        double tp[8], sc[4];
+        tp[0] = 1.0;
+#pragma unroll
+        for (int i = 1; i < 8; ++i) tp[i] = tp[i - 1] * s;
+        sc[0] = 1.0; sc[1] = ts_; sc[2] = ts_ * ts_; sc[3] = sc[2] * ts_;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            pvaj[a] = poly_eval<8, 0>(c + 8 * a, tp, sc[0]);
+            pvaj[3 + a] = poly_eval<8, 1>(c + 8 * a, tp, sc[1]);
+            pvaj[6 + a] = poly_eval<8, 2>(c + 8 * a, tp, sc[2]);
+            pvaj[9 + a] = poly_eval<8, 3>(c + 8 * a, tp, sc[3]);
+        }
+        yaw = poly_eval<4, 0>(c + 24, tp, sc[0]);
+        yawd = poly_eval<4, 1>(c + 24, tp, sc[1]);
+    }
+    // differential flatness (pt_publisher.py:188-248)
+    const double td[3] = {pvaj[6], pvaj[7], pvaj[8] + cf.g};
+    const double tn = sqrt(td[0] * td[0] + td[1] * td[1] + td[2] * td[2]);
+    const double zb[3] = {td[0] / tn, td[1] / tn, td[2] / tn};
+    const double u1 = tn * cf.mass;
+    double sy, cy;
+    sincos(yaw, &sy, &cy);
+    const double xc[3] = {cy, sy, 0.0};
+    const double zx[3] = {zb[1] * xc[2] - zb[2] * xc[1], zb[2] * xc[0] - zb[0] * xc[2], zb[0] * xc[1] - zb[1] * xc[0]};
+    const double nzx = sqrt(zx[0] * zx[0] + zx[1] * zx[1] + zx[2] * zx[2]);
+    const double yb[3] = {zx[0] / nzx, zx[1] / nzx, zx[2] / nzx};
+    const double xb[3] = {yb[1] * zb[2] - yb[2] * zb[1], yb[2] * zb[0] - yb[0] * zb[2], yb[0] * zb[1] - yb[1] * zb[0]};
+    const double zj = zb[0] * pvaj[9] + zb[1] * pvaj[10] + zb[2] * pvaj[11];
+    double ho[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ho[i] = (cf.mass / u1) * (pvaj[9 + i] - zj * zb[i]);
+    const double wp = -(ho[0] * yb[0] + ho[1] * yb[1] + ho[2] * yb[2]);
+    const double wq = ho[0] * xb[0] + ho[1] * xb[1] + ho[2] * xb[2];
+    const double wr = yawd * zb[2];
+    // tf.transformations.quaternion_from_matrix on [x_b y_b z_b] (ROS geometry; restated): R[i][0..2] = xb[i], yb[i], zb[i]
+    const double R[3][3] = {{xb[0], yb[0], zb[0]}, {xb[1], yb[1], zb[1]}, {xb[2], yb[2], zb[2]}};
+    double q[4], tt = R[0][0] + R[1][1] + R[2][2] + 1.0;
+    if (tt > 1.0) {
+        q[3] = tt; q[2] = R[1][0] - R[0][1]; q[1] = R[0][2] - R[2][0]; q[0] = R[2][1] - R[1][2];
+    } else {
+        int i = 0, j = 1, kk = 2;
+        if (R[1][1] > R[0][0]) { i = 1; j = 2; kk = 0; }
+        if (R[2][2] > R[i][i]) { i = 2; j = 0; kk = 1; }
+        tt = R[i][i] - (R[j][j] + R[kk][kk]) + 1.0;
+        q[i] = tt; q[j] = R[i][j] + R[j][i]; q[kk] = R[kk][i] + R[i][kk]; q[3] = R[kk][j] - R[j][kk];
+    }
+    const double qs = 0.5 / sqrt(tt);
+    double2 *xo = reinterpret_cast<double2 *>(xr) + (size_t)row * 5;
+    xo[0] = make_double2(pvaj[0], pvaj[1]);
+    xo[1] = make_double2(pvaj[2], pvaj[3]);
+    xo[2] = make_double2(pvaj[4], pvaj[5]);
+    xo[3] = make_double2(q[3] * qs, q[0] * qs);            // [qw, qx, qy, qz] (pt_publisher.py:237-240, :115-128)
+    xo[4] = make_double2(q[1] * qs, q[2] * qs);
+    if (k < cf.N) {
+        double2 *uo = reinterpret_cast<double2 *>(ur) + ((size_t)b * cf.N + k) * 2;
+        uo[0] = make_double2(wp, wq);
+        uo[1] = make_double2(wr, u1 / cf.mass);             // collective_force / mass (:145)
+    }
+}
+
 }  // namespace ndp
 
 // ------------------------------------------------------------------------------------------ C-ABI
@@ -596,6 +701,8 @@ struct ndp_handle {
     int *dTables = nullptr;    // per-lane index tables of the Riccati sweep (fill_tables)
     double *dThr = nullptr;    // hover-throttle estimator state, SoA [8][B]
     double *dStamps = nullptr; // [B][16] whole-batch phase stamps (ndp_debug_stamps)
+    double *dTraj = nullptr;   // f1: [B][n_seg][28] coeff | [B][n_seg+1] time_cum | [B][n_seg] time_seg | [B][3] final_pt
+    int traj_seg = 0;
     double *dRelay = nullptr;  // follower relay: [B][4] = filtered offset xyz + initialised flag
     double *sThr = nullptr;    // staging: vz[B] throttle[B] k[B] | u0[B][4] cmd[B][4]
     bool have_mlp = false;
@@ -661,7 +768,7 @@ int ndp_destroy(ndp_handle *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    void *ptrs[] = {h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dX, h->dU, h->dStatus, h->dIters, h->dForce, h->dFrag, h->sx0, h->sxr, h->sur,
+    void *ptrs[] = {h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dX, h->dU, h->dStatus, h->dIters, h->dForce, h->dFrag, h->sx0, h->sxr, h->sur,
                     h->sother, h->sego, h->su0, h->sdbg, h->sf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1148,6 +1255,71 @@ int ndp_relay_reference(ndp_handle *h, const double *xr_lead, double *xr_out)
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
     NDP_HIP(h, hipMemcpyAsync(xr_out, h->sxr, nxs(h) * 8, hipMemcpyDeviceToHost, h->stream));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- f1: reference window generation
+int ndp_ref_set_trajectory(ndp_handle *h, int n_seg, const double *coeff_x, const double *coeff_y, const double *coeff_z,
+                           const double *coeff_yaw, const double *time_cum, const double *time_seg, const double *final_pt)
+{
+    if (!h || n_seg < 1 || !coeff_x || !coeff_y || !coeff_z || !coeff_yaw || !time_cum || !time_seg || !final_pt) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const size_t B = h->cfg.batch, S = (size_t)n_seg;
+    const size_t n_coeff = B * S * 28, n_cum = B * (S + 1), n_seg_t = B * S, total = n_coeff + n_cum + n_seg_t + B * 3;
+    std::vector<double> host(total);
+    for (size_t b = 0; b < B; ++b)
+        for (size_t s = 0; s < S; ++s) {
+            double *d = host.data() + (b * S + s) * 28;          // interleave the four message arrays per segment
+            for (int i = 0; i < 8; ++i) {
+                d[i] = coeff_x[(b * S + s) * 8 + i];
+                d[8 + i] = coeff_y[(b * S + s) * 8 + i];
+                d[16 + i] = coeff_z[(b * S + s) * 8 + i];
+            }
+            for (int i = 0; i < 4; ++i) d[24 + i] = coeff_yaw[(b * S + s) * 4 + i];
+        }
+    memcpy(host.data() + n_coeff, time_cum, n_cum * 8);
+    memcpy(host.data() + n_coeff + n_cum, time_seg, n_seg_t * 8);
+    memcpy(host.data() + n_coeff + n_cum + n_seg_t, final_pt, B * 3 * 8);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->dTraj) { (void)hipFree(h->dTraj); h->dTraj = nullptr; }
+    NDP_HIP(h, hipMalloc((void **)&h->dTraj, total * 8));
+    NDP_HIP(h, hipMemcpy(h->dTraj, host.data(), total * 8, hipMemcpyHostToDevice));
+    h->traj_seg = n_seg;
+    return 0;
+}
+
+int ndp_ref_window_device(ndp_handle *h, const void *d_t, void *d_xr, void *d_ur, void *stream)
+{
+    if (!h || !d_t || !d_xr || !d_ur) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->dTraj) { h->err = "ndp_ref_window: ndp_ref_set_trajectory was never called"; return -11; }
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    const size_t B = h->cfg.batch, S = (size_t)h->traj_seg;
+    const double *coeff = h->dTraj, *cum = coeff + B * S * 28, *seg = cum + B * (S + 1), *fpt = seg + B * S;
+    RefCfg cf{h->cfg.batch, h->cfg.N, h->traj_seg, h->cfg.dt, h->cfg.mass, h->cfg.gravity};
+    const int rows = h->cfg.batch * (h->cfg.N + 1);
+    hipLaunchKernelGGL(ref_window_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, cf, coeff, cum, seg, fpt,
+                       (const double *)d_t, (double *)d_xr, (double *)d_ur);
+    NDP_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int ndp_ref_window(ndp_handle *h, const double *t, double *xr, double *ur)
+{
+    if (!h || !t || !xr || !ur) return -1;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        NDP_HIP(h, hipSetDevice(h->cfg.device));
+        NDP_HIP(h, hipMemcpyAsync(h->sThr, t, (size_t)h->cfg.batch * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    int rc = ndp_ref_window_device(h, h->sThr, h->sxr, h->sur, nullptr);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipMemcpyAsync(xr, h->sxr, nxs(h) * 8, hipMemcpyDeviceToHost, h->stream));
+    NDP_HIP(h, hipMemcpyAsync(ur, h->sur, nus(h) * 8, hipMemcpyDeviceToHost, h->stream));
     NDP_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
 }

@@ -824,3 +824,126 @@ void orc_plant_step(const orc_cfg *c, int V, double *x, const double *u, const d
         for (int i = 6; i < 10; ++i) xv[i] /= n;
     }
 }
+
+/* ------------------------------------------------- f1: reference window generation */
+
+/* PolymOptimizer.get_poly_params(deriv, t) (pt_pub/polym_optimizer.py:104-139) for a polynomial with n coefficients:
+ * params[i] = i (i-1) ... (i-deriv+1) * t^(i-deriv) for i >= deriv, 0 below. */
+static void poly_params(int n, int deriv, double t, double *params)
+{
+    for (int i = 0; i < n; ++i) {
+        double p = 1.0;
+        int ord = i;
+        for (int j = 0; j < deriv; ++j) {
+            p *= (double)ord;
+            if (ord > 0) --ord;
+        }
+        params[i] = p * pow(t, (double)ord);
+    }
+}
+
+/* _get_output_value (base_pt_publisher.py:136-143): (params / t_segment^deriv) @ coeff */
+static double poly_value(int n, int deriv, double ts, double tseg, const double *c)
+{
+    double params[8], acc = 0.0;
+    poly_params(n, deriv, ts, params);
+    const double sc = pow(tseg, (double)deriv);
+    for (int i = 0; i < n; ++i) acc += params[i] / sc * c[i];
+    return acc;
+}
+
+void orc_traj_point(int n_seg, const double *coeff, const double *t_cum, const double *t_seg, const double *final_pt,
+                    double t, double *pvaj, double *yaw)
+{
+    for (int i = 0; i < 12; ++i) pvaj[i] = 0.0;
+    yaw[0] = yaw[1] = 0.0;
+    if (t >= t_cum[n_seg]) {                   /* base_pt_publisher.py:93-94: hover at final_pt after the end */
+        for (int i = 0; i < 3; ++i) pvaj[i] = final_pt[i];
+        return;
+    }
+    int idx = 0;                               /* :100: first i with time_cum[i] > t, minus one */
+    while (idx < n_seg && !(t_cum[idx] > t)) ++idx;
+    idx -= 1;
+    if (idx < 0) idx = 0;                      /* t < time_cum[0]: callers never ask; clamp instead of numpy's wrap-around */
+    const double tseg = t_seg[idx];
+    const double ts = (t - t_cum[idx]) / tseg; /* :102-103 */
+    const double *c = coeff + (size_t)idx * 28;
+    for (int d = 0; d < 4; ++d)                /* :110-124: position, velocity, acceleration, jerk */
+        for (int a = 0; a < 3; ++a) pvaj[3 * d + a] = poly_value(8, d, ts, tseg, c + 8 * a);
+    yaw[0] = poly_value(4, 0, ts, tseg, c + 24);   /* :127-129 */
+    yaw[1] = poly_value(4, 1, ts, tseg, c + 24);
+}
+
+static void cross3(const double *a, const double *b, double *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* tf.transformations.quaternion_from_matrix (ROS geometry, tf/src/tf/transformations.py) on a homogeneous matrix
+ * with M[3][3] = 1; R columns = x_b, y_b, z_b.  Returns (x, y, z, w). */
+static void quat_from_matrix(const double R[3][3], double *q)
+{
+    const double m33 = 1.0;
+    double t = R[0][0] + R[1][1] + R[2][2] + m33;
+    if (t > m33) {
+        q[3] = t;
+        q[2] = R[1][0] - R[0][1];
+        q[1] = R[0][2] - R[2][0];
+        q[0] = R[2][1] - R[1][2];
+    } else {
+        int i = 0, j = 1, k = 2;
+        if (R[1][1] > R[0][0]) { i = 1; j = 2; k = 0; }
+        if (R[2][2] > R[i][i]) { i = 2; j = 0; k = 1; }
+        t = R[i][i] - (R[j][j] + R[k][k]) + m33;
+        q[i] = t;
+        q[j] = R[i][j] + R[j][i];
+        q[k] = R[k][i] + R[i][k];
+        q[3] = R[k][j] - R[j][k];
+    }
+    const double s = 0.5 / sqrt(t * m33);
+    for (int a = 0; a < 4; ++a) q[a] *= s;
+}
+
+void orc_diff_flatness(double mass, double g, const double *pvaj, const double *yaw, double *x, double *u)
+{
+    const double *acc = pvaj + 6, *jerk = pvaj + 9;
+    double t_des[3] = {acc[0] + 0.0, acc[1] + 0.0, acc[2] + g};              /* pt_publisher.py:198 */
+    const double tn = sqrt(t_des[0] * t_des[0] + t_des[1] * t_des[1] + t_des[2] * t_des[2]);
+    double zb[3] = {t_des[0] / tn, t_des[1] / tn, t_des[2] / tn};            /* :204 */
+    const double u1 = tn * mass;                                             /* :206 */
+    const double xc[3] = {cos(yaw[0]), sin(yaw[0]), 0.0};                    /* :208 */
+    double zx[3], yb[3], xb[3];
+    cross3(zb, xc, zx);                                                      /* :209 */
+    const double nzx = sqrt(zx[0] * zx[0] + zx[1] * zx[1] + zx[2] * zx[2]);
+    for (int i = 0; i < 3; ++i) yb[i] = zx[i] / nzx;                         /* :215 */
+    cross3(yb, zb, xb);                                                      /* :217 */
+    const double zj = zb[0] * jerk[0] + zb[1] * jerk[1] + zb[2] * jerk[2];
+    double ho[3];
+    for (int i = 0; i < 3; ++i) ho[i] = (mass / u1) * (jerk[i] - zj * zb[i]); /* :222 */
+    const double p = -(ho[0] * yb[0] + ho[1] * yb[1] + ho[2] * yb[2]);       /* :223 */
+    const double q = ho[0] * xb[0] + ho[1] * xb[1] + ho[2] * xb[2];          /* :224 */
+    const double r = yaw[1] * zb[2];                                         /* :225 */
+    double R[3][3], qq[4];
+    for (int i = 0; i < 3; ++i) { R[i][0] = xb[i]; R[i][1] = yb[i]; R[i][2] = zb[i]; }   /* :218 */
+    quat_from_matrix(R, qq);                                                 /* :234 */
+    for (int i = 0; i < 6; ++i) x[i] = pvaj[i];
+    x[6] = qq[3]; x[7] = qq[0]; x[8] = qq[1]; x[9] = qq[2];                  /* :237-240, :115-128 */
+    u[0] = p; u[1] = q; u[2] = r; u[3] = u1 / mass;                          /* :138-145 */
+}
+
+void orc_ref_window(int V, int N, double dt, double mass, double g, int n_seg, const double *coeff, const double *t_cum,
+                    const double *t_seg, const double *final_pt, const double *t, double *xr, double *ur)
+{
+    for (int v = 0; v < V; ++v)
+        for (int k = 0; k <= N; ++k) {
+            double pvaj[12], yaw[2], x[10], u[4];
+            orc_traj_point(n_seg, coeff + (size_t)v * n_seg * 28, t_cum + (size_t)v * (n_seg + 1), t_seg + (size_t)v * n_seg,
+                           final_pt + (size_t)v * 3, t[v] + k * dt, pvaj, yaw);
+            orc_diff_flatness(mass, g, pvaj, yaw, x, u);
+            for (int i = 0; i < 10; ++i) xr[((size_t)v * (N + 1) + k) * 10 + i] = x[i];
+            if (k < N)
+                for (int i = 0; i < 4; ++i) ur[((size_t)v * N + k) * 4 + i] = u[i];
+        }
+}

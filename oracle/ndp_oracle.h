@@ -131,6 +131,23 @@ void orc_relay_reference(int V, int N, const double *state, const double *xr_lea
  * (no reference implementation exists: dop_sim is an empty submodule). x[V][10] in/out, u[V][4], f[V][3] or NULL. */
 void orc_plant_step(const orc_cfg *c, int V, double *x, const double *u, const double *f, double dt, int sub);
 
+/* f1: reference window generation -- the step before the path.
+ * Per vehicle a piecewise polynomial trajectory (TrajCoefficients.msg: coeff_x/y/z 8 per segment (minimum snap),
+ * coeff_yaw 4 per segment (minimum acceleration), traj_time_cum[n_seg+1], traj_time_seg[n_seg], final_pt).
+ *   orc_traj_point   : BasePtPublisher.get_traj_pt (pt_pub/base_pt_publisher.py:81-133) at trajectory time t:
+ *                      pva j[12] = pos, vel, acc, jerk; yaw[2] = yaw, yaw_dot; past the end: final_pt, all else 0
+ *   orc_diff_flatness: diff_flatness (pt_pub/pt_publisher.py:188-248) + traj_full_pt_2_x_u (:115-146):
+ *                      -> x[10] = [p, v, qw, qx, qy, qz], u[4] = [wx, wy, wz, collective_force / mass];
+ *                      the quaternion follows tf.transformations.quaternion_from_matrix (ROS; not vendored, restated)
+ *   orc_ref_window   : what NMPCRefPublisher.get_nmpc_pts hands the controller (pt_publisher.py:79-103 with the
+ *                      index rule of params/nmpc_params.py:40-43): node k at trajectory time t + k*dt.
+ * Layouts: coeff[V][n_seg][28] = x(8) y(8) z(8) yaw(4) per segment. */
+void orc_traj_point(int n_seg, const double *coeff, const double *t_cum, const double *t_seg, const double *final_pt,
+                    double t, double *pvaj /*12*/, double *yaw /*2*/);
+void orc_diff_flatness(double mass, double g, const double *pvaj, const double *yaw, double *x /*10*/, double *u /*4*/);
+void orc_ref_window(int V, int N, double dt, double mass, double g, int n_seg, const double *coeff, const double *t_cum,
+                    const double *t_seg, const double *final_pt, const double *t /*V*/, double *xr, double *ur);
+
 #ifdef __cplusplus
 }
 #endif

@@ -213,3 +213,30 @@ def plant_step(cfg, x, u, f, dt, sub=4):
     u, f = _f64(u), _f64(f)
     lib().orc_plant_step(C.byref(cfg), C.c_int(x.shape[0]), _p(x), _p(u), _p(f), C.c_double(dt), C.c_int(sub))
     return x
+
+
+# ---- f1: reference window generation
+def traj_point(coeff, t_cum, t_seg, final_pt, t):
+    """coeff[n_seg,28] of ONE vehicle -> (pvaj[12], yaw[2]) at trajectory time t."""
+    coeff, t_cum, t_seg, final_pt = _f64(coeff), _f64(t_cum), _f64(t_seg), _f64(final_pt)
+    pvaj, yaw = np.zeros(12), np.zeros(2)
+    lib().orc_traj_point(C.c_int(coeff.shape[0]), _p(coeff), _p(t_cum), _p(t_seg), _p(final_pt), C.c_double(t),
+                         _p(pvaj), _p(yaw))
+    return pvaj, yaw
+
+
+def diff_flatness(pvaj, yaw, mass=1.4844, g=9.81):
+    pvaj, yaw = _f64(pvaj), _f64(yaw)
+    x, u = np.zeros(10), np.zeros(4)
+    lib().orc_diff_flatness(C.c_double(mass), C.c_double(g), _p(pvaj), _p(yaw), _p(x), _p(u))
+    return x, u
+
+
+def ref_window(coeff, t_cum, t_seg, final_pt, t, N=20, dt=0.1, mass=1.4844, g=9.81):
+    """coeff[V,n_seg,28], t_cum[V,n_seg+1], t_seg[V,n_seg], final_pt[V,3], t[V] -> xr[V,N+1,10], ur[V,N,4]."""
+    coeff, t_cum, t_seg, final_pt, t = _f64(coeff), _f64(t_cum), _f64(t_seg), _f64(final_pt), _f64(t)
+    V, n_seg = coeff.shape[0], coeff.shape[1]
+    xr, ur = np.zeros((V, N + 1, 10)), np.zeros((V, N, 4))
+    lib().orc_ref_window(C.c_int(V), C.c_int(N), C.c_double(dt), C.c_double(mass), C.c_double(g), C.c_int(n_seg),
+                         _p(coeff), _p(t_cum), _p(t_seg), _p(final_pt), _p(t), _p(xr), _p(ur))
+    return xr, ur

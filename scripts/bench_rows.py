@@ -27,6 +27,8 @@ def main():
     import ndp_nmpc_qd_amd as ndp
     B = a.batch
     dev = torch.device("cuda:0")
+    if a.row == "ref_window":
+        return bench_ref_window(a, torch, ndp, dev)
     eng = ndp.BatchedNMPC(B, N=2, load_mlp=False)       # tiny horizon: only the estimator state matters here
     vz = torch.randn(B, dtype=torch.float64, device=dev) * 0.1
     th = torch.rand(B, dtype=torch.float64, device=dev) * 0.8 + 0.15
@@ -59,6 +61,46 @@ def main():
     bytes_per = 152 + 72
     print(json.dumps({"row": "f3 hover-throttle estimator + actuator command", "metric": "vehicle updates/s",
                       "value": B * a.steps / el, "batch": B, "ms_per_step": el / a.steps * 1e3, "dtype": "f64",
+                      "roofline": {"bound": "hbm", "achieved": bytes_per * B / dev_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                   "frac": bytes_per * B / dev_s / 1e9 / 8000.0, "algorithmic_bytes_per_vehicle": bytes_per}}))
+
+
+def bench_ref_window(a, torch, ndp, dev):
+    """f1: reference windows of B vehicles per tick (4-segment minimum-snap trajectories, N = 20).  Algorithmic bytes
+    per vehicle: read t 8 + the coefficients of the segments the window touches (one or two: 224..448, counted as 224)
+    + 5 time_cum + 4 time_seg doubles 72, write xr 1680 + ur 640 = 2624 B."""
+    import numpy as np
+    from ndp_nmpc_qd_amd.pt_pub import TrajCoefficients
+    B, M = a.batch, 4
+    rng = np.random.default_rng(7)
+    wp = np.zeros((B, 4, M + 1))
+    wp[:, 0:2] = np.cumsum(rng.uniform(-1.0, 1.0, (B, 2, M + 1)), axis=2)
+    wp[:, 2] = 1.0 + 0.2 * rng.uniform(-1, 1, (B, M + 1))
+    wp[:, 3] = np.cumsum(rng.uniform(-0.3, 0.3, (B, M + 1)), axis=1)
+    tc = TrajCoefficients.from_waypoints(wp, rng.uniform(3.0, 5.0, (B, M)))
+    eng = ndp.BatchedNMPC(B, load_mlp=False)
+    eng.ref_set_trajectory(tc.coeff_x, tc.coeff_y, tc.coeff_z, tc.coeff_yaw, tc.traj_time_cum, tc.traj_time_seg, tc.final_pt)
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(st)
+    ts = [torch.full((B,), 0.02 * i, dtype=torch.float64, device=dev) for i in range(8)]
+    xr = torch.empty(B, 21, 10, dtype=torch.float64, device=dev)
+    ur = torch.empty(B, 20, 4, dtype=torch.float64, device=dev)
+    for i in range(a.warmup):
+        eng.ref_window_device(ts[i % 8], xr, ur, stream=st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(a.steps):
+        eng.ref_window_device(ts[i % 8], xr, ur, stream=st)
+    e1.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    dev_s = e0.elapsed_time(e1) * 1e-3 / a.steps
+    bytes_per = 8 + 224 + 72 + 1680 + 640
+    print(json.dumps({"row": "f1 reference window generation (polynomial trajectory + differential flatness)",
+                      "metric": "vehicle windows/s", "value": B * a.steps / el, "batch": B, "ms_per_step": el / a.steps * 1e3,
+                      "dtype": "f64", "kernel_us": dev_s * 1e6,
                       "roofline": {"bound": "hbm", "achieved": bytes_per * B / dev_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                                    "frac": bytes_per * B / dev_s / 1e9 / 8000.0, "algorithmic_bytes_per_vehicle": bytes_per}}))
 
