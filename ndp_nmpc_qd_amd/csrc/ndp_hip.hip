@@ -595,18 +595,24 @@ __device__ __forceinline__ double poly_eval(const double *__restrict__ c, const 
         double f = 1.0;
 #pragma unroll
         for (int j = 0; j < D; ++j) f *= (double)(i - j);
-        acc += f * tp[i - D] / inv_scale_den * c[i];
+        acc += f * tp[i - D] * c[i];
     }
-    return acc;
+    return acc / inv_scale_den;      // one division per quantity (the reference divides every term: same value to ~1 ulp)
 }
 
-__global__ __launch_bounds__(256) void ref_window_kernel(RefCfg cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
+#define REF_ROWS 64     // rows (vehicle, node) per workgroup = one wave: small batches spread over all CUs
+__global__ __launch_bounds__(REF_ROWS) void ref_window_kernel(RefCfg cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
                                                          const double *__restrict__ tseg, const double *__restrict__ fpt,
                                                          const double *__restrict__ tq, double *__restrict__ xr, double *__restrict__ ur)
 {
-    const int row = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int np1 = cf.N + 1;
-    if (row >= cf.B * np1) return;
+    // Each lane produces 80 + 32 contiguous bytes; written directly that is a 16-byte store at an 80-byte lane stride
+    // (one fifth of every cache line per instruction).  The wave's rows are contiguous in xr (and, minus the node-N
+    // rows, in ur), so the outputs are transposed through LDS and leave as dense 512-byte wave stores.
+    __shared__ double sx[REF_ROWS * 10], su[REF_ROWS * 4];
+    const int lane = (int)threadIdx.x;
+    const int row0 = (int)blockIdx.x * REF_ROWS;
+    const int np1 = cf.N + 1, nrows = cf.B * np1;
+    const int row = row0 + lane < nrows ? row0 + lane : nrows - 1;      // tail lanes recompute the last row, never store
     const int b = row / np1, k = row - b * np1;
     const double t = tq[b] + k * cf.dt;
     const double *tc = tcum + (size_t)b * (cf.n_seg + 1);
@@ -669,17 +675,28 @@ __global__ __launch_bounds__(256) void ref_window_kernel(RefCfg cf, const double
         q[i] = tt; q[j] = R[i][j] + R[j][i]; q[kk] = R[kk][i] + R[i][kk]; q[3] = R[kk][j] - R[j][kk];
     }
     const double qs = 0.5 / sqrt(tt);
-    double2 *xo = reinterpret_cast<double2 *>(xr) + (size_t)row * 5;
-    xo[0] = make_double2(pvaj[0], pvaj[1]);
-    xo[1] = make_double2(pvaj[2], pvaj[3]);
-    xo[2] = make_double2(pvaj[4], pvaj[5]);
-    xo[3] = make_double2(q[3] * qs, q[0] * qs);            // [qw, qx, qy, qz] (pt_publisher.py:237-240, :115-128)
-    xo[4] = make_double2(q[1] * qs, q[2] * qs);
-    if (k < cf.N) {
-        double2 *uo = reinterpret_cast<double2 *>(ur) + ((size_t)b * cf.N + k) * 2;
-        uo[0] = make_double2(wp, wq);
-        uo[1] = make_double2(wr, u1 / cf.mass);             // collective_force / mass (:145)
+    // [qw, qx, qy, qz] (pt_publisher.py:237-240, :115-128); u = [p, q, r, collective_force / mass] (:138-145)
+    const double xv[10] = {pvaj[0], pvaj[1], pvaj[2], pvaj[3], pvaj[4], pvaj[5], q[3] * qs, q[0] * qs, q[1] * qs, q[2] * qs};
+    const double uv[4] = {wp, wq, wr, u1 / cf.mass};
+#pragma unroll
+    for (int i = 0; i < 10; ++i) sx[lane * 10 + i] = xv[i];
+    // ur has no node-N rows: the number of u rows before row (b, k) is b N + k = row - b
+    const int ufirst = row0 - row0 / np1;
+    const int uslot = (row - b) - ufirst;
+    if (k < cf.N && row0 + lane < nrows) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) su[uslot * 4 + i] = uv[i];
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int rows_here = nrows - row0 < REF_ROWS ? nrows - row0 : REF_ROWS;
+    double *xg = xr + (size_t)row0 * 10;
+    for (int i = lane; i < rows_here * 10; i += REF_ROWS) xg[i] = sx[i];
+    const int rend = row0 + rows_here;
+    const int nu = (rend - rend / np1) - ufirst;                                 // u rows among [row0, rend)
+    double *ug = ur + (size_t)ufirst * 4;
+    for (int i = lane; i < nu * 4; i += REF_ROWS) ug[i] = su[i];
 }
 
 }  // namespace ndp
@@ -1301,7 +1318,7 @@ int ndp_ref_window_device(ndp_handle *h, const void *d_t, void *d_xr, void *d_ur
     const double *coeff = h->dTraj, *cum = coeff + B * S * 28, *seg = cum + B * (S + 1), *fpt = seg + B * S;
     RefCfg cf{h->cfg.batch, h->cfg.N, h->traj_seg, h->cfg.dt, h->cfg.mass, h->cfg.gravity};
     const int rows = h->cfg.batch * (h->cfg.N + 1);
-    hipLaunchKernelGGL(ref_window_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, cf, coeff, cum, seg, fpt,
+    hipLaunchKernelGGL(ref_window_kernel, dim3((rows + REF_ROWS - 1) / REF_ROWS), dim3(REF_ROWS), 0, s, cf, coeff, cum, seg, fpt,
                        (const double *)d_t, (double *)d_xr, (double *)d_ur);
     NDP_HIP(h, hipGetLastError());
     return 0;
