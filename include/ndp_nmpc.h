@@ -172,6 +172,8 @@ int ndp_plant_step_device(ndp_handle *h, void *d_x, const void *d_u, const void 
 
 /* Test hook: number of doubles of the LDS image dump, and a step that also dumps it (B = 1 use). */
 int ndp_debug_lds_doubles(int N);
+/* Test hook: where things sit in that dump: out8 = {XI, MB, CB, MB stride, CB stride, image size, first stamp, 0} (doubles). */
+int ndp_debug_lds_layout(int N, int *out8);
 /* Test hook: one v_mfma_f64_16x16x4_f64 on caller-chosen per-lane operands a[64], b[64], c[4][64];
  * d[0..255] = result registers [4][64], d[256..319] = a cross-lane checksum (readlane + wave reductions). */
 int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, double *d);

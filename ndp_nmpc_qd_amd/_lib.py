@@ -33,7 +33,7 @@ EXPORTS = [
     "ndp_default_cfg", "ndp_create", "ndp_destroy", "ndp_last_error", "ndp_set_mlp_weights", "ndp_reset",
     "ndp_reset_device", "ndp_step", "ndp_step_device", "ndp_downwash", "ndp_downwash_device", "ndp_get_iterate",
     "ndp_set_iterate", "ndp_get_status", "ndp_device_iterate_x", "ndp_device_iterate_u", "ndp_device_force",
-    "ndp_synchronize", "ndp_timing_enable", "ndp_timing_read", "ndp_debug_lds_doubles", "ndp_step_debug", "ndp_debug_mfma_probe", "ndp_debug_stamps", "ndp_throttle_reset", "ndp_throttle_update",
+    "ndp_synchronize", "ndp_timing_enable", "ndp_timing_read", "ndp_debug_lds_doubles", "ndp_step_debug", "ndp_debug_mfma_probe", "ndp_debug_stamps", "ndp_debug_lds_layout", "ndp_throttle_reset", "ndp_throttle_update",
     "ndp_throttle_update_device", "ndp_actuator_cmd", "ndp_actuator_cmd_device", "ndp_throttle_get_state", "ndp_relay_reset", "ndp_relay_formation",
     "ndp_relay_reference", "ndp_relay_reference_device", "ndp_plant_step", "ndp_plant_step_device",
     "ndp_ref_set_trajectory", "ndp_ref_window", "ndp_ref_window_device",
@@ -81,6 +81,7 @@ def load():
     lib.ndp_timing_enable.argtypes = [vp, C.c_int]
     lib.ndp_timing_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.ndp_debug_lds_doubles.argtypes = [C.c_int]
+    lib.ndp_debug_lds_layout.argtypes = [C.c_int, vp]
     lib.ndp_step_debug.argtypes = [vp] * 9
     lib.ndp_debug_mfma_probe.argtypes = [vp] * 4
     lib.ndp_debug_stamps.argtypes = [vp, C.c_int, vp]
@@ -101,6 +102,13 @@ def load():
     lib.ndp_plant_step_device.argtypes = [vp, vp, vp, vp, C.c_double, C.c_int, vp]
     _lib = lib
     return lib
+
+
+def lds_layout(N):
+    """Offsets (doubles) inside the debug dump: dict XI, MB, CB, MB_STRIDE, CB_STRIDE, total, stamps."""
+    out = (C.c_int * 8)()
+    load().ndp_debug_lds_layout(int(N), out)
+    return dict(zip(("XI", "MB", "CB", "MB_STRIDE", "CB_STRIDE", "total", "stamps"), list(out)[:7]))
 
 
 def default_cfg(**kw):

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
             zb[s] = (float)(oth[idx] - io.xr[idx]);       // downwash_nn.py:22-23
         }
         const LdsMap m = make_map(N);
-        if (io.dbg && lane == 0) io.dbg[m.KT + 9] = (double)__builtin_amdgcn_s_memtime();
+        if (io.dbg && lane == 0) io.dbg[m.total + 9] = (double)__builtin_amdgcn_s_memtime();
         if (io.stamps && lane == 0) io.stamps[9] = (double)__builtin_amdgcn_s_memtime();
         // the whole workgroup's LDS is still unused: park the weight fragments there for the MLP phase
         lds_f32 wl = (lds_f32)smem;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
         mlp_tile(wl, zb, lane, o);
         __syncthreads();                              // every wave is done with the weights before LDS becomes RTI state
         if (!active) return;
-        if (io.dbg && lane == 0) io.dbg[m.KT + 10] = (double)__builtin_amdgcn_s_memtime();
+        if (io.dbg && lane == 0) io.dbg[m.total + 10] = (double)__builtin_amdgcn_s_memtime();
         if (io.stamps && lane == 0) io.stamps[10] = (double)__builtin_amdgcn_s_memtime();
         if (j < np1 && h == 0) {
 #pragma unroll
@@ -762,7 +762,14 @@ int ndp_default_cfg(ndp_cfg *cfg)
 
 const char *ndp_last_error(const ndp_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
-int ndp_debug_lds_doubles(int N) { return lds_doubles(N); }
+int ndp_debug_lds_doubles(int N) { return lds_doubles(N) + DBG_EXTRA; }
+
+int ndp_debug_lds_layout(int N, int *out8)
+{
+    if (!out8) return -1;
+    lds_layout(N, out8);
+    return 0;
+}
 
 int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, double *d)
 {
@@ -844,7 +851,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     }
     ALLOC(h->sx0, B * NX * 8); ALLOC(h->sxr, nxs(h) * 8); ALLOC(h->sur, nus(h) * 8);
     ALLOC(h->sother, nxs(h) * 8); ALLOC(h->sego, B * 2 * 8); ALLOC(h->su0, B * NU * 8);
-    ALLOC(h->sf, nfs(h) * 4); ALLOC(h->sdbg, (size_t)lds_doubles(cfg->N) * 8);
+    ALLOC(h->sf, nfs(h) * 4); ALLOC(h->sdbg, (size_t)(lds_doubles(cfg->N) + DBG_EXTRA) * 8);
 #undef ALLOC
     (void)hipMemsetAsync(h->dX, 0, nxs(h) * 8, h->stream);
     (void)hipMemsetAsync(h->dU, 0, nus(h) * 8, h->stream);
@@ -1036,7 +1043,7 @@ static int step_host(ndp_handle *h, const double *x0, const double *xr, const do
     }
     if (rc) return rc;
     NDP_HIP(h, hipMemcpyAsync(u0, h->su0, B * NU * 8, hipMemcpyDeviceToHost, s));
-    if (dump) NDP_HIP(h, hipMemcpyAsync(dump, h->sdbg, (size_t)lds_doubles(h->cfg.N) * 8, hipMemcpyDeviceToHost, s));
+    if (dump) NDP_HIP(h, hipMemcpyAsync(dump, h->sdbg, (size_t)(lds_doubles(h->cfg.N) + DBG_EXTRA) * 8, hipMemcpyDeviceToHost, s));
     NDP_HIP(h, hipStreamSynchronize(s));
     int w = 0;
     rc = worst_status(h, &w);

@@ -26,8 +26,12 @@
 #ifndef NDP_D        // wave-program functions: __device__ in the gfx950 build, plain inline under the emulator
 #define NDP_D inline
 #endif
-#ifndef NDP_EXP
-#define NDP_EXP 0
+// the stage loops of the sweeps are fully unrolled when the horizon is a compile-time constant (clang only: the
+// host emulator build ignores it)
+#if defined(__clang__)
+#define NDP_UNROLL_STAGES _Pragma("unroll UNROLL_STAGES")
+#else
+#define NDP_UNROLL_STAGES
 #endif
 #ifdef NDP_FINE_STAMPS
 #define NDP_FINE(x) x
@@ -42,11 +46,14 @@ namespace ndp {
 
 enum { NX = 10, NU = 4 };
 enum { QP_AUTO = 0, QP_IPM_ALWAYS = 1 };
-enum { MB_STRIDE = 86, CB_STRIDE = 47, KT_STRIDE = 48 };
-// stage block MB_k: 6x8 [d(p,v)+/d(q,u)] | 4x7 [dq+/d(q,w)] | b(10)
-enum { MB_PV = 0, MB_Q = 48, MB_B = 76 };
-// cost block CB_k: Qq(4x4) | qe(10) | re(4) | dex(6) | deu(4) | qbv(3) | rb(4)
-enum { CB_QQ = 0, CB_QE = 16, CB_RE = 26, CB_DEX = 30, CB_DEU = 36, CB_QBV = 40, CB_RB = 43 };
+// Every per-stage operand of the sweeps lives in a stage block of ONE stride, constants included, so that the address
+// of element e of stage k is (per-lane base of e) + k * stride: with a compile-time horizon the stage term is the
+// immediate offset of the DS instruction and the sweeps carry no address arithmetic at all.
+enum { MB_STRIDE = 137, CB_STRIDE = 48 };
+// stage block MB_k: 6x8 [d(p,v)+/d(q,u)] | 4x7 [dq+/d(q,w)] | b(10) | constants 0, 1, h | K~'(12x4, written by the backward sweep)
+enum { MB_PV = 0, MB_Q = 48, MB_B = 76, MB_ZERO = 86, MB_ONE = 87, MB_H = 88, MB_KT = 89 };
+// cost block CB_k: Qq(4x4) | qe(10) | re(4) | dex(6) | deu(4) | qbv(3) | rb(4) | constant 0
+enum { CB_QQ = 0, CB_QE = 16, CB_RE = 26, CB_DEX = 30, CB_DEU = 36, CB_QBV = 40, CB_RB = 43, CB_ZERO = 47 };
 // constants area
 enum { KC_ZERO = 0, KC_ONE = 1, KC_H = 2, KC_QD = 4, KC_RD = 14, KC_LBU = 18, KC_UBU = 22, KC_LBV = 26, KC_UBV = 29, KC_SC = 32, KC_DUMP = 48, KC_SIZE = 50 };
 
@@ -100,16 +107,23 @@ NDP_HD LdsMap make_map(int N)
     m.CU = o; o += N * NU;
     m.MB = o; o += N * MB_STRIDE;
     m.CB = o; o += (N + 1) * CB_STRIDE;
-    m.KT = o; o += N * KT_STRIDE;
     m.total = o;
-    // staged inputs alias the gain storage, which is dead until the first backward sweep
-    m.TXR = m.KT;
+    m.KT = m.MB + MB_KT;   // K~' of stage 0; stage k at + k * MB_STRIDE
+    // staged inputs (17N + 13 doubles) alias ZX|ZU|CX|CU (28N + 20), which are dead until the first sweep / step
+    m.TXR = m.ZX;
     m.TUR = m.TXR + (N + 1) * NX;
     m.TF = m.TUR + N * NU;
     return m;
 }
 
 NDP_HD int lds_doubles(int N) { return make_map(N).total; }
+enum { DBG_EXTRA = 32 };   // the debug dump is the LDS image followed by 16 phase stamps and 16 fine stamps
+// layout facts for tests and scripts: {XI, MB, CB, MB_STRIDE, CB_STRIDE, total, stamps, 0}
+NDP_HD void lds_layout(int N, int *out)
+{
+    const LdsMap m = make_map(N);
+    out[0] = m.XI; out[1] = m.MB; out[2] = m.CB; out[3] = MB_STRIDE; out[4] = CB_STRIDE; out[5] = m.total; out[6] = m.total; out[7] = 0;
+}
 
 // the constants area of the LDS image, written once by the host and copied by the kernel (one coalesced load
 // instead of a 30-way select chain per launch)
@@ -132,23 +146,26 @@ NDP_HD void fill_kc(const RtiParams &P, double *kc)
 template <class W, int NSLOT, int NC = 0, bool HT = false, int NR = 0>
 struct RtiWave {
     static NDP_D int horizon(const RtiParams &P) { return NC ? NC : P.N; }
+    static constexpr int UNROLL_STAGES = NC > 0 ? NC : 1;
+    static NDP_D int mb(int k) { return k * int(MB_STRIDE); }   // stage offsets (immediates once the stage loops are unrolled)
+    static NDP_D int cb(int k) { return k * int(CB_STRIDE); }
     using vd = typename W::vd;
     using vi = typename W::vi;
     using vb = typename W::vb;
     using vd4 = typename W::vd4;
     using lp = typename W::lds_ptr;   // pointer into this wave's LDS slice
 
-    struct Tables {
-        vi mk_off[3], mk_mul[3];  // M~ as B operand / M~' as A operand: element (4c+g, j)
-        vi fw_off[3], fw_mul[3];  // forward A operand [M~x ; K~]: rows j<12 element (j, 4c+g) of M~, rows j>=12 K~[j-12][4c+g]
-        vi mu_off, mu_mul;        // M~ columns 12..15 (B~) as A operand: element (j, 12+g)
-        vi c_off[4], c_mul[4];    // C~ in accumulator layout: element (g+4r, j)
+    struct Tables {               // per-lane LDS offsets of stage 0 (doubles); stage k adds k * MB_STRIDE / CB_STRIDE / NX / NU
+        vi mk_off[3];             // M~ as B operand / M~' as A operand: element (4c+g, j)
+        vi fw_off[3];             // forward A operand [M~x ; K~]: rows j<12 element (j, 4c+g) of M~, rows j>=12 K~[j-12][4c+g]
+        vi mu_off;                // M~ columns 12..15 (B~) as A operand: element (j, 12+g)
+        vi c_off[4];              // C~ in accumulator layout: element (g+4r, j)
         vi kt_off[3];             // where lanes j>=12 keep K~'[4c+g][j-12]
-        vi kt_st[3], kt_mul;      // the same for stores: lanes j<12 aim at the dump slot (branch-free store, stride 0)
-        vi zu_st, zu_mul, zx_st[3], zx_mul[3];   // forward-sweep result stores (lanes j==0), others to the dump slot
+        vi zu_off, zx_off[3];     // forward-sweep results of lanes j == 0: du[g], x+[4c+g]
         vb kt_pred;               // j >= 12
         vb lo4;                   // j < 4
         vb col0;                  // j == 0
+        vb zx_pred[3];            // j == 0 and 4c+g < 10
         // 4x4 inverse (lam_inverse): LDS scratch SC holds Lam row-major
         vi lam_w_off;             // lanes j >= 12 publish H~[12+g][j] to SC[g*4 + j-12]
         vi minor_off[9];          // the 3x3 minor of (g, j&3)
@@ -169,8 +186,8 @@ struct RtiWave {
     };
 
     // ---------------------------------------------------------------- index tables
-    // element (r, c) of M~_k = [[A b 0 B], [0 1 0 0], [0 0 0 0]] -> LDS offset (+ k * mul)
-    static NDP_HD void m_entry(const LdsMap &m, vi r, vi c, vi &off, vi &mul)
+    // element (r, c) of M~_0 = [[A b 0 B], [0 1 0 0], [0 0 0 0]] -> LDS offset (stage k: + k * MB_STRIDE)
+    static NDP_HD vi m_entry(const LdsMap &m, vi r, vi c)
     {
         vb isP = r < 3, isPV = r < 6, isQ = (r >= 6) && (r < 10);
         vb colq = (c >= 6) && (c < 10), colu = c >= 12;
@@ -181,15 +198,14 @@ struct RtiWave {
         vb one = (isPV && (c == r)) || ((r == 10) && (c == 10));
         vb hh = isP && (c == r + 3);
         vi rel = W::sel(var_pv, r * 8 + colpos + int(MB_PV),
-                 W::sel(var_q, (r - 6) * 7 + colpos + int(MB_Q), r + int(MB_B)));
-        vb isvar = var_pv || var_q || var_b;
-        vi kc = W::sel(one, vi(m.KC + KC_ONE), W::sel(hh, vi(m.KC + KC_H), vi(m.KC + KC_ZERO)));
-        off = W::sel(isvar, rel + m.MB, kc);
-        mul = W::sel(isvar, vi(int(MB_STRIDE)), vi(0));
+                 W::sel(var_q, (r - 6) * 7 + colpos + int(MB_Q),
+                 W::sel(var_b, r + int(MB_B),
+                 W::sel(one, vi(int(MB_ONE)), W::sel(hh, vi(int(MB_H)), vi(int(MB_ZERO)))))));
+        return rel + m.MB;
     }
 
-    // element (row, col) of C~_k = [[Q q 0 0], [q' 0 0 r'], [0], [0 r 0 R]] -> LDS offset (+ k * mul)
-    static NDP_HD void c_entry(const LdsMap &m, vi row, vi col, vi &off, vi &mul)
+    // element (row, col) of C~_0 = [[Q q 0 0], [q' 0 0 r'], [0], [0 r 0 R]] -> LDS offset (stage k: + k * CB_STRIDE)
+    static NDP_HD vi c_entry(const LdsMap &m, vi row, vi col)
     {
         vb rx = row < 10, cx = col < 10, ru = row >= 12, cu = col >= 12;
         vb dgx = rx && (row == col) && (row < 6);
@@ -202,10 +218,9 @@ struct RtiWave {
         vi rel = W::sel(dgx, row + int(CB_DEX),
                  W::sel(qq, (row - 6) * 4 + (col - 6) + int(CB_QQ),
                  W::sel(gx, gxi + int(CB_QE),
-                 W::sel(dgu, row - 12 + int(CB_DEU), gui + int(CB_RE)))));
-        vb isvar = dgx || qq || gx || dgu || gu;
-        off = W::sel(isvar, rel + m.CB, vi(m.KC + KC_ZERO));
-        mul = W::sel(isvar, vi(int(CB_STRIDE)), vi(0));
+                 W::sel(dgu, row - 12 + int(CB_DEU),
+                 W::sel(gu, gui + int(CB_RE), vi(int(CB_ZERO)))))));
+        return rel + m.CB;
     }
 
     // lane-derived predicates and constants of the tables (cheap: a handful of compares)
@@ -216,6 +231,7 @@ struct RtiWave {
         T.kt_pred = j >= 12;
         T.lo4 = j < 4;
         T.col0 = j == 0;
+        for (int c = 0; c < 3; ++c) T.zx_pred[c] = T.col0 && (g + 4 * c < 10);
         T.cof_sign = W::sel(((g + jc) & 1) == 1, vd(-1.0), vd(1.0));
         T.lam_diag = g == jc;
         for (int c = 0; c < 4; ++c) T.eye[c] = W::sel(j == g + 4 * c, vd(1.0), vd(0.0));
@@ -226,26 +242,15 @@ struct RtiWave {
         lane_preds(T);
         vi lane = W::lane();
         vi g = lane >> 4, j = lane & 15;
-        for (int c = 0; c < 3; ++c) m_entry(m, g + 4 * c, j, T.mk_off[c], T.mk_mul[c]);
-        for (int r = 0; r < 4; ++r) c_entry(m, g + 4 * r, j, T.c_off[r], T.c_mul[r]);
+        for (int c = 0; c < 3; ++c) T.mk_off[c] = m_entry(m, g + 4 * c, j);
+        for (int r = 0; r < 4; ++r) T.c_off[r] = c_entry(m, g + 4 * r, j);
         for (int c = 0; c < 3; ++c) {
             T.kt_off[c] = (g + 4 * c) * 4 + (j & 3) + m.KT;
-            vi mo, mm;
-            m_entry(m, j, g + 4 * c, mo, mm);
-            T.kt_st[c] = W::sel(T.kt_pred, T.kt_off[c], vi(m.KC + KC_DUMP));
-            T.kt_mul = W::sel(T.kt_pred, vi(int(KT_STRIDE)), vi(0));
-            T.fw_off[c] = W::sel(T.kt_pred, T.kt_off[c], mo);
-            T.fw_mul[c] = W::sel(T.kt_pred, vi(int(KT_STRIDE)), mm);
+            T.fw_off[c] = W::sel(T.kt_pred, T.kt_off[c], m_entry(m, j, g + 4 * c));
+            T.zx_off[c] = W::sel(T.zx_pred[c], g + 4 * c + m.ZX, vi(m.ZX));
         }
-        m_entry(m, j, g + 12, T.mu_off, T.mu_mul);
-        T.zu_st = W::sel(T.col0, g + m.ZU, vi(m.KC + KC_DUMP));
-        for (int c = 0; c < 3; ++c) {
-            vi idx = g + 4 * c;
-            vb p = T.col0 && (idx < 10);
-            T.zx_st[c] = W::sel(p, idx + m.ZX, vi(m.KC + KC_DUMP));
-            T.zx_mul[c] = W::sel(p, vi(int(NX)), vi(0));
-        }
-        T.zu_mul = W::sel(T.col0, vi(int(NU)), vi(0));
+        T.mu_off = m_entry(m, j, g + 12);
+        T.zu_off = g + m.ZU;
         vi jc = j & 3;
         T.lam_w_off = g * 4 + jc + m.SC;
         for (int a = 0; a < 3; ++a)
@@ -259,16 +264,14 @@ struct RtiWave {
 
     // the integer fields of Tables in a fixed order: f(index, field).  Used by the host to serialise the tables
     // (fill_tables) and by the device to read them back (load_tables).
-    enum { TB_FIELDS = 48 };
+    enum { TB_FIELDS = 32 };
     template <class F>
     static NDP_HD void for_each_int(Tables &T, F &&f)
     {
         int i = 0;
-        for (int c = 0; c < 3; ++c) { f(i++, T.mk_off[c]); f(i++, T.mk_mul[c]); f(i++, T.fw_off[c]); f(i++, T.fw_mul[c]); }
-        for (int r = 0; r < 4; ++r) { f(i++, T.c_off[r]); f(i++, T.c_mul[r]); }
-        for (int c = 0; c < 3; ++c) { f(i++, T.kt_off[c]); f(i++, T.kt_st[c]); f(i++, T.zx_st[c]); f(i++, T.zx_mul[c]); }
-        f(i++, T.mu_off); f(i++, T.mu_mul); f(i++, T.kt_mul); f(i++, T.zu_st); f(i++, T.zu_mul);
-        f(i++, T.lam_w_off); f(i++, T.own_off);
+        for (int c = 0; c < 3; ++c) { f(i++, T.mk_off[c]); f(i++, T.fw_off[c]); f(i++, T.kt_off[c]); f(i++, T.zx_off[c]); }
+        for (int r = 0; r < 4; ++r) f(i++, T.c_off[r]);
+        f(i++, T.mu_off); f(i++, T.zu_off); f(i++, T.lam_w_off); f(i++, T.own_off);
         for (int a = 0; a < 9; ++a) f(i++, T.minor_off[a]);
     }
     // block layout [field / 4][lane][field % 4]: the four fields of a group are one 16-byte load per lane, a
@@ -402,6 +405,7 @@ struct RtiWave {
                 grad = grad + h * qi[t][b];
             }
             W::stp(lds, cb + a + (int(CB_QE) + 6), grad, p);
+            W::stp(lds, cb + int(CB_ZERO), vd(0.0), p && (a == 0));     // the block's structural zero
         }
         for (int t = 0; t < RB; ++t) {
             vi task = lane + 64 * t;
@@ -560,6 +564,12 @@ struct RtiWave {
             vi task = lane + t;
             vb p = task < N;
             vi k = W::sel(p, task, vi(0));
+            {   // the block's structural constants 0, 1, h (entries of M~ that are the same at every stage)
+                vi mc = k * int(MB_STRIDE) + m.MB;
+                W::stp(lds, mc + int(MB_ZERO), vd(0.0), p);
+                W::stp(lds, mc + int(MB_ONE), vd(1.0), p);
+                W::stp(lds, mc + int(MB_H), vd(P.dt), p);
+            }
             vi xi = k * NX + m.XI, ui = k * NU + m.UI, fi = k * 3 + m.TF;
             vd x[10];
             for (int i = 0; i < 10; ++i) x[i] = W::ld(lds, xi + i);
@@ -650,36 +660,26 @@ struct RtiWave {
         vd4 H;
         {   // stage N-1 from the terminal block (no control part: keep columns 12..15 exactly zero)
             vd4 Pt;
-            for (int c = 0; c < 3; ++c) Pt.r[c] = W::sel(j < 12, W::ld(lds, T.c_off[c] + T.c_mul[c] * N), vd(0.0));
+            for (int c = 0; c < 3; ++c) Pt.r[c] = W::sel(j < 12, W::ld(lds, T.c_off[c] + cb(N)), vd(0.0));
             vd mk[3];
-            for (int c = 0; c < 3; ++c) mk[c] = W::ld(lds, T.mk_off[c] + T.mk_mul[c] * (N - 1));
-            for (int r = 0; r < 4; ++r) H.r[r] = W::ld(lds, T.c_off[r] + T.c_mul[r] * (N - 1));
+            for (int c = 0; c < 3; ++c) mk[c] = W::ld(lds, T.mk_off[c] + mb(N - 1));
+            for (int r = 0; r < 4; ++r) H.r[r] = W::ld(lds, T.c_off[r] + cb(N - 1));
             vd4 Wm = W::zero4();
             for (int c = 0; c < 3; ++c) Wm = W::mfma(Pt.r[c], mk[c], Wm);
             for (int c = 0; c < 3; ++c) H = W::mfma(mk[c], Wm.r[c], H);
         }
         vd mk[3], cc[4];       // operands of the NEXT stage to be formed (k-1), requested one iteration ahead
-        // running LDS addresses (one add per operand and stage instead of a quarter-rate integer multiply)
-        vi a_mk[3], a_cc[4], a_kt[3];
         {
             const int kn = N > 1 ? N - 2 : 0;
-            for (int c = 0; c < 3; ++c) { a_mk[c] = T.mk_off[c] + T.mk_mul[c] * kn; mk[c] = W::ld(lds, a_mk[c]); }
-            for (int r = 0; r < 4; ++r) { a_cc[r] = T.c_off[r] + T.c_mul[r] * kn; cc[r] = W::ld(lds, a_cc[r]); }
-            for (int c = 0; c < 3; ++c) a_kt[c] = T.kt_st[c] + T.kt_mul * (N - 1);
+            for (int c = 0; c < 3; ++c) mk[c] = W::ld(lds, T.mk_off[c] + mb(kn));
+            for (int r = 0; r < 4; ++r) cc[r] = W::ld(lds, T.c_off[r] + cb(kn));
         }
+        NDP_UNROLL_STAGES
         for (int k = N - 1; k >= 1; --k) {
             vd nmk[3], ncc[4];
-            if (k >= 2) {      // prefetch stage k-2; at k = 1 there is none: re-read stage 0 (values unused)
-                for (int c = 0; c < 3; ++c) a_mk[c] = a_mk[c] - T.mk_mul[c];
-                for (int r = 0; r < 4; ++r) a_cc[r] = a_cc[r] - T.c_mul[r];
-            }
-#if NDP_EXP == 6
-            for (int c = 0; c < 3; ++c) nmk[c] = mk[c] * 0.5;
-            for (int r = 0; r < 4; ++r) ncc[r] = cc[r] * 0.5;
-#else
-            for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, a_mk[c]);
-            for (int r = 0; r < 4; ++r) ncc[r] = W::ld(lds, a_cc[r]);
-#endif
+            const int kp = k >= 2 ? k - 2 : 0;      // prefetch stage k-2; at k = 1 there is none: re-read stage 0 (values unused)
+            for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, T.mk_off[c] + mb(kp));
+            for (int r = 0; r < 4; ++r) ncc[r] = W::ld(lds, T.c_off[r] + cb(kp));
             // Lam[a][b] = H~[12+a][12+b] and H~ux both sit in accumulator register 3
             vd hux = H.r[3];
             // [H~xx ; H~ux] M~_{k-1}: H~'s registers as A operand mean H~' -- equal up to rounding (see the
@@ -691,12 +691,7 @@ struct RtiWave {
             //   M~'' H~xu = (H~ux M~')' = T', hence  H~' = [C~' + M~'' (H~xx M~')] - T' Lam^-1 T:
             // the bracket needs no Lam^-1, only two dependent MFMAs (adj T, then the rank-4 correction) follow it.
             LamRegs LR;
-#if NDP_EXP == 1
-            for (int i = 0; i < 9; ++i) LR.mm[i] = hux * (0.1 * i);
-            LR.own = hux;
-#else
             lam_gather(T, lds, hux, LR);
-#endif
             W::pin();
             vd4 Wf = W::zero4();
             for (int c = 0; c < 3; ++c) Wf = W::mfma(H.r[c], mk[c], Wf);
@@ -725,37 +720,21 @@ struct RtiWave {
             vd r0 = W::rcp_seed(det);
             W::pin();
             vd tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
-#if NDP_EXP == 5
-            vd4 G; for (int r = 0; r < 4; ++r) G.r[r] = ladj * tt;
-#else
             vd4 G = W::mfma(ladj, tt, W::zero4());            // adj T
-#endif
             W::pin();
             vd e0 = W::fma(-det, r0, vd(1.0));
             vd r1 = W::fma(e0, r0, r0);
             W::pin();
-#if NDP_EXP == 5
-            vd4 Kt; for (int r = 0; r < 4; ++r) Kt.r[r] = hux * nahi;
-#else
             vd4 Kt = W::mfma(hux, nahi, W::zero4());          // det * K~'[i][b], lands in column 12+b (rows 12..15 of the forward operand)
-#endif
             W::pin();
-#if NDP_EXP == 2
-            vd rdet = r1;
-#else
             vd e1 = W::fma(-det, r1, vd(1.0));
             vd rdet = W::fma(e1, r1, r1);                     // 1/det: v_rcp_f64 seed + two Newton steps
-#endif
             okv = okv && (det > 0.0) && (!T.lam_diag || (cof > 0.0));
-#if NDP_EXP == 3
-            vd gs = G.r[0];
-#else
             vd gs = G.r[0] * rdet;                            // Lam^-1 T
-#endif
             W::pin();
             vd4 Hn = W::mfma(-tt, gs, Hb);                    // - T' Lam^-1 T on top of the bracket
-            for (int c = 0; c < 3; ++c) { W::st(lds, a_kt[c], Kt.r[c] * rdet); a_kt[c] = a_kt[c] - T.kt_mul; }
-            if (NDP_EXP != 4 && (k & 3) == 0) {
+            for (int c = 0; c < 3; ++c) W::stp(lds, T.kt_off[c] + mb(k), Kt.r[c] * rdet, T.kt_pred);
+            if ((k & 3) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
                 // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
                 // re-symmetrise every 4th stage.  H~' = (H~ as A operand) x I costs four MFMAs, no LDS.
@@ -775,7 +754,7 @@ struct RtiWave {
             vd rdet = lam_rdet(T, LR, cof, ok);
             vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));
             vd4 Kt = W::mfma(hux, nahi, W::zero4());
-            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c], Kt.r[c] * rdet);
+            for (int c = 0; c < 3; ++c) W::stp(lds, T.kt_off[c], Kt.r[c] * rdet, T.kt_pred);
         }
         ok = W::all(okv) && ok;
         W::sync();
@@ -790,17 +769,14 @@ struct RtiWave {
         // per stage: Y = [M~x ; K~] z~ (3 MFMAs) holds M~x z~ in rows 0..11 and du = K~ z~ in rows 12..15, i.e. du is
         // accumulator register 3 -- exactly the B operand of the 4th MFMA, which adds B~ du to rows 0..11.
         vd fw[3], mu;
-        vi a_fw[3], a_mu = T.mu_off, a_zu = T.zu_st, a_zx[3];
-        for (int c = 0; c < 3; ++c) { a_fw[c] = T.fw_off[c]; fw[c] = W::ld(lds, a_fw[c]); a_zx[c] = T.zx_st[c] + T.zx_mul[c]; }
-        mu = W::ld(lds, a_mu);
+        for (int c = 0; c < 3; ++c) fw[c] = W::ld(lds, T.fw_off[c]);
+        mu = W::ld(lds, T.mu_off);
+        NDP_UNROLL_STAGES
         for (int k = 0; k < N; ++k) {
             vd nfw[3], nmu;
-            if (k + 1 < N) {
-                for (int c = 0; c < 3; ++c) a_fw[c] = a_fw[c] + T.fw_mul[c];
-                a_mu = a_mu + T.mu_mul;
-            }
-            for (int c = 0; c < 3; ++c) nfw[c] = W::ld(lds, a_fw[c]);
-            nmu = W::ld(lds, a_mu);
+            const int kn = k + 1 < N ? k + 1 : k;
+            for (int c = 0; c < 3; ++c) nfw[c] = W::ld(lds, T.fw_off[c] + mb(kn));
+            nmu = W::ld(lds, T.mu_off + mb(kn));
             W::pin();   // keep the prefetch ahead of this stage's MFMAs (the scheduler otherwise sinks it behind them)
             vd4 Y = W::zero4();
             Y = W::mfma(fw[0], zc[0], Y);
@@ -808,12 +784,10 @@ struct RtiWave {
             Y = W::mfma(fw[2], zc[2], Y);
             vd du = Y.r[3];
             vd4 xn = W::mfma(mu, du, Y);
-            W::st(lds, a_zu, du);
-            a_zu = a_zu + T.zu_mul;
+            W::stp(lds, T.zu_off + k * int(NU), du, T.col0);
             for (int c = 0; c < 3; ++c) {
                 zc[c] = xn.r[c];
-                W::st(lds, a_zx[c], xn.r[c]);
-                a_zx[c] = a_zx[c] + T.zx_mul[c];
+                W::stp(lds, T.zx_off[c] + (k + 1) * int(NX), xn.r[c], T.zx_pred[c]);
             }
             for (int c = 0; c < 3; ++c) fw[c] = nfw[c];
             mu = nmu;
@@ -993,7 +967,7 @@ struct RtiWave {
     static NDP_D void fstamp(const RtiIo &io, const LdsMap &m, int idx, vd dep = vd(0.0))
     {
         vd t = W::clock_after(dep);
-        W::gst(io.dbg, W::lane() * 0 + (m.KT + 16 + idx), t, W::lane() == 0);
+        W::gst(io.dbg, W::lane() * 0 + (m.total + 16 + idx), t, W::lane() == 0);
     }
 
     // debug-path phase stamps (shader clock) written behind the LDS image dump; no-op when io.dbg is null
@@ -1001,7 +975,7 @@ struct RtiWave {
     {
         if (io.dbg) {
             vd t = W::clock();
-            W::gst(io.dbg, W::lane() * 0 + (m.KT + idx), t, W::lane() == 0);
+            W::gst(io.dbg, W::lane() * 0 + (m.total + idx), t, W::lane() == 0);
         }
         if (io.stamps) {
             vd t = W::clock();
@@ -1062,9 +1036,9 @@ struct RtiWave {
             W::stp(lds, lane + m.ZX, x0v - W::ldp(lds, lane + m.XI, lane < NX), lane < NX);
             W::sync();
             if (io.dbg && it == 0) {   // test hook: dump the linearisation + cost blocks
-                for (int t = 0; t < m.KT; t += 64) {
+                for (int t = 0; t < m.total; t += 64) {
                     vi i = lane + t;
-                    W::gst(io.dbg, i, W::ldp(lds, i, i < m.KT), i < m.KT);
+                    W::gst(io.dbg, i, W::ldp(lds, i, i < m.total), i < m.total);
                 }
             }
             bool done = false;
@@ -1155,7 +1129,7 @@ struct LaneW {
     static vi sel(vb p, vi a, vi b) { return p ? a : b; }
 };
 
-enum { TB_WORDS = 48 * 64 };
+enum { TB_WORDS = 32 * 64 };
 
 inline void fill_tables(int N, int *out /* [TB_WORDS] */)
 {

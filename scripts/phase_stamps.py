@@ -5,7 +5,8 @@ import ndp_nmpc_qd_amd as ndp
 from ndp_nmpc_qd_amd import synth
 b = synth.make_batch(1, seed=3, downwash=True)
 names = ['start', 'tables', 'stage_in', 'cost', 'linearize', 'pre_sweep(dump)', 'backward', 'forward', 'end']
-KT = 50 + 3 * (21 * 10 + 20 * 4) + 20 * 86 + 21 * 47
+from ndp_nmpc_qd_amd import _lib
+KT = _lib.lds_layout(20)["stamps"]      # the stamps follow the LDS image in the debug dump
 for fused in (False, True):
     eng = ndp.BatchedNMPC(1, disturbance=fused)
     for rep in range(3):

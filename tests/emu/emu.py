@@ -44,6 +44,12 @@ def default_cfg(N=20, n_rti=1, use_fd=False, qp_mode=0):
     return c
 
 
+def lds_layout(N):
+    out = (C.c_int * 8)()
+    lib().emu_lds_layout(int(N), out)
+    return dict(zip(("XI", "MB", "CB", "MB_STRIDE", "CB_STRIDE", "total", "stamps"), list(out)[:7]))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

@@ -9,7 +9,9 @@ extern "C" {
 
 int emu_default_cfg(ndp_cfg *c) { ndp::fill_default_cfg(c); return 0; }
 
-int emu_lds_doubles(int N) { return ndp::lds_doubles(N); }
+int emu_lds_doubles(int N) { return ndp::lds_doubles(N) + ndp::DBG_EXTRA; }
+
+int emu_lds_layout(int N, int *out8) { ndp::lds_layout(N, out8); return 0; }
 
 // One instance, one emulated wave.  counters: [mfma, lds_ld, lds_st, readlane]
 int emu_rti_step(const ndp_cfg *cfg, const double *x0, const double *xr, const double *ur, const float *f,

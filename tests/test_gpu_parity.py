@@ -219,15 +219,16 @@ def test_lds_image_matches_oracle_linearisation(ndp, oracle):
     eng.set_iterate(X, U)
     _, lds = eng.update_debug(b["x0"], b["xr"], b["ur"])
     qp = oracle.linearize(oracle.default_cfg(), b["x0"][0], b["xr"][0], b["ur"][0], None, X[0], U[0])
-    MB = 50 + 3 * ((N + 1) * 10 + N * 4)
-    CB = MB + N * 86
+    from ndp_nmpc_qd_amd import _lib
+    L = _lib.lds_layout(N)
+    MB, CB, MS, CS = L["MB"], L["CB"], L["MB_STRIDE"], L["CB_STRIDE"]
     for k in range(N):
-        blk = lds[MB + k * 86: MB + (k + 1) * 86]
+        blk = lds[MB + k * MS: MB + (k + 1) * MS]
         np.testing.assert_allclose(blk[0:48].reshape(6, 8)[:, 0:4], qp["A"][k][0:6, 6:10], atol=1e-12)
         np.testing.assert_allclose(blk[0:48].reshape(6, 8)[:, 4:8], qp["B"][k][0:6, :], atol=1e-12)
         np.testing.assert_allclose(blk[48:76].reshape(4, 7)[:, 0:4], qp["A"][k][6:10, 6:10], atol=1e-12)
         np.testing.assert_allclose(blk[76:86], qp["b"][k], atol=1e-12)
-        cb = lds[CB + k * 47: CB + (k + 1) * 47]
+        cb = lds[CB + k * CS: CB + (k + 1) * CS]
         np.testing.assert_allclose(cb[16:26], qp["q"][k], atol=1e-10)
         np.testing.assert_allclose(cb[26:30], qp["r"][k], atol=1e-10)
 

@@ -146,12 +146,11 @@ def test_lds_image_matches_oracle_linearisation(oracle):
     cfg, cfgo = E.default_cfg(use_fd=True), oracle.default_cfg(use_fd=True)
     qp = oracle.linearize(cfgo, b["x0"][0], b["xr"][0], b["ur"][0], f, X, U)
     _, _, _, lds, _ = E.rti_step(cfg, b["x0"][0], b["xr"][0], b["ur"][0], f, X.copy(), U.copy(), dump=True)
-    KC = 0
-    XI = KC + 50
-    MB = XI + 3 * ((N + 1) * 10 + N * 4)
-    CB = MB + N * 86
+    L = E.lds_layout(N)
+    MB, CB, MS, CS = L["MB"], L["CB"], L["MB_STRIDE"], L["CB_STRIDE"]
     for k in range(N):
-        blk = lds[MB + k * 86: MB + (k + 1) * 86]
+        blk = lds[MB + k * MS: MB + (k + 1) * MS]
+        np.testing.assert_array_equal(blk[86:89], [0.0, 1.0, cfg.dt])          # the block's structural constants
         S_pv = blk[0:48].reshape(6, 8)
         S_q = blk[48:76].reshape(4, 7)
         np.testing.assert_allclose(S_pv[:, 0:4], qp["A"][k][0:6, 6:10], atol=1e-13)
@@ -160,7 +159,8 @@ def test_lds_image_matches_oracle_linearisation(oracle):
         np.testing.assert_allclose(S_q[:, 4:7], qp["B"][k][6:10, 0:3], atol=1e-13)
         np.testing.assert_allclose(blk[76:86], qp["b"][k], atol=1e-13)
     for k in range(N + 1):
-        blk = lds[CB + k * 47: CB + (k + 1) * 47]
+        blk = lds[CB + k * CS: CB + (k + 1) * CS]
+        assert blk[47] == 0.0
         np.testing.assert_allclose(blk[0:16].reshape(4, 4), qp["Q"][k][6:10, 6:10], atol=1e-12)
         np.testing.assert_allclose(blk[16:26], qp["q"][k], atol=1e-11)
         np.testing.assert_allclose(blk[30:36], np.diag(qp["Q"][k])[0:6], atol=1e-13)
