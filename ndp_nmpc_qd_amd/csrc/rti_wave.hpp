@@ -731,6 +731,8 @@ struct RtiWave {
             vd rdet = W::fma(e1, r1, r1);                     // 1/det: v_rcp_f64 seed + two Newton steps
             okv = okv && (det > 0.0) && (!T.lam_diag || (cof > 0.0));
             vd gs = G.r[0] * rdet;                            // Lam^-1 T
+            W::keep(hux);   // hux stays live to here: reusing its register right behind the K~' MFMA (which is still reading
+                            // it) costs a 17-cycle hazard stall per stage
             W::pin();
             vd4 Hn = W::mfma(-tt, gs, Hb);                    // - T' Lam^-1 T on top of the bracket
             for (int c = 0; c < 3; ++c) W::stp(lds, T.kt_off[c] + mb(k), Kt.r[c] * rdet, T.kt_pred);

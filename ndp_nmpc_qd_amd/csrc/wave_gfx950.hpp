@@ -33,6 +33,7 @@ struct WaveGfx950 {
     static NDP_D void stp(lds_ptr lds, vi off, vd v, vb p) { if (p) lds[off] = v; }
     static NDP_D void st(lds_ptr lds, vi off, vd v) { lds[off] = v; }
     static NDP_D void pin() { __builtin_amdgcn_sched_barrier(0); }   // instruction-scheduling fence only
+    static NDP_D void keep(vd a) { asm volatile("" ::"v"(a)); }         // extends a's live range to this point (no code)
     static NDP_D void sync()
     {   // lanes exchange data through LDS: forbid the compiler to move LDS accesses across this point
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -89,6 +89,7 @@ struct Wave {
     static void stp(double *lds, const vi &off, const vd &val, const vb &p) { stats().lds_st++; for (int l = 0; l < 64; ++l) if (p.v[l]) { chk(off.v[l]); lds[off.v[l]] = val.v[l]; } }
     static void st(double *lds, const vi &off, const vd &val) { stats().lds_st++; for (int l = 0; l < 64; ++l) { chk(off.v[l]); lds[off.v[l]] = val.v[l]; } }
     static void pin() {}
+    static void keep(const vd &) {}
     static void sync() {}
 
     // global memory
