@@ -42,6 +42,10 @@ extern "C" {
 #define NDP_QP_AUTO 0       /* exact early exit when no bound is active, else interior point */
 #define NDP_QP_IPM_ALWAYS 1 /* always run the interior-point loop (what HPIPM does) */
 
+#define NDP_PREC_F64 0
+#define NDP_PREC_F32_STUDY 1
+#define NDP_PREC_BF16_STUDY 2
+
 typedef struct ndp_cfg {
     int32_t batch;      /* B: independent OCP instances in this handle            */
     int32_t N;          /* shooting intervals        params/nmpc_params.py:9      */
@@ -50,7 +54,8 @@ typedef struct ndp_cfg {
     int32_t qp_mode;    /* NDP_QP_*                                               */
     int32_t iter_max;   /* interior-point iteration cap (acados default 50)       */
     int32_t device;     /* HIP device ordinal                                     */
-    int32_t reserved;
+    int32_t qp_precision; /* 0 = product path (fp64).  Precision study of BASELINE config 5 only: 1 / 2 round the operands of
+                           * the Riccati sweeps' matrix instructions to fp32 / bf16 and their accumulators to fp32 */
     double dt;          /* T_horizon / N_node        params/nmpc_params.py:10,12  */
     double mass;        /* params/fhnp_params.py:9   */
     double gravity;     /* params/fhnp_params.py:12  */

@@ -62,7 +62,7 @@ __device__ __forceinline__ bool gate_open(const double *other_inst, const double
 // FUSED: the wave first predicts its own instance's disturbance force (gate + MLP over the N+1 <= 32 horizon rows,
 // one 32x32 f32 MFMA tile) and leaves it in the LDS staging slot the RTI program reads f from -- no second
 // launch and no trip of f through HBM.
-template <int NSLOT, int WAVES, bool FUSED, int NC = 0>
+template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0>
 __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs bp, int B, int lds_per_wave, MlpArgs ma)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
     io.stamps = bp.stamps ? bp.stamps + (size_t)inst * 16 : nullptr;
     const int lpw = NC ? ((lds_doubles(NC) + 1) & ~1) : lds_per_wave;
     WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lpw);
-    using Prog = RtiWave<WaveGfx950, NSLOT, NC, true, NC ? 1 : 0>;   // the compile-time-horizon form is also the 1-iteration form
+    using Prog = RtiWave<WaveGfx950, NSLOT, NC, true, NC ? 1 : 0, PREC>;   // the compile-time-horizon form is also the 1-iteration form
     typename Prog::InBuf inb;
     double x0v;
     Prog::issue_first(P, io, inb, x0v);      // every global input of the RTI step is now in flight (hidden under the MLP when fused)
@@ -805,8 +805,8 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
 {
     if (!cfg || !out) { g_create_err = "ndp_create: null argument"; return -1; }
     *out = nullptr;
-    if (cfg->batch < 1 || cfg->N < 2 || slots_for(cfg->N) > 5 || cfg->n_rti < 1) {
-        g_create_err = "ndp_create: need batch >= 1, 2 <= N <= 46, n_rti >= 1";
+    if (cfg->batch < 1 || cfg->N < 2 || slots_for(cfg->N) > 5 || cfg->n_rti < 1 || cfg->qp_precision < 0 || cfg->qp_precision > 2) {
+        g_create_err = "ndp_create: need batch >= 1, 2 <= N <= 46, n_rti >= 1, qp_precision in 0..2";
         return -2;
     }
     int ndev = 0;
@@ -863,7 +863,8 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     const void *fns[] = {(const void *)rti_kernel<3, 4, false>, (const void *)rti_kernel<3, 2, false>, (const void *)rti_kernel<3, 1, false>,
                          (const void *)rti_kernel<5, 4, false>, (const void *)rti_kernel<5, 2, false>, (const void *)rti_kernel<5, 1, false>,
                          (const void *)rti_kernel<3, 4, true>, (const void *)rti_kernel<3, 2, true>, (const void *)rti_kernel<3, 1, true>,
-                         (const void *)rti_kernel<3, 4, false, 20>, (const void *)rti_kernel<3, 4, true, 20>};
+                         (const void *)rti_kernel<3, 4, false, 20>, (const void *)rti_kernel<3, 4, true, 20>,
+                         (const void *)rti_kernel<5, 1, false, 0, 1>, (const void *)rti_kernel<5, 1, false, 0, 2>};
     if ((e = hipFuncSetAttribute((const void *)mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(FR_TOTAL * sizeof(float)))) != hipSuccess)
         return fail("hipFuncSetAttribute(mlp_kernel)", e);
@@ -936,6 +937,14 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     const int ns = slots_for(h->cfg.N);
     int rc = begin_timing(h, s, 0);
     if (rc) return rc;
+    if (h->cfg.qp_precision) {      // precision study (BASELINE config 5): one wave per workgroup, unfused, any horizon
+        if (d_other) { h->err = "qp_precision != 0 supports f / no disturbance only (run ndp_downwash first)"; return -12; }
+        const size_t shm1 = (size_t)h->lds_per_wave * sizeof(double);
+        if (h->cfg.qp_precision == 1) hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 1>), dim3(B), dim3(64), shm1, s, h->P, bp, B, h->lds_per_wave, ma);
+        else hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 2>), dim3(B), dim3(64), shm1, s, h->P, bp, B, h->lds_per_wave, ma);
+        NDP_HIP(h, hipGetLastError());
+        return end_timing(h, s);
+    }
 #define LAUNCH(NS, WV, FU) hipLaunchKernelGGL((rti_kernel<NS, WV, FU>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma)
     if (h->cfg.N == 20 && h->cfg.n_rti == 1 && W == 4) {   // the reference configuration (params/nmpc_params.py:9, 1 RTI iteration): compile-time instantiation
         if (d_other) hipLaunchKernelGGL((rti_kernel<3, 4, true, 20>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma);
@@ -951,7 +960,7 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
 // downwash inside the RTI launch when one 32-row tile covers the horizon; otherwise mlp_kernel first
 static bool can_fuse(const ndp_handle *h)
 {
-    return h->cfg.N + 1 <= 32 && slots_for(h->cfg.N) <= 3 &&
+    return h->cfg.qp_precision == 0 && h->cfg.N + 1 <= 32 && slots_for(h->cfg.N) <= 3 &&
            (size_t)h->lds_per_wave * sizeof(double) * h->waves >= FR_TOTAL * sizeof(float);
 }
 

@@ -143,10 +143,20 @@ NDP_HD void fill_kc(const RtiParams &P, double *kc)
 // VALU instructions per launch.
 // NR > 0: compile-time number of RTI iterations per step (NR = 1 removes the iteration loop, which otherwise makes the
 // compiler hoist every address computation of the loop body in front of it and spill them).
-template <class W, int NSLOT, int NC = 0, bool HT = false, int NR = 0>
+// PREC: precision study of BASELINE config 5 (0 = the product path).  1 / 2 round every operand of every matrix
+// instruction of the Riccati sweeps to fp32 / bf16 and every accumulator to fp32 after each instruction -- the numbers
+// a sweep on v_mfma_f32_16x16x4_f32 / a bf16-input MFMA with fp32 accumulation would see; everything else stays f64.
+template <class W, int NSLOT, int NC = 0, bool HT = false, int NR = 0, int PREC = 0>
 struct RtiWave {
     static NDP_D int horizon(const RtiParams &P) { return NC ? NC : P.N; }
     static constexpr int UNROLL_STAGES = NC > 0 ? NC : 1;
+    static NDP_D typename W::vd4 mma(typename W::vd a, typename W::vd b, const typename W::vd4 &c)
+    {
+        if (PREC == 0) return W::mfma(a, b, c);
+        typename W::vd4 d = W::mfma(W::round_op(a, PREC), W::round_op(b, PREC), c);
+        for (int r = 0; r < 4; ++r) d.r[r] = W::round_op(d.r[r], 1);
+        return d;
+    }
     static NDP_D int mb(int k) { return k * int(MB_STRIDE); }   // stage offsets (immediates once the stage loops are unrolled)
     static NDP_D int cb(int k) { return k * int(CB_STRIDE); }
     using vd = typename W::vd;
@@ -665,8 +675,8 @@ struct RtiWave {
             for (int c = 0; c < 3; ++c) mk[c] = W::ld(lds, T.mk_off[c] + mb(N - 1));
             for (int r = 0; r < 4; ++r) H.r[r] = W::ld(lds, T.c_off[r] + cb(N - 1));
             vd4 Wm = W::zero4();
-            for (int c = 0; c < 3; ++c) Wm = W::mfma(Pt.r[c], mk[c], Wm);
-            for (int c = 0; c < 3; ++c) H = W::mfma(mk[c], Wm.r[c], H);
+            for (int c = 0; c < 3; ++c) Wm = mma(Pt.r[c], mk[c], Wm);
+            for (int c = 0; c < 3; ++c) H = mma(mk[c], Wm.r[c], H);
         }
         vd mk[3], cc[4];       // operands of the NEXT stage to be formed (k-1), requested one iteration ahead
         {
@@ -694,7 +704,7 @@ struct RtiWave {
             lam_gather(T, lds, hux, LR);
             W::pin();
             vd4 Wf = W::zero4();
-            for (int c = 0; c < 3; ++c) Wf = W::mfma(H.r[c], mk[c], Wf);
+            for (int c = 0; c < 3; ++c) Wf = mma(H.r[c], mk[c], Wf);
             W::pin();
             const vd *mm = LR.mm;
             vd d0 = mm[4] * mm[8] - mm[5] * mm[7];
@@ -703,29 +713,29 @@ struct RtiWave {
             W::pin();
             vd4 Hb;
             for (int r = 0; r < 4; ++r) Hb.r[r] = cc[r];
-            Hb = W::mfma(mk[0], Wf.r[0], Hb);
+            Hb = mma(mk[0], Wf.r[0], Hb);
             W::pin();
             vd cof = (mm[0] * d0 - mm[1] * d1 + mm[2] * d2) * T.cof_sign;
             W::pin();
-            Hb = W::mfma(mk[1], Wf.r[1], Hb);
+            Hb = mma(mk[1], Wf.r[1], Hb);
             W::pin();
             vd dq = LR.own * cof;                             // row expansion of det: lanes 16g..16g+3 form one quad
             dq = dq + W::quad_swap1(dq);
             vd ladj = W::sel(T.lo4, cof, vd(0.0));            // A operand: adj[g][j], j < 4
             vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));       // B operand of K~': -adj[g][j-12] in columns 12..15
             W::pin();
-            Hb = W::mfma(mk[2], Wf.r[2], Hb);
+            Hb = mma(mk[2], Wf.r[2], Hb);
             W::pin();
             vd det = dq + W::quad_swap2(dq);
             vd r0 = W::rcp_seed(det);
             W::pin();
             vd tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
-            vd4 G = W::mfma(ladj, tt, W::zero4());            // adj T
+            vd4 G = mma(ladj, tt, W::zero4());            // adj T
             W::pin();
             vd e0 = W::fma(-det, r0, vd(1.0));
             vd r1 = W::fma(e0, r0, r0);
             W::pin();
-            vd4 Kt = W::mfma(hux, nahi, W::zero4());          // det * K~'[i][b], lands in column 12+b (rows 12..15 of the forward operand)
+            vd4 Kt = mma(hux, nahi, W::zero4());          // det * K~'[i][b], lands in column 12+b (rows 12..15 of the forward operand)
             W::pin();
             vd e1 = W::fma(-det, r1, vd(1.0));
             vd rdet = W::fma(e1, r1, r1);                     // 1/det: v_rcp_f64 seed + two Newton steps
@@ -734,14 +744,14 @@ struct RtiWave {
             W::keep(hux);   // hux stays live to here: reusing its register right behind the K~' MFMA (which is still reading
                             // it) costs a 17-cycle hazard stall per stage
             W::pin();
-            vd4 Hn = W::mfma(-tt, gs, Hb);                    // - T' Lam^-1 T on top of the bracket
+            vd4 Hn = mma(-tt, gs, Hb);                    // - T' Lam^-1 T on top of the bracket
             for (int c = 0; c < 3; ++c) W::stp(lds, T.kt_off[c] + mb(k), Kt.r[c] * rdet, T.kt_pred);
             if ((k & 3) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
                 // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
                 // re-symmetrise every 4th stage.  H~' = (H~ as A operand) x I costs four MFMAs, no LDS.
                 vd4 Tp = W::zero4();
-                for (int c = 0; c < 4; ++c) Tp = W::mfma(Hn.r[c], T.eye[c], Tp);
+                for (int c = 0; c < 4; ++c) Tp = mma(Hn.r[c], T.eye[c], Tp);
                 for (int r = 0; r < 4; ++r) Hn.r[r] = (Hn.r[r] + Tp.r[r]) * 0.5;
             }
             H = Hn;
@@ -755,7 +765,7 @@ struct RtiWave {
             vd cof = lam_cofactor(T, LR);
             vd rdet = lam_rdet(T, LR, cof, ok);
             vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));
-            vd4 Kt = W::mfma(hux, nahi, W::zero4());
+            vd4 Kt = mma(hux, nahi, W::zero4());
             for (int c = 0; c < 3; ++c) W::stp(lds, T.kt_off[c], Kt.r[c] * rdet, T.kt_pred);
         }
         ok = W::all(okv) && ok;
@@ -781,11 +791,11 @@ struct RtiWave {
             nmu = W::ld(lds, T.mu_off + mb(kn));
             W::pin();   // keep the prefetch ahead of this stage's MFMAs (the scheduler otherwise sinks it behind them)
             vd4 Y = W::zero4();
-            Y = W::mfma(fw[0], zc[0], Y);
-            Y = W::mfma(fw[1], zc[1], Y);
-            Y = W::mfma(fw[2], zc[2], Y);
+            Y = mma(fw[0], zc[0], Y);
+            Y = mma(fw[1], zc[1], Y);
+            Y = mma(fw[2], zc[2], Y);
             vd du = Y.r[3];
-            vd4 xn = W::mfma(mu, du, Y);
+            vd4 xn = mma(mu, du, Y);
             W::stp(lds, T.zu_off + k * int(NU), du, T.col0);
             for (int c = 0; c < 3; ++c) {
                 zc[c] = xn.r[c];

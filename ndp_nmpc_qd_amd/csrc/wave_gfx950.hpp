@@ -59,6 +59,17 @@ struct WaveGfx950 {
         r = __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
         return r;
     }
+    // precision study: x rounded to fp32 (mode 1) or bf16 (mode 2), round-to-nearest-even, returned as a double
+    static NDP_D vd round_op(vd x, int mode)
+    {
+        float f = (float)x;
+        if (mode == 2) {
+            unsigned u = __float_as_uint(f);
+            u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+            f = __uint_as_float(u);
+        }
+        return (double)f;
+    }
     // the pieces of rcp / quad_sum, for callers that interleave them with matrix instructions
     static NDP_D vd rcp_seed(vd a) { return __builtin_amdgcn_rcp(a); }
     static NDP_D vd fma(vd a, vd b, vd c) { return __builtin_fma(a, b, c); }

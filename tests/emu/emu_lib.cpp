@@ -31,7 +31,9 @@ int emu_rti_step(const ndp_cfg *cfg, const double *x0, const double *xr, const d
     const int ns = ndp::slots_for(P.N);
     // horizon 20 and the 5-slot form run as the product does (host-built tables; N = 20 also compile-time horizon);
     // the other horizons build the tables in the wave program
-    if (P.N == 20 && P.n_rti == 1) ndp::RtiWave<emu::Wave, 3, 20, true, 1>::run(P, io, lds.data());
+    if (cfg->qp_precision == 1) ndp::RtiWave<emu::Wave, 5, 0, true, 0, 1>::run(P, io, lds.data());
+    else if (cfg->qp_precision == 2) ndp::RtiWave<emu::Wave, 5, 0, true, 0, 2>::run(P, io, lds.data());
+    else if (P.N == 20 && P.n_rti == 1) ndp::RtiWave<emu::Wave, 3, 20, true, 1>::run(P, io, lds.data());
     else if (ns <= 3) ndp::RtiWave<emu::Wave, 3>::run(P, io, lds.data());
     else if (ns <= 5) ndp::RtiWave<emu::Wave, 5, 0, true>::run(P, io, lds.data());
     else return -1;

@@ -105,6 +105,20 @@ struct Wave {
     static vd clock() { return vd(0.0); }
     static vd clock_after(const vd &) { return vd(0.0); }
     static vd rcp(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = 1.0 / a.v[l]; return o; }
+    static vd round_op(const vd &x, int mode)
+    {
+        vd o;
+        for (int l = 0; l < 64; ++l) {
+            float f = (float)x.v[l];
+            if (mode == 2) {
+                unsigned u; std::memcpy(&u, &f, 4);
+                u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+                std::memcpy(&f, &u, 4);
+            }
+            o.v[l] = (double)f;
+        }
+        return o;
+    }
     static vd rcp_seed(const vd &a) { return rcp(a); }
     static vd fma(const vd &a, const vd &b, const vd &c) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = std::fma(a.v[l], b.v[l], c.v[l]); return o; }
     static vd quad_swap1(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[l ^ 1]; return o; }

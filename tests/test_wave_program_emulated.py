@@ -180,3 +180,25 @@ def test_qp_failure_status(oracle):
     X, U = b["xr"][0].copy(), b["ur"][0].copy()
     u0, st, it, *_ = E.rti_step(cfg, b["x0"][0], b["xr"][0], b["ur"][0], None, X, U)
     assert st in (1, 4) and it == 15
+
+
+def test_config5_precision_study_modes(oracle):
+    """BASELINE config 5 (fp32 vs bf16 matrix instructions on the QP solve): qp_precision 1 / 2 round every operand of
+    the sweeps' matrix instructions to fp32 / bf16 and the accumulators to fp32.  Without active bounds the fp32 sweep
+    stays inside the 1e-5 bar, the bf16 sweep does not -- which is why the product path is fp64 and has no bf16 mode."""
+    b = synth.make_batch(8, N=40, seed=11)
+    cfgo = oracle.default_cfg(N=40, n_rti=2)
+    Xo, Uo = b["xr"].copy(), b["ur"].copy()
+    uo, sto, ito = oracle.step_batch(cfgo, b["x0"], b["xr"], b["ur"], None, Xo, Uo)
+    worst = {}
+    for prec in (0, 1, 2):
+        errs = []
+        for i in range(8):
+            cfg = E.default_cfg(N=40, n_rti=2)
+            cfg.qp_precision = prec
+            X, U = b["xr"][i].copy(), b["ur"][i].copy()
+            u0, st, it, *_ = E.rti_step(cfg, b["x0"][i], b["xr"][i], b["ur"][i], None, X, U)
+            assert st == 0
+            errs.append(np.max(np.abs(u0 - uo[i]) / np.maximum(1.0, np.abs(uo[i]))))
+        worst[prec] = max(errs)
+    assert worst[0] < 1e-8 and worst[1] < 1e-5 and 1e-4 < worst[2] < 0.5, worst
