@@ -35,6 +35,24 @@ def exchange_neighbours(xr_local, gathered=None, group=None):
     return gathered[neighbour_rank(rank, world)], gathered
 
 
+def exchange_neighbours_begin(xr_local, gathered, group=None):
+    """Starts the all-gather of exchange_neighbours without waiting for it (async_op): with RCCL it runs on the
+    process group's own stream, ordered after everything already enqueued on the current stream, so a control-step
+    kernel launched next on the current stream overlaps it.  The reference windows are functions of time only
+    (trajectory generator output), so the windows of tick i+1 can be gathered while tick i is being solved.
+    Returns the work handle for exchange_neighbours_end."""
+    import torch.distributed as dist
+    return dist.all_gather_into_tensor(gathered.view(-1), xr_local.reshape(-1), group=group, async_op=True)
+
+
+def exchange_neighbours_end(work, gathered, group=None):
+    """Makes the current stream (RCCL) / the caller (gloo) wait for the gather started by exchange_neighbours_begin and
+    returns the neighbour windows: a view of `gathered`, the slice of rank (r+1) % W."""
+    import torch.distributed as dist
+    work.wait()
+    return gathered[neighbour_rank(dist.get_rank(group), dist.get_world_size(group))]
+
+
 def make_formation_shard(B_local, rank, world, N=20, seed=synth.SEED0 + 4, t0=0.0):
     """Synthetic formation data for one rank (vehicle-major placement).
 

@@ -156,6 +156,13 @@ def _worker(rank, world, port, q):
         ok = ok and np.array_equal(gathered[rank].numpy(), shard["xr"])
         other2, g2 = ndist.exchange_neighbours(xr, gathered)                # steady state: reuse the gather buffer
         ok = ok and g2.data_ptr() == gathered.data_ptr() and np.array_equal(other2.numpy(), shard["other"])
+        # split form used by bench.py: the gather of the next tick is started before the current tick is solved
+        nxt = ndist.make_formation_shard(B, rank, world, N=N, t0=0.02)
+        buf2 = torch.empty_like(gathered)
+        work = ndist.exchange_neighbours_begin(torch.from_numpy(nxt["xr"]), buf2)
+        ok = ok and np.array_equal(other2.numpy(), shard["other"])          # the current tick's windows are untouched meanwhile
+        other3 = ndist.exchange_neighbours_end(work, buf2)
+        ok = ok and np.array_equal(other3.numpy(), nxt["other"]) and other3.data_ptr() == buf2[(rank + 1) % world].data_ptr()
         # the gate statistic of the synthetic formation: a sensible fraction of neighbours inside r_horiz
         d2 = ((shard["other"][:, 0, 0:2] - shard["ego_xy"]) ** 2).sum(axis=1)
         q.put((rank, bool(ok), float((d2 < 1.0).mean())))
