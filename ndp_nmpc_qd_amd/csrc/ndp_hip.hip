@@ -597,7 +597,7 @@ __device__ __forceinline__ double poly_eval(const double *__restrict__ c, const 
         for (int j = 0; j < D; ++j) f *= (double)(i - j);
         acc += f * tp[i - D] * c[i];
     }
-    return acc / inv_scale_den;      // one division per quantity (the reference divides every term: same value to ~1 ulp)
+    return acc * inv_scale_den;      // one scale per quantity (the reference divides every term by tseg^d: same value to ~1 ulp)
 }
 
 #define REF_ROWS 64     // rows (vehicle, node) per workgroup = one wave: small batches spread over all CUs
@@ -626,13 +626,14 @@ __global__ __launch_bounds__(REF_ROWS) void ref_window_kernel(RefCfg cf, const d
         while (idx < cf.n_seg && !(tc[idx] > t)) ++idx;
         idx = idx > 0 ? idx - 1 : 0;
         const double ts_ = tseg[(size_t)b * cf.n_seg + idx];
-        const double s = (t - tc[idx]) / ts_;             // :102-103
         const double *c = coeff + ((size_t)b * cf.n_seg + idx) * 28;
         double tp[8], sc[4];
         tp[0] = 1.0;
+        sc[0] = 1.0; sc[1] = 1.0 / ts_; sc[2] = sc[1] * sc[1]; sc[3] = sc[2] * sc[1];   // 1 / tseg^d: one divide per row
+        // (an f64 divide is ~30 VALU instructions here; the row had 23 of them, now 6)
+        const double s = (t - tc[idx]) * sc[1];           // :102-103
 #pragma unroll
         for (int i = 1; i < 8; ++i) tp[i] = tp[i - 1] * s;
-        sc[0] = 1.0; sc[1] = ts_; sc[2] = ts_ * ts_; sc[3] = sc[2] * ts_;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             pvaj[a] = poly_eval<8, 0>(c + 8 * a, tp, sc[0]);
@@ -646,19 +647,21 @@ __global__ __launch_bounds__(REF_ROWS) void ref_window_kernel(RefCfg cf, const d
     // differential flatness (pt_publisher.py:188-248)
     const double td[3] = {pvaj[6], pvaj[7], pvaj[8] + cf.g};
     const double tn = sqrt(td[0] * td[0] + td[1] * td[1] + td[2] * td[2]);
-    const double zb[3] = {td[0] / tn, td[1] / tn, td[2] / tn};
+    const double rtn = 1.0 / tn;
+    const double zb[3] = {td[0] * rtn, td[1] * rtn, td[2] * rtn};
     const double u1 = tn * cf.mass;
     double sy, cy;
     sincos(yaw, &sy, &cy);
     const double xc[3] = {cy, sy, 0.0};
     const double zx[3] = {zb[1] * xc[2] - zb[2] * xc[1], zb[2] * xc[0] - zb[0] * xc[2], zb[0] * xc[1] - zb[1] * xc[0]};
     const double nzx = sqrt(zx[0] * zx[0] + zx[1] * zx[1] + zx[2] * zx[2]);
-    const double yb[3] = {zx[0] / nzx, zx[1] / nzx, zx[2] / nzx};
+    const double rnzx = 1.0 / nzx;
+    const double yb[3] = {zx[0] * rnzx, zx[1] * rnzx, zx[2] * rnzx};
     const double xb[3] = {yb[1] * zb[2] - yb[2] * zb[1], yb[2] * zb[0] - yb[0] * zb[2], yb[0] * zb[1] - yb[1] * zb[0]};
     const double zj = zb[0] * pvaj[9] + zb[1] * pvaj[10] + zb[2] * pvaj[11];
     double ho[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) ho[i] = (cf.mass / u1) * (pvaj[9 + i] - zj * zb[i]);
+    for (int i = 0; i < 3; ++i) ho[i] = rtn * (pvaj[9 + i] - zj * zb[i]);      // mass / u1 = 1 / |t_des|
     const double wp = -(ho[0] * yb[0] + ho[1] * yb[1] + ho[2] * yb[2]);
     const double wq = ho[0] * xb[0] + ho[1] * xb[1] + ho[2] * xb[2];
     const double wr = yawd * zb[2];
