@@ -12,7 +12,7 @@
 // Control flow is wave-uniform everywhere; per-lane decisions are selects / predicated stores.
 //
 // Design:
-//  * everything of one instance lives in that wave's LDS slice (~38 KB at N=20) for the whole step;
+//  * everything of one instance lives in that wave's LDS slice (37 KB at N=20) for the whole step;
 //  * linearisation (RK4 + forward sensitivities) is lane-parallel over (stage, sensitivity column);
 //  * the Riccati recursion runs in homogeneous coordinates z~ = [x(10), 1, 0, u(4)] so that one
 //    16x16 f64 MFMA tile carries the Hessian AND the gradient: per stage
@@ -656,9 +656,9 @@ struct RtiWave {
     // backward: H~_k = M~_k' P~_{k+1} M~_k + C~_k with P~_{k+1} = H~xx - H~xu Lam^-1 H~ux of stage k+1, P~_N = C~_N.
     // P~ is never formed: the next stage needs only W' = P~ M~' = H~xx M~' - H~xu (Lam^-1 (H~ux M~')), and
     // [H~xx ; H~ux] M~' is ONE product (the accumulator registers of H~ as A operand), which does not depend on
-    // Lam^-1 -- its three MFMAs run on the matrix pipe while the VALU inverts Lam.  Stores K~' per stage.
+    // Lam^-1 -- only two dependent MFMAs follow the inverse.  Stores K~' per stage.
     // forward: z~_0 = [dx0,1,0]; du = K~ z~; z~+ = M~ [z~; du].  Writes ZX[1..N], ZU[0..N-1].
-    // The LDS operands of the next stage are requested one stage ahead, so their latency hides under the MFMA chain.
+    // The LDS operands of the next stage are requested one stage ahead, so the LDS latency is paid while the MFMA chain runs (LDS, unlike the wave's own VALU work, does proceed under it).
     static NDP_D bool riccati_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, lp lds,
                                     const RtiIo *io = nullptr)
     {
