@@ -65,6 +65,8 @@ typedef struct ndp_cfg {
     double lbu[4], ubu[4]; /* nmpc_body_rate_ctl.py:56-58 */
     double lbv[3], ubv[3]; /* nmpc_body_rate_ctl.py:59-61 (stages 1..N-1) */
     double mu0, thr0, tol, tau; /* interior-point constants */
+    double auto_margin;         /* NDP_QP_AUTO accepts the equality-constrained minimiser only if it is this far inside every
+                                 * bound (default 0.1); closer to a bound the interior-point loop runs, as in the reference */
 } ndp_cfg;
 
 typedef struct ndp_handle ndp_handle;

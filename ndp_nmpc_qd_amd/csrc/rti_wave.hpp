@@ -61,7 +61,7 @@ struct RtiParams {
     int N, n_rti, use_fd, qp_mode, iter_max;
     double dt, inv_mass, g;
     double Qd[10], Rd[4], lbu[4], ubu[4], lbv[3], ubv[3];
-    double mu0, thr0, tol, tau;
+    double mu0, thr0, tol, tau, auto_margin;
     // host-evaluated quotients (an f64 divide is a ~30-instruction VALU sequence on the device, even for uniforms)
     double h_6, h2_6, h4_24, h3_6, h4_12, two_over_h2, inv2m;
 };
@@ -845,12 +845,17 @@ struct RtiWave {
         }
     }
 
-    static NDP_D bool strictly_inside(const Slots &S, lp lds)
+    // Inside the box by at least `margin` on every bounded variable.  The margin is what keeps QP_AUTO within ~1e-6 of an
+    // interior-point solve stopped at mu <= tol (HPIPM, the oracle): at a slack t the barrier leaves a multiplier mu / t
+    // on an INACTIVE bound, which moves the solution by ~mu / (t * weight); with tol = 1e-8 and t >= 0.1 (the default) that is below
+    // 1e-6, whereas a minimiser 1e-4 inside a bound differs from the interior-point answer by 1e-4 -- such instances
+    // take the interior-point loop like the reference does.
+    static NDP_D bool strictly_inside(const Slots &S, lp lds, double margin)
     {
         vb okv = W::lane() >= 0;
         for (int s = 0; s < NSLOT; ++s) {
             vd z = W::ld(lds, S.zoff[s]);
-            okv = okv && (!S.valid[s] || ((z > S.lo[s]) && (z < S.hi[s])));
+            okv = okv && (!S.valid[s] || ((z > S.lo[s] + margin) && (z < S.hi[s] - margin)));
         }
         return W::all(okv);
     }
@@ -1066,7 +1071,7 @@ struct RtiWave {
                 Slots S;
                 build_slots(P, m, S);
                 load_bounds(m, S, lds);
-                done = strictly_inside(S, lds) || !ok;
+                done = strictly_inside(S, lds, P.auto_margin) || !ok;
                 if (done) {
                     for (int t = 0; t < nzx + nzu; t += 64) {
                         vi i = lane + t;

@@ -1,0 +1,30 @@
+import sys; sys.path.insert(0,'.')
+import numpy as np
+import ndp_nmpc_qd_amd as ndp
+from ndp_nmpc_qd_amd import synth
+from oracle import oracle as O
+O.build()
+worst=0
+for seed,kw,dw in ((1,{},True),(2,dict(pos_sigma=0.5,vel_sigma=1.0,quat_sigma=0.15),True),(3,dict(omega_range=(1.5,2.5)),False),(4,dict(pos_sigma=1.0,vel_sigma=2.0,quat_sigma=0.3),False)):
+    B=1536
+    b=synth.make_batch(B, seed=seed, downwash=dw, **kw)
+    eng=ndp.BatchedNMPC(B, disturbance=dw)
+    cfg=O.default_cfg(use_fd=dw)
+    eng.reset(b["xr"], b["ur"])
+    X,U=b["xr"].copy(), b["ur"].copy()
+    blob=np.fromfile("ndp_nmpc_qd_amd/weights/downwash_sn4.bin",dtype="<f4")
+    for tick in range(3):
+        f=None
+        if dw:
+            u0=eng.update(b["x0"],b["xr"],b["ur"],other=b["other"],ego_xy=b["ego_xy"],raise_on_status=False)
+            f=O.downwash_batch(blob,b["other"],b["xr"],b["ego_xy"])
+        else:
+            u0=eng.update(b["x0"],b["xr"],b["ur"],raise_on_status=False)
+        uo,sto,ito=O.step_batch(cfg,b["x0"],b["xr"],b["ur"],f,X,U)
+        st,it=eng.status()
+        ok = (sto==0)&(st==0)
+        err=np.abs(u0-uo)/np.maximum(1,np.abs(uo))
+        e=err[ok].max()
+        worst=max(worst,e)
+        print(seed,tick,"max rel err",e,"ipm instances",(it>0).sum(),"status dev",np.bincount(st,minlength=5)[:5],"oracle",np.bincount(sto,minlength=5)[:5], "status mismatch", (st!=sto).sum())
+print("worst",worst)

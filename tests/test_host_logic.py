@@ -43,7 +43,8 @@ def test_default_cfg_carries_the_reference_constants():
     assert list(cfg.lbu) == [CP.w_min] * 3 + [CP.c_min] and list(cfg.ubu) == [CP.w_max] * 3 + [CP.c_max]
     assert list(cfg.lbv) == [CP.v_min] * 3 and list(cfg.ubv) == [CP.v_max] * 3
     assert CP.c_max == 9.81 / 0.36
-    assert C.sizeof(_lib.NdpCfg) == 8 * 4 + 8 * (4 + 10 + 4 + 4 + 4 + 3 + 3 + 4)
+    assert C.sizeof(_lib.NdpCfg) == 8 * 4 + 8 * (4 + 10 + 4 + 4 + 4 + 3 + 3 + 5)
+    assert cfg.auto_margin == 0.1 and cfg.qp_precision == 0
     # horizon indexing of the reference generator (nmpc_params.py:40-43): 21 states / 20 controls out of 101
     assert CP.long_list_size == 101 and list(range(101))[CP.xr_list_index] == list(range(0, 101, 5))
 
