@@ -202,3 +202,24 @@ def test_config5_precision_study_modes(oracle):
             errs.append(np.max(np.abs(u0 - uo[i]) / np.maximum(1.0, np.abs(uo[i]))))
         worst[prec] = max(errs)
     assert worst[0] < 1e-8 and worst[1] < 1e-5 and 1e-4 < worst[2] < 0.5, worst
+
+
+def test_auto_margin_switches_between_early_exit_and_interior_point(oracle):
+    """auto_margin = 0: strictly-inside minimisers leave early (0 interior-point iterations); a margin wider than the box
+    forces the loop, which then reproduces the always-interior-point oracle iteration for iteration."""
+    b = synth.make_batch(1, seed=7)
+    cfgo = oracle.default_cfg()
+    Xo, Uo = b["xr"].copy(), b["ur"].copy()
+    uo, sto, ito = oracle.step_batch(cfgo, b["x0"], b["xr"], b["ur"], None, Xo, Uo)
+    res = {}
+    for margin in (0.0, 0.1, 100.0):
+        cfg = E.default_cfg()
+        cfg.auto_margin = margin
+        X, U = b["xr"][0].copy(), b["ur"][0].copy()
+        u0, st, it, *_ = E.rti_step(cfg, b["x0"][0], b["xr"][0], b["ur"][0], None, X, U)
+        assert st == 0
+        res[margin] = (u0, it)
+    assert res[0.0][1] == 0 and res[0.1][1] == 0 and res[100.0][1] == ito[0] > 0
+    np.testing.assert_allclose(res[100.0][0], uo[0], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(res[0.0][0], uo[0], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(res[0.0][0], res[0.1][0])
