@@ -439,3 +439,20 @@ def test_auto_mode_against_the_interior_point_oracle_under_large_perturbations(n
                 err = (np.abs(u0 - uo) / np.maximum(1.0, np.abs(uo))).max(axis=1)[ok]
                 assert err.max() < bar and (err > 1e-5).mean() < 0.01
             assert n_ipm > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [5, 12, 27, 31, 40])
+def test_downwash_step_at_other_horizons(ndp, oracle, mlp_blob, N):
+    """The gate + MLP + NDP step away from the reference horizon: N <= 27 takes the fused launch of the run-time-horizon
+    kernel (2 or 4 instances per workgroup), N = 31 the two-launch form (its 214 box constraints need the 5-slot kernel),
+    N = 40 the multi-tile standalone MLP kernel; a ragged batch size on top."""
+    B = 37
+    b = synth.make_batch(B, N=N, seed=100 + N, downwash=True)
+    eng = ndp.BatchedNMPC(B, N=N, disturbance=True)
+    eng.reset(b["xr"], b["ur"])
+    u0 = eng.update(b["x0"], b["xr"], b["ur"], other=b["other"], ego_xy=b["ego_xy"])
+    f_or = oracle.downwash_batch(mlp_blob, b["other"], b["xr"], b["ego_xy"])
+    assert 0 < (np.abs(f_or).max(axis=(1, 2)) > 0).sum() < B
+    u0o, *_ = _oracle_batch(oracle, b, N=N, use_fd=True, f=f_or)
+    _assert_u(u0, u0o, 2e-6)
