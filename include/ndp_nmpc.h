@@ -176,6 +176,12 @@ int ndp_ref_window_device(ndp_handle *h, const void *d_t, void *d_xr, void *d_ur
  * x[B][10] in/out, u[B][4], f[B][3] force or NULL; RK4 with `substeps` over dt, quaternion renormalised. */
 int ndp_plant_step(ndp_handle *h, double *x, const double *u, const double *f, double dt, int substeps);
 int ndp_plant_step_device(ndp_handle *h, void *d_x, const void *d_u, const void *d_f, double dt, int substeps, void *stream);
+/* Closed-loop rollout of every instance on the device (what nmpc_node.py's control timer + a simulator would do tick by
+ * tick): reset at the trajectory's window at t0, then for k = 0..ticks-1: reference window at t0 + k*dt_tick
+ * (ndp_ref_set_trajectory must have been called) -> control step from the plant state -> plant step with u0.
+ * d_x[B][10] plant state in/out; d_log[ticks][B][10] receives the state after every tick, or NULL.  3 launches per tick
+ * enqueued back to back on the stream; nothing returns to the host in between, nothing is synchronised. */
+int ndp_rollout_device(ndp_handle *h, int ticks, double t0, double dt_tick, int substeps, void *d_x, void *d_log, void *stream);
 
 /* Test hook: number of doubles of the LDS image dump, and a step that also dumps it (B = 1 use). */
 int ndp_debug_lds_doubles(int N);

@@ -36,7 +36,7 @@ EXPORTS = [
     "ndp_synchronize", "ndp_timing_enable", "ndp_timing_read", "ndp_debug_lds_doubles", "ndp_step_debug", "ndp_debug_mfma_probe", "ndp_debug_stamps", "ndp_debug_lds_layout", "ndp_throttle_reset", "ndp_throttle_update",
     "ndp_throttle_update_device", "ndp_actuator_cmd", "ndp_actuator_cmd_device", "ndp_throttle_get_state", "ndp_relay_reset", "ndp_relay_formation",
     "ndp_relay_reference", "ndp_relay_reference_device", "ndp_plant_step", "ndp_plant_step_device",
-    "ndp_ref_set_trajectory", "ndp_ref_window", "ndp_ref_window_device",
+    "ndp_ref_set_trajectory", "ndp_ref_window", "ndp_ref_window_device", "ndp_rollout_device",
 ]
 
 _lib = None
@@ -98,6 +98,7 @@ def load():
     lib.ndp_ref_set_trajectory.argtypes = [vp, C.c_int] + [vp] * 7
     lib.ndp_ref_window.argtypes = [vp] * 4
     lib.ndp_ref_window_device.argtypes = [vp] * 5
+    lib.ndp_rollout_device.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp, vp]
     lib.ndp_plant_step.argtypes = [vp, vp, vp, vp, C.c_double, C.c_int]
     lib.ndp_plant_step_device.argtypes = [vp, vp, vp, vp, C.c_double, C.c_int, vp]
     _lib = lib

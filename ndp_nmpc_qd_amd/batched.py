@@ -184,6 +184,14 @@ class BatchedNMPC:
                     "ndp_plant_step")
         return x
 
+    def rollout_device(self, ticks, x, log=None, t0=0.0, dt=CP.ts_nmpc, substeps=4, stream=None):
+        """Closed loop on the device: reference window -> control step -> plant step, `ticks` times, enqueued on `stream`.
+        x[B,10] (CUDA tensor) is the plant state, updated in place; log[ticks,B,10] (optional) receives every state."""
+        import torch
+        self._check(self._lib.ndp_rollout_device(
+            self._h, int(ticks), float(t0), float(dt), int(substeps), self._dptr(x, torch.float64, (self.B, 10)),
+            self._dptr(log, torch.float64, (int(ticks), self.B, 10)), self._stream(stream)), "ndp_rollout_device")
+
     def get_iterate(self):
         X = np.empty((self.B, self.N + 1, 10))
         U = np.empty((self.B, self.N, 4))

@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void plant_kernel(double *__restrict__ x, cons
 // what NMPCRefPublisher.get_nmpc_pts returns (pt_pub/pt_publisher.py:79-103, base_pt_publisher.py:81-133,
 // diff_flatness :188-248, traj_full_pt_2_x_u :115-146).  One thread per (vehicle, node): reads its segment's 28
 // coefficients (224 contiguous bytes, shared by the neighbouring nodes of the vehicle), writes 80 + 32 contiguous bytes.
-struct RefCfg { int B, N, n_seg; double dt, mass, g; };
+struct RefCfg { int B, N, n_seg; double dt, mass, g, toff; };   // toff: added to every vehicle's node-0 time (rollouts)
 
 // sum_i [i (i-1) .. (i-d+1) t^(i-d)] / tseg^d * c[i]  (get_poly_params + _get_output_value), powers by repeated products
 template <int NC_, int D>
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(REF_ROWS) void ref_window_kernel(RefCfg cf, const d
     const int np1 = cf.N + 1, nrows = cf.B * np1;
     const int row = row0 + lane < nrows ? row0 + lane : nrows - 1;      // tail lanes recompute the last row, never store
     const int b = row / np1, k = row - b * np1;
-    const double t = tq[b] + k * cf.dt;
+    const double t = (tq ? tq[b] : 0.0) + cf.toff + k * cf.dt;
     const double *tc = tcum + (size_t)b * (cf.n_seg + 1);
     double pvaj[12], yaw = 0.0, yawd = 0.0;
 #pragma unroll
@@ -1326,21 +1326,27 @@ int ndp_ref_set_trajectory(ndp_handle *h, int n_seg, const double *coeff_x, cons
     return 0;
 }
 
+// enqueue helper (no locking): windows at node-0 times d_t[b] (or 0 when null) + toff
+static int launch_ref_window(ndp_handle *h, const double *d_t, double toff, double *d_xr, double *d_ur, hipStream_t s)
+{
+    if (!h->dTraj) { h->err = "ndp_ref_window: ndp_ref_set_trajectory was never called"; return -11; }
+    const size_t B = h->cfg.batch, S = (size_t)h->traj_seg;
+    const double *coeff = h->dTraj, *cum = coeff + B * S * 28, *seg = cum + B * (S + 1), *fpt = seg + B * S;
+    RefCfg cf{h->cfg.batch, h->cfg.N, h->traj_seg, h->cfg.dt, h->cfg.mass, h->cfg.gravity, toff};
+    const int rows = h->cfg.batch * (h->cfg.N + 1);
+    hipLaunchKernelGGL(ref_window_kernel, dim3((rows + REF_ROWS - 1) / REF_ROWS), dim3(REF_ROWS), 0, s, cf, coeff, cum, seg, fpt,
+                       d_t, d_xr, d_ur);
+    NDP_HIP(h, hipGetLastError());
+    return 0;
+}
+
 int ndp_ref_window_device(ndp_handle *h, const void *d_t, void *d_xr, void *d_ur, void *stream)
 {
     if (!h || !d_t || !d_xr || !d_ur) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
-    if (!h->dTraj) { h->err = "ndp_ref_window: ndp_ref_set_trajectory was never called"; return -11; }
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    const size_t B = h->cfg.batch, S = (size_t)h->traj_seg;
-    const double *coeff = h->dTraj, *cum = coeff + B * S * 28, *seg = cum + B * (S + 1), *fpt = seg + B * S;
-    RefCfg cf{h->cfg.batch, h->cfg.N, h->traj_seg, h->cfg.dt, h->cfg.mass, h->cfg.gravity};
-    const int rows = h->cfg.batch * (h->cfg.N + 1);
-    hipLaunchKernelGGL(ref_window_kernel, dim3((rows + REF_ROWS - 1) / REF_ROWS), dim3(REF_ROWS), 0, s, cf, coeff, cum, seg, fpt,
-                       (const double *)d_t, (double *)d_xr, (double *)d_ur);
-    NDP_HIP(h, hipGetLastError());
-    return 0;
+    return launch_ref_window(h, (const double *)d_t, 0.0, (double *)d_xr, (double *)d_ur, s);
 }
 
 int ndp_ref_window(ndp_handle *h, const double *t, double *xr, double *ur)
@@ -1389,6 +1395,31 @@ int ndp_plant_step(ndp_handle *h, double *x, const double *u, const double *f, d
     std::lock_guard<std::mutex> lk(h->mu);
     NDP_HIP(h, hipMemcpyAsync(x, h->sx0, B * 80, hipMemcpyDeviceToHost, h->stream));
     NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- f4: closed-loop rollout, everything enqueued back to back on one stream, nothing returns to the host in between
+int ndp_rollout_device(ndp_handle *h, int ticks, double t0, double dt_tick, int substeps, void *d_x, void *d_log, void *stream)
+{
+    if (!h || ticks < 1 || substeps < 1 || !d_x) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    if (h->cfg.use_fd) { h->err = "ndp_rollout_device: the rollout drives the NMPC model (use_fd = 0)"; return -8; }
+    const size_t B = h->cfg.batch;
+    double *x = (double *)d_x, *log = (double *)d_log;
+    int rc = launch_ref_window(h, nullptr, t0, h->sxr, h->sur, s);     // reset(xr, ur) at the first tick's reference
+    if (rc) return rc;
+    NDP_HIP(h, hipMemcpyAsync(h->dX, h->sxr, nxs(h) * 8, hipMemcpyDeviceToDevice, s));
+    NDP_HIP(h, hipMemcpyAsync(h->dU, h->sur, nus(h) * 8, hipMemcpyDeviceToDevice, s));
+    for (int k = 0; k < ticks; ++k) {
+        if (k > 0 && (rc = launch_ref_window(h, nullptr, t0 + k * dt_tick, h->sxr, h->sur, s))) return rc;
+        if ((rc = launch_rti(h, x, h->sxr, h->sur, nullptr, h->su0, nullptr, s))) return rc;
+        hipLaunchKernelGGL(plant_kernel, dim3((h->cfg.batch + 255) / 256), dim3(256), 0, s, x, (const double *)h->su0,
+                           (const double *)nullptr, dt_tick / substeps, substeps, 1.0 / h->cfg.mass, h->cfg.gravity, h->cfg.batch);
+        NDP_HIP(h, hipGetLastError());
+        if (log) NDP_HIP(h, hipMemcpyAsync(log + (size_t)k * B * NX, x, B * NX * 8, hipMemcpyDeviceToDevice, s));
+    }
     return 0;
 }
 

@@ -29,6 +29,8 @@ def main():
     dev = torch.device("cuda:0")
     if a.row == "ref_window":
         return bench_ref_window(a, torch, ndp, dev)
+    if a.row == "rollout":
+        return bench_rollout(a, torch, ndp, dev)
     eng = ndp.BatchedNMPC(B, N=2, load_mlp=False)       # tiny horizon: only the estimator state matters here
     vz = torch.randn(B, dtype=torch.float64, device=dev) * 0.1
     th = torch.rand(B, dtype=torch.float64, device=dev) * 0.8 + 0.15
@@ -103,6 +105,36 @@ def bench_ref_window(a, torch, ndp, dev):
                       "dtype": "f64", "kernel_us": dev_s * 1e6,
                       "roofline": {"bound": "hbm", "achieved": bytes_per * B / dev_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                                    "frac": bytes_per * B / dev_s / 1e9 / 8000.0, "algorithmic_bytes_per_vehicle": bytes_per}}))
+
+
+def bench_rollout(a, torch, ndp, dev):
+    """f4 + f1 + the control step: closed-loop rollout of B vehicles on their minimum-snap trajectories, a.steps ticks in
+    one ndp_rollout_device call (3 launches per tick: reference window, control step, plant step)."""
+    import numpy as np
+    from ndp_nmpc_qd_amd.pt_pub import TrajCoefficients
+    B, M = a.batch, 4
+    rng = np.random.default_rng(7)
+    wp = np.zeros((B, 4, M + 1))
+    wp[:, 0:2] = np.cumsum(rng.uniform(-1.0, 1.0, (B, 2, M + 1)), axis=2)
+    wp[:, 2] = 1.0 + 0.2 * rng.uniform(-1, 1, (B, M + 1))
+    wp[:, 3] = np.cumsum(rng.uniform(-0.3, 0.3, (B, M + 1)), axis=1)
+    tc = TrajCoefficients.from_waypoints(wp, rng.uniform(3.0, 5.0, (B, M)))
+    eng = ndp.BatchedNMPC(B)
+    eng.ref_set_trajectory(tc.coeff_x, tc.coeff_y, tc.coeff_z, tc.coeff_yaw, tc.traj_time_cum, tc.traj_time_seg, tc.final_pt)
+    xr0, _ = eng.ref_window(np.zeros(B))
+    x = torch.from_numpy(xr0[:, 0].copy()).to(dev)
+    eng.rollout_device(a.warmup, x)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    eng.rollout_device(a.steps, x, t0=a.warmup * 0.02)
+    eng.synchronize()
+    el = time.perf_counter() - t0
+    xr_end, _ = eng.ref_window(np.full(B, (a.warmup + a.steps) * 0.02))
+    err = np.linalg.norm(x.cpu().numpy()[:, 0:3] - xr_end[:, 0, 0:3], axis=1)
+    print(json.dumps({"row": "closed-loop rollout: reference window + control step (N=20, 1 RTI) + plant step per tick",
+                      "metric": "vehicle ticks/s", "value": B * a.steps / el, "batch": B, "ticks": a.steps,
+                      "us_per_tick": el / a.steps * 1e6, "simulated_seconds_per_vehicle": a.steps * 0.02,
+                      "tracking_error_at_end_m": {"median": float(np.median(err)), "max": float(err.max())}}))
 
 
 if __name__ == "__main__":

@@ -88,3 +88,47 @@ def test_gpu_plant_step_and_device_closed_loop(oracle):
         xs = eng.plant_step(xs, u0, None, CP.ts_nmpc, 4)
     pr = synth.figure_eight(omega, phi, np.full(B, 100 * CP.ts_nmpc))[0]
     assert np.linalg.norm(xs[:, 0:3] - pr, axis=1).max() < 0.04
+
+
+@pytest.mark.gpu
+def test_gpu_closed_loop_rollout_matches_the_tick_by_tick_loop(oracle):
+    """ndp_rollout_device (reference window -> control step -> plant step, 3 launches per tick, nothing returns to the
+    host) against the same three calls made tick by tick from the host: identical states, bit for bit; and the vehicles
+    follow their minimum-snap trajectories."""
+    import torch
+    import ndp_nmpc_qd_amd as ndp
+    from ndp_nmpc_qd_amd.pt_pub import TrajCoefficients
+    B, M, K = 96, 3, 60
+    rng = np.random.default_rng(3)
+    wp = np.zeros((B, 4, M + 1))
+    wp[:, 0:2] = np.cumsum(rng.uniform(-1.0, 1.0, (B, 2, M + 1)), axis=2)
+    wp[:, 2] = 1.0 + 0.2 * rng.uniform(-1, 1, (B, M + 1))
+    wp[:, 3] = np.cumsum(rng.uniform(-0.2, 0.2, (B, M + 1)), axis=1)
+    tc = TrajCoefficients.from_waypoints(wp, rng.uniform(3.0, 4.0, (B, M)))
+    t0 = 0.4
+    engs = [ndp.BatchedNMPC(B) for _ in range(2)]
+    for e in engs:
+        e.ref_set_trajectory(tc.coeff_x, tc.coeff_y, tc.coeff_z, tc.coeff_yaw, tc.traj_time_cum, tc.traj_time_seg, tc.final_pt)
+    xr0, ur0 = engs[0].ref_window(np.full(B, t0))
+    x_init = xr0[:, 0].copy()
+    x_init[:, 0:3] += rng.normal(0, 0.05, (B, 3))
+    # host loop
+    e = engs[0]
+    e.reset(xr0, ur0)
+    xs = x_init.copy()
+    states = []
+    for k in range(K):
+        xr, ur = e.ref_window(np.full(B, t0 + k * CP.ts_nmpc))
+        u0 = e.update(xs, xr, ur)
+        xs = e.plant_step(xs, u0, None, CP.ts_nmpc, 4)
+        states.append(xs.copy())
+    # device rollout
+    dev = torch.device("cuda", 0)
+    xd = torch.from_numpy(x_init).to(dev)
+    log = torch.empty(K, B, 10, dtype=torch.float64, device=dev)
+    engs[1].rollout_device(K, xd, log, t0=t0, dt=CP.ts_nmpc, substeps=4)
+    engs[1].synchronize()
+    assert np.array_equal(log.cpu().numpy(), np.stack(states))
+    assert np.array_equal(xd.cpu().numpy(), states[-1])
+    ref_end, _ = engs[0].ref_window(np.full(B, t0 + K * CP.ts_nmpc))
+    assert np.linalg.norm(states[-1][:, 0:3] - ref_end[:, 0, 0:3], axis=1).max() < 0.03
