@@ -244,6 +244,30 @@ def main():
             out["cpu_baseline"] = {"value": B * args.cpu_passes / tc, "unit": "solves/s", "cores": nthr, "kind": "port",
                                    "sample": f"{args.cpu_passes} control ticks of the same batch={B} workload "
                                              f"(oracle/ndp_oracle.c: fp64 RTI + IPM always, fp32 MLP), OpenMP over instances"}
+            # BASELINE config 1 (one vehicle, N = 20, no downwash, 1 RTI iteration): latency of the CPU restatement on one
+            # thread next to the same single instance on the GPU (host call to host return, device-resident inputs)
+            c1 = O.default_cfg(N=N, use_fd=False)
+            X1, U1 = host0["xr"][:1].copy(), host0["ur"][:1].copy()
+            n1 = 300
+            t1 = time.perf_counter()
+            for _ in range(n1):
+                O.step_batch(c1, host0["x0"][:1], host0["xr"][:1], host0["ur"][:1], None, X1, U1, nthreads=1)
+            t1 = (time.perf_counter() - t1) / n1
+            e1 = ndp.BatchedNMPC(1, N=N, device=local_rank)
+            d1 = {k: ticks[0][k][:1].contiguous() for k in ("x0", "xr", "ur")}
+            u1 = torch.empty(1, 4, dtype=torch.float64, device=dev)
+            e1.reset_device(d1["xr"], d1["ur"], stream=stream)
+            for _ in range(20):
+                e1.update_device(d1["x0"], d1["xr"], d1["ur"], u1, stream=stream)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(n1):
+                e1.update_device(d1["x0"], d1["xr"], d1["ur"], u1, stream=stream)
+                torch.cuda.synchronize()
+            t2 = (time.perf_counter() - t2) / n1
+            out["config1_single_vehicle"] = {"cpu_restatement_us_per_solve_1_thread": t1 * 1e6,
+                                             "gpu_us_per_solve_sync_each_call": t2 * 1e6,
+                                             "note": "N=%d, no downwash, 1 RTI iteration; CPU = oracle (interior point always)" % N}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
