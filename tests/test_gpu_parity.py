@@ -456,3 +456,42 @@ def test_downwash_step_at_other_horizons(ndp, oracle, mlp_blob, N):
     assert 0 < (np.abs(f_or).max(axis=(1, 2)) > 0).sum() < B
     u0o, *_ = _oracle_batch(oracle, b, N=N, use_fd=True, f=f_or)
     _assert_u(u0, u0o, 2e-6)
+
+
+@pytest.mark.gpu
+def test_three_vehicle_formations_in_one_batch(ndp, oracle, mlp_blob):
+    """BASELINE config 4 semantics, formation-major placement (all three vehicles of a formation on one GPU, no exchange):
+    vehicle 0 = NDP controller whose neighbour is vehicle 1 (ndp_nmpc_leader_node.py:40,60-76); vehicles 1 and 2 = plain
+    NMPC followers tracking the leader's window shifted by the filtered formation offsets (0, +-1, 0)
+    (nmpc_leader_node.py:42-43, nmpc_follower_node.py:44-77).  One batch of 3R instances: the followers ride in the NDP
+    engine with their gate closed, which is the NMPC model exactly (f = 0)."""
+    R, N = 96, 20
+    lead = synth.make_batch(R, seed=77)
+    rel = ndp.BatchedNMPC(R, load_mlp=False)
+    xr_f = []
+    for off in ((0.0, 1.0, 0.0), (0.0, -1.0, 0.0)):
+        rel.relay_reset()
+        rel.relay_formation(np.tile(off, (R, 1)))
+        xr_f.append(rel.relay_reference(lead["xr"]))
+    rng = np.random.default_rng(5)
+    # leaders fly 0.4 m above follower 1's track displaced sideways: about half of them inside the 1 m gate
+    xr_l = lead["xr"].copy()
+    xr_l[:, :, 1] += rng.uniform(0.0, 4.0, (R, 1))
+    xr_l[:, :, 2] += 0.4
+    xr = np.concatenate([xr_l, xr_f[0], xr_f[1]])
+    ur = np.concatenate([lead["ur"]] * 3)
+    x0 = xr[:, 0].copy()
+    x0[:, 0:3] += rng.normal(0, 0.05, (3 * R, 3))
+    other = np.concatenate([xr_f[0], xr_l, xr_l])                 # followers: any window, their gate is closed below
+    ego_xy = np.concatenate([x0[:R, 0:2], np.full((2 * R, 2), 1e6)])
+    eng = ndp.BatchedNMPC(3 * R, disturbance=True)
+    eng.reset(xr, ur)
+    u0 = eng.update(x0, xr, ur, other=other, ego_xy=ego_xy)
+    f = oracle.downwash_batch(mlp_blob, other, xr, ego_xy)
+    assert np.all(f[R:] == 0) and 0.2 < (np.abs(f[:R]).max(axis=(1, 2)) > 0).mean() < 0.8
+    X, U = xr.copy(), ur.copy()
+    uo, st, _ = oracle.step_batch(oracle.default_cfg(use_fd=True), x0, xr, ur, f, X, U)
+    _assert_u(u0, uo, 2e-6)
+    Xn, Un = xr[R:].copy(), ur[R:].copy()
+    un, *_ = oracle.step_batch(oracle.default_cfg(use_fd=False), x0[R:], xr[R:], ur[R:], None, Xn, Un)
+    _assert_u(u0[R:], un, 1e-7)                                    # followers: the plain NMPC controller's answer
