@@ -737,8 +737,8 @@ struct RtiWave {
             W::pin();
             vd4 Kt = mma(hux, nahi, W::zero4());          // det * K~'[i][b], lands in column 12+b (rows 12..15 of the forward operand)
             W::pin();
-            vd e1 = W::fma(-det, r1, vd(1.0));
-            vd rdet = W::fma(e1, r1, r1);                     // 1/det: v_rcp_f64 seed + two Newton steps
+            vd rdet = r1;   // 1/det: v_rcp_f64 seed (4.5e-8) + ONE Newton step = 2.2e-15 (profiles/r01_ubench_mfma_latency.txt),
+                            // below the cofactors' own cond * eps; a second step is two more dependent f64 ops per stage
             okv = okv && (det > 0.0) && (!T.lam_diag || (cof > 0.0));
             vd gs = G.r[0] * rdet;                            // Lam^-1 T
             W::keep(hux);   // hux stays live to here: reusing its register right behind the K~' MFMA (which is still reading
