@@ -688,18 +688,18 @@ struct RtiWave {
         for (int k = N - 1; k >= 1; --k) {
             vd nmk[3], ncc[4];
             const int kp = k >= 2 ? k - 2 : 0;      // prefetch stage k-2; at k = 1 there is none: re-read stage 0 (values unused)
-            for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, T.mk_off[c] + mb(kp));
-            for (int r = 0; r < 4; ++r) ncc[r] = W::ld(lds, T.c_off[r] + cb(kp));
             // Lam[a][b] = H~[12+a][12+b] and H~ux both sit in accumulator register 3
             vd hux = H.r[3];
             // [H~xx ; H~ux] M~_{k-1}: H~'s registers as A operand mean H~' -- equal up to rounding (see the
             // re-symmetrisation below); rows 12..15 of the result are T = H~ux M~_{k-1}
-            // Issue order matters: one in-order wave, an asynchronous matrix pipe that takes one MFMA per 64 cycles, and
-            // ~32 cycles per DEPENDENT f64 VALU op.  The inverse (cofactors -> det -> 1/det, ~20 dependent ops) is cut
-            // into pieces of one or two ops and each piece is issued right behind an MFMA, so it runs while that MFMA
-            // occupies the pipe; every pin() keeps the compiler from regrouping them.
             //   M~'' H~xu = (H~ux M~')' = T', hence  H~' = [C~' + M~'' (H~xx M~')] - T' Lam^-1 T:
             // the bracket needs no Lam^-1, only two dependent MFMAs (adj T, then the rank-4 correction) follow it.
+            // Issue order (every pin() keeps the compiler from regrouping): a wave issues nothing under its own MFMA, and a
+            // DEPENDENT f64 VALU op waits ~32 cycles for its operand.  The inverse's dependency chain (cofactor 5 levels,
+            // determinant 3, 1/det 2, scale 1) is cut into pieces placed behind the MFMAs that do not need it; the tail that
+            // nothing can follow (1/det -> scale -> last MFMA) carries the stage's independent instructions, the operand
+            // prefetch of stage k-2, between its levels.  Measured: worth ~1 % of the sweep -- what counts is the number of
+            // instructions and of chain levels (dropping the second Newton step of 1/det saved 5 %), not their order.
             LamRegs LR;
             lam_gather(T, lds, hux, LR);
             W::pin();
@@ -707,39 +707,47 @@ struct RtiWave {
             for (int c = 0; c < 3; ++c) Wf = mma(H.r[c], mk[c], Wf);
             W::pin();
             const vd *mm = LR.mm;
-            vd d0 = mm[4] * mm[8] - mm[5] * mm[7];
-            vd d1 = mm[3] * mm[8] - mm[5] * mm[6];
-            vd d2 = mm[3] * mm[7] - mm[4] * mm[6];
+            vd p0 = mm[4] * mm[8], p1 = mm[3] * mm[8], p2 = mm[3] * mm[7];
+            vd os = LR.own * T.cof_sign;
             W::pin();
             vd4 Hb;
             for (int r = 0; r < 4; ++r) Hb.r[r] = cc[r];
             Hb = mma(mk[0], Wf.r[0], Hb);
             W::pin();
-            vd cof = (mm[0] * d0 - mm[1] * d1 + mm[2] * d2) * T.cof_sign;
+            vd d0 = p0 - mm[5] * mm[7], d1 = p1 - mm[5] * mm[6], d2 = p2 - mm[4] * mm[6];
             W::pin();
             Hb = mma(mk[1], Wf.r[1], Hb);
             W::pin();
-            vd dq = LR.own * cof;                             // row expansion of det: lanes 16g..16g+3 form one quad
-            dq = dq + W::quad_swap1(dq);
-            vd ladj = W::sel(T.lo4, cof, vd(0.0));            // A operand: adj[g][j], j < 4
-            vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));       // B operand of K~': -adj[g][j-12] in columns 12..15
+            vd c0 = mm[0] * d0;
             W::pin();
             Hb = mma(mk[2], Wf.r[2], Hb);
             W::pin();
-            vd det = dq + W::quad_swap2(dq);
-            vd r0 = W::rcp_seed(det);
+            vd c1 = c0 - mm[1] * d1;
+            vd cofu = c1 + mm[2] * d2;                        // unsigned cofactor: the 3x3 minor's determinant
+            vd cof = cofu * T.cof_sign;                       // adj(Lam)[g][j&3]
+            vd dq = os * cofu;                                // row expansion of det: lanes 16g..16g+3 form one quad
+            vd ladj = W::sel(T.lo4, cof, vd(0.0));            // A operand: adj[g][j], j < 4
+            vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));       // B operand of K~': -adj[g][j-12] in columns 12..15
             W::pin();
             vd tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
             vd4 G = mma(ladj, tt, W::zero4());            // adj T
             W::pin();
-            vd e0 = W::fma(-det, r0, vd(1.0));
-            vd r1 = W::fma(e0, r0, r0);
+            dq = dq + W::quad_swap1(dq);
+            vd det = dq + W::quad_swap2(dq);
             W::pin();
             vd4 Kt = mma(hux, nahi, W::zero4());          // det * K~'[i][b], lands in column 12+b (rows 12..15 of the forward operand)
             W::pin();
-            vd rdet = r1;   // 1/det: v_rcp_f64 seed (4.5e-8) + ONE Newton step = 2.2e-15 (profiles/r01_ubench_mfma_latency.txt),
-                            // below the cofactors' own cond * eps; a second step is two more dependent f64 ops per stage
+            vd r0 = W::rcp_seed(det);
+            for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, T.mk_off[c] + mb(kp));
+            W::pin();
+            vd e0 = W::fma(-det, r0, vd(1.0));
+            for (int r = 0; r < 2; ++r) ncc[r] = W::ld(lds, T.c_off[r] + cb(kp));
+            W::pin();
+            vd rdet = W::fma(e0, r0, r0);   // 1/det: v_rcp_f64 seed (4.5e-8) + ONE Newton step = 2.2e-15 (profiles/r01_ubench_mfma_latency.txt),
+                                            // below the cofactors' own cond * eps; a second step is two more dependent f64 ops per stage
+            for (int r = 2; r < 4; ++r) ncc[r] = W::ld(lds, T.c_off[r] + cb(kp));
             okv = okv && (det > 0.0) && (!T.lam_diag || (cof > 0.0));
+            W::pin();
             vd gs = G.r[0] * rdet;                            // Lam^-1 T
             W::keep(hux);   // hux stays live to here: reusing its register right behind the K~' MFMA (which is still reading
                             // it) costs a 17-cycle hazard stall per stage
