@@ -718,21 +718,26 @@ struct RtiWave {
             W::pin();
             Hb = mma(mk[1], Wf.r[1], Hb);
             W::pin();
-            vd c0 = mm[0] * d0;
+            vd cx = mm[0] * d0, cy = mm[1] * d1;
             W::pin();
             Hb = mma(mk[2], Wf.r[2], Hb);
             W::pin();
-            vd c1 = c0 - mm[1] * d1;
-            vd cofu = c1 + mm[2] * d2;                        // unsigned cofactor: the 3x3 minor's determinant
+            vd cz = cx + mm[2] * d2;
+            vd oy = os * cy;
+            W::pin();
+            // unsigned cofactor cz - cy (the 3x3 minor's determinant) and, one level earlier than through it, this lane's
+            // term of the row expansion of det: own * sign * (cz - cy)
+            vd dq = os * cz - oy;
+            vd cofu = cz - cy;
+            W::pin();
+            dq = dq + W::quad_swap1(dq);                      // lanes 16g..16g+3 form one quad
             vd cof = cofu * T.cof_sign;                       // adj(Lam)[g][j&3]
-            vd dq = os * cofu;                                // row expansion of det: lanes 16g..16g+3 form one quad
             vd ladj = W::sel(T.lo4, cof, vd(0.0));            // A operand: adj[g][j], j < 4
             vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));       // B operand of K~': -adj[g][j-12] in columns 12..15
             W::pin();
             vd tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
             vd4 G = mma(ladj, tt, W::zero4());            // adj T
             W::pin();
-            dq = dq + W::quad_swap1(dq);
             vd det = dq + W::quad_swap2(dq);
             W::pin();
             vd4 Kt = mma(hux, nahi, W::zero4());          // det * K~'[i][b], lands in column 12+b (rows 12..15 of the forward operand)
@@ -740,15 +745,16 @@ struct RtiWave {
             vd r0 = W::rcp_seed(det);
             for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, T.mk_off[c] + mb(kp));
             W::pin();
-            vd e0 = W::fma(-det, r0, vd(1.0));
+            // 1/det = r0 (2 - det r0): v_rcp_f64 seed (4.5e-8) + ONE Newton step = 2.2e-15 (profiles/r01_ubench_mfma_latency.txt),
+            // below the cofactors' own cond * eps.  The scale of Lam^-1 T is applied as (G r0) e0 so that G r0 runs beside e0.
+            vd e0 = W::fma(-det, r0, vd(2.0));
+            vd g0 = G.r[0] * r0;
             for (int r = 0; r < 2; ++r) ncc[r] = W::ld(lds, T.c_off[r] + cb(kp));
             W::pin();
-            vd rdet = W::fma(e0, r0, r0);   // 1/det: v_rcp_f64 seed (4.5e-8) + ONE Newton step = 2.2e-15 (profiles/r01_ubench_mfma_latency.txt),
-                                            // below the cofactors' own cond * eps; a second step is two more dependent f64 ops per stage
+            vd gs = g0 * e0;                                  // Lam^-1 T
+            vd rdet = r0 * e0;
             for (int r = 2; r < 4; ++r) ncc[r] = W::ld(lds, T.c_off[r] + cb(kp));
             okv = okv && (det > 0.0) && (!T.lam_diag || (cof > 0.0));
-            W::pin();
-            vd gs = G.r[0] * rdet;                            // Lam^-1 T
             W::keep(hux);   // hux stays live to here: reusing its register right behind the K~' MFMA (which is still reading
                             // it) costs a 17-cycle hazard stall per stage
             W::pin();
