@@ -49,9 +49,10 @@ enum { QP_AUTO = 0, QP_IPM_ALWAYS = 1 };
 // Every per-stage operand of the sweeps lives in a stage block of ONE stride, constants included, so that the address
 // of element e of stage k is (per-lane base of e) + k * stride: with a compile-time horizon the stage term is the
 // immediate offset of the DS instruction and the sweeps carry no address arithmetic at all.
-enum { MB_STRIDE = 137, CB_STRIDE = 48 };
+enum { MB_STRIDE = 138, CB_STRIDE = 48 };
 // stage block MB_k: 6x8 [d(p,v)+/d(q,u)] | 4x7 [dq+/d(q,w)] | b(10) | constants 0, 1, h | K~'(12x4, written by the backward sweep)
-enum { MB_PV = 0, MB_Q = 48, MB_B = 76, MB_ZERO = 86, MB_ONE = 87, MB_H = 88, MB_KT = 89 };
+// | one dump slot (where the lanes that hold no K~' entry store, so that the sweep's stores need no predicate)
+enum { MB_PV = 0, MB_Q = 48, MB_B = 76, MB_ZERO = 86, MB_ONE = 87, MB_H = 88, MB_KT = 89, MB_DUMP = 137 };
 // cost block CB_k: Qq(4x4) | qe(10) | re(4) | dex(6) | deu(4) | qbv(3) | rb(4) | constant 0
 enum { CB_QQ = 0, CB_QE = 16, CB_RE = 26, CB_DEX = 30, CB_DEU = 36, CB_QBV = 40, CB_RB = 43, CB_ZERO = 47 };
 // constants area
@@ -90,7 +91,7 @@ struct RtiIo {            // global-memory views of ONE instance
 };
 
 struct LdsMap {
-    int KC, SC, XI, UI, ZX, ZU, CX, CU, MB, CB, KT, TXR, TUR, TF, total;
+    int KC, SC, XI, UI, ZX, ZU, CX, CU, ZD, MB, CB, KT, TXR, TUR, TF, total;
 };
 
 NDP_HD LdsMap make_map(int N)
@@ -105,11 +106,12 @@ NDP_HD LdsMap make_map(int N)
     m.ZU = o; o += N * NU;
     m.CX = o; o += (N + 1) * NX;
     m.CU = o; o += N * NU;
+    m.ZD = o; o += (N + 1) * NX + N * NU;   // shadow of ZX|ZU: where the lanes that hold no forward-sweep result store
     m.MB = o; o += N * MB_STRIDE;
     m.CB = o; o += (N + 1) * CB_STRIDE;
     m.total = o;
     m.KT = m.MB + MB_KT;   // K~' of stage 0; stage k at + k * MB_STRIDE
-    // staged inputs (17N + 13 doubles) alias ZX|ZU|CX|CU (28N + 20), which are dead until the first sweep / step
+    // staged inputs (17N + 13 doubles) alias ZX|ZU|CX|CU|ZD (42N + 30), which are dead until the first sweep / step
     m.TXR = m.ZX;
     m.TUR = m.TXR + (N + 1) * NX;
     m.TF = m.TUR + N * NU;
@@ -171,11 +173,11 @@ struct RtiWave {
         vi mu_off;                // M~ columns 12..15 (B~) as A operand: element (j, 12+g)
         vi c_off[4];              // C~ in accumulator layout: element (g+4r, j)
         vi kt_off[3];             // where lanes j>=12 keep K~'[4c+g][j-12]
-        vi zu_off, zx_off[3];     // forward-sweep results of lanes j == 0: du[g], x+[4c+g]
+        vi kt_st[3];              // store form of kt_off: lanes j<12 aim at the block's dump slot
+        vi zu_st, zx_st[3];       // forward-sweep results du[g], x+[4c+g] of lanes j == 0; the other lanes aim at the shadow ZD
         vb kt_pred;               // j >= 12
         vb lo4;                   // j < 4
         vb col0;                  // j == 0
-        vb zx_pred[3];            // j == 0 and 4c+g < 10
         // 4x4 inverse (lam_inverse): LDS scratch SC holds Lam row-major
         vi lam_w_off;             // lanes j >= 12 publish H~[12+g][j] to SC[g*4 + j-12]
         vi minor_off[9];          // the 3x3 minor of (g, j&3)
@@ -241,7 +243,6 @@ struct RtiWave {
         T.kt_pred = j >= 12;
         T.lo4 = j < 4;
         T.col0 = j == 0;
-        for (int c = 0; c < 3; ++c) T.zx_pred[c] = T.col0 && (g + 4 * c < 10);
         T.cof_sign = W::sel(((g + jc) & 1) == 1, vd(-1.0), vd(1.0));
         T.lam_diag = g == jc;
         for (int c = 0; c < 4; ++c) T.eye[c] = W::sel(j == g + 4 * c, vd(1.0), vd(0.0));
@@ -257,12 +258,14 @@ struct RtiWave {
         for (int c = 0; c < 3; ++c) {
             T.kt_off[c] = (g + 4 * c) * 4 + (j & 3) + m.KT;
             T.fw_off[c] = W::sel(T.kt_pred, T.kt_off[c], m_entry(m, j, g + 4 * c));
-            T.zx_off[c] = W::sel(T.zx_pred[c], g + 4 * c + m.ZX, vi(m.ZX));
+            T.kt_st[c] = W::sel(T.kt_pred, T.kt_off[c], vi(m.MB + int(MB_DUMP)));
+            vi xi = W::sel(g + 4 * c < 10, g + 4 * c, vi(0));
+            T.zx_st[c] = xi + W::sel(T.col0 && (g + 4 * c < 10), vi(m.ZX), vi(m.ZD));
         }
         T.mu_off = m_entry(m, j, g + 12);
-        T.zu_off = g + m.ZU;
+        T.zu_st = g + W::sel(T.col0, vi(m.ZU), vi(m.ZD + (m.ZU - m.ZX)));
         vi jc = j & 3;
-        T.lam_w_off = g * 4 + jc + m.SC;
+        T.lam_w_off = W::sel(T.kt_pred, g * 4 + jc + m.SC, vi(m.KC + KC_DUMP));
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) {
                 vi ra = W::sel(g <= a, vi(a + 1), vi(a));    // rows {0..3} \ {g}
@@ -274,14 +277,16 @@ struct RtiWave {
 
     // the integer fields of Tables in a fixed order: f(index, field).  Used by the host to serialise the tables
     // (fill_tables) and by the device to read them back (load_tables).
-    enum { TB_FIELDS = 32 };
+    enum { TB_FIELDS = 36 };
     template <class F>
     static NDP_HD void for_each_int(Tables &T, F &&f)
     {
         int i = 0;
-        for (int c = 0; c < 3; ++c) { f(i++, T.mk_off[c]); f(i++, T.fw_off[c]); f(i++, T.kt_off[c]); f(i++, T.zx_off[c]); }
+        for (int c = 0; c < 3; ++c) { f(i++, T.mk_off[c]); f(i++, T.fw_off[c]); f(i++, T.kt_off[c]); f(i++, T.zx_st[c]); }
+        for (int c = 0; c < 3; ++c) f(i++, T.kt_st[c]);
+        i++;   // pad to a multiple of four fields
         for (int r = 0; r < 4; ++r) f(i++, T.c_off[r]);
-        f(i++, T.mu_off); f(i++, T.zu_off); f(i++, T.lam_w_off); f(i++, T.own_off);
+        f(i++, T.mu_off); f(i++, T.zu_st); f(i++, T.lam_w_off); f(i++, T.own_off);
         for (int a = 0; a < 9; ++a) f(i++, T.minor_off[a]);
     }
     // block layout [field / 4][lane][field % 4]: the four fields of a group are one 16-byte load per lane, a
@@ -632,7 +637,7 @@ struct RtiWave {
     struct LamRegs { vd mm[9], own; };
     static NDP_D void lam_gather(const Tables &T, lp lds, vd h3, LamRegs &L)
     {
-        W::stp(lds, T.lam_w_off, h3, T.kt_pred);             // H~[12+g][12+b] -> SC[g*4+b]
+        W::st(lds, T.lam_w_off, h3);                         // H~[12+g][12+b] -> SC[g*4+b]; lanes j<12 -> dump slot
         W::sync();
         for (int i = 0; i < 9; ++i) L.mm[i] = W::ld(lds, T.minor_off[i]);
         L.own = W::ld(lds, T.own_off);
@@ -684,6 +689,9 @@ struct RtiWave {
             for (int c = 0; c < 3; ++c) mk[c] = W::ld(lds, T.mk_off[c] + mb(kn));
             for (int r = 0; r < 4; ++r) cc[r] = W::ld(lds, T.c_off[r] + cb(kn));
         }
+        vd4 Ktp = W::zero4();
+        vd rdp = 0.0;
+        int kprev = -1;
         NDP_UNROLL_STAGES
         for (int k = N - 1; k >= 1; --k) {
             vd nmk[3], ncc[4];
@@ -705,6 +713,9 @@ struct RtiWave {
             W::pin();
             vd4 Wf = W::zero4();
             for (int c = 0; c < 3; ++c) Wf = mma(H.r[c], mk[c], Wf);
+            W::pin();
+            if (kprev >= 0)
+                for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), Ktp.r[c] * rdp);
             W::pin();
             const vd *mm = LR.mm;
             vd p0 = mm[4] * mm[8], p1 = mm[3] * mm[8], p2 = mm[3] * mm[7];
@@ -759,7 +770,7 @@ struct RtiWave {
                             // it) costs a 17-cycle hazard stall per stage
             W::pin();
             vd4 Hn = mma(-tt, gs, Hb);                    // - T' Lam^-1 T on top of the bracket
-            for (int c = 0; c < 3; ++c) W::stp(lds, T.kt_off[c] + mb(k), Kt.r[c] * rdet, T.kt_pred);
+            Ktp = Kt; rdp = rdet; kprev = k;     // K~'_k is scaled and stored behind the next stage's first MFMAs
             if ((k & 3) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
                 // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
@@ -772,6 +783,8 @@ struct RtiWave {
             for (int c = 0; c < 3; ++c) mk[c] = nmk[c];
             for (int r = 0; r < 4; ++r) cc[r] = ncc[r];
         }
+        if (kprev >= 0)
+            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), Ktp.r[c] * rdp);
         {   // stage 0: only the gain is needed
             vd hux = H.r[3];
             LamRegs LR;
@@ -780,7 +793,7 @@ struct RtiWave {
             vd rdet = lam_rdet(T, LR, cof, ok);
             vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));
             vd4 Kt = mma(hux, nahi, W::zero4());
-            for (int c = 0; c < 3; ++c) W::stp(lds, T.kt_off[c], Kt.r[c] * rdet, T.kt_pred);
+            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c], Kt.r[c] * rdet);
         }
         ok = W::all(okv) && ok;
         W::sync();
@@ -810,10 +823,10 @@ struct RtiWave {
             Y = mma(fw[2], zc[2], Y);
             vd du = Y.r[3];
             vd4 xn = mma(mu, du, Y);
-            W::stp(lds, T.zu_off + k * int(NU), du, T.col0);
+            W::st(lds, T.zu_st + k * int(NU), du);
             for (int c = 0; c < 3; ++c) {
                 zc[c] = xn.r[c];
-                W::stp(lds, T.zx_off[c] + (k + 1) * int(NX), xn.r[c], T.zx_pred[c]);
+                W::st(lds, T.zx_st[c] + (k + 1) * int(NX), xn.r[c]);
             }
             for (int c = 0; c < 3; ++c) fw[c] = nfw[c];
             mu = nmu;
@@ -1160,7 +1173,7 @@ struct LaneW {
     static vi sel(vb p, vi a, vi b) { return p ? a : b; }
 };
 
-enum { TB_WORDS = 32 * 64 };
+enum { TB_WORDS = 36 * 64 };
 
 inline void fill_tables(int N, int *out /* [TB_WORDS] */)
 {
