@@ -690,7 +690,6 @@ struct RtiWave {
             for (int r = 0; r < 4; ++r) cc[r] = W::ld(lds, T.c_off[r] + cb(kn));
         }
         vd4 Ktp = W::zero4();
-        vd rdp = 0.0;
         int kprev = -1;
         NDP_UNROLL_STAGES
         for (int k = N - 1; k >= 1; --k) {
@@ -715,7 +714,7 @@ struct RtiWave {
             for (int c = 0; c < 3; ++c) Wf = mma(H.r[c], mk[c], Wf);
             W::pin();
             if (kprev >= 0)
-                for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), Ktp.r[c] * rdp);
+                for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), Ktp.r[c]);
             W::pin();
             const vd *mm = LR.mm;
             vd p0 = mm[4] * mm[8], p1 = mm[3] * mm[8], p2 = mm[3] * mm[7];
@@ -750,9 +749,6 @@ struct RtiWave {
             vd4 G = mma(ladj, tt, W::zero4());            // adj T
             W::pin();
             vd det = dq + W::quad_swap2(dq);
-            W::pin();
-            vd4 Kt = mma(hux, nahi, W::zero4());          // det * K~'[i][b], lands in column 12+b (rows 12..15 of the forward operand)
-            W::pin();
             vd r0 = W::rcp_seed(det);
             for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, T.mk_off[c] + mb(kp));
             W::pin();
@@ -766,11 +762,12 @@ struct RtiWave {
             vd rdet = r0 * e0;
             for (int r = 2; r < 4; ++r) ncc[r] = W::ld(lds, T.c_off[r] + cb(kp));
             okv = okv && (det > 0.0) && (!T.lam_diag || (cof > 0.0));
-            W::keep(hux);   // hux stays live to here: reusing its register right behind the K~' MFMA (which is still reading
-                            // it) costs a 17-cycle hazard stall per stage
             W::pin();
             vd4 Hn = mma(-tt, gs, Hb);                    // - T' Lam^-1 T on top of the bracket
-            Ktp = Kt; rdp = rdet; kprev = k;     // K~'_k is scaled and stored behind the next stage's first MFMAs
+            // K~' = H~ux' (-Lam^-1): the 1/det rides in the B operand (one multiply instead of one per result register); lands in
+            // column 12+b = rows 12..15 of the forward operand; stored behind the next stage's first MFMAs
+            vd4 Kt = mma(hux, nahi * rdet, W::zero4());
+            Ktp = Kt; kprev = k;
             if ((k & 3) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
                 // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
@@ -784,7 +781,7 @@ struct RtiWave {
             for (int r = 0; r < 4; ++r) cc[r] = ncc[r];
         }
         if (kprev >= 0)
-            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), Ktp.r[c] * rdp);
+            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), Ktp.r[c]);
         {   // stage 0: only the gain is needed
             vd hux = H.r[3];
             LamRegs LR;
