@@ -183,6 +183,7 @@ struct RtiWave {
         vi minor_off[9];          // the 3x3 minor of (g, j&3)
         vi own_off;               // Lam[g][j&3]
         vd cof_sign;              // (-1)^(g + j&3)
+        vd adj_a, adj_b;          // cof_sign * [j < 4], -cof_sign * [j >= 12]: minor determinant -> MFMA operand in one multiply
         vb lam_diag;              // g == j&3
         vd eye[4];                // identity as B operand: chunk c, lane (g,j) = [j == 4c+g]
     };
@@ -245,6 +246,8 @@ struct RtiWave {
         T.col0 = j == 0;
         T.cof_sign = W::sel(((g + jc) & 1) == 1, vd(-1.0), vd(1.0));
         T.lam_diag = g == jc;
+        T.adj_a = W::sel(T.lo4, T.cof_sign, vd(0.0));
+        T.adj_b = W::sel(T.kt_pred, -T.cof_sign, vd(0.0));
         for (int c = 0; c < 4; ++c) T.eye[c] = W::sel(j == g + 4 * c, vd(1.0), vd(0.0));
     }
 
@@ -741,9 +744,8 @@ struct RtiWave {
             vd cofu = cz - cy;
             W::pin();
             dq = dq + W::quad_swap1(dq);                      // lanes 16g..16g+3 form one quad
-            vd cof = cofu * T.cof_sign;                       // adj(Lam)[g][j&3]
-            vd ladj = W::sel(T.lo4, cof, vd(0.0));            // A operand: adj[g][j], j < 4
-            vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));       // B operand of K~': -adj[g][j-12] in columns 12..15
+            vd ladj = cofu * T.adj_a;                         // A operand: adj(Lam)[g][j], j < 4 (sign and lane mask in one factor)
+            vd nahi = cofu * T.adj_b;                         // B operand of K~': -adj[g][j-12] in columns 12..15
             W::pin();
             vd tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
             vd4 G = mma(ladj, tt, W::zero4());            // adj T
@@ -761,7 +763,7 @@ struct RtiWave {
             vd gs = g0 * e0;                                  // Lam^-1 T
             vd rdet = r0 * e0;
             for (int r = 2; r < 4; ++r) ncc[r] = W::ld(lds, T.c_off[r] + cb(kp));
-            okv = okv && (det > 0.0) && (!T.lam_diag || (cof > 0.0));
+            okv = okv && (det > 0.0) && (!T.lam_diag || (cofu > 0.0));   // on the diagonal the cofactor's sign factor is +1
             W::pin();
             vd4 Hn = mma(-tt, gs, Hb);                    // - T' Lam^-1 T on top of the bracket
             // K~' = H~ux' (-Lam^-1): the 1/det rides in the B operand (one multiply instead of one per result register); lands in
