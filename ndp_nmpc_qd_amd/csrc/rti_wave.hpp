@@ -12,7 +12,7 @@
 // Control flow is wave-uniform everywhere; per-lane decisions are selects / predicated stores.
 //
 // Design:
-//  * everything of one instance lives in that wave's LDS slice (37 KB at N=20) for the whole step;
+//  * everything of one instance lives in that wave's LDS slice (40 KB at N=20) for the whole step;
 //  * linearisation (RK4 + forward sensitivities) is lane-parallel over (stage, sensitivity column);
 //  * the Riccati recursion runs in homogeneous coordinates z~ = [x(10), 1, 0, u(4)] so that one
 //    16x16 f64 MFMA tile carries the Hessian AND the gradient: per stage
