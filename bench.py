@@ -202,9 +202,9 @@ def main():
         ach_tf = f_qp * B / rti_s / 1e12
         abytes = algorithmic_bytes_per_solve(N, downwash)
         # matrix-pipe occupancy estimate: every v_mfma_f64_16x16x4 / v_mfma_f32_32x32x2 holds the SIMD's pipe 64 cycles
-        # (measured, scripts/ubench); one instance per SIMD: 274 f64 MFMAs per sweep at N = 20; the MLP tile adds 12 f32 (64 clk)
-        # and 96 fp16 (32 clk) MFMAs.  PMC cross-check: SQ_INSTS_MFMA = 382 per instance, SQ_VALU_MFMA_BUSY_CYCLES = 21.4 k per SIMD
-        n_f64 = sweeps * (6 + 8 * (N - 1) + N + 16 * ((N - 1) // 4) + 4 * N)
+        # (measured, scripts/ubench); one instance per SIMD: 266 f64 MFMAs per sweep at N = 20; the MLP tile adds 12 f32 (64 clk)
+        # and 96 fp16 (32 clk) MFMAs.  PMC cross-check: SQ_INSTS_MFMA = 374 per instance, SQ_VALU_MFMA_BUSY_CYCLES = 21.4 k per SIMD
+        n_f64 = sweeps * (6 + 8 * (N - 1) + N + 16 * ((N - 1) // 8) + 4 * N)
         pipe_cycles = n_f64 * 64 + ((12 * 64 + 96 * 32) if fused else 0)
         out = {
             "metric": "NMPC solves/sec (N=20, 1 RTI iter + downwash MLP) at batch",

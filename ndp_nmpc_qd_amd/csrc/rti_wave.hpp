@@ -770,10 +770,10 @@ struct RtiWave {
             // column 12+b = rows 12..15 of the forward operand; stored behind the next stage's first MFMAs
             vd4 Kt = mma(hux, nahi * rdet, W::zero4());
             Ktp = Kt; kprev = k;
-            if ((k & 3) == 0) {
+            if ((k & 7) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
                 // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
-                // re-symmetrise every 4th stage.  H~' = (H~ as A operand) x I costs four MFMAs, no LDS.
+                // re-symmetrise every 8th stage (growth x550 in between: 1e-16 -> 5e-14).  H~' = (H~ as A operand) x I costs four MFMAs, no LDS.
                 vd4 Tp = W::zero4();
                 for (int c = 0; c < 4; ++c) Tp = mma(Hn.r[c], T.eye[c], Tp);
                 for (int r = 0; r < 4; ++r) Hn.r[r] = (Hn.r[r] + Tp.r[r]) * 0.5;

@@ -40,7 +40,7 @@ def test_nominal_batch_matches_oracle(oracle, qp_mode):
         np.testing.assert_allclose(X, Xo, atol=1e-8)
         np.testing.assert_allclose(U, Uo, atol=1e-8)
         if qp_mode == 0:
-            assert it == 0 and cnt["mfma"] == 6 + 8 * 19 + 20 + 4 * 4 + 4 * 20      # unchanged count: 3 + 3 + 1 + 1 per stage   # prologue 6, 8 per backward stage (19) + K~' (20), 4 re-symmetrisations x 4, 4 per forward stage
+            assert it == 0 and cnt["mfma"] == 6 + 8 * 19 + 20 + 2 * 4 + 4 * 20      # prologue 6, 8 per backward stage (19) + K~' (20), 2 re-symmetrisations x 4, 4 per forward stage
         else:
             assert it == sto.ipm_iters                      # same algorithm, same iteration count
 
