@@ -343,21 +343,24 @@ struct RtiWave {
         const int N = horizon(P);
         vi lane = W::lane();
         const int nx = (N + 1) * NX, nu = N * NU, nf = (N + 1) * 3;
+        // the loads came from clamped indices: lanes past the end hold a copy of the last element and store it to the last
+        // slot again -- an identical duplicate, so no store needs a predicate (a predicated LDS store is an exec-mask
+        // save / branch / restore around it)
         for (int t = 0; t < RX; ++t) {
-            vi i = lane + 64 * t;
-            W::stp(lds, i + m.TXR, b.xr[t], i < nx);
-            if (first) W::stp(lds, i + m.XI, b.xi[t], i < nx);
+            vi i = W::imin(lane + 64 * t, nx - 1);
+            W::st(lds, i + m.TXR, b.xr[t]);
+            if (first) W::st(lds, i + m.XI, b.xi[t]);
         }
         for (int t = 0; t < RU; ++t) {
-            vi i = lane + 64 * t;
-            W::stp(lds, i + m.TUR, b.ur[t], i < nu);
-            if (first) W::stp(lds, i + m.UI, b.ui[t], i < nu);
+            vi i = W::imin(lane + 64 * t, nu - 1);
+            W::st(lds, i + m.TUR, b.ur[t]);
+            if (first) W::st(lds, i + m.UI, b.ui[t]);
         }
         for (int t = 0; t < RF; ++t) {
-            vi i = lane + 64 * t;
-            W::stp(lds, i + m.TF, b.f[t], i < nf);
+            vi i = W::imin(lane + 64 * t, nf - 1);
+            W::st(lds, i + m.TF, b.f[t]);
         }
-        if (first) W::stp(lds, lane + m.KC, b.kc, lane < KC_SC);   // constants area
+        if (first) W::st(lds, W::imin(lane, KC_SC - 1) + m.KC, b.kc);   // constants area
         W::sync();
     }
 
@@ -367,15 +370,16 @@ struct RtiWave {
     {
         const int N = horizon(P);
         vi lane = W::lane();
-        // Three task families, each at most a few 64-lane rounds.  Every LDS read of every round is issued before the
+        // Three task families, each at most a few 64-lane rounds; lanes past a family's last task repeat that task and store
+        // the same values to the same places (no predicates).  Every LDS read of every round is issued before the
         // first result is needed (one wait per family instead of one per round), then computed, then stored.
         constexpr int RA = (4 * (NMAXS + 1) + 63) / 64, RB = (6 * (NMAXS + 1) + 63) / 64, RC = (4 * NMAXS + 63) / 64;
         // (a) quaternion block, one lane per (stage, row a)
         vd qr[RA][4], qi[RA][4];
         vd xb[RB], rb[RB], wb[RB], uc[RC], rc[RC], wc[RC];
         for (int t = 0; t < RA; ++t) {
-            vi task = lane + 64 * t;
-            vi k = W::sel(task < 4 * (N + 1), task >> 2, vi(0));
+            vi task = W::imin(lane + 64 * t, 4 * (N + 1) - 1);
+            vi k = task >> 2;
             for (int i = 0; i < 4; ++i) {
                 qr[t][i] = W::ld(lds, k * NX + (m.TXR + 6 + i));
                 qi[t][i] = W::ld(lds, k * NX + (m.XI + 6 + i));
@@ -383,27 +387,23 @@ struct RtiWave {
         }
         // (b) position / velocity rows, one lane per (stage, i < 6)
         for (int t = 0; t < RB; ++t) {
-            vi task = lane + 64 * t;
-            vb p = task < 6 * (N + 1);
-            vi k = W::sel(p, W::div6(task), vi(0));
-            vi i = W::sel(p, task - k * 6, vi(0));
+            vi task = W::imin(lane + 64 * t, 6 * (N + 1) - 1);
+            vi k = W::div6(task);
+            vi i = task - k * 6;
             wb[t] = W::ld(lds, i + (m.KC + KC_QD));
             xb[t] = W::ld(lds, k * NX + i + m.XI);
             rb[t] = W::ld(lds, k * NX + i + m.TXR);
         }
         // (c) control rows, one lane per (stage < N, i < 4)
         for (int t = 0; t < RC; ++t) {
-            vi task = lane + 64 * t;
-            vb p = task < 4 * N;
-            vi ti = W::sel(p, task, vi(0));
+            vi ti = W::imin(lane + 64 * t, 4 * N - 1);
             wc[t] = W::ld(lds, (ti & 3) + (m.KC + KC_RD));
             uc[t] = W::ld(lds, ti + m.UI);
             rc[t] = W::ld(lds, ti + m.TUR);
         }
         for (int t = 0; t < RA; ++t) {
-            vi task = lane + 64 * t;
-            vb p = task < 4 * (N + 1);
-            vi k = W::sel(p, task >> 2, vi(0));
+            vi task = W::imin(lane + 64 * t, 4 * (N + 1) - 1);
+            vi k = task >> 2;
             vi a = task & 3;
             vd s = W::sel(k < N, vd(P.dt), vd(1.0));
             const vd qwr = qr[t][0], qxr = qr[t][1], qyr = qr[t][2], qzr = qr[t][3];
@@ -419,36 +419,34 @@ struct RtiWave {
             vi cb = k * int(CB_STRIDE) + m.CB;
             for (int b = 0; b < 4; ++b) {
                 vd h = w0 * E0[b] + w1 * E1[b] + w2 * E2[b];
-                W::stp(lds, cb + a * 4 + (int(CB_QQ) + b), h, p);
+                W::st(lds, cb + a * 4 + (int(CB_QQ) + b), h);
                 grad = grad + h * qi[t][b];
             }
-            W::stp(lds, cb + a + (int(CB_QE) + 6), grad, p);
-            W::stp(lds, cb + int(CB_ZERO), vd(0.0), p && (a == 0));     // the block's structural zero
+            W::st(lds, cb + a + (int(CB_QE) + 6), grad);
+            W::st(lds, cb + int(CB_ZERO), vd(0.0));                     // the block's structural zero (all four lanes of the stage)
         }
         for (int t = 0; t < RB; ++t) {
-            vi task = lane + 64 * t;
-            vb p = task < 6 * (N + 1);
-            vi k = W::sel(p, W::div6(task), vi(0));
-            vi i = W::sel(p, task - k * 6, vi(0));
+            vi task = W::imin(lane + 64 * t, 6 * (N + 1) - 1);
+            vi k = W::div6(task);
+            vi i = task - k * 6;
             vd s = W::sel(k < N, vd(P.dt), vd(1.0));
             vd de = s * wb[t];
             vd grad = de * (xb[t] - rb[t]);
             vi cb = k * int(CB_STRIDE) + m.CB;
-            W::stp(lds, cb + i + int(CB_DEX), de, p);
-            W::stp(lds, cb + i + int(CB_QE), grad, p);
-            W::stp(lds, cb + i + (int(CB_QBV) - 3), grad, p && (i >= 3));
+            W::st(lds, cb + i + int(CB_DEX), de);
+            W::st(lds, cb + i + int(CB_QE), grad);
+            W::stp(lds, cb + i + (int(CB_QBV) - 3), grad, i >= 3);
         }
         for (int t = 0; t < RC; ++t) {
-            vi task = lane + 64 * t;
-            vb p = task < 4 * N;
-            vi k = W::sel(p, task >> 2, vi(0));
+            vi task = W::imin(lane + 64 * t, 4 * N - 1);
+            vi k = task >> 2;
             vi i = task & 3;
             vd de = P.dt * wc[t];
             vd grad = de * (uc[t] - rc[t]);
             vi cb = k * int(CB_STRIDE) + m.CB;
-            W::stp(lds, cb + i + int(CB_DEU), de, p);
-            W::stp(lds, cb + i + int(CB_RE), grad, p);
-            W::stp(lds, cb + i + int(CB_RB), grad, p);
+            W::st(lds, cb + i + int(CB_DEU), de);
+            W::st(lds, cb + i + int(CB_RE), grad);
+            W::st(lds, cb + i + int(CB_RB), grad);
         }
     }
 
@@ -512,9 +510,8 @@ struct RtiWave {
         vi lane = W::lane();
         // ---- d/dq columns: one lane per (stage, j), 4N tasks
         for (int t = 0; t < 4 * N; t += 64) {
-            vi task = lane + t;
-            vb p = task < 4 * N;
-            vi k = W::sel(p, task >> 2, vi(0));
+            vi task = W::imin(lane + t, 4 * N - 1);       // lanes past the last task repeat it: identical duplicate stores, no predicates
+            vi k = task >> 2;
             vi j = task & 3;
             vi xi = k * NX + m.XI + 6, ui = k * NU + m.UI;
             vd q[4] = {W::ld(lds, xi), W::ld(lds, xi + 1), W::ld(lds, xi + 2), W::ld(lds, xi + 3)};
@@ -533,18 +530,17 @@ struct RtiWave {
             }
             vi mb = k * int(MB_STRIDE) + m.MB + j;
             thrust_dir_tan(q, Uv, t1); thrust_dir_tan(r, Vv, t2);
-            for (int i = 0; i < 3; ++i) W::stp(lds, mb + (int(MB_PV) + (3 + i) * 8), (t1[i] + t2[i]) * c, p);
+            for (int i = 0; i < 3; ++i) W::st(lds, mb + (int(MB_PV) + (3 + i) * 8), (t1[i] + t2[i]) * c);
             thrust_dir_tan(q, Up, t1); thrust_dir_tan(r, Vp, t2);
-            for (int i = 0; i < 3; ++i) W::stp(lds, mb + (int(MB_PV) + i * 8), (t1[i] + t2[i]) * c, p);
-            for (int i = 0; i < 4; ++i) W::stp(lds, mb + (int(MB_Q) + i * 7), e[i] * K.A + z[i] * K.B, p);
+            for (int i = 0; i < 3; ++i) W::st(lds, mb + (int(MB_PV) + i * 8), (t1[i] + t2[i]) * c);
+            for (int i = 0; i < 4; ++i) W::st(lds, mb + (int(MB_Q) + i * 7), e[i] * K.A + z[i] * K.B);
         }
         // ---- d/dw columns: one lane per (stage, mth rate), 3N tasks.  d q_i = eps (a_i' q + b_i' r) + b_i g,
         //      eps = w_m/2 = d sigma/d w_m, g = Z_m q; only a_3' = -h^2/4, a_4' = -h^2/2, b_4' = -h^3/4 are non-zero
         for (int t = 0; t < 3 * N; t += 64) {
-            vi task = lane + t;
-            vb p = task < 3 * N;
-            vi k = W::sel(p, W::div3(task), vi(0));
-            vi mm = W::sel(p, task - k * 3, vi(0));
+            vi task = W::imin(lane + t, 3 * N - 1);
+            vi k = W::div3(task);
+            vi mm = task - k * 3;
             vi xi = k * NX + m.XI + 6, ui = k * NU + m.UI;
             vd q[4] = {W::ld(lds, xi), W::ld(lds, xi + 1), W::ld(lds, xi + 2), W::ld(lds, xi + 3)};
             vd w[3] = {W::ld(lds, ui), W::ld(lds, ui + 1), W::ld(lds, ui + 2)};
@@ -572,21 +568,19 @@ struct RtiWave {
             }
             vi mb = k * int(MB_STRIDE) + m.MB + 4 + mm;
             thrust_dir_tan(q, Uv, t1); thrust_dir_tan(r, Vv, t2);
-            for (int i = 0; i < 3; ++i) W::stp(lds, mb + (int(MB_PV) + (3 + i) * 8), (t1[i] + t2[i]) * c, p);
+            for (int i = 0; i < 3; ++i) W::st(lds, mb + (int(MB_PV) + (3 + i) * 8), (t1[i] + t2[i]) * c);
             thrust_dir_tan(q, Up, t1); thrust_dir_tan(r, Vp, t2);
-            for (int i = 0; i < 3; ++i) W::stp(lds, mb + (int(MB_PV) + i * 8), (t1[i] + t2[i]) * c, p);
-            for (int i = 0; i < 4; ++i) W::stp(lds, mb + (int(MB_Q) + i * 7), (q[i] * dA + r[i] * dB) * eps + g[i] * K.B, p);
+            for (int i = 0; i < 3; ++i) W::st(lds, mb + (int(MB_PV) + i * 8), (t1[i] + t2[i]) * c);
+            for (int i = 0; i < 4; ++i) W::st(lds, mb + (int(MB_Q) + i * 7), (q[i] * dA + r[i] * dB) * eps + g[i] * K.B);
         }
         // ---- d/dc column + nominal step and dynamics defect b_k = phi(x_k,u_k) - x_{k+1}; one lane per stage
         for (int t = 0; t < N; t += 64) {
-            vi task = lane + t;
-            vb p = task < N;
-            vi k = W::sel(p, task, vi(0));
+            vi k = W::imin(lane + t, N - 1);
             {   // the block's structural constants 0, 1, h (entries of M~ that are the same at every stage)
                 vi mc = k * int(MB_STRIDE) + m.MB;
-                W::stp(lds, mc + int(MB_ZERO), vd(0.0), p);
-                W::stp(lds, mc + int(MB_ONE), vd(1.0), p);
-                W::stp(lds, mc + int(MB_H), vd(P.dt), p);
+                W::st(lds, mc + int(MB_ZERO), vd(0.0));
+                W::st(lds, mc + int(MB_ONE), vd(1.0));
+                W::st(lds, mc + int(MB_H), vd(P.dt));
             }
             vi xi = k * NX + m.XI, ui = k * NU + m.UI, fi = k * 3 + m.TF;
             vd x[10];
@@ -608,14 +602,14 @@ struct RtiWave {
                 const double e3 = i == 2 ? 1.0 : 0.0;
                 vd Dv = (tqq[i] * K.Sv_aa + tqr[i] * (K.Sv_ab * 2.0) + trr[i] * K.Sv_bb) * 0.5 + e3 * h;
                 vd Dp = (tqq[i] * K.Sp_aa + tqr[i] * (K.Sp_ab * 2.0) + trr[i] * K.Sp_bb) * 0.5 + e3 * (0.5 * h2);
-                W::stp(lds, mb + (int(MB_PV) + (3 + i) * 8 + 7), Dv, p);      // column 7 = d/dc
-                W::stp(lds, mb + (int(MB_PV) + i * 8 + 7), Dp, p);
+                W::st(lds, mb + (int(MB_PV) + (3 + i) * 8 + 7), Dv);      // column 7 = d/dc
+                W::st(lds, mb + (int(MB_PV) + i * 8 + 7), Dp);
                 vd vn = x[3 + i] + Dv * c + acc[i] * h;
                 vd pn = x[i] + x[3 + i] * h + Dp * c + acc[i] * (0.5 * h2);
-                W::stp(lds, mb + (int(MB_B) + 3 + i), vn - xn1[3 + i], p);
-                W::stp(lds, mb + (int(MB_B) + i), pn - xn1[i], p);
+                W::st(lds, mb + (int(MB_B) + 3 + i), vn - xn1[3 + i]);
+                W::st(lds, mb + (int(MB_B) + i), pn - xn1[i]);
             }
-            for (int i = 0; i < 4; ++i) W::stp(lds, mb + (int(MB_B) + 6 + i), q[i] * K.A + r[i] * K.B - xn1[6 + i], p);
+            for (int i = 0; i < 4; ++i) W::st(lds, mb + (int(MB_B) + 6 + i), q[i] * K.A + r[i] * K.B - xn1[6 + i]);
         }
     }
 
