@@ -906,8 +906,8 @@ struct RtiWave {
             vb v = S.valid[s];
             S.tl[s] = W::sel(v, W::vmax(-S.lo[s], vd(P.thr0)), vd(1.0));
             S.tu[s] = W::sel(v, W::vmax(S.hi[s], vd(P.thr0)), vd(1.0));
-            S.ll[s] = W::sel(v, P.mu0 / S.tl[s], vd(0.0));
-            S.lu[s] = W::sel(v, P.mu0 / S.tu[s], vd(0.0));
+            S.ll[s] = W::sel(v, W::rcp(S.tl[s]) * P.mu0, vd(0.0));     // reciprocals (v_rcp_f64 + Newton), not IEEE divides:
+            S.lu[s] = W::sel(v, W::rcp(S.tu[s]) * P.mu0, vd(0.0));     // a divide is ~30 VALU instructions, the loop had 14 per slot
             S.dtl[s] = 0.0; S.dtu[s] = 0.0; S.dll[s] = 0.0; S.dlu[s] = 0.0;
             musum = musum + S.ll[s] * S.tl[s] + S.lu[s] * S.tu[s];
             nrm = W::vmax(nrm, W::vmax(S.ll[s], S.lu[s]));
@@ -938,9 +938,10 @@ struct RtiWave {
                 for (int s = 0; s < NSLOT; ++s) {
                     vd sl = pass ? vd(sigma_mu) - S.dll[s] * S.dtl[s] : vd(0.0);
                     vd su = pass ? vd(sigma_mu) - S.dlu[s] * S.dtu[s] : vd(0.0);
-                    vd gl = S.ll[s] / S.tl[s], gu = S.lu[s] / S.tu[s];
+                    vd rtl = W::rcp(S.tl[s]), rtu = W::rcp(S.tu[s]);
+                    vd gl = S.ll[s] * rtl, gu = S.lu[s] * rtu;
                     vd Gam = gl + gu;
-                    vd gam = -sl / S.tl[s] - S.ll[s] - gl * S.lo[s] + su / S.tu[s] + S.lu[s] - gu * S.hi[s];
+                    vd gam = -sl * rtl - S.ll[s] - gl * S.lo[s] + su * rtu + S.lu[s] - gu * S.hi[s];
                     vd dbase = P.dt * W::ld(lds, S.dw_off[s]);
                     W::stp(lds, S.de_off[s], dbase + Gam, S.valid[s]);
                     W::stp(lds, S.ge_off[s], W::ld(lds, S.gb_off[s]) + gam, S.valid[s]);
@@ -954,15 +955,18 @@ struct RtiWave {
                     vd sl = pass ? vd(sigma_mu) - S.dll[s] * S.dtl[s] : vd(0.0);
                     vd su = pass ? vd(sigma_mu) - S.dlu[s] * S.dtu[s] : vd(0.0);
                     vd dtl = zn - S.lo[s] - S.tl[s], dtu = S.hi[s] - zn - S.tu[s];
-                    vd dll = sl / S.tl[s] - S.ll[s] - S.ll[s] / S.tl[s] * dtl;
-                    vd dlu = su / S.tu[s] - S.lu[s] - S.lu[s] / S.tu[s] * dtu;
+                    vd rtl = W::rcp(S.tl[s]), rtu = W::rcp(S.tu[s]);
+                    vd dll = sl * rtl - S.ll[s] - S.ll[s] * rtl * dtl;
+                    vd dlu = su * rtu - S.lu[s] - S.lu[s] * rtu * dtu;
                     dtl = W::sel(v, dtl, vd(0.0)); dtu = W::sel(v, dtu, vd(0.0));
                     dll = W::sel(v, dll, vd(0.0)); dlu = W::sel(v, dlu, vd(0.0));
                     S.dtl[s] = dtl; S.dtu[s] = dtu; S.dll[s] = dll; S.dlu[s] = dlu;
-                    amin = W::vmin(amin, W::sel(dtl < 0.0, -S.tl[s] / dtl, vd(1.0)));
-                    amin = W::vmin(amin, W::sel(dtu < 0.0, -S.tu[s] / dtu, vd(1.0)));
-                    amin = W::vmin(amin, W::sel(dll < 0.0, -S.ll[s] / dll, vd(1.0)));
-                    amin = W::vmin(amin, W::sel(dlu < 0.0, -S.lu[s] / dlu, vd(1.0)));
+                    // ratio test: lanes whose direction does not shrink the variable see a clamped denominator (-1) and are
+                    // discarded by the select, so no reciprocal of zero is formed
+                    amin = W::vmin(amin, W::sel(dtl < 0.0, -S.tl[s] * W::rcp(W::vmin(dtl, vd(-1e-300))), vd(1.0)));
+                    amin = W::vmin(amin, W::sel(dtu < 0.0, -S.tu[s] * W::rcp(W::vmin(dtu, vd(-1e-300))), vd(1.0)));
+                    amin = W::vmin(amin, W::sel(dll < 0.0, -S.ll[s] * W::rcp(W::vmin(dll, vd(-1e-300))), vd(1.0)));
+                    amin = W::vmin(amin, W::sel(dlu < 0.0, -S.lu[s] * W::rcp(W::vmin(dlu, vd(-1e-300))), vd(1.0)));
                 }
                 double alpha = W::wave_min(amin);
                 if (pass == 0) {
