@@ -1095,16 +1095,9 @@ struct RtiWave {
                 Slots S;
                 build_slots(P, m, S);
                 load_bounds(m, S, lds);
-                done = strictly_inside(S, lds, P.auto_margin) || !ok;
-                if (done) {
-                    for (int t = 0; t < nzx + nzu; t += 64) {
-                        vi i = lane + t;
-                        vb p = i < nzx + nzu;
-                        W::stp(lds, i + m.CX, W::ldp(lds, i + m.ZX, p), p);
-                    }
-                    W::sync();
-                }
+                done = strictly_inside(S, lds, P.auto_margin) || !ok;   // then the step is the sweep's solution, read where it lies (ZX|ZU)
             }
+            const int zsrc = done ? m.ZX : m.CX;       // ZX|ZU and CX|CU are laid out alike
             if (!done) {
                 Slots S;
                 build_slots(P, m, S);
@@ -1122,17 +1115,16 @@ struct RtiWave {
                 for (int t = 0; t < RZ; ++t) {
                     vi i = W::imin(lane + 64 * t, nzx + nzu - 1);
                     xa[t] = W::ld(lds, i + m.XI);
-                    xc[t] = W::ld(lds, i + m.CX);
+                    xc[t] = W::ld(lds, i + zsrc);
                 }
                 for (int t = 0; t < RZ; ++t) {
-                    vi i = lane + 64 * t;
-                    vb p = i < nzx + nzu;
+                    // lanes past the end repeat the last element: identical duplicate stores, no predicates
+                    vi i = W::imin(lane + 64 * t, nzx + nzu - 1);
                     vd xn = xa[t] + xc[t];
-                    W::stp(lds, i + m.XI, xn, p);
+                    W::st(lds, i + m.XI, xn);
                     if (last) {
                         // X and U are separate global arrays: element i < nzx goes to X[i], else to U[i - nzx]
-                        W::gst(io.X, i, xn, i < nzx);
-                        W::gst(io.U, i - nzx, xn, p && (i >= nzx));
+                        W::gst2(io.X, io.U, i, nzx, xn);
                         if (t == (nzx >> 6)) {   // the round that holds u_0 = U[0..3] (wave-uniform test)
                             vb pu = (i >= nzx) && (i < nzx + NU);
                             W::gst(io.u0, i - nzx, xn, pu);

@@ -49,6 +49,8 @@ struct WaveGfx950 {
     static NDP_D vi gldi(const int *g, vi off) { return g[off]; }
     static NDP_D vi imin(vi a, vi b) { return a < b ? a : b; }
     static NDP_D void gst(double *g, vi off, vd v, vb p) { if (p) g[off] = v; }
+    // element i of the concatenation [a (n elements) | b]: one store through a per-lane pointer instead of two predicated ones
+    static NDP_D void gst2(double *a, double *b, vi i, int n, vd v) { (i < n ? a + i : b + (i - n))[0] = v; }
     static NDP_D void gsti(int *g, int v) { if (g && lane() == 0) *g = v; }
 
     // 1/a: v_rcp_f64 seed + two Newton steps (a full IEEE divide is ~100 dependent cycles on gfx950)

@@ -100,6 +100,7 @@ struct Wave {
     static vd gldfu(const float *g, const vi &off) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)g[off.v[l]]; return o; }
     static vi gldi(const int *g, const vi &off) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = g[off.v[l]]; return o; }
     static vi imin(const vi &a, const vi &b) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return o; }
+    static void gst2(double *a, double *b, const vi &i, int n, const vd &val) { for (int l = 0; l < 64; ++l) (i.v[l] < n ? a + i.v[l] : b + (i.v[l] - n))[0] = val.v[l]; }
     static void gsti(int *g, int val) { if (g) *g = val; }
 
     static vd clock() { return vd(0.0); }
