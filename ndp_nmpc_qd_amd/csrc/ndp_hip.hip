@@ -62,7 +62,7 @@ __device__ __forceinline__ bool gate_open(const double *other_inst, const double
 // FUSED: the wave first predicts its own instance's disturbance force (gate + MLP over the N+1 <= 32 horizon rows,
 // one 32x32 f32 MFMA tile) and leaves it in the LDS staging slot the RTI program reads f from -- no second
 // launch and no trip of f through HBM.
-template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0>
+template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0)>
 __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs bp, int B, int lds_per_wave, MlpArgs ma)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
     io.stamps = bp.stamps ? bp.stamps + (size_t)inst * 16 : nullptr;
     const int lpw = NC ? ((lds_doubles(NC) + 1) & ~1) : lds_per_wave;
     WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lpw);
-    using Prog = RtiWave<WaveGfx950, NSLOT, NC, true, NC ? 1 : 0, PREC>;   // the compile-time-horizon form is also the 1-iteration form
+    using Prog = RtiWave<WaveGfx950, NSLOT, NC, true, NRC, PREC>;   // compile-time horizon and iteration count (NC = 0: both at run time)
     typename Prog::InBuf inb;
     double x0v;
     Prog::issue_first(P, io, inb, x0v);      // every global input of the RTI step is now in flight (hidden under the MLP when fused)
@@ -867,7 +867,8 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
                          (const void *)rti_kernel<5, 4, false>, (const void *)rti_kernel<5, 2, false>, (const void *)rti_kernel<5, 1, false>,
                          (const void *)rti_kernel<3, 4, true>, (const void *)rti_kernel<3, 2, true>, (const void *)rti_kernel<3, 1, true>,
                          (const void *)rti_kernel<3, 4, false, 20>, (const void *)rti_kernel<3, 4, true, 20>,
-                         (const void *)rti_kernel<5, 1, false, 0, 1>, (const void *)rti_kernel<5, 1, false, 0, 2>};
+                         (const void *)rti_kernel<5, 1, false, 0, 1>, (const void *)rti_kernel<5, 1, false, 0, 2>,
+                         (const void *)rti_kernel<5, 2, false, 40, 0, 2>};
     if ((e = hipFuncSetAttribute((const void *)mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(FR_TOTAL * sizeof(float)))) != hipSuccess)
         return fail("hipFuncSetAttribute(mlp_kernel)", e);
@@ -952,6 +953,8 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     if (h->cfg.N == 20 && h->cfg.n_rti == 1 && W == 4) {   // the reference configuration (params/nmpc_params.py:9, 1 RTI iteration): compile-time instantiation
         if (d_other) hipLaunchKernelGGL((rti_kernel<3, 4, true, 20>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma);
         else hipLaunchKernelGGL((rti_kernel<3, 4, false, 20>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma);
+    } else if (h->cfg.N == 40 && h->cfg.n_rti == 2 && W == 2 && !d_other) {   // BASELINE config 5's shape, compile-time as well
+        hipLaunchKernelGGL((rti_kernel<5, 2, false, 40, 0, 2>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma);
     } else if (d_other) { if (W == 4) LAUNCH(3, 4, true); else if (W == 2) LAUNCH(3, 2, true); else LAUNCH(3, 1, true); }
     else if (ns <= 3) { if (W == 4) LAUNCH(3, 4, false); else if (W == 2) LAUNCH(3, 2, false); else LAUNCH(3, 1, false); }
     else { if (W == 4) LAUNCH(5, 4, false); else if (W == 2) LAUNCH(5, 2, false); else LAUNCH(5, 1, false); }
