@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--workload", default="ndp_downwash", choices=["ndp_downwash", "nmpc"])
     ap.add_argument("--qp-mode", type=int, default=0, help="0 auto (exact early exit), 1 interior point always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--placement", default="vehicle", choices=["vehicle", "formation"],
+                    help="N > 1: vehicle-major (a formation's vehicles on different GPUs: one all-gather per step, the default) "
+                         "or formation-major (all vehicles of a formation on one GPU: no exchange)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of replaying a hipGraph (N = 1)")
     ap.add_argument("--cpu-passes", type=int, default=200)
     args = ap.parse_args()
@@ -117,16 +120,17 @@ def main():
     # tick i's kernel is launched and runs on RCCL's stream beside it -- one all-gather and one kernel per step, overlapped
     gathered = [torch.empty(world, B, N + 1, 10, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
     pending = {}
+    exchange = world > 1 and args.placement == "vehicle"
 
     def prefetch(i):
-        if downwash and world > 1:
+        if downwash and exchange:
             pending[i] = ndist.exchange_neighbours_begin(ticks[i % T]["xr"], gathered[i % 2])   # one RCCL all-gather over xGMI
 
     def step(i):
         d = ticks[i % T]
         other = None
         if downwash:
-            if world > 1:
+            if exchange:
                 if i not in pending:
                     prefetch(i)
                 other = ndist.exchange_neighbours_end(pending.pop(i), gathered[i % 2])
@@ -167,7 +171,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    if downwash and world > 1:                # the first timed tick's windows are in place before the clock starts; every
+    if downwash and exchange:                 # the first timed tick's windows are in place before the clock starts; every
         prefetch(args.warmup)                 # timed step then starts exactly one gather (the next tick's) and one kernel
         pending[args.warmup].wait()
         torch.cuda.synchronize()
@@ -177,7 +181,7 @@ def main():
     # predecessor ends, a host launch 2.6 us (scripts/ubench/launch_floor.hip).  The graph holds G = a multiple of T steps
     # (at most 256); every step still runs: K // G replays plus K % G host launches.  N > 1 keeps host launches (the step also starts an RCCL all-gather).
     graph, launch_mode = None, "host launch per step"
-    if world == 1 and not args.no_graph and args.steps >= T:
+    if not exchange and not args.no_graph and args.steps >= T:
         try:
             base = ((args.warmup + T - 1) // T) * T          # a multiple of T: the replayed cycle starts at tick 0
             G = min(256, args.steps) // T * T
@@ -247,7 +251,7 @@ def main():
             "config": {"workload": f"batch={B}/GPU independent quadrotors, N={N}, 1 RTI iter, "
                                    + ("MLP downwash on (NDP controller, gate+MLP fused into the RTI launch)" if fused else
                                       "MLP downwash on (NDP controller)" if downwash else "no downwash (NMPC controller)")
-                                   + (", neighbour windows all-gathered over RCCL" if world > 1 else ""),
+                                   + (", neighbour windows all-gathered over RCCL" if exchange else ", formation-major placement (no exchange)" if world > 1 else ""),
                        "batch_per_gpu": B, "horizon": N, "n_rti": 1, "qp_mode": "auto" if args.qp_mode == 0 else "ipm_always",
                        "launch": launch_mode,
                        "parallelism": f"instances sharded x{world}"},
