@@ -179,7 +179,8 @@ def main():
     # N = 1: the K timed steps are a launch-bound chain of dependent kernels -> one cycle through the T input ticks is
     # captured into a hipGraph (T kernel nodes) and replayed; a node of a replayed graph starts 1.6 us after its
     # predecessor ends, a host launch 2.6 us (scripts/ubench/launch_floor.hip).  The graph holds G = a multiple of T steps
-    # (at most 256); every step still runs: K // G replays plus K % G host launches.  N > 1 keeps host launches (the step also starts an RCCL all-gather).
+    # (at most 256); every step still runs: K // G replays plus K % G host launches.  With the
+    # neighbour exchange on (N > 1, vehicle-major) steps are launched from the host: each also starts an RCCL all-gather.
     graph, launch_mode = None, "host launch per step"
     if not exchange and not args.no_graph and args.steps >= T:
         try:
