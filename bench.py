@@ -9,9 +9,12 @@ Workload (BASELINE.json metric / configs[2]): per GPU batch = 1024 independent q
 1 SQP-RTI iteration per step + the downwash MLP (NDP controller), inputs resident in HBM.
 A "step" is one control tick of the whole batch: [all-gather of neighbour windows when N > 1] ->
 rti_kernel (gate + MLP fused in front of linearise, QP, full step).  Weak scaling: the per-GPU batch is fixed.
-Prints ONE JSON line on rank 0.
+`--config 4` is BASELINE configs[3]: 4096 three-vehicle formations (12 288 instances) split over the GPUs (strong scaling).
+Prints ONE JSON line on rank 0.  Exit code 1 (and "value": null) if the parity spot check fails or instances did not converge.
 """
 import argparse
+import csv
+import glob
 import json
 import os
 import sys
@@ -24,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, datasheet; v_mfma_f64_16x16x4 = 2048 FLOP / 64 clk / SIMD
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+PROFILE_TAG = "r02"           # profiles/<tag>_kernel_stats.csv, <tag>_pmc_rti_kernel.json belong to the default configuration
 
 
 def algorithmic_flops_per_solve(N, sweeps, downwash):
@@ -40,16 +44,27 @@ def algorithmic_bytes_per_solve(N, downwash):
     return b
 
 
-def measured_traffic(B, N, fused):
-    """HBM bytes per rti_kernel launch from the committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE runs
-    of this same command; KB units; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  None if the
-    profiled configuration differs from the one being run."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_rti_kernel_fused_b1024.json")
-    if not (fused and B == 1024 and N == 20 and os.path.exists(path)):
-        return None
-    with open(path) as fh:
-        pmc = json.load(fh)
-    return (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
+def committed_profile(default_cfg):
+    """What the committed rocprofv3 summaries say about the default configuration's rti_kernel: average duration
+    (kernel trace) and HBM bytes per launch (separate FETCH_SIZE / WRITE_SIZE passes; KB units; FETCH_SIZE doubled per the
+    gfx950 note in MI355X_MICROARCH.md).  None when the running configuration is not the profiled one."""
+    out = {"kernel_us": None, "traffic": None, "wave_cycles_per_simd": None}
+    if not default_cfg:
+        return out
+    for path in glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "_kernel_stats*.csv")):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if "rti_kernel" in row.get("Name", "") and "true, 20" in row.get("Name", "").replace("(bool)1", "true"):
+                    out["kernel_us"] = float(row["AverageNs"]) / 1e3
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_rti_kernel.json")
+    if os.path.exists(path):
+        with open(path) as fh:
+            pmc = json.load(fh)
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            out["traffic"] = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
+        if "SQ_WAVE_CYCLES" in pmc and "SQ_WAVES" in pmc:
+            out["wave_cycles_per_simd"] = 4.0 * pmc["SQ_WAVE_CYCLES"]["mean"] / pmc["SQ_WAVES"]["mean"]   # quad-cycles -> cycles
+    return out
 
 
 def effective_cores():
@@ -73,13 +88,24 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--workload", default="ndp_downwash", choices=["ndp_downwash", "nmpc"])
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4],
+                    help="BASELINE.json configs[] (1-based): 3 = batch of independent quadrotors (the metric's configuration), "
+                         "4 = 4096 three-vehicle formations split over the GPUs")
+    ap.add_argument("--formations", type=int, default=4096, help="--config 4: number of three-vehicle formations (whole job)")
     ap.add_argument("--qp-mode", type=int, default=0, help="0 auto (exact early exit), 1 interior point always")
+    ap.add_argument("--work-queue", type=int, default=0, help="0 automatic, 1 on, 2 off (ndp_cfg.work_queue)")
+    ap.add_argument("--perturb", default="nominal", choices=["nominal", "mixed"],
+                    help="mixed: 0.5 m / 1 m/s / 0.15 initial errors, ~20 %% of the instances need the interior-point loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-timed", action="store_true",
+                    help="no parity check, no extra legs: just warm-up + the timed steps (profiling runs: nothing but the kernel)")
     ap.add_argument("--placement", default="vehicle", choices=["vehicle", "formation"],
-                    help="N > 1: vehicle-major (a formation's vehicles on different GPUs: one all-gather per step, the default) "
-                         "or formation-major (all vehicles of a formation on one GPU: no exchange)")
-    ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of replaying a hipGraph (N = 1)")
-    ap.add_argument("--cpu-passes", type=int, default=200)
+                    help="N > 1 (and --config 4): vehicle-major (a formation's vehicles on different GPUs: one all-gather per step, "
+                         "the default) or formation-major (all vehicles of a formation on one GPU: no exchange)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of replaying a hipGraph")
+    ap.add_argument("--graph-exchange", action="store_true",
+                    help="N > 1 with the exchange on: capture gather + kernel of every step into the hipGraph too (default: host launches)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: bounded sample, about this many seconds")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,104 +126,162 @@ def main():
 
     import ndp_nmpc_qd_amd as ndp
     from ndp_nmpc_qd_amd import dist as ndist
+    from ndp_nmpc_qd_amd import synth
 
-    B, N = args.batch, args.horizon
-    downwash = args.workload == "ndp_downwash"
+    N = args.horizon
+    cfg4 = args.config == 4
+    downwash = args.workload == "ndp_downwash" or cfg4
     T = 8  # distinct control ticks cycled through (reference window slides by ts_nmpc = 0.02 s per tick)
+    mixed_kw = dict(pos_sigma=0.5, vel_sigma=1.0, quat_sigma=0.15)
+
+    def make_tick(B, t0, perturb):
+        if cfg4:
+            return ndist.make_config4_shard(rank, world, args.formations, args.placement, N=N, t0=t0)
+        if perturb == "mixed":
+            return synth.make_batch(B, N=N, seed=synth.SEED0 + 40 + rank, downwash=True, t0=t0, **mixed_kw)
+        return ndist.make_formation_shard(B, rank, world, N=N, t0=t0)
+
+    B = ndist.config4_gids(rank, world, args.formations, args.placement)[1] if cfg4 else args.batch
+    keys = ("x0", "xr", "ur", "ego_xy") + (("other_index",) if cfg4 else ("other",))
     ticks = []
     for t in range(T):
-        b = ndist.make_formation_shard(B, rank, world, N=N, t0=0.02 * t)
-        ticks.append({k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur", "other", "ego_xy")})
-    host0 = ndist.make_formation_shard(B, rank, world, N=N, t0=0.0)
+        b = make_tick(B, 0.02 * t, args.perturb)
+        ticks.append({k: torch.from_numpy(b[k]).to(dev) for k in keys})
+    host0 = make_tick(B, 0.0, args.perturb)
 
-    eng = ndp.BatchedNMPC(B, N=N, disturbance=downwash, qp_mode=args.qp_mode, device=local_rank)
+    eng = ndp.BatchedNMPC(B, N=N, disturbance=downwash, qp_mode=args.qp_mode, device=local_rank, work_queue=args.work_queue)
     # an explicit non-default stream: torch's default stream has handle 0, which the C-ABI reads as "use the
     # library's own stream" -- with a real handle the all-gather (N > 1) and the kernel are ordered on ONE stream
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     u0 = torch.empty(B, 4, dtype=torch.float64, device=dev)
-    # N > 1: two gather buffers; the all-gather of tick i+1's reference windows (functions of time only) is started before
-    # tick i's kernel is launched and runs on RCCL's stream beside it -- one all-gather and one kernel per step, overlapped
-    gathered = [torch.empty(world, B, N + 1, 10, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    # Neighbour exchange.  config 3, N > 1 (vehicle-major ring of ranks): all-gather of the ranks' xr windows, rank r reads
+    # rank r+1's slice.  config 4, vehicle-major: all-gather of the [B, N+1, 6] position/velocity columns, the kernel picks
+    # each leader's neighbour row through other_index.  Two gather buffers: the gather of tick i+1's windows (functions of
+    # time only) is started before tick i's kernel is launched and runs on RCCL's stream beside it.
+    exchange = downwash and args.placement == "vehicle" and (world > 1 or cfg4)
+    if cfg4 and exchange:
+        gathered = [torch.empty(world * B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev) for _ in range(2)]
+        pv_local = torch.empty(B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev)
+    elif exchange:
+        gathered = [torch.empty(world, B, N + 1, 10, dtype=torch.float64, device=dev) for _ in range(2)]
     pending = {}
-    exchange = world > 1 and args.placement == "vehicle"
 
     def prefetch(i):
-        if downwash and exchange:
+        if not exchange:
+            return
+        if cfg4:
+            pending[i] = ndist.exchange_pv_begin(ticks[i % T]["xr"], pv_local, gathered[i % 2])
+        else:
             pending[i] = ndist.exchange_neighbours_begin(ticks[i % T]["xr"], gathered[i % 2])   # one RCCL all-gather over xGMI
 
-    def step(i):
+    def step(i, e=None):
+        e = e or eng
         d = ticks[i % T]
-        other = None
+        other, oidx = None, None
         if downwash:
             if exchange:
                 if i not in pending:
                     prefetch(i)
-                other = ndist.exchange_neighbours_end(pending.pop(i), gathered[i % 2])
+                if cfg4:
+                    ndist.exchange_pv_end(pending.pop(i))
+                    other, oidx = gathered[i % 2], d["other_index"]
+                else:
+                    other = ndist.exchange_neighbours_end(pending.pop(i), gathered[i % 2])
                 prefetch(i + 1)
+            elif cfg4:
+                other, oidx = d["xr"], d["other_index"]      # formation-major: the neighbour's window is a local row of xr
             else:
                 other = d["other"]
-        eng.update_device(d["x0"], d["xr"], d["ur"], u0, other=other, ego_xy=d["ego_xy"] if downwash else None,
-                          stream=stream)
+        e.update_device(d["x0"], d["xr"], d["ur"], u0, other=other, ego_xy=d["ego_xy"] if downwash else None,
+                        stream=stream, other_index=oidx)
 
     def fence():
         for w in list(pending.values()):      # a gather started for a tick that is never solved (end of a phase)
-            w.wait()
+            if w is not None:
+                w.wait()
         pending.clear()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def host_other(h):
+        """The neighbour windows of the host copy of tick 0 (oracle legs)."""
+        if not cfg4:
+            return h["other"]
+        allv = ndist.make_config4_all(args.formations, N=N, t0=0.0)
+        nb = np.where(h["gids"] % 3 == 0, h["gids"] + 1, h["gids"])
+        oth = allv["xr"][nb].copy()
+        return oth
+
     # ---- parity spot check against the CPU oracle (rank 0, first tick, 64 instances) before timing
     parity = None
     eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
-    step(0)
-    torch.cuda.synchronize()
-    if rank == 0:
-        from oracle import oracle as O
-        ns = min(64, B)
-        cfgo = O.default_cfg(N=N, use_fd=downwash)
-        f = None
-        if downwash:
-            blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
-            f = O.downwash_batch(blob, host0["other"][:ns], host0["xr"][:ns], host0["ego_xy"][:ns])
-        Xo, Uo = host0["xr"][:ns].copy(), host0["ur"][:ns].copy()
-        u_or, st_or, _ = O.step_batch(cfgo, host0["x0"][:ns], host0["xr"][:ns], host0["ur"][:ns], f, Xo, Uo)
-        u_dev = u0[:ns].cpu().numpy()
-        parity = float(np.max(np.abs(u_dev - u_or) / np.maximum(1.0, np.abs(u_or))))
+    if not args.only_timed:
+        step(0)
+        fence()
+        if rank == 0:
+            from oracle import oracle as O
+            ns = min(64, B)
+            cfgo = O.default_cfg(N=N, use_fd=downwash)
+            f = None
+            if downwash:
+                blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
+                ego = host0["ego_xy"][:ns].copy()
+                if cfg4:
+                    ego[host0["other_index"][:ns] < 0] = 1e9       # followers: no neighbour, gate closed
+                f = O.downwash_batch(blob, host_other(host0)[:ns], host0["xr"][:ns], ego)
+            Xo, Uo = host0["xr"][:ns].copy(), host0["ur"][:ns].copy()
+            u_or, st_or, _ = O.step_batch(cfgo, host0["x0"][:ns], host0["xr"][:ns], host0["ur"][:ns], f, Xo, Uo)
+            u_dev = u0[:ns].cpu().numpy()
+            parity = float(np.max(np.abs(u_dev - u_or) / np.maximum(1.0, np.abs(u_or))))
 
     # ---- warm-up, then EXACTLY --steps timed steps between barrier + synchronize
     eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
     for i in range(args.warmup):
         step(i)
     fence()
-    if downwash and exchange:                 # the first timed tick's windows are in place before the clock starts; every
+    if exchange:                              # the first timed tick's windows are in place before the clock starts; every
         prefetch(args.warmup)                 # timed step then starts exactly one gather (the next tick's) and one kernel
-        pending[args.warmup].wait()
+        if pending[args.warmup] is not None:
+            pending[args.warmup].wait()
         torch.cuda.synchronize()
-        dist.barrier()
-    # N = 1: the K timed steps are a launch-bound chain of dependent kernels -> one cycle through the T input ticks is
-    # captured into a hipGraph (T kernel nodes) and replayed; a node of a replayed graph starts 1.6 us after its
-    # predecessor ends, a host launch 2.6 us (scripts/ubench/launch_floor.hip).  The graph holds G = a multiple of T steps
-    # (at most 256); every step still runs: K // G replays plus K % G host launches.  With the
-    # neighbour exchange on (N > 1, vehicle-major) steps are launched from the host: each also starts an RCCL all-gather.
+        if world > 1:
+            dist.barrier()
+    # The K timed steps are a launch-bound chain of dependent kernels -> one cycle through the T input ticks is captured into
+    # a hipGraph (T kernel nodes) and replayed; a node of a replayed graph starts 1.6 us after its predecessor ends, a host
+    # launch 2.6 us (scripts/ubench/launch_floor.hip).  The graph holds G = a multiple of T steps (at most 256); every step
+    # still runs: K // G replays plus K % G host launches.  With the neighbour exchange on, steps are launched from the host
+    # by default (each also starts an RCCL all-gather); --graph-exchange captures gather + kernel as well.
     graph, launch_mode = None, "host launch per step"
-    if not exchange and not args.no_graph and args.steps >= T:
+    want_graph = not args.no_graph and args.steps >= T and (not exchange or args.graph_exchange or world == 1)
+    if want_graph:
         try:
             base = ((args.warmup + T - 1) // T) * T          # a multiple of T: the replayed cycle starts at tick 0
             G = min(256, args.steps) // T * T
+            fence()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream, capture_error_mode="relaxed"):
                 for i in range(G):
                     step(base + i)
+                for w in list(pending.values()):             # the last step's prefetch belongs to the captured cycle
+                    if w is not None:
+                        w.wait()
+                pending.clear()
             torch.cuda.set_stream(stream)
             graph.replay()                                    # instantiate / upload outside the timed region
             torch.cuda.synchronize()
             launch_mode = f"hipGraph of {G} steps replayed"
         except Exception as e:                                # capture unsupported: fall back, say so
-            graph, launch_mode = None, f"host launch per step (graph capture failed: {type(e).__name__})"
+            graph, launch_mode = None, f"host launch per step (graph capture failed: {type(e).__name__}: {e})"[:300]
+            pending.clear()
             torch.cuda.set_stream(stream)
             torch.cuda.synchronize()
+            if exchange:
+                prefetch(args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     if graph is not None:
         for _ in range(args.steps // G):
@@ -214,7 +298,7 @@ def main():
         eng.timing_enable(1)
         for i in range(64):
             step(i)
-        torch.cuda.synchronize()
+        fence()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -224,11 +308,33 @@ def main():
     eng.timing_enable(0)
     st, it = eng.status()
     bad = int((st != 0).sum())
+    frac_ipm = float((it > 0).mean()) if args.qp_mode == 0 else 1.0
     sweeps = float(np.mean(np.where(it > 0, 1 + 2 * it, 1))) if args.qp_mode == 0 else float(np.mean(2 * it))
     if world > 1:
         agg = torch.tensor([bad], dtype=torch.int64, device=dev)
         dist.all_reduce(agg)
         bad = int(agg.item())
+
+    def timed_leg(e, batch_ticks, n_steps, n_warm=10):
+        """Device-resident steps of another engine / workload: (solves/s, ms per step, ipm fraction, sweeps per solve)."""
+        uu = torch.empty(e.B, 4, dtype=torch.float64, device=dev)
+        e.reset_device(batch_ticks[0]["xr"], batch_ticks[0]["ur"], stream=stream)
+
+        def one(i):
+            d = batch_ticks[i % len(batch_ticks)]
+            e.update_device(d["x0"], d["xr"], d["ur"], uu, other=d.get("other"), ego_xy=d.get("ego_xy"), stream=stream)
+        for i in range(n_warm):
+            one(i)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for i in range(n_steps):
+            one(n_warm + i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - ta) / n_steps
+        s_, i_ = e.status()
+        return {"value": e.B / dt, "ms_per_step": dt * 1e3, "frac_interior_point": float((i_ > 0).mean()),
+                "riccati_sweeps_per_solve": float(np.mean(np.where(i_ > 0, (0 if e.cfg.qp_mode else 1) + 2 * i_, 1))),
+                "not_converged": int((s_ != 0).sum()), "batch": e.B, "work_queue": e.work_queue}
 
     if rank == 0:
         total = B * world * args.steps
@@ -239,77 +345,189 @@ def main():
         fused = downwash and mlp_n == 0          # gate + MLP run inside rti_kernel (one launch per step)
         ach_tf = f_qp * B / rti_s / 1e12
         abytes = algorithmic_bytes_per_solve(N, downwash)
+        is_default = (not cfg4 and fused and B == 1024 and N == 20 and args.qp_mode == 0 and args.perturb == "nominal" and world == 1)
+        prof = committed_profile(is_default)
         # matrix-pipe occupancy estimate: every v_mfma_f64_16x16x4 / v_mfma_f32_32x32x2 holds the SIMD's pipe 64 cycles
         # (measured, scripts/ubench); one instance per SIMD: 266 f64 MFMAs per sweep at N = 20; the MLP tile adds 12 f32 (64 clk)
-        # and 96 fp16 (32 clk) MFMAs.  PMC cross-check: SQ_INSTS_MFMA = 374 per instance, SQ_VALU_MFMA_BUSY_CYCLES = 21.4 k per SIMD
+        # and 96 fp16 (32 clk) MFMAs.  The shader clock is MEASURED: wave-cycles per SIMD of the committed PMC pass over the
+        # committed kernel duration when the profile belongs to this configuration, else the in-kernel stamp span of one
+        # launch over its HIP-event duration.
         n_f64 = sweeps * (6 + 8 * (N - 1) + N + 16 * ((N - 1) // 8) + 4 * N)
         pipe_cycles = n_f64 * 64 + ((12 * 64 + 96 * 32) if fused else 0)
+        clock_hz, clock_src = None, None
+        if prof["wave_cycles_per_simd"] and prof["kernel_us"]:
+            clock_hz, clock_src = prof["wave_cycles_per_simd"] / (prof["kernel_us"] * 1e-6), f"profiles/{PROFILE_TAG} PMC SQ_WAVE_CYCLES / kernel trace duration"
+        if clock_hz is None and not args.only_timed:
+            eng.debug_stamps(True)
+            eng.timing_enable(1)
+            step(0)
+            torch.cuda.synchronize()
+            sm = eng.debug_stamps(False, read=True)
+            ms1, n1 = eng.timing_read("rti")
+            eng.timing_enable(0)
+            # stamps 12 / 13: s_memrealtime (100 MHz) at kernel entry / exit of every wave, 14 / 15: s_memtime (shader clock) there
+            okw = (sm[:, 13] > sm[:, 12]) & (sm[:, 15] > sm[:, 14])
+            if okw.any():
+                clock_hz = float(np.median((sm[okw, 15] - sm[okw, 14]) / (sm[okw, 13] - sm[okw, 12]))) * 100e6
+                clock_src = "in-kernel s_memtime / s_memrealtime (100 MHz) over one stamped launch, median over waves"
         out = {
             "metric": "NMPC solves/sec (N=20, 1 RTI iter + downwash MLP) at batch",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if cfg4 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"batch={B}/GPU independent quadrotors, N={N}, 1 RTI iter, "
+            "config": {"workload": (f"BASELINE config 4: {args.formations} three-vehicle formations = {3 * args.formations} instances over {world} GPU(s) "
+                                    f"({B}/GPU; vehicle 0 = NDP controller reading vehicle 1, vehicles 1-2 = NMPC followers), N={N}, 1 RTI iter, "
+                                    if cfg4 else f"batch={B}/GPU independent quadrotors, N={N}, 1 RTI iter, ")
                                    + ("MLP downwash on (NDP controller, gate+MLP fused into the RTI launch)" if fused else
                                       "MLP downwash on (NDP controller)" if downwash else "no downwash (NMPC controller)")
-                                   + (", neighbour windows all-gathered over RCCL" if exchange else ", formation-major placement (no exchange)" if world > 1 else ""),
+                                   + (", neighbour windows all-gathered over RCCL" if exchange and world > 1 else
+                                      ", vehicle-major placement (position/velocity columns packed for the all-gather; one rank: no RCCL call)" if exchange else
+                                      ", formation-major placement (no exchange)" if (world > 1 or cfg4) else "")
+                                   + (", perturbed starts (~20 % of the instances need the interior-point loop)" if args.perturb == "mixed" else ""),
                        "batch_per_gpu": B, "horizon": N, "n_rti": 1, "qp_mode": "auto" if args.qp_mode == 0 else "ipm_always",
-                       "launch": launch_mode,
+                       "work_queue": eng.work_queue, "launch": launch_mode,
                        "parallelism": f"instances sharded x{world}"},
             "roofline": {"kernel": "rti_kernel", "bound": "mfma", "achieved": ach_tf, "peak": F64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach_tf / F64_MFMA_PEAK_TFLOPS, "traffic": measured_traffic(B, N, fused),
-                         "traffic_note": "HBM bytes per launch, PMC (profiles/r01_pmc_rti_kernel_fused_b1024.json); algorithmic bytes per launch = %d" % (abytes * B),
-                         "kernel_us": rti_s * 1e6, "flops_per_solve_f64": f_qp, "riccati_sweeps_per_solve": sweeps,
+                         "unit": "TFLOP/s", "frac": ach_tf / F64_MFMA_PEAK_TFLOPS, "traffic": prof["traffic"],
+                         "traffic_note": f"HBM bytes per launch, PMC (profiles/{PROFILE_TAG}_pmc_rti_kernel.json); algorithmic bytes per launch = %d" % (abytes * B),
+                         "kernel_us": rti_s * 1e6, "kernel_us_rocprof": prof["kernel_us"],
+                         "frac_rocprof": (f_qp * B / (prof["kernel_us"] * 1e-6) / 1e12 / F64_MFMA_PEAK_TFLOPS) if prof["kernel_us"] else None,
+                         "flops_per_solve_f64": f_qp, "riccati_sweeps_per_solve": sweeps, "frac_interior_point": frac_ipm,
                          "fused_mlp_flops_per_solve": f_mlp if fused else 0.0,
-                         "mfma_pipe_busy_est": pipe_cycles / (rti_s * 2.4e9),
+                         "shader_clock_ghz_measured": clock_hz / 1e9 if clock_hz else None, "shader_clock_source": clock_src,
+                         "mfma_pipe_busy_est": pipe_cycles / (rti_s * clock_hz) if clock_hz else None,
                          "hbm_algorithmic_GBps": abytes * B / (rti_s + mlp_s) / 1e9,
                          "hbm_frac": abytes * B / (rti_s + mlp_s) / 1e9 / HBM_PEAK_GBS,
                          "mlp_kernel_us": mlp_s * 1e6 if mlp_n else None},
             "parity_max_rel_vs_oracle": parity, "instances_not_converged": bad,
         }
-        if not args.no_cpu_baseline and world == 1:
+        extras = world == 1 and not args.only_timed and not cfg4 and args.perturb == "nominal" and args.qp_mode == 0
+        if extras:
+            # ---- what the reference's QP solver actually does (HPIPM always iterates): every instance through the interior-point loop
+            e_ipm = ndp.BatchedNMPC(B, N=N, disturbance=downwash, qp_mode=1, device=local_rank)
+            nom = [{k: v for k, v in d.items() if k in ("x0", "xr", "ur", "other", "ego_xy")} for d in ticks]
+            if not downwash:
+                nom = [{k: d[k] for k in ("x0", "xr", "ur")} for d in ticks]
+            out["ipm_always"] = timed_leg(e_ipm, nom, 60)
+            del e_ipm
+            # ---- mixed workload: ~20 % of the instances hit a bound and run the loop, the rest take the early exit.  At
+            # batch = SIMD count the step lasts as long as its slowest instance; with several instances per SIMD the work queue
+            # hands the interior-point solves to whichever wave is free (compare work_queue on / off at the larger batch).
+            def mixed_ticks(bb):
+                tk = []
+                for t in range(4):
+                    m = synth.make_batch(bb, N=N, seed=synth.SEED0 + 40, downwash=downwash, t0=0.02 * t, **mixed_kw)
+                    tk.append({k: torch.from_numpy(m[k]).to(dev) for k in (("x0", "xr", "ur", "other", "ego_xy") if downwash else ("x0", "xr", "ur"))})
+                return tk
+            out["mixed"] = {"perturbation": mixed_kw}
+            mt = mixed_ticks(B)
+            e_m = ndp.BatchedNMPC(B, N=N, disturbance=downwash, device=local_rank)
+            out["mixed"]["batch_%d" % B] = timed_leg(e_m, mt, 60)
+            del e_m, mt
+            Bq = 8 * B
+            mt = mixed_ticks(Bq)
+            for wq, name in ((1, "work_queue_on"), (2, "work_queue_off")):
+                e_q = ndp.BatchedNMPC(Bq, N=N, disturbance=downwash, device=local_rank, work_queue=wq)
+                out["mixed"]["batch_%d_%s" % (Bq, name)] = timed_leg(e_q, mt, 30)
+                del e_q
+            del mt
+            # ---- the metric as SURVEY 8d words it: host arrays in, host arrays out (H2D of the inputs and D2H of u0 inside the time)
+            hb = {k: np.ascontiguousarray(host0[k]) for k in ("x0", "xr", "ur", "other", "ego_xy")}
+            e_h = ndp.BatchedNMPC(B, N=N, disturbance=downwash, device=local_rank)
+            e_h.reset(hb["xr"], hb["ur"])
+            kw = dict(other=hb["other"], ego_xy=hb["ego_xy"]) if downwash else {}
+            for _ in range(5):
+                e_h.update(hb["x0"], hb["xr"], hb["ur"], **kw)
+            nh = 50
+            th = time.perf_counter()
+            for _ in range(nh):
+                e_h.update(hb["x0"], hb["xr"], hb["ur"], **kw)
+            th = (time.perf_counter() - th) / nh
+            in_b = 8 * (10 + 10 * (N + 1) + 4 * N) + ((8 * 10 * (N + 1) + 16) if downwash else 0)      # host -> device bytes per solve
+            out["value_host_inclusive"] = {"value": B / th, "unit": "solves/s", "ms_per_step": th * 1e3,
+                                           "note": "ndp_step on pageable numpy arrays: H2D of x0/xr/ur/other/ego_xy (%.1f MB per step), kernel, D2H of u0 + "
+                                                   "status, one synchronisation; PCIe Gen5 x16 (63 GB/s spec) alone bounds this at %.1f M solves/s"
+                                                   % (in_b * B / 1e6, 63e9 / (in_b + 36) / 1e6)}
+            del e_h
+        if not args.no_cpu_baseline and not args.only_timed and world == 1 and not cfg4:
             from oracle import oracle as O
-            cfgo = O.default_cfg(N=N, use_fd=downwash)
             nthr = min(O.num_threads(), effective_cores())
             blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
-            Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
-            O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], None, Xo, Uo, nthreads=nthr)       # warm the thread pool
-            Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
-            tc = time.perf_counter()
-            for _ in range(args.cpu_passes):
-                f = O.downwash_batch(blob, host0["other"], host0["xr"], host0["ego_xy"], nthreads=nthr) if downwash else None
-                O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], f, Xo, Uo, nthreads=nthr)
-            tc = time.perf_counter() - tc
-            out["cpu_baseline"] = {"value": B * args.cpu_passes / tc, "unit": "solves/s", "cores": nthr, "kind": "port",
-                                   "sample": f"{args.cpu_passes} control ticks of the same batch={B} workload "
-                                             f"(oracle/ndp_oracle.c: fp64 RTI + IPM always, fp32 MLP), OpenMP over instances"}
-            # BASELINE config 1 (one vehicle, N = 20, no downwash, 1 RTI iteration): latency of the CPU restatement on one
-            # thread next to the same single instance on the GPU (host call to host return, device-resident inputs)
+
+            def cpu_rate(qp_mode, seconds):
+                cfgo = O.default_cfg(N=N, use_fd=downwash)
+                cfgo.qp_mode = qp_mode
+                Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
+                O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], None, Xo, Uo, nthreads=nthr)       # warm the thread pool
+                Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
+                n, tc = 0, time.perf_counter()
+                while True:
+                    f = O.downwash_batch(blob, host0["other"], host0["xr"], host0["ego_xy"], nthreads=nthr) if downwash else None
+                    O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], f, Xo, Uo, nthreads=nthr)
+                    n += 1
+                    if time.perf_counter() - tc >= seconds:
+                        break
+                return B * n / (time.perf_counter() - tc), n
+            mode = args.qp_mode
+            v_same, n_same = cpu_rate(mode, args.cpu_seconds)
+            v_ipm, n_ipm = (v_same, n_same) if mode == 1 else cpu_rate(1, args.cpu_seconds * 0.5)
+            out["cpu_baseline"] = {"value": v_same, "unit": "solves/s", "cores": nthr, "kind": "port",
+                                   "qp_mode": "auto (the same early-exit rule as the timed GPU path)" if mode == 0 else "ipm_always",
+                                   "sample": f"{n_same} control ticks of the same batch={B} workload in ~{args.cpu_seconds:.0f} s "
+                                             f"(oracle/ndp_oracle.c: fp64 RTI, fp32 MLP), OpenMP over instances",
+                                   "ipm_always_value": v_ipm,
+                                   "ipm_always_note": f"the same oracle iterating on every instance like HPIPM ({n_ipm} ticks); compare with ipm_always.value"}
+            # BASELINE config 1 (one vehicle, N = 20, no downwash, 1 RTI iteration), the reference's own drop-in shape: the
+            # controller object exactly as nmpc_node.py:202-209 calls it -- numpy x0 / xr / ur in, numpy u0 out, every tick --
+            # next to the CPU restatement on one thread.  The reference's budget per tick is 20 ms (nmpc_node.py:216-220).
+            from ndp_nmpc_qd_amd.nmpc_ctl import NMPCBodyRateController
             c1 = O.default_cfg(N=N, use_fd=False)
-            X1, U1 = host0["xr"][:1].copy(), host0["ur"][:1].copy()
+            x0_1, xr_1, ur_1 = host0["x0"][0].copy(), host0["xr"][0].copy(), host0["ur"][0].copy()
             n1 = 300
-            t1 = time.perf_counter()
-            for _ in range(n1):
-                O.step_batch(c1, host0["x0"][:1], host0["xr"][:1], host0["ur"][:1], None, X1, U1, nthreads=1)
-            t1 = (time.perf_counter() - t1) / n1
-            e1 = ndp.BatchedNMPC(1, N=N, device=local_rank)
-            d1 = {k: ticks[0][k][:1].contiguous() for k in ("x0", "xr", "ur")}
-            u1 = torch.empty(1, 4, dtype=torch.float64, device=dev)
-            e1.reset_device(d1["xr"], d1["ur"], stream=stream)
+            lat = {}
+            for qm, nm in ((1, "cpu_restatement_ipm_always_us"), (0, "cpu_restatement_auto_us")):
+                c1.qp_mode = qm
+                X1, U1 = xr_1[None].copy(), ur_1[None].copy()
+                t1 = time.perf_counter()
+                for _ in range(n1):
+                    O.step_batch(c1, x0_1[None], xr_1[None], ur_1[None], None, X1, U1, nthreads=1)
+                lat[nm] = (time.perf_counter() - t1) / n1 * 1e6
+            ctl = NMPCBodyRateController(device=local_rank)
+            ctl.reset(xr_1, ur_1)
             for _ in range(20):
-                e1.update_device(d1["x0"], d1["xr"], d1["ur"], u1, stream=stream)
-            torch.cuda.synchronize()
+                ctl.update(x0_1, xr_1, ur_1)
             t2 = time.perf_counter()
             for _ in range(n1):
-                e1.update_device(d1["x0"], d1["xr"], d1["ur"], u1, stream=stream)
-                torch.cuda.synchronize()
-            t2 = (time.perf_counter() - t2) / n1
-            out["config1_single_vehicle"] = {"cpu_restatement_us_per_solve_1_thread": t1 * 1e6,
-                                             "gpu_us_per_solve_sync_each_call": t2 * 1e6,
-                                             "note": "N=%d, no downwash, 1 RTI iteration; CPU = oracle (interior point always)" % N}
+                ctl.update(x0_1, xr_1, ur_1)
+            lat["gpu_drop_in_update_us"] = (time.perf_counter() - t2) / n1 * 1e6
+            # the same tick without the Python facade's 42 solver.set calls: BatchedNMPC(1).update(full=True) on numpy arrays
+            e1 = ndp.BatchedNMPC(1, N=N, device=local_rank)
+            e1.reset(xr_1[None], ur_1[None])
+            for _ in range(20):
+                e1.update(x0_1[None], xr_1[None], ur_1[None], full=True)
+            t3 = time.perf_counter()
+            for _ in range(n1):
+                e1.update(x0_1[None], xr_1[None], ur_1[None], full=True)
+            lat["gpu_ndp_step_ex_us"] = (time.perf_counter() - t3) / n1 * 1e6
+            lat["deadline_us"] = 20000.0
+            lat["note"] = ("N=%d, no downwash, 1 RTI iteration, host numpy in / numpy out per tick.  gpu_drop_in_update = "
+                           "NMPCBodyRateController.update (42 solver.set calls in Python + ONE ndp_step_ex: packed pinned H2D, kernel, "
+                           "u0 + iterate + status D2H, one sync); deadline = the reference's 20 ms warning (nmpc_node.py:216-220)" % N)
+            out["config1_single_vehicle"] = lat
+        fail = (parity is not None and not parity <= 1e-5) or bad > 0
+        if fail:
+            out["error"] = f"parity_max_rel_vs_oracle {parity} (bar 1e-5), instances_not_converged {bad}: value withheld"
+            out["value_unchecked"], out["value"] = out["value"], None
         print(json.dumps(out), flush=True)
+    else:
+        fail = False
     if world > 1:
+        flag = torch.tensor([int(fail)], dtype=torch.int64, device=dev)
+        dist.broadcast(flag, 0)
+        fail = bool(flag.item())
         dist.destroy_process_group()
+    if fail:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

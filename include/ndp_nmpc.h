@@ -56,6 +56,9 @@ typedef struct ndp_cfg {
     int32_t device;     /* HIP device ordinal                                     */
     int32_t qp_precision; /* 0 = product path (fp64).  Precision study of BASELINE config 5 only: 1 / 2 round the operands of
                            * the Riccati sweeps' matrix instructions to fp32 / bf16 and their accumulators to fp32 */
+    int32_t work_queue; /* instances whose QP needs the interior-point loop are re-distributed over all SIMDs through an
+                         * in-kernel queue: 0 = automatic (on when batch > SIMDs of the device and qp_mode is AUTO), 1 = on, 2 = off */
+    int32_t reserved0;
     double dt;          /* T_horizon / N_node        params/nmpc_params.py:10,12  */
     double mass;        /* params/fhnp_params.py:9   */
     double gravity;     /* params/fhnp_params.py:12  */
@@ -67,6 +70,9 @@ typedef struct ndp_cfg {
     double mu0, thr0, tol, tau; /* interior-point constants */
     double auto_margin;         /* NDP_QP_AUTO accepts the equality-constrained minimiser only if it is this far inside every
                                  * bound (default 0.1); closer to a bound the interior-point loop runs, as in the reference */
+    double ts_nmpc;             /* control period, params/nmpc_params.py:11 (0.02): spacing of the reference list entries */
+    double mu_floor;            /* interior point: the centring target sigma*mu never goes below mu_floor * tol (default 0.1) --
+                                 * slacks are differences, so driving mu far below tol only loses digits */
 } ndp_cfg;
 
 typedef struct ndp_handle ndp_handle;
@@ -103,6 +109,22 @@ int ndp_step(ndp_handle *h, const double *x0, const double *xr, const double *ur
              const double *other, const double *ego_xy, double *u0);
 int ndp_step_device(ndp_handle *h, const void *d_x0, const void *d_xr, const void *d_ur, const void *d_f,
                     const void *d_other, const void *d_ego_xy, void *d_u0, void *stream);
+/* ndp_step plus, from the same call (one synchronisation, no further round trips), what the reference's callers read
+ * after solve_for_x0: the new iterate (solver.get(i,"x"/"u"), nmpc_node.py:237), solver.status
+ * (nmpc_body_rate_ctl.py:109) and the interior-point iterations.  Any of the four output pointers may be NULL.
+ * Batches whose inputs fit 1 MiB travel as ONE host-to-device copy through a pinned mirror owned by the handle. */
+int ndp_step_ex(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
+                const double *other, const double *ego_xy, double *u0, double *X_out, double *U_out,
+                int32_t *status_out, int32_t *ipm_iters_out);
+/* ndp_step_device with the neighbour windows addressed the way a multi-GPU exchange leaves them (the reference's PredXU
+ * traffic, nmpc_node.py:116-133 -> ndp_nmpc_leader_node.py:60-76):
+ *   other_stride   : doubles per node of d_other, 10 (full windows) or 6 (positions + velocities, all the gate and the MLP
+ *                    read, downwash_nn.py:22) -- d_other is [rows][N+1][other_stride]
+ *   d_other_index  : int32[B], row of d_other holding instance i's neighbour, < 0 = no neighbour (force 0: the plain NMPC
+ *                    followers of a formation, three_qd_ndp_nmpc.launch:8,12); NULL = row i */
+int ndp_step_device_ex(ndp_handle *h, const void *d_x0, const void *d_xr, const void *d_ur, const void *d_f,
+                       const void *d_other, int other_stride, const void *d_other_index, const void *d_ego_xy,
+                       void *d_u0, void *stream);
 
 /* Replaces DownwashNN.update(other_pred_x, ego_pred_x) (downwash_nn.py:21-29), batched, with the
  * optional r_horiz gate.  f_out: [B][N+1][3] fp32. */
@@ -119,11 +141,13 @@ int ndp_set_iterate(ndp_handle *h, const double *X, const double *U);
  * interior-point iterations it took (0 = early exit).  Either pointer may be NULL. */
 int ndp_get_status(ndp_handle *h, int32_t *status, int32_t *ipm_iters);
 
-/* Device views for callers that keep everything in HBM (bench, multi-GPU driver). */
+/* Device views for callers that keep everything in HBM (bench, multi-GPU driver).  The getters above and
+ * ndp_synchronize also wait for the last stream a *_device call was given. */
 void *ndp_device_iterate_x(ndp_handle *h);
 void *ndp_device_iterate_u(ndp_handle *h);
 void *ndp_device_force(ndp_handle *h);   /* [B][N+1][3] fp32 written by the fused downwash */
 int ndp_synchronize(ndp_handle *h);
+int ndp_work_queue_enabled(ndp_handle *h);   /* 1 if this handle's steps run the interior-point work queue (cfg.work_queue) */
 
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on:
  * on = n > 0 brackets every n-th launch of each kernel (n = 1: every launch), on = 0 stops and clears.
@@ -171,6 +195,22 @@ int ndp_ref_set_trajectory(ndp_handle *h, int n_seg, const double *coeff_x, cons
                            const double *coeff_yaw, const double *time_cum, const double *time_seg, const double *final_pt);
 int ndp_ref_window(ndp_handle *h, const double *t, double *xr, double *ur);
 int ndp_ref_window_device(ndp_handle *h, const void *d_t, void *d_xr, void *d_ur, void *stream);
+
+/* The reference's own bookkeeping of that window (NMPCRefPublisher, pt_pub/pt_publisher.py:36-103): a list of 5N+1 reference
+ * points per vehicle, ts_nmpc apart; every control tick drops the oldest entry and appends the point at ros_t + T_horizon;
+ * the controller's window is every 5th entry (params/nmpc_params.py:40-43).  Kept on the device as a ring per vehicle.
+ *   ndp_ref_list_reset  : _gen_long_list_w_traj (:62-76) from the trajectory of ndp_ref_set_trajectory: points at
+ *                         i*ts_nmpc, i = 0..5N-1, the first one duplicated in front
+ *   ndp_ref_list_fix_pt : gen_fix_pt_ref (:40-55): every entry = x_odom[B][10], u = [0, 0, 0, mass*g] (quirk_b1 = 1: the
+ *                         reference's value although u[3] is an acceleration) or [0, 0, 0, g] (quirk_b1 = 0)
+ *   ndp_ref_list_window : t[B] = (ros_t - start_ros_t).to_sec(): get_nmpc_pts (:79-97) = pop, append the point at
+ *                         t + T_horizon, return the window; t = NULL: get_nmpc_ref_from_long_list only (:99-103)
+ *   *_device            : the two halves separately, on device buffers */
+int ndp_ref_list_reset(ndp_handle *h);
+int ndp_ref_list_fix_pt(ndp_handle *h, const double *x_odom, int quirk_b1);
+int ndp_ref_list_window(ndp_handle *h, const double *t, double *xr, double *ur);
+int ndp_ref_list_advance_device(ndp_handle *h, const void *d_t, void *stream);
+int ndp_ref_list_window_device(ndp_handle *h, void *d_xr, void *d_ur, void *stream);
 
 /* ---- "next" row f4: plant step for closed-loop rollouts on the device (dop_sim is absent from the reference).
  * x[B][10] in/out, u[B][4], f[B][3] force or NULL; RK4 with `substeps` over dt, quaternion renormalised. */

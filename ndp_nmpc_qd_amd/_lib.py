@@ -22,10 +22,12 @@ class NdpCfg(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("N", C.c_int32), ("n_rti", C.c_int32), ("use_fd", C.c_int32),
         ("qp_mode", C.c_int32), ("iter_max", C.c_int32), ("device", C.c_int32), ("qp_precision", C.c_int32),
+        ("work_queue", C.c_int32), ("reserved0", C.c_int32),
         ("dt", C.c_double), ("mass", C.c_double), ("gravity", C.c_double), ("r_horiz", C.c_double),
         ("Qd", C.c_double * 10), ("Rd", C.c_double * 4),
         ("lbu", C.c_double * 4), ("ubu", C.c_double * 4), ("lbv", C.c_double * 3), ("ubv", C.c_double * 3),
         ("mu0", C.c_double), ("thr0", C.c_double), ("tol", C.c_double), ("tau", C.c_double), ("auto_margin", C.c_double),
+        ("ts_nmpc", C.c_double), ("mu_floor", C.c_double),
     ]
 
 
@@ -37,6 +39,8 @@ EXPORTS = [
     "ndp_throttle_update_device", "ndp_actuator_cmd", "ndp_actuator_cmd_device", "ndp_throttle_get_state", "ndp_relay_reset", "ndp_relay_formation",
     "ndp_relay_reference", "ndp_relay_reference_device", "ndp_plant_step", "ndp_plant_step_device",
     "ndp_ref_set_trajectory", "ndp_ref_window", "ndp_ref_window_device", "ndp_rollout_device",
+    "ndp_step_ex", "ndp_step_device_ex", "ndp_work_queue_enabled", "ndp_ref_list_reset", "ndp_ref_list_fix_pt",
+    "ndp_ref_list_window", "ndp_ref_list_advance_device", "ndp_ref_list_window_device",
 ]
 
 _lib = None
@@ -69,6 +73,14 @@ def load():
     lib.ndp_reset_device.argtypes = [vp, vp, vp, vp]
     lib.ndp_step.argtypes = [vp] * 8
     lib.ndp_step_device.argtypes = [vp] * 9
+    lib.ndp_step_ex.argtypes = [vp] * 12
+    lib.ndp_step_device_ex.argtypes = [vp] * 6 + [C.c_int] + [vp] * 4
+    lib.ndp_work_queue_enabled.argtypes = [vp]
+    lib.ndp_ref_list_reset.argtypes = [vp]
+    lib.ndp_ref_list_fix_pt.argtypes = [vp, vp, C.c_int]
+    lib.ndp_ref_list_window.argtypes = [vp] * 4
+    lib.ndp_ref_list_advance_device.argtypes = [vp] * 3
+    lib.ndp_ref_list_window_device.argtypes = [vp] * 4
     lib.ndp_downwash.argtypes = [vp] * 5
     lib.ndp_downwash_device.argtypes = [vp] * 6
     lib.ndp_get_iterate.argtypes = [vp, vp, vp]

@@ -66,11 +66,13 @@ class BatchedNMPC:
         ur = _lib.f64(ur, (self.B, self.N, 4))
         self._check(self._lib.ndp_reset(self._h, _lib.ptr(xr), _lib.ptr(ur)), "ndp_reset")
 
-    def update(self, x0, xr, ur, f=None, other=None, ego_xy=None, raise_on_status=True):
+    def update(self, x0, xr, ur, f=None, other=None, ego_xy=None, raise_on_status=True, full=False):
         """update(x0, xr, ur[, f]) for every instance; returns u0[B,4] float64.
 
         f: [B,N+1,3] disturbance force (NDP).  other/ego_xy: neighbour reference windows and ego
         odometry xy; the force is then predicted on the device (DownwashNN.update + r_horiz gate).
+        full=True: returns (u0, X, U, status, ipm_iters) from the same call (ndp_step_ex: one synchronisation) -- what
+        the reference's callers read after solve_for_x0 (solver.get / solver.status).
         """
         x0 = _lib.f64(x0, (self.B, 10))
         xr = _lib.f64(xr, (self.B, self.N + 1, 10))
@@ -79,12 +81,19 @@ class BatchedNMPC:
         other = _lib.f64(other, (self.B, self.N + 1, 10))
         ego_xy = _lib.f64(ego_xy, (self.B, 2))
         u0 = np.empty((self.B, 4), dtype=np.float64)
-        rc = self._check(self._lib.ndp_step(self._h, _lib.ptr(x0), _lib.ptr(xr), _lib.ptr(ur), _lib.ptr(f32),
-                                            _lib.ptr(other), _lib.ptr(ego_xy), _lib.ptr(u0)), "ndp_step")
+        if full:
+            X, U = np.empty((self.B, self.N + 1, 10)), np.empty((self.B, self.N, 4))
+            st, it = np.empty(self.B, dtype=np.int32), np.empty(self.B, dtype=np.int32)
+            rc = self._check(self._lib.ndp_step_ex(self._h, _lib.ptr(x0), _lib.ptr(xr), _lib.ptr(ur), _lib.ptr(f32),
+                                                   _lib.ptr(other), _lib.ptr(ego_xy), _lib.ptr(u0), _lib.ptr(X), _lib.ptr(U),
+                                                   _lib.ptr(st), _lib.ptr(it)), "ndp_step_ex")
+        else:
+            rc = self._check(self._lib.ndp_step(self._h, _lib.ptr(x0), _lib.ptr(xr), _lib.ptr(ur), _lib.ptr(f32),
+                                                _lib.ptr(other), _lib.ptr(ego_xy), _lib.ptr(u0)), "ndp_step")
         if rc != 0 and raise_on_status:
             # same text as nmpc_body_rate_ctl.py:109-110
             raise Exception("acados acados_ocp_solver returned status {}. Exiting.".format(rc))
-        return u0
+        return (u0, X, U, st, it) if full else u0
 
     def update_debug(self, x0, xr, ur, f=None, other=None, ego_xy=None):
         """B = 1 only: one step that also returns the kernel's LDS image after linearisation (tests)."""
@@ -169,6 +178,35 @@ class BatchedNMPC:
         self._check(self._lib.ndp_ref_window(self._h, _lib.ptr(t), _lib.ptr(xr), _lib.ptr(ur)), "ndp_ref_window")
         return xr, ur
 
+    # the reference's own sliding list of reference points (NMPCRefPublisher, pt_pub/pt_publisher.py:36-103), on the device
+    def ref_list_reset(self):
+        """_gen_long_list_w_traj for every vehicle (needs ref_set_trajectory)."""
+        self._check(self._lib.ndp_ref_list_reset(self._h), "ndp_ref_list_reset")
+
+    def ref_list_fix_pt(self, x_odom, quirk_b1=True):
+        """gen_fix_pt_ref's list: every entry = x_odom[B,10], u = [0, 0, 0, mass*g] (the reference's value)."""
+        x_odom = _lib.f64(x_odom, (self.B, 10))
+        self._check(self._lib.ndp_ref_list_fix_pt(self._h, _lib.ptr(x_odom), int(bool(quirk_b1))), "ndp_ref_list_fix_pt")
+
+    def ref_list_window(self, t=None):
+        """t[B] given: get_nmpc_pts (drop the oldest entry, append the point at t + T_horizon, return the window);
+        t None: get_nmpc_ref_from_long_list only."""
+        t = _lib.f64(t, (self.B,))
+        xr, ur = np.empty((self.B, self.N + 1, 10)), np.empty((self.B, self.N, 4))
+        self._check(self._lib.ndp_ref_list_window(self._h, _lib.ptr(t), _lib.ptr(xr), _lib.ptr(ur)), "ndp_ref_list_window")
+        return xr, ur
+
+    def ref_list_advance_device(self, t, stream=None):
+        import torch
+        self._check(self._lib.ndp_ref_list_advance_device(self._h, self._dptr(t, torch.float64, (self.B,)), self._stream(stream)),
+                    "ndp_ref_list_advance_device")
+
+    def ref_list_window_device(self, xr_out, ur_out, stream=None):
+        import torch
+        self._check(self._lib.ndp_ref_list_window_device(
+            self._h, self._dptr(xr_out, torch.float64, (self.B, self.N + 1, 10)),
+            self._dptr(ur_out, torch.float64, (self.B, self.N, 4)), self._stream(stream)), "ndp_ref_list_window_device")
+
     def ref_window_device(self, t, xr_out, ur_out, stream=None):
         import torch
         self._check(self._lib.ndp_ref_window_device(
@@ -226,15 +264,32 @@ class BatchedNMPC:
                                                self._dptr(ur, torch.float64, (self.B, self.N, 4)),
                                                self._stream(stream)), "ndp_reset_device")
 
-    def update_device(self, x0, xr, ur, u0_out, f=None, other=None, ego_xy=None, stream=None):
-        """Enqueues one control step on `stream` (default: the library's stream); no synchronisation."""
+    def update_device(self, x0, xr, ur, u0_out, f=None, other=None, ego_xy=None, stream=None, other_index=None):
+        """Enqueues one control step on `stream` (default: the library's stream); no synchronisation.
+
+        other: [B,N+1,10] neighbour windows, or -- with other_index (int32[B]: row of `other` holding instance i's
+        neighbour, < 0 = none) -- any [rows,N+1,10] or [rows,N+1,6] buffer, e.g. what an all-gather over the GPUs left."""
         import torch
         B, N = self.B, self.N
-        self._check(self._lib.ndp_step_device(
+        stride = 10
+        if other is not None and other_index is not None:
+            if not (other.is_cuda and other.is_contiguous() and other.dtype == torch.float64 and other.dim() == 3
+                    and other.shape[1] == N + 1 and other.shape[2] in (6, 10)):
+                raise ValueError("other: expected a contiguous CUDA float64 [rows, N+1, 6 or 10] tensor")
+            stride = int(other.shape[2])
+            optr = C.c_void_p(other.data_ptr())
+        else:
+            optr = self._dptr(other, torch.float64, (B, N + 1, 10))
+        self._check(self._lib.ndp_step_device_ex(
             self._h, self._dptr(x0, torch.float64, (B, 10)), self._dptr(xr, torch.float64, (B, N + 1, 10)),
             self._dptr(ur, torch.float64, (B, N, 4)), self._dptr(f, torch.float32, (B, N + 1, 3)),
-            self._dptr(other, torch.float64, (B, N + 1, 10)), self._dptr(ego_xy, torch.float64, (B, 2)),
+            optr, stride, self._dptr(other_index, torch.int32, (B,)), self._dptr(ego_xy, torch.float64, (B, 2)),
             self._dptr(u0_out, torch.float64, (B, 4)), self._stream(stream)), "ndp_step_device")
+
+    @property
+    def work_queue(self):
+        """True when this engine's steps send interior-point solves through the in-kernel work queue (cfg.work_queue)."""
+        return self._lib.ndp_work_queue_enabled(self._h) == 1
 
     def downwash_device(self, other, ego_ref, f_out, ego_xy=None, stream=None):
         import torch

@@ -34,9 +34,11 @@ inline void fill_default_cfg(ndp_cfg *c)
     c->ubu[3] = 9.81 / 0.36;
     c->mu0 = 10.0;
     c->thr0 = 0.1;
-    c->tol = 1e-8;
+    c->tol = 1e-8;     // HPIPM's default [acados-knowledge]
+    c->mu_floor = 0.1; // the centring target never goes below mu_floor * tol (see RtiWave::ipm)
     c->tau = 0.995;
     c->auto_margin = 0.1;
+    c->ts_nmpc = 0.02;
 }
 
 inline RtiParams to_params(const ndp_cfg &c)
@@ -47,7 +49,7 @@ inline RtiParams to_params(const ndp_cfg &c)
     memcpy(p.Qd, c.Qd, sizeof(p.Qd)); memcpy(p.Rd, c.Rd, sizeof(p.Rd));
     memcpy(p.lbu, c.lbu, sizeof(p.lbu)); memcpy(p.ubu, c.ubu, sizeof(p.ubu));
     memcpy(p.lbv, c.lbv, sizeof(p.lbv)); memcpy(p.ubv, c.ubv, sizeof(p.ubv));
-    p.mu0 = c.mu0; p.thr0 = c.thr0; p.tol = c.tol; p.tau = c.tau; p.auto_margin = c.auto_margin;
+    p.mu0 = c.mu0; p.thr0 = c.thr0; p.tol = c.tol; p.tau = c.tau; p.auto_margin = c.auto_margin; p.mu_floor = c.mu_floor;
     fill_quotients(p);
     return p;
 }

@@ -47,11 +47,55 @@ struct BatchPtrs {
 
 struct MlpArgs {            // fused downwash (null frag = not fused)
     const float *frag;
-    const double *other;    // [B][N+1][10] neighbour windows
+    const double *other;    // neighbour windows: row (instance) r starts at other + r * (N+1) * other_stride, node k at + k * other_stride
     const double *ego_xy;   // [B][2] or null (gate always open)
     float *force_out;       // [B][N+1][3] copy of the predicted force for callers
     double r2;
+    int other_stride;       // doubles per node of `other`: 10 (a full reference window) or 6 (positions + velocities only, what the MLP reads)
+    const int *other_index; // [B] row of `other` that holds instance i's neighbour (multi-GPU: a row of the gathered buffer);
+                            // < 0 = no neighbour (force 0: the plain NMPC followers of a formation); null = row i
 };
+
+// Work queue of instances whose QP needs the interior-point loop (QUEUE launches).  An interior-point solve costs ~18
+// Riccati sweeps against 1 for the early exit, so with several instances per SIMD one such instance per workgroup leaves
+// the other three SIMDs of its CU idle for most of the launch.  Instead every wave first runs the cheap part of its own
+// instance; instances that need the loop are pushed here, and every wave that is done pops and solves them -- its own
+// push included, so whatever was pushed is solved by the end of the launch.  Counters are monotonic across launches
+// (nothing to reset, hipGraph-replayable): ctr[0] slots reserved, ctr[1] slots published (ids stored), ctr[2] slots taken.
+struct QueueArgs {
+    unsigned *ctr;
+    int *ids;               // ring of B instance ids
+    float *fq;              // [B][64]: the fused downwash force of every instance, 256-byte records written write-through
+};
+
+__device__ __forceinline__ void queue_push(const QueueArgs &q, int inst, int B)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores (fq) have left before the id is published
+    if ((threadIdx.x & 63u) == 0) {
+        const unsigned s = __hip_atomic_fetch_add(&q.ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&q.ids[s % (unsigned)B], inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        while (__hip_atomic_load(&q.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != s) __builtin_amdgcn_s_sleep(2);   // publish in slot order
+        __hip_atomic_store(&q.ctr[1], s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__device__ __forceinline__ int queue_pop(const QueueArgs &q, int B)
+{
+    int id = -1;
+    if ((threadIdx.x & 63u) == 0) {
+        for (;;) {
+            unsigned h = __hip_atomic_load(&q.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned c = __hip_atomic_load(&q.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)(c - h) <= 0) break;
+            if (__hip_atomic_compare_exchange_strong(&q.ctr[2], &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                id = __hip_atomic_load(&q.ids[h % (unsigned)B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(id);
+}
 
 typedef __attribute__((address_space(3))) float *lds_f32;
 typedef const __attribute__((address_space(3))) float *lds_cf32;
@@ -59,21 +103,9 @@ __device__ __forceinline__ void stage_fragments(const float *__restrict__ fr, ld
 __device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lane, float o[3]);
 __device__ __forceinline__ bool gate_open(const double *other_inst, const double *ego_xy_inst, double r2);
 
-// FUSED: the wave first predicts its own instance's disturbance force (gate + MLP over the N+1 <= 32 horizon rows,
-// one 32x32 f32 MFMA tile) and leaves it in the LDS staging slot the RTI program reads f from -- no second
-// launch and no trip of f through HBM.
-template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0)>
-__global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs bp, int B, int lds_per_wave, MlpArgs ma)
+__device__ __forceinline__ void bind_instance(RtiIo &io, const BatchPtrs &bp, int inst, int N)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int wave = (int)(threadIdx.x >> 6);
-    const int inst_raw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave);
-    const bool active = inst_raw < B;
-    if (!FUSED && !active) return;
-    const int inst = active ? inst_raw : B - 1;   // fused: idle waves of the last workgroup still take part in the barriers
-    const int N = NC ? NC : P.N;
     const size_t nx = (size_t)(N + 1) * NX, nu = (size_t)N * NU, nf = (size_t)(N + 1) * 3;
-    RtiIo io;
     io.x0 = bp.x0 + (size_t)inst * NX;
     io.xr = bp.xr + inst * nx;
     io.ur = bp.ur + inst * nu;
@@ -85,12 +117,36 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
     io.iters = bp.iters + inst;
     io.dbg = bp.dbg;
     io.f_in_lds = 0;
+    io.f_coherent = 0;
     io.kc = bp.kc;
     io.tables = bp.tables;
     io.stamps = bp.stamps ? bp.stamps + (size_t)inst * 16 : nullptr;
+}
+
+// FUSED: the wave first predicts its own instance's disturbance force (gate + MLP over the N+1 <= 32 horizon rows,
+// one 32x32 f32 MFMA tile) and leaves it in the LDS staging slot the RTI program reads f from -- no second
+// launch and no trip of f through HBM.
+// QUEUE: interior-point solves go through the work queue above (launches with more instances than SIMDs).
+template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), bool QUEUE = false>
+__global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs bp, int B, int lds_per_wave, MlpArgs ma, QueueArgs qa)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int wave = (int)(threadIdx.x >> 6);
+    const int inst_raw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave);
+    const bool active = inst_raw < B;
+    if (!FUSED && !active) return;
+    const int inst = active ? inst_raw : B - 1;   // fused: idle waves of the last workgroup still take part in the barriers
+    const int N = NC ? NC : P.N;
+    const size_t nx = (size_t)(N + 1) * NX, nf = (size_t)(N + 1) * 3;
+    RtiIo io;
+    bind_instance(io, bp, inst, N);
     const int lpw = NC ? ((lds_doubles(NC) + 1) & ~1) : lds_per_wave;
     WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lpw);
     using Prog = RtiWave<WaveGfx950, NSLOT, NC, true, NRC, PREC>;   // compile-time horizon and iteration count (NC = 0: both at run time)
+    if (io.stamps && (threadIdx.x & 63u) == 0) {    // profiling hook: real time (100 MHz) and shader clock at entry -> the clock the launch ran at
+        io.stamps[12] = (double)__builtin_amdgcn_s_memrealtime();
+        io.stamps[14] = (double)__builtin_amdgcn_s_memtime();
+    }
     typename Prog::InBuf inb;
     double x0v;
     Prog::issue_first(P, io, inb, x0v);      // every global input of the RTI step is now in flight (hidden under the MLP when fused)
@@ -98,15 +154,15 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
     if (FUSED) {
         const int lane = (int)(threadIdx.x & 63u), j = lane & 31, h = lane >> 5;
         const int np1 = N + 1;
-        const double *oth = ma.other + inst * nx;
-        const bool open = ma.ego_xy ? gate_open(oth, ma.ego_xy + (size_t)inst * 2, ma.r2) : true;
+        const int orow = ma.other_index ? ma.other_index[inst] : inst;
+        const int st = ma.other_stride;
+        const double *oth = ma.other + (size_t)(orow < 0 ? 0 : orow) * np1 * st;
+        const bool open = orow >= 0 && (ma.ego_xy ? gate_open(oth, ma.ego_xy + (size_t)inst * 2, ma.r2) : true);
         const int jr = j < np1 ? j : np1 - 1;
         float zb[3], o[3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const size_t idx = (size_t)jr * NX + 2 * s + h;
-            zb[s] = (float)(oth[idx] - io.xr[idx]);       // downwash_nn.py:22-23
-        }
+        for (int s = 0; s < 3; ++s)
+            zb[s] = (float)(oth[(size_t)jr * st + 2 * s + h] - io.xr[(size_t)jr * NX + 2 * s + h]);       // downwash_nn.py:22-23
         const LdsMap m = make_map(N);
         if (io.dbg && lane == 0) io.dbg[m.total + 9] = (double)__builtin_amdgcn_s_memtime();
         if (io.stamps && lane == 0) io.stamps[9] = (double)__builtin_amdgcn_s_memtime();
@@ -126,13 +182,31 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
                 const float v = open ? o[c] : 0.0f;      // ndp_nmpc_leader_node.py:75-76
                 lds[m.TF + j * 3 + c] = (double)v;       // fp32 value promoted to fp64
                 ma.force_out[inst * nf + j * 3 + c] = v;
+                if (QUEUE) __hip_atomic_store(&qa.fq[(size_t)inst * 64 + j * 3 + c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         WaveGfx950::sync();
         io.f = nullptr;
         io.f_in_lds = 1;
     }
-    Prog::run(P, io, lds, inb, x0v);
+    const bool deferred = Prog::template run<QUEUE>(P, io, lds, inb, x0v);
+    if (io.stamps && (threadIdx.x & 63u) == 0) {
+        io.stamps[13] = (double)__builtin_amdgcn_s_memrealtime();
+        io.stamps[15] = (double)__builtin_amdgcn_s_memtime();
+    }
+    if (QUEUE) {
+        if (deferred) queue_push(qa, inst, B);
+        for (;;) {
+            const int id = queue_pop(qa, B);
+            if (id < 0) break;
+            RtiIo io2;
+            bind_instance(io2, bp, id, N);
+            io2.dbg = nullptr;
+            if (FUSED) { io2.f = qa.fq + (size_t)id * 64; io2.f_coherent = 1; }
+            Prog::run(P, io2, lds);
+        }
+    }
+    (void)nx;
 }
 
 // test hook: one v_mfma_f64_16x16x4_f64 with caller-chosen per-lane operands (pins the register maps)
@@ -327,7 +401,8 @@ __device__ __forceinline__ bool gate_open(const double *other_inst, const double
 // a loop would make every weight load loop-invariant and the compiler then tries to keep 17k weights in registers.
 __global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, const double *__restrict__ other,
                                                   const double *__restrict__ ego, const double *__restrict__ ego_xy,
-                                                  float *__restrict__ fout, int rows, int np1, double r2)
+                                                  float *__restrict__ fout, int rows, int np1, double r2,
+                                                  int other_stride, const int *__restrict__ other_index)
 {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
@@ -341,16 +416,16 @@ __global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, 
     const int row = tile * 32 + j;
     const bool valid = row < rows;
     const int rowc = valid ? row : rows - 1;
-    const int inst = rowc / np1;
-    bool open = valid;
-    if (ego_xy) open = open && gate_open(other + (size_t)inst * np1 * NX, ego_xy + inst * 2, r2);
+    const int inst = rowc / np1, k = rowc - inst * np1;
+    const int orow = other_index ? other_index[inst] : inst;          // see MlpArgs
+    const double *oth = other + (size_t)(orow < 0 ? 0 : orow) * np1 * other_stride;
+    bool open = valid && orow >= 0;
+    if (ego_xy) open = open && gate_open(oth, ego_xy + inst * 2, r2);
     // downwash_nn.py:22-23: (other - ego)[:, 0:6] in fp64, cast to fp32
     float zb[3], o[3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const size_t idx = (size_t)rowc * NX + 2 * s + h;
-        zb[s] = (float)(other[idx] - ego[idx]);
-    }
+    for (int s = 0; s < 3; ++s)
+        zb[s] = (float)(oth[(size_t)k * other_stride + 2 * s + h] - ego[(size_t)rowc * NX + 2 * s + h]);
     mlp_tile(wl, zb, lane, o);
     if (valid && h == 0) {
 #pragma unroll
@@ -600,21 +675,12 @@ __device__ __forceinline__ double poly_eval(const double *__restrict__ c, const 
     return acc * inv_scale_den;      // one scale per quantity (the reference divides every term by tseg^d: same value to ~1 ulp)
 }
 
-#define REF_ROWS 64     // rows (vehicle, node) per workgroup = one wave: small batches spread over all CUs
-__global__ __launch_bounds__(REF_ROWS) void ref_window_kernel(RefCfg cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
-                                                         const double *__restrict__ tseg, const double *__restrict__ fpt,
-                                                         const double *__restrict__ tq, double *__restrict__ xr, double *__restrict__ ur)
+// One reference point: trajectory of vehicle b at trajectory time t -> x[10] = [p, v, qw, qx, qy, qz], u[4] = [wx, wy, wz, c]
+// (get_traj_pt, base_pt_publisher.py:81-133; diff_flatness, pt_publisher.py:188-248; traj_full_pt_2_x_u, :115-146)
+__device__ __forceinline__ void ref_point(const RefCfg &cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
+                                          const double *__restrict__ tseg, const double *__restrict__ fpt, int b, double t,
+                                          double xv[10], double uv[4])
 {
-    // Each lane produces 80 + 32 contiguous bytes; written directly that is a 16-byte store at an 80-byte lane stride
-    // (one fifth of every cache line per instruction).  The wave's rows are contiguous in xr (and, minus the node-N
-    // rows, in ur), so the outputs are transposed through LDS and leave as dense 512-byte wave stores.
-    __shared__ double sx[REF_ROWS * 10], su[REF_ROWS * 4];
-    const int lane = (int)threadIdx.x;
-    const int row0 = (int)blockIdx.x * REF_ROWS;
-    const int np1 = cf.N + 1, nrows = cf.B * np1;
-    const int row = row0 + lane < nrows ? row0 + lane : nrows - 1;      // tail lanes recompute the last row, never store
-    const int b = row / np1, k = row - b * np1;
-    const double t = (tq ? tq[b] : 0.0) + cf.toff + k * cf.dt;
     const double *tc = tcum + (size_t)b * (cf.n_seg + 1);
     double pvaj[12], yaw = 0.0, yawd = 0.0;
 #pragma unroll
@@ -679,8 +745,28 @@ __global__ __launch_bounds__(REF_ROWS) void ref_window_kernel(RefCfg cf, const d
     }
     const double qs = 0.5 / sqrt(tt);
     // [qw, qx, qy, qz] (pt_publisher.py:237-240, :115-128); u = [p, q, r, collective_force / mass] (:138-145)
-    const double xv[10] = {pvaj[0], pvaj[1], pvaj[2], pvaj[3], pvaj[4], pvaj[5], q[3] * qs, q[0] * qs, q[1] * qs, q[2] * qs};
-    const double uv[4] = {wp, wq, wr, u1 / cf.mass};
+    xv[0] = pvaj[0]; xv[1] = pvaj[1]; xv[2] = pvaj[2]; xv[3] = pvaj[3]; xv[4] = pvaj[4]; xv[5] = pvaj[5];
+    xv[6] = q[3] * qs; xv[7] = q[0] * qs; xv[8] = q[1] * qs; xv[9] = q[2] * qs;
+    uv[0] = wp; uv[1] = wq; uv[2] = wr; uv[3] = u1 / cf.mass;
+}
+
+#define REF_ROWS 64     // rows (vehicle, node) per workgroup = one wave: small batches spread over all CUs
+__global__ __launch_bounds__(REF_ROWS) void ref_window_kernel(RefCfg cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
+                                                         const double *__restrict__ tseg, const double *__restrict__ fpt,
+                                                         const double *__restrict__ tq, double *__restrict__ xr, double *__restrict__ ur)
+{
+    // Each lane produces 80 + 32 contiguous bytes; written directly that is a 16-byte store at an 80-byte lane stride
+    // (one fifth of every cache line per instruction).  The wave's rows are contiguous in xr (and, minus the node-N
+    // rows, in ur), so the outputs are transposed through LDS and leave as dense 512-byte wave stores.
+    __shared__ double sx[REF_ROWS * 10], su[REF_ROWS * 4];
+    const int lane = (int)threadIdx.x;
+    const int row0 = (int)blockIdx.x * REF_ROWS;
+    const int np1 = cf.N + 1, nrows = cf.B * np1;
+    const int row = row0 + lane < nrows ? row0 + lane : nrows - 1;      // tail lanes recompute the last row, never store
+    const int b = row / np1, k = row - b * np1;
+    const double t = (tq ? tq[b] : 0.0) + cf.toff + k * cf.dt;
+    double xv[10], uv[4];
+    ref_point(cf, coeff, tcum, tseg, fpt, b, t, xv, uv);
 #pragma unroll
     for (int i = 0; i < 10; ++i) sx[lane * 10 + i] = xv[i];
     // ur has no node-N rows: the number of u rows before row (b, k) is b N + k = row - b
@@ -702,6 +788,66 @@ __global__ __launch_bounds__(REF_ROWS) void ref_window_kernel(RefCfg cf, const d
     for (int i = lane; i < nu * 4; i += REF_ROWS) ug[i] = su[i];
 }
 
+// ---- f1, the reference's own bookkeeping: NMPCRefPublisher keeps a list of `ring` = 5N+1 reference points per vehicle,
+// ts_nmpc apart (pt_publisher.py:36-38, params/nmpc_params.py:40-43); every control tick drops the oldest and appends the
+// point at ros_t + T_horizon (:78-97); the controller's window is every 5th entry (:99-103).  On the device the list is a
+// ring [B][ring][14] (x(10) | u(4)); `head` (the same for every vehicle) lives on the host.
+// Fills list entries: point i of vehicle b at trajectory time (tq ? tq[b] : 0) + toff + i * tstep goes to slot
+// (slot0 + i) % ring; dup0 also copies point 0 to slot (slot0 - 1) % ring (_gen_long_list_w_traj's duplicate, :73-74).
+__global__ __launch_bounds__(256) void ref_list_fill_kernel(RefCfg cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
+                                                            const double *__restrict__ tseg, const double *__restrict__ fpt,
+                                                            const double *__restrict__ tq, double tstep, int npts, int slot0, int ring,
+                                                            int dup0, double *__restrict__ list)
+{
+    const int id = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (id >= cf.B * npts) return;
+    const int b = id / npts, i = id - b * npts;
+    double xv[10], uv[4];
+    ref_point(cf, coeff, tcum, tseg, fpt, b, (tq ? tq[b] : 0.0) + cf.toff + i * tstep, xv, uv);
+    double *d = list + ((size_t)b * ring + (slot0 + i) % ring) * 14;
+#pragma unroll
+    for (int c = 0; c < 10; ++c) d[c] = xv[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d[10 + c] = uv[c];
+    if (dup0 && i == 0) {
+        double *e = list + ((size_t)b * ring + (slot0 + ring - 1) % ring) * 14;
+#pragma unroll
+        for (int c = 0; c < 10; ++c) e[c] = xv[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) e[10 + c] = uv[c];
+    }
+}
+
+// gen_fix_pt_ref (pt_publisher.py:40-55): every entry = the odometry state, u = [0, 0, 0, c_hover]
+__global__ __launch_bounds__(256) void ref_list_fix_kernel(const double *__restrict__ x_odom, double c_hover, int B, int ring, double *__restrict__ list)
+{
+    const int id = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (id >= B * ring) return;
+    const int b = id / ring;
+    double *d = list + (size_t)id * 14;
+#pragma unroll
+    for (int c = 0; c < 10; ++c) d[c] = x_odom[(size_t)b * 10 + c];
+    d[10] = 0.0; d[11] = 0.0; d[12] = 0.0; d[13] = c_hover;
+}
+
+// get_nmpc_ref_from_long_list (:99-103): entries head, head + step, ... -> xr[B][N+1][10], ur[B][N][4]
+__global__ __launch_bounds__(256) void ref_list_window_kernel(const double *__restrict__ list, int head, int ring, int step, int B, int N,
+                                                              double *__restrict__ xr, double *__restrict__ ur)
+{
+    const int id = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (id >= B * (N + 1)) return;
+    const int b = id / (N + 1), k = id - b * (N + 1);
+    const double *s = list + ((size_t)b * ring + (head + k * step) % ring) * 14;
+    double *x = xr + (size_t)id * 10;
+#pragma unroll
+    for (int c = 0; c < 10; ++c) x[c] = s[c];
+    if (k < N) {
+        double *u = ur + ((size_t)b * N + k) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) u[c] = s[10 + c];
+    }
+}
+
 }  // namespace ndp
 
 // ------------------------------------------------------------------------------------------ C-ABI
@@ -712,10 +858,11 @@ struct ndp_handle {
     RtiParams P;
     int lds_per_wave = 0;      // doubles
     int waves = 4;             // instances per workgroup
+    int n_simd = 1024;         // SIMDs of the device (4 per CU)
+    bool use_queue = false;    // interior-point solves through the in-kernel work queue (QueueArgs)
     hipStream_t stream = nullptr;
     // persistent device state
     double *dX = nullptr, *dU = nullptr;
-    int *dStatus = nullptr, *dIters = nullptr;
     float *dForce = nullptr, *dFrag = nullptr;
     double *dKC = nullptr;     // constants block of the LDS image (fill_kc)
     int *dTables = nullptr;    // per-lane index tables of the Riccati sweep (fill_tables)
@@ -723,12 +870,27 @@ struct ndp_handle {
     double *dStamps = nullptr; // [B][16] whole-batch phase stamps (ndp_debug_stamps)
     double *dTraj = nullptr;   // f1: [B][n_seg][28] coeff | [B][n_seg+1] time_cum | [B][n_seg] time_seg | [B][3] final_pt
     int traj_seg = 0;
+    double *dRefList = nullptr; // f1: the reference's sliding list of reference points, ring [B][5N+1][14] (allocated on first use)
+    int list_head = 0, list_step = 5;
     double *dRelay = nullptr;  // follower relay: [B][4] = filtered offset xyz + initialised flag
-    double *sThr = nullptr;    // staging: vz[B] throttle[B] k[B] | u0[B][4] cmd[B][4]
+    double *sThr = nullptr;    // staging of the f1-f4 host entry points: 11 B doubles
+    unsigned *dQctr = nullptr; // work queue: 3 monotonic counters | ring of B ids | [B][64] forces
+    int *dQids = nullptr;
+    float *dQf = nullptr;
     bool have_mlp = false;
-    // staging for the host-pointer entry points
+    // Host-pointer entry points.  ONE device block holds every input of a step (x0 | xr | ur | f | other | ego_xy, each
+    // 256-byte aligned) and one holds its small outputs (u0 | status | iters): with a pinned host mirror of both (batches
+    // whose inputs fit PACK_LIMIT) a step is one H2D copy, the launch, and D2H copies that are all in flight before the
+    // single synchronisation.  The sx0.. / dStatus.. pointers below are views into those blocks.
+    unsigned char *dIn = nullptr, *dOut = nullptr, *hIn = nullptr, *hOut = nullptr;
+    size_t off_x0 = 0, off_xr = 0, off_ur = 0, off_f = 0, off_other = 0, off_ego = 0, in_bytes = 0;
+    size_t off_u0 = 0, off_st = 0, off_it = 0, out_bytes = 0;
     double *sx0 = nullptr, *sxr = nullptr, *sur = nullptr, *sother = nullptr, *sego = nullptr, *su0 = nullptr, *sdbg = nullptr;
     float *sf = nullptr;
+    int *dStatus = nullptr, *dIters = nullptr;
+    // the last foreign stream a *_device call enqueued on: the getters wait for it (hipEvent)
+    hipEvent_t evLast = nullptr;
+    bool ev_pending = false;
     // timing
     int timing = 0;            // 0 off, n > 0: bracket every n-th launch of each kernel with HIP events
     int64_t launch_no[2] = {0, 0};
@@ -738,6 +900,8 @@ struct ndp_handle {
     std::mutex mu;
     std::string err;
 };
+
+enum : size_t { PACK_LIMIT = (size_t)1 << 20 };
 
 static thread_local std::string g_create_err;
 
@@ -753,6 +917,14 @@ static thread_local std::string g_create_err;
 static size_t nxs(const ndp_handle *h) { return (size_t)h->cfg.batch * (h->cfg.N + 1) * NX; }
 static size_t nus(const ndp_handle *h) { return (size_t)h->cfg.batch * h->cfg.N * NU; }
 static size_t nfs(const ndp_handle *h) { return (size_t)h->cfg.batch * (h->cfg.N + 1) * 3; }
+static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// the shapes the work-queue form of rti_kernel is instantiated for (compile-time horizon and iteration count)
+static bool queue_shape(const ndp_handle *h)
+{
+    return h->cfg.qp_precision == 0 &&
+           ((h->cfg.N == 20 && h->cfg.n_rti == 1 && h->waves == 4) || (h->cfg.N == 40 && h->cfg.n_rti == 2 && h->waves == 2));
+}
 
 extern "C" {
 
@@ -794,11 +966,15 @@ int ndp_destroy(ndp_handle *h)
     if (!h) return -1;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->ev_pending) (void)hipEventSynchronize(h->evLast);
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    void *ptrs[] = {h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dX, h->dU, h->dStatus, h->dIters, h->dForce, h->dFrag, h->sx0, h->sxr, h->sur,
-                    h->sother, h->sego, h->su0, h->sdbg, h->sf};
+    if (h->evLast) (void)hipEventDestroy(h->evLast);
+    void *ptrs[] = {h->dRefList, h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dX, h->dU, h->dForce, h->dFrag,
+                    h->dIn, h->dOut, h->sdbg, h->dQctr, h->dQids, h->dQf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->hIn) (void)hipHostFree(h->hIn);
+    if (h->hOut) (void)hipHostFree(h->hOut);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -808,8 +984,9 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
 {
     if (!cfg || !out) { g_create_err = "ndp_create: null argument"; return -1; }
     *out = nullptr;
-    if (cfg->batch < 1 || cfg->N < 2 || slots_for(cfg->N) > 5 || cfg->n_rti < 1 || cfg->qp_precision < 0 || cfg->qp_precision > 2) {
-        g_create_err = "ndp_create: need batch >= 1, 2 <= N <= 46, n_rti >= 1, qp_precision in 0..2";
+    if (cfg->batch < 1 || cfg->N < 2 || slots_for(cfg->N) > 5 || cfg->n_rti < 1 || cfg->qp_precision < 0 || cfg->qp_precision > 2 ||
+        cfg->work_queue < 0 || cfg->work_queue > 2 || !(cfg->ts_nmpc > 0.0) || cfg->dt < cfg->ts_nmpc) {
+        g_create_err = "ndp_create: need batch >= 1, 2 <= N <= 46, n_rti >= 1, qp_precision in 0..2, work_queue in 0..2, 0 < ts_nmpc <= dt";
         return -2;
     }
     int ndev = 0;
@@ -822,6 +999,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     if (!h) return -4;
     h->cfg = *cfg;
     h->P = to_params(*cfg);
+    h->list_step = (int)(cfg->dt / cfg->ts_nmpc + 0.5);      // params/nmpc_params.py:40-43: every 5th list entry is a node
     h->lds_per_wave = (lds_doubles(cfg->N) + 1) & ~1;   // keep 16-byte alignment per wave slice
     const size_t per_wave_bytes = (size_t)h->lds_per_wave * sizeof(double);
     h->waves = 4;
@@ -832,16 +1010,33 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         return -5;
     };
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return fail("hipSetDevice", e);
+    {
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
+        h->n_simd = 4 * prop.multiProcessorCount;
+    }
+    // work queue: by default when the batch holds more instances than the device has SIMDs (below that every SIMD has at
+    // most one instance and nothing can be re-balanced) and the QP mode has an early exit to defer from
+    if (cfg->work_queue == 1 && !(queue_shape(h) && cfg->qp_mode == NDP_QP_AUTO)) {
+        g_create_err = "ndp_create: work_queue = 1 needs qp_mode AUTO, qp_precision 0 and (N, n_rti) = (20, 1) or (40, 2)";
+        delete h;
+        return -2;
+    }
+    h->use_queue = cfg->work_queue == 1 ||
+                   (cfg->work_queue == 0 && queue_shape(h) && cfg->qp_mode == NDP_QP_AUTO && cfg->batch > h->n_simd);
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&h->evLast, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     const size_t B = cfg->batch;
 #define ALLOC(p, n)                                                                      \
     if ((e = hipMalloc((void **)&(p), (n))) != hipSuccess) return fail("hipMalloc " #p, e)
     ALLOC(h->dX, nxs(h) * 8); ALLOC(h->dU, nus(h) * 8);
-    ALLOC(h->dStatus, B * 4); ALLOC(h->dIters, B * 4);
     ALLOC(h->dForce, nfs(h) * 4); ALLOC(h->dFrag, FR_TOTAL * 4); ALLOC(h->dKC, KC_SC * 8);
     ALLOC(h->dThr, B * 8 * 8); ALLOC(h->sThr, B * 11 * 8);
     ALLOC(h->dRelay, B * 4 * 8);
+    ALLOC(h->dQctr, 256); ALLOC(h->dQids, B * 4); ALLOC(h->dQf, B * 64 * 4);
     (void)hipMemsetAsync(h->dRelay, 0, B * 4 * 8, h->stream);
+    (void)hipMemsetAsync(h->dQctr, 0, 256, h->stream);
+    (void)hipMemsetAsync(h->dQf, 0, B * 64 * 4, h->stream);
     {
         double kc[KC_SC];
         fill_kc(h->P, kc);
@@ -852,14 +1047,35 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         if ((e = hipMemcpyAsync(h->dTables, tb.data(), TB_WORDS * 4, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail("hipMemcpy tables", e);
         if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
     }
-    ALLOC(h->sx0, B * NX * 8); ALLOC(h->sxr, nxs(h) * 8); ALLOC(h->sur, nus(h) * 8);
-    ALLOC(h->sother, nxs(h) * 8); ALLOC(h->sego, B * 2 * 8); ALLOC(h->su0, B * NU * 8);
-    ALLOC(h->sf, nfs(h) * 4); ALLOC(h->sdbg, (size_t)(lds_doubles(cfg->N) + DBG_EXTRA) * 8);
+    {   // input / output blocks and their views
+        size_t o = 0;
+        h->off_x0 = o; o += up256(B * NX * 8);
+        h->off_xr = o; o += up256(nxs(h) * 8);
+        h->off_ur = o; o += up256(nus(h) * 8);
+        h->off_f = o; o += up256(nfs(h) * 4);
+        h->off_other = o; o += up256(nxs(h) * 8);
+        h->off_ego = o; o += up256(B * 2 * 8);
+        h->in_bytes = o;
+        o = 0;
+        h->off_u0 = o; o += up256(B * NU * 8);
+        h->off_st = o; o += up256(B * 4);
+        h->off_it = o; o += up256(B * 4);
+        h->out_bytes = o;
+        ALLOC(h->dIn, h->in_bytes); ALLOC(h->dOut, h->out_bytes);
+        h->sx0 = (double *)(h->dIn + h->off_x0); h->sxr = (double *)(h->dIn + h->off_xr); h->sur = (double *)(h->dIn + h->off_ur);
+        h->sf = (float *)(h->dIn + h->off_f); h->sother = (double *)(h->dIn + h->off_other); h->sego = (double *)(h->dIn + h->off_ego);
+        h->su0 = (double *)(h->dOut + h->off_u0); h->dStatus = (int *)(h->dOut + h->off_st); h->dIters = (int *)(h->dOut + h->off_it);
+        if (h->in_bytes <= PACK_LIMIT) {
+            if ((e = hipHostMalloc((void **)&h->hIn, h->in_bytes, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc hIn", e);
+            if ((e = hipHostMalloc((void **)&h->hOut, h->out_bytes + (nxs(h) + nus(h)) * 8, hipHostMallocDefault)) != hipSuccess)
+                return fail("hipHostMalloc hOut", e);
+        }
+        ALLOC(h->sdbg, (size_t)(lds_doubles(cfg->N) + DBG_EXTRA) * 8);
+    }
 #undef ALLOC
     (void)hipMemsetAsync(h->dX, 0, nxs(h) * 8, h->stream);
     (void)hipMemsetAsync(h->dU, 0, nus(h) * 8, h->stream);
-    (void)hipMemsetAsync(h->dStatus, 0, B * 4, h->stream);
-    (void)hipMemsetAsync(h->dIters, 0, B * 4, h->stream);
+    (void)hipMemsetAsync(h->dOut, 0, h->out_bytes, h->stream);
     (void)hipMemsetAsync(h->dForce, 0, nfs(h) * 4, h->stream);
     // allow the big dynamic-LDS launches
     const int lds_bytes = (int)(per_wave_bytes * h->waves);
@@ -867,8 +1083,9 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
                          (const void *)rti_kernel<5, 4, false>, (const void *)rti_kernel<5, 2, false>, (const void *)rti_kernel<5, 1, false>,
                          (const void *)rti_kernel<3, 4, true>, (const void *)rti_kernel<3, 2, true>, (const void *)rti_kernel<3, 1, true>,
                          (const void *)rti_kernel<3, 4, false, 20>, (const void *)rti_kernel<3, 4, true, 20>,
+                         (const void *)rti_kernel<3, 4, false, 20, 0, 1, true>, (const void *)rti_kernel<3, 4, true, 20, 0, 1, true>,
                          (const void *)rti_kernel<5, 1, false, 0, 1>, (const void *)rti_kernel<5, 1, false, 0, 2>,
-                         (const void *)rti_kernel<5, 2, false, 40, 0, 2>};
+                         (const void *)rti_kernel<5, 2, false, 40, 0, 2>, (const void *)rti_kernel<5, 2, false, 40, 0, 2, true>};
     if ((e = hipFuncSetAttribute((const void *)mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(FR_TOTAL * sizeof(float)))) != hipSuccess)
         return fail("hipFuncSetAttribute(mlp_kernel)", e);
@@ -914,8 +1131,36 @@ static int end_timing(ndp_handle *h, hipStream_t s)
     return 0;
 }
 
-static int launch_mlp(ndp_handle *h, const double *d_other, const double *d_ego, const double *d_ego_xy, float *d_f,
-                      hipStream_t s)
+// A *_device call enqueued on a caller's stream: remember it so that the getters (ndp_get_status, ndp_get_iterate, ...)
+// wait for that work and not only for the library's own stream.  Streams being captured into a graph are skipped (an
+// event recorded there belongs to the graph and cannot be waited on from the host).
+static int note_stream(ndp_handle *h, hipStream_t s)
+{
+    if (s == h->stream) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
+    NDP_HIP(h, hipEventRecord(h->evLast, s));
+    h->ev_pending = true;
+    return 0;
+}
+static int wait_all(ndp_handle *h)
+{
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->ev_pending) {
+        NDP_HIP(h, hipEventSynchronize(h->evLast));
+        h->ev_pending = false;
+    }
+    return 0;
+}
+
+struct Neigh {                 // neighbour windows of a step (device pointers)
+    const double *other = nullptr;
+    int stride = NX;           // doubles per node: 10 or 6
+    const int *index = nullptr;
+    const double *ego_xy = nullptr;
+};
+
+static int launch_mlp(ndp_handle *h, const Neigh &nb, const double *d_ego, float *d_f, hipStream_t s)
 {
     if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }
     const int np1 = h->cfg.N + 1, rows = h->cfg.batch * np1;
@@ -923,39 +1168,42 @@ static int launch_mlp(ndp_handle *h, const double *d_other, const double *d_ego,
     const int grid = (ntiles + 3) / 4;
     int rc = begin_timing(h, s, 1);
     if (rc) return rc;
-    hipLaunchKernelGGL(mlp_kernel, dim3(grid), dim3(256), FR_TOTAL * sizeof(float), s, (const float *)h->dFrag, d_other, d_ego, d_ego_xy, d_f,
-                       rows, np1, h->cfg.r_horiz * h->cfg.r_horiz);
+    hipLaunchKernelGGL(mlp_kernel, dim3(grid), dim3(256), FR_TOTAL * sizeof(float), s, (const float *)h->dFrag, nb.other, d_ego, nb.ego_xy, d_f,
+                       rows, np1, h->cfg.r_horiz * h->cfg.r_horiz, nb.stride, nb.index);
     NDP_HIP(h, hipGetLastError());
     return end_timing(h, s);
 }
 
 static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, const double *d_ur, const float *d_f,
-                      double *d_u0, double *d_dbg, hipStream_t s, const double *d_other = nullptr,
-                      const double *d_ego_xy = nullptr)
+                      double *d_u0, double *d_dbg, hipStream_t s, const Neigh *nb = nullptr)
 {
     BatchPtrs bp{h->dKC, h->dTables, d_x0, d_xr, d_ur, d_f, h->dX, h->dU, d_u0, h->dStatus, h->dIters, d_dbg, h->dStamps};
-    MlpArgs ma{d_other ? h->dFrag : nullptr, d_other, d_ego_xy, h->dForce, h->cfg.r_horiz * h->cfg.r_horiz};
+    const bool fused = nb && nb->other;
+    MlpArgs ma{fused ? h->dFrag : nullptr, fused ? nb->other : nullptr, fused ? nb->ego_xy : nullptr, h->dForce,
+               h->cfg.r_horiz * h->cfg.r_horiz, fused ? nb->stride : NX, fused ? nb->index : nullptr};
+    QueueArgs qa{h->dQctr, h->dQids, h->dQf};
     const int B = h->cfg.batch, W = h->waves;
     const dim3 grid((B + W - 1) / W), block(64 * W);
     const size_t shm = (size_t)h->lds_per_wave * sizeof(double) * W;
     const int ns = slots_for(h->cfg.N);
+    const bool q = h->use_queue && !d_dbg;
     int rc = begin_timing(h, s, 0);
     if (rc) return rc;
     if (h->cfg.qp_precision) {      // precision study (BASELINE config 5): one wave per workgroup, unfused, any horizon
-        if (d_other) { h->err = "qp_precision != 0 supports f / no disturbance only (run ndp_downwash first)"; return -12; }
+        if (fused) { h->err = "qp_precision != 0 supports f / no disturbance only (run ndp_downwash first)"; return -12; }
         const size_t shm1 = (size_t)h->lds_per_wave * sizeof(double);
-        if (h->cfg.qp_precision == 1) hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 1>), dim3(B), dim3(64), shm1, s, h->P, bp, B, h->lds_per_wave, ma);
-        else hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 2>), dim3(B), dim3(64), shm1, s, h->P, bp, B, h->lds_per_wave, ma);
+        if (h->cfg.qp_precision == 1) hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 1>), dim3(B), dim3(64), shm1, s, h->P, bp, B, h->lds_per_wave, ma, qa);
+        else hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 2>), dim3(B), dim3(64), shm1, s, h->P, bp, B, h->lds_per_wave, ma, qa);
         NDP_HIP(h, hipGetLastError());
         return end_timing(h, s);
     }
-#define LAUNCH(NS, WV, FU) hipLaunchKernelGGL((rti_kernel<NS, WV, FU>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma)
+#define LAUNCH(...) hipLaunchKernelGGL((rti_kernel<__VA_ARGS__>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma, qa)
     if (h->cfg.N == 20 && h->cfg.n_rti == 1 && W == 4) {   // the reference configuration (params/nmpc_params.py:9, 1 RTI iteration): compile-time instantiation
-        if (d_other) hipLaunchKernelGGL((rti_kernel<3, 4, true, 20>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma);
-        else hipLaunchKernelGGL((rti_kernel<3, 4, false, 20>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma);
-    } else if (h->cfg.N == 40 && h->cfg.n_rti == 2 && W == 2 && !d_other) {   // BASELINE config 5's shape, compile-time as well
-        hipLaunchKernelGGL((rti_kernel<5, 2, false, 40, 0, 2>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma);
-    } else if (d_other) { if (W == 4) LAUNCH(3, 4, true); else if (W == 2) LAUNCH(3, 2, true); else LAUNCH(3, 1, true); }
+        if (fused) { if (q) LAUNCH(3, 4, true, 20, 0, 1, true); else LAUNCH(3, 4, true, 20); }
+        else { if (q) LAUNCH(3, 4, false, 20, 0, 1, true); else LAUNCH(3, 4, false, 20); }
+    } else if (h->cfg.N == 40 && h->cfg.n_rti == 2 && W == 2 && !fused) {   // BASELINE config 5's shape, compile-time as well
+        if (q) LAUNCH(5, 2, false, 40, 0, 2, true); else LAUNCH(5, 2, false, 40, 0, 2);
+    } else if (fused) { if (W == 4) LAUNCH(3, 4, true); else if (W == 2) LAUNCH(3, 2, true); else LAUNCH(3, 1, true); }
     else if (ns <= 3) { if (W == 4) LAUNCH(3, 4, false); else if (W == 2) LAUNCH(3, 2, false); else LAUNCH(3, 1, false); }
     else { if (W == 4) LAUNCH(5, 4, false); else if (W == 2) LAUNCH(5, 2, false); else LAUNCH(5, 1, false); }
 #undef LAUNCH
@@ -970,6 +1218,23 @@ static bool can_fuse(const ndp_handle *h)
            (size_t)h->lds_per_wave * sizeof(double) * h->waves >= FR_TOTAL * sizeof(float);
 }
 
+// one control step on device pointers: [mlp_kernel ->] rti_kernel (no locking, no sync)
+static int enqueue_step(ndp_handle *h, const double *d_x0, const double *d_xr, const double *d_ur, const float *d_f,
+                        const Neigh &nb, double *d_u0, double *d_dbg, hipStream_t s)
+{
+    if ((d_f || nb.other) && !h->cfg.use_fd) { h->err = "ndp_step: a disturbance force needs use_fd = 1 (NDP model)"; return -8; }
+    if (nb.other) {
+        if (d_f) { h->err = "ndp_step: pass either f or other, not both"; return -7; }
+        if (nb.stride != 10 && nb.stride != 6) { h->err = "ndp_step: other_stride must be 10 or 6"; return -13; }
+        if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }
+        if (can_fuse(h)) return launch_rti(h, d_x0, d_xr, d_ur, nullptr, d_u0, d_dbg, s, &nb);
+        int rc = launch_mlp(h, nb, d_xr, h->dForce, s);
+        if (rc) return rc;
+        d_f = h->dForce;
+    }
+    return launch_rti(h, d_x0, d_xr, d_ur, d_f, d_u0, d_dbg, s);
+}
+
 int ndp_reset_device(ndp_handle *h, const void *d_xr, const void *d_ur, void *stream)
 {
     if (!h || !d_xr || !d_ur) return -1;
@@ -978,7 +1243,7 @@ int ndp_reset_device(ndp_handle *h, const void *d_xr, const void *d_ur, void *st
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     NDP_HIP(h, hipMemcpyAsync(h->dX, d_xr, nxs(h) * 8, hipMemcpyDeviceToDevice, s));
     NDP_HIP(h, hipMemcpyAsync(h->dU, d_ur, nus(h) * 8, hipMemcpyDeviceToDevice, s));
-    return 0;
+    return note_stream(h, s);
 }
 
 int ndp_reset(ndp_handle *h, const double *xr, const double *ur)
@@ -986,96 +1251,120 @@ int ndp_reset(ndp_handle *h, const double *xr, const double *ur)
     if (!h || !xr || !ur) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
     NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = wait_all(h);
+    if (rc) return rc;
     NDP_HIP(h, hipMemcpyAsync(h->dX, xr, nxs(h) * 8, hipMemcpyHostToDevice, h->stream));
     NDP_HIP(h, hipMemcpyAsync(h->dU, ur, nus(h) * 8, hipMemcpyHostToDevice, h->stream));
     NDP_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 
-int ndp_step_device(ndp_handle *h, const void *d_x0, const void *d_xr, const void *d_ur, const void *d_f,
-                    const void *d_other, const void *d_ego_xy, void *d_u0, void *stream)
+int ndp_step_device_ex(ndp_handle *h, const void *d_x0, const void *d_xr, const void *d_ur, const void *d_f,
+                       const void *d_other, int other_stride, const void *d_other_index, const void *d_ego_xy,
+                       void *d_u0, void *stream)
 {
     if (!h || !d_x0 || !d_xr || !d_ur || !d_u0) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    const float *force = (const float *)d_f;
-    if ((d_f || d_other) && !h->cfg.use_fd) { h->err = "ndp_step: a disturbance force needs use_fd = 1 (NDP model)"; return -8; }
-    if (d_other) {
-        if (d_f) { h->err = "ndp_step: pass either f or other, not both"; return -7; }
-        if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }
-        if (can_fuse(h))
-            return launch_rti(h, (const double *)d_x0, (const double *)d_xr, (const double *)d_ur, nullptr,
-                              (double *)d_u0, nullptr, s, (const double *)d_other, (const double *)d_ego_xy);
-        int rc = launch_mlp(h, (const double *)d_other, (const double *)d_xr, (const double *)d_ego_xy, h->dForce, s);
-        if (rc) return rc;
-        force = h->dForce;
-    }
-    return launch_rti(h, (const double *)d_x0, (const double *)d_xr, (const double *)d_ur, force, (double *)d_u0,
-                      nullptr, s);
+    Neigh nb;
+    nb.other = (const double *)d_other; nb.stride = other_stride; nb.index = (const int *)d_other_index; nb.ego_xy = (const double *)d_ego_xy;
+    int rc = enqueue_step(h, (const double *)d_x0, (const double *)d_xr, (const double *)d_ur, (const float *)d_f, nb,
+                          (double *)d_u0, nullptr, s);
+    return rc ? rc : note_stream(h, s);
 }
 
-static int worst_status(ndp_handle *h, int *out)
+int ndp_step_device(ndp_handle *h, const void *d_x0, const void *d_xr, const void *d_ur, const void *d_f,
+                    const void *d_other, const void *d_ego_xy, void *d_u0, void *stream)
 {
-    std::vector<int> st(h->cfg.batch);
-    NDP_HIP(h, hipMemcpy(st.data(), h->dStatus, st.size() * 4, hipMemcpyDeviceToHost));
-    int w = 0;
-    for (int v : st) w = v > w ? v : w;
-    *out = w;
-    return 0;
+    return ndp_step_device_ex(h, d_x0, d_xr, d_ur, d_f, d_other, NX, nullptr, d_ego_xy, d_u0, stream);
 }
 
+// Host-pointer step.  Everything under one lock; one synchronisation.
 static int step_host(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
-                     const double *other, const double *ego_xy, double *u0, double *dump)
+                     const double *other, const double *ego_xy, double *u0, double *X_out, double *U_out,
+                     int32_t *status_out, int32_t *iters_out, double *dump)
 {
     if (!h || !x0 || !xr || !ur || !u0) return -1;
-    std::unique_lock<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t s = h->stream;
     const size_t B = h->cfg.batch;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    NDP_HIP(h, hipMemcpyAsync(h->sx0, x0, B * NX * 8, hipMemcpyHostToDevice, s));
-    NDP_HIP(h, hipMemcpyAsync(h->sxr, xr, nxs(h) * 8, hipMemcpyHostToDevice, s));
-    NDP_HIP(h, hipMemcpyAsync(h->sur, ur, nus(h) * 8, hipMemcpyHostToDevice, s));
-    if (f) NDP_HIP(h, hipMemcpyAsync(h->sf, f, nfs(h) * 4, hipMemcpyHostToDevice, s));
-    if (other) NDP_HIP(h, hipMemcpyAsync(h->sother, other, nxs(h) * 8, hipMemcpyHostToDevice, s));
-    if (ego_xy) NDP_HIP(h, hipMemcpyAsync(h->sego, ego_xy, B * 2 * 8, hipMemcpyHostToDevice, s));
-    const float *force = f ? h->sf : nullptr;
-    if ((f || other) && !h->cfg.use_fd) { h->err = "ndp_step: a disturbance force needs use_fd = 1 (NDP model)"; return -8; }
-    int rc = 0;
-    if (other) {
-        if (f) { h->err = "ndp_step: pass either f or other, not both"; return -7; }
-        if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }
-        if (can_fuse(h)) {
-            rc = launch_rti(h, h->sx0, h->sxr, h->sur, nullptr, h->su0, dump ? h->sdbg : nullptr, s, h->sother,
-                            ego_xy ? h->sego : nullptr);
-        } else {
-            rc = launch_mlp(h, h->sother, h->sxr, ego_xy ? h->sego : nullptr, h->dForce, s);
-            if (rc) return rc;
-            rc = launch_rti(h, h->sx0, h->sxr, h->sur, h->dForce, h->su0, dump ? h->sdbg : nullptr, s);
-        }
+    if (h->ev_pending) { int rc = wait_all(h); if (rc) return rc; }   // work a caller left on its own stream comes first
+    const bool pack = h->hIn != nullptr;
+    if (pack) {
+        // pinned mirror: one copy covers the leading blocks up to the last one present (x0 | xr | ur | f | other | ego_xy)
+        memcpy(h->hIn + h->off_x0, x0, B * NX * 8);
+        memcpy(h->hIn + h->off_xr, xr, nxs(h) * 8);
+        memcpy(h->hIn + h->off_ur, ur, nus(h) * 8);
+        size_t end = h->off_ur + nus(h) * 8;
+        if (f) { memcpy(h->hIn + h->off_f, f, nfs(h) * 4); end = h->off_f + nfs(h) * 4; }
+        if (other) { memcpy(h->hIn + h->off_other, other, nxs(h) * 8); end = h->off_other + nxs(h) * 8; }
+        if (ego_xy) { memcpy(h->hIn + h->off_ego, ego_xy, B * 2 * 8); end = h->off_ego + B * 2 * 8; }
+        NDP_HIP(h, hipMemcpyAsync(h->dIn, h->hIn, end, hipMemcpyHostToDevice, s));
     } else {
-        rc = launch_rti(h, h->sx0, h->sxr, h->sur, force, h->su0, dump ? h->sdbg : nullptr, s);
+        NDP_HIP(h, hipMemcpyAsync(h->sx0, x0, B * NX * 8, hipMemcpyHostToDevice, s));
+        NDP_HIP(h, hipMemcpyAsync(h->sxr, xr, nxs(h) * 8, hipMemcpyHostToDevice, s));
+        NDP_HIP(h, hipMemcpyAsync(h->sur, ur, nus(h) * 8, hipMemcpyHostToDevice, s));
+        if (f) NDP_HIP(h, hipMemcpyAsync(h->sf, f, nfs(h) * 4, hipMemcpyHostToDevice, s));
+        if (other) NDP_HIP(h, hipMemcpyAsync(h->sother, other, nxs(h) * 8, hipMemcpyHostToDevice, s));
+        if (ego_xy) NDP_HIP(h, hipMemcpyAsync(h->sego, ego_xy, B * 2 * 8, hipMemcpyHostToDevice, s));
     }
+    Neigh nb;
+    nb.other = other ? h->sother : nullptr;
+    nb.ego_xy = ego_xy ? h->sego : nullptr;
+    int rc = enqueue_step(h, h->sx0, h->sxr, h->sur, f ? h->sf : nullptr, nb, h->su0, dump ? h->sdbg : nullptr, s);
     if (rc) return rc;
-    NDP_HIP(h, hipMemcpyAsync(u0, h->su0, B * NU * 8, hipMemcpyDeviceToHost, s));
-    if (dump) NDP_HIP(h, hipMemcpyAsync(dump, h->sdbg, (size_t)(lds_doubles(h->cfg.N) + DBG_EXTRA) * 8, hipMemcpyDeviceToHost, s));
-    NDP_HIP(h, hipStreamSynchronize(s));
+    std::vector<int32_t> st_tmp;
+    const int32_t *st = nullptr;
+    if (pack) {
+        unsigned char *ho = h->hOut;
+        NDP_HIP(h, hipMemcpyAsync(ho, h->dOut, h->out_bytes, hipMemcpyDeviceToHost, s));           // u0 | status | iters
+        if (X_out) NDP_HIP(h, hipMemcpyAsync(ho + h->out_bytes, h->dX, nxs(h) * 8, hipMemcpyDeviceToHost, s));
+        if (U_out) NDP_HIP(h, hipMemcpyAsync(ho + h->out_bytes + nxs(h) * 8, h->dU, nus(h) * 8, hipMemcpyDeviceToHost, s));
+        if (dump) NDP_HIP(h, hipMemcpyAsync(dump, h->sdbg, (size_t)(lds_doubles(h->cfg.N) + DBG_EXTRA) * 8, hipMemcpyDeviceToHost, s));
+        NDP_HIP(h, hipStreamSynchronize(s));
+        memcpy(u0, ho + h->off_u0, B * NU * 8);
+        st = (const int32_t *)(ho + h->off_st);
+        if (status_out) memcpy(status_out, st, B * 4);
+        if (iters_out) memcpy(iters_out, ho + h->off_it, B * 4);
+        if (X_out) memcpy(X_out, ho + h->out_bytes, nxs(h) * 8);
+        if (U_out) memcpy(U_out, ho + h->out_bytes + nxs(h) * 8, nus(h) * 8);
+    } else {
+        int32_t *stp = status_out;
+        if (!stp) { st_tmp.resize(B); stp = st_tmp.data(); }
+        NDP_HIP(h, hipMemcpyAsync(u0, h->su0, B * NU * 8, hipMemcpyDeviceToHost, s));
+        NDP_HIP(h, hipMemcpyAsync(stp, h->dStatus, B * 4, hipMemcpyDeviceToHost, s));
+        if (iters_out) NDP_HIP(h, hipMemcpyAsync(iters_out, h->dIters, B * 4, hipMemcpyDeviceToHost, s));
+        if (X_out) NDP_HIP(h, hipMemcpyAsync(X_out, h->dX, nxs(h) * 8, hipMemcpyDeviceToHost, s));
+        if (U_out) NDP_HIP(h, hipMemcpyAsync(U_out, h->dU, nus(h) * 8, hipMemcpyDeviceToHost, s));
+        if (dump) NDP_HIP(h, hipMemcpyAsync(dump, h->sdbg, (size_t)(lds_doubles(h->cfg.N) + DBG_EXTRA) * 8, hipMemcpyDeviceToHost, s));
+        NDP_HIP(h, hipStreamSynchronize(s));
+        st = stp;
+    }
     int w = 0;
-    rc = worst_status(h, &w);
-    return rc ? rc : w;
+    for (size_t i = 0; i < B; ++i) w = st[i] > w ? st[i] : w;
+    return w;
 }
 
 int ndp_step(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
              const double *other, const double *ego_xy, double *u0)
 {
-    return step_host(h, x0, xr, ur, f, other, ego_xy, u0, nullptr);
+    return step_host(h, x0, xr, ur, f, other, ego_xy, u0, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+int ndp_step_ex(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
+                const double *other, const double *ego_xy, double *u0, double *X_out, double *U_out,
+                int32_t *status_out, int32_t *iters_out)
+{
+    return step_host(h, x0, xr, ur, f, other, ego_xy, u0, X_out, U_out, status_out, iters_out, nullptr);
 }
 
 int ndp_step_debug(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
                    const double *other, const double *ego_xy, double *u0, double *lds_dump)
 {
     if (h && h->cfg.batch != 1) { h->err = "ndp_step_debug: batch must be 1"; return -9; }
-    return step_host(h, x0, xr, ur, f, other, ego_xy, u0, lds_dump);
+    return step_host(h, x0, xr, ur, f, other, ego_xy, u0, nullptr, nullptr, nullptr, nullptr, lds_dump);
 }
 
 int ndp_downwash_device(ndp_handle *h, const void *d_other, const void *d_ego_ref, const void *d_ego_xy,
@@ -1085,7 +1374,10 @@ int ndp_downwash_device(ndp_handle *h, const void *d_other, const void *d_ego_re
     std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    return launch_mlp(h, (const double *)d_other, (const double *)d_ego_ref, (const double *)d_ego_xy, (float *)d_f_out, s);
+    Neigh nb;
+    nb.other = (const double *)d_other; nb.ego_xy = (const double *)d_ego_xy;
+    int rc = launch_mlp(h, nb, (const double *)d_ego_ref, (float *)d_f_out, s);
+    return rc ? rc : note_stream(h, s);
 }
 
 int ndp_downwash(ndp_handle *h, const double *other, const double *ego_ref, const double *ego_xy, float *f_out)
@@ -1098,7 +1390,9 @@ int ndp_downwash(ndp_handle *h, const double *other, const double *ego_ref, cons
     NDP_HIP(h, hipMemcpyAsync(h->sother, other, nxs(h) * 8, hipMemcpyHostToDevice, s));
     NDP_HIP(h, hipMemcpyAsync(h->sxr, ego_ref, nxs(h) * 8, hipMemcpyHostToDevice, s));
     if (ego_xy) NDP_HIP(h, hipMemcpyAsync(h->sego, ego_xy, B * 2 * 8, hipMemcpyHostToDevice, s));
-    int rc = launch_mlp(h, h->sother, h->sxr, ego_xy ? h->sego : nullptr, h->dForce, s);
+    Neigh nb;
+    nb.other = h->sother; nb.ego_xy = ego_xy ? h->sego : nullptr;
+    int rc = launch_mlp(h, nb, h->sxr, h->dForce, s);
     if (rc) return rc;
     NDP_HIP(h, hipMemcpyAsync(f_out, h->dForce, nfs(h) * 4, hipMemcpyDeviceToHost, s));
     NDP_HIP(h, hipStreamSynchronize(s));
@@ -1110,7 +1404,8 @@ int ndp_get_iterate(ndp_handle *h, double *X, double *U)
     if (!h) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    int rc = wait_all(h);
+    if (rc) return rc;
     if (X) NDP_HIP(h, hipMemcpy(X, h->dX, nxs(h) * 8, hipMemcpyDeviceToHost));
     if (U) NDP_HIP(h, hipMemcpy(U, h->dU, nus(h) * 8, hipMemcpyDeviceToHost));
     return 0;
@@ -1121,7 +1416,8 @@ int ndp_set_iterate(ndp_handle *h, const double *X, const double *U)
     if (!h) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    int rc = wait_all(h);
+    if (rc) return rc;
     if (X) NDP_HIP(h, hipMemcpy(h->dX, X, nxs(h) * 8, hipMemcpyHostToDevice));
     if (U) NDP_HIP(h, hipMemcpy(h->dU, U, nus(h) * 8, hipMemcpyHostToDevice));
     return 0;
@@ -1132,7 +1428,8 @@ int ndp_get_status(ndp_handle *h, int32_t *status, int32_t *ipm_iters)
     if (!h) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    int rc = wait_all(h);
+    if (rc) return rc;
     if (status) NDP_HIP(h, hipMemcpy(status, h->dStatus, (size_t)h->cfg.batch * 4, hipMemcpyDeviceToHost));
     if (ipm_iters) NDP_HIP(h, hipMemcpy(ipm_iters, h->dIters, (size_t)h->cfg.batch * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -1163,33 +1460,44 @@ int ndp_throttle_reset(ndp_handle *h)
     return 0;
 }
 
+// The host-pointer forms below hold the handle's lock from the first staging copy to the read-back: they share the
+// staging area sThr (and sx0 / sxr / sur / su0 of the step), which a concurrent call must not overwrite in between.
+static int launch_throttle(ndp_handle *h, const double *d_vz, const double *d_throttle, double *d_k, hipStream_t s)
+{
+    hipLaunchKernelGGL(throttle_kernel, dim3((h->cfg.batch + 255) / 256), dim3(256), 0, s, thr_cfg(h), h->dThr, d_vz, d_throttle, d_k, h->cfg.batch);
+    NDP_HIP(h, hipGetLastError());
+    return 0;
+}
+
 int ndp_throttle_update_device(ndp_handle *h, const void *d_vz, const void *d_throttle, void *d_k, void *stream)
 {
     if (!h || !d_vz || !d_throttle || !d_k) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(throttle_kernel, dim3((h->cfg.batch + 255) / 256), dim3(256), 0, s, thr_cfg(h), h->dThr,
-                       (const double *)d_vz, (const double *)d_throttle, (double *)d_k, h->cfg.batch);
-    NDP_HIP(h, hipGetLastError());
-    return 0;
+    int rc = launch_throttle(h, (const double *)d_vz, (const double *)d_throttle, (double *)d_k, s);
+    return rc ? rc : note_stream(h, s);
 }
 
 int ndp_throttle_update(ndp_handle *h, const double *vz, const double *throttle, double *k)
 {
     if (!h || !vz || !throttle || !k) return -1;
     const size_t B = h->cfg.batch;
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        NDP_HIP(h, hipSetDevice(h->cfg.device));
-        NDP_HIP(h, hipMemcpyAsync(h->sThr, vz, B * 8, hipMemcpyHostToDevice, h->stream));
-        NDP_HIP(h, hipMemcpyAsync(h->sThr + B, throttle, B * 8, hipMemcpyHostToDevice, h->stream));
-    }
-    int rc = ndp_throttle_update_device(h, h->sThr, h->sThr + B, h->sThr + 2 * B, nullptr);
-    if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipMemcpyAsync(h->sThr, vz, B * 8, hipMemcpyHostToDevice, h->stream));
+    NDP_HIP(h, hipMemcpyAsync(h->sThr + B, throttle, B * 8, hipMemcpyHostToDevice, h->stream));
+    int rc = launch_throttle(h, h->sThr, h->sThr + B, h->sThr + 2 * B, h->stream);
+    if (rc) return rc;
     NDP_HIP(h, hipMemcpyAsync(k, h->sThr + 2 * B, B * 8, hipMemcpyDeviceToHost, h->stream));
     NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int launch_actuator(ndp_handle *h, const double *d_u0, const double *d_k, double *d_cmd, hipStream_t s)
+{
+    hipLaunchKernelGGL(actuator_kernel, dim3((h->cfg.batch + 255) / 256), dim3(256), 0, s, d_u0, d_k, d_cmd, h->cfg.mass, h->cfg.batch);
+    NDP_HIP(h, hipGetLastError());
     return 0;
 }
 
@@ -1199,25 +1507,20 @@ int ndp_actuator_cmd_device(ndp_handle *h, const void *d_u0, const void *d_k, vo
     std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(actuator_kernel, dim3((h->cfg.batch + 255) / 256), dim3(256), 0, s, (const double *)d_u0,
-                       (const double *)d_k, (double *)d_cmd, h->cfg.mass, h->cfg.batch);
-    NDP_HIP(h, hipGetLastError());
-    return 0;
+    int rc = launch_actuator(h, (const double *)d_u0, (const double *)d_k, (double *)d_cmd, s);
+    return rc ? rc : note_stream(h, s);
 }
 
 int ndp_actuator_cmd(ndp_handle *h, const double *u0, const double *k, double *cmd)
 {
     if (!h || !u0 || !k || !cmd) return -1;
     const size_t B = h->cfg.batch;
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        NDP_HIP(h, hipSetDevice(h->cfg.device));
-        NDP_HIP(h, hipMemcpyAsync(h->sThr + 2 * B, k, B * 8, hipMemcpyHostToDevice, h->stream));
-        NDP_HIP(h, hipMemcpyAsync(h->sThr + 3 * B, u0, B * 32, hipMemcpyHostToDevice, h->stream));
-    }
-    int rc = ndp_actuator_cmd_device(h, h->sThr + 3 * B, h->sThr + 2 * B, h->sThr + 7 * B, nullptr);
-    if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipMemcpyAsync(h->sThr + 2 * B, k, B * 8, hipMemcpyHostToDevice, h->stream));
+    NDP_HIP(h, hipMemcpyAsync(h->sThr + 3 * B, u0, B * 32, hipMemcpyHostToDevice, h->stream));
+    int rc = launch_actuator(h, h->sThr + 3 * B, h->sThr + 2 * B, h->sThr + 7 * B, h->stream);
+    if (rc) return rc;
     NDP_HIP(h, hipMemcpyAsync(cmd, h->sThr + 7 * B, B * 32, hipMemcpyDeviceToHost, h->stream));
     NDP_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -1229,7 +1532,8 @@ int ndp_throttle_get_state(ndp_handle *h, double *state)
     std::lock_guard<std::mutex> lk(h->mu);
     const size_t B = h->cfg.batch;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    int rc = wait_all(h);
+    if (rc) return rc;
     std::vector<double> soa(B * 8);
     NDP_HIP(h, hipMemcpy(soa.data(), h->dThr, B * 64, hipMemcpyDeviceToHost));
     for (size_t v = 0; v < B; ++v)
@@ -1269,30 +1573,32 @@ int ndp_relay_formation(ndp_handle *h, const double *form, double *offset_out)
     return 0;
 }
 
+static int launch_relay_reference(ndp_handle *h, const double *d_xr_lead, double *d_xr_out, hipStream_t s)
+{
+    const int np1 = h->cfg.N + 1, rows = h->cfg.batch * np1;
+    hipLaunchKernelGGL(relay_reference_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, (const double *)h->dRelay, d_xr_lead, d_xr_out, rows, np1);
+    NDP_HIP(h, hipGetLastError());
+    return 0;
+}
+
 int ndp_relay_reference_device(ndp_handle *h, const void *d_xr_lead, void *d_xr_out, void *stream)
 {
     if (!h || !d_xr_lead || !d_xr_out) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    const int np1 = h->cfg.N + 1, rows = h->cfg.batch * np1;
-    hipLaunchKernelGGL(relay_reference_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, (const double *)h->dRelay,
-                       (const double *)d_xr_lead, (double *)d_xr_out, rows, np1);
-    NDP_HIP(h, hipGetLastError());
-    return 0;
+    int rc = launch_relay_reference(h, (const double *)d_xr_lead, (double *)d_xr_out, s);
+    return rc ? rc : note_stream(h, s);
 }
 
 int ndp_relay_reference(ndp_handle *h, const double *xr_lead, double *xr_out)
 {
     if (!h || !xr_lead || !xr_out) return -1;
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        NDP_HIP(h, hipSetDevice(h->cfg.device));
-        NDP_HIP(h, hipMemcpyAsync(h->sother, xr_lead, nxs(h) * 8, hipMemcpyHostToDevice, h->stream));
-    }
-    int rc = ndp_relay_reference_device(h, h->sother, h->sxr, nullptr);
-    if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipMemcpyAsync(h->sother, xr_lead, nxs(h) * 8, hipMemcpyHostToDevice, h->stream));
+    int rc = launch_relay_reference(h, h->sother, h->sxr, h->stream);
+    if (rc) return rc;
     NDP_HIP(h, hipMemcpyAsync(xr_out, h->sxr, nxs(h) * 8, hipMemcpyDeviceToHost, h->stream));
     NDP_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -1321,7 +1627,8 @@ int ndp_ref_set_trajectory(ndp_handle *h, int n_seg, const double *coeff_x, cons
     memcpy(host.data() + n_coeff + n_cum, time_seg, n_seg_t * 8);
     memcpy(host.data() + n_coeff + n_cum + n_seg_t, final_pt, B * 3 * 8);
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    int rc = wait_all(h);
+    if (rc) return rc;
     if (h->dTraj) { (void)hipFree(h->dTraj); h->dTraj = nullptr; }
     NDP_HIP(h, hipMalloc((void **)&h->dTraj, total * 8));
     NDP_HIP(h, hipMemcpy(h->dTraj, host.data(), total * 8, hipMemcpyHostToDevice));
@@ -1349,20 +1656,134 @@ int ndp_ref_window_device(ndp_handle *h, const void *d_t, void *d_xr, void *d_ur
     std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    return launch_ref_window(h, (const double *)d_t, 0.0, (double *)d_xr, (double *)d_ur, s);
+    int rc = launch_ref_window(h, (const double *)d_t, 0.0, (double *)d_xr, (double *)d_ur, s);
+    return rc ? rc : note_stream(h, s);
 }
 
 int ndp_ref_window(ndp_handle *h, const double *t, double *xr, double *ur)
 {
     if (!h || !t || !xr || !ur) return -1;
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        NDP_HIP(h, hipSetDevice(h->cfg.device));
-        NDP_HIP(h, hipMemcpyAsync(h->sThr, t, (size_t)h->cfg.batch * 8, hipMemcpyHostToDevice, h->stream));
-    }
-    int rc = ndp_ref_window_device(h, h->sThr, h->sxr, h->sur, nullptr);
-    if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipMemcpyAsync(h->sThr, t, (size_t)h->cfg.batch * 8, hipMemcpyHostToDevice, h->stream));
+    int rc = launch_ref_window(h, h->sThr, 0.0, h->sxr, h->sur, h->stream);
+    if (rc) return rc;
+    NDP_HIP(h, hipMemcpyAsync(xr, h->sxr, nxs(h) * 8, hipMemcpyDeviceToHost, h->stream));
+    NDP_HIP(h, hipMemcpyAsync(ur, h->sur, nus(h) * 8, hipMemcpyDeviceToHost, h->stream));
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- f1, the reference's sliding list (ref_list_* kernels)
+static int list_ring(const ndp_handle *h) { return h->cfg.N * h->list_step + 1; }
+
+static int list_alloc(ndp_handle *h)
+{
+    if (h->dRefList) return 0;
+    NDP_HIP(h, hipMalloc((void **)&h->dRefList, (size_t)h->cfg.batch * list_ring(h) * 14 * 8));
+    return 0;
+}
+
+static RefCfg ref_cfg(const ndp_handle *h, double toff)
+{
+    return RefCfg{h->cfg.batch, h->cfg.N, h->traj_seg, h->cfg.dt, h->cfg.mass, h->cfg.gravity, toff};
+}
+
+static int launch_list_fill(ndp_handle *h, const double *d_t, double toff, int npts, int slot0, int dup0, hipStream_t s)
+{
+    if (!h->dTraj) { h->err = "ndp_ref_list: ndp_ref_set_trajectory was never called"; return -11; }
+    const size_t B = h->cfg.batch, S = (size_t)h->traj_seg;
+    const double *coeff = h->dTraj, *cum = coeff + B * S * 28, *seg = cum + B * (S + 1), *fpt = seg + B * S;
+    const int n = h->cfg.batch * npts;
+    hipLaunchKernelGGL(ref_list_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ref_cfg(h, toff), coeff, cum, seg, fpt, d_t,
+                       h->cfg.ts_nmpc, npts, slot0, list_ring(h), dup0, h->dRefList);
+    NDP_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int ndp_ref_list_reset(ndp_handle *h)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = list_alloc(h);
+    if (rc) return rc;
+    h->list_head = 0;
+    // points at i * ts_nmpc, i = 0 .. ring-2, in slots 1 .. ring-1, the first one duplicated into slot 0 (:62-76)
+    rc = launch_list_fill(h, nullptr, 0.0, list_ring(h) - 1, 1, 1, h->stream);
+    if (rc) return rc;
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ndp_ref_list_fix_pt(ndp_handle *h, const double *x_odom, int quirk_b1)
+{
+    if (!h || !x_odom) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = list_alloc(h);
+    if (rc) return rc;
+    h->list_head = 0;
+    NDP_HIP(h, hipMemcpyAsync(h->sThr, x_odom, (size_t)h->cfg.batch * 80, hipMemcpyHostToDevice, h->stream));
+    const int n = h->cfg.batch * list_ring(h);
+    hipLaunchKernelGGL(ref_list_fix_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const double *)h->sThr,
+                       quirk_b1 ? h->cfg.mass * h->cfg.gravity : h->cfg.gravity, h->cfg.batch, list_ring(h), h->dRefList);
+    NDP_HIP(h, hipGetLastError());
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// pop the oldest entry, append the point at trajectory time t + T_horizon (get_nmpc_pts, :79-93)
+static int list_advance(ndp_handle *h, const double *d_t, hipStream_t s)
+{
+    if (!h->dRefList) { h->err = "ndp_ref_list_advance: no list (ndp_ref_list_reset / ndp_ref_list_fix_pt first)"; return -11; }
+    const int ring = list_ring(h), tail = h->list_head;          // the popped slot becomes the new last entry
+    h->list_head = (h->list_head + 1) % ring;
+    return launch_list_fill(h, d_t, h->cfg.N * h->cfg.dt, 1, tail, 0, s);
+}
+
+int ndp_ref_list_advance_device(ndp_handle *h, const void *d_t, void *stream)
+{
+    if (!h || !d_t) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = list_advance(h, (const double *)d_t, s);
+    return rc ? rc : note_stream(h, s);
+}
+
+static int launch_list_window(ndp_handle *h, double *d_xr, double *d_ur, hipStream_t s)
+{
+    if (!h->dRefList) { h->err = "ndp_ref_list_window: no list (ndp_ref_list_reset / ndp_ref_list_fix_pt first)"; return -11; }
+    const int n = h->cfg.batch * (h->cfg.N + 1);
+    hipLaunchKernelGGL(ref_list_window_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double *)h->dRefList, h->list_head,
+                       list_ring(h), h->list_step, h->cfg.batch, h->cfg.N, d_xr, d_ur);
+    NDP_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int ndp_ref_list_window_device(ndp_handle *h, void *d_xr, void *d_ur, void *stream)
+{
+    if (!h || !d_xr || !d_ur) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = launch_list_window(h, (double *)d_xr, (double *)d_ur, s);
+    return rc ? rc : note_stream(h, s);
+}
+
+// t == NULL: only read the current window (get_nmpc_ref_from_long_list); else advance first (get_nmpc_pts)
+int ndp_ref_list_window(ndp_handle *h, const double *t, double *xr, double *ur)
+{
+    if (!h || !xr || !ur) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = 0;
+    if (t) {
+        NDP_HIP(h, hipMemcpyAsync(h->sThr, t, (size_t)h->cfg.batch * 8, hipMemcpyHostToDevice, h->stream));
+        if ((rc = list_advance(h, h->sThr, h->stream))) return rc;
+    }
+    if ((rc = launch_list_window(h, h->sxr, h->sur, h->stream))) return rc;
     NDP_HIP(h, hipMemcpyAsync(xr, h->sxr, nxs(h) * 8, hipMemcpyDeviceToHost, h->stream));
     NDP_HIP(h, hipMemcpyAsync(ur, h->sur, nus(h) * 8, hipMemcpyDeviceToHost, h->stream));
     NDP_HIP(h, hipStreamSynchronize(h->stream));
@@ -1370,32 +1791,35 @@ int ndp_ref_window(ndp_handle *h, const double *t, double *xr, double *ur)
 }
 
 // ---- f4: plant step
+static int launch_plant(ndp_handle *h, double *d_x, const double *d_u, const double *d_f, double dt, int substeps, hipStream_t s)
+{
+    hipLaunchKernelGGL(plant_kernel, dim3((h->cfg.batch + 255) / 256), dim3(256), 0, s, d_x, d_u, d_f, dt / substeps, substeps,
+                       1.0 / h->cfg.mass, h->cfg.gravity, h->cfg.batch);
+    NDP_HIP(h, hipGetLastError());
+    return 0;
+}
+
 int ndp_plant_step_device(ndp_handle *h, void *d_x, const void *d_u, const void *d_f, double dt, int substeps, void *stream)
 {
     if (!h || !d_x || !d_u || substeps < 1) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(plant_kernel, dim3((h->cfg.batch + 255) / 256), dim3(256), 0, s, (double *)d_x, (const double *)d_u,
-                       (const double *)d_f, dt / substeps, substeps, 1.0 / h->cfg.mass, h->cfg.gravity, h->cfg.batch);
-    NDP_HIP(h, hipGetLastError());
-    return 0;
+    int rc = launch_plant(h, (double *)d_x, (const double *)d_u, (const double *)d_f, dt, substeps, s);
+    return rc ? rc : note_stream(h, s);
 }
 
 int ndp_plant_step(ndp_handle *h, double *x, const double *u, const double *f, double dt, int substeps)
 {
-    if (!h || !x || !u) return -1;
+    if (!h || !x || !u || substeps < 1) return -1;
     const size_t B = h->cfg.batch;
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        NDP_HIP(h, hipSetDevice(h->cfg.device));
-        NDP_HIP(h, hipMemcpyAsync(h->sx0, x, B * 80, hipMemcpyHostToDevice, h->stream));
-        NDP_HIP(h, hipMemcpyAsync(h->su0, u, B * 32, hipMemcpyHostToDevice, h->stream));
-        if (f) NDP_HIP(h, hipMemcpyAsync(h->sThr, f, B * 24, hipMemcpyHostToDevice, h->stream));
-    }
-    int rc = ndp_plant_step_device(h, h->sx0, h->su0, f ? h->sThr : nullptr, dt, substeps, nullptr);
-    if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipMemcpyAsync(h->sx0, x, B * 80, hipMemcpyHostToDevice, h->stream));
+    NDP_HIP(h, hipMemcpyAsync(h->su0, u, B * 32, hipMemcpyHostToDevice, h->stream));
+    if (f) NDP_HIP(h, hipMemcpyAsync(h->sThr, f, B * 24, hipMemcpyHostToDevice, h->stream));
+    int rc = launch_plant(h, h->sx0, h->su0, f ? h->sThr : nullptr, dt, substeps, h->stream);
+    if (rc) return rc;
     NDP_HIP(h, hipMemcpyAsync(x, h->sx0, B * 80, hipMemcpyDeviceToHost, h->stream));
     NDP_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -1418,12 +1842,10 @@ int ndp_rollout_device(ndp_handle *h, int ticks, double t0, double dt_tick, int 
     for (int k = 0; k < ticks; ++k) {
         if (k > 0 && (rc = launch_ref_window(h, nullptr, t0 + k * dt_tick, h->sxr, h->sur, s))) return rc;
         if ((rc = launch_rti(h, x, h->sxr, h->sur, nullptr, h->su0, nullptr, s))) return rc;
-        hipLaunchKernelGGL(plant_kernel, dim3((h->cfg.batch + 255) / 256), dim3(256), 0, s, x, (const double *)h->su0,
-                           (const double *)nullptr, dt_tick / substeps, substeps, 1.0 / h->cfg.mass, h->cfg.gravity, h->cfg.batch);
-        NDP_HIP(h, hipGetLastError());
+        if ((rc = launch_plant(h, x, h->su0, nullptr, dt_tick, substeps, s))) return rc;
         if (log) NDP_HIP(h, hipMemcpyAsync(log + (size_t)k * B * NX, x, B * NX * 8, hipMemcpyDeviceToDevice, s));
     }
-    return 0;
+    return note_stream(h, s);
 }
 
 // test/profiling hook: every instance writes its phase stamps (shader clock) to [B][16] doubles
@@ -1449,14 +1871,14 @@ int ndp_debug_stamps(ndp_handle *h, int enable, double *out)
 void *ndp_device_iterate_x(ndp_handle *h) { return h ? h->dX : nullptr; }
 void *ndp_device_iterate_u(ndp_handle *h) { return h ? h->dU : nullptr; }
 void *ndp_device_force(ndp_handle *h) { return h ? h->dForce : nullptr; }
+int ndp_work_queue_enabled(ndp_handle *h) { return h ? (int)h->use_queue : -1; }
 
 int ndp_synchronize(ndp_handle *h)
 {
     if (!h) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    NDP_HIP(h, hipStreamSynchronize(h->stream));
-    return 0;
+    return wait_all(h);
 }
 
 int ndp_timing_enable(ndp_handle *h, int on)

@@ -62,7 +62,7 @@ struct RtiParams {
     int N, n_rti, use_fd, qp_mode, iter_max;
     double dt, inv_mass, g;
     double Qd[10], Rd[4], lbu[4], ubu[4], lbv[3], ubv[3];
-    double mu0, thr0, tol, tau, auto_margin;
+    double mu0, thr0, tol, tau, auto_margin, mu_floor;
     // host-evaluated quotients (an f64 divide is a ~30-instruction VALU sequence on the device, even for uniforms)
     double h_6, h2_6, h4_24, h3_6, h4_12, two_over_h2, inv2m;
 };
@@ -88,6 +88,7 @@ struct RtiIo {            // global-memory views of ONE instance
     const double *kc;     // [KC_SC] lane-indexable constants block prepared by the host (fill_kc)
     double *stamps = nullptr;   // optional [16] per-instance phase stamps (whole-batch profiling), or null
     const int *tables = nullptr;   // [TB_WORDS] host-built index tables (fill_tables), read when RtiWave<..., HT = true>
+    int f_coherent = 0;            // 1: f was written by ANOTHER workgroup of this launch (work queue): read it past the non-coherent caches
 };
 
 struct LdsMap {
@@ -332,7 +333,7 @@ struct RtiWave {
         }
         for (int t = 0; t < RF; ++t) {
             vi i = W::imin(lane + 64 * t, nf - 1);
-            b.f[t] = have_f ? W::gldfu(io.f, i) : vd(0.0);
+            b.f[t] = have_f ? (io.f_coherent ? W::gldfu_coherent(io.f, i) : W::gldfu(io.f, i)) : vd(0.0);
         }
         b.kc = first ? W::gldu(io.kc, W::imin(lane, KC_SC - 1)) : vd(0.0);
     }
@@ -893,7 +894,10 @@ struct RtiWave {
 
     // Mehrotra predictor-corrector in absolute form; every Newton system is one riccati_sweep with
     // diag += Gamma, grad += gamma on the bounded variables (same algorithm as oracle orc_qp_solve).
-    static NDP_D int ipm(const RtiParams &P, const LdsMap &m, const Tables &T, Slots &S, lp lds, int &iters_out)
+    // `failed` is set when no usable step exists (factorisation failure or NaN): the caller then keeps the iterate, as
+    // acados' SQP_RTI returns ACADOS_QP_FAILURE before updating the variables; an exhausted iteration budget (status 4
+    // as well) still hands over the last interior-point iterate.
+    static NDP_D int ipm(const RtiParams &P, const LdsMap &m, const Tables &T, Slots &S, lp lds, int &iters_out, bool &failed)
     {
         const int N = horizon(P);
         const int nzx = (N + 1) * NX, nzu = N * NU;
@@ -948,6 +952,7 @@ struct RtiWave {
                 }
                 W::sync();
                 ok = riccati_sweep(P, m, T, lds) && ok;
+                if (!ok) break;
                 vd amin = 1.0;
                 for (int s = 0; s < NSLOT; ++s) {
                     vb v = S.valid[s];
@@ -976,7 +981,9 @@ struct RtiWave {
                                   + (S.lu[s] + S.dlu[s] * alpha) * (S.tu[s] + S.dtu[s] * alpha);
                     const double mu_aff = W::wave_sum(acc) * inv2m;
                     const double r = mu_aff / mu;
-                    sigma_mu = r * r * r * mu;
+                    // Mehrotra's centring target, kept from undershooting the tolerance (slacks are formed by subtraction:
+                    // their relative accuracy, and the Newton systems', is eps / t) -- same rule as the oracle
+                    sigma_mu = fmax_u(r * r * r * mu, P.mu_floor * P.tol);
                 } else {
                     if (alpha < 1.0) alpha *= P.tau;
                     for (int t = 0; t < nzx + nzu; t += 64) {   // (ZX,ZU) and (CX,CU) are laid out alike
@@ -995,9 +1002,9 @@ struct RtiWave {
                     rho *= (1.0 - alpha);
                 }
             }
-            if (!(mu == mu)) { status = 1; break; }
+            if (!ok) { status = 4; failed = true; break; }
+            if (!(mu == mu)) { status = 1; failed = true; break; }
         }
-        if (!ok && status == 0) status = 4;
         iters_out += iters;
         return status;
     }
@@ -1040,10 +1047,14 @@ struct RtiWave {
         InBuf inb;
         vd x0v;
         issue_first(P, io, inb, x0v);
-        run(P, io, lds, inb, x0v);
+        run<false>(P, io, lds, inb, x0v);
     }
 
-    static NDP_D void run(const RtiParams &P, const RtiIo &io, lp lds, InBuf &inb, vd x0v)
+    // DEFER (work-queue launches): when the first QP that needs the interior-point loop shows up, return true at once --
+    // nothing of this instance has been written to global memory then, and whichever wave pops the instance from the
+    // queue redoes the step from the same inputs with DEFER = false.  The interior-point code is not instantiated at all.
+    template <bool DEFER>
+    static NDP_D bool run(const RtiParams &P, const RtiIo &io, lp lds, InBuf &inb, vd x0v)
     {
         const int N = horizon(P);
         const LdsMap m = make_map(N);
@@ -1082,32 +1093,34 @@ struct RtiWave {
                     W::gst(io.dbg, i, W::ldp(lds, i, i < m.total), i < m.total);
                 }
             }
-            bool done = false;
+            bool done = false, failed = false;
             int st = 0;
-            if (P.qp_mode == QP_AUTO) {
+            if (DEFER || P.qp_mode == QP_AUTO) {
                 // equality-constrained minimiser strictly inside the box => it IS the QP solution (all multipliers 0)
                 stamp(io, m, 5);
                 bool ok = riccati_sweep(P, m, T, lds, &io);
                 stamp(io, m, 7);
-                if (!ok) st = 4;
+                if (!ok) { st = 4; failed = true; }
                 // the constraint slots are built only now: keeping ~90 more registers live across the sweep
                 // forces the MFMA accumulators into AGPRs with copies on every dependency
                 Slots S;
                 build_slots(P, m, S);
                 load_bounds(m, S, lds);
-                done = strictly_inside(S, lds, P.auto_margin) || !ok;   // then the step is the sweep's solution, read where it lies (ZX|ZU)
+                done = (P.qp_mode == QP_AUTO && strictly_inside(S, lds, P.auto_margin)) || !ok;   // then the step is the sweep's solution, read where it lies (ZX|ZU)
             }
             const int zsrc = done ? m.ZX : m.CX;       // ZX|ZU and CX|CU are laid out alike
             if (!done) {
+                if (DEFER) return true;
                 Slots S;
                 build_slots(P, m, S);
                 load_bounds(m, S, lds);
-                st = ipm(P, m, T, S, lds, iters);
+                st = ipm(P, m, T, S, lds, iters, failed);
             }
             if (st && !status) status = st;
             // full step, no line search; XI|UI and CX|CU are laid out alike.
             // All LDS reads of the step are issued before the first add (one wait, not one per 64 elements); after the
             // last RTI iteration the new iterate goes straight to global memory as well.
+            // No usable step (factorisation failure, NaN): the iterate stays as it is and u_0 is read from it.
             {
                 constexpr int RZ = RX + RU;     // rounds that cover X|U contiguously: nzx + nzu <= 64 * RZ
                 const bool last = it + 1 == n_rti;
@@ -1117,10 +1130,16 @@ struct RtiWave {
                     xa[t] = W::ld(lds, i + m.XI);
                     xc[t] = W::ld(lds, i + zsrc);
                 }
+                vb bad = lane < 0;
+                for (int t = 0; t < RZ; ++t) bad = bad || !(xc[t] == xc[t]);
+                if (!failed && W::any(bad)) {
+                    failed = true;
+                    if (!status) status = 1;
+                }
                 for (int t = 0; t < RZ; ++t) {
                     // lanes past the end repeat the last element: identical duplicate stores, no predicates
                     vi i = W::imin(lane + 64 * t, nzx + nzu - 1);
-                    vd xn = xa[t] + xc[t];
+                    vd xn = failed ? xa[t] : xa[t] + xc[t];
                     W::st(lds, i + m.XI, xn);
                     if (last) {
                         // X and U are separate global arrays: element i < nzx goes to X[i], else to U[i - nzx]
@@ -1143,6 +1162,7 @@ struct RtiWave {
         stamp(io, m, 8);
         W::gsti(io.status, status);
         W::gsti(io.iters, iters);
+        return false;
     }
 };
 

@@ -79,3 +79,85 @@ def make_formation_shard(B_local, rank, world, N=20, seed=synth.SEED0 + 4, t0=0.
     out["ego_xy"] = np.ascontiguousarray(out["x0"][:, 0:2])
     out["offset"] = mine
     return out
+
+
+# ------------------------------------------------------------------------------------------- BASELINE config 4
+# 4096 three-vehicle formations (12 288 instances) over the GPUs of one node.  Reference semantics: vehicle 0
+# of a formation runs the NDP controller and reads vehicle 1's published reference (ndp_nmpc_leader_node.py:40,60-76);
+# vehicles 1 and 2 are plain NMPC followers tracking the leader's window shifted by (0, +-1, 0)
+# (nmpc_leader_node.py:42-43, nmpc_follower_node.py:44-77; three_qd_ndp_nmpc.launch:4-12).
+# Global instance g = 3 * formation + vehicle.  Placements:
+#   "vehicle"   (vehicle-major round-robin): rank = g % W, local index g // W -- a leader's neighbour g + 1 lives on the
+#               next rank: one all-gather of the [B_local, N+1, 6] position/velocity columns per control step (all that
+#               the gate and the MLP read, downwash_nn.py:22; fp64 so that (other - ego) is the reference's subtraction);
+#   "formation" (formation-major): rank = g // B_local -- a formation stays on one GPU, no exchange; the kernel reads the
+#               neighbour's window straight out of the local xr through other_index.
+PV_COLS = 6
+
+
+def config4_gids(rank, world, n_form, placement):
+    """Global ids of this rank's instances in local order, and B_local."""
+    total = 3 * n_form
+    if total % world or (placement == "formation" and (total // world) % 3):
+        raise ValueError(f"{total} instances do not split over {world} ranks")
+    bl = total // world
+    g = np.arange(bl) * world + rank if placement == "vehicle" else rank * bl + np.arange(bl)
+    return g.astype(np.int64), bl
+
+
+def config4_other_index(rank, world, n_form, placement):
+    """int32[B_local]: row of the neighbour buffer holding each local instance's neighbour (-1 = none).  The buffer is the
+    all-gathered [W * B_local, N+1, 6] array (vehicle-major) or the local xr [B_local, N+1, 10] (formation-major)."""
+    g, bl = config4_gids(rank, world, n_form, placement)
+    nb = np.where(g % 3 == 0, g + 1, -1)                   # leaders read vehicle 1 of their formation; followers nobody
+    if placement == "vehicle":
+        row = (nb % world) * bl + nb // world
+    else:
+        row = nb - rank * bl
+    return np.where(nb >= 0, row, -1).astype(np.int32)
+
+
+def make_config4_all(n_form, N=20, seed=synth.SEED0 + 4, t0=0.0):
+    """The whole synthetic formation set, global order [3 * n_form]: x0, xr, ur, ego_xy (every rank can build it: the
+    seed does not depend on the rank).  Leaders fly 0.4 m above follower 1's track, displaced sideways by 0..2.5 m, so that
+    about 40 % of them sit inside the r_horiz gate."""
+    base = synth.make_batch(n_form, N=N, seed=seed, downwash=False, t0=t0)
+    rng = np.random.Generator(np.random.PCG64([seed, 77]))
+    xr = np.repeat(base["xr"], 3, axis=0)                  # [3F, N+1, 10], formation-major global order
+    side = rng.uniform(0.0, 2.5, n_form)
+    xr[0::3, :, 1] += 1.0 + side[:, None]
+    xr[0::3, :, 2] += 0.4
+    xr[1::3, :, 1] += 1.0
+    xr[2::3, :, 1] -= 1.0
+    ur = np.repeat(base["ur"], 3, axis=0)
+    x0 = xr[:, 0].copy()
+    x0[:, 0:3] += rng.normal(0.0, 0.05, (3 * n_form, 3))
+    return dict(x0=x0, xr=xr, ur=ur, ego_xy=np.ascontiguousarray(x0[:, 0:2]))
+
+
+def make_config4_shard(rank, world, n_form, placement, N=20, seed=synth.SEED0 + 4, t0=0.0):
+    """This rank's instances of make_config4_all plus `other_index` and `gids`."""
+    allv = make_config4_all(n_form, N=N, seed=seed, t0=t0)
+    g, _ = config4_gids(rank, world, n_form, placement)
+    out = {k: np.ascontiguousarray(v[g]) for k, v in allv.items()}
+    out["other_index"] = config4_other_index(rank, world, n_form, placement)
+    out["gids"] = g
+    return out
+
+
+def exchange_pv_begin(xr_local, pv_local, gathered, group=None):
+    """Vehicle-major exchange, started without waiting: packs the position/velocity columns of this rank's windows
+    (pv_local[B_local, N+1, 6]) and all-gathers them into gathered[W * B_local, N+1, 6].  Returns the work handle (None for
+    a single rank, where the pack IS the gathered buffer)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        gathered.view(pv_local.shape).copy_(xr_local[:, :, :PV_COLS])
+        return None
+    pv_local.copy_(xr_local[:, :, :PV_COLS])
+    return dist.all_gather_into_tensor(gathered.view(-1), pv_local.view(-1), group=group, async_op=True)
+
+
+def exchange_pv_end(work):
+    if work is not None:
+        work.wait()

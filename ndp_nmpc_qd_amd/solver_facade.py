@@ -65,9 +65,9 @@ class SolverFacade:
             if not np.array_equal(self._p[:, 0:4], xr[:, 6:10]):
                 raise Exception("this drop-in requires p[0:4] == yref[6:10] (as nmpc_body_rate_ctl.py:99-104 sets it)")
             f = self._p[:, 4:7].astype(np.float32)[None] if self._np == 7 else None
-            u0 = self._eng.update(np.asarray(x0, dtype=np.float64)[None], xr[None], ur[None], f=f,
-                                  raise_on_status=False)[0]
-            self.status = int(self._eng.status()[0][0])
-            X, U = self._eng.get_iterate()
+            # one C-ABI call: inputs in, u0 + new iterate + status out (ndp_step_ex); nothing else touches the device per tick
+            u0, X, U, st, _ = self._eng.update(np.asarray(x0, dtype=np.float64)[None], xr[None], ur[None], f=f,
+                                               raise_on_status=False, full=True)
+            self.status = int(st[0])
             self._X, self._U = X[0], U[0]
-            return u0
+            return u0[0]

@@ -42,9 +42,12 @@ void orc_default_cfg(orc_cfg *c)
     c->use_fd = 0;
     c->mu0 = 10.0;
     c->thr0 = 0.1;
-    c->tol = 1e-8;
+    c->tol = 1e-8;     /* HPIPM's default [acados-knowledge] */
+    c->mu_floor = 0.1; /* centring target >= mu_floor * tol */
     c->tau = 0.995;
     c->iter_max = 50;
+    c->qp_mode = 1;
+    c->auto_margin = 0.1;
 }
 
 /* ---------------------------------------------------------------- dynamics */
@@ -395,7 +398,8 @@ static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B
     ipm_con *cn = w->cn;
     double *Qe = w->Qe, *qe = w->qe, *Re = w->Re, *re = w->re, *zx = w->zx, *zu = w->zu, *nx_ = w->nx_, *nu_ = w->nu_;
     ric_gain *G = &w->G;
-    int status = 0, iters = 0, n = 0;
+    int status = 0, iters = 0, n = 0, failed = 0;
+    double norm0 = 1.0, mu = 0.0, rho = 1.0;
     memset(cn, 0, sizeof(ipm_con) * (size_t)m);
     memset(zx, 0, sizeof(double) * (size_t)(N + 1) * NX);
     memset(zu, 0, sizeof(double) * (size_t)N * NU);
@@ -411,8 +415,22 @@ static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B
             cn[n].lo = lv[k * 3 + i]; cn[n].hi = uv[k * 3 + i];
         }
 
+    /* qp_mode 0 (the device's QP_AUTO): the equality-constrained minimiser, if it lies auto_margin inside every bound,
+     * IS the QP solution (all multipliers zero) -- no interior-point iterations.  qp_mode 1 (default): HPIPM-like, always iterate. */
+    if (c->qp_mode == 0) {
+        if (riccati_solve(N, A, B, b, Q, q, Rd, r, dx0, nx_, nu_, G)) { status = 4; failed = 1; goto done; }
+        int inside = 1;
+        for (int i = 0; i < m && inside; ++i) {
+            const double zn = con_value(&cn[i], nx_, nu_);
+            inside = zn > cn[i].lo + c->auto_margin && zn < cn[i].hi - c->auto_margin;
+        }
+        if (inside) {
+            memcpy(zx, nx_, sizeof(double) * (size_t)(N + 1) * NX);
+            memcpy(zu, nu_, sizeof(double) * (size_t)N * NU);
+            goto done;
+        }
+    }
     /* cold start (qp_solver_warm_start left at 0, nmpc_body_rate_ctl.py:73-74) */
-    double norm0 = 1.0, mu = 0.0;
     for (int i = 0; i < m; ++i) {
         cn[i].tl = fmax(-cn[i].lo, c->thr0);
         cn[i].tu = fmax(cn[i].hi, c->thr0);
@@ -427,7 +445,6 @@ static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B
     for (int i = 0; i < N * NU; ++i) norm0 = fmax(norm0, fabs(r[i]));
     for (int i = 0; i < N * NX; ++i) norm0 = fmax(norm0, fabs(b[i]));
     for (int i = 0; i < NX; ++i) norm0 = fmax(norm0, fabs(dx0[i]));
-    double rho = 1.0;
 
     for (;;) {
         if (mu <= c->tol && rho * norm0 <= c->tol) break;
@@ -456,7 +473,7 @@ static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B
                     qe[cc->stage * NX + j] += gam;
                 }
             }
-            if (riccati_solve(N, A, B, b, Qe, qe, Re, re, dx0, nx_, nu_, G)) { status = 4; goto done; }
+            if (riccati_solve(N, A, B, b, Qe, qe, Re, re, dx0, nx_, nu_, G)) { status = 4; failed = 1; goto done; }
             /* slack / multiplier steps and the largest feasible step length */
             double alpha = 1.0;
             for (int i = 0; i < m; ++i) {
@@ -482,7 +499,11 @@ static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B
                 }
                 mu_aff /= (2.0 * m);
                 const double s = mu_aff / mu;
-                sigma_mu = s * s * s * mu;
+                /* Mehrotra's centring target, kept from undershooting the tolerance: slacks are formed by subtraction
+                 * (t = z - lb), so their relative accuracy -- and with it the Newton systems' -- is eps / t; a target
+                 * of 1e-12 would cost six digits of the answer for nothing.  HPIPM guards the same way with lower
+                 * thresholds on t and lambda [acados-knowledge]. */
+                sigma_mu = fmax(s * s * s * mu, c->mu_floor * c->tol);
             } else {
                 if (alpha < 1.0) alpha *= c->tau;
                 for (int i = 0; i < (N + 1) * NX; ++i) zx[i] += alpha * (nx_[i] - zx[i]);
@@ -498,9 +519,16 @@ static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B
                 rho *= (1.0 - alpha);
             }
         }
-        if (!(mu == mu)) { status = 1; break; }
+        if (!(mu == mu)) { status = 1; failed = 1; break; }
     }
 done:
+    /* No usable step (factorisation failure, NaN): hand back a zero step, i.e. the caller's iterate stays as it is --
+     * acados' SQP_RTI returns ACADOS_QP_FAILURE before it updates the variables [acados-knowledge].  An exhausted
+     * iteration budget (status 4 as well) still hands over the last interior-point iterate. */
+    if (failed) {
+        memset(zx, 0, sizeof(double) * (size_t)(N + 1) * NX);
+        memset(zu, 0, sizeof(double) * (size_t)N * NU);
+    }
     memcpy(dx, zx, sizeof(double) * (size_t)(N + 1) * NX);
     memcpy(du, zu, sizeof(double) * (size_t)N * NU);
     if (st) {

@@ -41,6 +41,9 @@ typedef struct {
     /* interior point (HPIPM-like Mehrotra predictor-corrector) */
     double mu0, thr0, tol, tau;
     int iter_max;
+    int qp_mode;        /* 1 (default) = interior point always, what HPIPM does; 0 = the device's QP_AUTO early exit */
+    double auto_margin; /* qp_mode 0: accept the equality-constrained minimiser only this far inside every bound */
+    double mu_floor;    /* the centring target sigma*mu never goes below mu_floor * tol (default 0.1), see orc_qp_solve */
 } orc_cfg;
 
 typedef struct {

@@ -23,7 +23,7 @@ class OrcCfg(C.Structure):
         ("lbu", C.c_double * 4), ("ubu", C.c_double * 4), ("lbv", C.c_double * 3), ("ubv", C.c_double * 3),
         ("use_fd", C.c_int),
         ("mu0", C.c_double), ("thr0", C.c_double), ("tol", C.c_double), ("tau", C.c_double),
-        ("iter_max", C.c_int),
+        ("iter_max", C.c_int), ("qp_mode", C.c_int), ("auto_margin", C.c_double), ("mu_floor", C.c_double),
     ]
 
 
@@ -41,10 +41,13 @@ _lib = None
 
 
 def lib():
+    """Loads the prebuilt oracle.  It never builds implicitly: a build spawns make -> sh -> cc, and a process that has
+    initialised the GPU (bench.py under rocprofv3 in particular) must not start such a chain on the GPU pool.  Build with
+    `make -C oracle`, oracle.build() (tests/conftest.py does) or __graft_entry__.build()."""
     global _lib
     if _lib is None:
         if not os.path.exists(_SO):
-            build()
+            raise RuntimeError("oracle/libndp_oracle.so is missing: run `make -C oracle` (or __graft_entry__.build()) first")
         _lib = C.CDLL(_SO)
         _lib.orc_num_threads.restype = C.c_int
     return _lib

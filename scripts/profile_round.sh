@@ -2,12 +2,17 @@
 # Round profile of the headline workload (run on the GPU box through gpurun, from the repo root):
 #   kernel trace + stats, then three separate PMC passes (never combined with tracing domains).
 # Outputs under gpurun_out/prof_<tag>/; scripts/summarise_profile.py turns them into the files kept in profiles/.
+# Every native piece is built BEFORE the first rocprofv3 line and the profiled command is `bench.py --only-timed` (no
+# oracle, no child processes): under rocprofv3 the preloaded profiler library initialises the GPU in every process, and a
+# GPU-initialised process must not start a make -> sh -> cc chain on this pool.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+EXTRA=${2:-}
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --no-cpu-baseline --steps 200 --warmup 20"
+[ -f "$PWD/ndp_nmpc_qd_amd/libndp_nmpc_hip.so" ] || python3 -c 'import __graft_entry__ as g; g.build()' > "$OUT/build.log" 2>&1
+BENCH="python3 $PWD/bench.py --only-timed --steps 200 --warmup 20 $EXTRA"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/pmc_fetch.log" 2>&1

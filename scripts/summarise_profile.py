@@ -25,7 +25,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
             per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
         for name, d in per.items():
             ids = sorted(d, key=lambda x: int(x))
-            vals = [d[i] for i in ids][30:] or [d[i] for i in ids]      # drop the parity launch + warm-up
+            vals = [d[i] for i in ids][20:] or [d[i] for i in ids]      # drop the warm-up launches
             pmc[name] = {"dispatches": len(vals), "mean": sum(vals) / len(vals), "min": min(vals), "max": max(vals)}
 json.dump(pmc, open(os.path.join(summ, f"{tag}_pmc_rti_kernel.json"), "w"), indent=1)
 print(json.dumps({k: v["mean"] for k, v in pmc.items()}))

@@ -9,16 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libndp_emu.so")
 
 
-class NdpCfg(C.Structure):
-    """Mirror of include/ndp_nmpc.h ndp_cfg."""
-    _fields_ = [
-        ("batch", C.c_int32), ("N", C.c_int32), ("n_rti", C.c_int32), ("use_fd", C.c_int32),
-        ("qp_mode", C.c_int32), ("iter_max", C.c_int32), ("device", C.c_int32), ("qp_precision", C.c_int32),
-        ("dt", C.c_double), ("mass", C.c_double), ("gravity", C.c_double), ("r_horiz", C.c_double),
-        ("Qd", C.c_double * 10), ("Rd", C.c_double * 4),
-        ("lbu", C.c_double * 4), ("ubu", C.c_double * 4), ("lbv", C.c_double * 3), ("ubv", C.c_double * 3),
-        ("mu0", C.c_double), ("thr0", C.c_double), ("tol", C.c_double), ("tau", C.c_double), ("auto_margin", C.c_double),
-    ]
+from ndp_nmpc_qd_amd._lib import NdpCfg  # noqa: E402  (the one mirror of include/ndp_nmpc.h's ndp_cfg)
 
 
 def build():

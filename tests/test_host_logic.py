@@ -43,8 +43,12 @@ def test_default_cfg_carries_the_reference_constants():
     assert list(cfg.lbu) == [CP.w_min] * 3 + [CP.c_min] and list(cfg.ubu) == [CP.w_max] * 3 + [CP.c_max]
     assert list(cfg.lbv) == [CP.v_min] * 3 and list(cfg.ubv) == [CP.v_max] * 3
     assert CP.c_max == 9.81 / 0.36
-    assert C.sizeof(_lib.NdpCfg) == 8 * 4 + 8 * (4 + 10 + 4 + 4 + 4 + 3 + 3 + 5)
-    assert cfg.auto_margin == 0.1 and cfg.qp_precision == 0
+    assert C.sizeof(_lib.NdpCfg) == 10 * 4 + 8 * (4 + 10 + 4 + 4 + 4 + 3 + 3 + 7)
+    assert cfg.auto_margin == 0.1 and cfg.qp_precision == 0 and cfg.work_queue == 0 and cfg.ts_nmpc == CP.ts_nmpc == 0.02
+    # interior-point constants are the same on both sides
+    from oracle import oracle as O
+    oc = O.default_cfg()
+    assert (cfg.tol, cfg.mu_floor, cfg.mu0, cfg.thr0, cfg.tau) == (oc.tol, oc.mu_floor, oc.mu0, oc.thr0, oc.tau) == (1e-8, 0.1, 10.0, 0.1, 0.995)
     # horizon indexing of the reference generator (nmpc_params.py:40-43): 21 states / 20 controls out of 101
     assert CP.long_list_size == 101 and list(range(101))[CP.xr_list_index] == list(range(0, 101, 5))
 
@@ -78,10 +82,11 @@ class _FakeEngine:
         self.calls.append(("set_iterate",))
         self.X, self.U = X.copy(), U.copy()
 
-    def update(self, x0, xr, ur, f=None, raise_on_status=True):
+    def update(self, x0, xr, ur, f=None, raise_on_status=True, full=False):
         self.calls.append(("update", x0.copy(), xr.copy(), ur.copy(), None if f is None else f.copy()))
         self.X = self.X + 1.0
-        return np.array([[1.0, 2.0, 3.0, 4.0]])
+        u0 = np.array([[1.0, 2.0, 3.0, 4.0]])
+        return (u0, self.X.copy(), self.U.copy(), np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32)) if full else u0
 
     def status(self):
         return np.array([0], dtype=np.int32), np.array([0], dtype=np.int32)
@@ -101,7 +106,7 @@ def test_solver_facade_marshals_like_acados_template():
     u0 = ctl.update(x0, xr, ur, f)
     assert np.array_equal(u0, [1.0, 2.0, 3.0, 4.0])
     kinds = [c[0] for c in ctl._engine.calls]
-    assert kinds == ["set_iterate", "update"]                      # reset is pushed lazily, right before the solve
+    assert kinds == ["set_iterate", "update"]                      # reset is pushed lazily, right before the solve; the solve is ONE engine call
     _, x0s, xrs, urs, fs = ctl._engine.calls[1]
     assert np.array_equal(x0s[0], x0) and np.array_equal(xrs[0], xr) and np.array_equal(urs[0], ur)
     assert fs.dtype == np.float32 and np.array_equal(fs[0], f)

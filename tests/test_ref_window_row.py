@@ -148,7 +148,7 @@ def test_gpu_reference_window_against_oracle_and_fixture(oracle, gold):
                               wpts[:, 0:3, -1].copy())
         pub.reset(tc)
         for s in range(0, tq.shape[1], 5):
-            xr, ur = pub.get_nmpc_pts(tq[:, s])
+            xr, ur = pub.get_nmpc_pts_direct(tq[:, s])
             xo, uo = oracle.ref_window(coeff, cum, tseg, tc.final_pt, tq[:, s])
             np.testing.assert_allclose(xr, xo, rtol=1e-10, atol=1e-10)
             np.testing.assert_allclose(ur, uo, rtol=1e-9, atol=1e-9)

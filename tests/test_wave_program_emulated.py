@@ -223,3 +223,47 @@ def test_auto_margin_switches_between_early_exit_and_interior_point(oracle):
     np.testing.assert_allclose(res[100.0][0], uo[0], rtol=1e-7, atol=1e-7)
     np.testing.assert_allclose(res[0.0][0], uo[0], rtol=1e-5, atol=1e-5)
     assert np.array_equal(res[0.0][0], res[0.1][0])
+
+
+def test_auto_mode_inside_1e_5_of_the_interior_point_oracle_at_default_settings(oracle):
+    """The emulated wave program in its default QP mode (exact early exit, interior point otherwise) against the
+    always-interior-point oracle on heavily perturbed instances, all defaults, two warm-started ticks: EVERY instance
+    inside the north-star's 1e-5 (the GPU suite repeats this at 768 instances x 3 ticks on the device)."""
+    n_ipm = 0
+    for seed, kw in ((2, dict(pos_sigma=0.5, vel_sigma=1.0, quat_sigma=0.15)), (4, dict(pos_sigma=1.0, vel_sigma=2.0, quat_sigma=0.3))):
+        B = 96
+        b = synth.make_batch(B, seed=seed, **kw)
+        cfgo = oracle.default_cfg()
+        X, U = b["xr"].copy(), b["ur"].copy()
+        Xe, Ue = b["xr"].copy(), b["ur"].copy()
+        for _ in range(2):
+            uo, sto, ito = oracle.step_batch(cfgo, b["x0"], b["xr"], b["ur"], None, X, U)
+            for i in range(B):
+                u0, st, it, *_ = E.rti_step(E.default_cfg(), b["x0"][i], b["xr"][i], b["ur"][i], None, Xe[i], Ue[i])
+                assert st == sto[i]
+                if st == 0:
+                    assert np.all(np.abs(u0 - uo[i]) <= 1e-5 * np.maximum(1.0, np.abs(uo[i]))), (seed, i)
+                    n_ipm += it > 0
+    assert n_ipm > 100
+
+
+def test_failed_factorisation_keeps_the_iterate(oracle):
+    """A QP whose factorisation fails (indefinite input weight) leaves no usable step: status 4, the iterate is NOT
+    updated and u0 is read from it -- acados' SQP_RTI returns ACADOS_QP_FAILURE before it updates the variables.  The
+    oracle hands back a zero step in that case; both agree."""
+    b = synth.make_batch(1, seed=9)
+    cfg = E.default_cfg()
+    cfg.Rd[3] = -50.0
+    X, U = b["xr"][0].copy(), b["ur"][0].copy()
+    u0, st, it, *_ = E.rti_step(cfg, b["x0"][0], b["xr"][0], b["ur"][0], None, X, U)
+    assert st == 4
+    np.testing.assert_array_equal(X, b["xr"][0])
+    np.testing.assert_array_equal(U, b["ur"][0])
+    np.testing.assert_array_equal(u0, b["ur"][0][0])
+    cfgo = oracle.default_cfg()
+    cfgo.Rd[3] = -50.0
+    Xo, Uo = b["xr"][0].copy(), b["ur"][0].copy()
+    uo, sto = oracle.step(cfgo, b["x0"][0], b["xr"][0], b["ur"][0], None, Xo, Uo)
+    assert sto.status == 4
+    np.testing.assert_array_equal(Xo, b["xr"][0])
+    np.testing.assert_array_equal(uo, b["ur"][0][0])
