@@ -59,8 +59,8 @@ struct MlpArgs {            // fused downwash (null frag = not fused)
 // Work queue of instances whose QP needs the interior-point loop (QUEUE launches).  An interior-point solve costs ~18
 // Riccati sweeps against 1 for the early exit, so with several instances per SIMD one such instance per workgroup leaves
 // the other three SIMDs of its CU idle for most of the launch.  Instead every wave first runs the cheap part of its own
-// instance; instances that need the loop are pushed here, and every wave that is done pops and solves them -- its own
-// push included, so whatever was pushed is solved by the end of the launch.  Counters are monotonic across launches
+// instance; instances that need the loop are pushed here, and every wave that is done pops one and solves it (a pusher
+// pops after publishing its own, so whatever was pushed is solved by the end of the launch).  Counters are monotonic across launches
 // (nothing to reset, hipGraph-replayable): ctr[0] slots reserved, ctr[1] slots published (ids stored), ctr[2] slots taken.
 struct QueueArgs {
     unsigned *ctr;
@@ -123,24 +123,62 @@ __device__ __forceinline__ void bind_instance(RtiIo &io, const BatchPtrs &bp, in
     io.stamps = bp.stamps ? bp.stamps + (size_t)inst * 16 : nullptr;
 }
 
+// All launch parameters of rti_kernel as ONE by-value kernel argument, so that a function the kernel calls can read them
+// back from the kernarg segment (uniform scalar loads) instead of having them passed in vector registers.
+struct KernArgs {
+    RtiParams P;
+    BatchPtrs bp;
+    int B, lds_per_wave;
+    MlpArgs ma;
+    QueueArgs qa;
+};
+
+// The step of an instance popped from the work queue.  Deliberately NOT inlined: it is a second copy of the fully unrolled
+// wave program, and inlined behind the first one the two share one register allocation (SGPR spills, accumulators pushed
+// to AGPRs: the interior-point path ran 2.3x slower).  As a function it gets its own allocation; it takes only the
+// instance id and reads everything else from the kernarg segment and the wave's own LDS slice.
+template <int NSLOT, int NC, int PREC, int NRC, bool FUSED>
+__device__ __attribute__((noinline)) void solve_popped(int id_v)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int id = __builtin_amdgcn_readfirstlane(id_v);
+    const KernArgs *ka = (const KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const RtiParams P = ka->P;
+    const BatchPtrs bp = ka->bp;
+    const int N = NC ? NC : P.N;
+    const int lpw = NC ? ((lds_doubles(NC) + 1) & ~1) : ka->lds_per_wave;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lpw);
+    RtiIo io;
+    bind_instance(io, bp, id, N);
+    io.dbg = nullptr;
+    if (FUSED) { io.f = ka->qa.fq + (size_t)id * 64; io.f_coherent = 1; }
+    RtiWave<WaveGfx950, NSLOT, NC, true, NRC, PREC>::run(P, io, lds);
+}
+
 // FUSED: the wave first predicts its own instance's disturbance force (gate + MLP over the N+1 <= 32 horizon rows,
 // one 32x32 f32 MFMA tile) and leaves it in the LDS staging slot the RTI program reads f from -- no second
 // launch and no trip of f through HBM.
 // QUEUE: interior-point solves go through the work queue above (launches with more instances than SIMDs).
 template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), bool QUEUE = false>
-__global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs bp, int B, int lds_per_wave, MlpArgs ma, QueueArgs qa)
+__global__ __launch_bounds__(64 * WAVES) void rti_kernel(KernArgs ka)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    const RtiParams &P = ka.P;
+    const BatchPtrs &bp = ka.bp;
+    const MlpArgs &ma = ka.ma;
+    const QueueArgs &qa = ka.qa;
+    const int B = ka.B;
     const int wave = (int)(threadIdx.x >> 6);
     const int inst_raw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave);
     const bool active = inst_raw < B;
     if (!FUSED && !active) return;
     const int inst = active ? inst_raw : B - 1;   // fused: idle waves of the last workgroup still take part in the barriers
     const int N = NC ? NC : P.N;
-    const size_t nx = (size_t)(N + 1) * NX, nf = (size_t)(N + 1) * 3;
+    const size_t nf = (size_t)(N + 1) * 3;
     RtiIo io;
     bind_instance(io, bp, inst, N);
-    const int lpw = NC ? ((lds_doubles(NC) + 1) & ~1) : lds_per_wave;
+    const int lpw = NC ? ((lds_doubles(NC) + 1) & ~1) : ka.lds_per_wave;
     WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lpw);
     using Prog = RtiWave<WaveGfx950, NSLOT, NC, true, NRC, PREC>;   // compile-time horizon and iteration count (NC = 0: both at run time)
     if (io.stamps && (threadIdx.x & 63u) == 0) {    // profiling hook: real time (100 MHz) and shader clock at entry -> the clock the launch ran at
@@ -195,18 +233,13 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(RtiParams P, BatchPtrs 
         io.stamps[15] = (double)__builtin_amdgcn_s_memtime();
     }
     if (QUEUE) {
+        // Every wave pops ONCE after its own instance (and after its own push, if any).  That is enough for every pushed
+        // instance to be solved: whenever a published instance is still waiting, the next wave that comes by takes one --
+        // and every pusher comes by after publishing its own.
         if (deferred) queue_push(qa, inst, B);
-        for (;;) {
-            const int id = queue_pop(qa, B);
-            if (id < 0) break;
-            RtiIo io2;
-            bind_instance(io2, bp, id, N);
-            io2.dbg = nullptr;
-            if (FUSED) { io2.f = qa.fq + (size_t)id * 64; io2.f_coherent = 1; }
-            Prog::run(P, io2, lds);
-        }
+        const int id = queue_pop(qa, B);
+        if (id >= 0) solve_popped<NSLOT, NC, PREC, NRC, FUSED>(id);
     }
-    (void)nx;
 }
 
 // test hook: one v_mfma_f64_16x16x4_f64 with caller-chosen per-lane operands (pins the register maps)
@@ -1183,6 +1216,7 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
                h->cfg.r_horiz * h->cfg.r_horiz, fused ? nb->stride : NX, fused ? nb->index : nullptr};
     QueueArgs qa{h->dQctr, h->dQids, h->dQf};
     const int B = h->cfg.batch, W = h->waves;
+    KernArgs ka{h->P, bp, B, h->lds_per_wave, ma, qa};
     const dim3 grid((B + W - 1) / W), block(64 * W);
     const size_t shm = (size_t)h->lds_per_wave * sizeof(double) * W;
     const int ns = slots_for(h->cfg.N);
@@ -1192,12 +1226,12 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     if (h->cfg.qp_precision) {      // precision study (BASELINE config 5): one wave per workgroup, unfused, any horizon
         if (fused) { h->err = "qp_precision != 0 supports f / no disturbance only (run ndp_downwash first)"; return -12; }
         const size_t shm1 = (size_t)h->lds_per_wave * sizeof(double);
-        if (h->cfg.qp_precision == 1) hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 1>), dim3(B), dim3(64), shm1, s, h->P, bp, B, h->lds_per_wave, ma, qa);
-        else hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 2>), dim3(B), dim3(64), shm1, s, h->P, bp, B, h->lds_per_wave, ma, qa);
+        if (h->cfg.qp_precision == 1) hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 1>), dim3(B), dim3(64), shm1, s, ka);
+        else hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 2>), dim3(B), dim3(64), shm1, s, ka);
         NDP_HIP(h, hipGetLastError());
         return end_timing(h, s);
     }
-#define LAUNCH(...) hipLaunchKernelGGL((rti_kernel<__VA_ARGS__>), grid, block, shm, s, h->P, bp, B, h->lds_per_wave, ma, qa)
+#define LAUNCH(...) hipLaunchKernelGGL((rti_kernel<__VA_ARGS__>), grid, block, shm, s, ka)
     if (h->cfg.N == 20 && h->cfg.n_rti == 1 && W == 4) {   // the reference configuration (params/nmpc_params.py:9, 1 RTI iteration): compile-time instantiation
         if (fused) { if (q) LAUNCH(3, 4, true, 20, 0, 1, true); else LAUNCH(3, 4, true, 20); }
         else { if (q) LAUNCH(3, 4, false, 20, 0, 1, true); else LAUNCH(3, 4, false, 20); }

@@ -522,9 +522,11 @@ def test_step_ex_returns_iterate_and_status_from_the_same_call(ndp, oracle):
 
 
 def test_work_queue_gives_the_same_answers(ndp, oracle, mlp_blob):
-    """The interior-point work queue only changes WHICH wave solves an instance: every output is bit-identical to the
-    in-place form, for the plain NMPC launch and for the fused gate + MLP launch (whose force reaches the solving wave
-    through the queue's write-through copy); three warm-started ticks; a ragged batch size."""
+    """The interior-point work queue only changes WHICH wave solves an instance: status and iteration counts are identical
+    to the in-place form and the iterates agree to rounding (the queue launch is a separate instantiation of the same
+    text: the compiler contracts a few multiply-adds differently), for the plain NMPC launch and for the fused gate + MLP
+    launch (whose force reaches the solving wave through the queue's write-through copy); three warm-started ticks; a
+    ragged batch size."""
     B = 1500 + 3
     for disturbance in (False, True):
         b = synth.make_batch(B, seed=55, downwash=disturbance, pos_sigma=0.5, vel_sigma=1.0, quat_sigma=0.15)
@@ -539,8 +541,9 @@ def test_work_queue_gives_the_same_answers(ndp, oracle, mlp_blob):
                 outs.append(eng.update(b["x0"], b["xr"], b["ur"], raise_on_status=False, full=True, **kw))
             res[wq] = outs
         for a, c in zip(res[1], res[2]):
-            for x, y in zip(a, c):
-                assert np.array_equal(x, y)
+            assert np.array_equal(a[3], c[3]) and np.array_equal(a[4], c[4])
+            for x, y in zip(a[:3], c[:3]):
+                np.testing.assert_allclose(x, y, rtol=0, atol=1e-8)
         u0, X, U, st, it = res[1][0]
         assert 0.05 < (it > 0).mean() < 0.6                      # the queue really carried a share of the batch
         f = oracle.downwash_batch(mlp_blob, b["other"], b["xr"], b["ego_xy"]) if disturbance else None
