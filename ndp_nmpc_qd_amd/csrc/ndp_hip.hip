@@ -56,46 +56,21 @@ struct MlpArgs {            // fused downwash (null frag = not fused)
                             // < 0 = no neighbour (force 0: the plain NMPC followers of a formation); null = row i
 };
 
-// Work queue of instances whose QP needs the interior-point loop (QUEUE launches).  An interior-point solve costs ~18
-// Riccati sweeps against 1 for the early exit, so with several instances per SIMD one such instance per workgroup leaves
-// the other three SIMDs of its CU idle for most of the launch.  Instead every wave first runs the cheap part of its own
-// instance; instances that need the loop are pushed here, and every wave that is done pops one and solves it (a pusher
-// pops after publishing its own, so whatever was pushed is solved by the end of the launch).  Counters are monotonic across launches
-// (nothing to reset, hipGraph-replayable): ctr[0] slots reserved, ctr[1] slots published (ids stored), ctr[2] slots taken.
+// Work list of instances whose QP needs the interior-point loop (batches with more instances than SIMDs).  An
+// interior-point solve costs ~18 Riccati sweeps against 1 for the early exit, so with several instances per SIMD one such
+// instance per workgroup leaves the other three SIMDs of its CU idle for most of the launch.  Instead the step is split:
+//   producer launch  (QMODE 1): every wave runs the cheap part of its own instance; an instance whose equality-constrained
+//                               minimiser is not inside the box is appended to the list (one atomic per such instance)
+//                               and NOT touched otherwise;
+//   consumer launch  (QMODE 2): wave j solves list entry j from scratch with the interior-point loop; waves past the end
+//                               of the list exit at once -- the listed instances are spread evenly over all SIMDs.
+// The list counter is zeroed by a memset node in front of the producer.  (An in-kernel queue -- finished waves popping
+// other instances' solves -- was built first: as a second inlined copy of the unrolled step it wrecked the register
+// allocation of both copies, as a called function it lost the scalar registers; either way 2.3x slower than this.)
 struct QueueArgs {
-    unsigned *ctr;
-    int *ids;               // ring of B instance ids
-    float *fq;              // [B][64]: the fused downwash force of every instance, 256-byte records written write-through
+    unsigned *count;        // entries of ids
+    int *ids;               // [B]
 };
-
-__device__ __forceinline__ void queue_push(const QueueArgs &q, int inst, int B)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores (fq) have left before the id is published
-    if ((threadIdx.x & 63u) == 0) {
-        const unsigned s = __hip_atomic_fetch_add(&q.ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&q.ids[s % (unsigned)B], inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        while (__hip_atomic_load(&q.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != s) __builtin_amdgcn_s_sleep(2);   // publish in slot order
-        __hip_atomic_store(&q.ctr[1], s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-__device__ __forceinline__ int queue_pop(const QueueArgs &q, int B)
-{
-    int id = -1;
-    if ((threadIdx.x & 63u) == 0) {
-        for (;;) {
-            unsigned h = __hip_atomic_load(&q.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned c = __hip_atomic_load(&q.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((int)(c - h) <= 0) break;
-            if (__hip_atomic_compare_exchange_strong(&q.ctr[2], &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                id = __hip_atomic_load(&q.ids[h % (unsigned)B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    return __builtin_amdgcn_readfirstlane(id);
-}
 
 typedef __attribute__((address_space(3))) float *lds_f32;
 typedef const __attribute__((address_space(3))) float *lds_cf32;
@@ -117,14 +92,11 @@ __device__ __forceinline__ void bind_instance(RtiIo &io, const BatchPtrs &bp, in
     io.iters = bp.iters + inst;
     io.dbg = bp.dbg;
     io.f_in_lds = 0;
-    io.f_coherent = 0;
     io.kc = bp.kc;
     io.tables = bp.tables;
     io.stamps = bp.stamps ? bp.stamps + (size_t)inst * 16 : nullptr;
 }
 
-// All launch parameters of rti_kernel as ONE by-value kernel argument, so that a function the kernel calls can read them
-// back from the kernarg segment (uniform scalar loads) instead of having them passed in vector registers.
 struct KernArgs {
     RtiParams P;
     BatchPtrs bp;
@@ -133,36 +105,14 @@ struct KernArgs {
     QueueArgs qa;
 };
 
-// The step of an instance popped from the work queue.  Deliberately NOT inlined: it is a second copy of the fully unrolled
-// wave program, and inlined behind the first one the two share one register allocation (SGPR spills, accumulators pushed
-// to AGPRs: the interior-point path ran 2.3x slower).  As a function it gets its own allocation; it takes only the
-// instance id and reads everything else from the kernarg segment and the wave's own LDS slice.
-template <int NSLOT, int NC, int PREC, int NRC, bool FUSED>
-__device__ __attribute__((noinline)) void solve_popped(int id_v)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int id = __builtin_amdgcn_readfirstlane(id_v);
-    const KernArgs *ka = (const KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    const RtiParams P = ka->P;
-    const BatchPtrs bp = ka->bp;
-    const int N = NC ? NC : P.N;
-    const int lpw = NC ? ((lds_doubles(NC) + 1) & ~1) : ka->lds_per_wave;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lpw);
-    RtiIo io;
-    bind_instance(io, bp, id, N);
-    io.dbg = nullptr;
-    if (FUSED) { io.f = ka->qa.fq + (size_t)id * 64; io.f_coherent = 1; }
-    RtiWave<WaveGfx950, NSLOT, NC, true, NRC, PREC>::run(P, io, lds);
-}
-
 // FUSED: the wave first predicts its own instance's disturbance force (gate + MLP over the N+1 <= 32 horizon rows,
 // one 32x32 f32 MFMA tile) and leaves it in the LDS staging slot the RTI program reads f from -- no second
 // launch and no trip of f through HBM.
-// QUEUE: interior-point solves go through the work queue above (launches with more instances than SIMDs).
-template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), bool QUEUE = false>
+// QMODE: 0 = the whole step in place; 1 / 2 = producer / consumer of the interior-point work list (see QueueArgs).
+template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), int QMODE = 0>
 __global__ __launch_bounds__(64 * WAVES) void rti_kernel(KernArgs ka)
 {
+    static_assert(!(FUSED && QMODE == 2), "the consumer reads the force the producer left in global memory");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const RtiParams &P = ka.P;
     const BatchPtrs &bp = ka.bp;
@@ -170,7 +120,12 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(KernArgs ka)
     const QueueArgs &qa = ka.qa;
     const int B = ka.B;
     const int wave = (int)(threadIdx.x >> 6);
-    const int inst_raw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave);
+    int inst_raw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave);
+    if (QMODE == 2) {         // list entry -> instance; past the end of the list: nothing to do
+        const int n = (int)*qa.count;
+        if (inst_raw >= n) return;
+        inst_raw = __builtin_amdgcn_readfirstlane(qa.ids[inst_raw]);
+    }
     const bool active = inst_raw < B;
     if (!FUSED && !active) return;
     const int inst = active ? inst_raw : B - 1;   // fused: idle waves of the last workgroup still take part in the barriers
@@ -219,26 +174,21 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(KernArgs ka)
             for (int c = 0; c < 3; ++c) {
                 const float v = open ? o[c] : 0.0f;      // ndp_nmpc_leader_node.py:75-76
                 lds[m.TF + j * 3 + c] = (double)v;       // fp32 value promoted to fp64
-                ma.force_out[inst * nf + j * 3 + c] = v;
-                if (QUEUE) __hip_atomic_store(&qa.fq[(size_t)inst * 64 + j * 3 + c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ma.force_out[inst * nf + j * 3 + c] = v; // also what the consumer launch of the work list reads
             }
         }
         WaveGfx950::sync();
         io.f = nullptr;
         io.f_in_lds = 1;
     }
-    const bool deferred = Prog::template run<QUEUE>(P, io, lds, inb, x0v);
+    const bool deferred = Prog::template run<QMODE == 1>(P, io, lds, inb, x0v);
     if (io.stamps && (threadIdx.x & 63u) == 0) {
         io.stamps[13] = (double)__builtin_amdgcn_s_memrealtime();
         io.stamps[15] = (double)__builtin_amdgcn_s_memtime();
     }
-    if (QUEUE) {
-        // Every wave pops ONCE after its own instance (and after its own push, if any).  That is enough for every pushed
-        // instance to be solved: whenever a published instance is still waiting, the next wave that comes by takes one --
-        // and every pusher comes by after publishing its own.
-        if (deferred) queue_push(qa, inst, B);
-        const int id = queue_pop(qa, B);
-        if (id >= 0) solve_popped<NSLOT, NC, PREC, NRC, FUSED>(id);
+    if (QMODE == 1 && deferred && (threadIdx.x & 63u) == 0) {
+        const unsigned s = __hip_atomic_fetch_add(qa.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        qa.ids[s] = inst;
     }
 }
 
@@ -892,7 +842,7 @@ struct ndp_handle {
     int lds_per_wave = 0;      // doubles
     int waves = 4;             // instances per workgroup
     int n_simd = 1024;         // SIMDs of the device (4 per CU)
-    bool use_queue = false;    // interior-point solves through the in-kernel work queue (QueueArgs)
+    bool use_queue = false;    // interior-point solves through the work list: producer + consumer launch per step (QueueArgs)
     hipStream_t stream = nullptr;
     // persistent device state
     double *dX = nullptr, *dU = nullptr;
@@ -907,9 +857,8 @@ struct ndp_handle {
     int list_head = 0, list_step = 5;
     double *dRelay = nullptr;  // follower relay: [B][4] = filtered offset xyz + initialised flag
     double *sThr = nullptr;    // staging of the f1-f4 host entry points: 11 B doubles
-    unsigned *dQctr = nullptr; // work queue: 3 monotonic counters | ring of B ids | [B][64] forces
+    unsigned *dQctr = nullptr; // work list: entry count | B instance ids
     int *dQids = nullptr;
-    float *dQf = nullptr;
     bool have_mlp = false;
     // Host-pointer entry points.  ONE device block holds every input of a step (x0 | xr | ur | f | other | ego_xy, each
     // 256-byte aligned) and one holds its small outputs (u0 | status | iters): with a pinned host mirror of both (batches
@@ -1003,7 +952,7 @@ int ndp_destroy(ndp_handle *h)
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->evLast) (void)hipEventDestroy(h->evLast);
     void *ptrs[] = {h->dRefList, h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dX, h->dU, h->dForce, h->dFrag,
-                    h->dIn, h->dOut, h->sdbg, h->dQctr, h->dQids, h->dQf};
+                    h->dIn, h->dOut, h->sdbg, h->dQctr, h->dQids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->hIn) (void)hipHostFree(h->hIn);
@@ -1066,10 +1015,9 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     ALLOC(h->dForce, nfs(h) * 4); ALLOC(h->dFrag, FR_TOTAL * 4); ALLOC(h->dKC, KC_SC * 8);
     ALLOC(h->dThr, B * 8 * 8); ALLOC(h->sThr, B * 11 * 8);
     ALLOC(h->dRelay, B * 4 * 8);
-    ALLOC(h->dQctr, 256); ALLOC(h->dQids, B * 4); ALLOC(h->dQf, B * 64 * 4);
+    ALLOC(h->dQctr, 256); ALLOC(h->dQids, B * 4);
     (void)hipMemsetAsync(h->dRelay, 0, B * 4 * 8, h->stream);
     (void)hipMemsetAsync(h->dQctr, 0, 256, h->stream);
-    (void)hipMemsetAsync(h->dQf, 0, B * 64 * 4, h->stream);
     {
         double kc[KC_SC];
         fill_kc(h->P, kc);
@@ -1116,9 +1064,9 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
                          (const void *)rti_kernel<5, 4, false>, (const void *)rti_kernel<5, 2, false>, (const void *)rti_kernel<5, 1, false>,
                          (const void *)rti_kernel<3, 4, true>, (const void *)rti_kernel<3, 2, true>, (const void *)rti_kernel<3, 1, true>,
                          (const void *)rti_kernel<3, 4, false, 20>, (const void *)rti_kernel<3, 4, true, 20>,
-                         (const void *)rti_kernel<3, 4, false, 20, 0, 1, true>, (const void *)rti_kernel<3, 4, true, 20, 0, 1, true>,
+                         (const void *)rti_kernel<3, 4, false, 20, 0, 1, 1>, (const void *)rti_kernel<3, 4, true, 20, 0, 1, 1>, (const void *)rti_kernel<3, 4, false, 20, 0, 1, 2>,
                          (const void *)rti_kernel<5, 1, false, 0, 1>, (const void *)rti_kernel<5, 1, false, 0, 2>,
-                         (const void *)rti_kernel<5, 2, false, 40, 0, 2>, (const void *)rti_kernel<5, 2, false, 40, 0, 2, true>};
+                         (const void *)rti_kernel<5, 2, false, 40, 0, 2>, (const void *)rti_kernel<5, 2, false, 40, 0, 2, 1>, (const void *)rti_kernel<5, 2, false, 40, 0, 2, 2>};
     if ((e = hipFuncSetAttribute((const void *)mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(FR_TOTAL * sizeof(float)))) != hipSuccess)
         return fail("hipFuncSetAttribute(mlp_kernel)", e);
@@ -1214,7 +1162,7 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     const bool fused = nb && nb->other;
     MlpArgs ma{fused ? h->dFrag : nullptr, fused ? nb->other : nullptr, fused ? nb->ego_xy : nullptr, h->dForce,
                h->cfg.r_horiz * h->cfg.r_horiz, fused ? nb->stride : NX, fused ? nb->index : nullptr};
-    QueueArgs qa{h->dQctr, h->dQids, h->dQf};
+    QueueArgs qa{h->dQctr, h->dQids};
     const int B = h->cfg.batch, W = h->waves;
     KernArgs ka{h->P, bp, B, h->lds_per_wave, ma, qa};
     const dim3 grid((B + W - 1) / W), block(64 * W);
@@ -1232,11 +1180,31 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
         return end_timing(h, s);
     }
 #define LAUNCH(...) hipLaunchKernelGGL((rti_kernel<__VA_ARGS__>), grid, block, shm, s, ka)
+    if (q) {
+        // work list: zero the counter, producer (every instance, early exit or defer), consumer (the deferred ones, from
+        // scratch; with one RTI iteration the consumer goes straight to the interior-point loop, with several it repeats the
+        // automatic rule per iteration).  The consumer reads the fused producer's force from dForce.
+        NDP_HIP(h, hipMemsetAsync(h->dQctr, 0, 4, s));
+        KernArgs kc = ka;
+        kc.bp.f = fused ? h->dForce : d_f;
+        kc.ma.frag = nullptr; kc.ma.other = nullptr;
+        if (h->cfg.n_rti == 1) kc.P.qp_mode = QP_IPM_ALWAYS;
+        if (h->cfg.N == 20) {
+            if (fused) LAUNCH(3, 4, true, 20, 0, 1, 1); else LAUNCH(3, 4, false, 20, 0, 1, 1);
+            NDP_HIP(h, hipGetLastError());
+            hipLaunchKernelGGL((rti_kernel<3, 4, false, 20, 0, 1, 2>), grid, block, shm, s, kc);
+        } else {
+            LAUNCH(5, 2, false, 40, 0, 2, 1);
+            NDP_HIP(h, hipGetLastError());
+            hipLaunchKernelGGL((rti_kernel<5, 2, false, 40, 0, 2, 2>), grid, block, shm, s, kc);
+        }
+        NDP_HIP(h, hipGetLastError());
+        return end_timing(h, s);
+    }
     if (h->cfg.N == 20 && h->cfg.n_rti == 1 && W == 4) {   // the reference configuration (params/nmpc_params.py:9, 1 RTI iteration): compile-time instantiation
-        if (fused) { if (q) LAUNCH(3, 4, true, 20, 0, 1, true); else LAUNCH(3, 4, true, 20); }
-        else { if (q) LAUNCH(3, 4, false, 20, 0, 1, true); else LAUNCH(3, 4, false, 20); }
+        if (fused) LAUNCH(3, 4, true, 20); else LAUNCH(3, 4, false, 20);
     } else if (h->cfg.N == 40 && h->cfg.n_rti == 2 && W == 2 && !fused) {   // BASELINE config 5's shape, compile-time as well
-        if (q) LAUNCH(5, 2, false, 40, 0, 2, true); else LAUNCH(5, 2, false, 40, 0, 2);
+        LAUNCH(5, 2, false, 40, 0, 2);
     } else if (fused) { if (W == 4) LAUNCH(3, 4, true); else if (W == 2) LAUNCH(3, 2, true); else LAUNCH(3, 1, true); }
     else if (ns <= 3) { if (W == 4) LAUNCH(3, 4, false); else if (W == 2) LAUNCH(3, 2, false); else LAUNCH(3, 1, false); }
     else { if (W == 4) LAUNCH(5, 4, false); else if (W == 2) LAUNCH(5, 2, false); else LAUNCH(5, 1, false); }

@@ -88,7 +88,6 @@ struct RtiIo {            // global-memory views of ONE instance
     const double *kc;     // [KC_SC] lane-indexable constants block prepared by the host (fill_kc)
     double *stamps = nullptr;   // optional [16] per-instance phase stamps (whole-batch profiling), or null
     const int *tables = nullptr;   // [TB_WORDS] host-built index tables (fill_tables), read when RtiWave<..., HT = true>
-    int f_coherent = 0;            // 1: f was written by ANOTHER workgroup of this launch (work queue): read it past the non-coherent caches
 };
 
 struct LdsMap {
@@ -333,7 +332,7 @@ struct RtiWave {
         }
         for (int t = 0; t < RF; ++t) {
             vi i = W::imin(lane + 64 * t, nf - 1);
-            b.f[t] = have_f ? (io.f_coherent ? W::gldfu_coherent(io.f, i) : W::gldfu(io.f, i)) : vd(0.0);
+            b.f[t] = have_f ? W::gldfu(io.f, i) : vd(0.0);
         }
         b.kc = first ? W::gldu(io.kc, W::imin(lane, KC_SC - 1)) : vd(0.0);
     }
@@ -1050,9 +1049,9 @@ struct RtiWave {
         run<false>(P, io, lds, inb, x0v);
     }
 
-    // DEFER (work-queue launches): when the first QP that needs the interior-point loop shows up, return true at once --
-    // nothing of this instance has been written to global memory then, and whichever wave pops the instance from the
-    // queue redoes the step from the same inputs with DEFER = false.  The interior-point code is not instantiated at all.
+    // DEFER (producer launch of the work list): when the first QP that needs the interior-point loop shows up, return true at
+    // once -- nothing of this instance has been written to global memory then, and the consumer launch redoes the step from
+    // the same inputs with DEFER = false.  The interior-point code is not instantiated at all.
     template <bool DEFER>
     static NDP_D bool run(const RtiParams &P, const RtiIo &io, lp lds, InBuf &inb, vd x0v)
     {

@@ -46,8 +46,6 @@ struct WaveGfx950 {
     static NDP_D vd gldf(const float *g, vi off, vb p) { return p ? (double)g[off] : 0.0; }
     static NDP_D vd gldu(const double *g, vi off) { return g[off]; }
     static NDP_D vd gldfu(const float *g, vi off) { return (double)g[off]; }
-    // a float another workgroup of the SAME launch stored write-through (work queue hand-off): sc1 load, past the CU's L1
-    static NDP_D vd gldfu_coherent(const float *g, vi off) { return (double)__hip_atomic_load(g + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     static NDP_D vi gldi(const int *g, vi off) { return g[off]; }
     static NDP_D vi imin(vi a, vi b) { return a < b ? a : b; }
     static NDP_D void gst(double *g, vi off, vd v, vb p) { if (p) g[off] = v; }

@@ -98,7 +98,6 @@ struct Wave {
     static void gst(double *g, const vi &off, const vd &val, const vb &p) { for (int l = 0; l < 64; ++l) if (p.v[l]) g[off.v[l]] = val.v[l]; }
     static vd gldu(const double *g, const vi &off) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = g[off.v[l]]; return o; }
     static vd gldfu(const float *g, const vi &off) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)g[off.v[l]]; return o; }
-    static vd gldfu_coherent(const float *g, const vi &off) { return gldfu(g, off); }
     static vi gldi(const int *g, const vi &off) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = g[off.v[l]]; return o; }
     static vi imin(const vi &a, const vi &b) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return o; }
     static void gst2(double *a, double *b, const vi &i, int n, const vd &val) { for (int l = 0; l < 64; ++l) (i.v[l] < n ? a + i.v[l] : b + (i.v[l] - n))[0] = val.v[l]; }
