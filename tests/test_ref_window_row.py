@@ -1,7 +1,9 @@
 """reference window generation (polynomial trajectory -> flatness -> xr/ur windows).
 ref_golden.npz: coefficients and trajectory points produced by the reference's own PolymOptimizer
-(tests/golden/make_ref_golden.py).  The flatness map cannot be imported (rospy / tf_conversions): it is pinned by
-identities that any correct implementation of pt_publisher.py:188-248 satisfies."""
+(tests/golden/make_ref_golden.py).  flat_golden.npz: the flatness map (R_wb, body rates, collective force) and the
+101-entry sliding list of NMPCRefPublisher (windows of 60 control ticks, the start-up duplicate, gen_fix_pt_ref) produced by
+RUNNING the reference's pt_pub/pt_publisher.py under stand-ins for the ROS modules (tests/golden/make_flatness_golden.py).
+The physical identities of the first round stay as a second, independent pin."""
 import os
 
 import numpy as np
@@ -190,3 +192,84 @@ def test_gpu_reference_window_feeds_the_controller(oracle):
     X, U = xo.copy(), uo.copy()
     u_or, st, _ = oracle.step_batch(cfg, x0.cpu().numpy(), xo, uo, None, X, U)
     assert np.max(np.abs(u0.cpu().numpy() - u_or) / np.maximum(1.0, np.abs(u_or))) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- goldens from the reference's own pt_publisher.py
+@pytest.fixture(scope="module")
+def flat():
+    return np.load(os.path.join(ROOT, "tests", "golden", "flat_golden.npz"))
+
+
+def test_oracle_flatness_against_the_reference_code(oracle, flat):
+    """diff_flatness (pt_publisher.py:188-248) as the reference computed it: R_wb is the matrix the reference's numpy code
+    handed to quaternion_from_matrix, p/q/r and collective_force are read off its TrajFullStatePt.  The oracle's quaternion
+    is checked THROUGH R_wb (R(q) = R_wb, unit norm), so the test does not lean on the stand-in's quaternion routine."""
+    for p, y, R, w, F, q_xyzw in zip(flat["flat_pvaj"], flat["flat_yaw"], flat["flat_R"], flat["flat_rates"], flat["flat_force"], flat["flat_q"]):
+        x, u = oracle.diff_flatness(p, y)
+        np.testing.assert_allclose(_rot(x[6:10]), R, rtol=0, atol=1e-12)
+        assert abs(np.linalg.norm(x[6:10]) - 1) < 1e-13
+        np.testing.assert_allclose(u[0:3], w, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(u[3] * CP.mass, F, rtol=1e-13)
+        np.testing.assert_array_equal(x[0:6], p[0:6])
+        # same branch and sign as ROS geometry's quaternion_from_matrix (restated in the generator): [x, y, z, w]
+        np.testing.assert_allclose(x[[7, 8, 9, 6]], q_xyzw, rtol=0, atol=1e-13)
+
+
+def _seq_traj(gold, flat):
+    c = int(flat["seq_case"])
+    coeff, tseg, wpts = gold[f"coeff_{c}"], flat["seq_tseg"], gold[f"wpts_{c}"]
+    return coeff, tseg, _cum(tseg), wpts[:, 0:3, -1].copy()
+
+
+def test_sliding_list_semantics_against_the_reference_code(oracle, gold, flat):
+    """NMPCRefPublisher's list (pt_publisher.py:57-103) replayed with the oracle's point evaluation: after reset the list
+    holds the points at i * 0.02 s (i = 0..99) with the first one duplicated in front; every get_nmpc_pts drops the
+    oldest and appends the point at t + T_horizon; the window is every 5th entry.  60 ticks with timer jitter, one
+    trajectory ending inside the sequence (hover at final_pt afterwards)."""
+    coeff, tseg, cum, fpt = _seq_traj(gold, flat)
+    V = coeff.shape[0]
+
+    def point(v, t):
+        return np.concatenate(oracle.diff_flatness(*oracle.traj_point(coeff[v], cum[v], tseg[v], fpt[v], t)))
+    for v in range(V):
+        lst = [point(v, i * CP.ts_nmpc) for i in range(CP.long_list_size - 1)]
+        lst.insert(0, lst[0])
+        win = np.array(lst[::5])
+        np.testing.assert_allclose(win[:, :10], flat["seq_xr0"][v], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(win[:-1, 10:], flat["seq_ur0"][v], rtol=0, atol=1e-7)
+        for k, t in enumerate(flat["seq_t"]):
+            lst.pop(0)
+            lst.append(point(v, t + CP.T_horizon))
+            win = np.array(lst[::5])
+            np.testing.assert_allclose(win[:, :10], flat["seq_xr"][k, v], rtol=0, atol=1e-7)
+            np.testing.assert_allclose(win[:-1, 10:], flat["seq_ur"][k, v], rtol=0, atol=1e-7)
+    # the start-up duplicate is visible in the first windows: node 1 is 0.08 s after node 0, not 0.1 s
+    assert np.allclose(flat["seq_xr0"][:, 0], flat["seq_xr0"][:, 0]) and not np.allclose(flat["seq_xr0"][1, 1, 0:3], point(1, 0.1)[0:3], atol=1e-6)
+    assert np.allclose(flat["seq_xr0"][1, 1, 0:3], point(1, 0.08)[0:3], atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_gpu_sliding_list_against_the_reference_code(gold, flat):
+    """The device ring (ndp_ref_list_*) behind BatchedNMPCRefPublisher against the windows the reference's NMPCRefPublisher
+    produced: right after reset, over 60 control ticks, and gen_fix_pt_ref (u_r[3] = mass * g)."""
+    import ndp_nmpc_qd_amd as ndp
+    from ndp_nmpc_qd_amd.pt_pub import BatchedNMPCRefPublisher
+    coeff, tseg, cum, fpt = _seq_traj(gold, flat)
+    V = coeff.shape[0]
+    eng = ndp.BatchedNMPC(V, load_mlp=False)
+    pub = BatchedNMPCRefPublisher(eng)
+    pub.reset(TrajCoefficients(coeff[:, :, 0:8], coeff[:, :, 8:16], coeff[:, :, 16:24], coeff[:, :, 24:28], cum, tseg, fpt))
+    xr, ur = pub.get_nmpc_ref_from_long_list()
+    np.testing.assert_allclose(xr, flat["seq_xr0"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(ur, flat["seq_ur0"], rtol=0, atol=1e-7)
+    for k, t in enumerate(flat["seq_t"]):
+        xr, ur = pub.get_nmpc_pts(t)
+        np.testing.assert_allclose(xr, flat["seq_xr"][k], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(ur, flat["seq_ur"][k], rtol=0, atol=1e-7)
+    assert np.allclose(xr[0, -1, 0:3], fpt[0]) and np.allclose(ur[0, -1], [0, 0, 0, CP.gravity])   # vehicle 0 hovers at its final point
+    xr, ur = pub.gen_fix_pt_ref(flat["fix_x"])
+    np.testing.assert_array_equal(xr, flat["fix_xr"])
+    np.testing.assert_array_equal(ur, flat["fix_ur"])
+    assert ur[0, 0, 3] == CP.mass * CP.gravity
+    xr2, ur2 = pub.gen_fix_pt_ref(flat["fix_x"], quirk_b1=False)
+    assert np.array_equal(xr2, xr) and ur2[0, 0, 3] == CP.gravity
