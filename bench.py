@@ -353,7 +353,7 @@ def main():
         # committed kernel duration when the profile belongs to this configuration, else the in-kernel stamp span of one
         # launch over its HIP-event duration.
         n_f64 = sweeps * (6 + 8 * (N - 1) + N + 16 * ((N - 1) // 8) + 4 * N)
-        pipe_cycles = n_f64 * 64 + ((12 * 64 + 96 * 32) if fused else 0)
+        pipe_cycles = (n_f64 * 64 + ((12 * 64 + 96 * 32) if fused else 0)) * -(-B // 1024)      # instances per SIMD (1024 SIMDs), in rounds
         clock_hz, clock_src = None, None
         if prof["wave_cycles_per_simd"] and prof["kernel_us"]:
             clock_hz, clock_src = prof["wave_cycles_per_simd"] / (prof["kernel_us"] * 1e-6), f"profiles/{PROFILE_TAG} PMC SQ_WAVE_CYCLES / kernel trace duration"
