@@ -42,9 +42,11 @@ extern "C" {
 #define NDP_QP_AUTO 0       /* exact early exit when no bound is active, else interior point */
 #define NDP_QP_IPM_ALWAYS 1 /* always run the interior-point loop (what HPIPM does) */
 
-#define NDP_PREC_F64 0
-#define NDP_PREC_F32_STUDY 1
-#define NDP_PREC_BF16_STUDY 2
+#define NDP_PREC_F64 0        /* product path: v_mfma_f64_16x16x4_f64 */
+#define NDP_PREC_F32_STUDY 1  /* f64 kernel, operands of the sweeps' matrix instructions rounded to fp32 (numerics only) */
+#define NDP_PREC_BF16_STUDY 2 /* ... rounded to bf16 */
+#define NDP_PREC_F32_MFMA 3   /* the Riccati sweeps on v_mfma_f32_16x16x4_f32 */
+#define NDP_PREC_BF16_MFMA 4  /* the Riccati sweeps on v_mfma_f32_16x16x16_bf16 (bf16 in, fp32 accumulate) */
 
 typedef struct ndp_cfg {
     int32_t batch;      /* B: independent OCP instances in this handle            */
@@ -54,8 +56,9 @@ typedef struct ndp_cfg {
     int32_t qp_mode;    /* NDP_QP_*                                               */
     int32_t iter_max;   /* interior-point iteration cap (acados default 50)       */
     int32_t device;     /* HIP device ordinal                                     */
-    int32_t qp_precision; /* 0 = product path (fp64).  Precision study of BASELINE config 5 only: 1 / 2 round the operands of
-                           * the Riccati sweeps' matrix instructions to fp32 / bf16 and their accumulators to fp32 */
+    int32_t qp_precision; /* NDP_PREC_*: 0 = product path (fp64).  BASELINE config 5 ("fp32 vs bf16 MFMA on the QP") only:
+                           * 3 / 4 run the Riccati sweeps on the fp32 / bf16-input matrix instructions (everything else stays
+                           * fp64); 1 / 2 are the first round's operand-rounding studies on the fp64 kernel */
     int32_t work_queue; /* instances whose QP needs the interior-point loop are re-distributed over all SIMDs through an
                          * in-kernel queue: 0 = automatic (on when batch > SIMDs of the device and qp_mode is AUTO), 1 = on, 2 = off */
     int32_t reserved0;
@@ -230,6 +233,10 @@ int ndp_debug_lds_layout(int N, int *out8);
 /* Test hook: one v_mfma_f64_16x16x4_f64 on caller-chosen per-lane operands a[64], b[64], c[4][64];
  * d[0..255] = result registers [4][64], d[256..319] = a cross-lane checksum (readlane + wave reductions). */
 int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, double *d);
+/* Test hook: the config-5 instructions through their backends.  mode 0: one v_mfma_f32_16x16x4_f32 on a[0][64], b[0][64];
+ * mode 1: one v_mfma_f32_16x16x16_bf16 on four packed contraction steps a[4][64], b[4][64]; c[4][64] -> d[0..255];
+ * d[256..319] = the four-lane row sum of a[0] (lanes 4 apart inside each 16-lane row). */
+int ndp_debug_mfma_probe_f32(const float *a, const float *b, const float *c, float *d, int mode);
 /* Profiling hook: enable = 1 makes every instance of the following steps write 16 phase stamps (shader clock);
  * out (or NULL) receives the [B][16] stamps of the last step before the switch is applied. */
 int ndp_debug_stamps(ndp_handle *h, int enable, double *out);

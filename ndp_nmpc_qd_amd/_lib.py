@@ -40,7 +40,7 @@ EXPORTS = [
     "ndp_relay_reference", "ndp_relay_reference_device", "ndp_plant_step", "ndp_plant_step_device",
     "ndp_ref_set_trajectory", "ndp_ref_window", "ndp_ref_window_device", "ndp_rollout_device",
     "ndp_step_ex", "ndp_step_device_ex", "ndp_work_queue_enabled", "ndp_ref_list_reset", "ndp_ref_list_fix_pt",
-    "ndp_ref_list_window", "ndp_ref_list_advance_device", "ndp_ref_list_window_device",
+    "ndp_ref_list_window", "ndp_ref_list_advance_device", "ndp_ref_list_window_device", "ndp_debug_mfma_probe_f32",
 ]
 
 _lib = None
@@ -96,6 +96,7 @@ def load():
     lib.ndp_debug_lds_layout.argtypes = [C.c_int, vp]
     lib.ndp_step_debug.argtypes = [vp] * 9
     lib.ndp_debug_mfma_probe.argtypes = [vp] * 4
+    lib.ndp_debug_mfma_probe_f32.argtypes = [vp] * 4 + [C.c_int]
     lib.ndp_debug_stamps.argtypes = [vp, C.c_int, vp]
     lib.ndp_throttle_reset.argtypes = [vp]
     lib.ndp_throttle_update.argtypes = [vp] * 4

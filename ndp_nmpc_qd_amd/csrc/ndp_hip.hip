@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "wave_gfx950.hpp"   // defines the device qualifiers, must precede rti_wave.hpp
@@ -135,7 +136,10 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(KernArgs ka)
     bind_instance(io, bp, inst, N);
     const int lpw = NC ? ((lds_doubles(NC) + 1) & ~1) : ka.lds_per_wave;
     WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lpw);
-    using Prog = RtiWave<WaveGfx950, NSLOT, NC, true, NRC, PREC>;   // compile-time horizon and iteration count (NC = 0: both at run time)
+    // PREC 0: the product path (f64 matrix instruction); 1 / 2: operand-rounding studies on it; 3 / 4: the sweeps on the real
+    // fp32 / bf16-input matrix instructions (BASELINE config 5)
+    using WB = std::conditional_t<PREC == 3, WaveGfx950F32, std::conditional_t<PREC == 4, WaveGfx950BF16, WaveGfx950>>;
+    using Prog = RtiWave<WB, NSLOT, NC, true, NRC, (PREC >= 3 ? 0 : PREC)>;   // compile-time horizon and iteration count (NC = 0: both at run time)
     if (io.stamps && (threadIdx.x & 63u) == 0) {    // profiling hook: real time (100 MHz) and shader clock at entry -> the clock the launch ran at
         io.stamps[12] = (double)__builtin_amdgcn_s_memrealtime();
         io.stamps[14] = (double)__builtin_amdgcn_s_memtime();
@@ -201,6 +205,27 @@ __global__ void mfma_probe_kernel(const double *a, const double *b, const double
     acc = WaveGfx950::mfma(a[l], b[l], acc);
     for (int r = 0; r < 4; ++r) d[r * 64 + l] = acc.r[r];
     d[256 + l] = WaveGfx950::readlane(a[l], 37) + WaveGfx950::wave_sum(b[l]) + WaveGfx950::wave_min(a[l]) + WaveGfx950::wave_max(a[l]);
+}
+
+// test hook: one v_mfma_f32_16x16x4_f32 (mode 0) or one v_mfma_f32_16x16x16_bf16 (mode 1: four packed contraction steps)
+// through the config-5 backends, caller-chosen per-lane operands a[4][64], b[4][64] (mode 0 uses row 0), c[4][64] -> d[4][64]
+__global__ void mfma_probe32_kernel(const float *a, const float *b, const float *c, float *d, int mode)
+{
+    const int l = (int)threadIdx.x;
+    WaveGfx950F32::md4 acc;
+    for (int r = 0; r < 4; ++r) acc.r[r] = c[r * 64 + l];
+    if (mode == 0) acc = WaveGfx950F32::mfma(a[l], b[l], acc);
+    else {
+        float av[4], bv[4];
+        for (int i = 0; i < 4; ++i) { av[i] = a[i * 64 + l]; bv[i] = b[i * 64 + l]; }
+        acc = WaveGfx950BF16::mfma_k(av, bv, 4, acc);
+    }
+    for (int r = 0; r < 4; ++r) d[r * 64 + l] = acc.r[r];
+    // the row sum of the config-5 layout: lanes 4 apart inside a 16-lane row
+    double x = (double)a[l];
+    x = x + WaveGfx950F32::csum1(x);
+    x = x + WaveGfx950F32::csum2(x);
+    d[256 + l] = (float)x;
 }
 
 // ------------------------------------------------------------------------------------------ MLP kernel
@@ -943,6 +968,21 @@ int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, doub
     return e == hipSuccess ? 0 : -2;
 }
 
+int ndp_debug_mfma_probe_f32(const float *a, const float *b, const float *c, float *d, int mode)
+{
+    float *da = nullptr, *db = nullptr, *dc = nullptr, *dd = nullptr;
+    if (hipMalloc((void **)&da, 256 * 4) != hipSuccess || hipMalloc((void **)&db, 256 * 4) != hipSuccess ||
+        hipMalloc((void **)&dc, 256 * 4) != hipSuccess || hipMalloc((void **)&dd, 320 * 4) != hipSuccess)
+        return -1;
+    (void)hipMemcpy(da, a, 256 * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, b, 256 * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dc, c, 256 * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(mfma_probe32_kernel, dim3(1), dim3(64), 0, 0, da, db, dc, dd, mode);
+    const hipError_t e = hipMemcpy(d, dd, 320 * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dd);
+    return e == hipSuccess ? 0 : -2;
+}
+
 int ndp_destroy(ndp_handle *h)
 {
     if (!h) return -1;
@@ -966,9 +1006,9 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
 {
     if (!cfg || !out) { g_create_err = "ndp_create: null argument"; return -1; }
     *out = nullptr;
-    if (cfg->batch < 1 || cfg->N < 2 || slots_for(cfg->N) > 5 || cfg->n_rti < 1 || cfg->qp_precision < 0 || cfg->qp_precision > 2 ||
+    if (cfg->batch < 1 || cfg->N < 2 || slots_for(cfg->N) > 5 || cfg->n_rti < 1 || cfg->qp_precision < 0 || cfg->qp_precision > 4 ||
         cfg->work_queue < 0 || cfg->work_queue > 2 || !(cfg->ts_nmpc > 0.0) || cfg->dt < cfg->ts_nmpc) {
-        g_create_err = "ndp_create: need batch >= 1, 2 <= N <= 46, n_rti >= 1, qp_precision in 0..2, work_queue in 0..2, 0 < ts_nmpc <= dt";
+        g_create_err = "ndp_create: need batch >= 1, 2 <= N <= 46, n_rti >= 1, qp_precision in 0..4, work_queue in 0..2, 0 < ts_nmpc <= dt";
         return -2;
     }
     int ndev = 0;
@@ -1024,7 +1064,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         if ((e = hipMemcpyAsync(h->dKC, kc, sizeof(kc), hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail("hipMemcpy kc", e);
         ALLOC(h->dTables, TB_WORDS * 4);
         std::vector<int> tb(TB_WORDS);
-        fill_tables(cfg->N, tb.data());
+        fill_tables(cfg->N, tb.data(), cfg->qp_precision >= 3 ? 1 : 0);   // the fp32 / bf16 instructions keep a different column per lane
         if ((e = hipMemcpyAsync(h->dTables, tb.data(), TB_WORDS * 4, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail("hipMemcpy tables", e);
         if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
     }
@@ -1066,6 +1106,8 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
                          (const void *)rti_kernel<3, 4, false, 20>, (const void *)rti_kernel<3, 4, true, 20>,
                          (const void *)rti_kernel<3, 4, false, 20, 0, 1, 1>, (const void *)rti_kernel<3, 4, true, 20, 0, 1, 1>, (const void *)rti_kernel<3, 4, false, 20, 0, 1, 2>,
                          (const void *)rti_kernel<5, 1, false, 0, 1>, (const void *)rti_kernel<5, 1, false, 0, 2>,
+                         (const void *)rti_kernel<5, 1, false, 0, 3>, (const void *)rti_kernel<5, 1, false, 0, 4>,
+                         (const void *)rti_kernel<5, 2, false, 40, 3, 2>, (const void *)rti_kernel<5, 2, false, 40, 4, 2>,
                          (const void *)rti_kernel<5, 2, false, 40, 0, 2>, (const void *)rti_kernel<5, 2, false, 40, 0, 2, 1>, (const void *)rti_kernel<5, 2, false, 40, 0, 2, 2>};
     if ((e = hipFuncSetAttribute((const void *)mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(FR_TOTAL * sizeof(float)))) != hipSuccess)
@@ -1171,11 +1213,17 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     const bool q = h->use_queue && !d_dbg;
     int rc = begin_timing(h, s, 0);
     if (rc) return rc;
-    if (h->cfg.qp_precision) {      // precision study (BASELINE config 5): one wave per workgroup, unfused, any horizon
+    if (h->cfg.qp_precision) {      // BASELINE config 5 (unfused; run ndp_downwash first for a force)
         if (fused) { h->err = "qp_precision != 0 supports f / no disturbance only (run ndp_downwash first)"; return -12; }
         const size_t shm1 = (size_t)h->lds_per_wave * sizeof(double);
-        if (h->cfg.qp_precision == 1) hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 1>), dim3(B), dim3(64), shm1, s, ka);
-        else hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 2>), dim3(B), dim3(64), shm1, s, ka);
+        const int pr = h->cfg.qp_precision;
+        if (pr >= 3 && h->cfg.N == 40 && h->cfg.n_rti == 2 && W == 2) {   // config 5's own shape: compile-time horizon, 2 instances per workgroup
+            if (pr == 3) hipLaunchKernelGGL((rti_kernel<5, 2, false, 40, 3, 2>), grid, block, shm, s, ka);
+            else hipLaunchKernelGGL((rti_kernel<5, 2, false, 40, 4, 2>), grid, block, shm, s, ka);
+        } else if (pr == 1) hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 1>), dim3(B), dim3(64), shm1, s, ka);   // any horizon: one wave per workgroup
+        else if (pr == 2) hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 2>), dim3(B), dim3(64), shm1, s, ka);
+        else if (pr == 3) hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 3>), dim3(B), dim3(64), shm1, s, ka);
+        else hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 4>), dim3(B), dim3(64), shm1, s, ka);
         NDP_HIP(h, hipGetLastError());
         return end_timing(h, s);
     }

@@ -152,19 +152,43 @@ template <class W, int NSLOT, int NC = 0, bool HT = false, int NR = 0, int PREC 
 struct RtiWave {
     static NDP_D int horizon(const RtiParams &P) { return NC ? NC : P.N; }
     static constexpr int UNROLL_STAGES = NC > 0 ? NC : 1;
-    static NDP_D typename W::vd4 mma(typename W::vd a, typename W::vd b, const typename W::vd4 &c)
-    {
-        if (PREC == 0) return W::mfma(a, b, c);
-        typename W::vd4 d = W::mfma(W::round_op(a, PREC), W::round_op(b, PREC), c);
-        for (int r = 0; r < 4; ++r) d.r[r] = W::round_op(d.r[r], 1);
-        return d;
-    }
-    static NDP_D int mb(int k) { return k * int(MB_STRIDE); }   // stage offsets (immediates once the stage loops are unrolled)
-    static NDP_D int cb(int k) { return k * int(CB_STRIDE); }
     using vd = typename W::vd;
     using vi = typename W::vi;
     using vb = typename W::vb;
     using vd4 = typename W::vd4;
+    // Matrix values of the Riccati sweeps: what the backend's matrix instruction consumes and produces.  The product backend
+    // has md = double (v_mfma_f64_16x16x4_f64); the BASELINE-config-5 backends have md = float (v_mfma_f32_16x16x4_f32, and the
+    // bf16-input v_mfma_f32_16x16x16_bf16 with fp32 accumulators).  Everything else -- linearisation, the 4x4 inverse, the
+    // interior-point bookkeeping, the LDS image -- stays in double; W::to_m / W::to_d convert at the sweeps' boundary.
+    using md = typename W::md;
+    using md4 = typename W::md4;
+    // one 4-deep contraction step D = A B + C
+    static NDP_D md4 mma(md a, md b, const md4 &c)
+    {
+        if constexpr (W::packed_k) {
+            const md aa[1] = {a}, bb[1] = {b};
+            return W::mfma_k(aa, bb, 1, c);
+        } else if constexpr (PREC == 0) {
+            return W::mfma(a, b, c);
+        } else {
+            md4 d = W::mfma(W::round_op(a, PREC), W::round_op(b, PREC), c);
+            for (int r = 0; r < 4; ++r) d.r[r] = W::round_op(d.r[r], 1);
+            return d;
+        }
+    }
+    // n <= 4 contraction steps on one accumulator: a backend whose instruction contracts 16 deep (bf16) packs them into one
+    template <int n>
+    static NDP_D md4 mman(const md *a, const md *b, const md4 &c)
+    {
+        if constexpr (W::packed_k) return W::mfma_k(a, b, n, c);
+        else {
+            md4 d = c;
+            for (int i = 0; i < n; ++i) d = mma(a[i], b[i], d);
+            return d;
+        }
+    }
+    static NDP_D int mb(int k) { return k * int(MB_STRIDE); }   // stage offsets (immediates once the stage loops are unrolled)
+    static NDP_D int cb(int k) { return k * int(CB_STRIDE); }
     using lp = typename W::lds_ptr;   // pointer into this wave's LDS slice
 
     struct Tables {               // per-lane LDS offsets of stage 0 (doubles); stage k adds k * MB_STRIDE / CB_STRIDE / NX / NU
@@ -237,10 +261,14 @@ struct RtiWave {
     }
 
     // lane-derived predicates and constants of the tables (cheap: a handful of compares)
+    // Lane (g, j): g = lane >> 4 is the lane's row group, j = W::lcol(lane) the matrix column it holds: lane & 15 for the f64
+    // instruction; the f32 / bf16 instructions keep row 4g + r (not g + 4r) in accumulator register r, which becomes the f64
+    // picture again once rows AND columns are renumbered by i -> (i >> 2) + 4 (i & 3) -- so those backends only report a
+    // different j and everything below (tables, predicates, operand chaining) reads the same.
     static NDP_HD void lane_preds(Tables &T)
     {
         vi lane = W::lane();
-        vi g = lane >> 4, j = lane & 15, jc = j & 3;
+        vi g = lane >> 4, j = W::lcol(lane), jc = j & 3;
         T.kt_pred = j >= 12;
         T.lo4 = j < 4;
         T.col0 = j == 0;
@@ -255,7 +283,7 @@ struct RtiWave {
     {
         lane_preds(T);
         vi lane = W::lane();
-        vi g = lane >> 4, j = lane & 15;
+        vi g = lane >> 4, j = W::lcol(lane);
         for (int c = 0; c < 3; ++c) T.mk_off[c] = m_entry(m, g + 4 * c, j);
         for (int r = 0; r < 4; ++r) T.c_off[r] = c_entry(m, g + 4 * r, j);
         for (int c = 0; c < 3; ++c) {
@@ -649,7 +677,9 @@ struct RtiWave {
     }
     static NDP_D vd lam_rdet(const Tables &T, const LamRegs &L, vd cof, bool &ok)
     {
-        vd det = W::quad_sum(L.own * cof);                    // row expansion: lanes 16g..16g+3 form one quad
+        vd det = L.own * cof;                                 // row expansion over the four lanes holding one row of Lam
+        det = det + W::csum1(det);
+        det = det + W::csum2(det);
         vb pd = (det > 0.0) && (!T.lam_diag || (cof > 0.0));
         ok = W::all(pd) && ok;
         return W::rcp(det);
@@ -667,33 +697,32 @@ struct RtiWave {
         const int N = horizon(P);
         bool ok = true;
         vi lane = W::lane();
-        vi g = lane >> 4, j = lane & 15;
+        vi g = lane >> 4, j = W::lcol(lane);
         vb okv = lane >= 0;        // per-lane positive-definiteness flags, reduced once after the sweep
-        vd4 H;
+        md4 H;
         {   // stage N-1 from the terminal block (no control part: keep columns 12..15 exactly zero)
-            vd4 Pt;
-            for (int c = 0; c < 3; ++c) Pt.r[c] = W::sel(j < 12, W::ld(lds, T.c_off[c] + cb(N)), vd(0.0));
-            vd mk[3];
-            for (int c = 0; c < 3; ++c) mk[c] = W::ld(lds, T.mk_off[c] + mb(N - 1));
-            for (int r = 0; r < 4; ++r) H.r[r] = W::ld(lds, T.c_off[r] + cb(N - 1));
-            vd4 Wm = W::zero4();
-            for (int c = 0; c < 3; ++c) Wm = mma(Pt.r[c], mk[c], Wm);
-            for (int c = 0; c < 3; ++c) H = mma(mk[c], Wm.r[c], H);
+            md Pt[3];
+            for (int c = 0; c < 3; ++c) Pt[c] = W::to_m(W::sel(j < 12, W::ld(lds, T.c_off[c] + cb(N)), vd(0.0)));
+            md mk[3];
+            for (int c = 0; c < 3; ++c) mk[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(N - 1)));
+            for (int r = 0; r < 4; ++r) H.r[r] = W::to_m(W::ld(lds, T.c_off[r] + cb(N - 1)));
+            md4 Wm = mman<3>(Pt, mk, W::mzero4());
+            H = mman<3>(mk, Wm.r, H);
         }
-        vd mk[3], cc[4];       // operands of the NEXT stage to be formed (k-1), requested one iteration ahead
+        md mk[3], cc[4];       // operands of the NEXT stage to be formed (k-1), requested one iteration ahead
         {
             const int kn = N > 1 ? N - 2 : 0;
-            for (int c = 0; c < 3; ++c) mk[c] = W::ld(lds, T.mk_off[c] + mb(kn));
-            for (int r = 0; r < 4; ++r) cc[r] = W::ld(lds, T.c_off[r] + cb(kn));
+            for (int c = 0; c < 3; ++c) mk[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(kn)));
+            for (int r = 0; r < 4; ++r) cc[r] = W::to_m(W::ld(lds, T.c_off[r] + cb(kn)));
         }
-        vd4 Ktp = W::zero4();
+        md4 Ktp = W::mzero4();
         int kprev = -1;
         NDP_UNROLL_STAGES
         for (int k = N - 1; k >= 1; --k) {
-            vd nmk[3], ncc[4];
+            md nmk[3], ncc[4];
             const int kp = k >= 2 ? k - 2 : 0;      // prefetch stage k-2; at k = 1 there is none: re-read stage 0 (values unused)
             // Lam[a][b] = H~[12+a][12+b] and H~ux both sit in accumulator register 3
-            vd hux = H.r[3];
+            md hux = H.r[3];
             // [H~xx ; H~ux] M~_{k-1}: H~'s registers as A operand mean H~' -- equal up to rounding (see the
             // re-symmetrisation below); rows 12..15 of the result are T = H~ux M~_{k-1}
             //   M~'' H~xu = (H~ux M~')' = T', hence  H~' = [C~' + M~'' (H~xx M~')] - T' Lam^-1 T:
@@ -705,29 +734,29 @@ struct RtiWave {
             // prefetch of stage k-2, between its levels.  Measured: worth ~1 % of the sweep -- what counts is the number of
             // instructions and of chain levels (dropping the second Newton step of 1/det saved 5 %), not their order.
             LamRegs LR;
-            lam_gather(T, lds, hux, LR);
+            lam_gather(T, lds, W::to_d(hux), LR);
             W::pin();
-            vd4 Wf = W::zero4();
-            for (int c = 0; c < 3; ++c) Wf = mma(H.r[c], mk[c], Wf);
+            md4 Wf = mman<3>(H.r, mk, W::mzero4());
             W::pin();
             if (kprev >= 0)
-                for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), Ktp.r[c]);
+                for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), W::to_d(Ktp.r[c]));
             W::pin();
             const vd *mm = LR.mm;
             vd p0 = mm[4] * mm[8], p1 = mm[3] * mm[8], p2 = mm[3] * mm[7];
             vd os = LR.own * T.cof_sign;
             W::pin();
-            vd4 Hb;
+            md4 Hb;
             for (int r = 0; r < 4; ++r) Hb.r[r] = cc[r];
-            Hb = mma(mk[0], Wf.r[0], Hb);
+            if constexpr (!W::packed_k) Hb = mma(mk[0], Wf.r[0], Hb);
             W::pin();
             vd d0 = p0 - mm[5] * mm[7], d1 = p1 - mm[5] * mm[6], d2 = p2 - mm[4] * mm[6];
             W::pin();
-            Hb = mma(mk[1], Wf.r[1], Hb);
+            if constexpr (!W::packed_k) Hb = mma(mk[1], Wf.r[1], Hb);
             W::pin();
             vd cx = mm[0] * d0, cy = mm[1] * d1;
             W::pin();
-            Hb = mma(mk[2], Wf.r[2], Hb);
+            if constexpr (W::packed_k) Hb = mman<3>(mk, Wf.r, Hb);
+            else Hb = mma(mk[2], Wf.r[2], Hb);
             W::pin();
             vd cz = cx + mm[2] * d2;
             vd oy = os * cy;
@@ -737,89 +766,87 @@ struct RtiWave {
             vd dq = os * cz - oy;
             vd cofu = cz - cy;
             W::pin();
-            dq = dq + W::quad_swap1(dq);                      // lanes 16g..16g+3 form one quad
+            dq = dq + W::csum1(dq);                           // the four lanes holding one row of Lam (a quad in the f64 layout)
             vd ladj = cofu * T.adj_a;                         // A operand: adj(Lam)[g][j], j < 4 (sign and lane mask in one factor)
             vd nahi = cofu * T.adj_b;                         // B operand of K~': -adj[g][j-12] in columns 12..15
             W::pin();
-            vd tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
-            vd4 G = mma(ladj, tt, W::zero4());            // adj T
+            md tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
+            md4 G = mma(W::to_m(ladj), tt, W::mzero4());      // adj T
             W::pin();
-            vd det = dq + W::quad_swap2(dq);
+            vd det = dq + W::csum2(dq);
             vd r0 = W::rcp_seed(det);
-            for (int c = 0; c < 3; ++c) nmk[c] = W::ld(lds, T.mk_off[c] + mb(kp));
+            for (int c = 0; c < 3; ++c) nmk[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(kp)));
             W::pin();
             // 1/det = r0 (2 - det r0): v_rcp_f64 seed (4.5e-8) + ONE Newton step = 2.2e-15 (profiles/r01_ubench_mfma_latency.txt),
             // below the cofactors' own cond * eps.  The scale of Lam^-1 T is applied as (G r0) e0 so that G r0 runs beside e0.
             vd e0 = W::fma(-det, r0, vd(2.0));
-            vd g0 = G.r[0] * r0;
-            for (int r = 0; r < 2; ++r) ncc[r] = W::ld(lds, T.c_off[r] + cb(kp));
+            vd g0 = W::to_d(G.r[0]) * r0;
+            for (int r = 0; r < 2; ++r) ncc[r] = W::to_m(W::ld(lds, T.c_off[r] + cb(kp)));
             W::pin();
             vd gs = g0 * e0;                                  // Lam^-1 T
             vd rdet = r0 * e0;
-            for (int r = 2; r < 4; ++r) ncc[r] = W::ld(lds, T.c_off[r] + cb(kp));
+            for (int r = 2; r < 4; ++r) ncc[r] = W::to_m(W::ld(lds, T.c_off[r] + cb(kp)));
             okv = okv && (det > 0.0) && (!T.lam_diag || (cofu > 0.0));   // on the diagonal the cofactor's sign factor is +1
             W::pin();
-            vd4 Hn = mma(-tt, gs, Hb);                    // - T' Lam^-1 T on top of the bracket
+            md4 Hn = mma(-tt, W::to_m(gs), Hb);               // - T' Lam^-1 T on top of the bracket
             // K~' = H~ux' (-Lam^-1): the 1/det rides in the B operand (one multiply instead of one per result register); lands in
             // column 12+b = rows 12..15 of the forward operand; stored behind the next stage's first MFMAs
-            vd4 Kt = mma(hux, nahi * rdet, W::zero4());
+            md4 Kt = mma(hux, W::to_m(nahi * rdet), W::mzero4());
             Ktp = Kt; kprev = k;
             if ((k & 7) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
                 // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
                 // re-symmetrise every 8th stage (growth x550 in between: 1e-16 -> 5e-14).  H~' = (H~ as A operand) x I costs four MFMAs, no LDS.
-                vd4 Tp = W::zero4();
-                for (int c = 0; c < 4; ++c) Tp = mma(Hn.r[c], T.eye[c], Tp);
-                for (int r = 0; r < 4; ++r) Hn.r[r] = (Hn.r[r] + Tp.r[r]) * 0.5;
+                md ey[4];
+                for (int c = 0; c < 4; ++c) ey[c] = W::to_m(T.eye[c]);
+                md4 Tp = mman<4>(Hn.r, ey, W::mzero4());
+                for (int r = 0; r < 4; ++r) Hn.r[r] = W::mavg(Hn.r[r], Tp.r[r]);
             }
             H = Hn;
             for (int c = 0; c < 3; ++c) mk[c] = nmk[c];
             for (int r = 0; r < 4; ++r) cc[r] = ncc[r];
         }
         if (kprev >= 0)
-            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), Ktp.r[c]);
+            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), W::to_d(Ktp.r[c]));
         {   // stage 0: only the gain is needed
-            vd hux = H.r[3];
+            md hux = H.r[3];
             LamRegs LR;
-            lam_gather(T, lds, hux, LR);
+            lam_gather(T, lds, W::to_d(hux), LR);
             vd cof = lam_cofactor(T, LR);
             vd rdet = lam_rdet(T, LR, cof, ok);
             vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));
-            vd4 Kt = mma(hux, nahi, W::zero4());
-            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c], Kt.r[c] * rdet);
+            md4 Kt = mma(hux, W::to_m(nahi), W::mzero4());
+            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c], W::to_d(Kt.r[c]) * rdet);
         }
         ok = W::all(okv) && ok;
         W::sync();
         if (io) stamp(*io, m, 6);
         // forward rollout; z~ index 4c+g lives in chunk c of the lanes with j == 0
-        vd zc[3];
+        md zc[3];
         for (int c = 0; c < 3; ++c) {
             vi idx = g + 4 * c;
             vd v = W::ldp(lds, idx + m.ZX, T.col0 && (idx < 10));
-            zc[c] = W::sel(T.col0 && (idx == 10), vd(1.0), v);
+            zc[c] = W::to_m(W::sel(T.col0 && (idx == 10), vd(1.0), v));
         }
         // per stage: Y = [M~x ; K~] z~ (3 MFMAs) holds M~x z~ in rows 0..11 and du = K~ z~ in rows 12..15, i.e. du is
         // accumulator register 3 -- exactly the B operand of the 4th MFMA, which adds B~ du to rows 0..11.
-        vd fw[3], mu;
-        for (int c = 0; c < 3; ++c) fw[c] = W::ld(lds, T.fw_off[c]);
-        mu = W::ld(lds, T.mu_off);
+        md fw[3], mu;
+        for (int c = 0; c < 3; ++c) fw[c] = W::to_m(W::ld(lds, T.fw_off[c]));
+        mu = W::to_m(W::ld(lds, T.mu_off));
         NDP_UNROLL_STAGES
         for (int k = 0; k < N; ++k) {
-            vd nfw[3], nmu;
+            md nfw[3], nmu;
             const int kn = k + 1 < N ? k + 1 : k;
-            for (int c = 0; c < 3; ++c) nfw[c] = W::ld(lds, T.fw_off[c] + mb(kn));
-            nmu = W::ld(lds, T.mu_off + mb(kn));
+            for (int c = 0; c < 3; ++c) nfw[c] = W::to_m(W::ld(lds, T.fw_off[c] + mb(kn)));
+            nmu = W::to_m(W::ld(lds, T.mu_off + mb(kn)));
             W::pin();   // keep the prefetch ahead of this stage's MFMAs (the scheduler otherwise sinks it behind them)
-            vd4 Y = W::zero4();
-            Y = mma(fw[0], zc[0], Y);
-            Y = mma(fw[1], zc[1], Y);
-            Y = mma(fw[2], zc[2], Y);
-            vd du = Y.r[3];
-            vd4 xn = mma(mu, du, Y);
-            W::st(lds, T.zu_st + k * int(NU), du);
+            md4 Y = mman<3>(fw, zc, W::mzero4());
+            md du = Y.r[3];
+            md4 xn = mma(mu, du, Y);
+            W::st(lds, T.zu_st + k * int(NU), W::to_d(du));
             for (int c = 0; c < 3; ++c) {
                 zc[c] = xn.r[c];
-                W::st(lds, T.zx_st[c] + (k + 1) * int(NX), xn.r[c]);
+                W::st(lds, T.zx_st[c] + (k + 1) * int(NX), W::to_d(xn.r[c]));
             }
             for (int c = 0; c < 3; ++c) fw[c] = nfw[c];
             mu = nmu;
@@ -1173,20 +1200,26 @@ struct LaneW {
     using vi = int;
     using vb = bool;
     struct vd4 { double r[4]; };
+    using md = double;
+    using md4 = vd4;
+    static constexpr bool packed_k = false;
     using lds_ptr = double *;
     // host-only on purpose (no device attribute): only fill_tables, a host function, instantiates code that calls them
     static int &cur() { static thread_local int l = 0; return l; }
+    static int &layout() { static thread_local int l = 0; return l; }   // 0: f64 instruction, 1: f32 / bf16 instructions (see lane_preds)
     static vi lane() { return cur(); }
+    static vi lcol(vi lane) { const int jt = lane & 15; return layout() ? (jt >> 2) + 4 * (jt & 3) : jt; }
     static vd sel(vb p, vd a, vd b) { return p ? a : b; }
     static vi sel(vb p, vi a, vi b) { return p ? a : b; }
 };
 
 enum { TB_WORDS = 36 * 64 };
 
-inline void fill_tables(int N, int *out /* [TB_WORDS] */)
+inline void fill_tables(int N, int *out /* [TB_WORDS] */, int layout = 0)
 {
     using Prog = RtiWave<LaneW, 1>;
     const LdsMap m = make_map(N);
+    LaneW::layout() = layout;
     for (int i = 0; i < TB_WORDS; ++i) out[i] = 0;
     for (int lane = 0; lane < 64; ++lane) {
         LaneW::cur() = lane;

@@ -15,6 +15,15 @@ struct WaveGfx950 {
     using vi = int;
     using vb = bool;
     struct vd4 { double r[4]; };
+    // matrix values of the Riccati sweeps (RtiWave::md): this backend's instruction is v_mfma_f64_16x16x4_f64
+    using md = double;
+    using md4 = vd4;
+    static constexpr bool packed_k = false;
+    static NDP_D md to_m(vd a) { return a; }
+    static NDP_D vd to_d(md a) { return a; }
+    static NDP_D md4 mzero4() { return zero4(); }
+    static NDP_D md mavg(md a, md b) { return (a + b) * 0.5; }
+    static NDP_D vi lcol(vi lane) { return lane & 15; }        // the matrix column a lane holds (RtiWave::lane_preds)
     typedef __attribute__((address_space(3))) double *lds_ptr;
     typedef double d4_t __attribute__((ext_vector_type(4)));
 
@@ -77,6 +86,9 @@ struct WaveGfx950 {
     static NDP_D vd fma(vd a, vd b, vd c) { return __builtin_fma(a, b, c); }
     static NDP_D vd quad_swap1(vd a) { return dpp_quad<0xB1>(a); }   // lane ^ 1
     static NDP_D vd quad_swap2(vd a) { return dpp_quad<0x4E>(a); }   // lane ^ 2
+    // x + csum1(x), then + csum2 of that: the sum over the four lanes (same g) that hold columns 4q..4q+3 of one matrix row
+    static NDP_D vd csum1(vd a) { return dpp_quad<0xB1>(a); }
+    static NDP_D vd csum2(vd a) { return dpp_quad<0x4E>(a); }
     // sum over the 4 lanes of each aligned quad, result in all 4 (DPP quad_perm, no LDS)
     static NDP_D vd quad_sum(vd a)
     {
@@ -143,6 +155,62 @@ struct WaveGfx950 {
         d4_t acc = {c.r[0], c.r[1], c.r[2], c.r[3]};
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         vd4 d;
+        d.r[0] = acc[0]; d.r[1] = acc[1]; d.r[2] = acc[2]; d.r[3] = acc[3];
+        return d;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BASELINE config 5 ("fp32 vs bf16 MFMA on the QP"): the same wave program with the Riccati sweeps on the fp32 matrix
+// instruction.  v_mfma_f32_16x16x4_f32: A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15] like the f64 form, but accumulator
+// register r of lane l holds D[4 (l>>4) + r][l&15] (f64: D[(l>>4) + 4r][l&15]).  Renumbering rows and columns by
+// i -> (i >> 2) + 4 (i & 3) turns that into the f64 picture (register r <-> rows g + 4r, contraction step c <-> indices
+// 4c..4c+3), so the program only has to be told which column a lane holds (lcol) and how to sum over a matrix row's four
+// lanes (stride 4 inside the 16-lane row: DPP row_ror 4 and 8 instead of the quad swaps).  Everything outside the sweeps
+// stays fp64; operands are converted on the way in and out.
+struct WaveGfx950F32 : WaveGfx950 {
+    using md = float;
+    struct md4 { float r[4]; };
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    static constexpr bool packed_k = false;
+    static NDP_D md to_m(vd a) { return (float)a; }
+    static NDP_D vd to_d(md a) { return (double)a; }
+    static NDP_D md4 mzero4() { md4 z; z.r[0] = z.r[1] = z.r[2] = z.r[3] = 0.0f; return z; }
+    static NDP_D md mavg(md a, md b) { return (a + b) * 0.5f; }
+    static NDP_D vi lcol(vi lane) { const int jt = lane & 15; return (jt >> 2) + 4 * (jt & 3); }
+    static NDP_D vd csum1(vd a) { return dpp_quad<0x124>(a); }   // row_ror:4
+    static NDP_D vd csum2(vd a) { return dpp_quad<0x128>(a); }   // row_ror:8
+    static NDP_D md4 mfma(md a, md b, const md4 &c)
+    {
+        f4_t acc = {c.r[0], c.r[1], c.r[2], c.r[3]};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        md4 d;
+        d.r[0] = acc[0]; d.r[1] = acc[1]; d.r[2] = acc[2]; d.r[3] = acc[3];
+        return d;
+    }
+};
+
+// ... and on the bf16-input instruction with fp32 accumulators, v_mfma_f32_16x16x16_bf16: lane l supplies four bf16 values
+// A[l&15][4 (l>>4) + i] / B[4 (l>>4) + i][l&15], i = 0..3 -- under the renumbering above element i is exactly the operand of
+// contraction step i of the fp32 form, so up to four steps on one accumulator become ONE instruction (packed_k).
+struct WaveGfx950BF16 : WaveGfx950F32 {
+    typedef short s4_t __attribute__((ext_vector_type(4)));
+    static constexpr bool packed_k = true;
+    static NDP_D short bf16_bits(float f)
+    {
+        unsigned u = __float_as_uint(f);
+        u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;          // round to nearest even (finite inputs)
+        return (short)u;
+    }
+    static NDP_D md4 mfma_k(const md *a, const md *b, int n, const md4 &c)
+    {
+        s4_t av = {0, 0, 0, 0}, bv = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n) { av[i] = bf16_bits(a[i]); bv[i] = bf16_bits(b[i]); }
+        f4_t acc = {c.r[0], c.r[1], c.r[2], c.r[3]};
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc, 0, 0, 0);
+        md4 d;
         d.r[0] = acc[0]; d.r[1] = acc[1]; d.r[2] = acc[2]; d.r[3] = acc[3];
         return d;
     }

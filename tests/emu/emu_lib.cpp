@@ -26,12 +26,14 @@ int emu_rti_step(const ndp_cfg *cfg, const double *x0, const double *xr, const d
     ndp::fill_kc(P, kc);
     ndp::RtiIo io{x0, xr, ur, f, X, U, u0, status, iters, lds_dump, 0, kc};
     std::vector<int> tb(ndp::TB_WORDS);
-    ndp::fill_tables(P.N, tb.data());
+    ndp::fill_tables(P.N, tb.data(), cfg->qp_precision >= 3 ? 1 : 0);
     io.tables = tb.data();
     const int ns = ndp::slots_for(P.N);
     // horizon 20 and the 5-slot form run as the product does (host-built tables; N = 20 also compile-time horizon);
     // the other horizons build the tables in the wave program
-    if (cfg->qp_precision == 1) ndp::RtiWave<emu::Wave, 5, 0, true, 0, 1>::run(P, io, lds.data());
+    if (cfg->qp_precision == 3) ndp::RtiWave<emu::Wave32, 5, 0, true>::run(P, io, lds.data());          // the real fp32 / bf16 backends' layout
+    else if (cfg->qp_precision == 4) ndp::RtiWave<emu::WaveBF16, 5, 0, true>::run(P, io, lds.data());
+    else if (cfg->qp_precision == 1) ndp::RtiWave<emu::Wave, 5, 0, true, 0, 1>::run(P, io, lds.data());
     else if (cfg->qp_precision == 2) ndp::RtiWave<emu::Wave, 5, 0, true, 0, 2>::run(P, io, lds.data());
     else if (P.N == 20 && P.n_rti == 1) ndp::RtiWave<emu::Wave, 3, 20, true, 1>::run(P, io, lds.data());
     else if (ns <= 3) ndp::RtiWave<emu::Wave, 3>::run(P, io, lds.data());

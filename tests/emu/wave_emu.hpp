@@ -70,6 +70,17 @@ struct Wave {
     using vb = emu::vb;
     using vd4 = emu::vd4;
     using lds_ptr = double *;
+    // matrix values of the Riccati sweeps (RtiWave::md): the f64 instruction
+    using md = emu::vd;
+    using md4 = emu::vd4;
+    static constexpr bool packed_k = false;
+    static vd to_m(const vd &a) { return a; }
+    static vd to_d(const vd &a) { return a; }
+    static vd4 mzero4() { return zero4(); }
+    static vd mavg(const vd &a, const vd &b) { return (a + b) * 0.5; }
+    static vi lcol(const vi &lane) { return lane & 15; }
+    static vd csum1(const vd &a) { return quad_swap1(a); }
+    static vd csum2(const vd &a) { return quad_swap2(a); }
 
     static int &lds_limit() { static thread_local int n = 0; return n; }
     static void chk(int i) { if (i < 0 || i >= lds_limit()) __builtin_trap(); }
@@ -158,6 +169,60 @@ struct Wave {
                 double acc = c.r[r].v[l];
                 for (int k = 0; k < 4; ++k) acc = std::fma(a.v[row + 16 * k], b.v[col + 16 * k], acc);
                 d.r[r].v[l] = acc;
+            }
+        return d;
+    }
+};
+
+// The fp32 / bf16 backends of BASELINE config 5 (wave_gfx950.hpp: WaveGfx950F32, WaveGfx950BF16) emulated: matrix values are
+// floats carried in doubles, accumulator register r of lane l holds D[4 (l>>4) + r][l&15], every product-accumulate step is
+// one fmaf (v_mfma_f32_16x16x4_f32 is bitwise an fmaf chain), the row sums run over lanes 4 apart.
+inline float f32(double x) { return (float)x; }
+inline float bf16r(float f)
+{
+    unsigned u; std::memcpy(&u, &f, 4);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+struct Wave32 : Wave {
+    static constexpr bool packed_k = false;
+    static vd to_m(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)f32(a.v[l]); return o; }
+    static vd mavg(const vd &a, const vd &b) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)((f32(a.v[l]) + f32(b.v[l])) * 0.5f); return o; }
+    static vi lcol(const vi &lane) { vi o; for (int l = 0; l < 64; ++l) { const int jt = lane.v[l] & 15; o.v[l] = (jt >> 2) + 4 * (jt & 3); } return o; }
+    static vd csum1(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[(l & 48) | ((l + 12) & 15)]; return o; }   // row_ror:4
+    static vd csum2(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[(l & 48) | ((l + 8) & 15)]; return o; }    // row_ror:8
+    static vd4 mfma(const vd &a, const vd &b, const vd4 &c)
+    {
+        stats().mfma++;
+        vd4 d;
+        for (int r = 0; r < 4; ++r)
+            for (int l = 0; l < 64; ++l) {
+                const int row = 4 * (l >> 4) + r, col = l & 15;
+                float acc = f32(c.r[r].v[l]);
+                for (int k = 0; k < 4; ++k) acc = std::fmaf(f32(a.v[row + 16 * k]), f32(b.v[col + 16 * k]), acc);
+                d.r[r].v[l] = (double)acc;
+            }
+        return d;
+    }
+};
+
+struct WaveBF16 : Wave32 {
+    static constexpr bool packed_k = true;
+    // up to four contraction steps in one instruction: bf16 operands, products exact in fp32, fp32 accumulation
+    static vd4 mfma_k(const vd *a, const vd *b, int n, const vd4 &c)
+    {
+        stats().mfma++;
+        vd4 d;
+        for (int r = 0; r < 4; ++r)
+            for (int l = 0; l < 64; ++l) {
+                const int row = 4 * (l >> 4) + r, col = l & 15;
+                float acc = f32(c.r[r].v[l]);
+                for (int i = 0; i < n; ++i)
+                    for (int k = 0; k < 4; ++k)
+                        acc = std::fmaf(bf16r(f32(a[i].v[row + 16 * k])), bf16r(f32(b[i].v[col + 16 * k])), acc);
+                d.r[r].v[l] = (double)acc;
             }
         return d;
     }
