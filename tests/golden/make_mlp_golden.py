@@ -53,5 +53,21 @@ with torch.no_grad():
         inp = (other[c] - ego[c])[:, 0:6]
         f_update[c] = net(torch.from_numpy(inp).to(torch.float32)).numpy()
 
-np.savez_compressed(os.path.join(HERE, "mlp_golden.npz"), z=z, f=f, other=other, ego=ego, f_update=f_update)
+# inputs at 10x and 100x the training envelope (|dxy| <= 15 / 150 m, |dv| <= 30 / 300 m/s): large hidden activations, where
+# the device's fp16 pair splitting has to stay relative-accurate (and far from its 65000 activation cap)
+zb = {}
+for scale in (10, 100):
+    rb = np.random.Generator(np.random.PCG64(20231213 + scale))
+    zz = (np.concatenate([rb.uniform(-1.5, 1.5, (252, 3)), rb.uniform(-3, 3, (252, 3))], axis=1) * scale).astype(np.float32)
+    with torch.no_grad():
+        zb[f"z_x{scale}"], zb[f"f_x{scale}"] = zz, net(torch.from_numpy(zz)).numpy()
+        acts = [zz]
+        h = torch.from_numpy(zz)
+        for layer in net:
+            h = layer(h)
+            acts.append(h.numpy())
+    zb[f"hmax_x{scale}"] = np.array([np.abs(a).max() for a in acts], dtype=np.float32)
+
+np.savez_compressed(os.path.join(HERE, "mlp_golden.npz"), z=z, f=f, other=other, ego=ego, f_update=f_update, **zb)
+print("largest activation per layer at x10 / x100:", zb["hmax_x10"], zb["hmax_x100"])
 print("blob", blob.size, "golden rows", z.shape[0], "kat f:\n", f[:5])

@@ -133,6 +133,23 @@ def test_downwash_mlp_against_reference_fixture(ndp, mlp_golden):
     assert np.all(np.abs(f2 - fz) <= 1e-5 * np.maximum(1.0, np.abs(fz)))
 
 
+@pytest.mark.parametrize("scale", [10, 100])
+def test_downwash_mlp_far_outside_the_training_envelope(ndp, mlp_golden, scale):
+    """Inputs at 10x and 100x the training envelope (reference-network goldens, hidden activations up to ~60 / ~660, still
+    two orders below the device's fp16 activation cap of 65000): the fp16 pair splitting of layers 2-3 is relative-accurate,
+    so the 1e-5 bar holds with the same margin as inside the envelope -- the bound is not an accident of small activations."""
+    z, want = mlp_golden[f"z_x{scale}"], mlp_golden[f"f_x{scale}"]
+    rows = z.shape[0]
+    Bz = rows // 21
+    assert Bz * 21 == rows and float(mlp_golden[f"hmax_x{scale}"].max()) < 6500.0
+    o2 = np.zeros((Bz, 21, 10))
+    o2[:, :, 0:6] = z.reshape(Bz, 21, 6)
+    f = ndp.BatchedNMPC(Bz, disturbance=True).downwash(o2, np.zeros((Bz, 21, 10))).reshape(-1, 3)
+    err = np.abs(f - want) / np.maximum(1.0, np.abs(want))
+    assert err.max() <= 1e-5, err.max()
+    assert err.max() <= 6e-6              # measured 3.7e-6 inside the envelope; the same headroom far outside it
+
+
 def test_fused_downwash_step_and_gate(ndp, oracle, mlp_blob):
     """update with neighbour windows: gate (ego odometry xy, strict <) + MLP + NDP solve, all on the device."""
     B = 128

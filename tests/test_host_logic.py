@@ -200,3 +200,94 @@ def test_formation_shards_are_mutually_consistent():
         assert np.array_equal(shards[r]["ego_xy"], shards[r]["x0"][:, 0:2])
     frac = np.mean([((s["other"][:, 0, 0:2] - s["ego_xy"]) ** 2).sum(axis=1) < 1.0 for s in shards])
     assert 0.1 < frac < 0.9
+
+
+# ------------------------------------------------------------------------------------------- BASELINE config 4 (three-vehicle formations)
+def test_config4_placements_are_consistent():
+    """Every placement / world size hands each leader the window of vehicle 1 of ITS formation and no neighbour to the
+    followers: what the all-gathered [W * B_local, N+1, 6] buffer (vehicle-major) or the local xr (formation-major) holds
+    at other_index is the position/velocity part of the neighbour's reference window."""
+    from ndp_nmpc_qd_amd import dist as ndist
+    F = 40
+    allv = ndist.make_config4_all(F)
+    for W in (1, 2, 4, 8):
+        for placement in ("vehicle", "formation"):
+            shards = [ndist.make_config4_shard(r, W, F, placement) for r in range(W)]
+            assert sorted(np.concatenate([s["gids"] for s in shards]).tolist()) == list(range(3 * F))
+            gathered = np.concatenate([s["xr"][:, :, :ndist.PV_COLS] for s in shards])
+            for r, s in enumerate(shards):
+                lead = s["gids"] % 3 == 0
+                assert (s["other_index"][~lead] == -1).all() and (s["other_index"][lead] >= 0).all()
+                buf = gathered if placement == "vehicle" else s["xr"][:, :, :ndist.PV_COLS]
+                assert np.array_equal(buf[s["other_index"][lead]], allv["xr"][s["gids"][lead] + 1][:, :, :ndist.PV_COLS])
+                if placement == "vehicle" and W > 1:      # the neighbour really lives on another rank
+                    assert ((s["other_index"][lead] // (3 * F // W)) != r).all()
+    with pytest.raises(ValueError):
+        ndist.config4_gids(0, 7, F, "vehicle")
+    d2 = ((allv["xr"][1::3, 0, 0:2] - allv["ego_xy"][0::3]) ** 2).sum(axis=1)
+    assert 0.25 < (d2 < 1.0).mean() < 0.55                # a sensible share of the leaders inside the r_horiz gate
+
+
+def _worker_cfg4(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from ndp_nmpc_qd_amd import dist as ndist
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        F, N = 8, 20
+        sh = ndist.make_config4_shard(rank, world, F, "vehicle", N=N)
+        B = sh["xr"].shape[0]
+        xr = torch.from_numpy(sh["xr"])
+        pv = torch.empty(B, N + 1, ndist.PV_COLS, dtype=torch.float64)
+        gathered = torch.empty(world * B, N + 1, ndist.PV_COLS, dtype=torch.float64)
+        work = ndist.exchange_pv_begin(xr, pv, gathered)          # ONE all-gather of the position/velocity columns
+        ndist.exchange_pv_end(work)
+        g = gathered.numpy()
+        idx = sh["other_index"]
+        allv = ndist.make_config4_all(F, N=N)
+        lead = sh["gids"] % 3 == 0
+        ok = np.array_equal(g[idx[lead]], allv["xr"][sh["gids"][lead] + 1][:, :, :ndist.PV_COLS])
+        ok = ok and (idx[~lead] == -1).all()
+        # the step each rank would run on its shard, on the CPU oracle: leaders = NDP controller reading the gathered window
+        # of vehicle 1, followers = the same model with no force.  The result must equal the single-process solution of the
+        # whole formation set (parity semantics of SURVEY 8e), bit for bit: the exchange delivers exact copies.
+        blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
+        other = np.zeros((B, N + 1, 10))
+        other[lead, :, :ndist.PV_COLS] = g[idx[lead]]
+        ego = sh["ego_xy"].copy()
+        ego[~lead] = 1e9
+        f = O.downwash_batch(blob, other, sh["xr"], ego)
+        cfg = O.default_cfg(N=N, use_fd=True)
+        X, U = sh["xr"].copy(), sh["ur"].copy()
+        u_loc, st, _ = O.step_batch(cfg, sh["x0"], sh["xr"], sh["ur"], f, X, U, nthreads=1)
+        oth_all = allv["xr"][np.where(np.arange(3 * F) % 3 == 0, np.arange(3 * F) + 1, np.arange(3 * F))]
+        ego_all = allv["ego_xy"].copy()
+        ego_all[np.arange(3 * F) % 3 != 0] = 1e9
+        f_all = O.downwash_batch(blob, oth_all, allv["xr"], ego_all)
+        Xa, Ua = allv["xr"].copy(), allv["ur"].copy()
+        u_all, *_ = O.step_batch(cfg, allv["x0"], allv["xr"], allv["ur"], f_all, Xa, Ua, nthreads=1)
+        ok = ok and np.array_equal(u_loc, u_all[sh["gids"]]) and (st == 0).all()
+        ok = ok and np.all(f[~lead] == 0) and (not lead.any() or (np.abs(f[lead]).max(axis=(1, 2)) > 0).any())
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_exchange_world_size_3():
+    """Three ranks, vehicle-major placement of 8 three-vehicle formations: every formation's vehicles sit on three different
+    ranks; one all-gather of the [B_local, N+1, 6] columns, then each rank's NDP / NMPC steps (CPU oracle) reproduce the
+    single-process solution."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_cfg4, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == [0, 1, 2] and all(r[1] for r in res)
