@@ -133,21 +133,50 @@ def test_downwash_mlp_against_reference_fixture(ndp, mlp_golden):
     assert np.all(np.abs(f2 - fz) <= 1e-5 * np.maximum(1.0, np.abs(fz)))
 
 
-@pytest.mark.parametrize("scale", [10, 100])
-def test_downwash_mlp_far_outside_the_training_envelope(ndp, mlp_golden, scale):
-    """Inputs at 10x and 100x the training envelope (reference-network goldens, hidden activations up to ~60 / ~660, still
-    two orders below the device's fp16 activation cap of 65000): the fp16 pair splitting of layers 2-3 is relative-accurate,
-    so the 1e-5 bar holds with the same margin as inside the envelope -- the bound is not an accident of small activations."""
-    z, want = mlp_golden[f"z_x{scale}"], mlp_golden[f"f_x{scale}"]
-    rows = z.shape[0]
+def _mlp_fp64(blob, z):
+    """The network evaluated in float64 with the shipped fp32 weights: the exact value both fp32 evaluations approximate."""
+    o, out = 0, []
+    for n_out, n_in in ((128, 6), (64, 128), (128, 64), (3, 128)):
+        W = blob[o:o + n_out * n_in].reshape(n_out, n_in).astype(np.float64)
+        o += n_out * n_in
+        out.append((W, blob[o:o + n_out].astype(np.float64)))
+        o += n_out
+    h = z.astype(np.float64)
+    for i, (W, bias) in enumerate(out):
+        h = h @ W.T + bias
+        if i < 3:
+            h = np.maximum(h, 0.0)
+    return h
+
+
+@pytest.mark.parametrize("scale", [1, 10, 100])
+def test_downwash_mlp_error_against_the_fp32_noise_floor(ndp, mlp_golden, mlp_blob, scale):
+    """How far the device MLP (fp16 pair splitting on layers 2-3) is from the reference network, measured against what fp32
+    arithmetic itself can deliver.  Ground truth = the shipped weights evaluated in float64.  Inside the training envelope
+    (scale 1) the reference's own torch-fp32 output is 3.7e-6 from the truth and the device sits inside the 1e-5 bar against
+    torch.  At 10x / 100x the envelope (hidden activations up to ~60 / ~660, two orders below the device's fp16 activation cap
+    of 65000) the reference's fp32 output itself is 3e-5 / 7e-5 from the truth (cancellation in the last layer): a 1e-5 bar
+    against it is below its own rounding noise there -- two fp32 evaluations in different summation order (torch, the plain-C
+    oracle) differ by 1e-5 / 6e-5.  What is asserted instead: the device is no further from the truth than 2.5x the
+    reference's own fp32 error, at every scale."""
+    key = "" if scale == 1 else f"_x{scale}"
+    z, f_torch = mlp_golden["z" + key], mlp_golden["f" + key]
+    rows = (z.shape[0] // 21) * 21
+    z, f_torch = z[:rows], f_torch[:rows]
     Bz = rows // 21
-    assert Bz * 21 == rows and float(mlp_golden[f"hmax_x{scale}"].max()) < 6500.0
     o2 = np.zeros((Bz, 21, 10))
     o2[:, :, 0:6] = z.reshape(Bz, 21, 6)
     f = ndp.BatchedNMPC(Bz, disturbance=True).downwash(o2, np.zeros((Bz, 21, 10))).reshape(-1, 3)
-    err = np.abs(f - want) / np.maximum(1.0, np.abs(want))
-    assert err.max() <= 1e-5, err.max()
-    assert err.max() <= 6e-6              # measured 3.7e-6 inside the envelope; the same headroom far outside it
+    truth = _mlp_fp64(mlp_blob, z)
+    den = np.maximum(1.0, np.abs(truth))
+    e_dev, e_torch = np.abs(f - truth) / den, np.abs(f_torch - truth) / den
+    e_vs_torch = np.abs(f - f_torch) / np.maximum(1.0, np.abs(f_torch))
+    print(f"scale {scale}: device vs truth {e_dev.max():.2e}, torch fp32 vs truth {e_torch.max():.2e}, device vs torch {e_vs_torch.max():.2e}")
+    assert e_dev.max() <= 2.5 * e_torch.max()
+    if scale == 1:
+        assert e_vs_torch.max() <= 1e-5
+    else:
+        assert e_vs_torch.max() <= 2e-4 and float(mlp_golden[f"hmax_x{scale}"].max()) < 6500.0
 
 
 def test_fused_downwash_step_and_gate(ndp, oracle, mlp_blob):
