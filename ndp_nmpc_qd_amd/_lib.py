@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libndp_nmpc_hip.so")
+# NDP_NMPC_LIB: kernel-development override (a library built with other flags, see scripts/dev_kernel.sh); unset in normal use
+LIB_PATH = os.environ.get("NDP_NMPC_LIB") or os.path.join(_HERE, "libndp_nmpc_hip.so")
 WEIGHTS_PATH = os.path.join(_HERE, "weights", "downwash_sn4.bin")
 
 NX, NU = 10, 4

@@ -276,13 +276,16 @@ struct Split2 { h16x8 hi, lo; };
 // x - hi is exact in fp32 and lo = fp16(residual * 2^11).  Relative error of the pair 2^-22.
 __device__ __forceinline__ void split2(const f16_t &v, int s, Split2 &o)
 {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = v[8 * s + j];
-        const _Float16 h = (_Float16)x;
-        const float r = x - (float)h;
-        o.hi[j] = h;
-        o.lo[j] = (_Float16)(r * NDP_LO_SCALE);
+    for (int j = 0; j < 8; j += 2) {            // two registers at a time: packed f32 subtract / multiply, packed conversions
+        const f2_t x = {v[8 * s + j], v[8 * s + j + 1]};
+        const h2_t hh = __builtin_convertvector(x, h2_t);
+        const f2_t r = (x - __builtin_convertvector(hh, f2_t)) * NDP_LO_SCALE;
+        const h2_t ll = __builtin_convertvector(r, h2_t);
+        o.hi[j] = hh[0]; o.hi[j + 1] = hh[1];
+        o.lo[j] = ll[0]; o.lo[j + 1] = ll[1];
     }
 }
 
@@ -310,6 +313,11 @@ __device__ __forceinline__ void load_w(lds_cf32 fr, int rec, int lane, Split2 &w
 
 // The four layers for one 32-row tile held by one wave.  zb[s] = input feature 2s + (lane>>5) of row lane&31;
 // returns the three outputs of row lane&31 in o[] (both half-waves hold the full sums).
+// Measured (scripts/ubench/mfma_f16_valu_overlap.hip, profiles/r02_ubench_mfma_f16_valu_overlap.txt): a wave's f32 VALU work is
+// NOT hidden behind its own v_mfma_f32_32x32x16_f16 -- 35 cycles per instruction alone, 35 + 6 + 2.5 per v_fma_f32 issued
+// behind it -- so a software-pipelined form of this tile (conversions of one layer issued between the matrix instructions
+// of the next) ran no faster than this layer-by-layer form (9.46 k against 9.18 k cycles); what counts is the instruction
+// count.  No scheduling fences here: the compiler's own order is 0.84 k cycles shorter than a fenced one.
 // Activations stay transposed [feature][row] in the accumulators.  Registers 8s..8s+7 of a 32x32 accumulator,
 // converted to fp16 pairs, ARE the B operand of k-step s of the next layer (feature 16s + 8(j>>2) + 4(lane>>5) + (j&3) in
 // element j); the weights are stored in that k order.
@@ -355,7 +363,6 @@ __device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lan
                 accl[r] = 0.0f;
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
         mm3(wc, l2 ? x1[it][s] : x2[it][s], acc, accl);
         if (last) {
 #pragma unroll
@@ -366,7 +373,6 @@ __device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lan
             if (l2) { split2(acc, 0, x2[ot][0]); split2(acc, 1, x2[ot][1]); }
             else h3[ot] = acc;
         }
-        __builtin_amdgcn_sched_barrier(0);
         wc = wn;
     }
     // last layer (128 -> 3) on the VALU in f32: each half-wave owns 64 of the 128 features of its row; weights come as
@@ -382,13 +388,11 @@ __device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lan
 #pragma unroll
             for (int r = 0; r < 16; ++r) qn[r] = w4[(it + 1) * 32 + f0(r) + 4 * h];
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) o[c] = fmaf(qc[r][c], h3[it][r], o[c]);
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) qc[r] = qn[r];
     }
@@ -861,6 +865,17 @@ __global__ __launch_bounds__(256) void ref_list_window_kernel(const double *__re
 // ------------------------------------------------------------------------------------------ C-ABI
 using namespace ndp;
 
+// RTI_K(...): the rti_kernel instantiation to reference.  -DNDP_DEV_HEADLINE_ONLY (kernel development builds only, never
+// the shipped library) collapses every instantiation but the reference configuration's two onto rti_kernel<3, 4, false, 20>, so
+// that an experiment on the headline kernel compiles in 20 s instead of 3 min; such a library serves N = 20, n_rti = 1 only.
+#ifdef NDP_DEV_HEADLINE_ONLY
+template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), int QMODE = 0>
+struct RtiK { static constexpr auto fn = rti_kernel<3, 4, (FUSED && NC == 20 && QMODE == 0), 20, 0, 1, 0>; };
+#define RTI_K(...) (RtiK<__VA_ARGS__>::fn)
+#else
+#define RTI_K(...) (rti_kernel<__VA_ARGS__>)
+#endif
+
 struct ndp_handle {
     ndp_cfg cfg;
     RtiParams P;
@@ -1100,15 +1115,15 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     (void)hipMemsetAsync(h->dForce, 0, nfs(h) * 4, h->stream);
     // allow the big dynamic-LDS launches
     const int lds_bytes = (int)(per_wave_bytes * h->waves);
-    const void *fns[] = {(const void *)rti_kernel<3, 4, false>, (const void *)rti_kernel<3, 2, false>, (const void *)rti_kernel<3, 1, false>,
-                         (const void *)rti_kernel<5, 4, false>, (const void *)rti_kernel<5, 2, false>, (const void *)rti_kernel<5, 1, false>,
-                         (const void *)rti_kernel<3, 4, true>, (const void *)rti_kernel<3, 2, true>, (const void *)rti_kernel<3, 1, true>,
-                         (const void *)rti_kernel<3, 4, false, 20>, (const void *)rti_kernel<3, 4, true, 20>,
-                         (const void *)rti_kernel<3, 4, false, 20, 0, 1, 1>, (const void *)rti_kernel<3, 4, true, 20, 0, 1, 1>, (const void *)rti_kernel<3, 4, false, 20, 0, 1, 2>,
-                         (const void *)rti_kernel<5, 1, false, 0, 1>, (const void *)rti_kernel<5, 1, false, 0, 2>,
-                         (const void *)rti_kernel<5, 1, false, 0, 3>, (const void *)rti_kernel<5, 1, false, 0, 4>,
-                         (const void *)rti_kernel<5, 2, false, 40, 3, 2>, (const void *)rti_kernel<5, 2, false, 40, 4, 2>,
-                         (const void *)rti_kernel<5, 2, false, 40, 0, 2>, (const void *)rti_kernel<5, 2, false, 40, 0, 2, 1>, (const void *)rti_kernel<5, 2, false, 40, 0, 2, 2>};
+    const void *fns[] = {(const void *)RTI_K(3, 4, false), (const void *)RTI_K(3, 2, false), (const void *)RTI_K(3, 1, false),
+                         (const void *)RTI_K(5, 4, false), (const void *)RTI_K(5, 2, false), (const void *)RTI_K(5, 1, false),
+                         (const void *)RTI_K(3, 4, true), (const void *)RTI_K(3, 2, true), (const void *)RTI_K(3, 1, true),
+                         (const void *)RTI_K(3, 4, false, 20), (const void *)RTI_K(3, 4, true, 20),
+                         (const void *)RTI_K(3, 4, false, 20, 0, 1, 1), (const void *)RTI_K(3, 4, true, 20, 0, 1, 1), (const void *)RTI_K(3, 4, false, 20, 0, 1, 2),
+                         (const void *)RTI_K(5, 1, false, 0, 1), (const void *)RTI_K(5, 1, false, 0, 2),
+                         (const void *)RTI_K(5, 1, false, 0, 3), (const void *)RTI_K(5, 1, false, 0, 4),
+                         (const void *)RTI_K(5, 2, false, 40, 3, 2), (const void *)RTI_K(5, 2, false, 40, 4, 2),
+                         (const void *)RTI_K(5, 2, false, 40, 0, 2), (const void *)RTI_K(5, 2, false, 40, 0, 2, 1), (const void *)RTI_K(5, 2, false, 40, 0, 2, 2)};
     if ((e = hipFuncSetAttribute((const void *)mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(FR_TOTAL * sizeof(float)))) != hipSuccess)
         return fail("hipFuncSetAttribute(mlp_kernel)", e);
@@ -1218,16 +1233,16 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
         const size_t shm1 = (size_t)h->lds_per_wave * sizeof(double);
         const int pr = h->cfg.qp_precision;
         if (pr >= 3 && h->cfg.N == 40 && h->cfg.n_rti == 2 && W == 2) {   // config 5's own shape: compile-time horizon, 2 instances per workgroup
-            if (pr == 3) hipLaunchKernelGGL((rti_kernel<5, 2, false, 40, 3, 2>), grid, block, shm, s, ka);
-            else hipLaunchKernelGGL((rti_kernel<5, 2, false, 40, 4, 2>), grid, block, shm, s, ka);
-        } else if (pr == 1) hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 1>), dim3(B), dim3(64), shm1, s, ka);   // any horizon: one wave per workgroup
-        else if (pr == 2) hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 2>), dim3(B), dim3(64), shm1, s, ka);
-        else if (pr == 3) hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 3>), dim3(B), dim3(64), shm1, s, ka);
-        else hipLaunchKernelGGL((rti_kernel<5, 1, false, 0, 4>), dim3(B), dim3(64), shm1, s, ka);
+            if (pr == 3) hipLaunchKernelGGL(RTI_K(5, 2, false, 40, 3, 2), grid, block, shm, s, ka);
+            else hipLaunchKernelGGL(RTI_K(5, 2, false, 40, 4, 2), grid, block, shm, s, ka);
+        } else if (pr == 1) hipLaunchKernelGGL(RTI_K(5, 1, false, 0, 1), dim3(B), dim3(64), shm1, s, ka);   // any horizon: one wave per workgroup
+        else if (pr == 2) hipLaunchKernelGGL(RTI_K(5, 1, false, 0, 2), dim3(B), dim3(64), shm1, s, ka);
+        else if (pr == 3) hipLaunchKernelGGL(RTI_K(5, 1, false, 0, 3), dim3(B), dim3(64), shm1, s, ka);
+        else hipLaunchKernelGGL(RTI_K(5, 1, false, 0, 4), dim3(B), dim3(64), shm1, s, ka);
         NDP_HIP(h, hipGetLastError());
         return end_timing(h, s);
     }
-#define LAUNCH(...) hipLaunchKernelGGL((rti_kernel<__VA_ARGS__>), grid, block, shm, s, ka)
+#define LAUNCH(...) hipLaunchKernelGGL(RTI_K(__VA_ARGS__), grid, block, shm, s, ka)
     if (q) {
         // work list: zero the counter, producer (every instance, early exit or defer), consumer (the deferred ones, from
         // scratch; with one RTI iteration the consumer goes straight to the interior-point loop, with several it repeats the
@@ -1240,11 +1255,11 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
         if (h->cfg.N == 20) {
             if (fused) LAUNCH(3, 4, true, 20, 0, 1, 1); else LAUNCH(3, 4, false, 20, 0, 1, 1);
             NDP_HIP(h, hipGetLastError());
-            hipLaunchKernelGGL((rti_kernel<3, 4, false, 20, 0, 1, 2>), grid, block, shm, s, kc);
+            hipLaunchKernelGGL(RTI_K(3, 4, false, 20, 0, 1, 2), grid, block, shm, s, kc);
         } else {
             LAUNCH(5, 2, false, 40, 0, 2, 1);
             NDP_HIP(h, hipGetLastError());
-            hipLaunchKernelGGL((rti_kernel<5, 2, false, 40, 0, 2, 2>), grid, block, shm, s, kc);
+            hipLaunchKernelGGL(RTI_K(5, 2, false, 40, 0, 2, 2), grid, block, shm, s, kc);
         }
         NDP_HIP(h, hipGetLastError());
         return end_timing(h, s);
