@@ -258,7 +258,7 @@ def main():
     if want_graph:
         try:
             base = ((args.warmup + T - 1) // T) * T          # a multiple of T: the replayed cycle starts at tick 0
-            G = min(256, args.steps) // T * T
+            G = min(1024, args.steps) // T * T
             fence()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream, capture_error_mode="relaxed"):
