@@ -691,8 +691,10 @@ struct RtiWave {
     // Lam^-1 -- only two dependent MFMAs follow the inverse.  Stores K~' per stage.
     // forward: z~_0 = [dx0,1,0]; du = K~ z~; z~+ = M~ [z~; du].  Writes ZX[1..N], ZU[0..N-1].
     // The LDS operands of the next stage are requested one stage ahead, so the LDS latency is paid while the MFMA chain runs (LDS, unlike the wave's own VALU work, does proceed under it).
+    // linv (compile-time horizons only, else null): per stage, -Lam^-1 in the lanes j >= 12 (the B operand of the K~' product),
+    // kept in registers for delta_sweep.
     static NDP_D bool riccati_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, lp lds,
-                                    const RtiIo *io = nullptr)
+                                    const RtiIo *io = nullptr, md *linv = nullptr)
     {
         const int N = horizon(P);
         bool ok = true;
@@ -791,7 +793,9 @@ struct RtiWave {
             md4 Hn = mma(-tt, W::to_m(gs), Hb);               // - T' Lam^-1 T on top of the bracket
             // K~' = H~ux' (-Lam^-1): the 1/det rides in the B operand (one multiply instead of one per result register); lands in
             // column 12+b = rows 12..15 of the forward operand; stored behind the next stage's first MFMAs
-            md4 Kt = mma(hux, W::to_m(nahi * rdet), W::mzero4());
+            const md nli = W::to_m(nahi * rdet);
+            if (linv) linv[k] = nli;
+            md4 Kt = mma(hux, nli, W::mzero4());
             Ktp = Kt; kprev = k;
             if ((k & 7) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
@@ -815,6 +819,7 @@ struct RtiWave {
             vd cof = lam_cofactor(T, LR);
             vd rdet = lam_rdet(T, LR, cof, ok);
             vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));
+            if (linv) linv[0] = W::to_m(nahi * rdet);
             md4 Kt = mma(hux, W::to_m(nahi), W::mzero4());
             for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c], W::to_d(Kt.r[c]) * rdet);
         }
@@ -853,6 +858,70 @@ struct RtiWave {
         }
         W::sync();
         return ok;
+    }
+
+    // ---------------------------------------------------------------- second solve with the same factorisation
+    // Mehrotra's corrector (and any further right-hand side) differs from the predictor only in the gradient of the bounded
+    // variables: the Hessians, Lam, the gains are the same, and the Riccati recursion is linear in the gradient.  With
+    // dc_k = change of the gradient of stage k (rows 3..5: v bounds, rows 12..15: u bounds), the change of the solution is
+    //   backward:  dg_k = dc_k + M~_k' dp_{k+1}     (3 MFMAs, dp as a single column)
+    //              [dp_k ; dk_k] = dg_k + [K~_k' ; -Lam_k^-1 - I] dg_k(u)     (1 MFMA; dk_k = change of the feed-forward)
+    //   forward:   du_k = K~_k dx_k + dk_k,  dx_{k+1} = A_k dx_k + B_k du_k,  dx_0 = 0      (the 4 MFMAs of the full forward sweep)
+    // and ZX|ZU += (dx, du).  No 4x4 inverse, no cost blocks: ~0.55 of a full sweep.  Needs -Lam_k^-1 of every stage (riccati_sweep's
+    // linv, in registers: compile-time horizons) and K~' where the sweep left it in LDS.
+    struct DeltaTabs { vi dc_off[4], kta_off; md eye12; vb row10; };
+    static NDP_D void build_delta_tabs(const LdsMap &m, DeltaTabs &D)
+    {
+        vi lane = W::lane();
+        vi g = lane >> 4, j = W::lcol(lane);
+        vb c0 = j == 0;
+        for (int r = 0; r < 4; ++r) {
+            vi row = g + 4 * r;
+            vb isv = c0 && (row >= 3) && (row < 6), isu = c0 && (row >= 12);
+            D.dc_off[r] = W::sel(isv, row + (m.CB + int(CB_QE)), W::sel(isu, row + (m.CB + int(CB_RE) - 12), vi(m.CB + int(CB_ZERO))));
+        }
+        D.kta_off = W::sel(j < 10, j * 4 + g + m.KT, vi(m.MB + int(MB_ZERO)));     // K~'[j][g] as A operand, rows 10..15 read a structural 0
+        D.eye12 = W::to_m(W::sel((j >= 12) && (j - 12 == g), vd(1.0), vd(0.0)));
+        D.row10 = c0 && (g == 2);                                                  // row 10 = g + 4r with g = 2, r = 2
+    }
+
+    static NDP_D void delta_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, const DeltaTabs &D, lp lds, const md *linv)
+    {
+        const int N = horizon(P);
+        md vc[3] = {W::to_m(vd(0.0)), W::to_m(vd(0.0)), W::to_m(vd(0.0))};
+        md dk[NC > 0 ? NC : 1];
+        NDP_UNROLL_STAGES
+        for (int k = N - 1; k >= 0; --k) {
+            md4 C;
+            for (int r = 0; r < 4; ++r) C.r[r] = W::to_m(W::ld(lds, D.dc_off[r] + cb(k)));
+            md a[3];
+            for (int c = 0; c < 3; ++c) a[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(k)));
+            md akl = W::to_m(W::ld(lds, D.kta_off + mb(k))) + (linv[k] - D.eye12);
+            md4 Dg = k == N - 1 ? C : mman<3>(a, vc, C);
+            md4 Dp = mma(akl, Dg.r[3], Dg);
+            dk[k] = Dp.r[3];
+            vc[0] = Dp.r[0]; vc[1] = Dp.r[1];
+            vc[2] = W::msel(D.row10, W::to_m(vd(0.0)), Dp.r[2]);                    // the constant-term row must not feed back
+        }
+        md zc[3] = {W::to_m(vd(0.0)), W::to_m(vd(0.0)), W::to_m(vd(0.0))};
+        NDP_UNROLL_STAGES
+        for (int k = 0; k < N; ++k) {
+            md fw[3], mu;
+            for (int c = 0; c < 3; ++c) fw[c] = W::to_m(W::ld(lds, T.fw_off[c] + mb(k)));
+            mu = W::to_m(W::ld(lds, T.mu_off + mb(k)));
+            vd zu0 = W::ld(lds, T.zu_st + k * int(NU));
+            vd zx0[3];
+            for (int c = 0; c < 3; ++c) zx0[c] = W::ld(lds, T.zx_st[c] + (k + 1) * int(NX));
+            md4 Y = k == 0 ? W::mzero4() : mman<3>(fw, zc, W::mzero4());
+            md du = Y.r[3] + dk[k];
+            md4 xn = mma(mu, du, Y);
+            W::st(lds, T.zu_st + k * int(NU), zu0 + W::to_d(du));
+            for (int c = 0; c < 3; ++c) {
+                zc[c] = xn.r[c];
+                W::st(lds, T.zx_st[c] + (k + 1) * int(NX), zx0[c] + W::to_d(xn.r[c]));
+            }
+        }
+        W::sync();
     }
 
     // ---------------------------------------------------------------- box constraints / interior point
@@ -959,6 +1028,10 @@ struct RtiWave {
         }
         W::sync();
         bool ok = true;
+        constexpr bool DELTA = NC > 0;      // corrector as a second solve with the predictor's factorisation (delta_sweep)
+        md linv[DELTA ? NC : 1];
+        DeltaTabs DT;
+        if (DELTA) build_delta_tabs(m, DT);
         for (;;) {
             if (mu <= P.tol && rho * norm0 <= P.tol) break;
             if (iters >= P.iter_max) { status = 4; break; }
@@ -972,12 +1045,18 @@ struct RtiWave {
                     vd gl = S.ll[s] * rtl, gu = S.lu[s] * rtu;
                     vd Gam = gl + gu;
                     vd gam = -sl * rtl - S.ll[s] - gl * S.lo[s] + su * rtu + S.lu[s] - gu * S.hi[s];
-                    vd dbase = P.dt * W::ld(lds, S.dw_off[s]);
-                    W::stp(lds, S.de_off[s], dbase + Gam, S.valid[s]);
-                    W::stp(lds, S.ge_off[s], W::ld(lds, S.gb_off[s]) + gam, S.valid[s]);
+                    if (DELTA && pass) {
+                        // same diagonal as the predictor; the gradient slot takes the CHANGE of the gradient only
+                        W::stp(lds, S.ge_off[s], su * rtu - sl * rtl, S.valid[s]);
+                    } else {
+                        vd dbase = P.dt * W::ld(lds, S.dw_off[s]);
+                        W::stp(lds, S.de_off[s], dbase + Gam, S.valid[s]);
+                        W::stp(lds, S.ge_off[s], W::ld(lds, S.gb_off[s]) + gam, S.valid[s]);
+                    }
                 }
                 W::sync();
-                ok = riccati_sweep(P, m, T, lds) && ok;
+                if (DELTA && pass) delta_sweep(P, m, T, DT, lds, linv);
+                else ok = riccati_sweep(P, m, T, lds, nullptr, DELTA ? linv : nullptr) && ok;
                 if (!ok) break;
                 vd amin = 1.0;
                 for (int s = 0; s < NSLOT; ++s) {

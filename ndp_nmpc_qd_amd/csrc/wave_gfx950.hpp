@@ -23,6 +23,7 @@ struct WaveGfx950 {
     static NDP_D vd to_d(md a) { return a; }
     static NDP_D md4 mzero4() { return zero4(); }
     static NDP_D md mavg(md a, md b) { return (a + b) * 0.5; }
+    static NDP_D md msel(vb p, md a, md b) { return p ? a : b; }
     static NDP_D vi lcol(vi lane) { return lane & 15; }        // the matrix column a lane holds (RtiWave::lane_preds)
     typedef __attribute__((address_space(3))) double *lds_ptr;
     typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -177,6 +178,7 @@ struct WaveGfx950F32 : WaveGfx950 {
     static NDP_D vd to_d(md a) { return (double)a; }
     static NDP_D md4 mzero4() { md4 z; z.r[0] = z.r[1] = z.r[2] = z.r[3] = 0.0f; return z; }
     static NDP_D md mavg(md a, md b) { return (a + b) * 0.5f; }
+    static NDP_D md msel(vb p, md a, md b) { return p ? a : b; }
     static NDP_D vi lcol(vi lane) { const int jt = lane & 15; return (jt >> 2) + 4 * (jt & 3); }
     static NDP_D vd csum1(vd a) { return dpp_quad<0x124>(a); }   // row_ror:4
     static NDP_D vd csum2(vd a) { return dpp_quad<0x128>(a); }   // row_ror:8

@@ -25,18 +25,20 @@ for label, kw in (("nominal", {}), ("perturbed", dict(pos_sigma=0.5, vel_sigma=1
     uo, sto, ito = O.step_batch(cfgo, b["x0"][:NS], b["xr"][:NS], b["ur"][:NS], None, Xo, Uo)
     t = {k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur")}
     res, ref, free = {}, None, None
-    for prec, name in ((0, "fp64"), (3, "fp32_mfma"), (4, "bf16_mfma"), (1, "fp32_rounding_study"), (2, "bf16_rounding_study")):
-        eng = ndp.BatchedNMPC(B, N=N, n_rti=2, qp_precision=prec, work_queue=2)
+    for prec, name in ((0, "fp64"), (0, "fp64_work_list"), (3, "fp32_mfma"), (4, "bf16_mfma"), (1, "fp32_rounding_study"), (2, "bf16_rounding_study")):
+        # "fp64" and the fp32 / bf16 kernels solve in place (one launch per step); "fp64_work_list" is the product default at this
+        # batch size: producer + consumer launch (the producer carries no interior-point code and does not spill at N = 40)
+        eng = ndp.BatchedNMPC(B, N=N, n_rti=2, qp_precision=prec, work_queue=1 if name == "fp64_work_list" else 2)
         eng.reset(b["xr"], b["ur"])
         u0 = eng.update(b["x0"], b["xr"], b["ur"], raise_on_status=False)
         st, it = eng.status()
         ok = (st[:NS] == 0) & (sto == 0)
         rel = np.abs(u0[:NS] - uo) / np.maximum(1.0, np.abs(uo))
-        if prec == 0:
+        if name == "fp64":
             ref, free = u0, it == 0                  # fp64 AUTO path left early: no bound active in that instance's QPs
             out.setdefault(label, {})["frac_interior_point"] = float((~free).mean())
         d = {"max_rel_err_vs_oracle": float(rel[ok].max()), "status_nonzero": int((st != 0).sum())}
-        if prec:
+        if name != "fp64":
             relall = np.abs(u0 - ref) / np.maximum(1.0, np.abs(ref))
             good = st == 0
             d["max_rel_err_vs_fp64_device_no_active_bounds"] = float(relall[free & good].max())

@@ -78,6 +78,7 @@ struct Wave {
     static vd to_d(const vd &a) { return a; }
     static vd4 mzero4() { return zero4(); }
     static vd mavg(const vd &a, const vd &b) { return (a + b) * 0.5; }
+    static vd msel(const vb &p, const vd &a, const vd &b) { return sel(p, a, b); }
     static vi lcol(const vi &lane) { return lane & 15; }
     static vd csum1(const vd &a) { return quad_swap1(a); }
     static vd csum2(const vd &a) { return quad_swap2(a); }
