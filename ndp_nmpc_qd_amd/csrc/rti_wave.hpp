@@ -1028,7 +1028,9 @@ struct RtiWave {
         }
         W::sync();
         bool ok = true;
-        constexpr bool DELTA = NC > 0;      // corrector as a second solve with the predictor's factorisation (delta_sweep)
+        // corrector as a second solve with the predictor's factorisation (delta_sweep): compile-time horizons (the per-stage
+        // -Lam^-1 operands live in registers) on the f64 instruction (in fp32 the interior-point loop converges worse with it)
+        constexpr bool DELTA = NC > 0 && W::delta_ok;
         md linv[DELTA ? NC : 1];
         DeltaTabs DT;
         if (DELTA) build_delta_tabs(m, DT);
@@ -1284,7 +1286,7 @@ struct LaneW {
     struct vd4 { double r[4]; };
     using md = double;
     using md4 = vd4;
-    static constexpr bool packed_k = false;
+    static constexpr bool packed_k = false, delta_ok = true;
     using lds_ptr = double *;
     // host-only on purpose (no device attribute): only fill_tables, a host function, instantiates code that calls them
     static int &cur() { static thread_local int l = 0; return l; }

@@ -18,7 +18,7 @@ struct WaveGfx950 {
     // matrix values of the Riccati sweeps (RtiWave::md): this backend's instruction is v_mfma_f64_16x16x4_f64
     using md = double;
     using md4 = vd4;
-    static constexpr bool packed_k = false;
+    static constexpr bool packed_k = false, delta_ok = true;
     static NDP_D md to_m(vd a) { return a; }
     static NDP_D vd to_d(md a) { return a; }
     static NDP_D md4 mzero4() { return zero4(); }
@@ -173,7 +173,7 @@ struct WaveGfx950F32 : WaveGfx950 {
     using md = float;
     struct md4 { float r[4]; };
     typedef float f4_t __attribute__((ext_vector_type(4)));
-    static constexpr bool packed_k = false;
+    static constexpr bool packed_k = false, delta_ok = false;
     static NDP_D md to_m(vd a) { return (float)a; }
     static NDP_D vd to_d(md a) { return (double)a; }
     static NDP_D md4 mzero4() { md4 z; z.r[0] = z.r[1] = z.r[2] = z.r[3] = 0.0f; return z; }

@@ -73,7 +73,7 @@ struct Wave {
     // matrix values of the Riccati sweeps (RtiWave::md): the f64 instruction
     using md = emu::vd;
     using md4 = emu::vd4;
-    static constexpr bool packed_k = false;
+    static constexpr bool packed_k = false, delta_ok = true;
     static vd to_m(const vd &a) { return a; }
     static vd to_d(const vd &a) { return a; }
     static vd4 mzero4() { return zero4(); }
@@ -188,7 +188,7 @@ inline float bf16r(float f)
 }
 
 struct Wave32 : Wave {
-    static constexpr bool packed_k = false;
+    static constexpr bool packed_k = false, delta_ok = false;
     static vd to_m(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)f32(a.v[l]); return o; }
     static vd mavg(const vd &a, const vd &b) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)((f32(a.v[l]) + f32(b.v[l])) * 0.5f); return o; }
     static vi lcol(const vi &lane) { vi o; for (int l = 0; l < 64; ++l) { const int jt = lane.v[l] & 15; o.v[l] = (jt >> 2) + 4 * (jt & 3); } return o; }
