@@ -596,9 +596,9 @@ def test_work_queue_gives_the_same_answers(ndp, oracle, mlp_blob):
         uo, sto, *_ = _oracle_batch(oracle, b, use_fd=disturbance, f=f)
         assert np.array_equal(st, sto)
         _assert_u(u0[sto == 0], uo[sto == 0])
-    # automatic choice: on only with more instances than SIMDs (and an early-exit QP mode to defer from)
-    assert not ndp.BatchedNMPC(1024).work_queue and ndp.BatchedNMPC(1500, qp_mode=1).work_queue is False
-    assert ndp.BatchedNMPC(1025).work_queue or ndp.BatchedNMPC(4097).work_queue
+    # automatic choice: on from four instances per SIMD (and an early-exit QP mode to defer from)
+    assert not ndp.BatchedNMPC(1024).work_queue and not ndp.BatchedNMPC(2048).work_queue
+    assert ndp.BatchedNMPC(4096).work_queue and not ndp.BatchedNMPC(4096, qp_mode=1).work_queue
 
 
 def test_neighbour_rows_by_index_and_six_column_windows(ndp):
