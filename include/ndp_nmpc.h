@@ -60,8 +60,8 @@ typedef struct ndp_cfg {
                            * 3 / 4 run the Riccati sweeps on the fp32 / bf16-input matrix instructions (everything else stays
                            * fp64); 1 / 2 are the first round's operand-rounding studies on the fp64 kernel */
     int32_t work_queue; /* instances whose QP needs the interior-point loop are re-distributed over all SIMDs through an
-                         * work list (producer + consumer launch per step): 0 = automatic (on when batch >= 4 x the device's SIMD
-                         * count and qp_mode is AUTO), 1 = on, 2 = off */
+                         * work list (producer + consumer launch per step): 0 = automatic (qp_mode AUTO and batch >= 4 x the device's
+                         * SIMD count, or the N = 40 / 2-iteration shape at any batch), 1 = on, 2 = off */
     int32_t reserved0;
     double dt;          /* T_horizon / N_node        params/nmpc_params.py:10,12  */
     double mass;        /* params/fhnp_params.py:9   */

@@ -1055,14 +1055,16 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     // work list: by default when the batch holds at least four instances per SIMD and the QP mode has an early exit to defer
     // from.  With one instance per SIMD nothing can be re-balanced; in between the list's fixed cost per step (a memset node
     // and a consumer launch, ~10 us even when nothing was listed) is 10-20 % of a step that needs no interior-point solve,
-    // against +30 % .. 2x when a fifth of the instances do -- callers who know their workload set cfg.work_queue = 1 / 2
+    // against +30 % .. 2x when a fifth of the instances do -- callers who know their workload set cfg.work_queue = 1 / 2.
+    // The N = 40 / 2-iteration shape always takes the list: its producer kernel carries no interior-point code and does not
+    // spill, which is worth 17 % even when nothing is listed (the in-place kernel of that shape uses 0.9 KB of scratch per lane)
     if (cfg->work_queue == 1 && !(queue_shape(h) && cfg->qp_mode == NDP_QP_AUTO)) {
         g_create_err = "ndp_create: work_queue = 1 needs qp_mode AUTO, qp_precision 0 and (N, n_rti) = (20, 1) or (40, 2)";
         delete h;
         return -2;
     }
     h->use_queue = cfg->work_queue == 1 ||
-                   (cfg->work_queue == 0 && queue_shape(h) && cfg->qp_mode == NDP_QP_AUTO && cfg->batch >= 4 * h->n_simd);
+                   (cfg->work_queue == 0 && queue_shape(h) && cfg->qp_mode == NDP_QP_AUTO && (cfg->batch >= 4 * h->n_simd || cfg->N == 40));
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&h->evLast, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     const size_t B = cfg->batch;
