@@ -155,25 +155,20 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     u0 = torch.empty(B, 4, dtype=torch.float64, device=dev)
-    # Neighbour exchange.  config 3, N > 1 (vehicle-major ring of ranks): all-gather of the ranks' xr windows, rank r reads
-    # rank r+1's slice.  config 4, vehicle-major: all-gather of the [B, N+1, 6] position/velocity columns, the kernel picks
-    # each leader's neighbour row through other_index.  Two gather buffers: the gather of tick i+1's windows (functions of
-    # time only) is started before tick i's kernel is launched and runs on RCCL's stream beside it.
+    # Neighbour exchange (vehicle-major placement): ONE all-gather per step of the position / velocity columns of the ranks'
+    # reference windows, [B, N+1, 6] fp64 per rank -- all that the gate and the MLP read (downwash_nn.py:22).  config 3 (ring of
+    # ranks): rank r reads rank r+1's slice of the gathered buffer as it lies; config 4: the kernel picks each leader's
+    # neighbour row through other_index.  Two gather buffers: the gather of tick i+1's windows (functions of time only) is
+    # started before tick i's kernel is launched and runs on RCCL's stream beside it.
     exchange = downwash and args.placement == "vehicle" and (world > 1 or cfg4)
-    if cfg4 and exchange:
+    if exchange:
         gathered = [torch.empty(world * B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev) for _ in range(2)]
         pv_local = torch.empty(B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev)
-    elif exchange:
-        gathered = [torch.empty(world, B, N + 1, 10, dtype=torch.float64, device=dev) for _ in range(2)]
     pending = {}
 
     def prefetch(i):
-        if not exchange:
-            return
-        if cfg4:
-            pending[i] = ndist.exchange_pv_begin(ticks[i % T]["xr"], pv_local, gathered[i % 2])
-        else:
-            pending[i] = ndist.exchange_neighbours_begin(ticks[i % T]["xr"], gathered[i % 2])   # one RCCL all-gather over xGMI
+        if exchange:
+            pending[i] = ndist.exchange_pv_begin(ticks[i % T]["xr"], pv_local, gathered[i % 2])   # one RCCL all-gather over xGMI
 
     def step(i, e=None):
         e = e or eng
@@ -183,11 +178,11 @@ def main():
             if exchange:
                 if i not in pending:
                     prefetch(i)
+                ndist.exchange_pv_end(pending.pop(i))
                 if cfg4:
-                    ndist.exchange_pv_end(pending.pop(i))
                     other, oidx = gathered[i % 2], d["other_index"]
                 else:
-                    other = ndist.exchange_neighbours_end(pending.pop(i), gathered[i % 2])
+                    other = gathered[i % 2].view(world, B, N + 1, ndist.PV_COLS)[ndist.neighbour_rank(rank, world)]
                 prefetch(i + 1)
             elif cfg4:
                 other, oidx = d["xr"], d["other_index"]      # formation-major: the neighbour's window is a local row of xr
@@ -198,8 +193,7 @@ def main():
 
     def fence():
         for w in list(pending.values()):      # a gather started for a tick that is never solved (end of a phase)
-            if w is not None:
-                w.wait()
+            ndist.exchange_pv_end(w)
         pending.clear()
         if world > 1:
             dist.barrier()
@@ -243,8 +237,7 @@ def main():
     fence()
     if exchange:                              # the first timed tick's windows are in place before the clock starts; every
         prefetch(args.warmup)                 # timed step then starts exactly one gather (the next tick's) and one kernel
-        if pending[args.warmup] is not None:
-            pending[args.warmup].wait()
+        ndist.exchange_pv_end(pending[args.warmup])
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -265,8 +258,7 @@ def main():
                 for i in range(G):
                     step(base + i)
                 for w in list(pending.values()):             # the last step's prefetch belongs to the captured cycle
-                    if w is not None:
-                        w.wait()
+                    ndist.exchange_pv_end(w)
                 pending.clear()
             torch.cuda.set_stream(stream)
             graph.replay()                                    # instantiate / upload outside the timed region

@@ -272,9 +272,10 @@ class BatchedNMPC:
         import torch
         B, N = self.B, self.N
         stride = 10
-        if other is not None and other_index is not None:
+        if other is not None and (other_index is not None or (other.dim() == 3 and other.shape[2] == 6)):
+            # rows picked through other_index (any number of rows), or row i = instance i of a [B, N+1, 6] position / velocity window
             if not (other.is_cuda and other.is_contiguous() and other.dtype == torch.float64 and other.dim() == 3
-                    and other.shape[1] == N + 1 and other.shape[2] in (6, 10)):
+                    and other.shape[1] == N + 1 and other.shape[2] in (6, 10) and (other_index is not None or other.shape[0] == B)):
                 raise ValueError("other: expected a contiguous CUDA float64 [rows, N+1, 6 or 10] tensor")
             stride = int(other.shape[2])
             optr = C.c_void_p(other.data_ptr())

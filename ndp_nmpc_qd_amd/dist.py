@@ -9,7 +9,9 @@ step, after which each rank reads the slice that holds its neighbours.
 
 Placement (vehicle-major): instance i of rank r and instance i of rank (r+1) % W belong to the same
 formation; rank r's downwash input is the window of rank (r+1) % W.  With W = 1 the neighbour windows
-are given directly.
+are given directly.  The gate and the MLP read only the position / velocity columns of a window
+(downwash_nn.py:22), so the exchange that bench.py runs moves just those: exchange_pv_begin / _end below
+(1 008 B per instance instead of 1 680); exchange_neighbours (full windows) is the plain form of the same thing.
 """
 import numpy as np
 

@@ -27,19 +27,23 @@ eng = ndp.BatchedNMPC(B, disturbance=True)
 stream = torch.cuda.Stream(device=dev)
 torch.cuda.set_stream(stream)
 u0 = torch.empty(B, 4, dtype=torch.float64, device=dev)
-gathered = [torch.empty(1, B, N + 1, 10, dtype=torch.float64, device=dev) for _ in range(2)]
+gathered = [torch.empty(B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev) for _ in range(2)]
+pv_local = torch.empty(B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev)
 pending = {}
 
 
 def prefetch(i):
-    pending[i] = ndist.exchange_neighbours_begin(ticks[i % T]["xr"], gathered[i % 2])
+    # force the collective even with one rank (exchange_pv_begin would shortcut it): this probe is about capturing RCCL
+    pv_local.copy_(ticks[i % T]["xr"][:, :, :ndist.PV_COLS])
+    pending[i] = dist.all_gather_into_tensor(gathered[i % 2].view(-1), pv_local.view(-1), async_op=True)
 
 
 def step(i):
     d = ticks[i % T]
     if i not in pending:
         prefetch(i)
-    other = ndist.exchange_neighbours_end(pending.pop(i), gathered[i % 2])
+    pending.pop(i).wait()
+    other = gathered[i % 2]
     prefetch(i + 1)
     eng.update_device(d["x0"], d["xr"], d["ur"], u0, other=other, ego_xy=d["ego_xy"], stream=stream)
 

@@ -620,19 +620,22 @@ def test_neighbour_rows_by_index_and_six_column_windows(ndp):
         ego[none] = 1e9                                    # plain form: the same instances gated off by distance
         t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in
              dict(x0=b["x0"], xr=b["xr"], ur=b["ur"], other=b["other"], ego=ego, ego_idx=b["ego_xy"], rows=rows, idx=idx).items()}
+        t["pv"] = t["other"][:, :, :6].contiguous()      # row i = instance i, six columns, no index: the ring exchange's slice
         outs = []
-        for form in ("plain", "indexed"):
+        for form in ("plain", "indexed", "six_columns"):
             eng = ndp.BatchedNMPC(B, N=N, disturbance=True)
             eng.reset_device(t["xr"], t["ur"])
             u = torch.empty(B, 4, dtype=torch.float64, device=dev)
             if form == "plain":
                 eng.update_device(t["x0"], t["xr"], t["ur"], u, other=t["other"], ego_xy=t["ego"])
+            elif form == "six_columns":
+                eng.update_device(t["x0"], t["xr"], t["ur"], u, other=t["pv"], ego_xy=t["ego"])
             else:
                 eng.update_device(t["x0"], t["xr"], t["ur"], u, other=t["rows"], ego_xy=t["ego_idx"], other_index=t["idx"])
             st, _ = eng.status()                           # no explicit synchronise: the getter waits for the foreign-free stream
             assert (st == 0).all()
             outs.append(u.cpu().numpy())
-        assert np.array_equal(outs[0], outs[1])
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 def test_getters_wait_for_the_callers_stream(ndp, oracle):

@@ -169,6 +169,12 @@ def _worker(rank, world, port, q):
         ok = ok and np.array_equal(other2.numpy(), shard["other"])          # the current tick's windows are untouched meanwhile
         other3 = ndist.exchange_neighbours_end(work, buf2)
         ok = ok and np.array_equal(other3.numpy(), nxt["other"]) and other3.data_ptr() == buf2[(rank + 1) % world].data_ptr()
+        # the form bench.py uses: only the position / velocity columns travel; rank r reads the slice of rank (r+1) % W as it lies
+        pv = torch.empty(B, N + 1, ndist.PV_COLS, dtype=torch.float64)
+        gpv = torch.empty(world * B, N + 1, ndist.PV_COLS, dtype=torch.float64)
+        ndist.exchange_pv_end(ndist.exchange_pv_begin(xr, pv, gpv))
+        nb = gpv.view(world, B, N + 1, ndist.PV_COLS)[ndist.neighbour_rank(rank, world)]
+        ok = ok and np.array_equal(nb.numpy(), shard["other"][:, :, :ndist.PV_COLS]) and nb.is_contiguous()
         # the gate statistic of the synthetic formation: a sensible fraction of neighbours inside r_horiz
         d2 = ((shard["other"][:, 0, 0:2] - shard["ego_xy"]) ** 2).sum(axis=1)
         q.put((rank, bool(ok), float((d2 < 1.0).mean())))
