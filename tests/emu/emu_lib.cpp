@@ -45,4 +45,28 @@ int emu_rti_step(const ndp_cfg *cfg, const double *x0, const double *xr, const d
     }
     return 0;
 }
+
+// The producer launch's view of one instance (work list, QMODE 1): RtiWave::run<DEFER = true> on the reference configuration's
+// instantiation.  Returns 1 if the instance was deferred (needs the interior-point loop: nothing may have been written),
+// 0 if it was solved by the early exit, < 0 on misuse.
+int emu_rti_step_defer(const ndp_cfg *cfg, const double *x0, const double *xr, const double *ur, const float *f,
+                       double *X, double *U, double *u0, int *status, int *iters)
+{
+    ndp::RtiParams P = ndp::to_params(*cfg);
+    if (P.N != 20 || P.n_rti != 1 || cfg->qp_precision != 0) return -1;
+    const int n = ndp::lds_doubles(P.N);
+    std::vector<double> lds((size_t)n, 0.0 / 0.0);
+    emu::Wave::lds_limit() = n;
+    double kc[ndp::KC_SC];
+    ndp::fill_kc(P, kc);
+    ndp::RtiIo io{x0, xr, ur, f, X, U, u0, status, iters, nullptr, 0, kc};
+    std::vector<int> tb(ndp::TB_WORDS);
+    ndp::fill_tables(P.N, tb.data(), 0);
+    io.tables = tb.data();
+    using Prog = ndp::RtiWave<emu::Wave, 3, 20, true, 1>;
+    Prog::InBuf inb;
+    emu::vd x0v;
+    Prog::issue_first(P, io, inb, x0v);
+    return Prog::run<true>(P, io, lds.data(), inb, x0v) ? 1 : 0;
+}
 }

@@ -271,3 +271,30 @@ def test_failed_factorisation_keeps_the_iterate(oracle):
     assert sto.status == 4
     np.testing.assert_array_equal(Xo, b["xr"][0])
     np.testing.assert_array_equal(uo, b["ur"][0][0])
+
+
+def test_work_list_producer_defers_without_writing(oracle):
+    """The work list's producer launch runs RtiWave::run<DEFER = true>: an instance whose equality-constrained minimiser is
+    not inside the box is handed back untouched -- iterate, u0, status and iteration count unwritten -- and the consumer's
+    from-scratch solve of it (run<false> with the interior-point loop) is the in-place answer; an instance that takes the
+    early exit is solved exactly as in place."""
+    b = synth.make_batch(48, seed=2, pos_sigma=0.5, vel_sigma=1.0, quat_sigma=0.15)
+    n_def = 0
+    for i in range(48):
+        X0, U0 = b["xr"][i].copy(), b["ur"][i].copy()
+        Xd, Ud = X0.copy(), U0.copy()
+        deferred, u0d, std, itd = E.rti_step_defer(E.default_cfg(), b["x0"][i], b["xr"][i], b["ur"][i], None, Xd, Ud)
+        Xi, Ui = X0.copy(), U0.copy()
+        u0i, sti, iti, *_ = E.rti_step(E.default_cfg(), b["x0"][i], b["xr"][i], b["ur"][i], None, Xi, Ui)
+        assert deferred == (iti > 0)
+        if deferred:
+            n_def += 1
+            assert np.array_equal(Xd, X0) and np.array_equal(Ud, U0) and np.isnan(u0d).all() and (std, itd) == (-7, -7)
+            Xc, Uc = X0.copy(), U0.copy()                     # consumer: interior point from scratch (qp_mode 1 when n_rti = 1)
+            u0c, stc, itc, *_ = E.rti_step(E.default_cfg(qp_mode=1), b["x0"][i], b["xr"][i], b["ur"][i], None, Xc, Uc)
+            assert (stc, itc) == (sti, iti)
+            np.testing.assert_allclose(u0c, u0i, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(Xc, Xi, rtol=0, atol=1e-12)
+        else:
+            assert (std, itd) == (sti, 0) and np.array_equal(u0d, u0i) and np.array_equal(Xd, Xi) and np.array_equal(Ud, Ui)
+    assert 5 < n_def < 40
