@@ -162,6 +162,13 @@ struct RtiWave {
     // interior-point bookkeeping, the LDS image -- stays in double; W::to_m / W::to_d convert at the sweeps' boundary.
     using md = typename W::md;
     using md4 = typename W::md4;
+    // Products with one four-wide side -- the gains K~' = H~ux' (-Lam^-1), adj(Lam) T, and every matrix-VECTOR product of the
+    // forward and second-solve sweeps -- run on the backend's four-block 4x4x4 instruction where it has one (W::mfma4, the f64
+    // backend): same operand registers as the 16x16x4 form, a quarter of its issue time.  A result then holds element 4b + i of
+    // a vector in lane (j, b, i) = j + 4b + 16i, whereas the next product wants element 4c + k as chunk register c of the lanes
+    // with l >> 4 == k: W::rowb<c> (one row broadcast) makes that register from block c.
+    static constexpr bool MMA4 = W::has_mma4 && PREC == 0;
+    static NDP_D md mma4(md a, md b, md c) { return W::mfma4(a, b, c); }
     // one 4-deep contraction step D = A B + C
     static NDP_D md4 mma(md a, md b, const md4 &c)
     {
@@ -199,6 +206,9 @@ struct RtiWave {
         vi kt_off[3];             // where lanes j>=12 keep K~'[4c+g][j-12]
         vi kt_st[3];              // store form of kt_off: lanes j<12 aim at the block's dump slot
         vi zu_st, zx_st[3];       // forward-sweep results du[g], x+[4c+g] of lanes j == 0; the other lanes aim at the shadow ZD
+        // 4x4x4 form (MMA4): a result register holds row x = 4b + i in lane j + 4b + 16i (j = l & 3, b = (l >> 2) & 3, i = l >> 4)
+        vi kt_st4;                // K~'[x][j] of every lane with x < 12 (the others: dump slot): ONE store per stage
+        vi zx_st4;                // x+[x] of the lanes with j == 0 and x < 10 (the others: shadow ZD): ONE store per stage
         vb kt_pred;               // j >= 12
         vb lo4;                   // j < 4
         vb col0;                  // j == 0
@@ -274,8 +284,9 @@ struct RtiWave {
         T.col0 = j == 0;
         T.cof_sign = W::sel(((g + jc) & 1) == 1, vd(-1.0), vd(1.0));
         T.lam_diag = g == jc;
-        T.adj_a = W::sel(T.lo4, T.cof_sign, vd(0.0));
-        T.adj_b = W::sel(T.kt_pred, -T.cof_sign, vd(0.0));
+        // the 4x4x4 products read the 4x4 operand from every lane (block b = its own copy): no lane mask
+        T.adj_a = MMA4 ? T.cof_sign : W::sel(T.lo4, T.cof_sign, vd(0.0));
+        T.adj_b = MMA4 ? -T.cof_sign : W::sel(T.kt_pred, -T.cof_sign, vd(0.0));
         for (int c = 0; c < 4; ++c) T.eye[c] = W::sel(j == g + 4 * c, vd(1.0), vd(0.0));
     }
 
@@ -304,6 +315,9 @@ struct RtiWave {
                 T.minor_off[3 * a + b] = ra * 4 + cb + m.SC;
             }
         T.own_off = g * 4 + jc + m.SC;
+        vi x4 = ((lane >> 2) & 3) * 4 + g, j4 = lane & 3;
+        T.kt_st4 = W::sel(x4 < 12, x4 * 4 + j4 + m.KT, vi(m.MB + int(MB_DUMP)));
+        T.zx_st4 = W::sel(x4 < 10, x4, vi(0)) + W::sel((j4 == 0) && (x4 < 10), vi(m.ZX), vi(m.ZD));
     }
 
     // the integer fields of Tables in a fixed order: f(index, field).  Used by the host to serialise the tables
@@ -319,6 +333,7 @@ struct RtiWave {
         for (int r = 0; r < 4; ++r) f(i++, T.c_off[r]);
         f(i++, T.mu_off); f(i++, T.zu_st); f(i++, T.lam_w_off); f(i++, T.own_off);
         for (int a = 0; a < 9; ++a) f(i++, T.minor_off[a]);
+        f(i++, T.kt_st4); f(i++, T.zx_st4);
     }
     // block layout [field / 4][lane][field % 4]: the four fields of a group are one 16-byte load per lane, a
     // contiguous 1 KB per wave
@@ -718,6 +733,7 @@ struct RtiWave {
             for (int r = 0; r < 4; ++r) cc[r] = W::to_m(W::ld(lds, T.c_off[r] + cb(kn)));
         }
         md4 Ktp = W::mzero4();
+        md Ktq = W::to_m(vd(0.0));     // MMA4: K~' of the previous stage in ONE register
         int kprev = -1;
         NDP_UNROLL_STAGES
         for (int k = N - 1; k >= 1; --k) {
@@ -740,8 +756,10 @@ struct RtiWave {
             W::pin();
             md4 Wf = mman<3>(H.r, mk, W::mzero4());
             W::pin();
-            if (kprev >= 0)
-                for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), W::to_d(Ktp.r[c]));
+            if (kprev >= 0) {
+                if constexpr (MMA4) W::st(lds, T.kt_st4 + mb(kprev), W::to_d(Ktq));
+                else for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), W::to_d(Ktp.r[c]));
+            }
             W::pin();
             const vd *mm = LR.mm;
             vd p0 = mm[4] * mm[8], p1 = mm[3] * mm[8], p2 = mm[3] * mm[7];
@@ -773,7 +791,9 @@ struct RtiWave {
             vd nahi = cofu * T.adj_b;                         // B operand of K~': -adj[g][j-12] in columns 12..15
             W::pin();
             md tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
-            md4 G = mma(W::to_m(ladj), tt, W::mzero4());      // adj T
+            md G0;                                            // adj T, lane l: row l >> 4, column l & 15
+            if constexpr (MMA4) G0 = mma4(W::to_m(ladj), tt, W::to_m(vd(0.0)));
+            else G0 = mma(W::to_m(ladj), tt, W::mzero4()).r[0];
             W::pin();
             vd det = dq + W::csum2(dq);
             vd r0 = W::rcp_seed(det);
@@ -782,7 +802,7 @@ struct RtiWave {
             // 1/det = r0 (2 - det r0): v_rcp_f64 seed (4.5e-8) + ONE Newton step = 2.2e-15 (profiles/r01_ubench_mfma_latency.txt),
             // below the cofactors' own cond * eps.  The scale of Lam^-1 T is applied as (G r0) e0 so that G r0 runs beside e0.
             vd e0 = W::fma(-det, r0, vd(2.0));
-            vd g0 = W::to_d(G.r[0]) * r0;
+            vd g0 = W::to_d(G0) * r0;
             for (int r = 0; r < 2; ++r) ncc[r] = W::to_m(W::ld(lds, T.c_off[r] + cb(kp)));
             W::pin();
             vd gs = g0 * e0;                                  // Lam^-1 T
@@ -795,8 +815,9 @@ struct RtiWave {
             // column 12+b = rows 12..15 of the forward operand; stored behind the next stage's first MFMAs
             const md nli = W::to_m(nahi * rdet);
             if (linv) linv[k] = nli;
-            md4 Kt = mma(hux, nli, W::mzero4());
-            Ktp = Kt; kprev = k;
+            if constexpr (MMA4) Ktq = mma4(hux, nli, W::to_m(vd(0.0)));     // K~'[4b + i][j] in lane j + 4b + 16i
+            else Ktp = mma(hux, nli, W::mzero4());
+            kprev = k;
             if ((k & 7) == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
                 // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
@@ -810,28 +831,36 @@ struct RtiWave {
             for (int c = 0; c < 3; ++c) mk[c] = nmk[c];
             for (int r = 0; r < 4; ++r) cc[r] = ncc[r];
         }
-        if (kprev >= 0)
-            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), W::to_d(Ktp.r[c]));
+        if (kprev >= 0) {
+            if constexpr (MMA4) W::st(lds, T.kt_st4 + mb(kprev), W::to_d(Ktq));
+            else for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), W::to_d(Ktp.r[c]));
+        }
         {   // stage 0: only the gain is needed
             md hux = H.r[3];
             LamRegs LR;
             lam_gather(T, lds, W::to_d(hux), LR);
             vd cof = lam_cofactor(T, LR);
             vd rdet = lam_rdet(T, LR, cof, ok);
-            vd nahi = W::sel(T.kt_pred, -cof, vd(0.0));
+            vd nahi = MMA4 ? -cof : W::sel(T.kt_pred, -cof, vd(0.0));
             if (linv) linv[0] = W::to_m(nahi * rdet);
-            md4 Kt = mma(hux, W::to_m(nahi), W::mzero4());
-            for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c], W::to_d(Kt.r[c]) * rdet);
+            if constexpr (MMA4) {
+                W::st(lds, T.kt_st4, W::to_d(mma4(hux, W::to_m(nahi), W::to_m(vd(0.0)))) * rdet);
+            } else {
+                md4 Kt = mma(hux, W::to_m(nahi), W::mzero4());
+                for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c], W::to_d(Kt.r[c]) * rdet);
+            }
         }
         ok = W::all(okv) && ok;
         W::sync();
         if (io) stamp(*io, m, 6);
-        // forward rollout; z~ index 4c+g lives in chunk c of the lanes with j == 0
+        // forward rollout; z~ index 4c+g lives in chunk c of the lanes with j == 0 (MMA4: of every lane -- the four blocks of the
+        // 4x4x4 instruction each read their own copy of the vector)
         md zc[3];
         for (int c = 0; c < 3; ++c) {
             vi idx = g + 4 * c;
-            vd v = W::ldp(lds, idx + m.ZX, T.col0 && (idx < 10));
-            zc[c] = W::to_m(W::sel(T.col0 && (idx == 10), vd(1.0), v));
+            vb mine = MMA4 ? (lane >= 0) : T.col0;
+            vd v = W::ldp(lds, idx + m.ZX, mine && (idx < 10));
+            zc[c] = W::to_m(W::sel(mine && (idx == 10), vd(1.0), v));
         }
         // per stage: Y = [M~x ; K~] z~ (3 MFMAs) holds M~x z~ in rows 0..11 and du = K~ z~ in rows 12..15, i.e. du is
         // accumulator register 3 -- exactly the B operand of the 4th MFMA, which adds B~ du to rows 0..11.
@@ -845,13 +874,25 @@ struct RtiWave {
             for (int c = 0; c < 3; ++c) nfw[c] = W::to_m(W::ld(lds, T.fw_off[c] + mb(kn)));
             nmu = W::to_m(W::ld(lds, T.mu_off + mb(kn)));
             W::pin();   // keep the prefetch ahead of this stage's MFMAs (the scheduler otherwise sinks it behind them)
-            md4 Y = mman<3>(fw, zc, W::mzero4());
-            md du = Y.r[3];
-            md4 xn = mma(mu, du, Y);
-            W::st(lds, T.zu_st + k * int(NU), W::to_d(du));
-            for (int c = 0; c < 3; ++c) {
-                zc[c] = xn.r[c];
-                W::st(lds, T.zx_st[c] + (k + 1) * int(NX), W::to_d(xn.r[c]));
+            if constexpr (MMA4) {
+                // four 4x4x4 products (a matrix-VECTOR product needs one column): y[4b + i] in lane j + 4b + 16i, any j
+                md y = mma4(fw[0], zc[0], W::to_m(vd(0.0)));
+                y = mma4(fw[1], zc[1], y);
+                y = mma4(fw[2], zc[2], y);
+                md du = W::template rowb<3>(y);                      // rows 12..15 = K~ z~, as the next product's B operand
+                md xn = mma4(mu, du, y);
+                W::st(lds, T.zu_st + k * int(NU), W::to_d(du));
+                W::st(lds, T.zx_st4 + (k + 1) * int(NX), W::to_d(xn));
+                zc[0] = W::template rowb<0>(xn); zc[1] = W::template rowb<1>(xn); zc[2] = W::template rowb<2>(xn);
+            } else {
+                md4 Y = mman<3>(fw, zc, W::mzero4());
+                md du = Y.r[3];
+                md4 xn = mma(mu, du, Y);
+                W::st(lds, T.zu_st + k * int(NU), W::to_d(du));
+                for (int c = 0; c < 3; ++c) {
+                    zc[c] = xn.r[c];
+                    W::st(lds, T.zx_st[c] + (k + 1) * int(NX), W::to_d(xn.r[c]));
+                }
             }
             for (int c = 0; c < 3; ++c) fw[c] = nfw[c];
             mu = nmu;
@@ -869,7 +910,7 @@ struct RtiWave {
     //   forward:   du_k = K~_k dx_k + dk_k,  dx_{k+1} = A_k dx_k + B_k du_k,  dx_0 = 0      (the 4 MFMAs of the full forward sweep)
     // and ZX|ZU += (dx, du).  No 4x4 inverse, no cost blocks: ~0.55 of a full sweep.  Needs -Lam_k^-1 of every stage (riccati_sweep's
     // linv, in registers: compile-time horizons) and K~' where the sweep left it in LDS.
-    struct DeltaTabs { vi dc_off[4], kta_off; md eye12; vb row10; };
+    struct DeltaTabs { vi dc_off[4], kta_off, dc_off4; md eye12, m12; vb row10, g2; };
     static NDP_D void build_delta_tabs(const LdsMap &m, DeltaTabs &D)
     {
         vi lane = W::lane();
@@ -883,6 +924,11 @@ struct RtiWave {
         D.kta_off = W::sel(j < 10, j * 4 + g + m.KT, vi(m.MB + int(MB_ZERO)));     // K~'[j][g] as A operand, rows 10..15 read a structural 0
         D.eye12 = W::to_m(W::sel((j >= 12) && (j - 12 == g), vd(1.0), vd(0.0)));
         D.row10 = c0 && (g == 2);                                                  // row 10 = g + 4r with g = 2, r = 2
+        // 4x4x4 form: dc of row x = 4b + i in lane j + 4b + 16i; riccati_sweep's linv is then unmasked (-Lam^-1 in every lane)
+        vi x4 = ((lane >> 2) & 3) * 4 + g;
+        D.dc_off4 = W::sel((x4 >= 3) && (x4 < 6), x4 + (m.CB + int(CB_QE)), W::sel(x4 >= 12, x4 + (m.CB + int(CB_RE) - 12), vi(m.CB + int(CB_ZERO))));
+        D.m12 = W::to_m(W::sel(j >= 12, vd(1.0), vd(0.0)));
+        D.g2 = g == 2;
     }
 
     static NDP_D void delta_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, const DeltaTabs &D, lp lds, const md *linv)
@@ -890,6 +936,42 @@ struct RtiWave {
         const int N = horizon(P);
         md vc[3] = {W::to_m(vd(0.0)), W::to_m(vd(0.0)), W::to_m(vd(0.0))};
         md dk[NC > 0 ? NC : 1];
+        if constexpr (MMA4) {
+            // every product here is matrix x vector: the 4x4x4 instruction, vectors as chunk registers replicated over the columns
+            NDP_UNROLL_STAGES
+            for (int k = N - 1; k >= 0; --k) {
+                md Dg = W::to_m(W::ld(lds, D.dc_off4 + cb(k)));
+                md a[3];
+                for (int c = 0; c < 3; ++c) a[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(k)));
+                md akl = W::to_m(W::ld(lds, D.kta_off + mb(k))) + W::fma(linv[k], D.m12, -D.eye12);
+                if (k != N - 1)
+                    for (int c = 0; c < 3; ++c) Dg = mma4(a[c], vc[c], Dg);
+                md Dp = mma4(akl, W::template rowb<3>(Dg), Dg);
+                dk[k] = W::template rowb<3>(Dp);
+                vc[0] = W::template rowb<0>(Dp); vc[1] = W::template rowb<1>(Dp);
+                vc[2] = W::msel(D.g2, W::to_m(vd(0.0)), W::template rowb<2>(Dp));   // the constant-term row must not feed back
+            }
+            md zc[3] = {W::to_m(vd(0.0)), W::to_m(vd(0.0)), W::to_m(vd(0.0))};
+            NDP_UNROLL_STAGES
+            for (int k = 0; k < N; ++k) {
+                md fw[3], mu;
+                for (int c = 0; c < 3; ++c) fw[c] = W::to_m(W::ld(lds, T.fw_off[c] + mb(k)));
+                mu = W::to_m(W::ld(lds, T.mu_off + mb(k)));
+                vd zu0 = W::ld(lds, T.zu_st + k * int(NU));
+                vd zx0 = W::ld(lds, T.zx_st4 + (k + 1) * int(NX));
+                md y = W::to_m(vd(0.0)), du = dk[k];
+                if (k != 0) {
+                    for (int c = 0; c < 3; ++c) y = mma4(fw[c], zc[c], y);
+                    du = W::template rowb<3>(y) + dk[k];
+                }
+                md xn = mma4(mu, du, y);
+                W::st(lds, T.zu_st + k * int(NU), zu0 + W::to_d(du));
+                W::st(lds, T.zx_st4 + (k + 1) * int(NX), zx0 + W::to_d(xn));
+                zc[0] = W::template rowb<0>(xn); zc[1] = W::template rowb<1>(xn); zc[2] = W::template rowb<2>(xn);
+            }
+            W::sync();
+            return;
+        }
         NDP_UNROLL_STAGES
         for (int k = N - 1; k >= 0; --k) {
             md4 C;
@@ -1286,7 +1368,7 @@ struct LaneW {
     struct vd4 { double r[4]; };
     using md = double;
     using md4 = vd4;
-    static constexpr bool packed_k = false, delta_ok = true;
+    static constexpr bool packed_k = false, delta_ok = true, has_mma4 = true;
     using lds_ptr = double *;
     // host-only on purpose (no device attribute): only fill_tables, a host function, instantiates code that calls them
     static int &cur() { static thread_local int l = 0; return l; }

@@ -18,7 +18,7 @@ struct WaveGfx950 {
     // matrix values of the Riccati sweeps (RtiWave::md): this backend's instruction is v_mfma_f64_16x16x4_f64
     using md = double;
     using md4 = vd4;
-    static constexpr bool packed_k = false, delta_ok = true;
+    static constexpr bool packed_k = false, delta_ok = true, has_mma4 = true;
     static NDP_D md to_m(vd a) { return a; }
     static NDP_D vd to_d(md a) { return a; }
     static NDP_D md4 mzero4() { return zero4(); }
@@ -159,6 +159,22 @@ struct WaveGfx950 {
         d.r[0] = acc[0]; d.r[1] = acc[1]; d.r[2] = acc[2]; d.r[3] = acc[3];
         return d;
     }
+    // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products, one per block b = (l >> 2) & 3 -- block b's A[i][k] in lane
+    // i + 4b + 16k, B[k][j] in lane j + 4b + 16k, D[i][j] in lane j + 4b + 16i (scripts/ubench/mfma_f64_4x4x4.hip;
+    // tests/test_gpu_parity.py::test_mfma_register_maps).  Read as ONE product it is (16x4 A, rows i + 4b) x (4x4 B shared by
+    // the blocks) or (4x4 A shared) x (4x16 B, columns j + 4b) with the operands exactly where the 16x16x4 form keeps them:
+    // a quarter of the work in a quarter of the time (18 cycles issue, 44 dependent, against 64) wherever one side of a product
+    // is only four wide -- the gains, adj(Lam) T, and every matrix-vector product of the forward / second-solve sweeps.
+    static NDP_D md mfma4(md a, md b, md c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+    // lane 4Q of every 16-lane row to all lanes of the row (DPP row_newbcast): column 0 of block Q of a mfma4 result
+    // becomes the B operand "vector element k = l >> 4, the same in every column" of the next one
+    template <int Q>
+    static NDP_D md rowb(md a)
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), 0x150 + 4 * Q, 0xF, 0xF, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), 0x150 + 4 * Q, 0xF, 0xF, false);
+        return __hiloint2double(hi, lo);
+    }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -173,7 +189,7 @@ struct WaveGfx950F32 : WaveGfx950 {
     using md = float;
     struct md4 { float r[4]; };
     typedef float f4_t __attribute__((ext_vector_type(4)));
-    static constexpr bool packed_k = false, delta_ok = false;
+    static constexpr bool packed_k = false, delta_ok = false, has_mma4 = false;
     static NDP_D md to_m(vd a) { return (float)a; }
     static NDP_D vd to_d(md a) { return (double)a; }
     static NDP_D md4 mzero4() { md4 z; z.r[0] = z.r[1] = z.r[2] = z.r[3] = 0.0f; return z; }

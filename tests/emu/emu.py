@@ -51,14 +51,14 @@ def rti_step(cfg, x0, xr, ur, f, X, U, dump=False):
     assert X.dtype == np.float64 and U.dtype == np.float64 and X.flags.c_contiguous and U.flags.c_contiguous
     u0 = np.zeros(4)
     status, iters = C.c_int(-1), C.c_int(-1)
-    counters = (C.c_long * 4)()
+    counters = (C.c_long * 5)()
     n = lib().emu_lds_doubles(cfg.N)
     lds = np.zeros(n) if dump else None
     rc = lib().emu_rti_step(C.byref(cfg), _p(x0), _p(xr), _p(ur), _p(f), _p(X), _p(U), _p(u0),
                             C.byref(status), C.byref(iters), _p(lds), counters)
     assert rc == 0
     return u0, status.value, iters.value, lds, dict(mfma=counters[0], lds_ld=counters[1], lds_st=counters[2],
-                                                   readlane=counters[3])
+                                                   readlane=counters[3], mfma4=counters[4])
 
 
 def rti_step_defer(cfg, x0, xr, ur, f, X, U):

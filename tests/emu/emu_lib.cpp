@@ -13,7 +13,7 @@ int emu_lds_doubles(int N) { return ndp::lds_doubles(N) + ndp::DBG_EXTRA; }
 
 int emu_lds_layout(int N, int *out8) { ndp::lds_layout(N, out8); return 0; }
 
-// One instance, one emulated wave.  counters: [mfma, lds_ld, lds_st, readlane]
+// One instance, one emulated wave.  counters: [mfma (16x16x4), lds_ld, lds_st, readlane, mfma4 (4x4x4, four blocks)]
 int emu_rti_step(const ndp_cfg *cfg, const double *x0, const double *xr, const double *ur, const float *f,
                  double *X, double *U, double *u0, int *status, int *iters, double *lds_dump, long *counters)
 {
@@ -42,6 +42,7 @@ int emu_rti_step(const ndp_cfg *cfg, const double *x0, const double *xr, const d
     if (counters) {
         counters[0] = emu::stats().mfma; counters[1] = emu::stats().lds_ld;
         counters[2] = emu::stats().lds_st; counters[3] = emu::stats().readlane;
+        counters[4] = emu::stats().mfma4;
     }
     return 0;
 }

@@ -61,7 +61,7 @@ inline vb operator==(const vi &a, int b) { return a == vi(b); }
 inline vd operator-(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = -a.v[l]; return o; }
 inline vb operator!(const vb &a) { vb o; for (int l = 0; l < 64; ++l) o.v[l] = !a.v[l]; return o; }
 
-struct Stats { long mfma = 0, lds_ld = 0, lds_st = 0, readlane = 0; };
+struct Stats { long mfma = 0, lds_ld = 0, lds_st = 0, readlane = 0, mfma4 = 0; };
 inline Stats &stats() { static thread_local Stats s; return s; }
 
 struct Wave {
@@ -73,7 +73,7 @@ struct Wave {
     // matrix values of the Riccati sweeps (RtiWave::md): the f64 instruction
     using md = emu::vd;
     using md4 = emu::vd4;
-    static constexpr bool packed_k = false, delta_ok = true;
+    static constexpr bool packed_k = false, delta_ok = true, has_mma4 = true;
     static vd to_m(const vd &a) { return a; }
     static vd to_d(const vd &a) { return a; }
     static vd4 mzero4() { return zero4(); }
@@ -173,6 +173,21 @@ struct Wave {
             }
         return d;
     }
+    // v_mfma_f64_4x4x4_4b_f64: block b = (l >> 2) & 3; A[i][k] lane i + 4b + 16k, B[k][j] lane j + 4b + 16k, D[i][j] lane j + 4b + 16i
+    static vd mfma4(const vd &a, const vd &b, const vd &c)
+    {
+        stats().mfma4++;
+        vd d;
+        for (int l = 0; l < 64; ++l) {
+            const int j = l & 3, blk = (l >> 2) & 3, i = l >> 4;
+            double acc = c.v[l];
+            for (int k = 0; k < 4; ++k) acc = std::fma(a.v[i + 4 * blk + 16 * k], b.v[j + 4 * blk + 16 * k], acc);
+            d.v[l] = acc;
+        }
+        return d;
+    }
+    template <int Q>
+    static vd rowb(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[(l & 48) + 4 * Q]; return o; }   // DPP row_newbcast:4Q
 };
 
 // The fp32 / bf16 backends of BASELINE config 5 (wave_gfx950.hpp: WaveGfx950F32, WaveGfx950BF16) emulated: matrix values are
@@ -188,7 +203,7 @@ inline float bf16r(float f)
 }
 
 struct Wave32 : Wave {
-    static constexpr bool packed_k = false, delta_ok = false;
+    static constexpr bool packed_k = false, delta_ok = false, has_mma4 = false;
     static vd to_m(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)f32(a.v[l]); return o; }
     static vd mavg(const vd &a, const vd &b) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)((f32(a.v[l]) + f32(b.v[l])) * 0.5f); return o; }
     static vi lcol(const vi &lane) { vi o; for (int l = 0; l < 64; ++l) { const int jt = lane.v[l] & 15; o.v[l] = (jt >> 2) + 4 * (jt & 3); } return o; }
