@@ -231,8 +231,10 @@ int ndp_rollout_device(ndp_handle *h, int ticks, double t0, double dt_tick, int 
 int ndp_debug_lds_doubles(int N);
 /* Test hook: where things sit in that dump: out8 = {XI, MB, CB, MB stride, CB stride, image size, first stamp, 0} (doubles). */
 int ndp_debug_lds_layout(int N, int *out8);
-/* Test hook: one v_mfma_f64_16x16x4_f64 on caller-chosen per-lane operands a[64], b[64], c[4][64];
- * d[0..255] = result registers [4][64], d[256..319] = a cross-lane checksum (readlane + wave reductions). */
+/* Test hook: one v_mfma_f64_16x16x4_f64 on caller-chosen per-lane operands a[64], b[64], c[4][64]; d has 640 doubles:
+ * d[0..255] = result registers [4][64], d[256..319] = a cross-lane checksum (readlane + wave reductions),
+ * d[320..383] = one v_mfma_f64_4x4x4_4b_f64 (four blocks) on a, b with accumulator c[0], d[384..639] = a after the row
+ * broadcasts of lanes 0, 4, 8, 12 of every 16-lane row (DPP row_newbcast). */
 int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, double *d);
 /* Test hook: the config-5 instructions through their backends.  mode 0: one v_mfma_f32_16x16x4_f32 on a[0][64], b[0][64];
  * mode 1: one v_mfma_f32_16x16x16_bf16 on four packed contraction steps a[4][64], b[4][64]; c[4][64] -> d[0..255];

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(KernArgs ka)
     }
 }
 
-// test hook: one v_mfma_f64_16x16x4_f64 with caller-chosen per-lane operands (pins the register maps)
+// test hook: one v_mfma_f64_16x16x4_f64 / v_mfma_f64_4x4x4_4b_f64 with caller-chosen per-lane operands (pins the register maps)
 __global__ void mfma_probe_kernel(const double *a, const double *b, const double *c, double *d)
 {
     const int l = (int)threadIdx.x;
@@ -205,6 +205,12 @@ __global__ void mfma_probe_kernel(const double *a, const double *b, const double
     acc = WaveGfx950::mfma(a[l], b[l], acc);
     for (int r = 0; r < 4; ++r) d[r * 64 + l] = acc.r[r];
     d[256 + l] = WaveGfx950::readlane(a[l], 37) + WaveGfx950::wave_sum(b[l]) + WaveGfx950::wave_min(a[l]) + WaveGfx950::wave_max(a[l]);
+    // the four-block v_mfma_f64_4x4x4_4b_f64 on the same operands (accumulator: c's first register) and the four row broadcasts
+    d[320 + l] = WaveGfx950::mfma4(a[l], b[l], c[l]);
+    d[384 + l] = WaveGfx950::rowb<0>(a[l]);
+    d[448 + l] = WaveGfx950::rowb<1>(a[l]);
+    d[512 + l] = WaveGfx950::rowb<2>(a[l]);
+    d[576 + l] = WaveGfx950::rowb<3>(a[l]);
 }
 
 // test hook: one v_mfma_f32_16x16x4_f32 (mode 0) or one v_mfma_f32_16x16x16_bf16 (mode 1: four packed contraction steps)
@@ -972,13 +978,13 @@ int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, doub
 {
     double *da = nullptr, *db = nullptr, *dc = nullptr, *dd = nullptr;
     if (hipMalloc((void **)&da, 64 * 8) != hipSuccess || hipMalloc((void **)&db, 64 * 8) != hipSuccess ||
-        hipMalloc((void **)&dc, 256 * 8) != hipSuccess || hipMalloc((void **)&dd, 320 * 8) != hipSuccess)
+        hipMalloc((void **)&dc, 256 * 8) != hipSuccess || hipMalloc((void **)&dd, 640 * 8) != hipSuccess)
         return -1;
     (void)hipMemcpy(da, a, 64 * 8, hipMemcpyHostToDevice);
     (void)hipMemcpy(db, b, 64 * 8, hipMemcpyHostToDevice);
     (void)hipMemcpy(dc, c, 256 * 8, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, 0, da, db, dc, dd);
-    const hipError_t e = hipMemcpy(d, dd, 320 * 8, hipMemcpyDeviceToHost);
+    const hipError_t e = hipMemcpy(d, dd, 640 * 8, hipMemcpyDeviceToHost);
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dd);
     return e == hipSuccess ? 0 : -2;
 }

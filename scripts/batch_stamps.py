@@ -23,15 +23,18 @@ for _ in range(3):
     eng.update_device(d["x0"], d["xr"], d["ur"], u0, **kw)
 eng.synchronize()
 t = eng.debug_stamps(False, read=True)
-names = ['start', 'tables', 'stage_in', 'cost', 'linearize', 'pre_sweep', 'backward', 'forward', 'end']
-t0 = t[:, 9].min() if downwash else t[:, 0].min()
-print(f"B={B} downwash={downwash}: all times in shader-clock ticks relative to the first wave's first stamp")
-if downwash:
-    print("kernel entry (stamp 9)    : min %d median %d max %d" % tuple(np.percentile(t[:, 9] - t0, [0, 50, 100])))
-    print("fragments staged (11)-(9) : min %d median %d max %d" % tuple(np.percentile(t[:, 11] - t[:, 9], [0, 50, 100])))
-    print("mlp tile (10)-(11)        : min %d median %d max %d" % tuple(np.percentile(t[:, 10] - t[:, 11], [0, 50, 100])))
-    print("mlp end -> rti start      : median %d" % np.median(t[:, 0] - t[:, 10]))
-for i in range(1, 9):
-    dphase = t[:, i] - t[:, i - 1]
-    print("%-26s: min %d median %d max %d" % ((names[i],) + tuple(np.percentile(dphase, [0, 50, 100]))))
-print("last stamp (end)          : min %d median %d max %d" % tuple(np.percentile(t[:, 8] - t0, [0, 50, 100])))
+# stamps: 9 kernel entry (fused), 0 program start, 1 tables requested, 2 inputs committed, 3 cost blocks, 11 / 10 downwash tile
+# start / end (fused), 4 linearised, 5 sweep start, 6 backward done, 7 forward done, 8 end.  With a compile-time horizon the fused
+# kernel computes the tile between the cost and the linearisation phase (the weight fragments are staged under the first phases);
+# otherwise before the program starts -- the phases are printed in the order the stamps were taken.
+label = {9: 'kernel entry', 0: 'program start', 1: 'tables', 2: 'stage_in', 3: 'cost', 11: 'fragments staged / barrier', 10: 'mlp tile',
+         4: 'linearize', 5: 'pre_sweep', 6: 'backward', 7: 'forward', 8: 'end'}
+ids = [i for i in (([9, 11, 10] if downwash else []) + list(range(9)))]
+ids.sort(key=lambda i: np.median(t[:, i] - t[:, 0]))
+t0 = t[:, ids[0]].min()
+print(f"B={B} downwash={downwash}: shader-clock ticks; each line = time since the previous stamp, stamps in the order they were taken")
+print("%-28s: min %d median %d max %d   (relative to the first wave's first stamp)" % ((label[ids[0]],) + tuple(np.percentile(t[:, ids[0]] - t0, [0, 50, 100]))))
+for a_, b_ in zip(ids[:-1], ids[1:]):
+    dphase = t[:, b_] - t[:, a_]
+    print("%-28s: min %d median %d max %d" % ((label[b_],) + tuple(np.percentile(dphase, [0, 50, 100]))))
+print("%-28s: min %d median %d max %d" % (("whole wave program",) + tuple(np.percentile(t[:, 8] - t[:, ids[0]], [0, 50, 100]))))

@@ -37,7 +37,7 @@ def _oracle_batch(oracle, b, N=20, n_rti=1, use_fd=False, f=None, X=None, U=None
 
 
 def test_mfma_register_maps(ndp):
-    """v_mfma_f64_16x16x4_f64 operand / result layouts are what rti_wave.hpp (and the emulator) assume."""
+    """v_mfma_f64_16x16x4_f64 and v_mfma_f64_4x4x4_4b_f64 operand / result layouts are what rti_wave.hpp (and the emulator) assume."""
     from ndp_nmpc_qd_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(0)
@@ -46,14 +46,22 @@ def test_mfma_register_maps(ndp):
     a = np.array([A[l & 15, l >> 4] for l in range(64)])
     b = np.array([Bm[l >> 4, l & 15] for l in range(64)])
     c = np.array([[Cm[(l >> 4) + 4 * r, l & 15] for l in range(64)] for r in range(4)])
-    d = np.zeros(320)
+    d = np.zeros(640)
     assert lib.ndp_debug_mfma_probe(_lib.ptr(a), _lib.ptr(b), _lib.ptr(np.ascontiguousarray(c)), _lib.ptr(d)) == 0
     D = A @ Bm + Cm
     got = d[:256].reshape(4, 64)
     for r in range(4):
         for l in range(64):
             assert got[r, l] == D[(l >> 4) + 4 * r, l & 15], (r, l)
-    np.testing.assert_allclose(d[256:], a[37] + b.sum() + a.min() + a.max(), atol=0)
+    np.testing.assert_allclose(d[256:320], a[37] + b.sum() + a.min() + a.max(), atol=0)
+    # v_mfma_f64_4x4x4_4b_f64 on the same registers: block q = (l >> 2) & 3 multiplies A rows 4q..4q+3 (lane i + 4q + 16k)
+    # with B columns 4q..4q+3 (lane j + 4q + 16k); D_q[i][j] lands in lane j + 4q + 16i (tests/emu/wave_emu.hpp: Wave::mfma4)
+    for l in range(64):
+        j, q, i = l & 3, (l >> 2) & 3, l >> 4
+        assert d[320 + l] == A[4 * q + i, :] @ Bm[:, 4 * q + j] + c[0][l], l
+    for q in range(4):      # DPP row_newbcast:4q
+        for l in range(64):
+            assert d[384 + 64 * q + l] == a[(l & 48) + 4 * q], (q, l)
 
 
 @pytest.mark.parametrize("qp_mode", [0, 1])
