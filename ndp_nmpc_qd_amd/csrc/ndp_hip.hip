@@ -168,7 +168,10 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(KernArgs ka)
         stage_fragments(ma.frag, wl, (int)threadIdx.x, 64 * WAVES);
         __syncthreads();
         if (io.stamps && lane == 0) io.stamps[11] = (double)__builtin_amdgcn_s_memtime();
-        mlp_tile(wl, zb, lane, o);
+        // gate closed (or no neighbour): the force is zero and the reference does not evaluate the network either
+        // (ndp_nmpc_leader_node.py:66-76).  The test is the same in every lane: a wave-uniform branch around the tile.
+        o[0] = o[1] = o[2] = 0.0f;
+        if (__builtin_amdgcn_readfirstlane((int)open)) mlp_tile(wl, zb, lane, o);
         __syncthreads();                              // every wave is done with the weights before LDS becomes RTI state
         if (!active) return;
         if (io.dbg && lane == 0) io.dbg[m.total + 10] = (double)__builtin_amdgcn_s_memtime();
