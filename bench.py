@@ -106,6 +106,11 @@ def main():
     ap.add_argument("--graph-exchange", action="store_true",
                     help="N > 1 with the exchange on: capture gather + kernel of every step into the hipGraph too (default: host launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: bounded sample, about this many seconds")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "rccl"],
+                    help="N > 1, vehicle-major placement: how a rank gets its neighbours' reference windows.  peer: it maps the "
+                         "neighbour rank's window buffer once (IPC handle) and the control-step kernel reads it over xGMI -- no "
+                         "per-step collective, steps replayed as a hipGraph like at N = 1; rccl: one all-gather of the "
+                         "position/velocity columns per step; auto: peer, falling back to rccl if the mapping fails on any rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,11 +123,20 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    # NDP_BENCH_SAME_DEVICE=1 (mechanics check on a one-GPU box): every rank on device 0, control-plane collectives over gloo
+    # -- RCCL refuses two ranks on one device, so only --exchange peer and --placement formation run in that mode
+    same_dev = os.environ.get("NDP_BENCH_SAME_DEVICE", "0") == "1"
+    if same_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if same_dev else dev       # where the few control-plane tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if same_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import ndp_nmpc_qd_amd as ndp
     from ndp_nmpc_qd_amd import dist as ndist
@@ -161,6 +175,24 @@ def main():
     # neighbour row through other_index.  Two gather buffers: the gather of tick i+1's windows (functions of time only) is
     # started before tick i's kernel is launched and runs on RCCL's stream beside it.
     exchange = downwash and args.placement == "vehicle" and (world > 1 or cfg4)
+    # peer windows (N > 1): map the neighbour rank's published windows once; no per-step exchange call
+    peer, exchange_mode = None, ("rccl all-gather per step" if exchange and world > 1 else "none")
+    if exchange and world > 1 and args.exchange in ("auto", "peer"):
+        try:
+            peer = ndist.PeerWindows(B, N, T, local_rank)
+            for t in range(T):
+                peer.local[t].copy_(ticks[t]["xr"])
+            peer.publish()
+            exchange, exchange_mode = False, "peer windows over xGMI (mapped once, read by the kernel)"
+            if cfg4:
+                nb_row = ndist.config4_other_index(rank, world, args.formations, "vehicle", peer_rows=True)
+                peer_oidx = torch.from_numpy(nb_row).to(dev)
+        except Exception as e:                                    # same outcome on every rank (PeerWindows exchanges the result)
+            if args.exchange == "peer":
+                raise
+            peer, exchange_mode = None, f"rccl all-gather per step (peer mapping failed: {type(e).__name__}: {e})"[:200]
+    if same_dev and exchange and world > 1:
+        raise SystemExit("NDP_BENCH_SAME_DEVICE=1 cannot run the RCCL exchange (two ranks on one device)")
     if exchange:
         gathered = [torch.empty(world * B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev) for _ in range(2)]
         pv_local = torch.empty(B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev)
@@ -184,6 +216,9 @@ def main():
                 else:
                     other = gathered[i % 2].view(world, B, N + 1, ndist.PV_COLS)[ndist.neighbour_rank(rank, world)]
                 prefetch(i + 1)
+            elif peer is not None:
+                other = peer.neighbour[i % T]                # the neighbour rank's windows, read over xGMI by the kernel
+                oidx = peer_oidx if cfg4 else None
             elif cfg4:
                 other, oidx = d["xr"], d["other_index"]      # formation-major: the neighbour's window is a local row of xr
             else:
@@ -292,7 +327,7 @@ def main():
             step(i)
         fence()
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     rti_ms, rti_n = eng.timing_read("rti")
@@ -303,7 +338,7 @@ def main():
     frac_ipm = float((it > 0).mean()) if args.qp_mode == 0 else 1.0
     sweeps = float(np.mean(np.where(it > 0, 1 + 2 * it, 1))) if args.qp_mode == 0 else float(np.mean(2 * it))
     if world > 1:
-        agg = torch.tensor([bad], dtype=torch.int64, device=dev)
+        agg = torch.tensor([bad], dtype=torch.int64, device=cdev)
         dist.all_reduce(agg)
         bad = int(agg.item())
 
@@ -376,11 +411,12 @@ def main():
                                    + ("MLP downwash on (NDP controller, gate+MLP fused into the RTI launch)" if fused else
                                       "MLP downwash on (NDP controller)" if downwash else "no downwash (NMPC controller)")
                                    + (", neighbour windows all-gathered over RCCL" if exchange and world > 1 else
+                                      ", neighbour windows read from the neighbour rank's HBM over xGMI (peer windows, mapped once)" if peer is not None else
                                       ", vehicle-major placement (position/velocity columns packed for the all-gather; one rank: no RCCL call)" if exchange else
                                       ", formation-major placement (no exchange)" if (world > 1 or cfg4) else "")
                                    + (", perturbed starts (~20 % of the instances need the interior-point loop)" if args.perturb == "mixed" else ""),
                        "batch_per_gpu": B, "horizon": N, "n_rti": 1, "qp_mode": "auto" if args.qp_mode == 0 else "ipm_always",
-                       "work_queue": eng.work_queue, "launch": launch_mode,
+                       "work_queue": eng.work_queue, "launch": launch_mode, "neighbour_exchange": exchange_mode,
                        "parallelism": f"instances sharded x{world}"},
             "roofline": {"kernel": "rti_kernel", "bound": "mfma", "achieved": ach_tf, "peak": F64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach_tf / F64_MFMA_PEAK_TFLOPS, "traffic": prof["traffic"],
@@ -517,7 +553,7 @@ def main():
     else:
         fail = False
     if world > 1:
-        flag = torch.tensor([int(fail)], dtype=torch.int64, device=dev)
+        flag = torch.tensor([int(fail)], dtype=torch.int64, device=cdev)
         dist.broadcast(flag, 0)
         fail = bool(flag.item())
         dist.destroy_process_group()

@@ -227,6 +227,22 @@ int ndp_plant_step_device(ndp_handle *h, void *d_x, const void *d_u, const void 
  * enqueued back to back on the stream; nothing returns to the host in between, nothing is synchronised. */
 int ndp_rollout_device(ndp_handle *h, int ticks, double t0, double dt_tick, int substeps, void *d_x, void *d_log, void *stream);
 
+/* ---- Peer windows: the neighbour exchange across GPUs as publish / subscribe over xGMI.
+ * Replaces the PredXU topic between processes: the publisher is nmpc_node.py:116-133 (`nmpc_x_ref`, 21x10 float64 per tick), the
+ * subscriber ndp_nmpc_leader_node.py:40,60-76.  One process per GPU: the publisher allocates its window buffer with
+ * ndp_peer_alloc and sends the 64-byte handle to the subscriber's process (any channel: torch.distributed object collectives,
+ * a socket); the subscriber maps it with ndp_peer_open and passes the mapped pointer as `other` of ndp_step_device[_ex] --
+ * the control-step kernel then reads the neighbour's windows out of the publisher's HBM (peer access), no per-step
+ * collective.  Ordering between the publisher's writes and the subscriber's reads is the caller's (events / barriers), as
+ * it is between a ROS publisher and its subscriber.
+ *   ndp_peer_alloc: bytes of device memory on `device` -> *ptr and its handle (64 bytes).
+ *   ndp_peer_open : maps another process's buffer into this process for use on `device` -> *ptr.
+ *   ndp_peer_close / ndp_peer_free: undo open / alloc.   All return 0 or a negative error code. */
+int ndp_peer_alloc(int device, size_t bytes, void **ptr, unsigned char *handle64);
+int ndp_peer_open(int device, const unsigned char *handle64, void **ptr);
+int ndp_peer_close(int device, void *ptr);
+int ndp_peer_free(int device, void *ptr);
+
 /* Test hook: number of doubles of the LDS image dump, and a step that also dumps it (B = 1 use). */
 int ndp_debug_lds_doubles(int N);
 /* Test hook: where things sit in that dump: out8 = {XI, MB, CB, MB stride, CB stride, image size, first stamp, 0} (doubles). */

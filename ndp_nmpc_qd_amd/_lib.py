@@ -42,6 +42,7 @@ EXPORTS = [
     "ndp_ref_set_trajectory", "ndp_ref_window", "ndp_ref_window_device", "ndp_rollout_device",
     "ndp_step_ex", "ndp_step_device_ex", "ndp_work_queue_enabled", "ndp_ref_list_reset", "ndp_ref_list_fix_pt",
     "ndp_ref_list_window", "ndp_ref_list_advance_device", "ndp_ref_list_window_device", "ndp_debug_mfma_probe_f32",
+    "ndp_peer_alloc", "ndp_peer_open", "ndp_peer_close", "ndp_peer_free",
 ]
 
 _lib = None
@@ -98,6 +99,10 @@ def load():
     lib.ndp_step_debug.argtypes = [vp] * 9
     lib.ndp_debug_mfma_probe.argtypes = [vp] * 4
     lib.ndp_debug_mfma_probe_f32.argtypes = [vp] * 4 + [C.c_int]
+    lib.ndp_peer_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(vp), vp]
+    lib.ndp_peer_open.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    lib.ndp_peer_close.argtypes = [C.c_int, vp]
+    lib.ndp_peer_free.argtypes = [C.c_int, vp]
     lib.ndp_debug_stamps.argtypes = [vp, C.c_int, vp]
     lib.ndp_throttle_reset.argtypes = [vp]
     lib.ndp_throttle_update.argtypes = [vp] * 4

@@ -1007,6 +1007,51 @@ int ndp_debug_mfma_probe_f32(const float *a, const float *b, const float *c, flo
     return e == hipSuccess ? 0 : -2;
 }
 
+// ------------------------------------------------------------------------------------------ peer windows (multi-GPU)
+// The reference's neighbour exchange is publish / subscribe of the 21x10 float64 reference window (PredXU: nmpc_node.py:116-133
+// publishes, ndp_nmpc_leader_node.py:40,60-76 subscribes).  One process per GPU: the publisher keeps its windows in a buffer
+// whose IPC handle it hands to the subscriber's process once; the subscriber maps it and its control-step kernel reads the
+// neighbour's window straight out of the publisher's HBM over xGMI (peer access) -- no per-step collective, no extra launch.
+int ndp_peer_alloc(int device, size_t bytes, void **ptr, unsigned char *handle64)
+{
+    if (!ptr || !handle64 || bytes == 0) return -1;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "ndp_peer_*: the handle is passed as 64 bytes");
+    if (hipSetDevice(device) != hipSuccess) return -2;
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return -3;
+    hipIpcMemHandle_t hd;
+    if (hipIpcGetMemHandle(&hd, p) != hipSuccess) { (void)hipFree(p); return -4; }
+    memcpy(handle64, &hd, 64);
+    *ptr = p;
+    return 0;
+}
+
+int ndp_peer_open(int device, const unsigned char *handle64, void **ptr)
+{
+    if (!ptr || !handle64) return -1;
+    if (hipSetDevice(device) != hipSuccess) return -2;
+    hipIpcMemHandle_t hd;
+    memcpy(&hd, handle64, 64);
+    void *p = nullptr;
+    if (hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return -3; }
+    *ptr = p;
+    return 0;
+}
+
+int ndp_peer_close(int device, void *ptr)
+{
+    if (!ptr) return -1;
+    if (hipSetDevice(device) != hipSuccess) return -2;
+    return hipIpcCloseMemHandle(ptr) == hipSuccess ? 0 : -3;
+}
+
+int ndp_peer_free(int device, void *ptr)
+{
+    if (!ptr) return -1;
+    if (hipSetDevice(device) != hipSuccess) return -2;
+    return hipFree(ptr) == hipSuccess ? 0 : -3;
+}
+
 int ndp_destroy(ndp_handle *h)
 {
     if (!h) return -1;

@@ -107,12 +107,15 @@ def config4_gids(rank, world, n_form, placement):
     return g.astype(np.int64), bl
 
 
-def config4_other_index(rank, world, n_form, placement):
+def config4_other_index(rank, world, n_form, placement, peer_rows=False):
     """int32[B_local]: row of the neighbour buffer holding each local instance's neighbour (-1 = none).  The buffer is the
-    all-gathered [W * B_local, N+1, 6] array (vehicle-major) or the local xr [B_local, N+1, 10] (formation-major)."""
+    all-gathered [W * B_local, N+1, 6] array (vehicle-major), the local xr [B_local, N+1, 10] (formation-major), or -- vehicle-major
+    with peer_rows -- the window buffer of rank (r+1) % W (PeerWindows.neighbour: a leader's neighbour g + 1 always lives there)."""
     g, bl = config4_gids(rank, world, n_form, placement)
     nb = np.where(g % 3 == 0, g + 1, -1)                   # leaders read vehicle 1 of their formation; followers nobody
-    if placement == "vehicle":
+    if placement == "vehicle" and peer_rows:
+        row = nb // world
+    elif placement == "vehicle":
         row = (nb % world) * bl + nb // world
     else:
         row = nb - rank * bl
@@ -163,3 +166,81 @@ def exchange_pv_begin(xr_local, pv_local, gathered, group=None):
 def exchange_pv_end(work):
     if work is not None:
         work.wait()
+
+
+# ------------------------------------------------------------------------------------------- peer windows (pull model)
+class _DevMem:
+    """Raw device memory as an object torch.as_tensor can alias (CUDA array interface, no ownership)."""
+
+    def __init__(self, ptr, shape, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class PeerWindows:
+    """The neighbour exchange without a per-step collective: every rank keeps the reference windows it publishes
+    (`ticks` x [B_local, N+1, 10] float64: what nmpc_node.py:116-133 publishes per tick) in a buffer allocated with
+    ndp_peer_alloc, the 64-byte handles are exchanged ONCE (all_gather_object), and each rank maps the buffer of the
+    rank that holds its neighbours (ndp_peer_open).  `local[t]` is this rank's window tensor of tick slot t (fill it, then
+    publish()); `neighbour[t]` aliases rank (r+1) % W's -- pass it as `other` of BatchedNMPC.update_device: the control-step
+    kernel reads it out of the neighbour GPU's HBM over xGMI.  With one rank the neighbour is the local buffer.
+
+    publish() = device synchronisation + barrier: the windows of the bench are written once; a deployment that rewrites a
+    slot every tick orders writer and readers with its own events, as a ROS publisher / subscriber pair does."""
+
+    def __init__(self, B_local, N, ticks, device, group=None, same_process_ok=True):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        self._lib = _lib.load()
+        self.device = int(device)
+        self.shape = (int(ticks), int(B_local), int(N) + 1, 10)
+        nbytes = 8 * int(np.prod(self.shape))
+        ptr, handle = C.c_void_p(), (C.c_ubyte * 64)()
+        rc = self._lib.ndp_peer_alloc(self.device, nbytes, C.byref(ptr), handle)
+        if rc:
+            raise RuntimeError(f"ndp_peer_alloc failed ({rc})")
+        self._own = ptr.value
+        self._mapped = None
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        with torch.cuda.device(self.device):
+            self._local = torch.as_tensor(_DevMem(self._own, self.shape), device=torch.device("cuda", self.device))
+        self.local = [self._local[t] for t in range(self.shape[0])]
+        if self.world == 1:
+            self.neighbour = self.local
+            return
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle), group=group)
+        nb = handles[neighbour_rank(self.rank, self.world)]
+        buf = (C.c_ubyte * 64).from_buffer_copy(nb)
+        mp = C.c_void_p()
+        rc = self._lib.ndp_peer_open(self.device, buf, C.byref(mp))
+        ok = [None] * self.world
+        dist.all_gather_object(ok, int(rc), group=group)         # every rank learns whether every mapping worked
+        if any(ok):
+            if rc == 0:
+                self._lib.ndp_peer_close(self.device, mp)
+            self.close()
+            raise RuntimeError(f"ndp_peer_open failed on some rank: {ok}")
+        self._mapped = mp.value
+        with torch.cuda.device(self.device):
+            self._nb = torch.as_tensor(_DevMem(self._mapped, self.shape), device=torch.device("cuda", self.device))
+        self.neighbour = [self._nb[t] for t in range(self.shape[0])]
+
+    def publish(self):
+        import torch
+        import torch.distributed as dist
+        torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+    def close(self):
+        if self._mapped:
+            self._lib.ndp_peer_close(self.device, self._mapped)
+            self._mapped = None
+        if self._own:
+            self.local, self.neighbour, self._local = None, None, None
+            self._lib.ndp_peer_free(self.device, self._own)
+            self._own = None

@@ -228,6 +228,11 @@ def test_config4_placements_are_consistent():
                 assert np.array_equal(buf[s["other_index"][lead]], allv["xr"][s["gids"][lead] + 1][:, :, :ndist.PV_COLS])
                 if placement == "vehicle" and W > 1:      # the neighbour really lives on another rank
                     assert ((s["other_index"][lead] // (3 * F // W)) != r).all()
+                if placement == "vehicle":                # peer windows: the neighbour is a row of rank (r + 1) % W's own buffer
+                    prow = ndist.config4_other_index(r, W, F, "vehicle", peer_rows=True)
+                    assert (prow[~lead] == -1).all()
+                    nxt = shards[ndist.neighbour_rank(r, W)]
+                    assert np.array_equal(nxt["xr"][prow[lead]], allv["xr"][s["gids"][lead] + 1])
     with pytest.raises(ValueError):
         ndist.config4_gids(0, 7, F, "vehicle")
     d2 = ((allv["xr"][1::3, 0, 0:2] - allv["ego_xy"][0::3]) ** 2).sum(axis=1)
