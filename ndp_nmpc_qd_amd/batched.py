@@ -272,7 +272,14 @@ class BatchedNMPC:
         import torch
         B, N = self.B, self.N
         stride = 10
-        if other is not None and (other_index is not None or (other.dim() == 3 and other.shape[2] == 6)):
+        if other is not None and hasattr(other, "dev_ptr"):
+            # raw device memory (dist.DevWindows: e.g. another process's window buffer mapped with ndp_peer_open)
+            shp = tuple(other.shape)
+            if not (len(shp) == 3 and shp[1] == N + 1 and shp[2] in (6, 10) and (other_index is not None or shp[0] == B)):
+                raise ValueError("other: expected device windows of shape [rows, N+1, 6 or 10]")
+            stride = int(shp[2])
+            optr = C.c_void_p(int(other.dev_ptr))
+        elif other is not None and (other_index is not None or (other.dim() == 3 and other.shape[2] == 6)):
             # rows picked through other_index (any number of rows), or row i = instance i of a [B, N+1, 6] position / velocity window
             if not (other.is_cuda and other.is_contiguous() and other.dtype == torch.float64 and other.dim() == 3
                     and other.shape[1] == N + 1 and other.shape[2] in (6, 10) and (other_index is not None or other.shape[0] == B)):

@@ -176,12 +176,20 @@ class _DevMem:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
+class DevWindows:
+    """float64 windows [rows, N+1, 6 or 10] at a raw device address (no torch tensor: the memory may belong to another
+    process and another GPU).  BatchedNMPC.update_device accepts it as `other`."""
+
+    def __init__(self, dev_ptr, shape):
+        self.dev_ptr, self.shape = int(dev_ptr), tuple(int(x) for x in shape)
+
+
 class PeerWindows:
     """The neighbour exchange without a per-step collective: every rank keeps the reference windows it publishes
     (`ticks` x [B_local, N+1, 10] float64: what nmpc_node.py:116-133 publishes per tick) in a buffer allocated with
     ndp_peer_alloc, the 64-byte handles are exchanged ONCE (all_gather_object), and each rank maps the buffer of the
     rank that holds its neighbours (ndp_peer_open).  `local[t]` is this rank's window tensor of tick slot t (fill it, then
-    publish()); `neighbour[t]` aliases rank (r+1) % W's -- pass it as `other` of BatchedNMPC.update_device: the control-step
+    publish()); `neighbour[t]` (DevWindows: a raw device address) is rank (r+1) % W's -- pass it as `other` of BatchedNMPC.update_device: the control-step
     kernel reads it out of the neighbour GPU's HBM over xGMI.  With one rank the neighbour is the local buffer.
 
     publish() = device synchronisation + barrier: the windows of the bench are written once; a deployment that rewrites a
@@ -225,9 +233,8 @@ class PeerWindows:
             self.close()
             raise RuntimeError(f"ndp_peer_open failed on some rank: {ok}")
         self._mapped = mp.value
-        with torch.cuda.device(self.device):
-            self._nb = torch.as_tensor(_DevMem(self._mapped, self.shape), device=torch.device("cuda", self.device))
-        self.neighbour = [self._nb[t] for t in range(self.shape[0])]
+        slot = 8 * int(np.prod(self.shape[1:]))
+        self.neighbour = [DevWindows(self._mapped + t * slot, self.shape[1:]) for t in range(self.shape[0])]
 
     def publish(self):
         import torch
