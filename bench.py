@@ -119,6 +119,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
+    # multi-process GPU work on this pool needs dmabuf IPC (RCCL and the peer-window mapping alike); must be set before HIP starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
