@@ -216,8 +216,9 @@ class PeerWindows:
         with torch.cuda.device(self.device):
             self._local = torch.as_tensor(_DevMem(self._own, self.shape), device=torch.device("cuda", self.device))
         self.local = [self._local[t] for t in range(self.shape[0])]
-        if self.world == 1:
-            self.neighbour = self.local
+        slot = 8 * int(np.prod(self.shape[1:]))
+        if self.world == 1:       # the neighbours are this rank's own vehicles: the same raw-address form over the own buffer
+            self.neighbour = [DevWindows(self._own + t * slot, self.shape[1:]) for t in range(self.shape[0])]
             return
         handles = [None] * self.world
         dist.all_gather_object(handles, bytes(handle), group=group)
@@ -233,7 +234,6 @@ class PeerWindows:
             self.close()
             raise RuntimeError(f"ndp_peer_open failed on some rank: {ok}")
         self._mapped = mp.value
-        slot = 8 * int(np.prod(self.shape[1:]))
         self.neighbour = [DevWindows(self._mapped + t * slot, self.shape[1:]) for t in range(self.shape[0])]
 
     def publish(self):

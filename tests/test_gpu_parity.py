@@ -784,3 +784,43 @@ def test_config5_qp_on_the_fp32_and_bf16_matrix_instructions(ndp, oracle, N, n_r
         assert (st == 0).all()
         err[prec] = float(np.max(np.abs(u0 - uo) / np.maximum(1.0, np.abs(uo))))
     assert err[0] < 1e-8 and err[3] < 1e-5 and 1e-4 < err[4] < 0.5, err
+
+
+def test_peer_window_buffer_as_neighbour_source(ndp):
+    """dist.PeerWindows on one rank: the windows live in memory from ndp_peer_alloc (IPC-exportable: the handle a second process
+    would map with ndp_peer_open), the step takes them as a raw device address (dist.DevWindows) -- same answers as the tensor
+    path, with and without other_index.  (Two and three processes mapping each other's buffers: DESIGN.md section 6,
+    profiles/r02_peer_windows_*.)"""
+    import torch
+    from ndp_nmpc_qd_amd import dist as ndist
+    B, N = 96, 20
+    b = synth.make_batch(B, seed=synth.SEED0 + 61, downwash=True)
+    dev = torch.device("cuda", 0)
+    d = {k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur", "other", "ego_xy")}
+    pw = ndist.PeerWindows(B, N, 2, 0)
+    try:
+        pw.local[1].copy_(d["other"])
+        pw.publish()
+        outs = []
+        for mode in ("tensor", "raw", "raw_indexed"):
+            eng = ndp.BatchedNMPC(B, N=N, disturbance=True)
+            u0 = torch.empty(B, 4, dtype=torch.float64, device=dev)
+            eng.reset_device(d["xr"], d["ur"])
+            if mode == "tensor":
+                eng.update_device(d["x0"], d["xr"], d["ur"], u0, other=d["other"], ego_xy=d["ego_xy"])
+            elif mode == "raw":
+                eng.update_device(d["x0"], d["xr"], d["ur"], u0, other=pw.neighbour[1], ego_xy=d["ego_xy"])
+            else:
+                idx = torch.arange(B, dtype=torch.int32, device=dev)
+                eng.update_device(d["x0"], d["xr"], d["ur"], u0, other=pw.neighbour[1], ego_xy=d["ego_xy"], other_index=idx)
+            eng.synchronize()
+            st, _ = eng.status()
+            assert (st == 0).all()
+            outs.append(u0.cpu().numpy().copy())
+            eng.close()
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+        with pytest.raises(ValueError):
+            ndp.BatchedNMPC(B, N=N, disturbance=True).update_device(d["x0"], d["xr"], d["ur"], u0,
+                                                                    other=ndist.DevWindows(pw.neighbour[1].dev_ptr, (B, N, 10)))
+    finally:
+        pw.close()
