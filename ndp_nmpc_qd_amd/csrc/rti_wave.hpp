@@ -1096,13 +1096,20 @@ struct RtiWave {
             nrm = W::vmax(nrm, W::sel(v, W::vmax(rdl, rdu), vd(0.0)));
         }
         double mu = W::wave_sum(musum) * inv2m;
-        double norm0 = W::wave_max(nrm);
-        for (int k = 0; k <= N; ++k) norm0 = fmax_u(norm0, absmax(lds, m.CB + k * CB_STRIDE + CB_QE, 10));
-        for (int k = 0; k < N; ++k) {
-            norm0 = fmax_u(norm0, absmax(lds, m.CB + k * CB_STRIDE + CB_RB, 4));
-            norm0 = fmax_u(norm0, absmax(lds, m.MB + k * MB_STRIDE + MB_B, 10));
+        // scale of the residuals: largest magnitude among the slack / multiplier start values, the gradients (q_e: 10 per stage
+        // 0..N, r_b: 4 per stage < N), the defects b (10 per stage < N) and dx_0.  One running maximum per lane -- 16 lanes per
+        // stage, four stages per round -- and ONE wave reduction (a reduction per block was 61 of them: ~9 k cycles per solve).
+        {
+            vi e = lane & 15, kq = lane >> 4;
+            for (int t = 0; 4 * t <= N; ++t) {
+                vi k = kq + 4 * t;
+                nrm = W::vmax(nrm, W::vabs(W::ldp(lds, k * int(CB_STRIDE) + e + (m.CB + int(CB_QE)), (e < 10) && (k <= N))));
+                nrm = W::vmax(nrm, W::vabs(W::ldp(lds, k * int(CB_STRIDE) + e + (m.CB + int(CB_RB)), (e < 4) && (k < N))));
+                nrm = W::vmax(nrm, W::vabs(W::ldp(lds, k * int(MB_STRIDE) + e + (m.MB + int(MB_B)), (e < 10) && (k < N))));
+            }
+            nrm = W::vmax(nrm, W::vabs(W::ldp(lds, lane + m.ZX, lane < 10)));
         }
-        norm0 = fmax_u(norm0, absmax(lds, m.ZX, 10));
+        double norm0 = W::wave_max(nrm);
         double rho = 1.0;
         for (int t = 0; t < nzx + nzu; t += 64) {   // CX and CU are contiguous
             vi i = lane + t;
