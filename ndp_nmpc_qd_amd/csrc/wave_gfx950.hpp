@@ -128,24 +128,22 @@ struct WaveGfx950 {
         const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(a));
         return __hiloint2double(hi, lo);
     }
-    static NDP_D double wave_min(vd a)
+    // wave reductions: four DPP steps (lane ^ 1, lane ^ 2, row_ror 4 and 8: every lane of a 16-lane row then holds the row's
+    // result), the four rows through v_readlane -- ~25 instructions; the xor-butterfly over ds_bpermute took ~650 cycles each
+    // and the interior-point loop does four per iteration
+    template <class Op>
+    static NDP_D double wave_reduce(vd a, Op op)
     {
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) a = fmin(a, __shfl_xor(a, s, 64));
-        return uniform(a);
+        a = op(a, dpp_quad<0xB1>(a));
+        a = op(a, dpp_quad<0x4E>(a));
+        a = op(a, dpp_quad<0x124>(a));
+        a = op(a, dpp_quad<0x128>(a));
+        const double r0 = readlane(a, 0), r1 = readlane(a, 16), r2 = readlane(a, 32), r3 = readlane(a, 48);
+        return op(op(r0, r1), op(r2, r3));
     }
-    static NDP_D double wave_max(vd a)
-    {
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) a = fmax(a, __shfl_xor(a, s, 64));
-        return uniform(a);
-    }
-    static NDP_D double wave_sum(vd a)
-    {
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) a = a + __shfl_xor(a, s, 64);
-        return uniform(a);
-    }
+    static NDP_D double wave_min(vd a) { return wave_reduce(a, [](double x, double y) { return fmin(x, y); }); }
+    static NDP_D double wave_max(vd a) { return wave_reduce(a, [](double x, double y) { return fmax(x, y); }); }
+    static NDP_D double wave_sum(vd a) { return wave_reduce(a, [](double x, double y) { return x + y; }); }
     static NDP_D bool all(vb p) { return __all((int)p) != 0; }
     static NDP_D bool any(vb p) { return __any((int)p) != 0; }
 
