@@ -937,28 +937,47 @@ struct RtiWave {
         md vc[3] = {W::to_m(vd(0.0)), W::to_m(vd(0.0)), W::to_m(vd(0.0))};
         md dk[NC > 0 ? NC : 1];
         if constexpr (MMA4) {
-            // every product here is matrix x vector: the 4x4x4 instruction, vectors as chunk registers replicated over the columns
+            // every product here is matrix x vector: the 4x4x4 instruction, vectors as chunk registers replicated over the columns.
+            // The LDS operands of a stage are requested one stage ahead (as in riccati_sweep): they arrive under the previous
+            // stage's dependent chain instead of in front of this one's.
+            md Dg = W::to_m(W::ld(lds, D.dc_off4 + cb(N - 1)));
+            md a[3], kta = W::to_m(W::ld(lds, D.kta_off + mb(N - 1)));
+            for (int c = 0; c < 3; ++c) a[c] = W::to_m(vd(0.0));           // stage N-1 has no successor term
             NDP_UNROLL_STAGES
             for (int k = N - 1; k >= 0; --k) {
-                md Dg = W::to_m(W::ld(lds, D.dc_off4 + cb(k)));
-                md a[3];
-                for (int c = 0; c < 3; ++c) a[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(k)));
-                md akl = W::to_m(W::ld(lds, D.kta_off + mb(k))) + W::fma(linv[k], D.m12, -D.eye12);
+                md nDg = Dg, na[3] = {a[0], a[1], a[2]}, nkta = kta;
+                if (k > 0) {
+                    nDg = W::to_m(W::ld(lds, D.dc_off4 + cb(k - 1)));
+                    for (int c = 0; c < 3; ++c) na[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(k - 1)));
+                    nkta = W::to_m(W::ld(lds, D.kta_off + mb(k - 1)));
+                }
+                W::pin();
+                md akl = kta + W::fma(linv[k], D.m12, -D.eye12);
                 if (k != N - 1)
                     for (int c = 0; c < 3; ++c) Dg = mma4(a[c], vc[c], Dg);
                 md Dp = mma4(akl, W::template rowb<3>(Dg), Dg);
                 dk[k] = W::template rowb<3>(Dp);
                 vc[0] = W::template rowb<0>(Dp); vc[1] = W::template rowb<1>(Dp);
                 vc[2] = W::msel(D.g2, W::to_m(vd(0.0)), W::template rowb<2>(Dp));   // the constant-term row must not feed back
+                Dg = nDg; kta = nkta;
+                for (int c = 0; c < 3; ++c) a[c] = na[c];
             }
             md zc[3] = {W::to_m(vd(0.0)), W::to_m(vd(0.0)), W::to_m(vd(0.0))};
+            md fw[3], mu;
+            for (int c = 0; c < 3; ++c) fw[c] = W::to_m(W::ld(lds, T.fw_off[c]));
+            mu = W::to_m(W::ld(lds, T.mu_off));
+            vd zu0 = W::ld(lds, T.zu_st), zx0 = W::ld(lds, T.zx_st4 + int(NX));
             NDP_UNROLL_STAGES
             for (int k = 0; k < N; ++k) {
-                md fw[3], mu;
-                for (int c = 0; c < 3; ++c) fw[c] = W::to_m(W::ld(lds, T.fw_off[c] + mb(k)));
-                mu = W::to_m(W::ld(lds, T.mu_off + mb(k)));
-                vd zu0 = W::ld(lds, T.zu_st + k * int(NU));
-                vd zx0 = W::ld(lds, T.zx_st4 + (k + 1) * int(NX));
+                md nfw[3] = {fw[0], fw[1], fw[2]}, nmu = mu;
+                vd nzu0 = zu0, nzx0 = zx0;
+                if (k + 1 < N) {
+                    for (int c = 0; c < 3; ++c) nfw[c] = W::to_m(W::ld(lds, T.fw_off[c] + mb(k + 1)));
+                    nmu = W::to_m(W::ld(lds, T.mu_off + mb(k + 1)));
+                    nzu0 = W::ld(lds, T.zu_st + (k + 1) * int(NU));
+                    nzx0 = W::ld(lds, T.zx_st4 + (k + 2) * int(NX));
+                }
+                W::pin();
                 md y = W::to_m(vd(0.0)), du = dk[k];
                 if (k != 0) {
                     for (int c = 0; c < 3; ++c) y = mma4(fw[c], zc[c], y);
@@ -968,6 +987,8 @@ struct RtiWave {
                 W::st(lds, T.zu_st + k * int(NU), zu0 + W::to_d(du));
                 W::st(lds, T.zx_st4 + (k + 1) * int(NX), zx0 + W::to_d(xn));
                 zc[0] = W::template rowb<0>(xn); zc[1] = W::template rowb<1>(xn); zc[2] = W::template rowb<2>(xn);
+                for (int c = 0; c < 3; ++c) fw[c] = nfw[c];
+                mu = nmu; zu0 = nzu0; zx0 = nzx0;
             }
             W::sync();
             return;
@@ -1074,7 +1095,8 @@ struct RtiWave {
     // `failed` is set when no usable step exists (factorisation failure or NaN): the caller then keeps the iterate, as
     // acados' SQP_RTI returns ACADOS_QP_FAILURE before updating the variables; an exhausted iteration budget (status 4
     // as well) still hands over the last interior-point iterate.
-    static NDP_D int ipm(const RtiParams &P, const LdsMap &m, const Tables &T, Slots &S, lp lds, int &iters_out, bool &failed)
+    static NDP_D int ipm(const RtiParams &P, const LdsMap &m, const Tables &T, Slots &S, lp lds, int &iters_out, bool &failed,
+                         const RtiIo *fio = nullptr /* fine stamps of the first iteration (-DNDP_FINE_STAMPS builds, debug path) */)
     {
         const int N = horizon(P);
         const int nzx = (N + 1) * NX, nzu = N * NU;
@@ -1146,8 +1168,10 @@ struct RtiWave {
                     }
                 }
                 W::sync();
+                NDP_FINE(if (fio && fio->dbg && iters == 1) fstamp(*fio, m, 6 + 3 * pass);)
                 if (DELTA && pass) delta_sweep(P, m, T, DT, lds, linv);
                 else ok = riccati_sweep(P, m, T, lds, nullptr, DELTA ? linv : nullptr) && ok;
+                NDP_FINE(if (fio && fio->dbg && iters == 1) fstamp(*fio, m, 7 + 3 * pass);)
                 if (!ok) break;
                 vd amin = 1.0;
                 for (int s = 0; s < NSLOT; ++s) {
@@ -1170,6 +1194,7 @@ struct RtiWave {
                     amin = W::vmin(amin, W::sel(dlu < 0.0, -S.lu[s] * W::rcp(W::vmin(dlu, vd(-1e-300))), vd(1.0)));
                 }
                 double alpha = W::wave_min(amin);
+                NDP_FINE(if (fio && fio->dbg && iters == 1) fstamp(*fio, m, 8 + 3 * pass);)
                 if (pass == 0) {
                     vd acc = 0.0;
                     for (int s = 0; s < NSLOT; ++s)
@@ -1198,6 +1223,7 @@ struct RtiWave {
                     rho *= (1.0 - alpha);
                 }
             }
+            NDP_FINE(if (fio && fio->dbg && iters == 1) fstamp(*fio, m, 12);)
             if (!ok) { status = 4; failed = true; break; }
             if (!(mu == mu)) { status = 1; failed = true; break; }
         }
@@ -1313,7 +1339,7 @@ struct RtiWave {
                 Slots S;
                 build_slots(P, m, S);
                 load_bounds(m, S, lds);
-                st = ipm(P, m, T, S, lds, iters, failed);
+                st = ipm(P, m, T, S, lds, iters, failed, &io);
             }
             if (st && !status) status = st;
             // full step, no line search; XI|UI and CX|CU are laid out alike.
