@@ -168,6 +168,10 @@ struct RtiWave {
     // a vector in lane (j, b, i) = j + 4b + 16i, whereas the next product wants element 4c + k as chunk register c of the lanes
     // with l >> 4 == k: W::rowb<c> (one row broadcast) makes that register from block c.
     static constexpr bool MMA4 = W::has_mma4 && PREC == 0;
+#ifndef NDP_DELTA_MAX_N
+#define NDP_DELTA_MAX_N 40
+#endif
+    static constexpr int DELTA_MAX_N = NDP_DELTA_MAX_N;   // longest compile-time horizon whose corrector is a second solve (2 registers per stage)
     static NDP_D md mma4(md a, md b, md c) { return W::mfma4(a, b, c); }
     // one 4-deep contraction step D = A B + C
     static NDP_D md4 mma(md a, md b, const md4 &c)
@@ -1141,7 +1145,7 @@ struct RtiWave {
         bool ok = true;
         // corrector as a second solve with the predictor's factorisation (delta_sweep): compile-time horizons (the per-stage
         // -Lam^-1 operands live in registers) on the f64 instruction (in fp32 the interior-point loop converges worse with it)
-        constexpr bool DELTA = NC > 0 && W::delta_ok;
+        constexpr bool DELTA = NC > 0 && NC <= DELTA_MAX_N && W::delta_ok;
         md linv[DELTA ? NC : 1];
         DeltaTabs DT;
         if (DELTA) build_delta_tabs(m, DT);
