@@ -154,12 +154,26 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(KernArgs ka)
         const int orow = ma.other_index ? ma.other_index[inst] : inst;
         const int st = ma.other_stride;
         const double *oth = ma.other + (size_t)(orow < 0 ? 0 : orow) * np1 * st;
-        const bool open = orow >= 0 && (ma.ego_xy ? gate_open(oth, ma.ego_xy + (size_t)inst * 2, ma.r2) : true);
+        // the gate's four numbers are only REQUESTED here; the comparison comes after the barrier (consuming them here would
+        // park the wave on the whole in-order load queue -- s_waitcnt vmcnt(0) -- before the weight transfer is even issued)
+        const double *exy = ma.ego_xy ? ma.ego_xy + (size_t)inst * 2 : oth;
+        const double g_ox = oth[0], g_oy = oth[1], g_ex = exy[0], g_ey = exy[1];
         const int jr = j < np1 ? j : np1 - 1;
         float zb[3], o[3];
+        // Network input (downwash_nn.py:22-23): columns 0..5 of (other - ego reference), rows 0..N, subtracted in fp64.  Lane
+        // (j, h) of the tile wants row j, columns 2s + h -- read that way it is an 8-byte load at an 80-byte lane stride (ten
+        // cache lines per quarter wave, six instructions).  Instead ONE 16-byte load per array covers a row's six columns with
+        // three adjacent lanes (lane l: row l / 3, columns 2 (l % 3), 2 (l % 3) + 1: 63 lanes for N = 20), and the tile's
+        // layout is made by a cross-lane gather of the fp32 differences (ds_bpermute: the LDS crossbar, no LDS storage).
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        constexpr int ZR = NC ? (3 * (NC + 1) + 63) / 64 : 2;      // load rounds: 3 (N+1) lanes, N + 1 <= 32
+        d2_t dv[ZR], ev[ZR];
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-            zb[s] = (float)(oth[(size_t)jr * st + 2 * s + h] - io.xr[(size_t)jr * NX + 2 * s + h]);       // downwash_nn.py:22-23
+        for (int t = 0; t < ZR; ++t) {
+            const int l3 = lane + 64 * t, r3 = l3 / 3, c3 = l3 - 3 * r3, rc = r3 < np1 ? r3 : np1 - 1;
+            dv[t] = *(const d2_t *)(oth + (size_t)rc * st + 2 * c3);
+            ev[t] = *(const d2_t *)(io.xr + (size_t)rc * NX + 2 * c3);
+        }
         const LdsMap m = make_map(N);
         if (io.dbg && lane == 0) io.dbg[m.total + 9] = (double)__builtin_amdgcn_s_memtime();
         if (io.stamps && lane == 0) io.stamps[9] = (double)__builtin_amdgcn_s_memtime();
@@ -167,6 +181,25 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(KernArgs ka)
         lds_f32 wl = (lds_f32)smem;
         stage_fragments(ma.frag, wl, (int)threadIdx.x, 64 * WAVES);
         __syncthreads();
+        const double g_o[2] = {g_ox, g_oy}, g_e[2] = {g_ex, g_ey};
+        const bool open = orow >= 0 && (ma.ego_xy ? gate_open(g_o, g_e, ma.r2) : true);
+        {
+            float fx[ZR], fy[ZR];
+#pragma unroll
+            for (int t = 0; t < ZR; ++t) { fx[t] = (float)(dv[t][0] - ev[t][0]); fy[t] = (float)(dv[t][1] - ev[t][1]); }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int src = 3 * jr + s, sl = (src & 63) << 2;
+                float vx = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(fx[0])));
+                float vy = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(fy[0])));
+                if (ZR > 1) {
+                    const float wx = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(fx[ZR - 1])));
+                    const float wy = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(fy[ZR - 1])));
+                    if (src >= 64) { vx = wx; vy = wy; }
+                }
+                zb[s] = h ? vy : vx;
+            }
+        }
         if (io.stamps && lane == 0) io.stamps[11] = (double)__builtin_amdgcn_s_memtime();
         // gate closed (or no neighbour): the force is zero and the reference does not evaluate the network either
         // (ndp_nmpc_leader_node.py:66-76).  The test is the same in every lane: a wave-uniform branch around the tile.
@@ -269,10 +302,17 @@ __device__ __forceinline__ int f0(int r) { return (r & 3) + 8 * (r >> 2); }
 // hot-spotting: the MLP tile took 33k cycles at B = 1024 against 25k alone).
 __device__ __forceinline__ void stage_fragments(const float *__restrict__ fr, lds_f32 dst, int tid, int nthreads)
 {
-    const int wave = tid >> 6, lane = tid & 63, nw = nthreads >> 6;
-    for (int c = wave; c < FR_CHUNKS; c += nw)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fr + c * 256 + lane * 4),
-                                         (__attribute__((address_space(3))) void *)(dst + c * 256), 16, 0, 0);
+    // the wave index is uniform: keep the piece loop scalar (derived from threadIdx it would run under an exec mask), a
+    // compile-time number of rounds with a uniform guard on the last one
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nthreads >> 6;
+#pragma unroll
+    for (int i = 0; i < FR_CHUNKS; ++i) {
+        if (i * nw >= FR_CHUNKS) break;
+        const int c = wave + i * nw;
+        if (c < FR_CHUNKS)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fr + c * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void *)(dst + c * 256), 16, 0, 0);
+    }
 }
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
