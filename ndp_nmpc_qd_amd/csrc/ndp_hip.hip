@@ -144,6 +144,14 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(KernArgs ka)
         io.stamps[12] = (double)__builtin_amdgcn_s_memrealtime();
         io.stamps[14] = (double)__builtin_amdgcn_s_memtime();
     }
+    // fused, neighbour rows picked through other_index: the row number is the head of a dependent load chain (index -> window
+    // address -> window loads).  Fetch it before anything else is in the wave's in-order load queue and consume it here, so
+    // that the one unavoidable wait covers one load, not the seventeen input loads requested next.
+    int orow = inst;
+    if (FUSED && ma.other_index) {
+        orow = __builtin_amdgcn_readfirstlane(ma.other_index[inst]);
+        asm volatile("" : : "s"(orow));
+    }
     typename Prog::InBuf inb;
     double x0v;
     Prog::issue_first(P, io, inb, x0v);      // every global input of the RTI step is now in flight (hidden under the MLP when fused)
@@ -151,7 +159,6 @@ __global__ __launch_bounds__(64 * WAVES) void rti_kernel(KernArgs ka)
     if (FUSED) {
         const int lane = (int)(threadIdx.x & 63u), j = lane & 31, h = lane >> 5;
         const int np1 = N + 1;
-        const int orow = ma.other_index ? ma.other_index[inst] : inst;
         const int st = ma.other_stride;
         const double *oth = ma.other + (size_t)(orow < 0 ? 0 : orow) * np1 * st;
         // the gate's four numbers are only REQUESTED here; the comparison comes after the barrier (consuming them here would
