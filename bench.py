@@ -533,7 +533,7 @@ def main():
             for _ in range(n1):
                 ctl.update(x0_1, xr_1, ur_1)
             lat["gpu_drop_in_update_us"] = (time.perf_counter() - t2) / n1 * 1e6
-            # the same tick without the Python facade's 42 solver.set calls: BatchedNMPC(1).update(full=True) on numpy arrays
+            # the same tick without the Python facade: BatchedNMPC(1).update(full=True) on numpy arrays
             e1 = ndp.BatchedNMPC(1, N=N, device=local_rank)
             e1.reset(xr_1[None], ur_1[None])
             for _ in range(20):
@@ -544,7 +544,7 @@ def main():
             lat["gpu_ndp_step_ex_us"] = (time.perf_counter() - t3) / n1 * 1e6
             lat["deadline_us"] = 20000.0
             lat["note"] = ("N=%d, no downwash, 1 RTI iteration, host numpy in / numpy out per tick.  gpu_drop_in_update = "
-                           "NMPCBodyRateController.update (42 solver.set calls in Python + ONE ndp_step_ex: packed pinned H2D, kernel, "
+                           "NMPCBodyRateController.update (reference staged by array assignment + ONE ndp_step_ex: packed pinned H2D, kernel, "
                            "u0 + iterate + status D2H, one sync); deadline = the reference's 20 ms warning (nmpc_node.py:216-220)" % N)
             out["config1_single_vehicle"] = lat
         fail = (parity is not None and not parity <= 1e-5) or bad > 0

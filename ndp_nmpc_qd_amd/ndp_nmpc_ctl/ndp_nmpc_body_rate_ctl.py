@@ -1,6 +1,5 @@
 """NDPNMPCBodyRateController on MI355X -- same constructor / reset / update(x0, xr, ur, f) as the
 reference class (ndp_nmpc/scripts/ndp_nmpc_ctl/ndp_nmpc_body_rate_ctl.py:20-112)."""
-import numpy as np
 
 from ..batched import BatchedNMPC
 from ..params import nmpc_params as CP
@@ -19,12 +18,9 @@ class NDPNMPCBodyRateController(object):
         self.solver.set(self.solver.N, "x", xr[self.solver.N, :])
 
     def update(self, x0, xr, ur, f):
-        for i in range(self.solver.N):
-            self.solver.set(i, "yref", np.concatenate((xr[i, :], ur[i, :])))
-            # p_k = [reference quaternion, disturbance force]   (ndp_nmpc_body_rate_ctl.py:97-99)
-            self.solver.set(i, "p", np.concatenate((xr[i, 6:10], f[i, :])))
-        self.solver.set(self.solver.N, "yref", xr[self.solver.N, :])
-        self.solver.set(self.solver.N, "p", np.concatenate((xr[self.solver.N, 6:10], f[self.solver.N, :])))
+        # yref_k = [xr_k, ur_k], p_k = [reference quaternion, disturbance force] (ndp_nmpc_body_rate_ctl.py:93-104): the
+        # reference's 2 (N + 1) solver.set calls as array assignments
+        self.solver.set_reference(xr, ur, f)
 
         u0 = self.solver.solve_for_x0(x0)  # feedback, take the first action
 

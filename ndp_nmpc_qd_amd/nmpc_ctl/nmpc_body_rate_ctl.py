@@ -1,6 +1,5 @@
 """NMPCBodyRateController on MI355X -- same constructor / reset / update as the reference class
 (ndp_nmpc/scripts/nmpc_ctl/nmpc_body_rate_ctl.py:20-112)."""
-import numpy as np
 
 from ..batched import BatchedNMPC
 from ..params import nmpc_params as CP
@@ -22,11 +21,9 @@ class NMPCBodyRateController(object):
         self.solver.set(self.solver.N, "x", xr[self.solver.N, :])
 
     def update(self, x0, xr, ur):
-        for i in range(self.solver.N):
-            self.solver.set(i, "yref", np.concatenate((xr[i, :], ur[i, :])))
-            self.solver.set(i, "p", xr[i, 6:10])  # reference quaternion for the nonlinear quaternion error
-        self.solver.set(self.solver.N, "yref", xr[self.solver.N, :])  # terminal: state only
-        self.solver.set(self.solver.N, "p", xr[self.solver.N, 6:10])
+        # yref_k = [xr_k, ur_k] (terminal: state only), p_k = xr_k[6:10] (reference quaternion for the nonlinear quaternion
+        # error): the reference's 2 (N + 1) solver.set calls (nmpc_body_rate_ctl.py:95-104) as array assignments
+        self.solver.set_reference(xr, ur)
 
         u0 = self.solver.solve_for_x0(x0)  # feedback, take the first action
 

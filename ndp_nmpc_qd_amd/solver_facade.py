@@ -42,6 +42,20 @@ class SolverFacade:
             else:
                 raise Exception(f"AcadosOcpSolver.set(): {field} is not supported by this drop-in")
 
+    def set_reference(self, xr, ur, f=None):
+        """What the reference's update() does with 2 (N + 1) solver.set calls (nmpc_body_rate_ctl.py:95-104,
+        ndp_nmpc_body_rate_ctl.py:93-104), as three array assignments: yref_k = [xr_k, ur_k] (terminal: xr_N), p_k = [xr_k[6:10]
+        (, f_k)].  The per-stage solver.set stays available to callers that use it."""
+        xr = np.asarray(xr, dtype=np.float64)
+        ur = np.asarray(ur, dtype=np.float64)
+        N = self.N
+        with self._lock:
+            self._yref[:, 0:10] = xr[:N + 1]
+            self._yref[:N, 10:14] = ur[:N]
+            self._p[:, 0:4] = xr[:N + 1, 6:10]
+            if self._np == 7:
+                self._p[:, 4:7] = np.asarray(f, dtype=np.float64)[:N + 1]
+
     # acados: solver.get(stage, field) -> fresh array the caller may mutate (nmpc_node.py:237-238)
     def get(self, stage, field):
         with self._lock:
