@@ -169,8 +169,10 @@ struct WaveGfx950 {
     template <int Q>
     static NDP_D md rowb(md a)
     {
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), 0x150 + 4 * Q, 0xF, 0xF, false);
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), 0x150 + 4 * Q, 0xF, 0xF, false);
+        // bound_ctrl = true: every lane has a valid source under row_newbcast, and with it the compiler knows the destination's
+        // previous value is dead -- without it each v_mov_b32_dpp was preceded by a v_mov_b32 dst, 0 (160 per forward sweep)
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), 0x150 + 4 * Q, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), 0x150 + 4 * Q, 0xF, 0xF, true);
         return __hiloint2double(hi, lo);
     }
 };
