@@ -116,7 +116,9 @@ int ndp_step_device(ndp_handle *h, const void *d_x0, const void *d_xr, const voi
 /* ndp_step plus, from the same call (one synchronisation, no further round trips), what the reference's callers read
  * after solve_for_x0: the new iterate (solver.get(i,"x"/"u"), nmpc_node.py:237), solver.status
  * (nmpc_body_rate_ctl.py:109) and the interior-point iterations.  Any of the four output pointers may be NULL.
- * Batches whose inputs fit 1 MiB travel as ONE host-to-device copy through a pinned mirror owned by the handle. */
+ * Batches whose inputs fit 1 MiB use page-locked host blocks owned by the handle that the kernel reads (inputs) and writes (u0,
+ * status, iterate) directly: one launch and one synchronisation per call, no DMA operation.  (For such handles
+ * ndp_device_iterate_x / _u return device-accessible pointers into that page-locked block.) */
 int ndp_step_ex(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
                 const double *other, const double *ego_xy, double *u0, double *X_out, double *U_out,
                 int32_t *status_out, int32_t *ipm_iters_out);

@@ -1107,12 +1107,12 @@ int ndp_destroy(ndp_handle *h)
     if (h->ev_pending) (void)hipEventSynchronize(h->evLast);
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->evLast) (void)hipEventDestroy(h->evLast);
-    void *ptrs[] = {h->dRefList, h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dX, h->dU, h->dForce, h->dFrag,
-                    h->dIn, h->dOut, h->sdbg, h->dQctr, h->dQids};
+    void *ptrs[] = {h->dRefList, h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dForce, h->dFrag,
+                    h->dIn, h->hOut ? nullptr : h->dOut, h->sdbg, h->dQctr, h->dQids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->hIn) (void)hipHostFree(h->hIn);
-    if (h->hOut) (void)hipHostFree(h->hOut);
+    if (h->hOut) (void)hipHostFree(h->hOut);      // (then dOut is that same block)
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -1171,7 +1171,6 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     const size_t B = cfg->batch;
 #define ALLOC(p, n)                                                                      \
     if ((e = hipMalloc((void **)&(p), (n))) != hipSuccess) return fail("hipMalloc " #p, e)
-    ALLOC(h->dX, nxs(h) * 8); ALLOC(h->dU, nus(h) * 8);
     ALLOC(h->dForce, nfs(h) * 4); ALLOC(h->dFrag, FR_TOTAL * 4); ALLOC(h->dKC, KC_SC * 8);
     ALLOC(h->dThr, B * 8 * 8); ALLOC(h->sThr, B * 11 * 8);
     ALLOC(h->dRelay, B * 4 * 8);
@@ -1202,14 +1201,25 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         h->off_st = o; o += up256(B * 4);
         h->off_it = o; o += up256(B * 4);
         h->out_bytes = o;
-        ALLOC(h->dIn, h->in_bytes); ALLOC(h->dOut, h->out_bytes);
+        // the persistent iterate lives right behind the output block: u0 | status | iterations | X | U come back to the host
+        // in ONE copy when a caller asks for the iterate as well (ndp_step_ex)
+        // Small batches (inputs up to PACK_LIMIT): that block is page-locked HOST memory the device reads and writes directly
+        // (fine-grained: ~7 KB per instance and tick over PCIe) -- a host-array step is then memcpy into the input mirror, ONE
+        // launch, one synchronisation, memcpy out of the output block; no DMA operation at all.
+        const size_t out_all = h->out_bytes + (nxs(h) + nus(h)) * 8;
+        ALLOC(h->dIn, h->in_bytes);
+        if (h->in_bytes <= PACK_LIMIT) {
+            if ((e = hipHostMalloc((void **)&h->hOut, out_all, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc hOut", e);
+            h->dOut = h->hOut;
+        } else {
+            ALLOC(h->dOut, out_all);
+        }
+        h->dX = (double *)(h->dOut + h->out_bytes); h->dU = h->dX + nxs(h);
         h->sx0 = (double *)(h->dIn + h->off_x0); h->sxr = (double *)(h->dIn + h->off_xr); h->sur = (double *)(h->dIn + h->off_ur);
         h->sf = (float *)(h->dIn + h->off_f); h->sother = (double *)(h->dIn + h->off_other); h->sego = (double *)(h->dIn + h->off_ego);
         h->su0 = (double *)(h->dOut + h->off_u0); h->dStatus = (int *)(h->dOut + h->off_st); h->dIters = (int *)(h->dOut + h->off_it);
         if (h->in_bytes <= PACK_LIMIT) {
             if ((e = hipHostMalloc((void **)&h->hIn, h->in_bytes, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc hIn", e);
-            if ((e = hipHostMalloc((void **)&h->hOut, h->out_bytes + (nxs(h) + nus(h)) * 8, hipHostMallocDefault)) != hipSuccess)
-                return fail("hipHostMalloc hOut", e);
         }
         ALLOC(h->sdbg, (size_t)(lds_doubles(cfg->N) + DBG_EXTRA) * 8);
     }
@@ -1411,8 +1421,8 @@ int ndp_reset_device(ndp_handle *h, const void *d_xr, const void *d_ur, void *st
     std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    NDP_HIP(h, hipMemcpyAsync(h->dX, d_xr, nxs(h) * 8, hipMemcpyDeviceToDevice, s));
-    NDP_HIP(h, hipMemcpyAsync(h->dU, d_ur, nus(h) * 8, hipMemcpyDeviceToDevice, s));
+    NDP_HIP(h, hipMemcpyAsync(h->dX, d_xr, nxs(h) * 8, hipMemcpyDefault, s));
+    NDP_HIP(h, hipMemcpyAsync(h->dU, d_ur, nus(h) * 8, hipMemcpyDefault, s));
     return note_stream(h, s);
 }
 
@@ -1423,8 +1433,8 @@ int ndp_reset(ndp_handle *h, const double *xr, const double *ur)
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     int rc = wait_all(h);
     if (rc) return rc;
-    NDP_HIP(h, hipMemcpyAsync(h->dX, xr, nxs(h) * 8, hipMemcpyHostToDevice, h->stream));
-    NDP_HIP(h, hipMemcpyAsync(h->dU, ur, nus(h) * 8, hipMemcpyHostToDevice, h->stream));
+    NDP_HIP(h, hipMemcpyAsync(h->dX, xr, nxs(h) * 8, hipMemcpyDefault, h->stream));
+    NDP_HIP(h, hipMemcpyAsync(h->dU, ur, nus(h) * 8, hipMemcpyDefault, h->stream));
     NDP_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -1471,7 +1481,7 @@ static int step_host(ndp_handle *h, const double *x0, const double *xr, const do
         if (f) { memcpy(h->hIn + h->off_f, f, nfs(h) * 4); end = h->off_f + nfs(h) * 4; }
         if (other) { memcpy(h->hIn + h->off_other, other, nxs(h) * 8); end = h->off_other + nxs(h) * 8; }
         if (ego_xy) { memcpy(h->hIn + h->off_ego, ego_xy, B * 2 * 8); end = h->off_ego + B * 2 * 8; }
-        NDP_HIP(h, hipMemcpyAsync(h->dIn, h->hIn, end, hipMemcpyHostToDevice, s));
+        (void)end;      // no H2D copy: the kernel reads the pinned mirror itself (fine-grained host memory, ~5 KB per instance)
     } else {
         NDP_HIP(h, hipMemcpyAsync(h->sx0, x0, B * NX * 8, hipMemcpyHostToDevice, s));
         NDP_HIP(h, hipMemcpyAsync(h->sxr, xr, nxs(h) * 8, hipMemcpyHostToDevice, s));
@@ -1481,17 +1491,17 @@ static int step_host(ndp_handle *h, const double *x0, const double *xr, const do
         if (ego_xy) NDP_HIP(h, hipMemcpyAsync(h->sego, ego_xy, B * 2 * 8, hipMemcpyHostToDevice, s));
     }
     Neigh nb;
-    nb.other = other ? h->sother : nullptr;
-    nb.ego_xy = ego_xy ? h->sego : nullptr;
-    int rc = enqueue_step(h, h->sx0, h->sxr, h->sur, f ? h->sf : nullptr, nb, h->su0, dump ? h->sdbg : nullptr, s);
+    const unsigned char *ib = pack ? h->hIn : h->dIn;
+    nb.other = other ? (const double *)(ib + h->off_other) : nullptr;
+    nb.ego_xy = ego_xy ? (const double *)(ib + h->off_ego) : nullptr;
+    int rc = enqueue_step(h, (const double *)(ib + h->off_x0), (const double *)(ib + h->off_xr), (const double *)(ib + h->off_ur),
+                          f ? (const float *)(ib + h->off_f) : nullptr, nb, h->su0, dump ? h->sdbg : nullptr, s);
     if (rc) return rc;
     std::vector<int32_t> st_tmp;
     const int32_t *st = nullptr;
     if (pack) {
         unsigned char *ho = h->hOut;
-        NDP_HIP(h, hipMemcpyAsync(ho, h->dOut, h->out_bytes, hipMemcpyDeviceToHost, s));           // u0 | status | iters
-        if (X_out) NDP_HIP(h, hipMemcpyAsync(ho + h->out_bytes, h->dX, nxs(h) * 8, hipMemcpyDeviceToHost, s));
-        if (U_out) NDP_HIP(h, hipMemcpyAsync(ho + h->out_bytes + nxs(h) * 8, h->dU, nus(h) * 8, hipMemcpyDeviceToHost, s));
+        // u0 | status | iters | X | U: the kernel wrote them into this block (page-locked host memory) itself
         if (dump) NDP_HIP(h, hipMemcpyAsync(dump, h->sdbg, (size_t)(lds_doubles(h->cfg.N) + DBG_EXTRA) * 8, hipMemcpyDeviceToHost, s));
         NDP_HIP(h, hipStreamSynchronize(s));
         memcpy(u0, ho + h->off_u0, B * NU * 8);
@@ -1503,11 +1513,11 @@ static int step_host(ndp_handle *h, const double *x0, const double *xr, const do
     } else {
         int32_t *stp = status_out;
         if (!stp) { st_tmp.resize(B); stp = st_tmp.data(); }
-        NDP_HIP(h, hipMemcpyAsync(u0, h->su0, B * NU * 8, hipMemcpyDeviceToHost, s));
-        NDP_HIP(h, hipMemcpyAsync(stp, h->dStatus, B * 4, hipMemcpyDeviceToHost, s));
-        if (iters_out) NDP_HIP(h, hipMemcpyAsync(iters_out, h->dIters, B * 4, hipMemcpyDeviceToHost, s));
-        if (X_out) NDP_HIP(h, hipMemcpyAsync(X_out, h->dX, nxs(h) * 8, hipMemcpyDeviceToHost, s));
-        if (U_out) NDP_HIP(h, hipMemcpyAsync(U_out, h->dU, nus(h) * 8, hipMemcpyDeviceToHost, s));
+        NDP_HIP(h, hipMemcpyAsync(u0, h->su0, B * NU * 8, hipMemcpyDefault, s));
+        NDP_HIP(h, hipMemcpyAsync(stp, h->dStatus, B * 4, hipMemcpyDefault, s));
+        if (iters_out) NDP_HIP(h, hipMemcpyAsync(iters_out, h->dIters, B * 4, hipMemcpyDefault, s));
+        if (X_out) NDP_HIP(h, hipMemcpyAsync(X_out, h->dX, nxs(h) * 8, hipMemcpyDefault, s));
+        if (U_out) NDP_HIP(h, hipMemcpyAsync(U_out, h->dU, nus(h) * 8, hipMemcpyDefault, s));
         if (dump) NDP_HIP(h, hipMemcpyAsync(dump, h->sdbg, (size_t)(lds_doubles(h->cfg.N) + DBG_EXTRA) * 8, hipMemcpyDeviceToHost, s));
         NDP_HIP(h, hipStreamSynchronize(s));
         st = stp;
@@ -1576,8 +1586,8 @@ int ndp_get_iterate(ndp_handle *h, double *X, double *U)
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     int rc = wait_all(h);
     if (rc) return rc;
-    if (X) NDP_HIP(h, hipMemcpy(X, h->dX, nxs(h) * 8, hipMemcpyDeviceToHost));
-    if (U) NDP_HIP(h, hipMemcpy(U, h->dU, nus(h) * 8, hipMemcpyDeviceToHost));
+    if (X) NDP_HIP(h, hipMemcpy(X, h->dX, nxs(h) * 8, hipMemcpyDefault));
+    if (U) NDP_HIP(h, hipMemcpy(U, h->dU, nus(h) * 8, hipMemcpyDefault));
     return 0;
 }
 
@@ -1588,8 +1598,8 @@ int ndp_set_iterate(ndp_handle *h, const double *X, const double *U)
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     int rc = wait_all(h);
     if (rc) return rc;
-    if (X) NDP_HIP(h, hipMemcpy(h->dX, X, nxs(h) * 8, hipMemcpyHostToDevice));
-    if (U) NDP_HIP(h, hipMemcpy(h->dU, U, nus(h) * 8, hipMemcpyHostToDevice));
+    if (X) NDP_HIP(h, hipMemcpy(h->dX, X, nxs(h) * 8, hipMemcpyDefault));
+    if (U) NDP_HIP(h, hipMemcpy(h->dU, U, nus(h) * 8, hipMemcpyDefault));
     return 0;
 }
 
@@ -1600,8 +1610,8 @@ int ndp_get_status(ndp_handle *h, int32_t *status, int32_t *ipm_iters)
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     int rc = wait_all(h);
     if (rc) return rc;
-    if (status) NDP_HIP(h, hipMemcpy(status, h->dStatus, (size_t)h->cfg.batch * 4, hipMemcpyDeviceToHost));
-    if (ipm_iters) NDP_HIP(h, hipMemcpy(ipm_iters, h->dIters, (size_t)h->cfg.batch * 4, hipMemcpyDeviceToHost));
+    if (status) NDP_HIP(h, hipMemcpy(status, h->dStatus, (size_t)h->cfg.batch * 4, hipMemcpyDefault));
+    if (ipm_iters) NDP_HIP(h, hipMemcpy(ipm_iters, h->dIters, (size_t)h->cfg.batch * 4, hipMemcpyDefault));
     return 0;
 }
 
@@ -2007,8 +2017,8 @@ int ndp_rollout_device(ndp_handle *h, int ticks, double t0, double dt_tick, int 
     double *x = (double *)d_x, *log = (double *)d_log;
     int rc = launch_ref_window(h, nullptr, t0, h->sxr, h->sur, s);     // reset(xr, ur) at the first tick's reference
     if (rc) return rc;
-    NDP_HIP(h, hipMemcpyAsync(h->dX, h->sxr, nxs(h) * 8, hipMemcpyDeviceToDevice, s));
-    NDP_HIP(h, hipMemcpyAsync(h->dU, h->sur, nus(h) * 8, hipMemcpyDeviceToDevice, s));
+    NDP_HIP(h, hipMemcpyAsync(h->dX, h->sxr, nxs(h) * 8, hipMemcpyDefault, s));
+    NDP_HIP(h, hipMemcpyAsync(h->dU, h->sur, nus(h) * 8, hipMemcpyDefault, s));
     for (int k = 0; k < ticks; ++k) {
         if (k > 0 && (rc = launch_ref_window(h, nullptr, t0 + k * dt_tick, h->sxr, h->sur, s))) return rc;
         if ((rc = launch_rti(h, x, h->sxr, h->sur, nullptr, h->su0, nullptr, s))) return rc;
