@@ -544,8 +544,9 @@ def main():
             lat["gpu_ndp_step_ex_us"] = (time.perf_counter() - t3) / n1 * 1e6
             lat["deadline_us"] = 20000.0
             lat["note"] = ("N=%d, no downwash, 1 RTI iteration, host numpy in / numpy out per tick.  gpu_drop_in_update = "
-                           "NMPCBodyRateController.update (reference staged by array assignment + ONE ndp_step_ex: packed pinned H2D, kernel, "
-                           "u0 + iterate + status D2H, one sync); deadline = the reference's 20 ms warning (nmpc_node.py:216-220)" % N)
+                           "NMPCBodyRateController.update (reference staged by array assignment + ONE ndp_step_ex: inputs into a page-locked mirror the "
+                           "kernel reads, one launch, u0 + iterate + status written by the kernel into a page-locked block, one sync -- no DMA "
+                           "operation); deadline = the reference's 20 ms warning (nmpc_node.py:216-220)" % N)
             out["config1_single_vehicle"] = lat
         fail = (parity is not None and not parity <= 1e-5) or bad > 0
         if fail:
