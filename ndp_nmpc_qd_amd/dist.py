@@ -206,13 +206,20 @@ class PeerWindows:
         nbytes = 8 * int(np.prod(self.shape))
         ptr, handle = C.c_void_p(), (C.c_ubyte * 64)()
         rc = self._lib.ndp_peer_alloc(self.device, nbytes, C.byref(ptr), handle)
-        if rc:
-            raise RuntimeError(f"ndp_peer_alloc failed ({rc})")
-        self._own = ptr.value
+        self._own = ptr.value if rc == 0 else None
         self._mapped = None
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if self.world > 1:
+            # every rank takes part in every collective below whatever happened locally, and all ranks reach the same verdict
+            allocs = [None] * self.world
+            dist.all_gather_object(allocs, int(rc), group=group)
+            if any(allocs):
+                self.close()
+                raise RuntimeError(f"ndp_peer_alloc failed on some rank: {allocs}")
+        elif rc:
+            raise RuntimeError(f"ndp_peer_alloc failed ({rc})")
         with torch.cuda.device(self.device):
             self._local = torch.as_tensor(_DevMem(self._own, self.shape), device=torch.device("cuda", self.device))
         self.local = [self._local[t] for t in range(self.shape[0])]
