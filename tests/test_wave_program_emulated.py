@@ -300,3 +300,18 @@ def test_work_list_producer_defers_without_writing(oracle):
         else:
             assert (std, itd) == (sti, 0) and np.array_equal(u0d, u0i) and np.array_equal(Xd, Xi) and np.array_equal(Ud, Ui)
     assert 5 < n_def < 40
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 5, 9, 17, 31, 33, 45])
+def test_any_horizon_matches_oracle(oracle, N):
+    """Run-time horizons from a single stage up to 45 (three- and five-slot constraint forms, partial last rounds of every
+    64-lane task family, the four-block matrix instruction on both sweeps), early exit and interior point, nominal and perturbed
+    starts: same answer as the oracle."""
+    for qp_mode in (0, 1):
+        for seed, kw in ((1, {}), (2, dict(pos_sigma=0.6, vel_sigma=1.2, quat_sigma=0.2))):
+            b = synth.make_batch(1, N=N, seed=seed, **kw)
+            (u0, st, it, X, U, cnt), (u0o, sto, Xo, Uo) = _run_pair(oracle, b, 0, N=N, qp_mode=qp_mode)
+            assert st == sto.status
+            _assert_u(u0, u0o, 1e-8)
+            np.testing.assert_allclose(X, Xo, atol=1e-8)
+            np.testing.assert_allclose(U, Uo, atol=1e-8)
