@@ -14,7 +14,6 @@ Prints ONE JSON line on rank 0.  Exit code 1 (and "value": null) if the parity s
 """
 import argparse
 import csv
-import glob
 import json
 import os
 import sys
@@ -27,7 +26,8 @@ sys.path.insert(0, ROOT)
 
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, datasheet; v_mfma_f64_16x16x4 = 2048 FLOP / 64 clk / SIMD
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_TAG = "r02"           # profiles/<tag>_kernel_stats.csv, <tag>_pmc_rti_kernel.json belong to the default configuration
+PROFILE_TAGS = ("r03", "r02")  # newest first: profiles/<tag>_kernel_stats_fused_b1024.csv + <tag>_pmc_rti_kernel.json = the DEFAULT configuration's profile
+PROFILE_TOLERANCE = 0.25       # a committed profile whose kernel duration is further than this from the live HIP-event duration is refused
 
 
 def algorithmic_flops_per_solve(N, sweeps, downwash):
@@ -44,27 +44,44 @@ def algorithmic_bytes_per_solve(N, downwash):
     return b
 
 
-def committed_profile(default_cfg):
-    """What the committed rocprofv3 summaries say about the default configuration's rti_kernel: average duration
-    (kernel trace) and HBM bytes per launch (separate FETCH_SIZE / WRITE_SIZE passes; KB units; FETCH_SIZE doubled per the
-    gfx950 note in MI355X_MICROARCH.md).  None when the running configuration is not the profiled one."""
-    out = {"kernel_us": None, "traffic": None, "wave_cycles_per_simd": None}
+def committed_profile(default_cfg, root=None):
+    """What the committed rocprofv3 summaries say about the DEFAULT configuration's rti_kernel (batch 1024, N = 20, 1 RTI
+    iteration, fused downwash, automatic QP mode, nominal starts): average duration (kernel trace) and HBM bytes per launch
+    (separate FETCH_SIZE / WRITE_SIZE passes; KB units; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).
+    The files are read BY NAME -- profiles/<tag>_kernel_stats_fused_b1024.csv and <tag>_pmc_rti_kernel.json of the newest
+    tag in PROFILE_TAGS that has the CSV -- never by a glob: other committed traces (interior point always, mixed workload)
+    hold the same kernel instantiation at other durations.  All None when the running configuration is not the profiled one."""
+    out = {"kernel_us": None, "traffic": None, "wave_cycles_per_simd": None, "tag": None}
     if not default_cfg:
         return out
-    for path in glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "_kernel_stats*.csv")):
+    pdir = os.path.join(root or ROOT, "profiles")
+    for tag in PROFILE_TAGS:
+        path = os.path.join(pdir, tag + "_kernel_stats_fused_b1024.csv")
+        if not os.path.exists(path):
+            continue
+        out["tag"] = tag
+        best = None
         with open(path) as fh:
             for row in csv.DictReader(fh):
-                if "rti_kernel" in row.get("Name", "") and "true, 20" in row.get("Name", "").replace("(bool)1", "true"):
-                    out["kernel_us"] = float(row["AverageNs"]) / 1e3
-    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_rti_kernel.json")
-    if os.path.exists(path):
-        with open(path) as fh:
-            pmc = json.load(fh)
-        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-            out["traffic"] = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
-        if "SQ_WAVE_CYCLES" in pmc and "SQ_WAVES" in pmc:
-            out["wave_cycles_per_simd"] = 4.0 * pmc["SQ_WAVE_CYCLES"]["mean"] / pmc["SQ_WAVES"]["mean"]   # quad-cycles -> cycles
+                if "rti_kernel" in row.get("Name", "") and (best is None or float(row["TotalDurationNs"]) > float(best["TotalDurationNs"])):
+                    best = row
+        if best is not None:
+            out["kernel_us"] = float(best["AverageNs"]) / 1e3
+        path = os.path.join(pdir, tag + "_pmc_rti_kernel.json")
+        if os.path.exists(path):
+            with open(path) as fh:
+                pmc = json.load(fh)
+            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                out["traffic"] = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
+            if "SQ_WAVE_CYCLES" in pmc and "SQ_WAVES" in pmc:
+                out["wave_cycles_per_simd"] = 4.0 * pmc["SQ_WAVE_CYCLES"]["mean"] / pmc["SQ_WAVES"]["mean"]   # quad-cycles -> cycles
+        break
     return out
+
+
+def profile_agrees(prof_us, live_us, tol=PROFILE_TOLERANCE):
+    """The committed profile may only annotate a run whose own HIP-event kernel duration it matches."""
+    return prof_us is not None and live_us is not None and live_us > 0 and abs(prof_us - live_us) <= tol * live_us
 
 
 def effective_cores():
@@ -278,31 +295,38 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-    # The K timed steps are a launch-bound chain of dependent kernels -> one cycle through the T input ticks is captured into
-    # a hipGraph (T kernel nodes) and replayed; a node of a replayed graph starts 1.6 us after its predecessor ends, a host
-    # launch 2.6 us (scripts/ubench/launch_floor.hip).  The graph holds G = a multiple of T steps (at most 256); every step
-    # still runs: K // G replays plus K % G host launches.  With the neighbour exchange on, steps are launched from the host
-    # by default (each also starts an RCCL all-gather); --graph-exchange captures gather + kernel as well.
-    graph, launch_mode = None, "host launch per step"
-    want_graph = not args.no_graph and args.steps >= T and (not exchange or args.graph_exchange or world == 1)
+    # The K timed steps are a launch-bound chain of dependent kernels -> they are captured into a hipGraph and replayed; a node
+    # of a replayed graph starts 1.6 us after its predecessor ends, a host launch 2.6 us (scripts/ubench/launch_floor.hip).
+    # K <= 1024: ONE graph of all K steps, replayed once (the driver's short run -- 20 steps -- is then the steady state, not
+    # 16 replayed + 4 host launches).  K > 1024: a graph of G = 1024 rounded down to whole cycles through the T input ticks,
+    # replayed K // G times, and a second graph with the K % G remaining steps.  Every step runs, inside the timed region.
+    # With the per-step RCCL exchange on, steps are launched from the host by default (each also starts an all-gather);
+    # --graph-exchange captures gather + kernel as well.
+    graphs, launch_mode = [], "host launch per step"
+    want_graph = not args.no_graph and (not exchange or args.graph_exchange or world == 1)
     if want_graph:
         try:
             base = ((args.warmup + T - 1) // T) * T          # a multiple of T: the replayed cycle starts at tick 0
-            G = min(1024, args.steps) // T * T
+            G = args.steps if args.steps <= 1024 else 1024 // T * T
+            plan = [(G, args.steps // G)] + ([(args.steps % G, 1)] if args.steps % G else [])
             fence()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream, capture_error_mode="relaxed"):
-                for i in range(G):
-                    step(base + i)
-                for w in list(pending.values()):             # the last step's prefetch belongs to the captured cycle
-                    ndist.exchange_pv_end(w)
-                pending.clear()
-            torch.cuda.set_stream(stream)
-            graph.replay()                                    # instantiate / upload outside the timed region
-            torch.cuda.synchronize()
-            launch_mode = f"hipGraph of {G} steps replayed"
+            first = base
+            for n_cap, n_rep in plan:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="relaxed"):
+                    for i in range(n_cap):
+                        step(first + i)
+                    for w in list(pending.values()):         # the last step's prefetch belongs to the captured cycle
+                        ndist.exchange_pv_end(w)
+                    pending.clear()
+                torch.cuda.set_stream(stream)
+                g.replay()                                    # instantiate / upload outside the timed region
+                torch.cuda.synchronize()
+                graphs.append((g, n_rep))
+                first += n_cap * n_rep
+            launch_mode = " + ".join(f"hipGraph of {n} steps x {r}" for n, r in plan)
         except Exception as e:                                # capture unsupported: fall back, say so
-            graph, launch_mode = None, f"host launch per step (graph capture failed: {type(e).__name__}: {e})"[:300]
+            graphs, launch_mode = [], f"host launch per step (graph capture failed: {type(e).__name__}: {e})"[:300]
             pending.clear()
             torch.cuda.set_stream(stream)
             torch.cuda.synchronize()
@@ -312,18 +336,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if graph is not None:
-        for _ in range(args.steps // G):
-            graph.replay()
-        for i in range(args.steps % G):
-            step(i)
+    if graphs:
+        for g, n_rep in graphs:
+            for _ in range(n_rep):
+                g.replay()
     else:
         eng.timing_enable(8)  # HIP events around every 8th launch (an event pair per launch costs a dispatch gap)
         for i in range(args.steps):
             step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    if graph is not None:     # the dominant kernel's duration (roofline): HIP events around host-launched steps, outside the timed region
+    if graphs:                # the dominant kernel's duration (roofline): HIP events around host-launched steps, outside the timed region
         eng.timing_enable(1)
         for i in range(64):
             step(i)
@@ -376,6 +399,13 @@ def main():
         abytes = algorithmic_bytes_per_solve(N, downwash)
         is_default = (not cfg4 and fused and B == 1024 and N == 20 and args.qp_mode == 0 and args.perturb == "nominal" and world == 1)
         prof = committed_profile(is_default)
+        # the committed profile annotates this run only if it describes it: its kernel duration must agree with the duration
+        # measured live (HIP events) -- otherwise every figure derived from it is withheld and the mismatch is reported
+        profile_mismatch = None
+        if prof["kernel_us"] is not None and not profile_agrees(prof["kernel_us"], rti_s * 1e6):
+            profile_mismatch = {"tag": prof["tag"], "kernel_us_rocprof": prof["kernel_us"], "kernel_us_live": rti_s * 1e6,
+                                "tolerance": PROFILE_TOLERANCE}
+            prof = {"kernel_us": None, "traffic": None, "wave_cycles_per_simd": None, "tag": prof["tag"]}
         # matrix-pipe occupancy estimate: a v_mfma_f64_16x16x4 / v_mfma_f32_32x32x2 holds the SIMD's pipe 64 cycles, the four-block
         # v_mfma_f64_4x4x4 16, a v_mfma_f32_32x32x16_f16 32 (scripts/ubench; PMC SQ_VALU_MFMA_BUSY_CYCLES of the committed profile
         # = 147 * 64 + 119 * 16 + 12 * 64 + 96 * 32 per instance exactly).  One instance per SIMD; per full sweep at horizon N:
@@ -388,7 +418,7 @@ def main():
         pipe_cycles = (n_16 * 64 + n_4 * 16 + ((12 * 64 + 96 * 32) if fused else 0)) * -(-B // 1024)      # instances per SIMD (1024 SIMDs), in rounds
         clock_hz, clock_src = None, None
         if prof["wave_cycles_per_simd"] and prof["kernel_us"]:
-            clock_hz, clock_src = prof["wave_cycles_per_simd"] / (prof["kernel_us"] * 1e-6), f"profiles/{PROFILE_TAG} PMC SQ_WAVE_CYCLES / kernel trace duration"
+            clock_hz, clock_src = prof["wave_cycles_per_simd"] / (prof["kernel_us"] * 1e-6), f"profiles/{prof['tag']} PMC SQ_WAVE_CYCLES / kernel trace duration"
         if clock_hz is None and not args.only_timed:
             eng.debug_stamps(True)
             eng.timing_enable(1)
@@ -422,7 +452,8 @@ def main():
                        "parallelism": f"instances sharded x{world}"},
             "roofline": {"kernel": "rti_kernel", "bound": "mfma", "achieved": ach_tf, "peak": F64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach_tf / F64_MFMA_PEAK_TFLOPS, "traffic": prof["traffic"],
-                         "traffic_note": f"HBM bytes per launch, PMC (profiles/{PROFILE_TAG}_pmc_rti_kernel.json); algorithmic bytes per launch = %d" % (abytes * B),
+                         "traffic_note": f"HBM bytes per launch, PMC (profiles/{prof['tag']}_pmc_rti_kernel.json); algorithmic bytes per launch = %d" % (abytes * B),
+                         "profile_tag": prof["tag"], "profile_mismatch": profile_mismatch,
                          "kernel_us": rti_s * 1e6, "kernel_us_rocprof": prof["kernel_us"],
                          "frac_rocprof": (f_qp * B / (prof["kernel_us"] * 1e-6) / 1e12 / F64_MFMA_PEAK_TFLOPS) if prof["kernel_us"] else None,
                          "flops_per_solve_f64": f_qp, "riccati_sweeps_per_solve": sweeps, "frac_interior_point": frac_ipm,

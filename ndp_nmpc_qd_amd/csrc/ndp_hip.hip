@@ -110,8 +110,11 @@ struct KernArgs {
 // one 32x32 f32 MFMA tile) and leaves it in the LDS staging slot the RTI program reads f from -- no second
 // launch and no trip of f through HBM.
 // QMODE: 0 = the whole step in place; 1 / 2 = producer / consumer of the interior-point work list (see QueueArgs).
+#ifndef NDP_RTI_ATTR       // kernel-development hook: extra attributes of rti_kernel (e.g. a register cap for occupancy studies)
+#define NDP_RTI_ATTR
+#endif
 template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), int QMODE = 0>
-__global__ __launch_bounds__(64 * WAVES) void rti_kernel(KernArgs ka)
+__global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs ka)
 {
     static_assert(!(FUSED && QMODE == 2), "the consumer reads the force the producer left in global memory");
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -926,7 +929,10 @@ using namespace ndp;
 // that an experiment on the headline kernel compiles in 20 s instead of 3 min; such a library serves N = 20, n_rti = 1 only.
 #ifdef NDP_DEV_HEADLINE_ONLY
 template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), int QMODE = 0>
-struct RtiK { static constexpr auto fn = rti_kernel<3, 4, (FUSED && NC == 20 && QMODE == 0), 20, 0, 1, 0>; };
+#ifndef NDP_DEV_QMODE      // 1: study the work list's producer form (no interior-point code) in place of the in-place kernel
+#define NDP_DEV_QMODE 0
+#endif
+struct RtiK { static constexpr auto fn = rti_kernel<3, 4, (FUSED && NC == 20 && QMODE == 0), 20, 0, 1, NDP_DEV_QMODE>; };
 #define RTI_K(...) (RtiK<__VA_ARGS__>::fn)
 #else
 #define RTI_K(...) (rti_kernel<__VA_ARGS__>)
