@@ -123,11 +123,13 @@ def main():
     ap.add_argument("--graph-exchange", action="store_true",
                     help="N > 1 with the exchange on: capture gather + kernel of every step into the hipGraph too (default: host launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: bounded sample, about this many seconds")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "rccl"],
-                    help="N > 1, vehicle-major placement: how a rank gets its neighbours' reference windows.  peer: it maps the "
-                         "neighbour rank's window buffer once (IPC handle) and the control-step kernel reads it over xGMI -- no "
-                         "per-step collective, steps replayed as a hipGraph like at N = 1; rccl: one all-gather of the "
-                         "position/velocity columns per step; auto: peer, falling back to rccl if the mapping fails on any rank")
+    ap.add_argument("--exchange", default="both", choices=["both", "peer", "rccl"],
+                    help="N > 1 (and --config 4), vehicle-major placement: how a rank gets its neighbours' reference windows, every "
+                         "step.  rccl: one all-gather of the position/velocity columns per step (the north star's collective); peer: "
+                         "one publish launch per step into a peer-mapped slot + epoch word, the control-step kernel reads the "
+                         "neighbour's slot over xGMI; both (default): the timed steps are run once in each form, `value` is the rccl "
+                         "form's, `exchange` carries both")
+    ap.add_argument("--peer-timeout-us", type=int, default=200000, help="bound of each wait of the peer form (epoch / acknowledgement)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -184,74 +186,45 @@ def main():
 
     eng = ndp.BatchedNMPC(B, N=N, disturbance=downwash, qp_mode=args.qp_mode, device=local_rank, work_queue=args.work_queue)
     # an explicit non-default stream: torch's default stream has handle 0, which the C-ABI reads as "use the
-    # library's own stream" -- with a real handle the all-gather (N > 1) and the kernel are ordered on ONE stream
+    # library's own stream" -- with a real handle the exchange (N > 1) and the kernel are ordered on ONE stream
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     u0 = torch.empty(B, 4, dtype=torch.float64, device=dev)
-    # Neighbour exchange (vehicle-major placement): ONE all-gather per step of the position / velocity columns of the ranks'
-    # reference windows, [B, N+1, 6] fp64 per rank -- all that the gate and the MLP read (downwash_nn.py:22).  config 3 (ring of
-    # ranks): rank r reads rank r+1's slice of the gathered buffer as it lies; config 4: the kernel picks each leader's
-    # neighbour row through other_index.  Two gather buffers: the gather of tick i+1's windows (functions of time only) is
-    # started before tick i's kernel is launched and runs on RCCL's stream beside it.
-    exchange = downwash and args.placement == "vehicle" and (world > 1 or cfg4)
-    # peer windows (N > 1): map the neighbour rank's published windows once; no per-step exchange call
-    peer, exchange_mode = None, ("rccl all-gather per step" if exchange and world > 1 else "none")
-    if exchange and world > 1 and args.exchange in ("auto", "peer"):
+    # ---- neighbour exchange (vehicle-major placement: a leader's neighbour lives on the next rank).  The reference publishes a
+    # NEW PredXU every control tick (nmpc_node.py:116-133,229-230) and the leader consumes it (ndp_nmpc_leader_node.py:40,60-76);
+    # every timed step therefore contains one exchange of this tick's windows, in one of two forms, BOTH of which are run and
+    # reported (`exchange`), the north star's collective first and as the headline `value`:
+    #   rccl : ONE all-gather per step of the position / velocity columns of the ranks' reference windows, [B, N+1, 6] fp64 per
+    #          rank -- all that the gate and the MLP read (downwash_nn.py:22).  config 3 (ring of ranks): rank r reads rank r+1's
+    #          slice of the gathered buffer as it lies; config 4: the kernel picks each leader's neighbour row through
+    #          other_index.  Two gather buffers: the gather of tick i+1's windows (functions of time only) is started before tick
+    #          i's kernel is launched and runs on RCCL's stream beside it.
+    #   peer : ONE publish launch per step (dist.PeerWindows / csrc/peer_epoch.hpp): this tick's windows into the rank's own
+    #          peer-mapped slot, epoch word, wait for the neighbour's epoch; the control-step kernel then reads the neighbour's
+    #          slot out of the neighbour GPU's HBM over xGMI.  No collective, no host round trip, hipGraph-replayed like N = 1.
+    need_exchange = downwash and args.placement == "vehicle" and (world > 1 or cfg4)
+    if not need_exchange:
+        modes = ["none"]
+    elif same_dev and world > 1:
+        modes = ["peer"]                          # RCCL refuses two ranks on one device
+    else:
+        modes = {"both": ["rccl", "peer"], "rccl": ["rccl"], "peer": ["peer"]}[args.exchange]
+    peer, peer_err = None, None
+    if "peer" in modes:
         try:
-            peer = ndist.PeerWindows(B, N, T, local_rank)
-            for t in range(T):
-                peer.local[t].copy_(ticks[t]["xr"])
-            peer.publish()
-            exchange, exchange_mode = False, "peer windows over xGMI (mapped once, read by the kernel)"
+            peer = ndist.PeerWindows(B, N, local_rank, timeout_us=args.peer_timeout_us)
             if cfg4:
-                nb_row = ndist.config4_other_index(rank, world, args.formations, "vehicle", peer_rows=True)
-                peer_oidx = torch.from_numpy(nb_row).to(dev)
-        except Exception as e:                                    # same outcome on every rank (PeerWindows exchanges the result)
-            if args.exchange == "peer":
+                peer_oidx = torch.from_numpy(ndist.config4_other_index(rank, world, args.formations, "vehicle", peer_rows=True)).to(dev)
+        except Exception as e:                    # same outcome on every rank (PeerWindows exchanges the result)
+            peer_err = f"{type(e).__name__}: {e}"[:200]
+            modes = [m for m in modes if m != "peer"]
+            if not modes:
                 raise
-            peer, exchange_mode = None, f"rccl all-gather per step (peer mapping failed: {type(e).__name__}: {e})"[:200]
-    if same_dev and exchange and world > 1:
-        raise SystemExit("NDP_BENCH_SAME_DEVICE=1 cannot run the RCCL exchange (two ranks on one device)")
-    if exchange:
+    if "rccl" in modes:
         gathered = [torch.empty(world * B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev) for _ in range(2)]
         pv_local = torch.empty(B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev)
-    pending = {}
-
-    def prefetch(i):
-        if exchange:
-            pending[i] = ndist.exchange_pv_begin(ticks[i % T]["xr"], pv_local, gathered[i % 2])   # one RCCL all-gather over xGMI
-
-    def step(i, e=None):
-        e = e or eng
-        d = ticks[i % T]
-        other, oidx = None, None
-        if downwash:
-            if exchange:
-                if i not in pending:
-                    prefetch(i)
-                ndist.exchange_pv_end(pending.pop(i))
-                if cfg4:
-                    other, oidx = gathered[i % 2], d["other_index"]
-                else:
-                    other = gathered[i % 2].view(world, B, N + 1, ndist.PV_COLS)[ndist.neighbour_rank(rank, world)]
-                prefetch(i + 1)
-            elif peer is not None:
-                other = peer.neighbour[i % T]                # the neighbour rank's windows, read over xGMI by the kernel
-                oidx = peer_oidx if cfg4 else None
-            elif cfg4:
-                other, oidx = d["xr"], d["other_index"]      # formation-major: the neighbour's window is a local row of xr
-            else:
-                other = d["other"]
-        e.update_device(d["x0"], d["xr"], d["ur"], u0, other=other, ego_xy=d["ego_xy"] if downwash else None,
-                        stream=stream, other_index=oidx)
-
-    def fence():
-        for w in list(pending.values()):      # a gather started for a tick that is never solved (end of a phase)
-            ndist.exchange_pv_end(w)
-        pending.clear()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    mode_names = {"none": "none", "rccl": "rccl all-gather per step" + ("" if world > 1 else " (one rank: the pack only, no RCCL call)"),
+                  "peer": "peer windows over xGMI: one publish launch per step (epoch-ordered), read by the control-step kernel"}
 
     def host_other(h):
         """The neighbour windows of the host copy of tick 0 (oracle legs)."""
@@ -259,113 +232,184 @@ def main():
             return h["other"]
         allv = ndist.make_config4_all(args.formations, N=N, t0=0.0)
         nb = np.where(h["gids"] % 3 == 0, h["gids"] + 1, h["gids"])
-        oth = allv["xr"][nb].copy()
-        return oth
+        return allv["xr"][nb].copy()
 
-    # ---- parity spot check against the CPU oracle (rank 0, first tick, 64 instances) before timing
-    parity = None
-    eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
-    if not args.only_timed:
-        step(0)
-        fence()
-        if rank == 0:
-            from oracle import oracle as O
-            ns = min(64, B)
-            cfgo = O.default_cfg(N=N, use_fd=downwash)
-            f = None
-            if downwash:
-                blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
-                ego = host0["ego_xy"][:ns].copy()
-                if cfg4:
-                    ego[host0["other_index"][:ns] < 0] = 1e9       # followers: no neighbour, gate closed
-                f = O.downwash_batch(blob, host_other(host0)[:ns], host0["xr"][:ns], ego)
-            Xo, Uo = host0["xr"][:ns].copy(), host0["ur"][:ns].copy()
-            u_or, st_or, _ = O.step_batch(cfgo, host0["x0"][:ns], host0["xr"][:ns], host0["ur"][:ns], f, Xo, Uo)
-            u_dev = u0[:ns].cpu().numpy()
-            parity = float(np.max(np.abs(u_dev - u_or) / np.maximum(1.0, np.abs(u_or))))
+    def run_mode(mode, check_parity):
+        """Parity spot check, warm-up and EXACTLY --steps timed steps of one exchange form; returns its measurements."""
+        exchange = mode == "rccl"
+        pending = {}
 
-    # ---- warm-up, then EXACTLY --steps timed steps between barrier + synchronize
-    eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    if exchange:                              # the first timed tick's windows are in place before the clock starts; every
-        prefetch(args.warmup)                 # timed step then starts exactly one gather (the next tick's) and one kernel
-        ndist.exchange_pv_end(pending[args.warmup])
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-    # The K timed steps are a launch-bound chain of dependent kernels -> they are captured into a hipGraph and replayed; a node
-    # of a replayed graph starts 1.6 us after its predecessor ends, a host launch 2.6 us (scripts/ubench/launch_floor.hip).
-    # K <= 1024: ONE graph of all K steps, replayed once (the driver's short run -- 20 steps -- is then the steady state, not
-    # 16 replayed + 4 host launches).  K > 1024: a graph of G = 1024 rounded down to whole cycles through the T input ticks,
-    # replayed K // G times, and a second graph with the K % G remaining steps.  Every step runs, inside the timed region.
-    # With the per-step RCCL exchange on, steps are launched from the host by default (each also starts an all-gather);
-    # --graph-exchange captures gather + kernel as well.
-    graphs, launch_mode = [], "host launch per step"
-    want_graph = not args.no_graph and (not exchange or args.graph_exchange or world == 1)
-    if want_graph:
-        try:
-            base = ((args.warmup + T - 1) // T) * T          # a multiple of T: the replayed cycle starts at tick 0
-            G = args.steps if args.steps <= 1024 else 1024 // T * T
-            plan = [(G, args.steps // G)] + ([(args.steps % G, 1)] if args.steps % G else [])
-            fence()
-            first = base
-            for n_cap, n_rep in plan:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream, capture_error_mode="relaxed"):
-                    for i in range(n_cap):
-                        step(first + i)
-                    for w in list(pending.values()):         # the last step's prefetch belongs to the captured cycle
-                        ndist.exchange_pv_end(w)
-                    pending.clear()
-                torch.cuda.set_stream(stream)
-                g.replay()                                    # instantiate / upload outside the timed region
-                torch.cuda.synchronize()
-                graphs.append((g, n_rep))
-                first += n_cap * n_rep
-            launch_mode = " + ".join(f"hipGraph of {n} steps x {r}" for n, r in plan)
-        except Exception as e:                                # capture unsupported: fall back, say so
-            graphs, launch_mode = [], f"host launch per step (graph capture failed: {type(e).__name__}: {e})"[:300]
-            pending.clear()
-            torch.cuda.set_stream(stream)
-            torch.cuda.synchronize()
+        def prefetch(i):
             if exchange:
-                prefetch(args.warmup)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if graphs:
-        for g, n_rep in graphs:
-            for _ in range(n_rep):
-                g.replay()
-    else:
-        eng.timing_enable(8)  # HIP events around every 8th launch (an event pair per launch costs a dispatch gap)
-        for i in range(args.steps):
-            step(args.warmup + i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if graphs:                # the dominant kernel's duration (roofline): HIP events around host-launched steps, outside the timed region
-        eng.timing_enable(1)
-        for i in range(64):
+                pending[i] = ndist.exchange_pv_begin(ticks[i % T]["xr"], pv_local, gathered[i % 2])   # one RCCL all-gather over xGMI
+
+        def step(i):
+            d = ticks[i % T]
+            other, oidx = None, None
+            if downwash:
+                if exchange:
+                    if i not in pending:
+                        prefetch(i)
+                    ndist.exchange_pv_end(pending.pop(i))
+                    if cfg4:
+                        other, oidx = gathered[i % 2], d["other_index"]
+                    else:
+                        other = gathered[i % 2].view(world, B, N + 1, ndist.PV_COLS)[ndist.neighbour_rank(rank, world)]
+                    prefetch(i + 1)
+                elif mode == "peer":
+                    other = peer.publish_device(d["xr"], stream)     # this tick's publish launch; the neighbour's slot of this tick
+                    oidx = peer_oidx if cfg4 else None
+                elif cfg4:
+                    other, oidx = d["xr"], d["other_index"]      # formation-major: the neighbour's window is a local row of xr
+                else:
+                    other = d["other"]
+            eng.update_device(d["x0"], d["xr"], d["ur"], u0, other=other, ego_xy=d["ego_xy"] if downwash else None,
+                              stream=stream, other_index=oidx)
+
+        def fence():
+            for w in list(pending.values()):      # a gather started for a tick that is never solved (end of a phase)
+                ndist.exchange_pv_end(w)
+            pending.clear()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        # ---- parity spot check against the CPU oracle (rank 0, first tick, 64 instances) before timing
+        parity = None
+        eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
+        if check_parity:
+            step(0)
+            fence()
+            if rank == 0:
+                from oracle import oracle as O
+                ns = min(64, B)
+                cfgo = O.default_cfg(N=N, use_fd=downwash)
+                f = None
+                if downwash:
+                    blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
+                    ego = host0["ego_xy"][:ns].copy()
+                    if cfg4:
+                        ego[host0["other_index"][:ns] < 0] = 1e9       # followers: no neighbour, gate closed
+                    f = O.downwash_batch(blob, host_other(host0)[:ns], host0["xr"][:ns], ego)
+                Xo, Uo = host0["xr"][:ns].copy(), host0["ur"][:ns].copy()
+                u_or, st_or, _ = O.step_batch(cfgo, host0["x0"][:ns], host0["xr"][:ns], host0["ur"][:ns], f, Xo, Uo)
+                u_dev = u0[:ns].cpu().numpy()
+                parity = float(np.max(np.abs(u_dev - u_or) / np.maximum(1.0, np.abs(u_or))))
+
+        # ---- warm-up, then EXACTLY --steps timed steps between barrier + synchronize
+        eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
+        for i in range(args.warmup):
             step(i)
         fence()
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    rti_ms, rti_n = eng.timing_read("rti")
-    mlp_ms, mlp_n = eng.timing_read("mlp")
-    eng.timing_enable(0)
-    st, it = eng.status()
-    bad = int((st != 0).sum())
+        if exchange:                              # the first timed tick's windows are in place before the clock starts; every
+            prefetch(args.warmup)                 # timed step then starts exactly one gather (the next tick's) and one kernel
+            ndist.exchange_pv_end(pending[args.warmup])
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+        # The K timed steps are a launch-bound chain of dependent kernels -> they are captured into a hipGraph and replayed; a
+        # node of a replayed graph starts 1.6 us after its predecessor ends, a host launch 2.6 us (scripts/ubench/launch_floor.hip).
+        # K <= 1024: ONE graph of all K steps, replayed once (the driver's short run -- 20 steps -- is then the steady state, not
+        # 16 replayed + 4 host launches).  K > 1024: a graph of G = 1024 rounded down to whole cycles through the T input ticks,
+        # replayed K // G times, and a second graph with the K % G remaining steps.  Every step runs, inside the timed region.
+        # rccl form: steps are launched from the host by default (each also starts an all-gather on RCCL's stream); --graph-exchange
+        # captures gather + kernel as well.  peer form: publish + control-step launches are captured like the N = 1 steps (the
+        # slot parity is baked into a launch, so every graph holds an even number of ticks; an odd remainder is host-launched).
+        graphs, tail, launch_mode = [], 0, "host launch per step"
+        want_graph = not args.no_graph and (not exchange or args.graph_exchange or world == 1)
+        if want_graph:
+            try:
+                base = ((args.warmup + T - 1) // T) * T          # a multiple of T: the replayed cycle starts at tick 0
+                G = args.steps if args.steps <= 1024 else 1024 // T * T
+                plan = [(G, args.steps // G)] + ([(args.steps % G, 1)] if args.steps % G else [])
+                if mode == "peer":                              # even graphs only
+                    plan = [(n - (n & 1), r) for n, r in plan if n - (n & 1) > 0]
+                    tail = args.steps - sum(n * r for n, r in plan)
+                fence()
+                first = base
+                for n_cap, n_rep in plan:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=stream, capture_error_mode="relaxed"):
+                        for i in range(n_cap):
+                            step(first + i)
+                        for w in list(pending.values()):         # the last step's prefetch belongs to the captured cycle
+                            ndist.exchange_pv_end(w)
+                        pending.clear()
+                    torch.cuda.set_stream(stream)
+                    g.replay()                                    # instantiate / upload outside the timed region
+                    torch.cuda.synchronize()
+                    graphs.append((g, n_rep))
+                    first += n_cap * n_rep
+                launch_mode = " + ".join(f"hipGraph of {n} steps x {r}" for n, r in plan) + (f" + {tail} host-launched" if tail else "")
+            except Exception as e:                                # capture unsupported: fall back, say so
+                graphs, tail, launch_mode = [], 0, f"host launch per step (graph capture failed: {type(e).__name__}: {e})"[:300]
+                pending.clear()
+                torch.cuda.set_stream(stream)
+                torch.cuda.synchronize()
+                if exchange:
+                    prefetch(args.warmup)
+            if mode == "peer":
+                peer.tick = peer.stats()["ticks"]                 # host mirror of the device-side tick count (capture ran no kernel)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if graphs:
+            for g, n_rep in graphs:
+                for _ in range(n_rep):
+                    g.replay()
+            for i in range(tail):
+                step(args.steps - tail + i)
+        else:
+            eng.timing_enable(8)  # HIP events around every 8th launch (an event pair per launch costs a dispatch gap)
+            for i in range(args.steps):
+                step(args.warmup + i)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if mode == "peer":
+            peer.tick = peer.stats()["ticks"]
+        if graphs:                # the dominant kernel's duration (roofline): HIP events around host-launched steps, outside the timed region
+            eng.timing_enable(1)
+            for i in range(64):
+                step(i)
+            fence()
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        rti_ms, rti_n = eng.timing_read("rti")
+        mlp_ms, mlp_n = eng.timing_read("mlp")
+        eng.timing_enable(0)
+        st, it = eng.status()
+        bad = int((st != 0).sum())
+        if world > 1:
+            agg = torch.tensor([bad], dtype=torch.int64, device=cdev)
+            dist.all_reduce(agg)
+            bad = int(agg.item())
+        res = {"elapsed": elapsed, "launch": launch_mode, "parity": parity, "bad": bad, "rti_ms": rti_ms, "rti_n": rti_n,
+               "mlp_ms": mlp_ms, "mlp_n": mlp_n, "it": it, "step": step, "name": mode_names[mode]}
+        if mode == "peer":
+            ps = peer.stats()
+            if world > 1:                                         # any rank's timed-out wait shows in the line
+                agg = torch.tensor([ps["ack_timeouts"], ps["epoch_timeouts"], ps["slot_mismatches"]], dtype=torch.int64, device=cdev)
+                dist.all_reduce(agg)
+                ps["ack_timeouts"], ps["epoch_timeouts"], ps["slot_mismatches"] = (int(x) for x in agg.tolist())
+            res["peer_stats"] = ps
+        return res
+
+    results = {}
+    for m in modes:
+        results[m] = run_mode(m, check_parity=not args.only_timed)
+    head = results[modes[0]]                      # the north star's collective when it ran, else the only form
+    elapsed, launch_mode, parity, bad, it = head["elapsed"], head["launch"], head["parity"], head["bad"], head["it"]
+    rti_ms, rti_n, mlp_ms, mlp_n, step = head["rti_ms"], head["rti_n"], head["mlp_ms"], head["mlp_n"], head["step"]
+    exchange_mode = head["name"]
+    for r in results.values():                    # a parity failure or a non-converged instance in ANY form fails the run
+        if r["parity"] is not None and (parity is None or r["parity"] > parity):
+            parity = r["parity"]
+        bad = max(bad, r["bad"])
     frac_ipm = float((it > 0).mean()) if args.qp_mode == 0 else 1.0
     sweeps = float(np.mean(np.where(it > 0, 1 + 2 * it, 1))) if args.qp_mode == 0 else float(np.mean(2 * it))
-    if world > 1:
-        agg = torch.tensor([bad], dtype=torch.int64, device=cdev)
-        dist.all_reduce(agg)
-        bad = int(agg.item())
 
     def timed_leg(e, batch_ticks, n_steps, n_warm=10):
         """Device-resident steps of another engine / workload: (solves/s, ms per step, ipm fraction, sweeps per solve)."""
@@ -442,9 +486,9 @@ def main():
                                     if cfg4 else f"batch={B}/GPU independent quadrotors, N={N}, 1 RTI iter, ")
                                    + ("MLP downwash on (NDP controller, gate+MLP fused into the RTI launch)" if fused else
                                       "MLP downwash on (NDP controller)" if downwash else "no downwash (NMPC controller)")
-                                   + (", neighbour windows all-gathered over RCCL" if exchange and world > 1 else
-                                      ", neighbour windows read from the neighbour rank's HBM over xGMI (peer windows, mapped once)" if peer is not None else
-                                      ", vehicle-major placement (position/velocity columns packed for the all-gather; one rank: no RCCL call)" if exchange else
+                                   + (", neighbour windows all-gathered over RCCL every step" if modes[0] == "rccl" and world > 1 else
+                                      ", neighbour windows published every step into a peer-mapped slot and read over xGMI by the kernel" if modes[0] == "peer" else
+                                      ", vehicle-major placement (position/velocity columns packed for the all-gather; one rank: no RCCL call)" if modes[0] == "rccl" else
                                       ", formation-major placement (no exchange)" if (world > 1 or cfg4) else "")
                                    + (", perturbed starts (~20 % of the instances need the interior-point loop)" if args.perturb == "mixed" else ""),
                        "batch_per_gpu": B, "horizon": N, "n_rti": 1, "qp_mode": "auto" if args.qp_mode == 0 else "ipm_always",
@@ -465,6 +509,15 @@ def main():
                          "mlp_kernel_us": mlp_s * 1e6 if mlp_n else None},
             "parity_max_rel_vs_oracle": parity, "instances_not_converged": bad,
         }
+        if need_exchange:
+            # both forms of the per-step neighbour exchange, same steps, same inputs (value = whole-job solves/s)
+            out["exchange"] = {m: {"value": total / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3, "launch": r["launch"],
+                                   "parity_max_rel_vs_oracle": r["parity"], "instances_not_converged": r["bad"], "form": r["name"],
+                                   **({"peer_stats": r["peer_stats"]} if "peer_stats" in r else {})}
+                               for m, r in results.items()}
+            if peer_err:
+                out["exchange"]["peer"] = {"error": peer_err}
+            out["exchange"]["headline"] = modes[0]
         extras = world == 1 and not args.only_timed and not cfg4 and args.perturb == "nominal" and args.qp_mode == 0
         if extras:
             # ---- what the reference's QP solver actually does (HPIPM always iterates): every instance through the interior-point loop
@@ -488,30 +541,57 @@ def main():
             e_m = ndp.BatchedNMPC(B, N=N, disturbance=downwash, device=local_rank)
             out["mixed"]["batch_%d" % B] = timed_leg(e_m, mt, 60)
             del e_m, mt
-            Bq = 8 * B
-            mt = mixed_ticks(Bq)
-            for wq, name in ((1, "work_queue_on"), (2, "work_queue_off")):
-                e_q = ndp.BatchedNMPC(Bq, N=N, disturbance=downwash, device=local_rank, work_queue=wq)
-                out["mixed"]["batch_%d_%s" % (Bq, name)] = timed_leg(e_q, mt, 30)
+            for Bq in (2 * B, 8 * B):      # two and eight instances per SIMD
+                mt = mixed_ticks(Bq)
+                e_q = ndp.BatchedNMPC(Bq, N=N, disturbance=downwash, device=local_rank)          # the automatic choice
+                out["mixed"]["batch_%d" % Bq] = timed_leg(e_q, mt, 30)
+                auto_on = e_q.work_queue
                 del e_q
-            del mt
-            # ---- the metric as SURVEY 8d words it: host arrays in, host arrays out (H2D of the inputs and D2H of u0 inside the time)
+                for wq, name in ((1, "work_queue_on"), (2, "work_queue_off")):
+                    if (wq == 1) == auto_on:
+                        out["mixed"]["batch_%d_%s" % (Bq, name)] = dict(out["mixed"]["batch_%d" % Bq])
+                        continue
+                    e_q = ndp.BatchedNMPC(Bq, N=N, disturbance=downwash, device=local_rank, work_queue=wq)
+                    out["mixed"]["batch_%d_%s" % (Bq, name)] = timed_leg(e_q, mt, 30)
+                    del e_q
+                del mt
+            # ---- the metric as SURVEY 8d words it: host arrays in, host arrays out (H2D of the inputs and D2H of u0 inside the
+            # time).  Pageable numpy arrays, as the reference's callers hold them (nmpc_body_rate_ctl.py:93-112).  Two forms of the
+            # same C-ABI path: ndp_step (one tick at a time: pack -> H2D -> kernel -> D2H -> wait) and ndp_step_begin / _end with
+            # two ticks in flight (tick i+1's packing and PCIe transfer run under tick i's kernel; x0 comes from odometry, not
+            # from the previous u0: nmpc_node.py:202-226).
             hb = {k: np.ascontiguousarray(host0[k]) for k in ("x0", "xr", "ur", "other", "ego_xy")}
             e_h = ndp.BatchedNMPC(B, N=N, disturbance=downwash, device=local_rank)
             e_h.reset(hb["xr"], hb["ur"])
             kw = dict(other=hb["other"], ego_xy=hb["ego_xy"]) if downwash else {}
             for _ in range(5):
-                e_h.update(hb["x0"], hb["xr"], hb["ur"], **kw)
-            nh = 50
+                u_sync = e_h.update(hb["x0"], hb["xr"], hb["ur"], **kw)
+            nh = 100
             th = time.perf_counter()
             for _ in range(nh):
                 e_h.update(hb["x0"], hb["xr"], hb["ur"], **kw)
             th = (time.perf_counter() - th) / nh
+            e_h.reset(hb["xr"], hb["ur"])
+            u_pipe = np.empty((B, 4))
+            e_h.update_begin(hb["x0"], hb["xr"], hb["ur"], **kw)
+            for _ in range(5):
+                e_h.update_begin(hb["x0"], hb["xr"], hb["ur"], **kw)
+                e_h.update_end(out=u_pipe)
+            tp = time.perf_counter()
+            for _ in range(nh):
+                e_h.update_begin(hb["x0"], hb["xr"], hb["ur"], **kw)
+                e_h.update_end(out=u_pipe)
+            tp = (time.perf_counter() - tp) / nh
+            e_h.update_end(out=u_pipe)
             in_b = 8 * (10 + 10 * (N + 1) + 4 * N) + ((8 * 10 * (N + 1) + 16) if downwash else 0)      # host -> device bytes per solve
-            out["value_host_inclusive"] = {"value": B / th, "unit": "solves/s", "ms_per_step": th * 1e3,
-                                           "note": "ndp_step on pageable numpy arrays: H2D of x0/xr/ur/other/ego_xy (%.1f MB per step), kernel, D2H of u0 + "
-                                                   "status, one synchronisation; PCIe Gen5 x16 (63 GB/s spec) alone bounds this at %.1f M solves/s"
-                                                   % (in_b * B / 1e6, 63e9 / (in_b + 36) / 1e6)}
+            out["value_host_inclusive"] = {
+                "value": B / tp, "unit": "solves/s", "ms_per_step": tp * 1e3,
+                "form": "ndp_step_begin / ndp_step_end, two ticks in flight (packing + H2D of tick i+1 under tick i's kernel)",
+                "pcie_GBps_implied": (in_b + 40) * B / tp / 1e9,
+                "one_tick_at_a_time": {"value": B / th, "ms_per_step": th * 1e3, "form": "ndp_step", "pcie_GBps_implied": (in_b + 40) * B / th / 1e9},
+                "note": "pageable numpy arrays in, numpy u0 out: pack into a page-locked mirror (pack threads) -> H2D in a few copies issued as "
+                        "they are packed (%.1f MB per step) -> kernel -> ONE D2H of u0 | status | iterations; PCIe Gen5 x16 (63 GB/s spec) alone "
+                        "bounds this at %.1f M solves/s" % (in_b * B / 1e6, 63e9 / (in_b + 40) / 1e6)}
             del e_h
         if not args.no_cpu_baseline and not args.only_timed and world == 1 and not cfg4:
             from oracle import oracle as O
@@ -579,13 +659,18 @@ def main():
                            "kernel reads, one launch, u0 + iterate + status written by the kernel into a page-locked block, one sync -- no DMA "
                            "operation); deadline = the reference's 20 ms warning (nmpc_node.py:216-220)" % N)
             out["config1_single_vehicle"] = lat
-        fail = (parity is not None and not parity <= 1e-5) or bad > 0
+        ps = results["peer"].get("peer_stats") if "peer" in results else None
+        peer_bad = bool(ps and (ps["ack_timeouts"] or ps["epoch_timeouts"] or ps["slot_mismatches"]))
+        fail = (parity is not None and not parity <= 1e-5) or bad > 0 or peer_bad
         if fail:
-            out["error"] = f"parity_max_rel_vs_oracle {parity} (bar 1e-5), instances_not_converged {bad}: value withheld"
+            out["error"] = (f"parity_max_rel_vs_oracle {parity} (bar 1e-5), instances_not_converged {bad}"
+                            + (f", peer exchange waits timed out / slots mismatched {ps}" if peer_bad else "") + ": value withheld")
             out["value_unchecked"], out["value"] = out["value"], None
         print(json.dumps(out), flush=True)
     else:
         fail = False
+    if peer is not None:
+        peer.close()
     if world > 1:
         flag = torch.tensor([int(fail)], dtype=torch.int64, device=cdev)
         dist.broadcast(flag, 0)

@@ -60,7 +60,7 @@ typedef struct ndp_cfg {
                            * 3 / 4 run the Riccati sweeps on the fp32 / bf16-input matrix instructions (everything else stays
                            * fp64); 1 / 2 are the first round's operand-rounding studies on the fp64 kernel */
     int32_t work_queue; /* instances whose QP needs the interior-point loop are re-distributed over all SIMDs through an
-                         * work list (producer + consumer launch per step): 0 = automatic (qp_mode AUTO and batch >= 4 x the device's
+                         * work list (producer + consumer launch per step): 0 = automatic (qp_mode AUTO and batch >= 2 x the device's
                          * SIMD count, or the N = 40 / 2-iteration shape at any batch), 1 = on, 2 = off */
     int32_t reserved0;
     double dt;          /* T_horizon / N_node        params/nmpc_params.py:10,12  */
@@ -116,12 +116,32 @@ int ndp_step_device(ndp_handle *h, const void *d_x0, const void *d_xr, const voi
 /* ndp_step plus, from the same call (one synchronisation, no further round trips), what the reference's callers read
  * after solve_for_x0: the new iterate (solver.get(i,"x"/"u"), nmpc_node.py:237), solver.status
  * (nmpc_body_rate_ctl.py:109) and the interior-point iterations.  Any of the four output pointers may be NULL.
- * Batches whose inputs fit 1 MiB use page-locked host blocks owned by the handle that the kernel reads (inputs) and writes (u0,
- * status, iterate) directly: one launch and one synchronisation per call, no DMA operation.  (For such handles
- * ndp_device_iterate_x / _u return device-accessible pointers into that page-locked block.) */
+ *
+ * How a host-array step moves its data (both forms; the reference's call shape is host arrays in, host array out,
+ * nmpc_body_rate_ctl.py:93-112).  The handle owns two slots of page-locked host mirrors (allocated by the first host step).
+ * The caller's arrays are packed into a slot's input mirror by the handle's pack threads (NDP_PACK_THREADS, default: half
+ * the hardware threads, at most 8); then
+ *   - batches whose inputs fit 1 MiB (B <= ~190 at N = 20): the kernel reads that mirror and writes u0 / status / iterations
+ *     -- and a copy of the new iterate when X_out / U_out are given -- into the slot's output mirror itself: one launch and
+ *     one synchronisation per call, no DMA operation;
+ *   - larger batches: the mirror goes to the slot's device block in a few H2D copies, each issued as soon as its part is
+ *     packed (packing and PCIe overlap); the kernel waits for the last; ONE D2H copy returns u0 | status | iterations
+ *     (| X | U when asked for).
+ * The persistent iterate itself always lives in HBM (ndp_device_iterate_x / _u), whatever the batch size. */
 int ndp_step_ex(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
                 const double *other, const double *ego_xy, double *u0, double *X_out, double *U_out,
                 int32_t *status_out, int32_t *ipm_iters_out);
+/* The same step in two halves, so that a caller can keep two control ticks in flight: ndp_step_begin packs the inputs, enqueues
+ * H2D -> kernel -> D2H and returns without waiting; ndp_step_end waits for the OLDEST begun step and hands its results over.
+ * With a second ndp_step_begin issued before the first ndp_step_end, the packing and PCIe transfer of tick i+1 run while tick
+ * i's kernel does -- the reference's control loop has that freedom too: x0 comes from odometry, not from the previous u0
+ * (nmpc_node.py:202-226).  At most two steps may be in flight (a third ndp_step_begin returns -14); steps complete in order;
+ * the warm start of tick i+1 is tick i's iterate, as always (stream order).
+ *   flags bit 0: ndp_step_end will be asked for the iterate (X_out / U_out) of this step.
+ * ndp_step / ndp_step_ex = begin + end under one lock. */
+int ndp_step_begin(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
+                   const double *other, const double *ego_xy, int flags);
+int ndp_step_end(ndp_handle *h, double *u0, double *X_out, double *U_out, int32_t *status_out, int32_t *ipm_iters_out);
 /* ndp_step_device with the neighbour windows addressed the way a multi-GPU exchange leaves them (the reference's PredXU
  * traffic, nmpc_node.py:116-133 -> ndp_nmpc_leader_node.py:60-76):
  *   other_stride   : doubles per node of d_other, 10 (full windows) or 6 (positions + velocities, all the gate and the MLP
@@ -230,18 +250,35 @@ int ndp_plant_step_device(ndp_handle *h, void *d_x, const void *d_u, const void 
 int ndp_rollout_device(ndp_handle *h, int ticks, double t0, double dt_tick, int substeps, void *d_x, void *d_log, void *stream);
 
 /* ---- Peer windows: the neighbour exchange across GPUs as publish / subscribe over xGMI.
- * Replaces the PredXU topic between processes: the publisher is nmpc_node.py:116-133 (`nmpc_x_ref`, 21x10 float64 per tick), the
- * subscriber ndp_nmpc_leader_node.py:40,60-76.  One process per GPU: the publisher allocates its window buffer with
- * ndp_peer_alloc and sends the 64-byte handle to the subscriber's process (any channel: torch.distributed object collectives,
- * a socket); the subscriber maps it with ndp_peer_open and passes the mapped pointer as `other` of ndp_step_device[_ex] --
- * the control-step kernel then reads the neighbour's windows out of the publisher's HBM (peer access), no per-step
- * collective.  Ordering between the publisher's writes and the subscriber's reads is the caller's (events / barriers), as
- * it is between a ROS publisher and its subscriber.
- *   ndp_peer_alloc: bytes of device memory on `device` -> *ptr and its handle (64 bytes).
- *   ndp_peer_open : maps another process's buffer into this process for use on `device` -> *ptr.
- *   ndp_peer_close / ndp_peer_free: undo open / alloc.   All return 0 or a negative error code. */
+ * Replaces the PredXU topic between processes: the publisher is nmpc_node.py:116-133,229-230 (`nmpc_x_ref`, 21x10 float64, a NEW
+ * message every control tick), the subscriber ndp_nmpc_leader_node.py:40,60-76 (consumes the latest one).  One process per GPU:
+ * the publisher allocates its window buffer with ndp_peer_alloc and sends the 64-byte handle to the subscriber's process once
+ * (any channel: torch.distributed object collectives, a socket); the subscriber maps it with ndp_peer_open.  Every control tick
+ * each rank then runs ONE ndp_peer_publish_device launch in front of its control-step launch: it writes this tick's windows into
+ * one of the two slots of its own buffer, publishes the tick number (an epoch word, system scope) and waits for the
+ * neighbour's epoch of the same tick; the control-step kernel launched next reads the neighbour's slot straight out of the
+ * publisher's HBM (peer access over xGMI) -- no collective, no host round trip.  Writer -> reader ordering, slot reuse (the
+ * reader's acknowledgement), bounded waits and their counters: csrc/peer_epoch.hpp.
+ *   ndp_peer_layout : bytes of a buffer whose slots hold n_doubles each ([B][N+1][10] windows: n = B*(N+1)*10), the offset
+ *                     of slot 0 and the slot stride (bytes).  The first 512 bytes are protocol words.
+ *   ndp_peer_alloc  : zeroed device memory on `device` -> *ptr and its IPC handle (64 bytes).
+ *   ndp_peer_open   : maps another process's buffer into this process for use on `device` -> *ptr.
+ *   ndp_peer_publish_device : the per-tick launch described above.  d_src: this rank's windows of the tick (n_doubles, device
+ *                     memory); own_buf / nb_buf: this rank's buffer and the mapped neighbour buffer (the same pointer with one
+ *                     rank); slot = parity of the tick (first tick = 1 -> slot 1, then alternating): the slot whose address
+ *                     the caller hands to the control step as `other` (a mismatch with the device-side tick is counted);
+ *                     timeout_us bounds each wait.  Capturable into a hipGraph (an even number of ticks per graph).
+ *   ndp_peer_stats  : synchronises `device`; out4 = {ticks published, reader-acknowledgement timeouts, neighbour-epoch
+ *                     timeouts (the slot was read as it was: stale), slot-parity mismatches}.
+ *   ndp_peer_close / ndp_peer_free: undo open / alloc (the mapping keeps the memory alive: a reader whose publisher has
+ *                     exited goes on reading the last published windows and counts epoch timeouts).
+ * All return 0 or a negative error code. */
+int ndp_peer_layout(size_t n_doubles, size_t *buffer_bytes, size_t *slot0_offset, size_t *slot_stride);
 int ndp_peer_alloc(int device, size_t bytes, void **ptr, unsigned char *handle64);
 int ndp_peer_open(int device, const unsigned char *handle64, void **ptr);
+int ndp_peer_publish_device(int device, const void *d_src, size_t n_doubles, void *own_buf, void *nb_buf, int slot,
+                            unsigned timeout_us, void *stream);
+int ndp_peer_stats(int device, const void *own_buf, unsigned long long *out4);
 int ndp_peer_close(int device, void *ptr);
 int ndp_peer_free(int device, void *ptr);
 

@@ -42,7 +42,8 @@ EXPORTS = [
     "ndp_ref_set_trajectory", "ndp_ref_window", "ndp_ref_window_device", "ndp_rollout_device",
     "ndp_step_ex", "ndp_step_device_ex", "ndp_work_queue_enabled", "ndp_ref_list_reset", "ndp_ref_list_fix_pt",
     "ndp_ref_list_window", "ndp_ref_list_advance_device", "ndp_ref_list_window_device", "ndp_debug_mfma_probe_f32",
-    "ndp_peer_alloc", "ndp_peer_open", "ndp_peer_close", "ndp_peer_free",
+    "ndp_peer_alloc", "ndp_peer_open", "ndp_peer_close", "ndp_peer_free", "ndp_step_begin", "ndp_step_end",
+    "ndp_peer_layout", "ndp_peer_publish_device", "ndp_peer_stats",
 ]
 
 _lib = None
@@ -76,6 +77,8 @@ def load():
     lib.ndp_step.argtypes = [vp] * 8
     lib.ndp_step_device.argtypes = [vp] * 9
     lib.ndp_step_ex.argtypes = [vp] * 12
+    lib.ndp_step_begin.argtypes = [vp] * 7 + [C.c_int]
+    lib.ndp_step_end.argtypes = [vp] * 6
     lib.ndp_step_device_ex.argtypes = [vp] * 6 + [C.c_int] + [vp] * 4
     lib.ndp_work_queue_enabled.argtypes = [vp]
     lib.ndp_ref_list_reset.argtypes = [vp]
@@ -103,6 +106,9 @@ def load():
     lib.ndp_peer_open.argtypes = [C.c_int, vp, C.POINTER(vp)]
     lib.ndp_peer_close.argtypes = [C.c_int, vp]
     lib.ndp_peer_free.argtypes = [C.c_int, vp]
+    lib.ndp_peer_layout.argtypes = [C.c_size_t] + [C.POINTER(C.c_size_t)] * 3
+    lib.ndp_peer_publish_device.argtypes = [C.c_int, vp, C.c_size_t, vp, vp, C.c_int, C.c_uint, vp]
+    lib.ndp_peer_stats.argtypes = [C.c_int, vp, C.POINTER(C.c_ulonglong)]
     lib.ndp_debug_stamps.argtypes = [vp, C.c_int, vp]
     lib.ndp_throttle_reset.argtypes = [vp]
     lib.ndp_throttle_update.argtypes = [vp] * 4

@@ -95,6 +95,33 @@ class BatchedNMPC:
             raise Exception("acados acados_ocp_solver returned status {}. Exiting.".format(rc))
         return (u0, X, U, st, it) if full else u0
 
+    def update_begin(self, x0, xr, ur, f=None, other=None, ego_xy=None, want_iterate=False):
+        """First half of update(): packs the host arrays, enqueues H2D -> kernel -> D2H and returns without waiting
+        (ndp_step_begin).  Up to two steps may be in flight: begin tick i+1 before update_end() of tick i and the packing and
+        PCIe transfer of tick i+1 overlap tick i's kernel.  The arrays may be reused as soon as this returns."""
+        x0 = _lib.f64(x0, (self.B, 10))
+        xr = _lib.f64(xr, (self.B, self.N + 1, 10))
+        ur = _lib.f64(ur, (self.B, self.N, 4))
+        f32 = None if f is None else np.ascontiguousarray(f, dtype=np.float32).reshape(self.B, self.N + 1, 3)
+        other = _lib.f64(other, (self.B, self.N + 1, 10))
+        ego_xy = _lib.f64(ego_xy, (self.B, 2))
+        self._check(self._lib.ndp_step_begin(self._h, _lib.ptr(x0), _lib.ptr(xr), _lib.ptr(ur), _lib.ptr(f32), _lib.ptr(other),
+                                             _lib.ptr(ego_xy), 1 if want_iterate else 0), "ndp_step_begin")
+
+    def update_end(self, raise_on_status=True, full=False, out=None):
+        """Second half: waits for the oldest begun step; returns u0[B,4] (full=True: (u0, X, U, status, ipm_iters); X, U only if
+        that step was begun with want_iterate).  `out`: a [B,4] float64 array to write u0 into."""
+        u0 = np.empty((self.B, 4), dtype=np.float64) if out is None else out
+        st = it = X = U = None
+        if full:
+            X, U = np.empty((self.B, self.N + 1, 10)), np.empty((self.B, self.N, 4))
+            st, it = np.empty(self.B, dtype=np.int32), np.empty(self.B, dtype=np.int32)
+        rc = self._check(self._lib.ndp_step_end(self._h, _lib.ptr(u0), _lib.ptr(X), _lib.ptr(U), _lib.ptr(st), _lib.ptr(it)),
+                         "ndp_step_end")
+        if rc != 0 and raise_on_status:
+            raise Exception("acados acados_ocp_solver returned status {}. Exiting.".format(rc))
+        return (u0, X, U, st, it) if full else u0
+
     def update_debug(self, x0, xr, ur, f=None, other=None, ego_xy=None):
         """B = 1 only: one step that also returns the kernel's LDS image after linearisation (tests)."""
         x0, xr, ur = _lib.f64(x0, (1, 10)), _lib.f64(xr, (1, self.N + 1, 10)), _lib.f64(ur, (1, self.N, 4))

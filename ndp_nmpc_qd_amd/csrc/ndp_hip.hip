@@ -8,15 +8,22 @@
 // There is no CPU fallback: every entry point fails (<0) if HIP is unusable.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
 #include "wave_gfx950.hpp"   // defines the device qualifiers, must precede rti_wave.hpp
 #include "cfg_params.hpp"
+#define NDP_PEER_FN __host__ __device__ inline
+#include "peer_epoch.hpp"
 
 namespace ndp {
 
@@ -42,6 +49,7 @@ struct BatchPtrs {
     const float *f;
     double *X, *U, *u0;
     int *status, *iters;
+    double *Xm, *Um;        // mirror of the new iterate ([B][N+1][10] | [B][N][4], page-locked host memory) or null
     double *dbg;
     double *stamps;         // [B][16] phase stamps of every instance (ndp_debug_stamps), or null
 };
@@ -65,11 +73,13 @@ struct MlpArgs {            // fused downwash (null frag = not fused)
 //                               and NOT touched otherwise;
 //   consumer launch  (QMODE 2): wave j solves list entry j from scratch with the interior-point loop; waves past the end
 //                               of the list exit at once -- the listed instances are spread evenly over all SIMDs.
-// The list counter is zeroed by a memset node in front of the producer.  (An in-kernel queue -- finished waves popping
+// The list counter is zeroed by the consumer itself: every consumer workgroup reads it once and counts itself; the workgroup
+// that counts last -- every other one has read the counter by then -- resets both words for the next step's producer (round 2
+// had a memset node per step in front of the producer: 4.6 us).  (An in-kernel queue -- finished waves popping
 // other instances' solves -- was built first: as a second inlined copy of the unrolled step it wrecked the register
 // allocation of both copies, as a called function it lost the scalar registers; either way 2.3x slower than this.)
 struct QueueArgs {
-    unsigned *count;        // entries of ids
+    unsigned *count;        // entries of ids; count[1] = consumer workgroups that have read count[0] (see rti_kernel, QMODE 2)
     int *ids;               // [B]
 };
 
@@ -88,6 +98,8 @@ __device__ __forceinline__ void bind_instance(RtiIo &io, const BatchPtrs &bp, in
     io.f = bp.f ? bp.f + inst * nf : nullptr;
     io.X = bp.X + inst * nx;
     io.U = bp.U + inst * nu;
+    io.Xm = bp.Xm ? bp.Xm + inst * nx : nullptr;
+    io.Um = bp.Xm ? bp.Um + inst * nu : nullptr;
     io.u0 = bp.u0 + (size_t)inst * NU;
     io.status = bp.status + inst;
     io.iters = bp.iters + inst;
@@ -126,7 +138,17 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     const int wave = (int)(threadIdx.x >> 6);
     int inst_raw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave);
     if (QMODE == 2) {         // list entry -> instance; past the end of the list: nothing to do
-        const int n = (int)*qa.count;
+        __shared__ int n_list;
+        if (threadIdx.x == 0) {
+            n_list = (int)qa.count[0];
+            const unsigned seen = __hip_atomic_fetch_add(qa.count + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen == gridDim.x - 1) {      // every workgroup of this launch has read the list length: reset for the next step
+                __hip_atomic_store(qa.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(qa.count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        const int n = n_list;
         if (inst_raw >= n) return;
         inst_raw = __builtin_amdgcn_readfirstlane(qa.ids[inst_raw]);
     }
@@ -919,6 +941,67 @@ __global__ __launch_bounds__(256) void ref_list_window_kernel(const double *__re
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ peer windows: per-tick publish
+// peer_epoch.hpp's protocol on the device.  ONE launch per control tick and rank, in front of the control-step launch:
+//   thread 0 of block 0   : reader role -- acknowledge tick t-1 in the neighbour's header (its slot may be overwritten now)
+//   thread 0 of each block: owner role  -- wait until the own slot t & 1 is free (the reader's acknowledgement of tick t-2)
+//   all threads           : copy this tick's windows (src, the reference generator's output) into the own slot
+//   last block to finish  : epoch[t & 1] := t (release, system scope), then -- reader role -- wait for the neighbour's
+//                           epoch of tick t.  When the launch has completed, the control-step kernel launched next on the same
+//                           stream may read the neighbour's slot t & 1 (kernel boundary = system-scope acquire).
+struct PeerDevMem {
+    typedef unsigned long long u64;
+    static __device__ __forceinline__ u64 load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    static __device__ __forceinline__ void store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    static __device__ __forceinline__ u64 now_us() { return __builtin_amdgcn_s_memrealtime() / 100; }   // 100 MHz constant clock
+};
+
+struct PeerPubArgs {
+    const double *src;              // [n] doubles: this rank's windows of the tick
+    unsigned long long *own;        // this rank's buffer (header + two slots)
+    unsigned long long *nb;         // the neighbour rank's buffer, mapped (== own with one rank)
+    size_t n;
+    int slot;                       // the slot parity the host baked into the control-step launch that follows
+    unsigned timeout_us;
+};
+
+__global__ __launch_bounds__(256) void peer_publish_kernel(PeerPubArgs a)
+{
+    typedef PeerProto<PeerDevMem> PP;
+    typedef unsigned long long u64;
+    __shared__ u64 tick_s;
+    __shared__ unsigned last_s;
+    if (threadIdx.x == 0) {
+        const u64 t = PP::next_tick(a.own);
+        if (blockIdx.x == 0) PP::ack_previous(a.nb, t);
+        const bool freed = PP::wait_slot_free(a.own, t, a.timeout_us);
+        if (blockIdx.x == 0 && !freed) a.own[PEER_W_STAT + PEER_STAT_ACK_TIMEOUT] += 1;
+        tick_s = t;
+    }
+    __syncthreads();
+    const u64 t = tick_s;
+    double2 *dst = reinterpret_cast<double2 *>(reinterpret_cast<unsigned char *>(a.own) + peer_slot_offset(a.n, (int)(t & 1)));
+    const double2 *src = reinterpret_cast<const double2 *>(a.src);
+    const size_t n2 = a.n / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    if ((a.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<double *>(dst)[a.n - 1] = a.src[a.n - 1];
+    __threadfence_system();                       // this thread's part of the slot is visible system-wide ...
+    __syncthreads();                              // ... and so is the whole block's, before the block counts itself done
+    if (threadIdx.x == 0) {
+        unsigned *done = reinterpret_cast<unsigned *>(a.own + PEER_W_DONE);
+        const unsigned prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = prev == gridDim.x - 1 ? 1u : 0u;
+        if (last_s) {
+            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            PP::set_epoch(a.own, t);
+            a.own[PEER_W_STAT + PEER_STAT_TICKS] = t;
+            if ((int)(t & 1) != a.slot) a.own[PEER_W_STAT + PEER_STAT_DESYNC] += 1;
+            if (!PP::wait_epoch(a.nb, t, a.timeout_us)) a.own[PEER_W_STAT + PEER_STAT_EPOCH_TIMEOUT] += 1;
+        }
+    }
+}
+
 }  // namespace ndp
 
 // ------------------------------------------------------------------------------------------ C-ABI
@@ -937,6 +1020,88 @@ struct RtiK { static constexpr auto fn = rti_kernel<3, 4, (FUSED && NC == 20 && 
 #else
 #define RTI_K(...) (rti_kernel<__VA_ARGS__>)
 #endif
+
+// ---- host pack threads.  A host-array step first moves the caller's (pageable) arrays into a page-locked mirror; at batch 1024
+// that is 4.2 MB per step, ~0.4 ms for one core -- more than the PCIe transfer (~80 us) and the kernel (~23 us) together.  The
+// mirror is therefore filled by a few persistent threads, a chunk (<= PACK_CHUNK bytes) at a time, while the calling thread
+// hands every finished run of chunks to the DMA engine: packing, H2D and (of the previous step) the kernel overlap.
+struct PackJob { unsigned char *dst; const unsigned char *src; size_t len, off; };
+enum : size_t { PACK_CHUNK = (size_t)256 << 10 };
+struct PackPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<const PackJob *> jobs{nullptr};
+    std::atomic<int> njobs{0}, next{0}, active{0};
+    std::unique_ptr<std::atomic<int>[]> done;
+    int done_cap = 0;
+    uint64_t gen = 0;
+    bool stop = false;
+
+    explicit PackPool(int n)
+    {
+        for (int i = 0; i < n; ++i) th.emplace_back([this] { work(); });
+    }
+    ~PackPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : th) t.join();
+    }
+    bool take_one()
+    {   // njobs is published last (release) and read first (acquire): a thread that sees a job count sees that list and its flags
+        const int n = njobs.load(std::memory_order_acquire);
+        if (n == 0) return false;
+        const int i = next.fetch_add(1, std::memory_order_acq_rel);
+        if (i >= n) return false;
+        const PackJob &j = jobs.load(std::memory_order_relaxed)[i];
+        memcpy(j.dst, j.src, j.len);
+        done[i].store(1, std::memory_order_release);
+        return true;
+    }
+    void drain() { while (take_one()) {} }
+    void work()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+                active.fetch_add(1, std::memory_order_acq_rel);   // under the lock: post() cannot miss a worker that saw this generation
+            }
+            drain();
+            active.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+    // hands the job list to the workers; the caller then consumes done[i] in order (wait_job) and must call finish()
+    void post(const PackJob *j, int n)
+    {
+        if (n > done_cap) { done.reset(new std::atomic<int>[n]); done_cap = n; }
+        for (int i = 0; i < n; ++i) done[i].store(0, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            jobs.store(j, std::memory_order_relaxed);
+            next.store(0, std::memory_order_relaxed);
+            njobs.store(n, std::memory_order_release);
+            ++gen;
+        }
+        if (!th.empty() && n > 1) cv.notify_all();
+    }
+    bool is_done(int i) const { return done[i].load(std::memory_order_acquire) != 0; }
+    void wait_job(int i)
+    {
+        // the caller packs as well while it has nothing to hand to the DMA engine (and does everything when there are no threads)
+        while (!is_done(i))
+            if (!take_one()) std::this_thread::yield();
+    }
+    void finish()
+    {   // the job list lives on the caller's stack: no worker may still be looking at it when the caller returns
+        njobs.store(0, std::memory_order_release);
+        while (active.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    }
+};
 
 struct ndp_handle {
     ndp_cfg cfg;
@@ -962,16 +1127,35 @@ struct ndp_handle {
     unsigned *dQctr = nullptr; // work list: entry count | B instance ids
     int *dQids = nullptr;
     bool have_mlp = false;
-    // Host-pointer entry points.  ONE device block holds every input of a step (x0 | xr | ur | f | other | ego_xy, each
-    // 256-byte aligned) and one holds its small outputs (u0 | status | iters): with a pinned host mirror of both (batches
-    // whose inputs fit PACK_LIMIT) a step is one H2D copy, the launch, and D2H copies that are all in flight before the
-    // single synchronisation.  The sx0.. / dStatus.. pointers below are views into those blocks.
-    unsigned char *dIn = nullptr, *dOut = nullptr, *hIn = nullptr, *hOut = nullptr;
+    // Host-pointer entry points.  ONE block holds every input of a step (x0 | xr | ur | f | other | ego_xy, each 256-byte
+    // aligned) and one its outputs (u0 | status | iters | X | U).  Two slots of page-locked host mirrors (HostSlot, allocated at
+    // the first host step): the caller's arrays are packed into a slot's input mirror by the handle's pack threads and
+    //   * batches whose inputs fit PACK_LIMIT: the kernel reads that mirror and writes u0 / status / iterations (and, when
+    //     asked, a copy of the new iterate) into the slot's output mirror itself -- no DMA operation at all;
+    //   * larger batches: the mirror goes to the slot's device input block in a few H2D copies on a copy stream, each issued
+    //     as soon as its part is packed; the kernel waits for the last one; ONE D2H copy brings u0 | status | iterations back.
+    // With two slots the packing + H2D of step i+1 runs while step i's kernel does (ndp_step_begin / ndp_step_end).
+    // The persistent iterate dX | dU always lives in HBM.  The sx0.. pointers are views into slot 0's device blocks (staging of
+    // the f1-f4 host entry points).
+    unsigned char *dIn = nullptr, *dOut = nullptr;
     size_t off_x0 = 0, off_xr = 0, off_ur = 0, off_f = 0, off_other = 0, off_ego = 0, in_bytes = 0;
-    size_t off_u0 = 0, off_st = 0, off_it = 0, out_bytes = 0;
+    size_t off_u0 = 0, off_st = 0, off_it = 0, out_bytes = 0, out_all = 0;
     double *sx0 = nullptr, *sxr = nullptr, *sur = nullptr, *sother = nullptr, *sego = nullptr, *su0 = nullptr, *sdbg = nullptr;
     float *sf = nullptr;
     int *dStatus = nullptr, *dIters = nullptr;
+    const int *lastStatus = nullptr, *lastIters = nullptr;   // where the last step wrote them (dStatus / dIters or a slot's output mirror)
+    struct HostSlot {
+        unsigned char *hIn = nullptr, *hOut = nullptr, *dIn = nullptr;    // dIn: null when the kernel reads hIn itself
+        hipEvent_t evIn = nullptr, evKernel = nullptr, evOut = nullptr;   // inputs landed | kernel done with dIn | outputs landed in hOut
+        bool busy = false, kernel_recorded = false, want_iter = false;
+        double *dump = nullptr;
+    } slot[2];
+    bool slots_ready = false, zero_copy = false;
+    bool staging_used = false;      // an f1-f4 host entry point staged through slot 0's device block since the last host step
+    hipEvent_t evFront = nullptr;
+    int slot_head = 0, slot_tail = 0, slots_busy = 0;   // begin fills slot_head, end drains slot_tail
+    hipStream_t copy_stream = nullptr;
+    std::unique_ptr<struct PackPool> pool;
     // the last foreign stream a *_device call enqueued on: the getters wait for it (hipEvent)
     hipEvent_t evLast = nullptr;
     bool ev_pending = false;
@@ -1072,6 +1256,7 @@ int ndp_peer_alloc(int device, size_t bytes, void **ptr, unsigned char *handle64
     if (hipSetDevice(device) != hipSuccess) return -2;
     void *p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) return -3;
+    if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return -3; }      // epochs, acknowledgements, counters start at 0
     hipIpcMemHandle_t hd;
     if (hipIpcGetMemHandle(&hd, p) != hipSuccess) { (void)hipFree(p); return -4; }
     memcpy(handle64, &hd, 64);
@@ -1105,20 +1290,59 @@ int ndp_peer_free(int device, void *ptr)
     return hipFree(ptr) == hipSuccess ? 0 : -3;
 }
 
+
+// ---- per-tick publish / subscribe through such buffers (peer_epoch.hpp)
+int ndp_peer_layout(size_t n_doubles, size_t *buffer_bytes, size_t *slot0_offset, size_t *slot_stride)
+{
+    if (buffer_bytes) *buffer_bytes = peer_buffer_bytes(n_doubles);
+    if (slot0_offset) *slot0_offset = peer_slot_offset(n_doubles, 0);
+    if (slot_stride) *slot_stride = peer_slot_bytes(n_doubles);
+    return 0;
+}
+
+int ndp_peer_publish_device(int device, const void *d_src, size_t n_doubles, void *own_buf, void *nb_buf, int slot,
+                            unsigned timeout_us, void *stream)
+{
+    if (!d_src || !own_buf || !nb_buf || n_doubles == 0 || (slot & ~1)) return -1;
+    if (hipSetDevice(device) != hipSuccess) return -2;
+    PeerPubArgs a{(const double *)d_src, (unsigned long long *)own_buf, (unsigned long long *)nb_buf, n_doubles, slot, timeout_us};
+    size_t blocks = (n_doubles / 2 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;      // all of them resident at once: every block's first thread may wait on the reader
+    hipLaunchKernelGGL(peer_publish_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int ndp_peer_stats(int device, const void *own_buf, unsigned long long *out4)
+{
+    if (!own_buf || !out4) return -1;
+    if (hipSetDevice(device) != hipSuccess) return -2;
+    if (hipDeviceSynchronize() != hipSuccess) return -3;
+    return hipMemcpy(out4, (const unsigned long long *)own_buf + PEER_W_STAT, PEER_STAT_N * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+
 int ndp_destroy(ndp_handle *h)
 {
     if (!h) return -1;
     (void)hipSetDevice(h->cfg.device);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ev_pending) (void)hipEventSynchronize(h->evLast);
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->evLast) (void)hipEventDestroy(h->evLast);
+    h->pool.reset();
     void *ptrs[] = {h->dRefList, h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dForce, h->dFrag,
-                    h->dIn, h->hOut ? nullptr : h->dOut, h->sdbg, h->dQctr, h->dQids};
+                    h->dIn, h->dOut, h->sdbg, h->dQctr, h->dQids, h->slot[1].dIn};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    if (h->hIn) (void)hipHostFree(h->hIn);
-    if (h->hOut) (void)hipHostFree(h->hOut);      // (then dOut is that same block)
+    for (auto &sl : h->slot) {
+        if (sl.hIn) (void)hipHostFree(sl.hIn);
+        if (sl.hOut) (void)hipHostFree(sl.hOut);
+        for (hipEvent_t e : {sl.evIn, sl.evKernel, sl.evOut})
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->evFront) (void)hipEventDestroy(h->evFront);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -1132,6 +1356,14 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         cfg->work_queue < 0 || cfg->work_queue > 2 || !(cfg->ts_nmpc > 0.0) || cfg->dt < cfg->ts_nmpc) {
         g_create_err = "ndp_create: need batch >= 1, 2 <= N <= 46, n_rti >= 1, qp_precision in 0..4, work_queue in 0..2, 0 < ts_nmpc <= dt";
         return -2;
+    }
+    {   // the reference list holds one point per control period and the window is every (dt / ts_nmpc)-th entry
+        // (params/nmpc_params.py:40-43): the ratio has to be a whole number, else ring windows and direct windows disagree
+        const double ratio = cfg->dt / cfg->ts_nmpc, nearest = (double)(long long)(ratio + 0.5);
+        if (ratio - nearest > 1e-9 || nearest - ratio > 1e-9) {
+            g_create_err = "ndp_create: dt must be a whole multiple of ts_nmpc (node spacing = every k-th entry of the reference list)";
+            return -2;
+        }
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1159,10 +1391,11 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         if ((e = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
         h->n_simd = 4 * prop.multiProcessorCount;
     }
-    // work list: by default when the batch holds at least four instances per SIMD and the QP mode has an early exit to defer
-    // from.  With one instance per SIMD nothing can be re-balanced; in between the list's fixed cost per step (a memset node
-    // and a consumer launch, ~10 us even when nothing was listed) is 10-20 % of a step that needs no interior-point solve,
-    // against +30 % .. 2x when a fifth of the instances do -- callers who know their workload set cfg.work_queue = 1 / 2.
+    // work list: by default when the batch holds at least two instances per SIMD and the QP mode has an early exit to defer
+    // from.  With one instance per SIMD nothing can be re-balanced; above that the list's fixed cost per step (one consumer
+    // launch whose workgroups read the counter and leave when nothing was listed) is a few per cent of a step that needs no
+    // interior-point solve, against +20 % .. 2x when a fifth of the instances do -- callers who know their workload set
+    // cfg.work_queue = 1 / 2.
     // The N = 40 / 2-iteration shape always takes the list: its producer kernel carries no interior-point code and does not
     // spill, which is worth 17 % even when nothing is listed (the in-place kernel of that shape uses 0.9 KB of scratch per lane)
     if (cfg->work_queue == 1 && !(queue_shape(h) && cfg->qp_mode == NDP_QP_AUTO)) {
@@ -1171,7 +1404,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         return -2;
     }
     h->use_queue = cfg->work_queue == 1 ||
-                   (cfg->work_queue == 0 && queue_shape(h) && cfg->qp_mode == NDP_QP_AUTO && (cfg->batch >= 4 * h->n_simd || cfg->N == 40));
+                   (cfg->work_queue == 0 && queue_shape(h) && cfg->qp_mode == NDP_QP_AUTO && (cfg->batch >= 2 * h->n_simd || cfg->N == 40));
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&h->evLast, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     const size_t B = cfg->batch;
@@ -1207,26 +1440,18 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         h->off_st = o; o += up256(B * 4);
         h->off_it = o; o += up256(B * 4);
         h->out_bytes = o;
-        // the persistent iterate lives right behind the output block: u0 | status | iterations | X | U come back to the host
-        // in ONE copy when a caller asks for the iterate as well (ndp_step_ex)
-        // Small batches (inputs up to PACK_LIMIT): that block is page-locked HOST memory the device reads and writes directly
-        // (fine-grained: ~7 KB per instance and tick over PCIe) -- a host-array step is then memcpy into the input mirror, ONE
-        // launch, one synchronisation, memcpy out of the output block; no DMA operation at all.
-        const size_t out_all = h->out_bytes + (nxs(h) + nus(h)) * 8;
+        // the persistent iterate lives right behind the small outputs: u0 | status | iterations | X | U come back to the host
+        // in ONE copy when a caller asks for the iterate as well (ndp_step_ex).  All of it is HBM; the page-locked host
+        // mirrors of the host-array entry points are allocated by their first call (ensure_slots).
+        h->out_all = h->out_bytes + (nxs(h) + nus(h)) * 8;
         ALLOC(h->dIn, h->in_bytes);
-        if (h->in_bytes <= PACK_LIMIT) {
-            if ((e = hipHostMalloc((void **)&h->hOut, out_all, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc hOut", e);
-            h->dOut = h->hOut;
-        } else {
-            ALLOC(h->dOut, out_all);
-        }
+        ALLOC(h->dOut, h->out_all);
+        h->zero_copy = h->in_bytes <= PACK_LIMIT;
         h->dX = (double *)(h->dOut + h->out_bytes); h->dU = h->dX + nxs(h);
         h->sx0 = (double *)(h->dIn + h->off_x0); h->sxr = (double *)(h->dIn + h->off_xr); h->sur = (double *)(h->dIn + h->off_ur);
         h->sf = (float *)(h->dIn + h->off_f); h->sother = (double *)(h->dIn + h->off_other); h->sego = (double *)(h->dIn + h->off_ego);
         h->su0 = (double *)(h->dOut + h->off_u0); h->dStatus = (int *)(h->dOut + h->off_st); h->dIters = (int *)(h->dOut + h->off_it);
-        if (h->in_bytes <= PACK_LIMIT) {
-            if ((e = hipHostMalloc((void **)&h->hIn, h->in_bytes, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc hIn", e);
-        }
+        h->lastStatus = h->dStatus; h->lastIters = h->dIters;
         ALLOC(h->sdbg, (size_t)(lds_doubles(cfg->N) + DBG_EXTRA) * 8);
     }
 #undef ALLOC
@@ -1333,10 +1558,19 @@ static int launch_mlp(ndp_handle *h, const Neigh &nb, const double *d_ego, float
     return end_timing(h, s);
 }
 
+struct StepOut {               // where a step's status / iteration counts go and whether the new iterate is mirrored (device-accessible
+    int *status = nullptr;     // pointers; null = the handle's HBM block / no mirror): the host-array step of small batches points
+    int *iters = nullptr;      // them into a page-locked host block
+    double *Xm = nullptr, *Um = nullptr;
+};
+
 static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, const double *d_ur, const float *d_f,
-                      double *d_u0, double *d_dbg, hipStream_t s, const Neigh *nb = nullptr)
+                      double *d_u0, double *d_dbg, hipStream_t s, const Neigh *nb = nullptr, const StepOut *so = nullptr)
 {
-    BatchPtrs bp{h->dKC, h->dTables, d_x0, d_xr, d_ur, d_f, h->dX, h->dU, d_u0, h->dStatus, h->dIters, d_dbg, h->dStamps};
+    int *d_status = so && so->status ? so->status : h->dStatus, *d_iters = so && so->iters ? so->iters : h->dIters;
+    h->lastStatus = d_status; h->lastIters = d_iters;
+    BatchPtrs bp{h->dKC, h->dTables, d_x0, d_xr, d_ur, d_f, h->dX, h->dU, d_u0, d_status, d_iters,
+                 so ? so->Xm : nullptr, so ? so->Um : nullptr, d_dbg, h->dStamps};
     const bool fused = nb && nb->other;
     MlpArgs ma{fused ? h->dFrag : nullptr, fused ? nb->other : nullptr, fused ? nb->ego_xy : nullptr, h->dForce,
                h->cfg.r_horiz * h->cfg.r_horiz, fused ? nb->stride : NX, fused ? nb->index : nullptr};
@@ -1365,10 +1599,10 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     }
 #define LAUNCH(...) hipLaunchKernelGGL(RTI_K(__VA_ARGS__), grid, block, shm, s, ka)
     if (q) {
-        // work list: zero the counter, producer (every instance, early exit or defer), consumer (the deferred ones, from
-        // scratch; with one RTI iteration the consumer goes straight to the interior-point loop, with several it repeats the
-        // automatic rule per iteration).  The consumer reads the fused producer's force from dForce.
-        NDP_HIP(h, hipMemsetAsync(h->dQctr, 0, 4, s));
+        // work list: producer (every instance, early exit or defer), consumer (the deferred ones, from scratch; with one RTI
+        // iteration the consumer goes straight to the interior-point loop, with several it repeats the automatic rule per
+        // iteration; its last workgroup to arrive zeroes the counter for the next step).  The consumer reads the fused
+        // producer's force from dForce.
         KernArgs kc = ka;
         kc.bp.f = fused ? h->dForce : d_f;
         kc.ma.frag = nullptr; kc.ma.other = nullptr;
@@ -1406,19 +1640,19 @@ static bool can_fuse(const ndp_handle *h)
 
 // one control step on device pointers: [mlp_kernel ->] rti_kernel (no locking, no sync)
 static int enqueue_step(ndp_handle *h, const double *d_x0, const double *d_xr, const double *d_ur, const float *d_f,
-                        const Neigh &nb, double *d_u0, double *d_dbg, hipStream_t s)
+                        const Neigh &nb, double *d_u0, double *d_dbg, hipStream_t s, const StepOut *so = nullptr)
 {
     if ((d_f || nb.other) && !h->cfg.use_fd) { h->err = "ndp_step: a disturbance force needs use_fd = 1 (NDP model)"; return -8; }
     if (nb.other) {
         if (d_f) { h->err = "ndp_step: pass either f or other, not both"; return -7; }
         if (nb.stride != 10 && nb.stride != 6) { h->err = "ndp_step: other_stride must be 10 or 6"; return -13; }
         if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }
-        if (can_fuse(h)) return launch_rti(h, d_x0, d_xr, d_ur, nullptr, d_u0, d_dbg, s, &nb);
+        if (can_fuse(h)) return launch_rti(h, d_x0, d_xr, d_ur, nullptr, d_u0, d_dbg, s, &nb, so);
         int rc = launch_mlp(h, nb, d_xr, h->dForce, s);
         if (rc) return rc;
         d_f = h->dForce;
     }
-    return launch_rti(h, d_x0, d_xr, d_ur, d_f, d_u0, d_dbg, s);
+    return launch_rti(h, d_x0, d_xr, d_ur, d_f, d_u0, d_dbg, s, nullptr, so);
 }
 
 int ndp_reset_device(ndp_handle *h, const void *d_xr, const void *d_ur, void *stream)
@@ -1466,71 +1700,181 @@ int ndp_step_device(ndp_handle *h, const void *d_x0, const void *d_xr, const voi
     return ndp_step_device_ex(h, d_x0, d_xr, d_ur, d_f, d_other, NX, nullptr, d_ego_xy, d_u0, stream);
 }
 
-// Host-pointer step.  Everything under one lock; one synchronisation.
+// ---- host-array step: ndp_step_begin (pack -> H2D -> kernel -> D2H, nothing waits) + ndp_step_end (wait, hand the results over)
+static int ensure_slots(ndp_handle *h)
+{
+    if (h->slots_ready) return 0;
+    for (int i = 0; i < 2; ++i) {
+        ndp_handle::HostSlot &sl = h->slot[i];
+        NDP_HIP(h, hipHostMalloc((void **)&sl.hIn, h->in_bytes, hipHostMallocDefault));
+        NDP_HIP(h, hipHostMalloc((void **)&sl.hOut, h->out_all, hipHostMallocDefault));
+        memset(sl.hOut, 0, h->out_bytes);
+        if (!h->zero_copy) {
+            if (i == 0) sl.dIn = h->dIn;
+            else NDP_HIP(h, hipMalloc((void **)&sl.dIn, h->in_bytes));
+        }
+        NDP_HIP(h, hipEventCreateWithFlags(&sl.evIn, hipEventDisableTiming));
+        NDP_HIP(h, hipEventCreateWithFlags(&sl.evKernel, hipEventDisableTiming));
+        NDP_HIP(h, hipEventCreateWithFlags(&sl.evOut, hipEventDisableTiming));
+    }
+    if (!h->zero_copy) {
+        NDP_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        NDP_HIP(h, hipEventCreateWithFlags(&h->evFront, hipEventDisableTiming));
+    }
+    // pack threads: NDP_PACK_THREADS, else half the hardware threads, at most 8; the caller packs too, so small blocks need none
+    int nt = 0;
+    if (const char *e = getenv("NDP_PACK_THREADS")) nt = atoi(e);
+    else if (h->in_bytes > 2 * PACK_CHUNK) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        nt = (int)(hw / 2 > 8 ? 8 : hw / 2) - 1;
+    }
+    h->pool.reset(new (std::nothrow) PackPool(nt > 0 ? (nt > 64 ? 64 : nt) : 0));
+    if (!h->pool) { h->err = "ensure_slots: out of memory"; return -4; }
+    h->slots_ready = true;
+    return 0;
+}
+
+static int step_begin_locked(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
+                             const double *other, const double *ego_xy, bool want_iter, double *dump)
+{
+    const size_t B = h->cfg.batch;
+    hipStream_t s = h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_slots(h);
+    if (rc) return rc;
+    if (h->slots_busy == 2) { h->err = "ndp_step_begin: two steps are already in flight (call ndp_step_end first)"; return -14; }
+    if (h->ev_pending && (rc = wait_all(h))) return rc;       // work a caller left on its own stream comes first
+    ndp_handle::HostSlot &sl = h->slot[h->slot_head];
+    // the slot's previous use is over: its results were handed out by ndp_step_end (busy is false) -- so its H2D copies, its
+    // kernel and its D2H copy have completed, and both mirrors are free to overwrite
+    struct Seg { size_t off; const void *src; size_t len; };
+    Seg segs[6];
+    int ns = 0;
+    segs[ns++] = {h->off_x0, x0, B * NX * 8};
+    segs[ns++] = {h->off_xr, xr, nxs(h) * 8};
+    segs[ns++] = {h->off_ur, ur, nus(h) * 8};
+    if (f) segs[ns++] = {h->off_f, f, nfs(h) * 4};
+    if (other) segs[ns++] = {h->off_other, other, nxs(h) * 8};
+    if (ego_xy) segs[ns++] = {h->off_ego, ego_xy, B * 2 * 8};
+    std::vector<PackJob> jobs;
+    for (int i = 0; i < ns; ++i)
+        for (size_t o = 0; o < segs[i].len; o += PACK_CHUNK) {
+            const size_t n = segs[i].len - o < PACK_CHUNK ? segs[i].len - o : PACK_CHUNK;
+            jobs.push_back({sl.hIn + segs[i].off + o, (const unsigned char *)segs[i].src + o, n, segs[i].off + o});
+        }
+    const int nj = (int)jobs.size();
+    PackPool &pool = *h->pool;
+    if (!h->zero_copy) {
+        // the slot's device block may still be read by the kernel of the step that used it last -- or, slot 0's, by one of the
+        // f1-f4 host entry points that stage through it (then the copies wait for everything enqueued so far)
+        if (sl.kernel_recorded) NDP_HIP(h, hipStreamWaitEvent(h->copy_stream, sl.evKernel, 0));
+        if (h->staging_used) {
+            NDP_HIP(h, hipEventRecord(h->evFront, s));
+            NDP_HIP(h, hipStreamWaitEvent(h->copy_stream, h->evFront, 0));
+            h->staging_used = false;
+        }
+    }
+    pool.post(jobs.data(), nj);      // from here to pool.finish() nothing returns early: the workers read `jobs`
+    if (h->zero_copy) {
+        for (int i = 0; i < nj; ++i) pool.wait_job(i);
+    } else {
+        // hand every finished run of chunks to the DMA engine while the rest is still being packed; a run never spans an
+        // absent array (f is usually absent: 0.26 MB at batch 1024), the <= 255 padding bytes between arrays are copied along
+        int i = 0;
+        hipError_t e = hipSuccess;
+        while (i < nj) {
+            pool.wait_job(i);
+            const size_t r0 = jobs[i].off;
+            size_t r1 = r0 + jobs[i].len;
+            ++i;
+            while (i < nj && pool.is_done(i) && jobs[i].off - r1 < 256) { r1 = jobs[i].off + jobs[i].len; ++i; }
+            if (e == hipSuccess) e = hipMemcpyAsync(sl.dIn + r0, sl.hIn + r0, r1 - r0, hipMemcpyHostToDevice, h->copy_stream);
+        }
+        pool.finish();
+        NDP_HIP(h, e);
+        NDP_HIP(h, hipEventRecord(sl.evIn, h->copy_stream));
+        NDP_HIP(h, hipStreamWaitEvent(s, sl.evIn, 0));
+    }
+    if (h->zero_copy) pool.finish();
+    const unsigned char *ib = h->zero_copy ? sl.hIn : sl.dIn;
+    Neigh nb;
+    nb.other = other ? (const double *)(ib + h->off_other) : nullptr;
+    nb.ego_xy = ego_xy ? (const double *)(ib + h->off_ego) : nullptr;
+    StepOut so;
+    double *u0_dst = h->su0;
+    if (h->zero_copy) {
+        // u0 | status | iterations (| the new iterate, when asked for) are written into the slot's page-locked block by the kernel
+        u0_dst = (double *)(sl.hOut + h->off_u0);
+        so.status = (int *)(sl.hOut + h->off_st); so.iters = (int *)(sl.hOut + h->off_it);
+        if (want_iter) { so.Xm = (double *)(sl.hOut + h->out_bytes); so.Um = so.Xm + nxs(h); }
+    }
+    rc = enqueue_step(h, (const double *)(ib + h->off_x0), (const double *)(ib + h->off_xr), (const double *)(ib + h->off_ur),
+                      f ? (const float *)(ib + h->off_f) : nullptr, nb, u0_dst, dump ? h->sdbg : nullptr, s, &so);
+    if (rc) return rc;
+    if (!h->zero_copy) {
+        NDP_HIP(h, hipEventRecord(sl.evKernel, s));
+        sl.kernel_recorded = true;
+        NDP_HIP(h, hipMemcpyAsync(sl.hOut, h->dOut, want_iter ? h->out_all : h->out_bytes, hipMemcpyDeviceToHost, s));
+    }
+    NDP_HIP(h, hipEventRecord(sl.evOut, s));
+    sl.busy = true; sl.want_iter = want_iter; sl.dump = dump;
+    h->slot_head ^= 1;
+    ++h->slots_busy;
+    return 0;
+}
+
+static int step_end_locked(ndp_handle *h, double *u0, double *X_out, double *U_out, int32_t *status_out, int32_t *iters_out)
+{
+    const size_t B = h->cfg.batch;
+    if (h->slots_busy == 0) { h->err = "ndp_step_end: no step in flight (ndp_step_begin first)"; return -14; }
+    ndp_handle::HostSlot &sl = h->slot[h->slot_tail];
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    if ((X_out || U_out) && !sl.want_iter) { h->err = "ndp_step_end: the iterate was not requested at ndp_step_begin (flags bit 0)"; return -15; }
+    hipError_t e = hipEventSynchronize(sl.evOut);
+    if (e == hipSuccess && sl.dump)
+        e = hipMemcpy(sl.dump, h->sdbg, (size_t)(lds_doubles(h->cfg.N) + DBG_EXTRA) * 8, hipMemcpyDeviceToHost);
+    sl.busy = false;
+    h->slot_tail ^= 1;
+    --h->slots_busy;
+    NDP_HIP(h, e);
+    const unsigned char *ho = sl.hOut;
+    if (u0) memcpy(u0, ho + h->off_u0, B * NU * 8);
+    const int32_t *st = (const int32_t *)(ho + h->off_st);
+    if (status_out) memcpy(status_out, st, B * 4);
+    if (iters_out) memcpy(iters_out, ho + h->off_it, B * 4);
+    if (X_out) memcpy(X_out, ho + h->out_bytes, nxs(h) * 8);
+    if (U_out) memcpy(U_out, ho + h->out_bytes + nxs(h) * 8, nus(h) * 8);
+    int w = 0;
+    for (size_t i = 0; i < B; ++i) w = st[i] > w ? st[i] : w;
+    return w;
+}
+
+int ndp_step_begin(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
+                   const double *other, const double *ego_xy, int flags)
+{
+    if (!h || !x0 || !xr || !ur) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    return step_begin_locked(h, x0, xr, ur, f, other, ego_xy, (flags & 1) != 0, nullptr);
+}
+
+int ndp_step_end(ndp_handle *h, double *u0, double *X_out, double *U_out, int32_t *status_out, int32_t *iters_out)
+{
+    if (!h || !u0) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    return step_end_locked(h, u0, X_out, U_out, status_out, iters_out);
+}
+
+// The synchronous form: begin + end under ONE lock (a concurrent caller cannot slip a step in between).
 static int step_host(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
                      const double *other, const double *ego_xy, double *u0, double *X_out, double *U_out,
                      int32_t *status_out, int32_t *iters_out, double *dump)
 {
     if (!h || !x0 || !xr || !ur || !u0) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
-    hipStream_t s = h->stream;
-    const size_t B = h->cfg.batch;
-    NDP_HIP(h, hipSetDevice(h->cfg.device));
-    if (h->ev_pending) { int rc = wait_all(h); if (rc) return rc; }   // work a caller left on its own stream comes first
-    const bool pack = h->hIn != nullptr;
-    if (pack) {
-        // pinned mirror: one copy covers the leading blocks up to the last one present (x0 | xr | ur | f | other | ego_xy)
-        memcpy(h->hIn + h->off_x0, x0, B * NX * 8);
-        memcpy(h->hIn + h->off_xr, xr, nxs(h) * 8);
-        memcpy(h->hIn + h->off_ur, ur, nus(h) * 8);
-        size_t end = h->off_ur + nus(h) * 8;
-        if (f) { memcpy(h->hIn + h->off_f, f, nfs(h) * 4); end = h->off_f + nfs(h) * 4; }
-        if (other) { memcpy(h->hIn + h->off_other, other, nxs(h) * 8); end = h->off_other + nxs(h) * 8; }
-        if (ego_xy) { memcpy(h->hIn + h->off_ego, ego_xy, B * 2 * 8); end = h->off_ego + B * 2 * 8; }
-        (void)end;      // no H2D copy: the kernel reads the pinned mirror itself (fine-grained host memory, ~5 KB per instance)
-    } else {
-        NDP_HIP(h, hipMemcpyAsync(h->sx0, x0, B * NX * 8, hipMemcpyHostToDevice, s));
-        NDP_HIP(h, hipMemcpyAsync(h->sxr, xr, nxs(h) * 8, hipMemcpyHostToDevice, s));
-        NDP_HIP(h, hipMemcpyAsync(h->sur, ur, nus(h) * 8, hipMemcpyHostToDevice, s));
-        if (f) NDP_HIP(h, hipMemcpyAsync(h->sf, f, nfs(h) * 4, hipMemcpyHostToDevice, s));
-        if (other) NDP_HIP(h, hipMemcpyAsync(h->sother, other, nxs(h) * 8, hipMemcpyHostToDevice, s));
-        if (ego_xy) NDP_HIP(h, hipMemcpyAsync(h->sego, ego_xy, B * 2 * 8, hipMemcpyHostToDevice, s));
-    }
-    Neigh nb;
-    const unsigned char *ib = pack ? h->hIn : h->dIn;
-    nb.other = other ? (const double *)(ib + h->off_other) : nullptr;
-    nb.ego_xy = ego_xy ? (const double *)(ib + h->off_ego) : nullptr;
-    int rc = enqueue_step(h, (const double *)(ib + h->off_x0), (const double *)(ib + h->off_xr), (const double *)(ib + h->off_ur),
-                          f ? (const float *)(ib + h->off_f) : nullptr, nb, h->su0, dump ? h->sdbg : nullptr, s);
+    if (h->slots_busy) { h->err = "ndp_step: steps begun with ndp_step_begin are still in flight (ndp_step_end them first)"; return -14; }
+    int rc = step_begin_locked(h, x0, xr, ur, f, other, ego_xy, X_out || U_out, dump);
     if (rc) return rc;
-    std::vector<int32_t> st_tmp;
-    const int32_t *st = nullptr;
-    if (pack) {
-        unsigned char *ho = h->hOut;
-        // u0 | status | iters | X | U: the kernel wrote them into this block (page-locked host memory) itself
-        if (dump) NDP_HIP(h, hipMemcpyAsync(dump, h->sdbg, (size_t)(lds_doubles(h->cfg.N) + DBG_EXTRA) * 8, hipMemcpyDeviceToHost, s));
-        NDP_HIP(h, hipStreamSynchronize(s));
-        memcpy(u0, ho + h->off_u0, B * NU * 8);
-        st = (const int32_t *)(ho + h->off_st);
-        if (status_out) memcpy(status_out, st, B * 4);
-        if (iters_out) memcpy(iters_out, ho + h->off_it, B * 4);
-        if (X_out) memcpy(X_out, ho + h->out_bytes, nxs(h) * 8);
-        if (U_out) memcpy(U_out, ho + h->out_bytes + nxs(h) * 8, nus(h) * 8);
-    } else {
-        int32_t *stp = status_out;
-        if (!stp) { st_tmp.resize(B); stp = st_tmp.data(); }
-        NDP_HIP(h, hipMemcpyAsync(u0, h->su0, B * NU * 8, hipMemcpyDefault, s));
-        NDP_HIP(h, hipMemcpyAsync(stp, h->dStatus, B * 4, hipMemcpyDefault, s));
-        if (iters_out) NDP_HIP(h, hipMemcpyAsync(iters_out, h->dIters, B * 4, hipMemcpyDefault, s));
-        if (X_out) NDP_HIP(h, hipMemcpyAsync(X_out, h->dX, nxs(h) * 8, hipMemcpyDefault, s));
-        if (U_out) NDP_HIP(h, hipMemcpyAsync(U_out, h->dU, nus(h) * 8, hipMemcpyDefault, s));
-        if (dump) NDP_HIP(h, hipMemcpyAsync(dump, h->sdbg, (size_t)(lds_doubles(h->cfg.N) + DBG_EXTRA) * 8, hipMemcpyDeviceToHost, s));
-        NDP_HIP(h, hipStreamSynchronize(s));
-        st = stp;
-    }
-    int w = 0;
-    for (size_t i = 0; i < B; ++i) w = st[i] > w ? st[i] : w;
-    return w;
+    return step_end_locked(h, u0, X_out, U_out, status_out, iters_out);
 }
 
 int ndp_step(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
@@ -1570,6 +1914,7 @@ int ndp_downwash(ndp_handle *h, const double *other, const double *ego_ref, cons
 {
     if (!h || !other || !ego_ref || !f_out) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
+    h->staging_used = true;
     hipStream_t s = h->stream;
     const size_t B = h->cfg.batch;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
@@ -1616,8 +1961,8 @@ int ndp_get_status(ndp_handle *h, int32_t *status, int32_t *ipm_iters)
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     int rc = wait_all(h);
     if (rc) return rc;
-    if (status) NDP_HIP(h, hipMemcpy(status, h->dStatus, (size_t)h->cfg.batch * 4, hipMemcpyDefault));
-    if (ipm_iters) NDP_HIP(h, hipMemcpy(ipm_iters, h->dIters, (size_t)h->cfg.batch * 4, hipMemcpyDefault));
+    if (status) NDP_HIP(h, hipMemcpy(status, h->lastStatus, (size_t)h->cfg.batch * 4, hipMemcpyDefault));
+    if (ipm_iters) NDP_HIP(h, hipMemcpy(ipm_iters, h->lastIters, (size_t)h->cfg.batch * 4, hipMemcpyDefault));
     return 0;
 }
 
@@ -1781,6 +2126,7 @@ int ndp_relay_reference(ndp_handle *h, const double *xr_lead, double *xr_out)
 {
     if (!h || !xr_lead || !xr_out) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
+    h->staging_used = true;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     NDP_HIP(h, hipMemcpyAsync(h->sother, xr_lead, nxs(h) * 8, hipMemcpyHostToDevice, h->stream));
     int rc = launch_relay_reference(h, h->sother, h->sxr, h->stream);
@@ -1850,6 +2196,7 @@ int ndp_ref_window(ndp_handle *h, const double *t, double *xr, double *ur)
 {
     if (!h || !t || !xr || !ur) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
+    h->staging_used = true;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     NDP_HIP(h, hipMemcpyAsync(h->sThr, t, (size_t)h->cfg.batch * 8, hipMemcpyHostToDevice, h->stream));
     int rc = launch_ref_window(h, h->sThr, 0.0, h->sxr, h->sur, h->stream);
@@ -1924,8 +2271,10 @@ static int list_advance(ndp_handle *h, const double *d_t, hipStream_t s)
 {
     if (!h->dRefList) { h->err = "ndp_ref_list_advance: no list (ndp_ref_list_reset / ndp_ref_list_fix_pt first)"; return -11; }
     const int ring = list_ring(h), tail = h->list_head;          // the popped slot becomes the new last entry
+    const int rc = launch_list_fill(h, d_t, h->cfg.N * h->cfg.dt, 1, tail, 0, s);
+    if (rc) return rc;                                             // nothing was launched (e.g. no trajectory): the ring keeps its head
     h->list_head = (h->list_head + 1) % ring;
-    return launch_list_fill(h, d_t, h->cfg.N * h->cfg.dt, 1, tail, 0, s);
+    return 0;
 }
 
 int ndp_ref_list_advance_device(ndp_handle *h, const void *d_t, void *stream)
@@ -1963,6 +2312,7 @@ int ndp_ref_list_window(ndp_handle *h, const double *t, double *xr, double *ur)
 {
     if (!h || !xr || !ur) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
+    h->staging_used = true;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     int rc = 0;
     if (t) {
@@ -2000,6 +2350,7 @@ int ndp_plant_step(ndp_handle *h, double *x, const double *u, const double *f, d
     if (!h || !x || !u || substeps < 1) return -1;
     const size_t B = h->cfg.batch;
     std::lock_guard<std::mutex> lk(h->mu);
+    h->staging_used = true;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     NDP_HIP(h, hipMemcpyAsync(h->sx0, x, B * 80, hipMemcpyHostToDevice, h->stream));
     NDP_HIP(h, hipMemcpyAsync(h->su0, u, B * 32, hipMemcpyHostToDevice, h->stream));
@@ -2016,6 +2367,7 @@ int ndp_rollout_device(ndp_handle *h, int ticks, double t0, double dt_tick, int 
 {
     if (!h || ticks < 1 || substeps < 1 || !d_x) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
+    h->staging_used = true;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     if (h->cfg.use_fd) { h->err = "ndp_rollout_device: the rollout drives the NMPC model (use_fd = 0)"; return -8; }

@@ -88,6 +88,7 @@ struct RtiIo {            // global-memory views of ONE instance
     const double *kc;     // [KC_SC] lane-indexable constants block prepared by the host (fill_kc)
     double *stamps = nullptr;   // optional [16] per-instance phase stamps (whole-batch profiling), or null
     const int *tables = nullptr;   // [TB_WORDS] host-built index tables (fill_tables), read when RtiWave<..., HT = true>
+    double *Xm = nullptr, *Um = nullptr;   // optional second destination of the new iterate (a page-locked host block the caller reads), or null
 };
 
 struct LdsMap {
@@ -914,7 +915,7 @@ struct RtiWave {
     //   forward:   du_k = K~_k dx_k + dk_k,  dx_{k+1} = A_k dx_k + B_k du_k,  dx_0 = 0      (the 4 MFMAs of the full forward sweep)
     // and ZX|ZU += (dx, du).  No 4x4 inverse, no cost blocks: ~0.55 of a full sweep.  Needs -Lam_k^-1 of every stage (riccati_sweep's
     // linv, in registers: compile-time horizons) and K~' where the sweep left it in LDS.
-    struct DeltaTabs { vi dc_off[4], kta_off, dc_off4; md eye12, m12; vb row10, g2; };
+    struct DeltaTabs { vi dc_off[4], kta_off, dc_off4, dk_off; md eye12, m12; vb row10, g2; };
     static NDP_D void build_delta_tabs(const LdsMap &m, DeltaTabs &D)
     {
         vi lane = W::lane();
@@ -933,13 +934,16 @@ struct RtiWave {
         D.dc_off4 = W::sel((x4 >= 3) && (x4 < 6), x4 + (m.CB + int(CB_QE)), W::sel(x4 >= 12, x4 + (m.CB + int(CB_RE) - 12), vi(m.CB + int(CB_ZERO))));
         D.m12 = W::to_m(W::sel(j >= 12, vd(1.0), vd(0.0)));
         D.g2 = g == 2;
+        // 4x4x4 form: the feed-forward change dk_k (4 values per stage) waits for the forward pass in the U part of the shadow
+        // ZD, entry 4k + g -- every lane of row g holds the same value, so all sixteen store it (identical duplicates).  The
+        // forward sweeps' own dump stores reach entry 4k + g only at the END of stage k, after dk_k has been read.
+        D.dk_off = g + (m.ZD + (m.ZU - m.ZX));
     }
 
     static NDP_D void delta_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, const DeltaTabs &D, lp lds, const md *linv)
     {
         const int N = horizon(P);
         md vc[3] = {W::to_m(vd(0.0)), W::to_m(vd(0.0)), W::to_m(vd(0.0))};
-        md dk[NC > 0 ? NC : 1];
         if constexpr (MMA4) {
             // every product here is matrix x vector: the 4x4x4 instruction, vectors as chunk registers replicated over the columns.
             // The LDS operands of a stage are requested one stage ahead (as in riccati_sweep): they arrive under the previous
@@ -960,7 +964,7 @@ struct RtiWave {
                 if (k != N - 1)
                     for (int c = 0; c < 3; ++c) Dg = mma4(a[c], vc[c], Dg);
                 md Dp = mma4(akl, W::template rowb<3>(Dg), Dg);
-                dk[k] = W::template rowb<3>(Dp);
+                W::st(lds, D.dk_off + k * int(NU), W::to_d(W::template rowb<3>(Dp)));   // dk_k (kept in LDS: NC registers pairs less)
                 vc[0] = W::template rowb<0>(Dp); vc[1] = W::template rowb<1>(Dp);
                 vc[2] = W::msel(D.g2, W::to_m(vd(0.0)), W::template rowb<2>(Dp));   // the constant-term row must not feed back
                 Dg = nDg; kta = nkta;
@@ -970,33 +974,37 @@ struct RtiWave {
             md fw[3], mu;
             for (int c = 0; c < 3; ++c) fw[c] = W::to_m(W::ld(lds, T.fw_off[c]));
             mu = W::to_m(W::ld(lds, T.mu_off));
+            W::sync();       // the dk stores above are read by other lanes below
             vd zu0 = W::ld(lds, T.zu_st), zx0 = W::ld(lds, T.zx_st4 + int(NX));
+            md dkk = W::to_m(W::ld(lds, D.dk_off));
             NDP_UNROLL_STAGES
             for (int k = 0; k < N; ++k) {
-                md nfw[3] = {fw[0], fw[1], fw[2]}, nmu = mu;
+                md nfw[3] = {fw[0], fw[1], fw[2]}, nmu = mu, ndk = dkk;
                 vd nzu0 = zu0, nzx0 = zx0;
                 if (k + 1 < N) {
                     for (int c = 0; c < 3; ++c) nfw[c] = W::to_m(W::ld(lds, T.fw_off[c] + mb(k + 1)));
                     nmu = W::to_m(W::ld(lds, T.mu_off + mb(k + 1)));
                     nzu0 = W::ld(lds, T.zu_st + (k + 1) * int(NU));
                     nzx0 = W::ld(lds, T.zx_st4 + (k + 2) * int(NX));
+                    ndk = W::to_m(W::ld(lds, D.dk_off + (k + 1) * int(NU)));
                 }
                 W::pin();
-                md y = W::to_m(vd(0.0)), du = dk[k];
+                md y = W::to_m(vd(0.0)), du = dkk;
                 if (k != 0) {
                     for (int c = 0; c < 3; ++c) y = mma4(fw[c], zc[c], y);
-                    du = W::template rowb<3>(y) + dk[k];
+                    du = W::template rowb<3>(y) + dkk;
                 }
                 md xn = mma4(mu, du, y);
                 W::st(lds, T.zu_st + k * int(NU), zu0 + W::to_d(du));
                 W::st(lds, T.zx_st4 + (k + 1) * int(NX), zx0 + W::to_d(xn));
                 zc[0] = W::template rowb<0>(xn); zc[1] = W::template rowb<1>(xn); zc[2] = W::template rowb<2>(xn);
                 for (int c = 0; c < 3; ++c) fw[c] = nfw[c];
-                mu = nmu; zu0 = nzu0; zx0 = nzx0;
+                mu = nmu; zu0 = nzu0; zx0 = nzx0; dkk = ndk;
             }
             W::sync();
             return;
         }
+        md dk[NC > 0 ? NC : 1];
         NDP_UNROLL_STAGES
         for (int k = N - 1; k >= 0; --k) {
             md4 C;
@@ -1373,6 +1381,7 @@ struct RtiWave {
                     if (last) {
                         // X and U are separate global arrays: element i < nzx goes to X[i], else to U[i - nzx]
                         W::gst2(io.X, io.U, i, nzx, xn);
+                        if (io.Xm) W::gst2(io.Xm, io.Um, i, nzx, xn);   // wave-uniform: the host step's mirror of the iterate
                         if (t == (nzx >> 6)) {   // the round that holds u_0 = U[0..3] (wave-uniform test)
                             vb pu = (i >= nzx) && (i < nzx + NU);
                             W::gst(io.u0, i - nzx, xn, pu);

@@ -185,76 +185,111 @@ class DevWindows:
 
 
 class PeerWindows:
-    """The neighbour exchange without a per-step collective: every rank keeps the reference windows it publishes
-    (`ticks` x [B_local, N+1, 10] float64: what nmpc_node.py:116-133 publishes per tick) in a buffer allocated with
-    ndp_peer_alloc, the 64-byte handles are exchanged ONCE (all_gather_object), and each rank maps the buffer of the
-    rank that holds its neighbours (ndp_peer_open).  `local[t]` is this rank's window tensor of tick slot t (fill it, then
-    publish()); `neighbour[t]` (DevWindows: a raw device address) is rank (r+1) % W's -- pass it as `other` of BatchedNMPC.update_device: the control-step
-    kernel reads it out of the neighbour GPU's HBM over xGMI.  With one rank the neighbour is the local buffer.
+    """The neighbour exchange as publish / subscribe over xGMI, one exchange PER CONTROL TICK like the reference's PredXU topic
+    (nmpc_node.py:116-133,229-230 publishes a new window every tick; ndp_nmpc_leader_node.py:40,60-76 consumes the latest).
 
-    publish() = device synchronisation + barrier: the windows of the bench are written once; a deployment that rewrites a
-    slot every tick orders writer and readers with its own events, as a ROS publisher / subscriber pair does."""
+    Every rank owns a buffer with two window slots ([B_local, N+1, 10] float64 each) allocated with ndp_peer_alloc; the 64-byte
+    IPC handles are exchanged ONCE (all_gather_object) and each rank maps the buffer of rank (r+1) % W, which holds its
+    neighbours.  Per tick, `other = peer.publish_device(xr_tick, stream)` enqueues ONE launch that copies this rank's windows
+    into its own slot, publishes the tick number and waits for the neighbour's (csrc/peer_epoch.hpp: epoch words, reader
+    acknowledgement before a slot is reused, bounded waits); `other` (DevWindows: a raw device address) is the neighbour's slot
+    of that tick -- pass it to BatchedNMPC.update_device on the same stream: the control-step kernel reads it out of the
+    neighbour GPU's HBM.  No collective, no host round trip; capturable into a hipGraph holding an even number of ticks.
+    With one rank the neighbour is the rank's own buffer (same code path)."""
 
-    def __init__(self, B_local, N, ticks, device, group=None, same_process_ok=True):
+    def __init__(self, B_local, N, device, group=None, timeout_us=200000):
         import ctypes as C
         import torch
         import torch.distributed as dist
         from . import _lib
         self._lib = _lib.load()
         self.device = int(device)
-        self.shape = (int(ticks), int(B_local), int(N) + 1, 10)
-        nbytes = 8 * int(np.prod(self.shape))
+        self.shape = (int(B_local), int(N) + 1, 10)
+        self.n = int(np.prod(self.shape))
+        self.timeout_us = int(timeout_us)
+        nbytes, off0, stride = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._lib.ndp_peer_layout(self.n, C.byref(nbytes), C.byref(off0), C.byref(stride))
+        self._off = (off0.value, off0.value + stride.value)
         ptr, handle = C.c_void_p(), (C.c_ubyte * 64)()
-        rc = self._lib.ndp_peer_alloc(self.device, nbytes, C.byref(ptr), handle)
+        rc = self._lib.ndp_peer_alloc(self.device, nbytes.value, C.byref(ptr), handle)
         self._own = ptr.value if rc == 0 else None
         self._mapped = None
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.tick = 0                      # host mirror of the device-side tick count (slot parity of the next launches)
         if self.world > 1:
             # every rank takes part in every collective below whatever happened locally, and all ranks reach the same verdict
             allocs = [None] * self.world
             dist.all_gather_object(allocs, int(rc), group=group)
             if any(allocs):
-                self.close()
+                self.close(collective=False)
                 raise RuntimeError(f"ndp_peer_alloc failed on some rank: {allocs}")
         elif rc:
             raise RuntimeError(f"ndp_peer_alloc failed ({rc})")
-        with torch.cuda.device(self.device):
-            self._local = torch.as_tensor(_DevMem(self._own, self.shape), device=torch.device("cuda", self.device))
-        self.local = [self._local[t] for t in range(self.shape[0])]
-        slot = 8 * int(np.prod(self.shape[1:]))
-        if self.world == 1:       # the neighbours are this rank's own vehicles: the same raw-address form over the own buffer
-            self.neighbour = [DevWindows(self._own + t * slot, self.shape[1:]) for t in range(self.shape[0])]
-            return
-        handles = [None] * self.world
-        dist.all_gather_object(handles, bytes(handle), group=group)
-        nb = handles[neighbour_rank(self.rank, self.world)]
-        buf = (C.c_ubyte * 64).from_buffer_copy(nb)
-        mp = C.c_void_p()
-        rc = self._lib.ndp_peer_open(self.device, buf, C.byref(mp))
-        ok = [None] * self.world
-        dist.all_gather_object(ok, int(rc), group=group)         # every rank learns whether every mapping worked
-        if any(ok):
-            if rc == 0:
-                self._lib.ndp_peer_close(self.device, mp)
-            self.close()
-            raise RuntimeError(f"ndp_peer_open failed on some rank: {ok}")
-        self._mapped = mp.value
-        self.neighbour = [DevWindows(self._mapped + t * slot, self.shape[1:]) for t in range(self.shape[0])]
+        if self.world == 1:       # the neighbours are this rank's own vehicles: the same protocol over the own buffer
+            self._nb = self._own
+        else:
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(handle), group=group)
+            nb = handles[neighbour_rank(self.rank, self.world)]
+            buf = (C.c_ubyte * 64).from_buffer_copy(nb)
+            mp = C.c_void_p()
+            rc = self._lib.ndp_peer_open(self.device, buf, C.byref(mp))
+            ok = [None] * self.world
+            dist.all_gather_object(ok, int(rc), group=group)         # every rank learns whether every mapping worked
+            if any(ok):
+                if rc == 0:
+                    self._lib.ndp_peer_close(self.device, mp)
+                self.close(collective=False)
+                raise RuntimeError(f"ndp_peer_open failed on some rank: {ok}")
+            self._mapped = mp.value
+            self._nb = self._mapped
+        self.neighbour = [DevWindows(self._nb + self._off[s], self.shape) for s in (0, 1)]
+        with torch.cuda.device(self.device):       # this rank's own slots as tensors (tests read them back)
+            self.local = [torch.as_tensor(_DevMem(self._own + self._off[s], self.shape), device=torch.device("cuda", self.device))
+                          for s in (0, 1)]
 
-    def publish(self):
+    def publish_device(self, xr, stream=None):
+        """Enqueues this tick's publish launch on `stream` (xr: this rank's [B_local, N+1, 10] float64 CUDA windows of the tick)
+        and returns the neighbour's windows of the same tick (DevWindows) for the control step enqueued next on that stream."""
+        import ctypes as C
+        import torch
+        if not (isinstance(xr, torch.Tensor) and xr.is_cuda and xr.is_contiguous() and xr.dtype == torch.float64
+                and tuple(xr.shape) == self.shape):
+            raise ValueError(f"expected a contiguous CUDA float64 tensor {self.shape}")
+        self.tick += 1
+        slot = self.tick & 1
+        sp = None if stream is None else C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+        rc = self._lib.ndp_peer_publish_device(self.device, C.c_void_p(xr.data_ptr()), self.n, C.c_void_p(self._own),
+                                               C.c_void_p(self._nb), slot, self.timeout_us, sp)
+        if rc:
+            raise RuntimeError(f"ndp_peer_publish_device failed ({rc})")
+        return self.neighbour[slot]
+
+    def stats(self):
+        """Synchronises the device; counters of this rank's publish launches."""
+        import ctypes as C
+        out = (C.c_ulonglong * 4)()
+        rc = self._lib.ndp_peer_stats(self.device, C.c_void_p(self._own), out)
+        if rc:
+            raise RuntimeError(f"ndp_peer_stats failed ({rc})")
+        return dict(ticks=int(out[0]), ack_timeouts=int(out[1]), epoch_timeouts=int(out[2]), slot_mismatches=int(out[3]))
+
+    def close(self, collective=True):
+        """Synchronise, unmap the neighbour's buffer, wait for every rank to have done so, then free the own buffer: the rank
+        that reads it may still have kernels in flight.  collective=False (error paths, or a rank leaving on its own) skips the
+        barrier -- the readers' mapping keeps the memory alive either way."""
         import torch
         import torch.distributed as dist
-        torch.cuda.synchronize(self.device)
-        if self.world > 1:
-            dist.barrier(group=self.group)
-
-    def close(self):
+        if self._own or self._mapped:
+            torch.cuda.synchronize(self.device)
         if self._mapped:
             self._lib.ndp_peer_close(self.device, self._mapped)
             self._mapped = None
+        if collective and self.world > 1 and dist.is_initialized():
+            dist.barrier(group=self.group)
         if self._own:
-            self.local, self.neighbour, self._local = None, None, None
+            self.local, self.neighbour = None, None
             self._lib.ndp_peer_free(self.device, self._own)
             self._own = None

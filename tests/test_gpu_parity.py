@@ -604,9 +604,9 @@ def test_work_queue_gives_the_same_answers(ndp, oracle, mlp_blob):
         uo, sto, *_ = _oracle_batch(oracle, b, use_fd=disturbance, f=f)
         assert np.array_equal(st, sto)
         _assert_u(u0[sto == 0], uo[sto == 0])
-    # automatic choice: on from four instances per SIMD (and an early-exit QP mode to defer from)
-    assert not ndp.BatchedNMPC(1024).work_queue and not ndp.BatchedNMPC(2048).work_queue
-    assert ndp.BatchedNMPC(4096).work_queue and not ndp.BatchedNMPC(4096, qp_mode=1).work_queue
+    # automatic choice: on from two instances per SIMD (and an early-exit QP mode to defer from)
+    assert not ndp.BatchedNMPC(1024).work_queue and not ndp.BatchedNMPC(2047).work_queue
+    assert ndp.BatchedNMPC(2048).work_queue and ndp.BatchedNMPC(4096).work_queue and not ndp.BatchedNMPC(4096, qp_mode=1).work_queue
 
 
 def test_neighbour_rows_by_index_and_six_column_windows(ndp):
@@ -787,40 +787,238 @@ def test_config5_qp_on_the_fp32_and_bf16_matrix_instructions(ndp, oracle, N, n_r
 
 
 def test_peer_window_buffer_as_neighbour_source(ndp):
-    """dist.PeerWindows on one rank: the windows live in memory from ndp_peer_alloc (IPC-exportable: the handle a second process
-    would map with ndp_peer_open), the step takes them as a raw device address (dist.DevWindows) -- same answers as the tensor
-    path, with and without other_index.  (Two and three processes mapping each other's buffers: DESIGN.md section 6,
-    profiles/r02_peer_windows_*.)"""
+    """dist.PeerWindows on one rank (the neighbour is the rank's own buffer: same launches, same protocol words): per tick ONE
+    publish launch puts this tick's windows into the slot of the tick's parity and returns the neighbour's slot as a raw device
+    address (dist.DevWindows); the control step that takes it gives the same answers as the tensor path, with and without
+    other_index; epochs count the ticks, no wait times out, the host's slot parity matches the device's.  (Two processes
+    mapping each other's buffers: test_peer_exchange_between_two_processes; the protocol alone: tests/test_peer_epoch.py.)"""
     import torch
     from ndp_nmpc_qd_amd import dist as ndist
     B, N = 96, 20
-    b = synth.make_batch(B, seed=synth.SEED0 + 61, downwash=True)
     dev = torch.device("cuda", 0)
-    d = {k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur", "other", "ego_xy")}
-    pw = ndist.PeerWindows(B, N, 2, 0)
+    pw = ndist.PeerWindows(B, N, 0)
     try:
-        pw.local[1].copy_(d["other"])
-        pw.publish()
-        outs = []
-        for mode in ("tensor", "raw", "raw_indexed"):
-            eng = ndp.BatchedNMPC(B, N=N, disturbance=True)
-            u0 = torch.empty(B, 4, dtype=torch.float64, device=dev)
-            eng.reset_device(d["xr"], d["ur"])
-            if mode == "tensor":
-                eng.update_device(d["x0"], d["xr"], d["ur"], u0, other=d["other"], ego_xy=d["ego_xy"])
-            elif mode == "raw":
-                eng.update_device(d["x0"], d["xr"], d["ur"], u0, other=pw.neighbour[1], ego_xy=d["ego_xy"])
-            else:
-                idx = torch.arange(B, dtype=torch.int32, device=dev)
-                eng.update_device(d["x0"], d["xr"], d["ur"], u0, other=pw.neighbour[1], ego_xy=d["ego_xy"], other_index=idx)
-            eng.synchronize()
-            st, _ = eng.status()
-            assert (st == 0).all()
-            outs.append(u0.cpu().numpy().copy())
-            eng.close()
-        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+        engs = {m: ndp.BatchedNMPC(B, N=N, disturbance=True) for m in ("tensor", "raw", "raw_indexed")}
+        u0 = {m: torch.empty(B, 4, dtype=torch.float64, device=dev) for m in engs}
+        idx = torch.arange(B, dtype=torch.int32, device=dev)
+        for tick in range(1, 6):
+            b = synth.make_batch(B, seed=synth.SEED0 + 61, downwash=True, t0=0.02 * tick)
+            d = {k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur", "other", "ego_xy")}
+            if tick == 1:
+                for e in engs.values():
+                    e.reset_device(d["xr"], d["ur"])
+            other = pw.publish_device(d["other"])             # "this rank's windows" = the neighbour windows of the synthetic batch
+            assert other.dev_ptr == pw.neighbour[tick & 1].dev_ptr
+            torch.cuda.synchronize()
+            assert torch.equal(pw.local[tick & 1], d["other"])
+            engs["tensor"].update_device(d["x0"], d["xr"], d["ur"], u0["tensor"], other=d["other"], ego_xy=d["ego_xy"])
+            engs["raw"].update_device(d["x0"], d["xr"], d["ur"], u0["raw"], other=other, ego_xy=d["ego_xy"])
+            engs["raw_indexed"].update_device(d["x0"], d["xr"], d["ur"], u0["raw_indexed"], other=other, ego_xy=d["ego_xy"], other_index=idx)
+            for e in engs.values():
+                e.synchronize()
+                assert (e.status()[0] == 0).all()
+            assert torch.equal(u0["tensor"], u0["raw"]) and torch.equal(u0["tensor"], u0["raw_indexed"])
+        st = pw.stats()
+        assert st == dict(ticks=5, ack_timeouts=0, epoch_timeouts=0, slot_mismatches=0), st
         with pytest.raises(ValueError):
-            ndp.BatchedNMPC(B, N=N, disturbance=True).update_device(d["x0"], d["xr"], d["ur"], u0,
-                                                                    other=ndist.DevWindows(pw.neighbour[1].dev_ptr, (B, N, 10)))
+            engs["raw"].update_device(d["x0"], d["xr"], d["ur"], u0["raw"], other=ndist.DevWindows(pw.neighbour[1].dev_ptr, (B, N, 10)))
+        for e in engs.values():
+            e.close()
     finally:
         pw.close()
+
+
+def test_peer_publish_replayed_from_a_graph(ndp):
+    """Publish + control step captured into a hipGraph (an even number of ticks) and replayed: the tick number is read from the
+    device-side epoch words, not baked into the launch, so every replay publishes new ticks into the right slots."""
+    import torch
+    from ndp_nmpc_qd_amd import dist as ndist
+    B, N, T = 64, 20, 4
+    dev = torch.device("cuda", 0)
+    ticks = []
+    for t in range(T):
+        b = synth.make_batch(B, seed=synth.SEED0 + 62, downwash=True, t0=0.02 * t)
+        ticks.append({k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur", "other", "ego_xy")})
+    pw = ndist.PeerWindows(B, N, 0)
+    try:
+        stream = torch.cuda.Stream(device=dev)
+        outs = {}
+        for mode in ("host", "graph"):
+            eng = ndp.BatchedNMPC(B, N=N, disturbance=True)
+            u0 = torch.empty(B, 4, dtype=torch.float64, device=dev)
+            eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
+
+            def step(i):
+                d = ticks[i % T]
+                eng.update_device(d["x0"], d["xr"], d["ur"], u0, other=pw.publish_device(d["other"], stream), ego_xy=d["ego_xy"], stream=stream)
+            with torch.cuda.stream(stream):
+                if mode == "host":
+                    for i in range(3 * T):
+                        step(i)
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g, stream=stream, capture_error_mode="relaxed"):
+                        for i in range(T):
+                            step(i)
+                    for _ in range(3):
+                        g.replay()
+            torch.cuda.synchronize()
+            outs[mode] = u0.cpu().numpy().copy()
+            eng.close()
+        assert np.array_equal(outs["host"], outs["graph"])
+        st = pw.stats()
+        assert st["ticks"] == 6 * T and st["epoch_timeouts"] == 0 and st["ack_timeouts"] == 0 and st["slot_mismatches"] == 0, st
+    finally:
+        pw.close()
+
+
+def _peer_proc(rank, world, port, q, leave_after):
+    """One of two processes on the SAME GPU (a one-GPU box): each maps the other's window buffer over IPC and runs the per-tick
+    publish launch + a copy of the neighbour's slot (standing in for the control step's read)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ndp_nmpc_qd_amd import dist as ndist
+    try:
+        B, N = 256, 20
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        pw = ndist.PeerWindows(B, N, 0, timeout_us=50000 if leave_after else 2000000)
+        ticks = 60
+        mine = leave_after if (leave_after and rank == 1) else ticks
+        bad = stale = 0
+        seen = torch.empty(B, N + 1, 10, dtype=torch.float64, device=dev)
+        seen_raw = ndist._DevMem(0, (B, N + 1, 10))
+        for t in range(1, mine + 1):
+            src = torch.full((B, N + 1, 10), 1000.0 * rank + t, dtype=torch.float64, device=dev)
+            other = pw.publish_device(src)
+            nb = torch.as_tensor(ndist._DevMem(other.dev_ptr, other.shape), device=dev)     # the neighbour's slot of this tick
+            seen.copy_(nb)
+            torch.cuda.synchronize()
+            v = seen.unique()
+            want = 1000.0 * ((rank + 1) % world) + t
+            if v.numel() != 1:
+                bad += 1                              # a torn window
+            elif float(v[0]) != want:
+                if leave_after and rank == 0 and t > leave_after:
+                    stale += 1                        # the publisher has left: its last windows
+                else:
+                    bad += 1
+        st = pw.stats()
+        q.put((rank, bad, stale, st))
+        pw.close(collective=not leave_after)
+        if not leave_after:
+            dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("leave_after", [0, 25])
+def test_peer_exchange_between_two_processes(ndp, leave_after):
+    """Two processes on this GPU, each reading the other's published windows through the IPC mapping, one exchange per tick:
+    every read of tick t returns the windows of tick t.  leave_after = 25: rank 1 stops publishing and closes its buffer after
+    25 ticks while rank 0 still has it mapped -- rank 0 keeps stepping on the last windows (its epoch waits time out and are
+    counted), nothing crashes."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_peer_proc, args=(r, 2, port, q, leave_after)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, bad0, stale0, st0), (r1, bad1, stale1, st1) = res
+    assert bad0 == 0 and bad1 == 0, res
+    if not leave_after:
+        for st in (st0, st1):
+            assert st["ticks"] == 60 and st["epoch_timeouts"] == 0 and st["ack_timeouts"] == 0 and st["slot_mismatches"] == 0, st
+    else:
+        assert st1["ticks"] == 25 and st0["ticks"] == 60
+        assert stale0 >= 30 and st0["epoch_timeouts"] >= 30, (stale0, st0)
+
+
+def test_host_step_in_two_halves_and_pipelined(ndp, oracle):
+    """ndp_step_begin / ndp_step_end: the same answers as ndp_step tick by tick -- one tick in flight, two ticks in flight
+    (the packing and H2D of tick i+1 under tick i's kernel) -- on the page-locked zero-copy path (small batch) and on the
+    packed DMA path (inputs over 1 MiB); misuse is refused."""
+    for B in (5, 700):
+        ticks = [synth.make_batch(B, seed=77, downwash=True, t0=0.02 * t) for t in range(6)]
+        ref = ndp.BatchedNMPC(B, disturbance=True)
+        ref.reset(ticks[0]["xr"], ticks[0]["ur"])
+        want = [ref.update(t["x0"], t["xr"], t["ur"], other=t["other"], ego_xy=t["ego_xy"], full=True) for t in ticks]
+        for depth in (1, 2):
+            eng = ndp.BatchedNMPC(B, disturbance=True)
+            eng.reset(ticks[0]["xr"], ticks[0]["ur"])
+            got = []
+            for i, t in enumerate(ticks):
+                arrs = {k: t[k].copy() for k in ("x0", "xr", "ur", "other", "ego_xy")}
+                eng.update_begin(arrs["x0"], arrs["xr"], arrs["ur"], other=arrs["other"], ego_xy=arrs["ego_xy"], want_iterate=True)
+                for a in arrs.values():
+                    a[...] = np.nan                       # the caller's arrays are free again as soon as begin returns
+                if i >= depth - 1:
+                    got.append(eng.update_end(full=True))
+            while len(got) < len(ticks):
+                got.append(eng.update_end(full=True))
+            for g, w in zip(got, want):
+                for x, y in zip(g, w):
+                    assert np.array_equal(x, y)
+            X, U = eng.get_iterate()
+            assert np.array_equal(X, want[-1][1]) and np.array_equal(U, want[-1][2])
+            # misuse: a third step in flight, an end without a begin, the iterate of a step begun without the flag
+            t = ticks[0]
+            eng.update_begin(t["x0"], t["xr"], t["ur"], other=t["other"], ego_xy=t["ego_xy"])
+            eng.update_begin(t["x0"], t["xr"], t["ur"], other=t["other"], ego_xy=t["ego_xy"])
+            with pytest.raises(ndp.batched.NdpError):
+                eng.update_begin(t["x0"], t["xr"], t["ur"], other=t["other"], ego_xy=t["ego_xy"])
+            with pytest.raises(ndp.batched.NdpError):
+                eng.update(t["x0"], t["xr"], t["ur"], other=t["other"], ego_xy=t["ego_xy"])
+            with pytest.raises(ndp.batched.NdpError):
+                eng.update_end(full=True)                 # X / U were not requested at begin
+            eng.update_end()
+            eng.update_end()
+            with pytest.raises(ndp.batched.NdpError):
+                eng.update_end()                          # nothing in flight any more
+            eng.close()
+        uo, sto, *_ = _oracle_batch(oracle, ticks[0], use_fd=True,
+                                    f=oracle.downwash_batch(np.fromfile(ndp._lib.WEIGHTS_PATH, dtype="<f4"), ticks[0]["other"], ticks[0]["xr"], ticks[0]["ego_xy"]))
+        _assert_u(want[0][0][sto == 0], uo[sto == 0])
+
+
+def test_small_handles_keep_the_iterate_in_hbm(ndp):
+    """Handles whose inputs fit the page-locked mirror: host steps and device steps interleave on ONE persistent iterate that
+    lives in HBM (round 2 kept it in page-locked host memory, so device-resident steps of small handles crossed PCIe)."""
+    import torch
+    B = 8
+    dev = torch.device("cuda", 0)
+    ticks = [synth.make_batch(B, seed=78, t0=0.02 * t) for t in range(4)]
+    a, b2 = ndp.BatchedNMPC(B), ndp.BatchedNMPC(B)
+    a.reset(ticks[0]["xr"], ticks[0]["ur"])
+    b2.reset(ticks[0]["xr"], ticks[0]["ur"])
+    u_dev = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    for i, t in enumerate(ticks):
+        ua = a.update(t["x0"], t["xr"], t["ur"])
+        if i % 2 == 0:
+            ub = b2.update(t["x0"], t["xr"], t["ur"])
+        else:
+            d = {k: torch.from_numpy(t[k]).to(dev) for k in ("x0", "xr", "ur")}
+            b2.update_device(d["x0"], d["xr"], d["ur"], u_dev)
+            b2.synchronize()
+            ub = u_dev.cpu().numpy()
+        assert np.array_equal(ua, ub), i
+        assert (b2.status()[0] == 0).all()
+    Xa, Ua = a.get_iterate()
+    Xb, Ub = b2.get_iterate()
+    assert np.array_equal(Xa, Xb) and np.array_equal(Ua, Ub)
+    import ctypes
+    attr_ptr = a._lib.ndp_device_iterate_x(a._h)
+    assert torch.cuda.is_available() and attr_ptr            # a device pointer (HBM); the step's mirror is a different block
