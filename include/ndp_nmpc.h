@@ -120,13 +120,9 @@ int ndp_step_device(ndp_handle *h, const void *d_x0, const void *d_xr, const voi
  * How a host-array step moves its data (both forms; the reference's call shape is host arrays in, host array out,
  * nmpc_body_rate_ctl.py:93-112).  The handle owns two slots of page-locked host mirrors (allocated by the first host step).
  * The caller's arrays are packed into a slot's input mirror by the handle's pack threads (NDP_PACK_THREADS, default: half
- * the hardware threads, at most 8); then
- *   - batches whose inputs fit 1 MiB (B <= ~190 at N = 20): the kernel reads that mirror and writes u0 / status / iterations
- *     -- and a copy of the new iterate when X_out / U_out are given -- into the slot's output mirror itself: one launch and
- *     one synchronisation per call, no DMA operation;
- *   - larger batches: the mirror goes to the slot's device block in a few H2D copies, each issued as soon as its part is
- *     packed (packing and PCIe overlap); the kernel waits for the last; ONE D2H copy returns u0 | status | iterations
- *     (| X | U when asked for).
+ * the hardware threads, at most 8, beside the caller); the kernel reads that mirror over PCIe and writes u0 / status /
+ * iterations -- and a copy of the new iterate when X_out / U_out are given -- into the slot's output mirror itself: one
+ * launch and one wait per call, no DMA operation, at every batch size.
  * The persistent iterate itself always lives in HBM (ndp_device_iterate_x / _u), whatever the batch size. */
 int ndp_step_ex(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
                 const double *other, const double *ego_xy, double *u0, double *X_out, double *U_out,
@@ -298,6 +294,9 @@ int ndp_debug_mfma_probe_f32(const float *a, const float *b, const float *c, flo
 /* Profiling hook: enable = 1 makes every instance of the following steps write 16 phase stamps (shader clock);
  * out (or NULL) receives the [B][16] stamps of the last step before the switch is applied. */
 int ndp_debug_stamps(ndp_handle *h, int enable, double *out);
+/* Profiling hook: where the last host-array step spent its time on the CPU, microseconds: out4 = {packing the inputs into the
+ * page-locked mirror, enqueueing (launches / copies), waiting for the results, copying them out}. */
+int ndp_debug_host_timing(ndp_handle *h, double *out4);
 int ndp_step_debug(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
                    const double *other, const double *ego_xy, double *u0, double *lds_dump);
 

@@ -43,7 +43,7 @@ EXPORTS = [
     "ndp_step_ex", "ndp_step_device_ex", "ndp_work_queue_enabled", "ndp_ref_list_reset", "ndp_ref_list_fix_pt",
     "ndp_ref_list_window", "ndp_ref_list_advance_device", "ndp_ref_list_window_device", "ndp_debug_mfma_probe_f32",
     "ndp_peer_alloc", "ndp_peer_open", "ndp_peer_close", "ndp_peer_free", "ndp_step_begin", "ndp_step_end",
-    "ndp_peer_layout", "ndp_peer_publish_device", "ndp_peer_stats",
+    "ndp_peer_layout", "ndp_peer_publish_device", "ndp_peer_stats", "ndp_debug_host_timing",
 ]
 
 _lib = None
@@ -79,6 +79,7 @@ def load():
     lib.ndp_step_ex.argtypes = [vp] * 12
     lib.ndp_step_begin.argtypes = [vp] * 7 + [C.c_int]
     lib.ndp_step_end.argtypes = [vp] * 6
+    lib.ndp_debug_host_timing.argtypes = [vp, vp]
     lib.ndp_step_device_ex.argtypes = [vp] * 6 + [C.c_int] + [vp] * 4
     lib.ndp_work_queue_enabled.argtypes = [vp]
     lib.ndp_ref_list_reset.argtypes = [vp]

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -986,9 +987,13 @@ __global__ __launch_bounds__(256) void peer_publish_kernel(PeerPubArgs a)
     const size_t n2 = a.n / 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
     if ((a.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<double *>(dst)[a.n - 1] = a.src[a.n - 1];
-    __threadfence_system();                       // this thread's part of the slot is visible system-wide ...
-    __syncthreads();                              // ... and so is the whole block's, before the block counts itself done
+    __syncthreads();                              // the whole block's stores are issued ...
     if (threadIdx.x == 0) {
+        // ... and the agent-scope release of the counting atomic below writes this XCD's L2 back (buffer_wbl2 sc1: the eight
+        // XCDs' L2s are not coherent with each other, so on gfx950 agent scope already means "in memory"): when the last block
+        // has counted, every block's part of the slot is in HBM, where the reading GPU's loads over xGMI find it.  ONE such
+        // release per block, and few blocks (scripts/ubench/publish_copy.hip: a release per thread made this launch 130 us for
+        // 20 MB, one per block with 4096 blocks 114 us, with 256 blocks 16 us; the plain copy is 9 us).
         unsigned *done = reinterpret_cast<unsigned *>(a.own + PEER_W_DONE);
         const unsigned prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         last_s = prev == gridDim.x - 1 ? 1u : 0u;
@@ -1015,17 +1020,17 @@ template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = 
 #ifndef NDP_DEV_QMODE      // 1: study the work list's producer form (no interior-point code) in place of the in-place kernel
 #define NDP_DEV_QMODE 0
 #endif
-struct RtiK { static constexpr auto fn = rti_kernel<3, 4, (FUSED && NC == 20 && QMODE == 0), 20, 0, 1, NDP_DEV_QMODE>; };
+struct RtiK { static constexpr auto fn = rti_kernel<3, (WAVES == 2 && NC == 20 ? 2 : 4), (FUSED && NC == 20 && QMODE == 0), 20, 0, 1, NDP_DEV_QMODE>; };
 #define RTI_K(...) (RtiK<__VA_ARGS__>::fn)
 #else
 #define RTI_K(...) (rti_kernel<__VA_ARGS__>)
 #endif
 
-// ---- host pack threads.  A host-array step first moves the caller's (pageable) arrays into a page-locked mirror; at batch 1024
-// that is 4.2 MB per step, ~0.4 ms for one core -- more than the PCIe transfer (~80 us) and the kernel (~23 us) together.  The
-// mirror is therefore filled by a few persistent threads, a chunk (<= PACK_CHUNK bytes) at a time, while the calling thread
-// hands every finished run of chunks to the DMA engine: packing, H2D and (of the previous step) the kernel overlap.
-struct PackJob { unsigned char *dst; const unsigned char *src; size_t len, off; };
+// ---- host pack threads.  A host-array step first moves the caller's (pageable) arrays into a page-locked mirror the kernel can
+// read; at batch 1024 that is 4.2 MB per step -- 56 us for one core, 26-30 us for eight (measured), against ~100 us for the
+// kernel that then pulls them over PCIe.  The mirror is filled by a few persistent threads and the caller, a chunk
+// (<= PACK_CHUNK bytes) at a time.
+struct PackJob { unsigned char *dst; const unsigned char *src; size_t len; };
 enum : size_t { PACK_CHUNK = (size_t)256 << 10 };
 struct PackPool {
     std::vector<std::thread> th;
@@ -1036,7 +1041,14 @@ struct PackPool {
     std::unique_ptr<std::atomic<int>[]> done;
     int done_cap = 0;
     uint64_t gen = 0;
+    std::atomic<uint64_t> gen_pub{0};   // gen, readable without the lock (the workers' polling phase)
     bool stop = false;
+    static void cpu_relax()
+    {
+#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(__i386__))
+        __asm__ __volatile__("pause");
+#endif
+    }
 
     explicit PackPool(int n)
     {
@@ -1064,6 +1076,9 @@ struct PackPool {
     {
         uint64_t seen = 0;
         for (;;) {
+            // back-to-back steps: the next job list arrives within microseconds -- poll for it a short while (a futex wake-up
+            // costs 30-60 us per thread) before going to sleep on the condition variable (a 50 Hz control loop sleeps)
+            for (int spin = 0; spin < 20000 && gen_pub.load(std::memory_order_acquire) == seen; ++spin) cpu_relax();
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return stop || gen != seen; });
@@ -1086,6 +1101,7 @@ struct PackPool {
             next.store(0, std::memory_order_relaxed);
             njobs.store(n, std::memory_order_release);
             ++gen;
+            gen_pub.store(gen, std::memory_order_release);
         }
         if (!th.empty() && n > 1) cv.notify_all();
     }
@@ -1128,15 +1144,15 @@ struct ndp_handle {
     int *dQids = nullptr;
     bool have_mlp = false;
     // Host-pointer entry points.  ONE block holds every input of a step (x0 | xr | ur | f | other | ego_xy, each 256-byte
-    // aligned) and one its outputs (u0 | status | iters | X | U).  Two slots of page-locked host mirrors (HostSlot, allocated at
-    // the first host step): the caller's arrays are packed into a slot's input mirror by the handle's pack threads and
-    //   * batches whose inputs fit PACK_LIMIT: the kernel reads that mirror and writes u0 / status / iterations (and, when
-    //     asked, a copy of the new iterate) into the slot's output mirror itself -- no DMA operation at all;
-    //   * larger batches: the mirror goes to the slot's device input block in a few H2D copies on a copy stream, each issued
-    //     as soon as its part is packed; the kernel waits for the last one; ONE D2H copy brings u0 | status | iterations back.
-    // With two slots the packing + H2D of step i+1 runs while step i's kernel does (ndp_step_begin / ndp_step_end).
-    // The persistent iterate dX | dU always lives in HBM.  The sx0.. pointers are views into slot 0's device blocks (staging of
-    // the f1-f4 host entry points).
+    // aligned) and one its outputs (u0 | status | iters | X | U).  Two slots of page-locked host mirrors of both (HostSlot,
+    // allocated at the first host step): the caller's arrays are packed into a slot's input mirror by the handle's pack threads,
+    // the kernel reads that mirror over PCIe and writes u0 / status / iterations (and, when asked, a copy of the new iterate)
+    // into the slot's output mirror itself -- one launch and one wait per step, no DMA operation, at every batch size (measured,
+    // batch 1024: 106 us per step with two steps in flight against 121 us with one H2D copy per step and 147-157 us with the
+    // block copied in chunks as it is packed: every asynchronous copy operation costs ~30 us of latency on this platform).
+    // With two slots the packing of step i+1 runs while step i's kernel does (ndp_step_begin / ndp_step_end).
+    // The persistent iterate dX | dU always lives in HBM.  dIn / dOut: device-side staging of the f1-f4 host entry points
+    // (views sx0 ..) and the small outputs of device-pointer steps.
     unsigned char *dIn = nullptr, *dOut = nullptr;
     size_t off_x0 = 0, off_xr = 0, off_ur = 0, off_f = 0, off_other = 0, off_ego = 0, in_bytes = 0;
     size_t off_u0 = 0, off_st = 0, off_it = 0, out_bytes = 0, out_all = 0;
@@ -1145,16 +1161,14 @@ struct ndp_handle {
     int *dStatus = nullptr, *dIters = nullptr;
     const int *lastStatus = nullptr, *lastIters = nullptr;   // where the last step wrote them (dStatus / dIters or a slot's output mirror)
     struct HostSlot {
-        unsigned char *hIn = nullptr, *hOut = nullptr, *dIn = nullptr;    // dIn: null when the kernel reads hIn itself
-        hipEvent_t evIn = nullptr, evKernel = nullptr, evOut = nullptr;   // inputs landed | kernel done with dIn | outputs landed in hOut
-        bool busy = false, kernel_recorded = false, want_iter = false;
+        unsigned char *hIn = nullptr, *hOut = nullptr;
+        hipEvent_t evOut = nullptr;                          // the step that uses the slot has completed
+        bool busy = false, want_iter = false;
         double *dump = nullptr;
     } slot[2];
-    bool slots_ready = false, zero_copy = false;
-    bool staging_used = false;      // an f1-f4 host entry point staged through slot 0's device block since the last host step
-    hipEvent_t evFront = nullptr;
+    bool slots_ready = false;
+    double host_us[4] = {0, 0, 0, 0};   // last host step: packing | enqueue | wait for the results | copy-out  (ndp_debug_host_timing)
     int slot_head = 0, slot_tail = 0, slots_busy = 0;   // begin fills slot_head, end drains slot_tail
-    hipStream_t copy_stream = nullptr;
     std::unique_ptr<struct PackPool> pool;
     // the last foreign stream a *_device call enqueued on: the getters wait for it (hipEvent)
     hipEvent_t evLast = nullptr;
@@ -1168,8 +1182,6 @@ struct ndp_handle {
     std::mutex mu;
     std::string err;
 };
-
-enum : size_t { PACK_LIMIT = (size_t)1 << 20 };
 
 static thread_local std::string g_create_err;
 
@@ -1308,7 +1320,7 @@ int ndp_peer_publish_device(int device, const void *d_src, size_t n_doubles, voi
     PeerPubArgs a{(const double *)d_src, (unsigned long long *)own_buf, (unsigned long long *)nb_buf, n_doubles, slot, timeout_us};
     size_t blocks = (n_doubles / 2 + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 1024) blocks = 1024;      // all of them resident at once: every block's first thread may wait on the reader
+    if (blocks > 256) blocks = 256;        // all resident at once (every block's first thread may wait on the reader), and one L2 release each
     hipLaunchKernelGGL(peer_publish_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -1325,24 +1337,20 @@ int ndp_destroy(ndp_handle *h)
 {
     if (!h) return -1;
     (void)hipSetDevice(h->cfg.device);
-    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ev_pending) (void)hipEventSynchronize(h->evLast);
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->evLast) (void)hipEventDestroy(h->evLast);
     h->pool.reset();
     void *ptrs[] = {h->dRefList, h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dForce, h->dFrag,
-                    h->dIn, h->dOut, h->sdbg, h->dQctr, h->dQids, h->slot[1].dIn};
+                    h->dIn, h->dOut, h->sdbg, h->dQctr, h->dQids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &sl : h->slot) {
         if (sl.hIn) (void)hipHostFree(sl.hIn);
         if (sl.hOut) (void)hipHostFree(sl.hOut);
-        for (hipEvent_t e : {sl.evIn, sl.evKernel, sl.evOut})
-            if (e) (void)hipEventDestroy(e);
+        if (sl.evOut) (void)hipEventDestroy(sl.evOut);
     }
-    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
-    if (h->evFront) (void)hipEventDestroy(h->evFront);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -1380,6 +1388,10 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     const size_t per_wave_bytes = (size_t)h->lds_per_wave * sizeof(double);
     h->waves = 4;
     while (h->waves > 1 && per_wave_bytes * h->waves > 160 * 1024) h->waves >>= 1;
+    if (const char *e = getenv("NDP_DEV_WAVES")) {      // measurement switch: instances per workgroup (2: two workgroups per CU)
+        const int w = atoi(e);
+        if ((w == 1 || w == 2 || w == 4) && w <= h->waves) h->waves = w;
+    }
     auto fail = [&](const char *what, hipError_t err) {
         g_create_err = std::string("ndp_create: ") + what + ": " + hipGetErrorString(err);
         ndp_destroy(h);
@@ -1446,7 +1458,6 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         h->out_all = h->out_bytes + (nxs(h) + nus(h)) * 8;
         ALLOC(h->dIn, h->in_bytes);
         ALLOC(h->dOut, h->out_all);
-        h->zero_copy = h->in_bytes <= PACK_LIMIT;
         h->dX = (double *)(h->dOut + h->out_bytes); h->dU = h->dX + nxs(h);
         h->sx0 = (double *)(h->dIn + h->off_x0); h->sxr = (double *)(h->dIn + h->off_xr); h->sur = (double *)(h->dIn + h->off_ur);
         h->sf = (float *)(h->dIn + h->off_f); h->sother = (double *)(h->dIn + h->off_other); h->sego = (double *)(h->dIn + h->off_ego);
@@ -1465,6 +1476,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
                          (const void *)RTI_K(5, 4, false), (const void *)RTI_K(5, 2, false), (const void *)RTI_K(5, 1, false),
                          (const void *)RTI_K(3, 4, true), (const void *)RTI_K(3, 2, true), (const void *)RTI_K(3, 1, true),
                          (const void *)RTI_K(3, 4, false, 20), (const void *)RTI_K(3, 4, true, 20),
+                         (const void *)RTI_K(3, 2, false, 20), (const void *)RTI_K(3, 2, true, 20),
                          (const void *)RTI_K(3, 4, false, 20, 0, 1, 1), (const void *)RTI_K(3, 4, true, 20, 0, 1, 1), (const void *)RTI_K(3, 4, false, 20, 0, 1, 2),
                          (const void *)RTI_K(5, 1, false, 0, 1), (const void *)RTI_K(5, 1, false, 0, 2),
                          (const void *)RTI_K(5, 1, false, 0, 3), (const void *)RTI_K(5, 1, false, 0, 4),
@@ -1621,6 +1633,8 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     }
     if (h->cfg.N == 20 && h->cfg.n_rti == 1 && W == 4) {   // the reference configuration (params/nmpc_params.py:9, 1 RTI iteration): compile-time instantiation
         if (fused) LAUNCH(3, 4, true, 20); else LAUNCH(3, 4, false, 20);
+    } else if (h->cfg.N == 20 && h->cfg.n_rti == 1 && W == 2) {   // (NDP_DEV_WAVES = 2: the same program, two instances per workgroup)
+        if (fused) LAUNCH(3, 2, true, 20); else LAUNCH(3, 2, false, 20);
     } else if (h->cfg.N == 40 && h->cfg.n_rti == 2 && W == 2 && !fused) {   // BASELINE config 5's shape, compile-time as well
         LAUNCH(5, 2, false, 40, 0, 2);
     } else if (fused) { if (W == 4) LAUNCH(3, 4, true); else if (W == 2) LAUNCH(3, 2, true); else LAUNCH(3, 1, true); }
@@ -1709,17 +1723,7 @@ static int ensure_slots(ndp_handle *h)
         NDP_HIP(h, hipHostMalloc((void **)&sl.hIn, h->in_bytes, hipHostMallocDefault));
         NDP_HIP(h, hipHostMalloc((void **)&sl.hOut, h->out_all, hipHostMallocDefault));
         memset(sl.hOut, 0, h->out_bytes);
-        if (!h->zero_copy) {
-            if (i == 0) sl.dIn = h->dIn;
-            else NDP_HIP(h, hipMalloc((void **)&sl.dIn, h->in_bytes));
-        }
-        NDP_HIP(h, hipEventCreateWithFlags(&sl.evIn, hipEventDisableTiming));
-        NDP_HIP(h, hipEventCreateWithFlags(&sl.evKernel, hipEventDisableTiming));
         NDP_HIP(h, hipEventCreateWithFlags(&sl.evOut, hipEventDisableTiming));
-    }
-    if (!h->zero_copy) {
-        NDP_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-        NDP_HIP(h, hipEventCreateWithFlags(&h->evFront, hipEventDisableTiming));
     }
     // pack threads: NDP_PACK_THREADS, else half the hardware threads, at most 8; the caller packs too, so small blocks need none
     int nt = 0;
@@ -1745,8 +1749,8 @@ static int step_begin_locked(ndp_handle *h, const double *x0, const double *xr, 
     if (h->slots_busy == 2) { h->err = "ndp_step_begin: two steps are already in flight (call ndp_step_end first)"; return -14; }
     if (h->ev_pending && (rc = wait_all(h))) return rc;       // work a caller left on its own stream comes first
     ndp_handle::HostSlot &sl = h->slot[h->slot_head];
-    // the slot's previous use is over: its results were handed out by ndp_step_end (busy is false) -- so its H2D copies, its
-    // kernel and its D2H copy have completed, and both mirrors are free to overwrite
+    // the slot's previous use is over: its results were handed out by ndp_step_end (busy is false), so the kernel that read
+    // its input mirror and wrote its output mirror has completed and both are free to overwrite
     struct Seg { size_t off; const void *src; size_t len; };
     Seg segs[6];
     int ns = 0;
@@ -1760,64 +1764,31 @@ static int step_begin_locked(ndp_handle *h, const double *x0, const double *xr, 
     for (int i = 0; i < ns; ++i)
         for (size_t o = 0; o < segs[i].len; o += PACK_CHUNK) {
             const size_t n = segs[i].len - o < PACK_CHUNK ? segs[i].len - o : PACK_CHUNK;
-            jobs.push_back({sl.hIn + segs[i].off + o, (const unsigned char *)segs[i].src + o, n, segs[i].off + o});
+            jobs.push_back({sl.hIn + segs[i].off + o, (const unsigned char *)segs[i].src + o, n});
         }
     const int nj = (int)jobs.size();
     PackPool &pool = *h->pool;
-    if (!h->zero_copy) {
-        // the slot's device block may still be read by the kernel of the step that used it last -- or, slot 0's, by one of the
-        // f1-f4 host entry points that stage through it (then the copies wait for everything enqueued so far)
-        if (sl.kernel_recorded) NDP_HIP(h, hipStreamWaitEvent(h->copy_stream, sl.evKernel, 0));
-        if (h->staging_used) {
-            NDP_HIP(h, hipEventRecord(h->evFront, s));
-            NDP_HIP(h, hipStreamWaitEvent(h->copy_stream, h->evFront, 0));
-            h->staging_used = false;
-        }
-    }
+    const auto tp0 = std::chrono::steady_clock::now();
     pool.post(jobs.data(), nj);      // from here to pool.finish() nothing returns early: the workers read `jobs`
-    if (h->zero_copy) {
-        for (int i = 0; i < nj; ++i) pool.wait_job(i);
-    } else {
-        // hand every finished run of chunks to the DMA engine while the rest is still being packed; a run never spans an
-        // absent array (f is usually absent: 0.26 MB at batch 1024), the <= 255 padding bytes between arrays are copied along
-        int i = 0;
-        hipError_t e = hipSuccess;
-        while (i < nj) {
-            pool.wait_job(i);
-            const size_t r0 = jobs[i].off;
-            size_t r1 = r0 + jobs[i].len;
-            ++i;
-            while (i < nj && pool.is_done(i) && jobs[i].off - r1 < 256) { r1 = jobs[i].off + jobs[i].len; ++i; }
-            if (e == hipSuccess) e = hipMemcpyAsync(sl.dIn + r0, sl.hIn + r0, r1 - r0, hipMemcpyHostToDevice, h->copy_stream);
-        }
-        pool.finish();
-        NDP_HIP(h, e);
-        NDP_HIP(h, hipEventRecord(sl.evIn, h->copy_stream));
-        NDP_HIP(h, hipStreamWaitEvent(s, sl.evIn, 0));
-    }
-    if (h->zero_copy) pool.finish();
-    const unsigned char *ib = h->zero_copy ? sl.hIn : sl.dIn;
+    for (int i = 0; i < nj; ++i) pool.wait_job(i);
+    pool.finish();
+    const auto tp1 = std::chrono::steady_clock::now();
+    // the kernel reads the input mirror and writes u0 | status | iterations (| the new iterate, when asked for) into the output
+    // mirror itself: page-locked host memory, device-accessible
+    const unsigned char *ib = sl.hIn;
     Neigh nb;
     nb.other = other ? (const double *)(ib + h->off_other) : nullptr;
     nb.ego_xy = ego_xy ? (const double *)(ib + h->off_ego) : nullptr;
     StepOut so;
-    double *u0_dst = h->su0;
-    if (h->zero_copy) {
-        // u0 | status | iterations (| the new iterate, when asked for) are written into the slot's page-locked block by the kernel
-        u0_dst = (double *)(sl.hOut + h->off_u0);
-        so.status = (int *)(sl.hOut + h->off_st); so.iters = (int *)(sl.hOut + h->off_it);
-        if (want_iter) { so.Xm = (double *)(sl.hOut + h->out_bytes); so.Um = so.Xm + nxs(h); }
-    }
+    so.status = (int *)(sl.hOut + h->off_st); so.iters = (int *)(sl.hOut + h->off_it);
+    if (want_iter) { so.Xm = (double *)(sl.hOut + h->out_bytes); so.Um = so.Xm + nxs(h); }
     rc = enqueue_step(h, (const double *)(ib + h->off_x0), (const double *)(ib + h->off_xr), (const double *)(ib + h->off_ur),
-                      f ? (const float *)(ib + h->off_f) : nullptr, nb, u0_dst, dump ? h->sdbg : nullptr, s, &so);
+                      f ? (const float *)(ib + h->off_f) : nullptr, nb, (double *)(sl.hOut + h->off_u0), dump ? h->sdbg : nullptr, s, &so);
     if (rc) return rc;
-    if (!h->zero_copy) {
-        NDP_HIP(h, hipEventRecord(sl.evKernel, s));
-        sl.kernel_recorded = true;
-        NDP_HIP(h, hipMemcpyAsync(sl.hOut, h->dOut, want_iter ? h->out_all : h->out_bytes, hipMemcpyDeviceToHost, s));
-    }
     NDP_HIP(h, hipEventRecord(sl.evOut, s));
     sl.busy = true; sl.want_iter = want_iter; sl.dump = dump;
+    h->host_us[0] = std::chrono::duration<double, std::micro>(tp1 - tp0).count();
+    h->host_us[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp1).count();
     h->slot_head ^= 1;
     ++h->slots_busy;
     return 0;
@@ -1830,13 +1801,18 @@ static int step_end_locked(ndp_handle *h, double *u0, double *X_out, double *U_o
     ndp_handle::HostSlot &sl = h->slot[h->slot_tail];
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     if ((X_out || U_out) && !sl.want_iter) { h->err = "ndp_step_end: the iterate was not requested at ndp_step_begin (flags bit 0)"; return -15; }
-    hipError_t e = hipEventSynchronize(sl.evOut);
+    // the step is a few tens of microseconds from done: poll the event before blocking on it (a blocking wait adds its wake-up)
+    const auto tw0 = std::chrono::steady_clock::now();
+    hipError_t e = hipErrorNotReady;
+    for (int spin = 0; spin < 4000 && e == hipErrorNotReady; ++spin) e = hipEventQuery(sl.evOut);
+    if (e == hipErrorNotReady) e = hipEventSynchronize(sl.evOut);
     if (e == hipSuccess && sl.dump)
         e = hipMemcpy(sl.dump, h->sdbg, (size_t)(lds_doubles(h->cfg.N) + DBG_EXTRA) * 8, hipMemcpyDeviceToHost);
     sl.busy = false;
     h->slot_tail ^= 1;
     --h->slots_busy;
     NDP_HIP(h, e);
+    const auto tw1 = std::chrono::steady_clock::now();
     const unsigned char *ho = sl.hOut;
     if (u0) memcpy(u0, ho + h->off_u0, B * NU * 8);
     const int32_t *st = (const int32_t *)(ho + h->off_st);
@@ -1846,7 +1822,17 @@ static int step_end_locked(ndp_handle *h, double *u0, double *X_out, double *U_o
     if (U_out) memcpy(U_out, ho + h->out_bytes + nxs(h) * 8, nus(h) * 8);
     int w = 0;
     for (size_t i = 0; i < B; ++i) w = st[i] > w ? st[i] : w;
+    h->host_us[2] = std::chrono::duration<double, std::micro>(tw1 - tw0).count();
+    h->host_us[3] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw1).count();
     return w;
+}
+
+int ndp_debug_host_timing(ndp_handle *h, double *out4)
+{
+    if (!h || !out4) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (int i = 0; i < 4; ++i) out4[i] = h->host_us[i];
+    return 0;
 }
 
 int ndp_step_begin(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
@@ -1914,7 +1900,6 @@ int ndp_downwash(ndp_handle *h, const double *other, const double *ego_ref, cons
 {
     if (!h || !other || !ego_ref || !f_out) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
-    h->staging_used = true;
     hipStream_t s = h->stream;
     const size_t B = h->cfg.batch;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
@@ -2126,7 +2111,6 @@ int ndp_relay_reference(ndp_handle *h, const double *xr_lead, double *xr_out)
 {
     if (!h || !xr_lead || !xr_out) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
-    h->staging_used = true;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     NDP_HIP(h, hipMemcpyAsync(h->sother, xr_lead, nxs(h) * 8, hipMemcpyHostToDevice, h->stream));
     int rc = launch_relay_reference(h, h->sother, h->sxr, h->stream);
@@ -2196,7 +2180,6 @@ int ndp_ref_window(ndp_handle *h, const double *t, double *xr, double *ur)
 {
     if (!h || !t || !xr || !ur) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
-    h->staging_used = true;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     NDP_HIP(h, hipMemcpyAsync(h->sThr, t, (size_t)h->cfg.batch * 8, hipMemcpyHostToDevice, h->stream));
     int rc = launch_ref_window(h, h->sThr, 0.0, h->sxr, h->sur, h->stream);
@@ -2312,7 +2295,6 @@ int ndp_ref_list_window(ndp_handle *h, const double *t, double *xr, double *ur)
 {
     if (!h || !xr || !ur) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
-    h->staging_used = true;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     int rc = 0;
     if (t) {
@@ -2350,7 +2332,6 @@ int ndp_plant_step(ndp_handle *h, double *x, const double *u, const double *f, d
     if (!h || !x || !u || substeps < 1) return -1;
     const size_t B = h->cfg.batch;
     std::lock_guard<std::mutex> lk(h->mu);
-    h->staging_used = true;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     NDP_HIP(h, hipMemcpyAsync(h->sx0, x, B * 80, hipMemcpyHostToDevice, h->stream));
     NDP_HIP(h, hipMemcpyAsync(h->su0, u, B * 32, hipMemcpyHostToDevice, h->stream));
@@ -2367,7 +2348,6 @@ int ndp_rollout_device(ndp_handle *h, int ticks, double t0, double dt_tick, int 
 {
     if (!h || ticks < 1 || substeps < 1 || !d_x) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
-    h->staging_used = true;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     if (h->cfg.use_fd) { h->err = "ndp_rollout_device: the rollout drives the NMPC model (use_fd = 0)"; return -8; }
