@@ -169,3 +169,51 @@ def active_set_solve(qp, max_iter=200):
         if not changed:
             return dx, du, active
     raise RuntimeError("active set did not converge")
+
+
+def pdas_solve(qp, max_iter=60):
+    """Primal-dual active-set iteration on the dense KKT system: ALL violated bounds are pinned and ALL wrong-signed pins are
+    released at once (Hintermueller-Ito-Kunisch); a handful of dense solves instead of one per constraint, which is what makes
+    hundreds of N = 20 and dozens of N = 40 problems affordable as an independent check.  Terminates at a point that satisfies
+    the KKT conditions of the box-constrained QP exactly (same stopping rule as active_set_solve); if the sets start to cycle
+    it hands over to the one-at-a-time method."""
+    table = bound_table(qp)
+    active, seen = {}, set()
+    for _ in range(max_iter):
+        key = frozenset(active.items())
+        if key in seen:
+            return active_set_solve(qp)
+        seen.add(key)
+        fixed = [(v, (lo if active[v] == "lo" else hi)) for (v, lo, hi) in table if v in active]
+        try:
+            dx, du, mult = kkt_solve(qp, fixed)
+        except np.linalg.LinAlgError:           # pinning everything that is violated at once over-determined a stage
+            return active_set_solve(qp)
+        z = np.concatenate([dx.ravel(), du.ravel()])
+        new, i = {}, 0
+        for (v, lo, hi) in table:
+            if v in active:
+                lam = mult[i] if active[v] == "lo" else -mult[i]
+                if lam >= -1e-10:
+                    new[v] = active[v]
+                i += 1
+            elif lo - z[v] > 1e-10:
+                new[v] = "lo"
+            elif z[v] - hi > 1e-10:
+                new[v] = "hi"
+        if new == active:
+            return dx, du, active
+        active = new
+    return active_set_solve(qp)
+
+
+def separation(qp, dx, du, active):
+    """How clearly the exact solution (dx, du, active set) decides each bound: min over the inactive bounds of the distance to
+    the bound and over the active ones of the multiplier's magnitude.  An interior-point answer stopped at complementarity mu
+    is off by ~ mu / separation (times a modest constant): a bound 0.01 from active leaves a multiplier mu / 0.01 on it."""
+    table = bound_table(qp)
+    fixed = [(v, (lo if active[v] == "lo" else hi)) for (v, lo, hi) in table if v in active]
+    _, _, mult = kkt_solve(qp, fixed)
+    z = np.concatenate([dx.ravel(), du.ravel()])
+    margin = min(min(z[v] - lo, hi - z[v]) for (v, lo, hi) in table if v not in active)
+    return min(margin, np.abs(mult).min() if len(mult) else np.inf)

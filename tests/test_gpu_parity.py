@@ -1022,3 +1022,45 @@ def test_small_handles_keep_the_iterate_in_hbm(ndp):
     import ctypes
     attr_ptr = a._lib.ndp_device_iterate_x(a._h)
     assert torch.cuda.is_available() and attr_ptr            # a device pointer (HBM); the step's mirror is a different block
+
+
+@pytest.mark.parametrize("scale", [10, 100])
+def test_control_error_from_the_mlp_outside_its_training_envelope(ndp, mlp_golden, mlp_blob, scale):
+    """What the MLP's rounding outside the training envelope does to the CONTROL: the 10x / 100x fixture rows (forces from the
+    imported reference network, torch fp32) as neighbour offsets of a batch; u0 from (a) the fused device step (device MLP), (b)
+    the same step fed the torch-fixture forces, (c) fed the float64 evaluation of the shipped weights.  The device's u0 is no
+    further from (c) than 2.5x what the reference's own fp32 forces are, and (a) equals the unfused device path."""
+    key = f"_x{scale}"
+    z, f_torch = mlp_golden["z" + key], mlp_golden["f" + key]
+    B = z.shape[0] // 21
+    z, f_torch = z[:B * 21].reshape(B, 21, 6), f_torch[:B * 21].reshape(B, 21, 3)
+    b = synth.make_batch(B, seed=91)
+    other = b["xr"].copy()
+    other[:, :, 0:6] += z.astype(np.float64)
+    z_seen = (other - b["xr"])[:, :, 0:6].astype(np.float32)           # downwash_nn.py:22-23: what the network is fed
+    f_true = _mlp_fp64(mlp_blob, z_seen.reshape(-1, 6)).reshape(B, 21, 3)
+
+    def u0_with(f=None, **kw):
+        eng = ndp.BatchedNMPC(B, disturbance=True)
+        eng.reset(b["xr"], b["ur"])
+        u = eng.update(b["x0"], b["xr"], b["ur"], f=f, raise_on_status=False, **kw)
+        st, _ = eng.status()
+        return u, st
+
+    u_fused, st_a = u0_with(other=other)                               # gate always open (no ego_xy)
+    eng = ndp.BatchedNMPC(B, disturbance=True)
+    f_dev = eng.downwash(other, b["xr"])
+    u_dev, _ = u0_with(f=f_dev)
+    u_fix, st_b = u0_with(f=f_torch)
+    u_true, st_c = u0_with(f=f_true.astype(np.float32))
+    ok = (st_a == 0) & (st_b == 0) & (st_c == 0)
+    assert ok.sum() >= B // 2
+    np.testing.assert_allclose(u_fused[ok], u_dev[ok], rtol=0, atol=1e-12)
+    den = np.maximum(1.0, np.abs(u_true[ok]))
+    e_dev = (np.abs(u_fused[ok] - u_true[ok]) / den).max()
+    e_fix = (np.abs(u_fix[ok] - u_true[ok]) / den).max()
+    e_df = (np.abs(u_fused[ok] - u_fix[ok]) / den).max()
+    print(f"scale {scale}: |f| up to {np.abs(f_true).max():.1f} N; u0 device-MLP vs fp64-MLP {e_dev:.2e}, torch-fixture vs fp64-MLP {e_fix:.2e}, "
+          f"device vs torch-fixture {e_df:.2e}")
+    assert e_dev <= 2.5 * e_fix + 1e-9
+    assert e_df <= 1e-3

@@ -248,3 +248,119 @@ def test_downwash_update_and_gate(oracle, mlp_blob, mlp_golden):
     ego_xy[2] += [3.0, 0.0]       # far -> off
     fg = oracle.downwash_batch(mlp_blob, other, ego, ego_xy)
     assert np.array_equal(fg[0], f[0]) and np.all(fg[1] == 0) and np.all(fg[2] == 0) and np.array_equal(fg[3], f[3])
+
+
+# ------------------------------------------------------------------------------------------- wider independent pins (round 3)
+# What these tests found, and assert.  The oracle's QP solver is an interior-point method stopped at complementarity
+# mu <= tol = 1e-8 (HPIPM's default, nmpc_body_rate_ctl.py:71-79 leaves it there).  Against the EXACT solution of the same QP
+# (primal-dual active set on the dense KKT system) it is
+#   * within 2e-7 on (all but the most weakly decided of) these problems once it is run to tol = 1e-10 -- the QP data and the
+#     algorithm are right;
+#   * in general within ~4e-6 (N / 20) (tol / 1e-8) / s, where s = how clearly the solution decides each bound (distance of the
+#     nearest inactive bound, magnitude of the weakest active multiplier): 1e-9 on well-separated problems, up to 3e-5 in u0
+#     when a bound is 0.01 from becoming active -- ONE more iteration takes such a problem from 3e-5 to 5e-9 (Mehrotra's
+#     iteration converges superlinearly, the stopping test is a threshold).  Two correct interior-point codes that stop one
+#     iteration apart therefore differ by up to ~3e-5 on such problems: this is the floor under any parity claim against the
+#     reference's HPIPM on near-active problems.  The device runs the SAME iteration as the oracle (same counts, asserted on
+#     the GPU), which is why device-vs-oracle parity is 1e-9 .. 4e-6 even there.
+DEFAULT_TOL_CONST = 4e-6
+
+
+def _check_qp(oracle, cfg, qp, stats=None, tight=True):
+    """Both QP modes of the oracle against the primal-dual active-set answer of the same QP data; returns the active set."""
+    dxa, dua, active = R.pdas_solve(qp)
+    sep = min(1.0, R.separation(qp, dxa, dua, active))
+    tol0 = cfg.tol
+    for mode in (1, 0):                         # 1: interior point always (HPIPM's behaviour), 0: the device's early-exit rule
+        cfg.qp_mode = mode
+        N = qp["A"].shape[0]                    # (the constant grows with the horizon: more bounds, longer error propagation)
+        for tol in ((1e-10,) if tight else ()) + (tol0,):
+            bar = max(2e-7, DEFAULT_TOL_CONST * (N / 20.0) * (tol / 1e-8) / sep)
+            cfg.tol = tol
+            dx, du, st = oracle.qp_solve(cfg, qp)
+            assert st.status == 0
+            err = max(np.abs(du - dua).max(), np.abs(dx - dxa).max())
+            assert err <= bar, (mode, tol, err, bar, len(active), sep)
+            if stats is not None and mode == 1:
+                stats.append((tol, err, sep, len(active)))
+    cfg.tol = tol0
+    return active
+
+
+def test_both_qp_modes_against_active_set_on_200_random_qps(oracle):
+    """200 QPs of the reference configuration (N = 20) from the two perturbation levels of the GPU suite's large-perturbation
+    test (seeds 2 and 4: the batches in which, before the floor under the centring target, rare instances sat 2e-5 apart
+    between the early-exit and the always-iterating form), first tick and a warm-started second tick."""
+    stats, n_active = [], 0
+    for seed, kw in ((2, dict(pos_sigma=0.5, vel_sigma=1.0, quat_sigma=0.15)), (4, dict(pos_sigma=1.0, vel_sigma=2.0, quat_sigma=0.3))):
+        b = synth.make_batch(768, seed=seed, **kw)
+        cfg = oracle.default_cfg()
+        for i in list(range(0, 768, 15))[:50]:
+            X, U = b["xr"][i].copy(), b["ur"][i].copy()
+            for tick in range(2):
+                qp = oracle.linearize(cfg, b["x0"][i], b["xr"][i], b["ur"][i], None, X, U)
+                n_active += len(_check_qp(oracle, cfg, qp, stats)) > 0
+                cfg.qp_mode = 1
+                oracle.step(cfg, b["x0"][i], b["xr"][i], b["ur"][i], None, X, U)      # the iterate the next tick starts from
+    st = np.array(stats)
+    tight, dflt = st[st[:, 0] == 1e-10], st[st[:, 0] != 1e-10]
+    assert len(tight) == 200 and n_active >= 40, (len(tight), n_active)                # a fifth and more of them with active bounds
+    assert tight[:, 1].max() <= 2e-7
+    assert np.median(dflt[:, 1]) < 1e-8 and (dflt[:, 1] <= 2e-7).mean() > 0.9          # the bulk at the default tolerance
+    assert dflt[:, 1].max() < 5e-5                                                      # the near-active tail (see the note above)
+
+
+def test_input_and_velocity_bounds_active_together(oracle):
+    """u- and v-bounds (nmpc_body_rate_ctl.py:56-61: both families) active in the SAME QP: the velocity box is shrunk below the
+    unconstrained solution's peak while the large initial error keeps input bounds active."""
+    both, stats = 0, []
+    for seed in range(40, 80):
+        cfg, qp = _hard_case(oracle, seed, 1.5)
+        cfg.qp_mode = 1
+        dx_free, _, _ = oracle.qp_solve(cfg, qp)
+        vmax = np.abs(dx_free[4:20, 3:6]).max()
+        qp["lv"][:4], qp["uv"][:4] = -1e3, 1e3          # keep the problem feasible near the fixed x0
+        qp["lv"][4:], qp["uv"][4:] = -0.7 * vmax, 0.7 * vmax
+        # Default tolerance only.  With ACTIVE STATE bounds the barrier puts lambda / t ~ 1e9 .. 1e11 on the diagonal of Q, and the
+        # classical Riccati recursion (P = Hxx - Hxu Lam^-1 Hux, an explicit difference) loses digits as mu shrinks: pushed to
+        # tol = 1e-10 the answer gets WORSE on some of these problems (1e-3), not better -- HPIPM propagates P in factored form
+        # [acados-knowledge].  The reference's velocity box (+-20 m/s, nmpc_body_rate_ctl.py:59-61) is far outside its flight
+        # envelope, so this only shows on boxes shrunk on purpose as here; at the default tolerance the usual bound holds.
+        active = _check_qp(oracle, cfg, qp, stats, tight=False)
+        nz = 21 * 10
+        has_v, has_u = any(v < nz for v in active), any(v >= nz for v in active)
+        both += has_v and has_u
+    st = np.array(stats)
+    assert both >= 30, both
+    assert np.median(st[:, 1]) < 1e-6 and st[:, 1].max() < 1e-3
+
+
+def test_long_horizon_two_iterations_against_active_set(oracle):
+    """BASELINE config 5's shape (N = 40, 2 RTI iterations per step): each iteration's QP -- linearised at the oracle's own
+    iterate -- against the active-set answer, in both QP modes, and the step's final u0 (run to tol = 1e-10) against the two
+    independent solves chained by hand (full step, no shift)."""
+    N = 40
+    n_active = 0
+    for seed in range(70, 82):
+        b = synth.make_batch(1, N=N, seed=seed, pos_sigma=0.7, vel_sigma=1.5, quat_sigma=0.2)
+        cfg = oracle.default_cfg(N=N, n_rti=1)
+        X, U = b["xr"][0].copy(), b["ur"][0].copy()
+        Xa, Ua = X.copy(), U.copy()
+        for it in range(2):
+            qp = oracle.linearize(cfg, b["x0"][0], b["xr"][0], b["ur"][0], None, X, U)
+            n_active += len(_check_qp(oracle, cfg, qp)) > 0
+            # the independent chain: active-set solution of the QP linearised at ITS OWN iterate
+            qpa = oracle.linearize(cfg, b["x0"][0], b["xr"][0], b["ur"][0], None, Xa, Ua)
+            dxa, dua, _ = R.pdas_solve(qpa)
+            Xa, Ua = Xa + dxa, Ua + dua
+            cfg.qp_mode = 1
+            oracle.step(cfg, b["x0"][0], b["xr"][0], b["ur"][0], None, X, U)
+        for mode in (1, 0):
+            cfg2 = oracle.default_cfg(N=N, n_rti=2)
+            cfg2.qp_mode, cfg2.tol = mode, 1e-10
+            X2, U2 = b["xr"][0].copy(), b["ur"][0].copy()
+            u2, st = oracle.step(cfg2, b["x0"][0], b["xr"][0], b["ur"][0], None, X2, U2)
+            assert st.status == 0
+            np.testing.assert_allclose(u2, Ua[0], atol=2e-7)
+            np.testing.assert_allclose(X2, Xa, atol=2e-7)
+    assert n_active >= 8, n_active
