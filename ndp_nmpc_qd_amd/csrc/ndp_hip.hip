@@ -754,19 +754,20 @@ __global__ __launch_bounds__(256) void plant_kernel(double *__restrict__ x, cons
 // coefficients (224 contiguous bytes, shared by the neighbouring nodes of the vehicle), writes 80 + 32 contiguous bytes.
 struct RefCfg { int B, N, n_seg; double dt, mass, g, toff; };   // toff: added to every vehicle's node-0 time (rollouts)
 
-// sum_i [i (i-1) .. (i-d+1) t^(i-d)] / tseg^d * c[i]  (get_poly_params + _get_output_value), powers by repeated products
+// Derivative d of sum_i c[i] s^i by Horner's rule, the factors i (i-1) .. (i-d+1) applied on the fly (get_poly_params +
+// _get_output_value, base_pt_publisher.py:102-133, polym_optimizer.py:104-139, evaluate every power, factor and term separately:
+// ~160 multiplies and adds per reference point; this is 2 per coefficient for the derivatives, 1 for the value: ~120).
+// Measured (round 3): folding factors and 1 / tseg^d into per-derivative coefficient blocks on the host (1 operation per
+// coefficient, but 85 instead of 28 loads per point) made the kernel SLOWER -- 1.32 ms against 0.97 ms per million windows: it
+// is bound by its loads, not by its f64 work.
 template <int NC_, int D>
-__device__ __forceinline__ double poly_eval(const double *__restrict__ c, const double *tp, double inv_scale_den)
+__device__ __forceinline__ double horner_d(const double *__restrict__ c, double s)
 {
-    double acc = 0.0;
+    auto fac = [](int i) { double f = 1.0; for (int j = 0; j < D; ++j) f *= (double)(i - j); return f; };
+    double acc = fac(NC_ - 1) * c[NC_ - 1];
 #pragma unroll
-    for (int i = D; i < NC_; ++i) {
-        double f = 1.0;
-#pragma unroll
-        for (int j = 0; j < D; ++j) f *= (double)(i - j);
-        acc += f * tp[i - D] * c[i];
-    }
-    return acc * inv_scale_den;      // one scale per quantity (the reference divides every term by tseg^d: same value to ~1 ulp)
+    for (int i = NC_ - 2; i >= D; --i) acc = fma(acc, s, fac(i) * c[i]);
+    return acc;
 }
 
 // One reference point: trajectory of vehicle b at trajectory time t -> x[10] = [p, v, qw, qx, qy, qz], u[4] = [wx, wy, wz, c]
@@ -785,24 +786,18 @@ __device__ __forceinline__ void ref_point(const RefCfg &cf, const double *__rest
         int idx = 0;                                      // :100: first i with time_cum[i] > t, minus one
         while (idx < cf.n_seg && !(tc[idx] > t)) ++idx;
         idx = idx > 0 ? idx - 1 : 0;
-        const double ts_ = tseg[(size_t)b * cf.n_seg + idx];
+        const double its = 1.0 / tseg[(size_t)b * cf.n_seg + idx], its2 = its * its;     // one divide per point
         const double *c = coeff + ((size_t)b * cf.n_seg + idx) * 28;
-        double tp[8], sc[4];
-        tp[0] = 1.0;
-        sc[0] = 1.0; sc[1] = 1.0 / ts_; sc[2] = sc[1] * sc[1]; sc[3] = sc[2] * sc[1];   // 1 / tseg^d: one divide per row
-        // (an f64 divide is ~30 VALU instructions here; the row had 23 of them, now 6)
-        const double s = (t - tc[idx]) * sc[1];           // :102-103
-#pragma unroll
-        for (int i = 1; i < 8; ++i) tp[i] = tp[i - 1] * s;
+        const double s = (t - tc[idx]) * its;             // :102-103
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            pvaj[a] = poly_eval<8, 0>(c + 8 * a, tp, sc[0]);
-            pvaj[3 + a] = poly_eval<8, 1>(c + 8 * a, tp, sc[1]);
-            pvaj[6 + a] = poly_eval<8, 2>(c + 8 * a, tp, sc[2]);
-            pvaj[9 + a] = poly_eval<8, 3>(c + 8 * a, tp, sc[3]);
+            pvaj[a] = horner_d<8, 0>(c + 8 * a, s);
+            pvaj[3 + a] = horner_d<8, 1>(c + 8 * a, s) * its;
+            pvaj[6 + a] = horner_d<8, 2>(c + 8 * a, s) * its2;
+            pvaj[9 + a] = horner_d<8, 3>(c + 8 * a, s) * (its2 * its);
         }
-        yaw = poly_eval<4, 0>(c + 24, tp, sc[0]);
-        yawd = poly_eval<4, 1>(c + 24, tp, sc[1]);
+        yaw = horner_d<4, 0>(c + 24, s);
+        yawd = horner_d<4, 1>(c + 24, s) * its;
     }
     // differential flatness (pt_publisher.py:188-248)
     const double td[3] = {pvaj[6], pvaj[7], pvaj[8] + cf.g};
@@ -827,16 +822,25 @@ __device__ __forceinline__ void ref_point(const RefCfg &cf, const double *__rest
     const double wr = yawd * zb[2];
     // tf.transformations.quaternion_from_matrix on [x_b y_b z_b] (ROS geometry; restated): R[i][0..2] = xb[i], yb[i], zb[i]
     const double R[3][3] = {{xb[0], yb[0], zb[0]}, {xb[1], yb[1], zb[1]}, {xb[2], yb[2], zb[2]}};
-    double q[4], tt = R[0][0] + R[1][1] + R[2][2] + 1.0;
+    // (q[3] = w; i = index of the largest diagonal entry, j = i + 1, k = i + 2 mod 3.  Written with selects over the three cases:
+    // dynamically indexed local arrays live in scratch memory on this target.)
+    double q0, q1, q2, q3, tt = R[0][0] + R[1][1] + R[2][2] + 1.0;
     if (tt > 1.0) {
-        q[3] = tt; q[2] = R[1][0] - R[0][1]; q[1] = R[0][2] - R[2][0]; q[0] = R[2][1] - R[1][2];
+        q3 = tt; q2 = R[1][0] - R[0][1]; q1 = R[0][2] - R[2][0]; q0 = R[2][1] - R[1][2];
     } else {
-        int i = 0, j = 1, kk = 2;
-        if (R[1][1] > R[0][0]) { i = 1; j = 2; kk = 0; }
-        if (R[2][2] > R[i][i]) { i = 2; j = 0; kk = 1; }
-        tt = R[i][i] - (R[j][j] + R[kk][kk]) + 1.0;
-        q[i] = tt; q[j] = R[i][j] + R[j][i]; q[kk] = R[kk][i] + R[i][kk]; q[3] = R[kk][j] - R[j][kk];
+        const bool c1 = R[1][1] > R[0][0];
+        const bool c2 = R[2][2] > (c1 ? R[1][1] : R[0][0]);
+        // case (i, j, k) = (0,1,2), (1,2,0), (2,0,1)
+        const double t0 = R[0][0] - (R[1][1] + R[2][2]) + 1.0, t1 = R[1][1] - (R[2][2] + R[0][0]) + 1.0, t2 = R[2][2] - (R[0][0] + R[1][1]) + 1.0;
+        const double s01 = R[0][1] + R[1][0], s12 = R[1][2] + R[2][1], s20 = R[2][0] + R[0][2];
+        const double d21 = R[2][1] - R[1][2], d02 = R[0][2] - R[2][0], d10 = R[1][0] - R[0][1];
+        tt = c2 ? t2 : (c1 ? t1 : t0);
+        q0 = c2 ? s20 : (c1 ? s01 : t0);       // q[i] = tt, q[j] = R[i][j] + R[j][i], q[k] = R[k][i] + R[i][k]
+        q1 = c2 ? s12 : (c1 ? t1 : s01);
+        q2 = c2 ? t2 : (c1 ? s12 : s20);
+        q3 = c2 ? d10 : (c1 ? d02 : d21);      // q[3] = R[k][j] - R[j][k]
     }
+    const double q[4] = {q0, q1, q2, q3};
     const double qs = 0.5 / sqrt(tt);
     // [qw, qx, qy, qz] (pt_publisher.py:237-240, :115-128); u = [p, q, r, collective_force / mass] (:138-145)
     xv[0] = pvaj[0]; xv[1] = pvaj[1]; xv[2] = pvaj[2]; xv[3] = pvaj[3]; xv[4] = pvaj[4]; xv[5] = pvaj[5];

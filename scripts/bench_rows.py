@@ -31,6 +31,8 @@ def main():
         return bench_ref_window(a, torch, ndp, dev)
     if a.row == "rollout":
         return bench_rollout(a, torch, ndp, dev)
+    if a.row == "ref_list":
+        return bench_ref_list(a, torch, ndp, dev)
     eng = ndp.BatchedNMPC(B, N=2, load_mlp=False)       # tiny horizon: only the estimator state matters here
     vz = torch.randn(B, dtype=torch.float64, device=dev) * 0.1
     th = torch.rand(B, dtype=torch.float64, device=dev) * 0.8 + 0.15
@@ -103,6 +105,52 @@ def bench_ref_window(a, torch, ndp, dev):
     print(json.dumps({"row": "f1 reference window generation (polynomial trajectory + differential flatness)",
                       "metric": "vehicle windows/s", "value": B * a.steps / el, "batch": B, "ms_per_step": el / a.steps * 1e3,
                       "dtype": "f64", "kernel_us": dev_s * 1e6,
+                      "roofline": {"bound": "hbm", "achieved": bytes_per * B / dev_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                   "frac": bytes_per * B / dev_s / 1e9 / 8000.0, "algorithmic_bytes_per_vehicle": bytes_per}}))
+
+
+def bench_ref_list(a, torch, ndp, dev):
+    """f1, the reference's own bookkeeping (NMPCRefPublisher's sliding list, pt_pub/pt_publisher.py:36-103) on the device: per
+    tick ONE new reference point per vehicle into the ring [B][5N+1][14] (ref_list_fill_kernel) and the window = every 5th
+    entry (ref_list_window_kernel).  Algorithmic bytes per vehicle and tick: advance = read t 8 + coefficients 224 + 72,
+    write one entry 112; window = read 21 entries 21 * 112, write xr 1680 + ur 640."""
+    import numpy as np
+    from ndp_nmpc_qd_amd.pt_pub import TrajCoefficients
+    B, M = a.batch, 4
+    rng = np.random.default_rng(7)
+    wp = np.zeros((B, 4, M + 1))
+    wp[:, 0:2] = np.cumsum(rng.uniform(-1.0, 1.0, (B, 2, M + 1)), axis=2)
+    wp[:, 2] = 1.0 + 0.2 * rng.uniform(-1, 1, (B, M + 1))
+    wp[:, 3] = np.cumsum(rng.uniform(-0.3, 0.3, (B, M + 1)), axis=1)
+    tc = TrajCoefficients.from_waypoints(wp, rng.uniform(3.0, 5.0, (B, M)))
+    eng = ndp.BatchedNMPC(B, load_mlp=False)
+    eng.ref_set_trajectory(tc.coeff_x, tc.coeff_y, tc.coeff_z, tc.coeff_yaw, tc.traj_time_cum, tc.traj_time_seg, tc.final_pt)
+    eng.ref_list_reset()
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(st)
+    ts = [torch.full((B,), 0.02 * i, dtype=torch.float64, device=dev) for i in range(8)]
+    xr = torch.empty(B, 21, 10, dtype=torch.float64, device=dev)
+    ur = torch.empty(B, 20, 4, dtype=torch.float64, device=dev)
+
+    def tick(i):
+        eng.ref_list_advance_device(ts[i % 8], stream=st)
+        eng.ref_list_window_device(xr, ur, stream=st)
+    for i in range(a.warmup):
+        tick(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(a.steps):
+        tick(i)
+    e1.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    dev_s = e0.elapsed_time(e1) * 1e-3 / a.steps
+    bytes_per = (8 + 224 + 72 + 112) + (21 * 112 + 1680 + 640)
+    print(json.dumps({"row": "f1 reference list on the device: one new point per vehicle and tick + window = every 5th entry",
+                      "metric": "vehicle windows/s", "value": B * a.steps / el, "batch": B, "ms_per_step": el / a.steps * 1e3,
+                      "dtype": "f64", "kernels_us": dev_s * 1e6,
                       "roofline": {"bound": "hbm", "achieved": bytes_per * B / dev_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                                    "frac": bytes_per * B / dev_s / 1e9 / 8000.0, "algorithmic_bytes_per_vehicle": bytes_per}}))
 

@@ -1054,6 +1054,12 @@ def test_control_error_from_the_mlp_outside_its_training_envelope(ndp, mlp_golde
     u_fix, st_b = u0_with(f=f_torch)
     u_true, st_c = u0_with(f=f_true.astype(np.float32))
     ok = (st_a == 0) & (st_b == 0) & (st_c == 0)
+    assert np.array_equal(st_a, st_b) and np.array_equal(st_a, st_c)      # whichever evaluation of the network: the same solver verdict
+    if scale == 100:
+        # forces of ~1.4 kN on a 1.5 kg vehicle: no QP of the batch converges inside the input box -- with ANY of the three
+        # force arrays; there is no control to compare (the 10x case, up to 142 N, is the informative one)
+        assert np.abs(f_true).max() > 500.0 and ok.sum() == 0
+        return
     assert ok.sum() >= B // 2
     np.testing.assert_allclose(u_fused[ok], u_dev[ok], rtol=0, atol=1e-12)
     den = np.maximum(1.0, np.abs(u_true[ok]))
