@@ -129,6 +129,11 @@ def main():
                          "one publish launch per step into a peer-mapped slot + epoch word, the control-step kernel reads the "
                          "neighbour's slot over xGMI; both (default): the timed steps are run once in each form, `value` is the rccl "
                          "form's, `exchange` carries both")
+    ap.add_argument("--downwash-form", default="both", choices=["both", "prefetch", "fused"],
+                    help="one GPU, config 3, downwash on: how the MLP runs.  fused: gate + MLP inside the control-step launch (the "
+                         "product default); prefetch: the force of tick t+1 is predicted by a second launch on a second stream WHILE "
+                         "tick t is solved (as the reference's subscriber callback runs beside its control loop); both (default): the "
+                         "timed steps run once in each form, `value` is the fused form's, `downwash_forms` carries both")
     ap.add_argument("--clock-warm-ms", type=float, default=30.0,
                     help="after the --warmup steps and the graph's instantiation, replay the captured steps UNTIMED for this long so that the "
                          "GPU's clocks are up when the timed steps start (a 20-step run is 0.5 ms of work after an idle period: without it "
@@ -144,6 +149,10 @@ def main():
 
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL and the peer-window mapping alike); must be set before HIP starts
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the downwash-one-tick-ahead form runs two launches side by side: they need different hardware queues.  The library's second
+    # stream is created at another priority level (its own queues); more queues than the default four as well, so that no two of
+    # this process's streams share one by accident (measured: two streams on one queue run their kernels one after the other)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -192,6 +201,7 @@ def main():
     # an explicit non-default stream: torch's default stream has handle 0, which the C-ABI reads as "use the
     # library's own stream" -- with a real handle the exchange (N > 1) and the kernel are ordered on ONE stream
     stream = torch.cuda.Stream(device=dev)
+    stream_b = torch.cuda.Stream(device=dev, priority=-1)     # the downwash-ahead launches (prefetch form): its own hardware queue
     torch.cuda.set_stream(stream)
     u0 = torch.empty(B, 4, dtype=torch.float64, device=dev)
     # ---- neighbour exchange (vehicle-major placement: a leader's neighbour lives on the next rank).  The reference publishes a
@@ -207,7 +217,11 @@ def main():
     #          peer-mapped slot, epoch word, wait for the neighbour's epoch; the control-step kernel then reads the neighbour's
     #          slot out of the neighbour GPU's HBM over xGMI.  No collective, no host round trip, hipGraph-replayed like N = 1.
     need_exchange = downwash and args.placement == "vehicle" and (world > 1 or cfg4)
-    if not need_exchange:
+    two_forms = (not need_exchange and downwash and world == 1 and not cfg4 and N + 1 <= 32 and args.qp_mode == 0
+                 and not eng.work_queue)
+    if two_forms:
+        modes = {"both": ["fused", "prefetch"], "prefetch": ["prefetch"], "fused": ["fused"]}[args.downwash_form]
+    elif not need_exchange:
         modes = ["none"]
     elif same_dev and world > 1:
         modes = ["peer"]                          # RCCL refuses two ranks on one device
@@ -227,7 +241,9 @@ def main():
     if "rccl" in modes:
         gathered = [torch.empty(world * B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev) for _ in range(2)]
         pv_local = torch.empty(B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev)
-    mode_names = {"none": "none", "rccl": "rccl all-gather per step" + ("" if world > 1 else " (one rank: the pack only, no RCCL call)"),
+    mode_names = {"prefetch": "none (one GPU); downwash of tick t+1 on a second stream beside the control step of tick t",
+                  "fused": "none (one GPU); gate + MLP fused into the control-step launch",
+                  "none": "none", "rccl": "rccl all-gather per step" + ("" if world > 1 else " (one rank: the pack only, no RCCL call)"),
                   "peer": "peer windows over xGMI: one publish launch per step (epoch-ordered), read by the control-step kernel"}
 
     def host_other(h):
@@ -248,9 +264,21 @@ def main():
             if exchange:
                 pending[i] = ndist.exchange_pv_begin(ticks[i % T]["xr"], pv_local, gathered[i % 2])   # one RCCL all-gather over xGMI
 
-        def step(i):
+        def step(i, first=True, last=True):
+            """One control tick.  first / last: position in a chain of consecutive ticks (prefetch form: the chain's first tick
+            predicts its own force before it starts, every tick but the last predicts the next one's beside its control step)."""
             d = ticks[i % T]
             other, oidx = None, None
+            if mode == "prefetch":
+                if first:
+                    eng.downwash_prefetch_device(d["other"], d["xr"], ego_xy=d["ego_xy"], after_stream=stream)
+                if not last:
+                    n = ticks[(i + 1) % T]
+                    eng.downwash_prefetch_device(n["other"], n["xr"], ego_xy=n["ego_xy"])
+                eng.update_device_prefetched(d["x0"], d["xr"], d["ur"], u0, stream=stream)
+                if last:
+                    eng.prefetch_join(stream)
+                return
             if downwash:
                 if exchange:
                     if i not in pending:
@@ -324,6 +352,12 @@ def main():
         # captures gather + kernel as well.  peer form: publish + control-step launches are captured like the N = 1 steps (the
         # slot parity is baked into a launch, so every graph holds an even number of ticks; an odd remainder is host-launched).
         graphs, tail, launch_mode = [], 0, "host launch per step"
+
+        def replay(gt):
+            if gt[2] is not None:
+                with torch.cuda.stream(stream_b):
+                    gt[2].replay()
+            gt[0].replay()
         want_graph = not args.no_graph and (not exchange or args.graph_exchange or world == 1)
         if want_graph:
             try:
@@ -339,16 +373,36 @@ def main():
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=stream, capture_error_mode="relaxed"):
                         for i in range(n_cap):
-                            step(first + i)
+                            if mode == "prefetch":                # the control steps only; the downwash launches: graph gb below
+                                d = ticks[(first + i) % T]
+                                eng.update_device_prefetched(d["x0"], d["xr"], d["ur"], u0, stream=stream)
+                            else:
+                                step(first + i, first=i == 0, last=i == n_cap - 1)
                         for w in list(pending.values()):         # the last step's prefetch belongs to the captured cycle
                             ndist.exchange_pv_end(w)
                         pending.clear()
                     torch.cuda.set_stream(stream)
+                    gb = None
+                    if mode == "prefetch":
+                        # The downwash launches of the same ticks as a SECOND graph on a second stream (another priority level =
+                        # its own hardware queue): the two chains order themselves through the device-side tick words, so the two
+                        # graphs are replayed side by side.  (Parallel branches inside ONE hipGraph execute one after the other on
+                        # ROCm 7.2: 37 us per tick against 19 us this way.)
+                        gb = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gb, stream=stream_b, capture_error_mode="relaxed"):
+                            for i in range(n_cap):
+                                d = ticks[(first + i) % T]
+                                eng.downwash_prefetch_device(d["other"], d["xr"], ego_xy=d["ego_xy"], on_stream=stream_b)
+                        torch.cuda.set_stream(stream)
+                        with torch.cuda.stream(stream_b):
+                            gb.replay()
                     g.replay()                                    # instantiate / upload outside the timed region
                     torch.cuda.synchronize()
-                    graphs.append((g, n_rep))
+                    graphs.append((g, n_rep, gb))
                     first += n_cap * n_rep
                 launch_mode = " + ".join(f"hipGraph of {n} steps x {r}" for n, r in plan) + (f" + {tail} host-launched" if tail else "")
+                if mode == "prefetch":
+                    launch_mode += " (control steps) beside a hipGraph of the same ticks' downwash launches on a second stream"
             except Exception as e:                                # capture unsupported: fall back, say so
                 graphs, tail, launch_mode = [], 0, f"host launch per step (graph capture failed: {type(e).__name__}: {e})"[:300]
                 pending.clear()
@@ -360,7 +414,7 @@ def main():
             if graphs and args.clock_warm_ms > 0:                 # untimed: bring the clocks up (see --clock-warm-ms)
                 tw = time.perf_counter()
                 while (time.perf_counter() - tw) * 1e3 < args.clock_warm_ms:
-                    graphs[0][0].replay()
+                    replay(graphs[0])
                     extra += plan[0][0]
                     torch.cuda.synchronize()
                 fence()
@@ -373,15 +427,15 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if graphs:
-            for g, n_rep in graphs:
-                for _ in range(n_rep):
-                    g.replay()
+            for gt in graphs:
+                for _ in range(gt[1]):
+                    replay(gt)
             for i in range(tail):
-                step(args.steps - tail + i)
+                step(args.steps - tail + i, first=i == 0, last=i == tail - 1)
         else:
             eng.timing_enable(8)  # HIP events around every 8th launch (an event pair per launch costs a dispatch gap)
             for i in range(args.steps):
-                step(args.warmup + i)
+                step(args.warmup + i, first=i == 0, last=i == args.steps - 1)
         fence()
         elapsed = time.perf_counter() - t0
         if mode == "peer":
@@ -389,7 +443,7 @@ def main():
         if graphs:                # the dominant kernel's duration (roofline): HIP events around host-launched steps, outside the timed region
             eng.timing_enable(1)
             for i in range(64):
-                step(i)
+                step(i, first=i == 0, last=i == 63)
             fence()
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -406,6 +460,8 @@ def main():
             bad = int(agg.item())
         res = {"extra_warm": extra, "elapsed": elapsed, "launch": launch_mode, "parity": parity, "bad": bad, "rti_ms": rti_ms, "rti_n": rti_n,
                "mlp_ms": mlp_ms, "mlp_n": mlp_n, "it": it, "step": step, "name": mode_names[mode]}
+        if mode == "prefetch":
+            res["prefetch_stats"] = eng.prefetch_stats()
         if mode == "peer":
             ps = peer.stats()
             if world > 1:                                         # any rank's timed-out wait shows in the line
@@ -415,14 +471,23 @@ def main():
             res["peer_stats"] = ps
         return res
 
-    results = {}
+    results, form_errors = {}, {}
     for m in modes:
-        results[m] = run_mode(m, check_parity=not args.only_timed)
+        if m == "prefetch" and modes[0] != "prefetch":        # the second form: measured beside the headline, never fatal to it
+            try:
+                results[m] = run_mode(m, check_parity=not args.only_timed)
+            except Exception as e:
+                form_errors[m] = f"{type(e).__name__}: {e}"[:300]
+                torch.cuda.set_stream(stream)
+        else:
+            results[m] = run_mode(m, check_parity=not args.only_timed)
     head = results[modes[0]]                      # the north star's collective when it ran, else the only form
     elapsed, launch_mode, parity, bad, it = head["elapsed"], head["launch"], head["parity"], head["bad"], head["it"]
     rti_ms, rti_n, mlp_ms, mlp_n, step = head["rti_ms"], head["rti_n"], head["mlp_ms"], head["mlp_n"], head["step"]
     exchange_mode = head["name"]
-    for r in results.values():                    # a parity failure or a non-converged instance in ANY form fails the run
+    for m_, r in results.items():                 # a parity failure or a non-converged instance in ANY exchange form fails the run
+        if m_ == "prefetch" and modes[0] != "prefetch":
+            continue                              # (the second downwash form reports its own figures under downwash_forms)
         if r["parity"] is not None and (parity is None or r["parity"] > parity):
             parity = r["parity"]
         bad = max(bad, r["bad"])
@@ -456,10 +521,11 @@ def main():
         f_qp, f_mlp = algorithmic_flops_per_solve(N, sweeps, downwash)
         rti_s = rti_ms * 1e-3 / max(rti_n, 1)
         mlp_s = mlp_ms * 1e-3 / max(mlp_n, 1) if mlp_n else 0.0
-        fused = downwash and mlp_n == 0          # gate + MLP run inside rti_kernel (one launch per step)
+        prefetch_form = modes[0] == "prefetch"
+        fused = downwash and mlp_n == 0 and not prefetch_form   # gate + MLP run inside rti_kernel (one launch per step)
         ach_tf = f_qp * B / rti_s / 1e12
         abytes = algorithmic_bytes_per_solve(N, downwash)
-        is_default = (not cfg4 and fused and B == 1024 and N == 20 and args.qp_mode == 0 and args.perturb == "nominal" and world == 1)
+        is_default = (not cfg4 and (fused or prefetch_form) and B == 1024 and N == 20 and args.qp_mode == 0 and args.perturb == "nominal" and world == 1)
         prof = committed_profile(is_default)
         # the committed profile annotates this run only if it describes it: its kernel duration must agree with the duration
         # measured live (HIP events) -- otherwise every figure derived from it is withheld and the mismatch is reported
@@ -502,7 +568,9 @@ def main():
             "config": {"workload": (f"BASELINE config 4: {args.formations} three-vehicle formations = {3 * args.formations} instances over {world} GPU(s) "
                                     f"({B}/GPU; vehicle 0 = NDP controller reading vehicle 1, vehicles 1-2 = NMPC followers), N={N}, 1 RTI iter, "
                                     if cfg4 else f"batch={B}/GPU independent quadrotors, N={N}, 1 RTI iter, ")
-                                   + ("MLP downwash on (NDP controller, gate+MLP fused into the RTI launch)" if fused else
+                                   + ("MLP downwash on (NDP controller; the force of tick t+1 predicted by a second launch on a second stream "
+                                      "while tick t is solved, consumed late by the control step)" if prefetch_form else
+                                      "MLP downwash on (NDP controller, gate+MLP fused into the RTI launch)" if fused else
                                       "MLP downwash on (NDP controller)" if downwash else "no downwash (NMPC controller)")
                                    + (", neighbour windows all-gathered over RCCL every step" if modes[0] == "rccl" and world > 1 else
                                       ", neighbour windows published every step into a peer-mapped slot and read over xGMI by the kernel" if modes[0] == "peer" else
@@ -528,6 +596,15 @@ def main():
                          "mlp_kernel_us": mlp_s * 1e6 if mlp_n else None},
             "parity_max_rel_vs_oracle": parity, "instances_not_converged": bad,
         }
+        if two_forms:
+            out["downwash_forms"] = {m: {"value": total / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3, "launch": r["launch"],
+                                         "kernel_us_rti": r["rti_ms"] * 1e3 / max(r["rti_n"], 1),
+                                         "parity_max_rel_vs_oracle": r["parity"], "instances_not_converged": r["bad"],
+                                         **({"prefetch_stats": r["prefetch_stats"]} if "prefetch_stats" in r else {})}
+                                     for m, r in results.items()}
+            for m, e in form_errors.items():
+                out["downwash_forms"][m] = {"error": e}
+            out["downwash_forms"]["headline"] = modes[0]
         if need_exchange:
             # both forms of the per-step neighbour exchange, same steps, same inputs (value = whole-job solves/s)
             out["exchange"] = {m: {"value": total / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3, "launch": r["launch"],
@@ -682,6 +759,9 @@ def main():
             out["config1_single_vehicle"] = lat
         ps = results["peer"].get("peer_stats") if "peer" in results else None
         peer_bad = bool(ps and (ps["ack_timeouts"] or ps["epoch_timeouts"] or ps["slot_mismatches"]))
+        pf = results["prefetch"].get("prefetch_stats") if "prefetch" in results else None
+        if pf and (pf["force_timeouts"] or pf["slot_timeouts"]) and modes[0] == "prefetch":
+            peer_bad, ps = True, pf
         fail = (parity is not None and not parity <= 1e-5) or bad > 0 or peer_bad
         if fail:
             out["error"] = (f"parity_max_rel_vs_oracle {parity} (bar 1e-5), instances_not_converged {bad}"

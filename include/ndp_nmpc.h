@@ -148,6 +148,38 @@ int ndp_step_device_ex(ndp_handle *h, const void *d_x0, const void *d_xr, const 
                        const void *d_other, int other_stride, const void *d_other_index, const void *d_ego_xy,
                        void *d_u0, void *stream);
 
+/* The downwash one tick ahead, beside the control step.  In the reference the network does not run inside the control loop: a
+ * subscriber callback predicts the force when a neighbour message arrives (ndp_nmpc_leader_node.py:60-76) and the next control tick
+ * uses the latest one (nmpc_node.py:202-209).  The same split on the device, as two launches that overlap:
+ *   ndp_downwash_prefetch_device : gate + MLP for the NEXT control step on the handle's second stream (LDS-free kernel, resident
+ *                                  beside the control-step kernel); d_other / other_stride / d_other_index / d_ego_xy as in
+ *                                  ndp_step_device_ex, d_ego_ref = that tick's xr.  after_stream: a stream whose work so far (the
+ *                                  producer of those windows) it must follow, or NULL; inside a stream capture pass the
+ *                                  capturing stream on the first call (fork), NULL afterwards, and ndp_prefetch_join at the end.
+ *                                  on_stream: NULL = the handle's second stream, or a stream of the caller's to launch on
+ *                                  instead (it must not share a hardware queue with the control steps' stream: create it at
+ *                                  another priority).  The two chains of launches order themselves through device-side tick
+ *                                  words, so they may also be captured into two SEPARATE graphs and replayed side by side --
+ *                                  measured on ROCm 7.2: parallel branches inside ONE hipGraph run one after the other.
+ *   ndp_step_device_prefetched   : the control step that consumes the oldest unconsumed prediction: linearises without the
+ *                                  force, takes it when it is there (normally long before) and corrects the dynamics defects --
+ *                                  the force enters them additively.  One prediction per step, in order; at most two
+ *                                  predictions may be ahead (two force slots).  A prediction that does not arrive within 100 ms
+ *                                  (no matching prefetch call) = zero force, per-instance status 5, counted.
+ *   ndp_prefetch_join            : makes `stream` wait for the second stream's work so far (end of a capture, or before reading
+ *                                  the slots).
+ *   ndp_prefetch_stats           : synchronises; out5 = {predictions completed, steps that took theirs, control-step waves whose
+ *                                  wait timed out, downwash launches whose wait for a free slot timed out, control-step waves
+ *                                  that started before their prediction was complete (they wait for it and read it past the L2)}.
+ *   ndp_device_force_slot        : the two force slots, [B][N+1][3] fp32 (prediction m is in slot m & 1).
+ * Not combined with the interior-point work list (cfg.work_queue = 2) and fp64 only. */
+int ndp_downwash_prefetch_device(ndp_handle *h, const void *d_other, int other_stride, const void *d_other_index,
+                                 const void *d_ego_ref, const void *d_ego_xy, void *after_stream, void *on_stream);
+int ndp_step_device_prefetched(ndp_handle *h, const void *d_x0, const void *d_xr, const void *d_ur, void *d_u0, void *stream);
+int ndp_prefetch_join(ndp_handle *h, void *stream);
+int ndp_prefetch_stats(ndp_handle *h, unsigned long long *out5);
+void *ndp_device_force_slot(ndp_handle *h, int slot);
+
 /* Replaces DownwashNN.update(other_pred_x, ego_pred_x) (downwash_nn.py:21-29), batched, with the
  * optional r_horiz gate.  f_out: [B][N+1][3] fp32. */
 int ndp_downwash(ndp_handle *h, const double *other, const double *ego_ref, const double *ego_xy, float *f_out);
@@ -294,6 +326,10 @@ int ndp_debug_mfma_probe_f32(const float *a, const float *b, const float *c, flo
 /* Profiling hook: enable = 1 makes every instance of the following steps write 16 phase stamps (shader clock);
  * out (or NULL) receives the [B][16] stamps of the last step before the switch is applied. */
 int ndp_debug_stamps(ndp_handle *h, int enable, double *out);
+/* Measurement hook: ndp_downwash_device through the LDS-free form of the downwash kernel (weights streamed from L2, at most 192
+ * registers per lane: it can be resident on a CU beside the control-step kernel). */
+int ndp_debug_downwash_stream_device(ndp_handle *h, const void *d_other, const void *d_ego_ref, const void *d_ego_xy,
+                                     void *d_f_out, void *stream);
 /* Profiling hook: where the last host-array step spent its time on the CPU, microseconds: out4 = {packing the inputs into the
  * page-locked mirror, enqueueing (launches / copies), waiting for the results, copying them out}. */
 int ndp_debug_host_timing(ndp_handle *h, double *out4);

@@ -43,7 +43,8 @@ EXPORTS = [
     "ndp_step_ex", "ndp_step_device_ex", "ndp_work_queue_enabled", "ndp_ref_list_reset", "ndp_ref_list_fix_pt",
     "ndp_ref_list_window", "ndp_ref_list_advance_device", "ndp_ref_list_window_device", "ndp_debug_mfma_probe_f32",
     "ndp_peer_alloc", "ndp_peer_open", "ndp_peer_close", "ndp_peer_free", "ndp_step_begin", "ndp_step_end",
-    "ndp_peer_layout", "ndp_peer_publish_device", "ndp_peer_stats", "ndp_debug_host_timing",
+    "ndp_peer_layout", "ndp_peer_publish_device", "ndp_peer_stats", "ndp_debug_host_timing", "ndp_debug_downwash_stream_device",
+    "ndp_downwash_prefetch_device", "ndp_step_device_prefetched", "ndp_prefetch_join", "ndp_prefetch_stats", "ndp_device_force_slot",
 ]
 
 _lib = None
@@ -80,6 +81,13 @@ def load():
     lib.ndp_step_begin.argtypes = [vp] * 7 + [C.c_int]
     lib.ndp_step_end.argtypes = [vp] * 6
     lib.ndp_debug_host_timing.argtypes = [vp, vp]
+    lib.ndp_debug_downwash_stream_device.argtypes = [vp] * 6
+    lib.ndp_downwash_prefetch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.ndp_step_device_prefetched.argtypes = [vp] * 6
+    lib.ndp_prefetch_join.argtypes = [vp, vp]
+    lib.ndp_prefetch_stats.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    lib.ndp_device_force_slot.argtypes = [vp, C.c_int]
+    lib.ndp_device_force_slot.restype = vp
     lib.ndp_step_device_ex.argtypes = [vp] * 6 + [C.c_int] + [vp] * 4
     lib.ndp_work_queue_enabled.argtypes = [vp]
     lib.ndp_ref_list_reset.argtypes = [vp]

@@ -321,6 +321,51 @@ class BatchedNMPC:
             optr, stride, self._dptr(other_index, torch.int32, (B,)), self._dptr(ego_xy, torch.float64, (B, 2)),
             self._dptr(u0_out, torch.float64, (B, 4)), self._stream(stream)), "ndp_step_device")
 
+    # ------------------------------------------------------------------ downwash one tick ahead (second stream)
+    def downwash_prefetch_device(self, other, ego_ref, ego_xy=None, other_index=None, after_stream=None, on_stream=None):
+        """Enqueues gate + MLP for the NEXT control step on the engine's second stream (ndp_downwash_prefetch_device): it runs
+        beside the control-step kernel of the current tick.  other / other_index as in update_device; ego_ref = that tick's xr."""
+        import torch
+        B, N = self.B, self.N
+        if hasattr(other, "dev_ptr"):
+            stride, optr = int(other.shape[2]), C.c_void_p(int(other.dev_ptr))
+        else:
+            if not (other.is_cuda and other.is_contiguous() and other.dtype == torch.float64 and other.dim() == 3
+                    and other.shape[1] == N + 1 and other.shape[2] in (6, 10) and (other_index is not None or other.shape[0] == B)):
+                raise ValueError("other: expected a contiguous CUDA float64 [rows, N+1, 6 or 10] tensor")
+            stride, optr = int(other.shape[2]), C.c_void_p(other.data_ptr())
+        self._check(self._lib.ndp_downwash_prefetch_device(
+            self._h, optr, stride, self._dptr(other_index, torch.int32, (B,)), self._dptr(ego_ref, torch.float64, (B, N + 1, 10)),
+            self._dptr(ego_xy, torch.float64, (B, 2)), self._stream(after_stream), self._stream(on_stream)),
+            "ndp_downwash_prefetch_device")
+
+    def update_device_prefetched(self, x0, xr, ur, u0_out, stream=None):
+        """The control step that consumes the oldest prediction of downwash_prefetch_device (ndp_step_device_prefetched)."""
+        import torch
+        B, N = self.B, self.N
+        self._check(self._lib.ndp_step_device_prefetched(
+            self._h, self._dptr(x0, torch.float64, (B, 10)), self._dptr(xr, torch.float64, (B, N + 1, 10)),
+            self._dptr(ur, torch.float64, (B, N, 4)), self._dptr(u0_out, torch.float64, (B, 4)), self._stream(stream)),
+            "ndp_step_device_prefetched")
+
+    def prefetch_join(self, stream=None):
+        self._check(self._lib.ndp_prefetch_join(self._h, self._stream(stream)), "ndp_prefetch_join")
+
+    def prefetch_stats(self):
+        out = (C.c_ulonglong * 5)()
+        self._check(self._lib.ndp_prefetch_stats(self._h, out), "ndp_prefetch_stats")
+        return dict(predictions=int(out[0]), steps=int(out[1]), force_timeouts=int(out[2]), slot_timeouts=int(out[3]),
+                    late_waves=int(out[4]))
+
+    def force_slot(self, slot):
+        """The force of prediction m (slot m & 1) as a CUDA tensor view [B, N+1, 3] float32 (valid after prefetch_join / stats)."""
+        import torch
+        from .dist import _DevMem
+        ptr = self._lib.ndp_device_force_slot(self._h, int(slot))
+        if not ptr:
+            raise NdpError("no force slots: downwash_prefetch_device was never called")
+        return torch.as_tensor(_DevMem(ptr, (self.B, self.N + 1, 3), "<f4"), device=torch.device("cuda", self.cfg.device))
+
     @property
     def work_queue(self):
         """True when this engine's steps send interior-point solves through the in-kernel work queue (cfg.work_queue)."""

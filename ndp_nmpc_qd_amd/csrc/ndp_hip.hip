@@ -111,12 +111,43 @@ __device__ __forceinline__ void bind_instance(RtiIo &io, const BatchPtrs &bp, in
     io.stamps = bp.stamps ? bp.stamps + (size_t)inst * 16 : nullptr;
 }
 
+// Downwash predicted one tick ahead by mlp_stream_kernel on a second stream (ndp_downwash_prefetch_device), consumed by the
+// control-step launch of the tick (ndp_step_device_prefetched).  Two chains of launches that order themselves on the device:
+//   second stream : prefetch_gate_kernel (one wave: number m = previous + 1; waits until control step m - 2, the last reader of
+//                   force slot m & 1, holds its values; publishes m in PF_CUR_M) -> mlp_stream_kernel (reads m with a plain load --
+//                   it was written by the launch before it in its own stream; every wave writes its 32 rows of slot m & 1 with
+//                   write-through stores and then its tile's epoch word := m)
+//   main stream   : control step t = (completed control-step groups) / groups + 1 (plain load: only control steps, in this
+//                   stream, advance it); waits late (after its cost phase) for the one or two tile epochs that cover its rows
+//                   to reach t, loads its forces past the L2, and counts itself done-reading (WaveGfx950::late_count):
+//                   PF_RTI_C1 + g  workgroups counted into group g = workgroup index mod groups, PF_RTI_C2 groups completed --
+//                   launch t has read its slot completely at t * groups.
+// The usual case costs the control step nothing at agent scope: prefetch_done_kernel, behind every downwash launch in its stream,
+// publishes PF_MLP_DONE = m; a control step that finds PF_MLP_DONE >= t when it STARTS (plain load, fresh after the launch
+// boundary) knows its slot was in memory before it began and reads it with ordinary cached loads.  Only a control step that
+// started before its prediction was complete takes the epoch path.
+// No word is shared by many waves at agent scope: the eight XCDs' L2s are not coherent with each other, agent-scope loads and
+// atomics are served at the memory side and serialise per address (30-60 ns each: 1024 waves on one flag word cost 7 us per wave,
+// one counting atomic per wave 18 us per launch).  Every word has its own 4 KB (PF_STRIDE words: its own memory channel).
+// Nothing is baked into a launch, so captured launches replay correctly.  PF_MISSED: control-step waves whose wait timed out
+// (zero force, status 5); PF_GATE_TIMEOUT: gate waits that timed out.
+enum { PF_GROUPS = 8, PF_STRIDE = 512, PF_CUR_M = 0, PF_RTI_C1 = 1 * PF_STRIDE, PF_RTI_C2 = 9 * PF_STRIDE,
+       PF_MISSED = 10 * PF_STRIDE, PF_GATE_TIMEOUT = 11 * PF_STRIDE, PF_MLP_DONE = 12 * PF_STRIDE, PF_SLOW = 13 * PF_STRIDE, PF_EPOCH = 14 * PF_STRIDE /* [2][ntiles] */ };
+struct LateArgs {
+    unsigned long long *proto;     // null = not a prefetched-force launch
+    const float *F[2];             // the two force slots, [B][N+1][3] each
+    unsigned timeout_us;
+    unsigned groups_rti, ntiles;
+};
+__device__ __host__ inline unsigned pf_group_size(unsigned n, unsigned groups, unsigned g) { return n / groups + (g < n % groups ? 1u : 0u); }
+
 struct KernArgs {
     RtiParams P;
     BatchPtrs bp;
     int B, lds_per_wave;
     MlpArgs ma;
     QueueArgs qa;
+    LateArgs la;
 };
 
 // FUSED: the wave first predicts its own instance's disturbance force (gate + MLP over the N+1 <= 32 horizon rows,
@@ -137,6 +168,11 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     const QueueArgs &qa = ka.qa;
     const int B = ka.B;
     const int wave = (int)(threadIdx.x >> 6);
+    __shared__ unsigned wg_done;     // prefetched-force launches: the workgroup's waves that hold their force values (see LateArgs)
+    if (!FUSED && QMODE == 0 && ka.la.proto) {
+        if (threadIdx.x == 0) wg_done = 0;
+        __syncthreads();             // (before any wave of a ragged last workgroup leaves)
+    }
     int inst_raw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave);
     if (QMODE == 2) {         // list entry -> instance; past the end of the list: nothing to do
         __shared__ int n_list;
@@ -160,6 +196,28 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     const size_t nf = (size_t)(N + 1) * 3;
     RtiIo io;
     bind_instance(io, bp, inst, N);
+    if (!FUSED && QMODE == 0 && ka.la.proto) {
+        // this launch is control step number t; its force was written into slot t & 1 by downwash launch t
+        const LateArgs &la = ka.la;
+        const unsigned long long t = la.proto[PF_RTI_C2] / la.groups_rti + 1;       // (plain load: see LateArgs)
+        const unsigned g = blockIdx.x % la.groups_rti;
+        const unsigned np1 = (unsigned)N + 1, row0 = (unsigned)inst * np1;
+        io.f_late = la.F[t & 1] + (size_t)inst * nf;
+        io.late_flag = la.proto + PF_EPOCH + (t & 1) * la.ntiles + row0 / 32;
+        io.late_flag2 = la.proto + PF_EPOCH + (t & 1) * la.ntiles + (row0 + np1 - 1) / 32;
+        io.late_want = t;
+        io.late_ready = la.proto[PF_MLP_DONE] >= t ? 1 : 0;                         // (plain load)
+        io.late_timeout_us = la.timeout_us;
+        io.late_missed = reinterpret_cast<int *>(la.proto + PF_MISSED);
+        io.late_slow = reinterpret_cast<int *>(la.proto + PF_SLOW);
+        io.late_cnt = reinterpret_cast<unsigned *>(la.proto + PF_RTI_C1 + PF_STRIDE * g);
+        io.late_done_word = la.proto + PF_RTI_C2;
+        io.late_gsize = pf_group_size(gridDim.x, la.groups_rti, g);
+        // (LDS offset + 1: the word may well sit at offset 0, and null means "no workgroup-level counter")
+        io.late_group = (void *)((size_t)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)&wg_done + 1);
+        const int left = B - (int)blockIdx.x * WAVES;
+        io.late_group_size = (unsigned)(left < WAVES ? left : WAVES);
+    }
     const int lpw = NC ? ((lds_doubles(NC) + 1) & ~1) : ka.lds_per_wave;
     WaveGfx950::lds_ptr lds = (WaveGfx950::lds_ptr)(smem + (size_t)wave * lpw);
     // PREC 0: the product path (f64 matrix instruction); 1 / 2: operand-rounding studies on it; 3 / 4: the sweeps on the real
@@ -525,6 +583,160 @@ __global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, 
 #pragma unroll
         for (int c = 0; c < 3; ++c) fout[(size_t)row * 3 + c] = open ? o[c] : 0.0f;   // :75-76 zeros when gated off
     }
+}
+
+// ---- LDS-free form of the tile (measurement: downwash of the NEXT tick in a second stream beside the control-step kernel, which
+// holds all of a CU's LDS and 320 of its 512 registers per lane).  The weight records come straight from global memory (L2),
+// NPRE records requested ahead; biases, first- and last-layer weights likewise.  Same arithmetic, same fragment blob.
+typedef const float *__restrict__ g_cf32;
+__device__ __forceinline__ void load_w_g(g_cf32 fr, int rec, int lane, Split2 &w)
+{
+    const h16x8 *p = reinterpret_cast<const h16x8 *>(fr + FR_HF) + rec * 128 + lane;
+    w.hi = p[0]; w.lo = p[64];
+}
+
+__device__ __forceinline__ void mlp_tile_stream(g_cf32 fr, const float zb[3], int lane, float o[3])
+{
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    constexpr int NPRE = 2;
+    const int h = lane >> 5;
+    Split2 wq[NPRE];
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) load_w_g(fr, i, lane, wq[i]);        // in flight under layer 1
+    Split2 x1[4][2], x2[2][2];
+    const f4_t *w4 = reinterpret_cast<const f4_t *>(fr + FR_W4);
+    o[0] = o[1] = o[2] = 0.0f;
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) {
+        f16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = fr[FR_B1 + ot * 32 + f0(r) + 4 * h];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[FR_L1 + (ot * 3 + s) * 64 + lane], zb[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = relu_cap(acc[r]);
+        split2(acc, 0, x1[ot][0]);
+        split2(acc, 1, x1[ot][1]);
+        __builtin_amdgcn_sched_barrier(0);     // keep the phases apart: left alone the scheduler hoists every later load up front (254 registers)
+    }
+    f16_t acc, accl;
+#pragma unroll
+    for (int rec = 0; rec < 32; ++rec) {
+        const bool l2 = rec < 16;
+        const int q = l2 ? rec : rec - 16;
+        const int ot = l2 ? q / 8 : q / 4, it = l2 ? (q / 2) % 4 : (q / 2) % 2, s = q % 2;
+        const bool first = l2 ? (q % 8 == 0) : (q % 4 == 0), last = l2 ? (q % 8 == 7) : (q % 4 == 3);
+        const Split2 wc = wq[rec % NPRE];
+        if (rec + NPRE < 32) load_w_g(fr, rec + NPRE, lane, wq[rec % NPRE]);
+        if (first) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[r] = fr[(l2 ? FR_B2 : FR_B3) + ot * 32 + f0(r) + 4 * h];
+                accl[r] = 0.0f;
+            }
+        }
+        mm3(wc, l2 ? x1[it][s] : x2[it][s], acc, accl);
+        if (last) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = fmaf(accl[r], NDP_LO_INV, acc[r]);
+                acc[r] = l2 ? relu_cap(v) : fmaxf(v, 0.0f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (l2) { split2(acc, 0, x2[ot][0]); split2(acc, 1, x2[ot][1]); }
+            else {      // last layer (128 -> 3) on this output tile at once: its 32 hidden features need not stay live
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f4_t qv = w4[ot * 32 + f0(r) + 4 * h];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) o[c] = fmaf(qv[c], acc[r], o[c]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = o[c] + __shfl_xor(o[c], 32, 64) + fr[FR_B4 + c];
+}
+
+// one wave = one 32-row tile, four per workgroup, no LDS and no barrier, ~180 registers per lane (control step: 320 -- the two fit on
+// a SIMD together; ensure_prefetch checks it).  proto != null: launch m of the prefetch protocol (see LateArgs).
+__global__ __launch_bounds__(256)
+void mlp_stream_kernel(const float *__restrict__ fr, const double *__restrict__ other, const double *__restrict__ ego,
+                       const double *__restrict__ ego_xy, float *__restrict__ fout, float *__restrict__ fout1, int rows, int np1, double r2,
+                       int other_stride, const int *__restrict__ other_index, unsigned long long *proto)
+{
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int ntiles = (rows + 31) / 32;
+    const int tile = (int)blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    unsigned long long m = 0;
+    if (proto) {
+        m = proto[PF_CUR_M];                        // written by the gate launch in front of this one (plain load)
+        if (m & 1) fout = fout1;
+    }
+    const int row = tile * 32 + j;
+    const bool valid = row < rows;
+    const int rowc = valid ? row : rows - 1;
+    const int inst = rowc / np1, k = rowc - inst * np1;
+    const int orow = other_index ? other_index[inst] : inst;
+    const double *oth = other + (size_t)(orow < 0 ? 0 : orow) * np1 * other_stride;
+    bool open = valid && orow >= 0;
+    if (ego_xy) open = open && gate_open(oth, ego_xy + inst * 2, r2);
+    float zb[3], o[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+        zb[s] = (float)(oth[(size_t)k * other_stride + 2 * s + h] - ego[(size_t)rowc * NX + 2 * s + h]);
+    mlp_tile_stream(fr, zb, lane, o);
+    if (!proto) {
+        if (valid && h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fout[(size_t)row * 3 + c] = open ? o[c] : 0.0f;
+        }
+        return;
+    }
+    // the rows go out past this XCD's L2 (agent-scope stores: the reader runs on other XCDs, now), then -- once they are complete --
+    // the tile's epoch word
+    if (valid && h == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            __hip_atomic_store(reinterpret_cast<unsigned *>(fout) + (size_t)row * 3 + c, __float_as_uint(open ? o[c] : 0.0f),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (the rows were written THROUGH to memory: what is needed is their completion -- s_waitcnt, which a workgroup-scope release
+    // is -- not an agent-scope release, whose buffer_wbl2 writes back the XCD's whole L2, the control step's dirty iterate
+    // included: one per wave, 672 per launch, made the control step beside it 50 % slower)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0)
+        __hip_atomic_store(proto + PF_EPOCH + (m & 1) * (unsigned)ntiles + tile, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave, in front of downwash launch m on the second stream: takes the number, waits until the control step that read force
+// slot m & 1 last (number m - 2) holds its values, publishes the number for the launch behind it.  A single wave polling gently
+// costs nothing (waves of the downwash kernel polling on every CU kept registers the next control-step workgroups needed).
+__global__ void prefetch_gate_kernel(unsigned long long *proto, unsigned timeout_us, unsigned groups_rti)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long m = proto[PF_CUR_M] + 1;
+    if (m > 2) {
+        const unsigned long long want = (m - 2) * groups_rti;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(proto + PF_RTI_C2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(16);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 100ull * timeout_us) {
+                atomicAdd(reinterpret_cast<int *>(proto + PF_GATE_TIMEOUT), 1);
+                break;
+            }
+        }
+    }
+    proto[PF_CUR_M] = m;
+}
+
+// behind downwash launch m in its stream: that launch is complete
+__global__ void prefetch_done_kernel(unsigned long long *proto)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(proto + PF_MLP_DONE, proto[PF_CUR_M], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // host: blob (W1 b1 W2 b2 W3 b3 W4 b4, row-major [out][in]) -> fragment order
@@ -1144,6 +1356,12 @@ struct ndp_handle {
     int list_head = 0, list_step = 5;
     double *dRelay = nullptr;  // follower relay: [B][4] = filtered offset xyz + initialised flag
     double *sThr = nullptr;    // staging of the f1-f4 host entry points: 11 B doubles
+    // downwash one tick ahead on a second stream (LateArgs): force slots, protocol words, the stream, its fork / join events
+    float *dForceAB[2] = {nullptr, nullptr};
+    unsigned long long *dProto = nullptr;
+    hipStream_t aux = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    unsigned prefetch_timeout_us = 100000, pf_groups_rti = 1, pf_ntiles = 1;
     unsigned *dQctr = nullptr; // work list: entry count | B instance ids
     int *dQids = nullptr;
     bool have_mlp = false;
@@ -1345,8 +1563,11 @@ int ndp_destroy(ndp_handle *h)
     if (h->ev_pending) (void)hipEventSynchronize(h->evLast);
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->evLast) (void)hipEventDestroy(h->evLast);
+    if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
+    for (hipEvent_t e : {h->evFork, h->evJoin})
+        if (e) (void)hipEventDestroy(e);
     h->pool.reset();
-    void *ptrs[] = {h->dRefList, h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dForce, h->dFrag,
+    void *ptrs[] = {h->dForceAB[0], h->dForceAB[1], h->dProto, h->dRefList, h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dForce, h->dFrag,
                     h->dIn, h->dOut, h->sdbg, h->dQctr, h->dQids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1581,7 +1802,8 @@ struct StepOut {               // where a step's status / iteration counts go an
 };
 
 static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, const double *d_ur, const float *d_f,
-                      double *d_u0, double *d_dbg, hipStream_t s, const Neigh *nb = nullptr, const StepOut *so = nullptr)
+                      double *d_u0, double *d_dbg, hipStream_t s, const Neigh *nb = nullptr, const StepOut *so = nullptr,
+                      bool prefetched = false)
 {
     int *d_status = so && so->status ? so->status : h->dStatus, *d_iters = so && so->iters ? so->iters : h->dIters;
     h->lastStatus = d_status; h->lastIters = d_iters;
@@ -1592,7 +1814,9 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
                h->cfg.r_horiz * h->cfg.r_horiz, fused ? nb->stride : NX, fused ? nb->index : nullptr};
     QueueArgs qa{h->dQctr, h->dQids};
     const int B = h->cfg.batch, W = h->waves;
-    KernArgs ka{h->P, bp, B, h->lds_per_wave, ma, qa};
+    LateArgs la{prefetched ? h->dProto : nullptr, {h->dForceAB[0], h->dForceAB[1]}, h->prefetch_timeout_us,
+                h->pf_groups_rti, h->pf_ntiles};
+    KernArgs ka{h->P, bp, B, h->lds_per_wave, ma, qa, la};
     const dim3 grid((B + W - 1) / W), block(64 * W);
     const size_t shm = (size_t)h->lds_per_wave * sizeof(double) * W;
     const int ns = slots_for(h->cfg.N);
@@ -1717,6 +1941,106 @@ int ndp_step_device(ndp_handle *h, const void *d_x0, const void *d_xr, const voi
 {
     return ndp_step_device_ex(h, d_x0, d_xr, d_ur, d_f, d_other, NX, nullptr, d_ego_xy, d_u0, stream);
 }
+
+// ---- downwash one tick ahead (second stream) + the control step that consumes it
+static int ensure_prefetch(ndp_handle *h)
+{
+    if (h->aux) return 0;
+    if (!h->cfg.use_fd) { h->err = "downwash prefetch needs use_fd = 1 (NDP model)"; return -8; }
+    if (h->use_queue) { h->err = "downwash prefetch is not combined with the interior-point work list (set cfg.work_queue = 2)"; return -16; }
+    if (h->cfg.qp_precision) { h->err = "downwash prefetch serves the fp64 product path only"; return -12; }
+    if (h->cfg.N + 1 > 32) { h->err = "downwash prefetch needs N + 1 <= 32 (an instance's rows in at most two 32-row tiles)"; return -12; }
+    if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }
+    for (int i = 0; i < 2; ++i) {
+        NDP_HIP(h, hipMalloc((void **)&h->dForceAB[i], nfs(h) * 4));
+        NDP_HIP(h, hipMemset(h->dForceAB[i], 0, nfs(h) * 4));
+    }
+    h->pf_ntiles = (unsigned)((h->cfg.batch * (h->cfg.N + 1) + 31) / 32);
+    const size_t proto_words = (size_t)PF_EPOCH + 2 * (size_t)h->pf_ntiles;
+    NDP_HIP(h, hipMalloc((void **)&h->dProto, proto_words * 8));
+    NDP_HIP(h, hipMemset(h->dProto, 0, proto_words * 8));
+    {
+        const unsigned grid_rti = (unsigned)((h->cfg.batch + h->waves - 1) / h->waves);
+        h->pf_groups_rti = grid_rti < PF_GROUPS ? grid_rti : PF_GROUPS;
+    }
+    // its own hardware queue: the downwash launch has to RUN beside the control step (a stream that shares the caller's hardware
+    // queue would execute behind it).  Streams of another priority level get queues of their own.
+    int lo = 0, hi = 0;
+    NDP_HIP(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    NDP_HIP(h, hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, hi));
+    NDP_HIP(h, hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
+    NDP_HIP(h, hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
+    return 0;
+}
+
+int ndp_downwash_prefetch_device(ndp_handle *h, const void *d_other, int other_stride, const void *d_other_index,
+                                 const void *d_ego_ref, const void *d_ego_xy, void *after_stream, void *on_stream)
+{
+    if (!h || !d_other || !d_ego_ref) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_prefetch(h);
+    if (rc) return rc;
+    if (other_stride != 10 && other_stride != 6) { h->err = "ndp_downwash_prefetch_device: other_stride must be 10 or 6"; return -13; }
+    hipStream_t a = on_stream ? (hipStream_t)on_stream : h->aux;
+    if (after_stream) {      // the windows are produced on that stream (and, inside a capture, this is what brings the second stream in)
+        NDP_HIP(h, hipEventRecord(h->evFork, (hipStream_t)after_stream));
+        NDP_HIP(h, hipStreamWaitEvent(a, h->evFork, 0));
+    }
+    const int np1 = h->cfg.N + 1, rows = h->cfg.batch * np1;
+    const int ntiles = (rows + 31) / 32;
+    hipLaunchKernelGGL(prefetch_gate_kernel, dim3(1), dim3(64), 0, a, h->dProto, h->prefetch_timeout_us, h->pf_groups_rti);
+    hipLaunchKernelGGL(mlp_stream_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, a, (const float *)h->dFrag, (const double *)d_other,
+                       (const double *)d_ego_ref, (const double *)d_ego_xy, h->dForceAB[0], h->dForceAB[1], rows, np1,
+                       h->cfg.r_horiz * h->cfg.r_horiz, other_stride, (const int *)d_other_index, h->dProto);
+    hipLaunchKernelGGL(prefetch_done_kernel, dim3(1), dim3(64), 0, a, h->dProto);
+    NDP_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int ndp_prefetch_join(ndp_handle *h, void *stream)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->aux) return 0;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    NDP_HIP(h, hipEventRecord(h->evJoin, h->aux));
+    NDP_HIP(h, hipStreamWaitEvent(stream ? (hipStream_t)stream : h->stream, h->evJoin, 0));
+    return 0;
+}
+
+int ndp_step_device_prefetched(ndp_handle *h, const void *d_x0, const void *d_xr, const void *d_ur, void *d_u0, void *stream)
+{
+    if (!h || !d_x0 || !d_xr || !d_ur || !d_u0) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_prefetch(h);
+    if (rc) return rc;
+    rc = launch_rti(h, (const double *)d_x0, (const double *)d_xr, (const double *)d_ur, nullptr, (double *)d_u0, nullptr, s,
+                    nullptr, nullptr, true);
+    return rc ? rc : note_stream(h, s);
+}
+
+int ndp_prefetch_stats(ndp_handle *h, unsigned long long *out4 /* [5] */)
+{
+    if (!h || !out4) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    out4[0] = out4[1] = out4[2] = out4[3] = out4[4] = 0;
+    if (!h->aux) return 0;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = wait_all(h);
+    if (rc) return rc;
+    NDP_HIP(h, hipStreamSynchronize(h->aux));
+    std::vector<unsigned long long> w(PF_EPOCH);
+    NDP_HIP(h, hipMemcpy(w.data(), h->dProto, (size_t)PF_EPOCH * 8, hipMemcpyDeviceToHost));
+    out4[0] = w[PF_CUR_M]; out4[1] = w[PF_RTI_C2] / h->pf_groups_rti;
+    out4[2] = (unsigned)(w[PF_MISSED] & 0xffffffffu); out4[3] = (unsigned)(w[PF_GATE_TIMEOUT] & 0xffffffffu);
+    out4[4] = (unsigned)(w[PF_SLOW] & 0xffffffffu);
+    return 0;
+}
+
+void *ndp_device_force_slot(ndp_handle *h, int slot) { return h && (slot == 0 || slot == 1) ? h->dForceAB[slot] : nullptr; }
 
 // ---- host-array step: ndp_step_begin (pack -> H2D -> kernel -> D2H, nothing waits) + ndp_step_end (wait, hand the results over)
 static int ensure_slots(ndp_handle *h)
@@ -1898,6 +2222,25 @@ int ndp_downwash_device(ndp_handle *h, const void *d_other, const void *d_ego_re
     nb.other = (const double *)d_other; nb.ego_xy = (const double *)d_ego_xy;
     int rc = launch_mlp(h, nb, (const double *)d_ego_ref, (float *)d_f_out, s);
     return rc ? rc : note_stream(h, s);
+}
+
+
+// measurement hook: the LDS-free downwash kernel (see mlp_stream_kernel) on a caller's stream
+int ndp_debug_downwash_stream_device(ndp_handle *h, const void *d_other, const void *d_ego_ref, const void *d_ego_xy,
+                                     void *d_f_out, void *stream)
+{
+    if (!h || !d_other || !d_ego_ref || !d_f_out) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }
+    const int np1 = h->cfg.N + 1, rows = h->cfg.batch * np1;
+    const int ntiles = (rows + 31) / 32;
+    hipLaunchKernelGGL(mlp_stream_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, s, (const float *)h->dFrag, (const double *)d_other,
+                       (const double *)d_ego_ref, (const double *)d_ego_xy, (float *)d_f_out, (float *)d_f_out, rows, np1,
+                       h->cfg.r_horiz * h->cfg.r_horiz, NX, (const int *)nullptr, (unsigned long long *)nullptr);
+    NDP_HIP(h, hipGetLastError());
+    return note_stream(h, s);
 }
 
 int ndp_downwash(ndp_handle *h, const double *other, const double *ego_ref, const double *ego_xy, float *f_out)

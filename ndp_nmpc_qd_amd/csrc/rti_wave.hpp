@@ -89,6 +89,23 @@ struct RtiIo {            // global-memory views of ONE instance
     double *stamps = nullptr;   // optional [16] per-instance phase stamps (whole-batch profiling), or null
     const int *tables = nullptr;   // [TB_WORDS] host-built index tables (fill_tables), read when RtiWave<..., HT = true>
     double *Xm = nullptr, *Um = nullptr;   // optional second destination of the new iterate (a page-locked host block the caller reads), or null
+    // Late force (downwash predicted by ANOTHER launch, one tick ahead, on a second stream): this instance's [(N+1)*3] floats, valid
+    // once *late_flag and *late_flag2 are >= late_want.  The force enters the dynamics additively (dv = h f/m, dp = h^2/2 f/m: it changes the defects
+    // b_k, not A_k, B_k or the cost), so it is not needed before the backward sweep: the flag is tested after the cost phase, the
+    // loads fly under the linearisation, the defects are corrected after it.  f and f_in_lds must be unset then.
+    const float *f_late = nullptr;
+    const unsigned long long *late_flag = nullptr, *late_flag2 = nullptr;   // both words must have reached late_want (the one or two
+    unsigned long long late_want = 0;                                        // 32-row tiles of the prediction that hold this instance's rows)
+    int late_ready = 0;            // 1: the prediction was complete before this launch started -- no wait, ordinary (cached) loads
+    unsigned late_timeout_us = 0;
+    int *late_missed = nullptr;    // counts waves whose wait timed out (the step then runs with zero force and status 5)
+    int *late_slow = nullptr;      // counts waves that started before their prediction was complete (epoch path)
+    // "done reading" accounting of the force slot (the launch that refills it two ticks later waits for it), see W::late_count
+    unsigned *late_cnt = nullptr;          // this workgroup's group counter (monotonic)
+    unsigned long long *late_done_word = nullptr;   // groups completed (monotonic)
+    unsigned late_gsize = 1;               // workgroups per group and launch
+    void *late_group = nullptr;            // backend-specific counter shared by the waves of a workgroup, or null
+    unsigned late_group_size = 1;
 };
 
 struct LdsMap {
@@ -1297,6 +1314,7 @@ struct RtiWave {
         stamp(io, m, 0);
         vi lane = W::lane();
         int status = 0, iters = 0;
+        typename W::late_t late_prev = W::late_none();
         // the global loads are already in flight (issue_first); the index tables (pure VALU) are built under them
         // fused downwash: f sits in the staging slot already; the slot is recycled by the sweep, so keep a register copy
         vd fkeep[RF];
@@ -1319,7 +1337,37 @@ struct RtiWave {
             stamp(io, m, 2);
             build_cost(P, m, lds);
             stamp(io, m, 3);
+            // late force: one lane per stage holds f_k (3 floats); requested here, used after the linearisation
+            vd fl[3] = {vd(0.0), vd(0.0), vd(0.0)};
+            bool late_ok = true;
+            if (io.f_late && P.use_fd) {
+                vi k3 = W::imin(lane, N - 1) * 3;
+                if (io.late_ready) {
+                    for (int i = 0; i < 3; ++i) fl[i] = W::gldfu(io.f_late, k3 + i);
+                } else if ((io.late_slow ? (W::count(io.late_slow), true) : true) &&
+                           (late_ok = W::wait_ge(io.late_flag, io.late_flag2, io.late_want, io.late_timeout_us))) {
+                    for (int i = 0; i < 3; ++i) fl[i] = W::gldf_fresh(io.f_late, k3 + i);
+                } else if (io.late_missed) {
+                    W::count(io.late_missed);
+                }
+            }
             linearize(P, m, lds);
+            if (io.f_late && P.use_fd && late_ok) {
+                // b_k += [h^2/2 f_k/m ; h f_k/m ; 0]  (ndp_nmpc_body_rate_ctl.py:155-157 through one RK4 step: exact, the force is
+                // constant over the step); lanes past the last stage repeat stage N-1's correction on a private copy (dump slot)
+                W::sync();
+                vi kk = W::imin(lane, N - 1);
+                vi mb = kk * int(MB_STRIDE) + m.MB + int(MB_B);
+                vb mine = lane < N;
+                for (int i = 0; i < 3; ++i) {
+                    vd a = fl[i] * P.inv_mass;
+                    vd bp = W::ld(lds, mb + i), bv = W::ld(lds, mb + 3 + i);
+                    W::stp(lds, mb + i, bp + a * (0.5 * P.dt * P.dt), mine);
+                    W::stp(lds, mb + 3 + i, bv + a * P.dt, mine);
+                }
+            }
+            if (!late_ok && !status) status = 5;
+            if (io.f_late && it == 0) late_prev = W::late_count(io.late_cnt, io.late_group, io.late_group_size);   // (looked at when the step is over)
             stamp(io, m, 4);
             // solve_for_x0: dx_0 = x0 - x_0  (nmpc_body_rate_ctl.py:107)
             W::stp(lds, lane + m.ZX, x0v - W::ldp(lds, lane + m.XI, lane < NX), lane < NX);
@@ -1400,6 +1448,7 @@ struct RtiWave {
         stamp(io, m, 8);
         W::gsti(io.status, status);
         W::gsti(io.iters, iters);
+        if (io.f_late) W::late_publish(late_prev, io.late_gsize, io.late_done_word);
         return false;
     }
 };

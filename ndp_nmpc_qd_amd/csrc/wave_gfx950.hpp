@@ -62,6 +62,61 @@ struct WaveGfx950 {
     // element i of the concatenation [a (n elements) | b]: one store through a per-lane pointer instead of two predicated ones
     static NDP_D void gst2(double *a, double *b, vi i, int n, vd v) { (i < n ? a + i : b + (i - n))[0] = v; }
     static NDP_D void gsti(int *g, int v) { if (g && lane() == 0) *g = v; }
+    // late-force protocol (rti_wave.hpp: RtiIo::f_late): wait until both words have reached `want` (agent-scope acquire), at most
+    // timeout_us.  The words differ from instance to instance (per-tile epochs of the downwash launch): 1024 waves reading ONE
+    // word at agent scope serialise at the memory side (the XCDs' L2s are not coherent with each other: such loads bypass them) --
+    // measured 7 us per wave.
+    static NDP_D bool wait_ge(const unsigned long long *flag, const unsigned long long *flag2, unsigned long long want, unsigned timeout_us)
+    {
+        auto both = [&](int order) {
+            const unsigned long long a = __hip_atomic_load(flag, order, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long b = __hip_atomic_load(flag2, order, __HIP_MEMORY_SCOPE_AGENT);
+            return a >= want && b >= want;
+        };
+        if (both(__ATOMIC_ACQUIRE)) return true;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
+        while (!both(__ATOMIC_RELAXED)) {
+            __builtin_amdgcn_s_sleep(8);                                        // ~0.25 us between polls
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 100ull * timeout_us) return false;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        return true;
+    }
+    // a float written by another launch that is still running elsewhere on the device: read past this XCD's L2 (agent scope)
+    static NDP_D vd gldf_fresh(const float *g, vi off)
+    {
+        const unsigned bits = __hip_atomic_load(reinterpret_cast<const unsigned *>(g) + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (double)__uint_as_float(bits);
+    }
+    static NDP_D void count(int *ctr) { if (lane() == 0) atomicAdd(ctr, 1); }
+    // "this wave has its force values".  Three levels, because an agent-scope atomic on ONE address costs 30-60 ns and they
+    // serialise (the eight XCDs' L2s are not coherent: such atomics execute at the memory side) -- one per wave made the launch
+    // 36 us instead of 18, one per workgroup (256) still 35: (1) the waves of a workgroup count themselves in an LDS word; (2) the
+    // one that counts last there adds the workgroup to its GROUP's counter (workgroup index mod 8: eight addresses, 32 atomics each
+    // at batch 1024) with a relaxed returning atomic whose result is not looked at before the end of the step; (3) the workgroup
+    // that completes its group for this launch adds one to the count of completed groups (late_publish, nothing returned).  All
+    // counters only ever grow: launch t has been read completely when the completed-groups word has reached t * groups, and a
+    // launch's own number is (completed groups) / groups + 1 -- stable while it runs.  Relaxed is enough for the counting: the
+    // loads being protected have completed (their values were used) before the first atomic is issued.
+    typedef unsigned late_t;
+    static NDP_D late_t late_none() { return 0xffffffffu; }
+    static NDP_D late_t late_count(unsigned *cnt, void *group, unsigned group_size)
+    {
+        late_t prev = 0xffffffffu;
+        if (lane() == 0) {
+            typedef __attribute__((address_space(3))) unsigned *lds_u32;
+            // group: LDS offset of the workgroup's counter + 1, or null
+            const bool last_of_group = !group || __hip_atomic_fetch_add((lds_u32)((unsigned)(size_t)group - 1u), 1u, __ATOMIC_RELAXED,
+                                                                       __HIP_MEMORY_SCOPE_WORKGROUP) == group_size - 1;
+            if (last_of_group) prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return prev;
+    }
+    static NDP_D void late_publish(late_t prev, unsigned gsize, unsigned long long *done_groups)
+    {
+        if (lane() == 0 && prev != 0xffffffffu && (prev + 1u) % gsize == 0u)
+            __hip_atomic_fetch_add(done_groups, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // 1/a: v_rcp_f64 seed + two Newton steps (a full IEEE divide is ~100 dependent cycles on gfx950)
     static NDP_D vd rcp(vd a)

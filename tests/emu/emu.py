@@ -71,3 +71,15 @@ def rti_step_defer(cfg, x0, xr, ur, f, X, U):
     rc = lib().emu_rti_step_defer(C.byref(cfg), _p(x0), _p(xr), _p(ur), _p(f), _p(X), _p(U), _p(u0), C.byref(status), C.byref(iters))
     assert rc in (0, 1), rc
     return bool(rc), u0, status.value, iters.value
+
+
+def rti_step_late(cfg, x0, xr, ur, f, X, U, ready=True):
+    """The late-force path (RtiIo::f_late): returns (u0, status, iters, missed)."""
+    x0, xr, ur = (np.ascontiguousarray(a, dtype=np.float64) for a in (x0, xr, ur))
+    f = np.ascontiguousarray(f, dtype=np.float32)
+    u0 = np.zeros(4)
+    status, iters, missed = C.c_int(-1), C.c_int(-1), C.c_int(0)
+    rc = lib().emu_rti_step_late(C.byref(cfg), _p(x0), _p(xr), _p(ur), _p(f), int(bool(ready)), _p(X), _p(U), _p(u0),
+                                 C.byref(status), C.byref(iters), C.byref(missed))
+    assert rc == 0
+    return u0, status.value, iters.value, missed.value

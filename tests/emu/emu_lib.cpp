@@ -47,6 +47,29 @@ int emu_rti_step(const ndp_cfg *cfg, const double *x0, const double *xr, const d
     return 0;
 }
 
+// The late-force path (RtiIo::f_late: the downwash force of a launch that ran one tick ahead on a second stream): the same step
+// with f handed over as f_late behind a flag that is already set (ready = 1) or not (ready = 0: the wait "times out" at once on the
+// emulator -> zero force, status 5).
+int emu_rti_step_late(const ndp_cfg *cfg, const double *x0, const double *xr, const double *ur, const float *f, int ready,
+                      double *X, double *U, double *u0, int *status, int *iters, int *missed)
+{
+    ndp::RtiParams P = ndp::to_params(*cfg);
+    if (P.N != 20 || P.n_rti != 1 || cfg->qp_precision != 0) return -1;
+    const int n = ndp::lds_doubles(P.N);
+    std::vector<double> lds((size_t)n, 0.0 / 0.0);
+    emu::Wave::lds_limit() = n;
+    double kc[ndp::KC_SC];
+    ndp::fill_kc(P, kc);
+    ndp::RtiIo io{x0, xr, ur, nullptr, X, U, u0, status, iters, nullptr, 0, kc};
+    std::vector<int> tb(ndp::TB_WORDS);
+    ndp::fill_tables(P.N, tb.data(), 0);
+    io.tables = tb.data();
+    const unsigned long long flag = ready ? 7 : 6;
+    io.f_late = f; io.late_flag = &flag; io.late_flag2 = &flag; io.late_want = 7; io.late_timeout_us = 1; io.late_missed = missed;
+    ndp::RtiWave<emu::Wave, 3, 20, true, 1>::run(P, io, lds.data());
+    return 0;
+}
+
 // The producer launch's view of one instance (work list, QMODE 1): RtiWave::run<DEFER = true> on the reference configuration's
 // instantiation.  Returns 1 if the instance was deferred (needs the interior-point loop: nothing may have been written),
 // 0 if it was solved by the early exit, < 0 on misuse.

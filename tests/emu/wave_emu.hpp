@@ -114,6 +114,16 @@ struct Wave {
     static vi imin(const vi &a, const vi &b) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return o; }
     static void gst2(double *a, double *b, const vi &i, int n, const vd &val) { for (int l = 0; l < 64; ++l) (i.v[l] < n ? a + i.v[l] : b + (i.v[l] - n))[0] = val.v[l]; }
     static void gsti(int *g, int val) { if (g) *g = val; }
+    static bool wait_ge(const unsigned long long *flag, const unsigned long long *flag2, unsigned long long want, unsigned) { return *flag >= want && *flag2 >= want; }
+    static vd gldf_fresh(const float *g, const vi &off) { return gldfu(g, off); }
+    static void count(int *ctr) { ++*ctr; }
+    typedef unsigned late_t;
+    static late_t late_none() { return 0xffffffffu; }
+    static late_t late_count(unsigned *cnt, void *, unsigned) { return cnt ? (*cnt)++ : 0xffffffffu; }
+    static void late_publish(late_t prev, unsigned gsize, unsigned long long *done_groups)
+    {
+        if (done_groups && prev != 0xffffffffu && (prev + 1u) % gsize == 0u) ++*done_groups;
+    }
 
     static vd clock() { return vd(0.0); }
     static vd clock_after(const vd &) { return vd(0.0); }

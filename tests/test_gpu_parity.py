@@ -1070,3 +1070,105 @@ def test_control_error_from_the_mlp_outside_its_training_envelope(ndp, mlp_golde
           f"device vs torch-fixture {e_df:.2e}")
     assert e_dev <= 2.5 * e_fix + 1e-9
     assert e_df <= 1e-3
+
+
+def test_downwash_one_tick_ahead_on_the_second_stream(ndp, oracle, mlp_blob):
+    """ndp_downwash_prefetch_device + ndp_step_device_prefetched: the force of tick t+1 is predicted by a second launch while
+    tick t is being solved; the control step takes it late (after its linearisation) and corrects the dynamics defects.  Same
+    controls as the fused single launch to rounding, and the oracle's; host-launched and replayed from a hipGraph (fork at the
+    first prediction, join at the end); ragged batch; the protocol's counters add up."""
+    import torch
+    B, N, T = 300, 20, 6
+    dev = torch.device("cuda", 0)
+    ticks, host = [], []
+    for t in range(T):
+        b = synth.make_batch(B, seed=synth.SEED0 + 71, downwash=True, t0=0.02 * t)
+        host.append(b)
+        ticks.append({k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur", "other", "ego_xy")})
+    stream = torch.cuda.Stream(device=dev)
+    fused = ndp.BatchedNMPC(B, disturbance=True)
+    uf = torch.empty(T, B, 4, dtype=torch.float64, device=dev)
+    fused.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
+    for t, d in enumerate(ticks):
+        fused.update_device(d["x0"], d["xr"], d["ur"], uf[t], other=d["other"], ego_xy=d["ego_xy"], stream=stream)
+    fused.synchronize()
+    assert (fused.status()[0] == 0).all()
+    want = uf.cpu().numpy()
+
+    def run(eng, out, first_after):
+        d = ticks[0]
+        eng.downwash_prefetch_device(d["other"], d["xr"], ego_xy=d["ego_xy"], after_stream=first_after)
+        for t, d in enumerate(ticks):
+            if t + 1 < T:
+                n = ticks[t + 1]
+                eng.downwash_prefetch_device(n["other"], n["xr"], ego_xy=n["ego_xy"])      # beside this tick's control step
+            eng.update_device_prefetched(d["x0"], d["xr"], d["ur"], out[t], stream=stream)
+
+    for mode in ("host", "graph"):
+        eng = ndp.BatchedNMPC(B, disturbance=True)
+        up = torch.empty(T, B, 4, dtype=torch.float64, device=dev)
+        eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
+        with torch.cuda.stream(stream):
+            if mode == "host":
+                run(eng, up, stream)
+            else:
+                eng.downwash_prefetch_device(ticks[0]["other"], ticks[0]["xr"], ego_xy=ticks[0]["ego_xy"])   # allocate outside the capture
+                eng.update_device_prefetched(ticks[0]["x0"], ticks[0]["xr"], ticks[0]["ur"], up[0], stream=stream)
+                eng.synchronize()
+                eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="relaxed"):
+                    run(eng, up, stream)
+                    eng.prefetch_join(stream)
+                g.replay()
+        eng.prefetch_join(stream)
+        torch.cuda.synchronize()                 # (the replay ran on torch's stream: the engine's own synchronize does not know it)
+        st = eng.prefetch_stats()
+        extra = 1 if mode == "graph" else 0
+        late = st.pop("late_waves")
+        assert st == dict(predictions=T + extra, steps=T + extra, force_timeouts=0, slot_timeouts=0), st
+        assert (eng.status()[0] == 0).all()
+        got = up.cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+        f_last = eng.force_slot((T + extra) & 1).cpu().numpy()
+        f_or = oracle.downwash_batch(mlp_blob, host[-1]["other"], host[-1]["xr"], host[-1]["ego_xy"])
+        assert np.all(np.abs(f_last - f_or) <= 1e-5 * np.maximum(1.0, np.abs(f_or)))
+        eng.close()
+    f0 = oracle.downwash_batch(mlp_blob, host[0]["other"], host[0]["xr"], host[0]["ego_xy"])
+    uo, sto, *_ = _oracle_batch(oracle, host[0], use_fd=True, f=f0)
+    _assert_u(want[0][sto == 0], uo[sto == 0], 1e-6)
+
+
+def test_downwash_prefetch_misuse_is_bounded_and_reported(ndp):
+    """A control step whose prediction was never enqueued gives up after the bounded wait: zero force, status 5 on every instance,
+    counted; a third prediction ahead of the steps waits for a free slot and is counted too.  Nothing hangs."""
+    import torch
+    B = 64
+    dev = torch.device("cuda", 0)
+    b = synth.make_batch(B, seed=9, downwash=True)
+    d = {k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur", "other", "ego_xy")}
+    eng = ndp.BatchedNMPC(B, disturbance=True)
+    u = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    eng.reset_device(d["xr"], d["ur"])
+    eng.downwash_prefetch_device(d["other"], d["xr"], ego_xy=d["ego_xy"])
+    eng.update_device_prefetched(d["x0"], d["xr"], d["ur"], u)
+    eng.synchronize()
+    assert (eng.status()[0] == 0).all()
+    eng.update_device_prefetched(d["x0"], d["xr"], d["ur"], u)          # no prediction for it
+    eng.synchronize()
+    st = eng.prefetch_stats()
+    assert (eng.status()[0] == 5).all() and st["force_timeouts"] == B and st["steps"] == 2 and st["predictions"] == 1, st
+    plain = ndp.BatchedNMPC(B)                                          # zero force = the plain NMPC step from the same iterate
+    X, U = eng.get_iterate()
+    for _ in range(3):                                                   # predictions 2, 3 fill the slots; 4 has to wait for step 2 ... which was taken
+        eng.downwash_prefetch_device(d["other"], d["xr"], ego_xy=d["ego_xy"])
+    eng.downwash_prefetch_device(d["other"], d["xr"], ego_xy=d["ego_xy"])    # prediction 5: its slot's reader (step 3) never ran
+    st = eng.prefetch_stats()
+    assert st["predictions"] == 5 and st["slot_timeouts"] >= 1, st
+    with pytest.raises(ndp.batched.NdpError):
+        ndp.BatchedNMPC(B).downwash_prefetch_device(d["other"], d["xr"])           # plain NMPC model: no force input
+    big = ndp.BatchedNMPC(4096, disturbance=True)                                  # work list on (two instances per SIMD and more): not combined
+    with pytest.raises(ndp.batched.NdpError):
+        big.downwash_prefetch_device(d["other"], torch.zeros(4096, 21, 10, dtype=torch.float64, device=dev),
+                                     other_index=torch.zeros(4096, dtype=torch.int32, device=dev))

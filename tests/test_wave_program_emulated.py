@@ -315,3 +315,33 @@ def test_any_horizon_matches_oracle(oracle, N):
             _assert_u(u0, u0o, 1e-8)
             np.testing.assert_allclose(X, Xo, atol=1e-8)
             np.testing.assert_allclose(U, Uo, atol=1e-8)
+
+
+def test_late_force_path_matches_the_force_given_up_front(oracle):
+    """The downwash force handed over late (RtiIo::f_late: predicted by another launch one tick ahead; tested after the cost phase,
+    loaded under the linearisation, added to the defects b_k afterwards -- it changes neither A_k, B_k nor the cost) gives the
+    step of the force given up front to rounding, and the oracle's.  A force that never arrives: the wait gives up, the step
+    runs with zero force and reports status 5."""
+    rng = np.random.default_rng(5)
+    b = synth.make_batch(6, seed=77)
+    for i in range(6):
+        f = rng.normal(0.0, 2.5, (21, 3)).astype(np.float32)
+        cfg = E.default_cfg(use_fd=True)
+        X1, U1 = b["xr"][i].copy(), b["ur"][i].copy()
+        u_up, st_up, it_up, *_ = E.rti_step(cfg, b["x0"][i], b["xr"][i], b["ur"][i], f, X1, U1)
+        X2, U2 = b["xr"][i].copy(), b["ur"][i].copy()
+        u_late, st_late, it_late, missed = E.rti_step_late(cfg, b["x0"][i], b["xr"][i], b["ur"][i], f, X2, U2)
+        assert st_up == st_late == 0 and it_up == it_late and missed == 0
+        np.testing.assert_allclose(u_late, u_up, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(X2, X1, rtol=0, atol=1e-11)
+        co = oracle.default_cfg(use_fd=True)
+        Xo, Uo = b["xr"][i].copy(), b["ur"][i].copy()
+        uo, _ = oracle.step(co, b["x0"][i], b["xr"][i], b["ur"][i], f.astype(np.float64), Xo, Uo)
+        np.testing.assert_allclose(u_late, uo, rtol=0, atol=1e-8)
+        # the flag never reaches the tick: zero force, status 5, counted
+        X3, U3 = b["xr"][i].copy(), b["ur"][i].copy()
+        u_miss, st_miss, _, missed = E.rti_step_late(cfg, b["x0"][i], b["xr"][i], b["ur"][i], f, X3, U3, ready=False)
+        X4, U4 = b["xr"][i].copy(), b["ur"][i].copy()
+        u_zero, *_ = E.rti_step(cfg, b["x0"][i], b["xr"][i], b["ur"][i], np.zeros((21, 3), np.float32), X4, U4)
+        assert st_miss == 5 and missed == 1
+        np.testing.assert_allclose(u_miss, u_zero, rtol=0, atol=1e-11)
