@@ -213,9 +213,10 @@ def main():
     #          slice of the gathered buffer as it lies; config 4: the kernel picks each leader's neighbour row through
     #          other_index.  Two gather buffers: the gather of tick i+1's windows (functions of time only) is started before tick
     #          i's kernel is launched and runs on RCCL's stream beside it.
-    #   peer : ONE publish launch per step (dist.PeerWindows / csrc/peer_epoch.hpp): this tick's windows into the rank's own
-    #          peer-mapped slot, epoch word, wait for the neighbour's epoch; the control-step kernel then reads the neighbour's
-    #          slot out of the neighbour GPU's HBM over xGMI.  No collective, no host round trip, hipGraph-replayed like N = 1.
+    #   peer : ONE publish per step (dist.PeerWindows / csrc/peer_epoch.hpp; a copy launch + a one-wave launch): this tick's
+    #          windows into the rank's own peer-mapped slot, epoch word, wait for the neighbour's epoch; the control-step kernel then
+    #          reads the neighbour's slot out of the neighbour GPU's HBM over xGMI.  No collective, no host round trip, hipGraph-
+    #          replayed like N = 1.
     need_exchange = downwash and args.placement == "vehicle" and (world > 1 or cfg4)
     two_forms = (not need_exchange and downwash and world == 1 and not cfg4 and N + 1 <= 32 and args.qp_mode == 0
                  and not eng.work_queue)
@@ -244,7 +245,7 @@ def main():
     mode_names = {"prefetch": "none (one GPU); downwash of tick t+1 on a second stream beside the control step of tick t",
                   "fused": "none (one GPU); gate + MLP fused into the control-step launch",
                   "none": "none", "rccl": "rccl all-gather per step" + ("" if world > 1 else " (one rank: the pack only, no RCCL call)"),
-                  "peer": "peer windows over xGMI: one publish launch per step (epoch-ordered), read by the control-step kernel"}
+                  "peer": "peer windows over xGMI: one publish (copy launch + one-wave epoch launch) per step, read by the control-step kernel"}
 
     def host_other(h):
         """The neighbour windows of the host copy of tick 0 (oracle legs)."""

@@ -282,9 +282,9 @@ int ndp_rollout_device(ndp_handle *h, int ticks, double t0, double dt_tick, int 
  * message every control tick), the subscriber ndp_nmpc_leader_node.py:40,60-76 (consumes the latest one).  One process per GPU:
  * the publisher allocates its window buffer with ndp_peer_alloc and sends the 64-byte handle to the subscriber's process once
  * (any channel: torch.distributed object collectives, a socket); the subscriber maps it with ndp_peer_open.  Every control tick
- * each rank then runs ONE ndp_peer_publish_device launch in front of its control-step launch: it writes this tick's windows into
- * one of the two slots of its own buffer, publishes the tick number (an epoch word, system scope) and waits for the
- * neighbour's epoch of the same tick; the control-step kernel launched next reads the neighbour's slot straight out of the
+ * each rank then calls ndp_peer_publish_device in front of its control-step launch (a copy launch + a one-wave launch): it writes
+ * this tick's windows into one of the two slots of its own buffer, publishes the tick number (an epoch word, system scope) and
+ * waits for the neighbour's epoch of the same tick; the control-step kernel launched next reads the neighbour's slot straight out of the
  * publisher's HBM (peer access over xGMI) -- no collective, no host round trip.  Writer -> reader ordering, slot reuse (the
  * reader's acknowledgement), bounded waits and their counters: csrc/peer_epoch.hpp.
  *   ndp_peer_layout : bytes of a buffer whose slots hold n_doubles each ([B][N+1][10] windows: n = B*(N+1)*10), the offset

@@ -74,13 +74,14 @@ struct MlpArgs {            // fused downwash (null frag = not fused)
 //                               and NOT touched otherwise;
 //   consumer launch  (QMODE 2): wave j solves list entry j from scratch with the interior-point loop; waves past the end
 //                               of the list exit at once -- the listed instances are spread evenly over all SIMDs.
-// The list counter is zeroed by the consumer itself: every consumer workgroup reads it once and counts itself; the workgroup
-// that counts last -- every other one has read the counter by then -- resets both words for the next step's producer (round 2
-// had a memset node per step in front of the producer: 4.6 us).  (An in-kernel queue -- finished waves popping
+// The list counter is zeroed by a one-wave launch behind the consumer (queue_reset_kernel).  (Round 3 first let the consumer do
+// it -- every consumer workgroup counted itself with an atomic, the last one reset -- and paid for it: agent-scope atomics on one
+// address are served at the memory side at 30-60 ns each and serialise, 61 us at batch 4096 where the memset node it replaced had
+// cost 4.6 us.)  (An in-kernel queue -- finished waves popping
 // other instances' solves -- was built first: as a second inlined copy of the unrolled step it wrecked the register
 // allocation of both copies, as a called function it lost the scalar registers; either way 2.3x slower than this.)
 struct QueueArgs {
-    unsigned *count;        // entries of ids; count[1] = consumer workgroups that have read count[0] (see rti_kernel, QMODE 2)
+    unsigned *count;        // entries of ids
     int *ids;               // [B]
 };
 
@@ -175,17 +176,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     }
     int inst_raw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave);
     if (QMODE == 2) {         // list entry -> instance; past the end of the list: nothing to do
-        __shared__ int n_list;
-        if (threadIdx.x == 0) {
-            n_list = (int)qa.count[0];
-            const unsigned seen = __hip_atomic_fetch_add(qa.count + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (seen == gridDim.x - 1) {      // every workgroup of this launch has read the list length: reset for the next step
-                __hip_atomic_store(qa.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(qa.count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();
-        const int n = n_list;
+        const int n = (int)*qa.count;
         if (inst_raw >= n) return;
         inst_raw = __builtin_amdgcn_readfirstlane(qa.ids[inst_raw]);
     }
@@ -359,6 +350,12 @@ __global__ void mfma_probe32_kernel(const float *a, const float *b, const float 
     x = x + WaveGfx950F32::csum1(x);
     x = x + WaveGfx950F32::csum2(x);
     d[256 + l] = (float)x;
+}
+
+// behind the work list's consumer launch: the list is empty again for the next step's producer
+__global__ void queue_reset_kernel(unsigned *count)
+{
+    if (threadIdx.x == 0) *count = 0u;
 }
 
 // ------------------------------------------------------------------------------------------ MLP kernel
@@ -1160,13 +1157,19 @@ __global__ __launch_bounds__(256) void ref_list_window_kernel(const double *__re
 
 
 // ------------------------------------------------------------------------------------------ peer windows: per-tick publish
-// peer_epoch.hpp's protocol on the device.  ONE launch per control tick and rank, in front of the control-step launch:
+// peer_epoch.hpp's protocol on the device.  TWO launches per control tick and rank, in front of the control-step launch:
+//  peer_publish_kernel (<= 256 blocks)
 //   thread 0 of block 0   : reader role -- acknowledge tick t-1 in the neighbour's header (its slot may be overwritten now)
 //   thread 0 of each block: owner role  -- wait until the own slot t & 1 is free (the reader's acknowledgement of tick t-2)
-//   all threads           : copy this tick's windows (src, the reference generator's output) into the own slot
-//   last block to finish  : epoch[t & 1] := t (release, system scope), then -- reader role -- wait for the neighbour's
-//                           epoch of tick t.  When the launch has completed, the control-step kernel launched next on the same
-//                           stream may read the neighbour's slot t & 1 (kernel boundary = system-scope acquire).
+//   all threads           : copy this tick's windows (src, the reference generator's output) into the own slot, plain stores;
+//                           the end of the launch is what makes them visible system-wide
+//  peer_epoch_kernel (one wave)
+//   epoch[t & 1] := t (release, system scope), then -- reader role -- wait for the neighbour's epoch of tick t.  When this launch
+//   has completed, the control-step kernel launched next on the same stream may read the neighbour's slot t & 1 (kernel
+//   boundary = system-scope acquire).
+// (One launch that counts its finished blocks with an atomic and lets the last one publish was the first form: agent-scope atomics
+// on one address serialise at 30-60 ns each -- 8.7 us for 1.7 MB of windows against 4.7 us this way, 15-114 us against 7-9 us
+// for 20 MB depending on the block count; scripts/ubench/publish_copy.hip.)
 struct PeerDevMem {
     typedef unsigned long long u64;
     static __device__ __forceinline__ u64 load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -1188,9 +1191,8 @@ __global__ __launch_bounds__(256) void peer_publish_kernel(PeerPubArgs a)
     typedef PeerProto<PeerDevMem> PP;
     typedef unsigned long long u64;
     __shared__ u64 tick_s;
-    __shared__ unsigned last_s;
     if (threadIdx.x == 0) {
-        const u64 t = PP::next_tick(a.own);
+        const u64 t = PP::next_tick(a.own);          // (the epochs only change in peer_epoch_kernel, behind this launch)
         if (blockIdx.x == 0) PP::ack_previous(a.nb, t);
         const bool freed = PP::wait_slot_free(a.own, t, a.timeout_us);
         if (blockIdx.x == 0 && !freed) a.own[PEER_W_STAT + PEER_STAT_ACK_TIMEOUT] += 1;
@@ -1203,24 +1205,18 @@ __global__ __launch_bounds__(256) void peer_publish_kernel(PeerPubArgs a)
     const size_t n2 = a.n / 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
     if ((a.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<double *>(dst)[a.n - 1] = a.src[a.n - 1];
-    __syncthreads();                              // the whole block's stores are issued ...
-    if (threadIdx.x == 0) {
-        // ... and the agent-scope release of the counting atomic below writes this XCD's L2 back (buffer_wbl2 sc1: the eight
-        // XCDs' L2s are not coherent with each other, so on gfx950 agent scope already means "in memory"): when the last block
-        // has counted, every block's part of the slot is in HBM, where the reading GPU's loads over xGMI find it.  ONE such
-        // release per block, and few blocks (scripts/ubench/publish_copy.hip: a release per thread made this launch 130 us for
-        // 20 MB, one per block with 4096 blocks 114 us, with 256 blocks 16 us; the plain copy is 9 us).
-        unsigned *done = reinterpret_cast<unsigned *>(a.own + PEER_W_DONE);
-        const unsigned prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = prev == gridDim.x - 1 ? 1u : 0u;
-        if (last_s) {
-            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            PP::set_epoch(a.own, t);
-            a.own[PEER_W_STAT + PEER_STAT_TICKS] = t;
-            if ((int)(t & 1) != a.slot) a.own[PEER_W_STAT + PEER_STAT_DESYNC] += 1;
-            if (!PP::wait_epoch(a.nb, t, a.timeout_us)) a.own[PEER_W_STAT + PEER_STAT_EPOCH_TIMEOUT] += 1;
-        }
-    }
+}
+
+__global__ void peer_epoch_kernel(PeerPubArgs a)
+{
+    typedef PeerProto<PeerDevMem> PP;
+    typedef unsigned long long u64;
+    if (threadIdx.x != 0) return;
+    const u64 t = PP::next_tick(a.own);
+    PP::set_epoch(a.own, t);
+    a.own[PEER_W_STAT + PEER_STAT_TICKS] = t;
+    if ((int)(t & 1) != a.slot) a.own[PEER_W_STAT + PEER_STAT_DESYNC] += 1;
+    if (!PP::wait_epoch(a.nb, t, a.timeout_us)) a.own[PEER_W_STAT + PEER_STAT_EPOCH_TIMEOUT] += 1;
 }
 
 }  // namespace ndp
@@ -1542,8 +1538,9 @@ int ndp_peer_publish_device(int device, const void *d_src, size_t n_doubles, voi
     PeerPubArgs a{(const double *)d_src, (unsigned long long *)own_buf, (unsigned long long *)nb_buf, n_doubles, slot, timeout_us};
     size_t blocks = (n_doubles / 2 + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 256) blocks = 256;        // all resident at once (every block's first thread may wait on the reader), and one L2 release each
+    if (blocks > 256) blocks = 256;        // all resident at once: every block's first thread may wait on the reader
     hipLaunchKernelGGL(peer_publish_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(peer_epoch_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -1629,10 +1626,10 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         h->n_simd = 4 * prop.multiProcessorCount;
     }
     // work list: by default when the batch holds at least two instances per SIMD and the QP mode has an early exit to defer
-    // from.  With one instance per SIMD nothing can be re-balanced; above that the list's fixed cost per step (one consumer
-    // launch whose workgroups read the counter and leave when nothing was listed) is a few per cent of a step that needs no
-    // interior-point solve, against +20 % .. 2x when a fifth of the instances do -- callers who know their workload set
-    // cfg.work_queue = 1 / 2.
+    // from.  With one instance per SIMD nothing can be re-balanced; above that the list's fixed cost per step (a consumer
+    // launch whose workgroups read the counter and leave when nothing was listed, and a one-wave reset launch) is a few per
+    // cent of a step that needs no interior-point solve, against +20 % .. 2x when a fifth of the instances do -- callers who
+    // know their workload set cfg.work_queue = 1 / 2.
     // The N = 40 / 2-iteration shape always takes the list: its producer kernel carries no interior-point code and does not
     // spill, which is worth 17 % even when nothing is listed (the in-place kernel of that shape uses 0.9 KB of scratch per lane)
     if (cfg->work_queue == 1 && !(queue_shape(h) && cfg->qp_mode == NDP_QP_AUTO)) {
@@ -1841,8 +1838,8 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     if (q) {
         // work list: producer (every instance, early exit or defer), consumer (the deferred ones, from scratch; with one RTI
         // iteration the consumer goes straight to the interior-point loop, with several it repeats the automatic rule per
-        // iteration; its last workgroup to arrive zeroes the counter for the next step).  The consumer reads the fused
-        // producer's force from dForce.
+        // iteration), a one-wave launch that empties the list for the next step.  The consumer reads the fused producer's
+        // force from dForce.
         KernArgs kc = ka;
         kc.bp.f = fused ? h->dForce : d_f;
         kc.ma.frag = nullptr; kc.ma.other = nullptr;
@@ -1856,6 +1853,8 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
             NDP_HIP(h, hipGetLastError());
             hipLaunchKernelGGL(RTI_K(5, 2, false, 40, 0, 2, 2), grid, block, shm, s, kc);
         }
+        NDP_HIP(h, hipGetLastError());
+        hipLaunchKernelGGL(queue_reset_kernel, dim3(1), dim3(64), 0, s, h->dQctr);
         NDP_HIP(h, hipGetLastError());
         return end_timing(h, s);
     }

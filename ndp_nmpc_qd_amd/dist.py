@@ -190,8 +190,8 @@ class PeerWindows:
 
     Every rank owns a buffer with two window slots ([B_local, N+1, 10] float64 each) allocated with ndp_peer_alloc; the 64-byte
     IPC handles are exchanged ONCE (all_gather_object) and each rank maps the buffer of rank (r+1) % W, which holds its
-    neighbours.  Per tick, `other = peer.publish_device(xr_tick, stream)` enqueues ONE launch that copies this rank's windows
-    into its own slot, publishes the tick number and waits for the neighbour's (csrc/peer_epoch.hpp: epoch words, reader
+    neighbours.  Per tick, `other = peer.publish_device(xr_tick, stream)` enqueues a copy launch and a one-wave launch that put this
+    rank's windows into its own slot, publish the tick number and wait for the neighbour's (csrc/peer_epoch.hpp: epoch words, reader
     acknowledgement before a slot is reused, bounded waits); `other` (DevWindows: a raw device address) is the neighbour's slot
     of that tick -- pass it to BatchedNMPC.update_device on the same stream: the control-step kernel reads it out of the
     neighbour GPU's HBM.  No collective, no host round trip; capturable into a hipGraph holding an even number of ticks.

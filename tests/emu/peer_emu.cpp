@@ -1,5 +1,5 @@
 // peer_emu.cpp -- csrc/peer_epoch.hpp between CPU processes (tests only; never linked into the product).
-// The per-tick publish step of ndp_hip.hip's peer_publish_kernel, run by one thread per process over POSIX shared memory:
+// The per-tick publish step of ndp_hip.hip's peer_publish_kernel + peer_epoch_kernel, run by one thread per process over POSIX shared memory:
 // the SAME protocol text (PeerProto) on a CPU memory backend, so that world-size-2 gloo tests can check writer -> reader
 // ordering, slot reuse and the bounded waits without a GPU.
 #include <string.h>
@@ -26,7 +26,7 @@ extern "C" {
 size_t peer_emu_buffer_bytes(size_t n) { return peer_buffer_bytes(n); }
 size_t peer_emu_slot_offset(size_t n, int s) { return peer_slot_offset(n, s); }
 
-// one publish step (peer_publish_kernel, one "block"); returns the tick it published
+// one publish step (peer_publish_kernel with one "block", then peer_epoch_kernel); returns the tick it published
 unsigned long long peer_emu_publish(const double *src, size_t n, void *own_buf, void *nb_buf, int slot, unsigned timeout_us)
 {
     typedef PeerProto<PeerCpuMem> PP;
