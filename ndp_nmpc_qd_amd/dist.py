@@ -3,15 +3,17 @@
 Every OCP instance is independent, so instances shard across ranks with no data-path collective except
 one: the downwash predictor of instance i needs its neighbour's reference window, which lives on another
 rank when a formation is spread over GPUs.  That is the reference's PredXU exchange
-(nmpc_node.py:116-133 -> ndp_nmpc_leader_node.py:40,60-76: the neighbour publishes its 21x10 float64
-`nmpc_x_ref`, the leader subtracts its own) -- here ONE all-gather of the ranks' xr windows per control
-step, after which each rank reads the slice that holds its neighbours.
+(nmpc_node.py:116-133,229-230 -> ndp_nmpc_leader_node.py:40,60-76: every tick the neighbour publishes its 21x10 float64
+`nmpc_x_ref`, the leader subtracts its own) -- here one exchange per control step, in one of two forms:
+  * ONE all-gather of the ranks' windows (exchange_pv_begin / _end: only the position / velocity columns travel, all that the
+    gate and the MLP read, downwash_nn.py:22 -- 1 008 B per instance instead of 1 680; exchange_neighbours is the plain full-window
+    form), after which each rank reads the slice that holds its neighbours;
+  * publish / subscribe through peer-mapped window slots over xGMI with device-side epoch ordering (PeerWindows below,
+    csrc/peer_epoch.hpp): no collective, no host round trip.
 
 Placement (vehicle-major): instance i of rank r and instance i of rank (r+1) % W belong to the same
 formation; rank r's downwash input is the window of rank (r+1) % W.  With W = 1 the neighbour windows
-are given directly.  The gate and the MLP read only the position / velocity columns of a window
-(downwash_nn.py:22), so the exchange that bench.py runs moves just those: exchange_pv_begin / _end below
-(1 008 B per instance instead of 1 680); exchange_neighbours (full windows) is the plain form of the same thing.
+are given directly.
 """
 import numpy as np
 
