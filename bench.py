@@ -7,8 +7,14 @@
 
 Workload (BASELINE.json metric / configs[2]): per GPU batch = 1024 independent quadrotor OCPs, N = 20,
 1 SQP-RTI iteration per step + the downwash MLP (NDP controller), inputs resident in HBM.
-A "step" is one control tick of the whole batch: [all-gather of neighbour windows when N > 1] ->
+A "step" is one control tick of the whole batch: [the neighbour-window exchange of that tick when N > 1 or --config 4] ->
 rti_kernel (gate + MLP fused in front of linearise, QP, full step).  Weak scaling: the per-GPU batch is fixed.
+All timed steps are captured in ONE hipGraph (chains of graphs beyond 1024 steps) and timed on the host clock around the
+replay (barrier + synchronize on both sides, max over ranks); `roofline.achieved` uses HIP events on the launch stream.
+`--exchange both|rccl|peer` (N > 1 / config 4): the per-tick exchange as one RCCL all-gather of the position / velocity
+columns, or as publish + epoch flags through peer-mapped windows; both are timed, `value` is the RCCL form.
+`--downwash-form both|fused|prefetch` (N = 1): the MLP fused into rti_kernel (= `value`), and the downwash of tick t + 1 on a
+second stream beside the control step of tick t (reported beside it in `downwash_forms`).
 `--config 4` is BASELINE configs[3]: 4096 three-vehicle formations (12 288 instances) split over the GPUs (strong scaling).
 Prints ONE JSON line on rank 0.  Exit code 1 (and "value": null) if the parity spot check fails or instances did not converge.
 """
@@ -259,7 +265,6 @@ def main():
         """Parity spot check, warm-up and EXACTLY --steps timed steps of one exchange form; returns its measurements."""
         exchange = mode == "rccl"
         pending = {}
-        done_ev = torch.cuda.Event()
 
         def prefetch(i):
             if exchange:
@@ -306,9 +311,9 @@ def main():
             pending.clear()
             if world > 1:
                 dist.barrier()
-            done_ev.record(stream)            # poll for the end of the work first: a blocking synchronise adds its wake-up latency
-            while not done_ev.query():        # (~10 us, 2 % of a 20-step run); the synchronise below then returns at once
-                pass
+            # plain synchronise: recording an event and polling it first was measured SLOWER on this image (one host-launched
+            # step 44.8 us against 37.3 us, a 20-step graph 452.7 against 449.2 us; profiles/r03_launch_floor.txt) -- the wait
+            # spins already, and the extra event costs a packet
             torch.cuda.synchronize()
 
         # ---- parity spot check against the CPU oracle (rank 0, first tick, 64 instances) before timing
@@ -426,6 +431,12 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        # HIP events on the launch stream around the timed region's launches (roofline.kernel_us).  The first one is recorded on the
+        # idle stream just BEFORE the clock starts (its packet is not part of the work being timed; it adds the host's launch latency
+        # of the first replay to the event time, once per region), the second behind the last launch, under the running kernels.
+        ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if graphs:
+            ev_a.record(stream)
         t0 = time.perf_counter()
         if graphs:
             for gt in graphs:
@@ -433,6 +444,7 @@ def main():
                     replay(gt)
             for i in range(tail):
                 step(args.steps - tail + i, first=i == 0, last=i == tail - 1)
+            ev_b.record(stream)
         else:
             eng.timing_enable(8)  # HIP events around every 8th launch (an event pair per launch costs a dispatch gap)
             for i in range(args.steps):
@@ -441,7 +453,8 @@ def main():
         elapsed = time.perf_counter() - t0
         if mode == "peer":
             peer.tick = peer.stats()["ticks"]
-        if graphs:                # the dominant kernel's duration (roofline): HIP events around host-launched steps, outside the timed region
+        region_ms = ev_a.elapsed_time(ev_b) if graphs else None
+        if graphs:                # an event pair around EVERY launch of 64 host-launched steps, outside the timed region (kernel_us_event_pairs)
             eng.timing_enable(1)
             for i in range(64):
                 step(i, first=i == 0, last=i == 63)
@@ -460,7 +473,7 @@ def main():
             dist.all_reduce(agg)
             bad = int(agg.item())
         res = {"extra_warm": extra, "elapsed": elapsed, "launch": launch_mode, "parity": parity, "bad": bad, "rti_ms": rti_ms, "rti_n": rti_n,
-               "mlp_ms": mlp_ms, "mlp_n": mlp_n, "it": it, "step": step, "name": mode_names[mode]}
+               "mlp_ms": mlp_ms, "mlp_n": mlp_n, "it": it, "step": step, "name": mode_names[mode], "region_ms": region_ms}
         if mode == "prefetch":
             res["prefetch_stats"] = eng.prefetch_stats()
         if mode == "peer":
@@ -520,8 +533,13 @@ def main():
         total = B * world * args.steps
         value = total / elapsed
         f_qp, f_mlp = algorithmic_flops_per_solve(N, sweeps, downwash)
-        rti_s = rti_ms * 1e-3 / max(rti_n, 1)
+        pair_s = rti_ms * 1e-3 / max(rti_n, 1)       # HIP event pair around each launch (adds the pair's own dispatch gap)
         mlp_s = mlp_ms * 1e-3 / max(mlp_n, 1) if mlp_n else 0.0
+        # One launch per step on the launch stream (N = 1, no exchange): the kernel's average duration is the HIP-event time over
+        # the timed region's launches / steps -- back to back in a replayed graph, so it includes the ~0.1 us between two nodes
+        # and, once per replay, the graph's start-up on the device.  With more launches per step (exchange forms) the pairs stay.
+        one_launch = head["region_ms"] is not None and modes[0] in ("none", "fused", "prefetch") and mlp_n == 0
+        rti_s = head["region_ms"] * 1e-3 / args.steps if one_launch else pair_s
         prefetch_form = modes[0] == "prefetch"
         fused = downwash and mlp_n == 0 and not prefetch_form   # gate + MLP run inside rti_kernel (one launch per step)
         ach_tf = f_qp * B / rti_s / 1e12
@@ -587,6 +605,9 @@ def main():
                          "traffic_note": f"HBM bytes per launch, PMC (profiles/{prof['tag']}_pmc_rti_kernel.json); algorithmic bytes per launch = %d" % (abytes * B),
                          "profile_tag": prof["tag"], "profile_mismatch": profile_mismatch,
                          "kernel_us": rti_s * 1e6, "kernel_us_rocprof": prof["kernel_us"],
+                         "kernel_us_source": ("HIP events on the launch stream around the timed region / steps" if one_launch
+                                              else "HIP event pair around each of 64 host-launched steps after the timed region"),
+                         "kernel_us_event_pairs": pair_s * 1e6,
                          "frac_rocprof": (f_qp * B / (prof["kernel_us"] * 1e-6) / 1e12 / F64_MFMA_PEAK_TFLOPS) if prof["kernel_us"] else None,
                          "flops_per_solve_f64": f_qp, "riccati_sweeps_per_solve": sweeps, "frac_interior_point": frac_ipm,
                          "fused_mlp_flops_per_solve": f_mlp if fused else 0.0,
@@ -600,6 +621,7 @@ def main():
         if two_forms:
             out["downwash_forms"] = {m: {"value": total / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3, "launch": r["launch"],
                                          "kernel_us_rti": r["rti_ms"] * 1e3 / max(r["rti_n"], 1),
+                                         "us_per_step_hip_events": (r["region_ms"] * 1e3 / args.steps) if r.get("region_ms") else None,
                                          "parity_max_rel_vs_oracle": r["parity"], "instances_not_converged": r["bad"],
                                          **({"prefetch_stats": r["prefetch_stats"]} if "prefetch_stats" in r else {})}
                                      for m, r in results.items()}

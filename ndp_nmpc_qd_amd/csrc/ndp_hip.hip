@@ -3,8 +3,16 @@
 // Kernels
 //   rti_kernel  : one wavefront per OCP instance runs the whole SQP-RTI step (rti_wave.hpp) out of its
 //                 LDS slice; 4 waves (= 4 instances) per 256-thread workgroup, one per SIMD of a CU.
+//                 FUSED: the downwash MLP tile (mlp_tile) runs in front of linearise inside the same launch.
+//                 QMODE 1 / 2: producer / consumer of the work list (instances whose QP needs the interior point).
 //   mlp_kernel  : DownwashNN.update + r_horiz gate for all (instance, horizon row) pairs; the four
 //                 layers are chained through v_mfma_f32_32x32x2_f32 accumulators (no LDS round trip).
+//   mlp_stream_kernel + prefetch_gate_kernel / prefetch_done_kernel : the downwash of the NEXT tick on a second stream, LDS-free
+//                 (weights out of L2), ordered against the control step by per-tile epochs (LateArgs / PF_* words).
+//   peer_publish_kernel + peer_epoch_kernel : the per-tick neighbour exchange through peer-mapped windows (peer_epoch.hpp).
+//   ref_window_kernel, ref_list_*_kernel, throttle / actuator / plant kernels : the rows either side of the step (f1, f3, f4).
+// The iterate (X, U) of a handle lives in HBM and stays there between steps; host-array steps (ndp_step / ndp_step_begin)
+// read their inputs from, and mirror their outputs to, page-locked host slots over PCIe (zero-copy) -- see step_begin_locked.
 // There is no CPU fallback: every entry point fails (<0) if HIP is unusable.
 #include <hip/hip_runtime.h>
 

@@ -152,13 +152,14 @@ def make_config4_shard(rank, world, n_form, placement, N=20, seed=synth.SEED0 + 
     return out
 
 
-def exchange_pv_begin(xr_local, pv_local, gathered, group=None):
+def exchange_pv_begin(xr_local, pv_local, gathered, group=None, force_collective=False):
     """Vehicle-major exchange, started without waiting: packs the position/velocity columns of this rank's windows
     (pv_local[B_local, N+1, 6]) and all-gathers them into gathered[W * B_local, N+1, 6].  Returns the work handle (None for
-    a single rank, where the pack IS the gathered buffer)."""
+    a single rank, where the pack IS the gathered buffer -- unless force_collective asks for the collective call all the same:
+    a one-rank RCCL group then exercises the call, its stream hand-over and its graph capture on a one-GPU box)."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         gathered.view(pv_local.shape).copy_(xr_local[:, :, :PV_COLS])
         return None
     pv_local.copy_(xr_local[:, :, :PV_COLS])

@@ -6,6 +6,7 @@ Tolerance (BASELINE.json north_star): |du0| <= 1e-5 * max(1, |u0|) after the sam
 iterations; the fp64 device path is expected (and asserted) to sit orders of magnitude inside that.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1172,3 +1173,79 @@ def test_downwash_prefetch_misuse_is_bounded_and_reported(ndp):
     with pytest.raises(ndp.batched.NdpError):
         big.downwash_prefetch_device(d["other"], torch.zeros(4096, 21, 10, dtype=torch.float64, device=dev),
                                      other_index=torch.zeros(4096, dtype=torch.int32, device=dev))
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", sys.argv[2]
+import numpy as np, torch, torch.distributed as dist
+import ndp_nmpc_qd_amd as ndp
+from ndp_nmpc_qd_amd import dist as ndist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+B, N = 96, 20
+b = ndist.make_formation_shard(B, 0, 1, N=N)
+t = {k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur", "ego_xy", "other")}
+stream = torch.cuda.Stream(device=dev)
+torch.cuda.set_stream(stream)
+# the exchange through RCCL (one rank: the gathered buffer must equal the packed position / velocity columns) ...
+pv = torch.empty(B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev)
+gathered = torch.full((B, N + 1, ndist.PV_COLS), float("nan"), dtype=torch.float64, device=dev)
+w = ndist.exchange_pv_begin(t["other"], pv, gathered, force_collective=True)
+assert w is not None, "the collective was not called"
+ndist.exchange_pv_end(w)
+u_a = torch.empty(B, 4, dtype=torch.float64, device=dev)
+eng = ndp.BatchedNMPC(B, N=N, disturbance=True)
+eng.reset_device(t["xr"], t["ur"], stream=stream)
+# ... consumed by the control step launched next on the same stream (no host synchronisation in between)
+eng.update_device(t["x0"], t["xr"], t["ur"], u_a, other=gathered, ego_xy=t["ego_xy"], stream=stream)
+torch.cuda.synchronize()
+assert torch.equal(gathered, t["other"][:, :, :ndist.PV_COLS])
+u_b = torch.empty(B, 4, dtype=torch.float64, device=dev)
+eng.reset_device(t["xr"], t["ur"], stream=stream)
+eng.update_device(t["x0"], t["xr"], t["ur"], u_b, other=t["other"], ego_xy=t["ego_xy"], stream=stream)
+torch.cuda.synchronize()
+assert torch.equal(u_a, u_b), float((u_a - u_b).abs().max())
+# the same exchange + step captured into a hipGraph and replayed with other windows (bench.py --graph-exchange)
+g = torch.cuda.CUDAGraph()
+src = t["other"].clone()
+eng.reset_device(t["xr"], t["ur"], stream=stream)
+torch.cuda.synchronize()
+with torch.cuda.graph(g, stream=stream, capture_error_mode="relaxed"):
+    w = ndist.exchange_pv_begin(src, pv, gathered, force_collective=True)
+    ndist.exchange_pv_end(w)
+    eng.update_device(t["x0"], t["xr"], t["ur"], u_a, other=gathered, ego_xy=t["ego_xy"], stream=stream)
+torch.cuda.set_stream(stream)
+src[:, :, 2] += 0.25                      # other neighbour heights: the replay must gather and use the NEW windows
+eng.reset_device(t["xr"], t["ur"], stream=stream)
+g.replay()
+torch.cuda.synchronize()
+assert torch.equal(gathered, src[:, :, :ndist.PV_COLS])
+eng.reset_device(t["xr"], t["ur"], stream=stream)
+eng.update_device(t["x0"], t["xr"], t["ur"], u_b, other=src, ego_xy=t["ego_xy"], stream=stream)
+torch.cuda.synchronize()
+assert torch.equal(u_a, u_b), float((u_a - u_b).abs().max())
+assert float((u_a - u_b).abs().max()) == 0.0 and bool(torch.isfinite(u_a).all())
+dist.destroy_process_group()
+print("RCCL-ONE-RANK-OK")
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_call_path_one_rank_group():
+    """The RCCL form of the per-tick exchange (dist.exchange_pv_begin / _end: pack, all_gather_into_tensor started async, the
+    compute stream made to wait, the control step launched behind it) through a REAL RCCL communicator -- one rank, all a
+    one-GPU box offers: the gathered buffer equals the pack, the step that consumes it equals the step given the windows
+    directly, and the pair replays inside a hipGraph with new windows.  In a child process (a process group is global state)."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, root, str(port)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
