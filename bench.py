@@ -316,27 +316,29 @@ def main():
             # spins already, and the extra event costs a packet
             torch.cuda.synchronize()
 
-        # ---- parity spot check against the CPU oracle (rank 0, first tick, 64 instances) before timing
-        parity = None
-        eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
-        if check_parity:
+        # ---- parity spot check against the CPU oracle (rank 0, first tick, 64 instances).  Runs AFTER the timed region: the
+        # oracle's OpenMP phase in front of it made the 20-step timed region 3-6 % slower (23.9 against 23.2 us per step on the
+        # same box: the launching thread comes back from it on a cold core); a failed check still withholds `value`.
+        def parity_check():
+            eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
             step(0)
             fence()
-            if rank == 0:
-                from oracle import oracle as O
-                ns = min(64, B)
-                cfgo = O.default_cfg(N=N, use_fd=downwash)
-                f = None
-                if downwash:
-                    blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
-                    ego = host0["ego_xy"][:ns].copy()
-                    if cfg4:
-                        ego[host0["other_index"][:ns] < 0] = 1e9       # followers: no neighbour, gate closed
-                    f = O.downwash_batch(blob, host_other(host0)[:ns], host0["xr"][:ns], ego)
-                Xo, Uo = host0["xr"][:ns].copy(), host0["ur"][:ns].copy()
-                u_or, st_or, _ = O.step_batch(cfgo, host0["x0"][:ns], host0["xr"][:ns], host0["ur"][:ns], f, Xo, Uo)
-                u_dev = u0[:ns].cpu().numpy()
-                parity = float(np.max(np.abs(u_dev - u_or) / np.maximum(1.0, np.abs(u_or))))
+            if rank != 0:
+                return None
+            from oracle import oracle as O
+            ns = min(64, B)
+            cfgo = O.default_cfg(N=N, use_fd=downwash)
+            f = None
+            if downwash:
+                blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
+                ego = host0["ego_xy"][:ns].copy()
+                if cfg4:
+                    ego[host0["other_index"][:ns] < 0] = 1e9       # followers: no neighbour, gate closed
+                f = O.downwash_batch(blob, host_other(host0)[:ns], host0["xr"][:ns], ego)
+            Xo, Uo = host0["xr"][:ns].copy(), host0["ur"][:ns].copy()
+            u_or, st_or, _ = O.step_batch(cfgo, host0["x0"][:ns], host0["xr"][:ns], host0["ur"][:ns], f, Xo, Uo)
+            u_dev = u0[:ns].cpu().numpy()
+            return float(np.max(np.abs(u_dev - u_or) / np.maximum(1.0, np.abs(u_or))))
 
         # ---- warm-up, then EXACTLY --steps timed steps between barrier + synchronize
         eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
@@ -467,13 +469,15 @@ def main():
         mlp_ms, mlp_n = eng.timing_read("mlp")
         eng.timing_enable(0)
         st, it = eng.status()
+        parity = None                         # filled in by the caller: the checks of ALL forms run after ALL timed regions
         bad = int((st != 0).sum())
         if world > 1:
             agg = torch.tensor([bad], dtype=torch.int64, device=cdev)
             dist.all_reduce(agg)
             bad = int(agg.item())
         res = {"extra_warm": extra, "elapsed": elapsed, "launch": launch_mode, "parity": parity, "bad": bad, "rti_ms": rti_ms, "rti_n": rti_n,
-               "mlp_ms": mlp_ms, "mlp_n": mlp_n, "it": it, "step": step, "name": mode_names[mode], "region_ms": region_ms}
+               "mlp_ms": mlp_ms, "mlp_n": mlp_n, "it": it, "step": step, "name": mode_names[mode], "region_ms": region_ms,
+               "parity_fn": parity_check if check_parity else None}
         if mode == "prefetch":
             res["prefetch_stats"] = eng.prefetch_stats()
         if mode == "peer":
@@ -495,6 +499,19 @@ def main():
                 torch.cuda.set_stream(stream)
         else:
             results[m] = run_mode(m, check_parity=not args.only_timed)
+    for m, r in results.items():                  # parity spot checks (CPU oracle, OpenMP): behind every form's timed region
+        fn = r.pop("parity_fn")
+        if fn is None:
+            continue
+        if m == "prefetch" and modes[0] != "prefetch":
+            try:
+                r["parity"] = fn()
+            except Exception as e:
+                form_errors[m] = f"{type(e).__name__}: {e}"[:300]
+                torch.cuda.set_stream(stream)
+        else:
+            r["parity"] = fn()
+    results = {m: r for m, r in results.items() if m not in form_errors}
     head = results[modes[0]]                      # the north star's collective when it ran, else the only form
     elapsed, launch_mode, parity, bad, it = head["elapsed"], head["launch"], head["parity"], head["bad"], head["it"]
     rti_ms, rti_n, mlp_ms, mlp_n, step = head["rti_ms"], head["rti_n"], head["mlp_ms"], head["mlp_n"], head["step"]

@@ -72,7 +72,28 @@ struct MlpArgs {            // fused downwash (null frag = not fused)
     int other_stride;       // doubles per node of `other`: 10 (a full reference window) or 6 (positions + velocities only, what the MLP reads)
     const int *other_index; // [B] row of `other` that holds instance i's neighbour (multi-GPU: a row of the gathered buffer);
                             // < 0 = no neighbour (force 0: the plain NMPC followers of a formation); null = row i
+    int other_sys;          // 1: `other` is another process's / GPU's memory mapped through ndp_peer_open -- read it with system-scope loads
 };
+
+// Neighbour windows that live in ANOTHER agent's memory (peer windows over xGMI) are read with system-scope loads: such lines are
+// not kept coherent in this GPU's L2s, and what a kernel boundary invalidates depends on the fence scope the runtime put on the
+// dispatch packet (agent scope between back-to-back launches of one queue).  A system-scope load always fetches from the owner's
+// memory -- two 8-byte loads per lane and launch instead of one 16-byte load, nothing else changes.  Local windows: plain loads.
+typedef double ndp_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double ld_other(const double *p, int sys)
+{
+    return sys ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *p;
+}
+__device__ __forceinline__ ndp_d2 ld_other2(const double *p, int sys)
+{
+    if (sys) {
+        ndp_d2 r;
+        r[0] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        r[1] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return r;
+    }
+    return *(const ndp_d2 *)p;
+}
 
 // Work list of instances whose QP needs the interior-point loop (batches with more instances than SIMDs).  An
 // interior-point solve costs ~18 Riccati sweeps against 1 for the early exit, so with several instances per SIMD one such
@@ -247,7 +268,8 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         // the gate's four numbers are only REQUESTED here; the comparison comes after the barrier (consuming them here would
         // park the wave on the whole in-order load queue -- s_waitcnt vmcnt(0) -- before the weight transfer is even issued)
         const double *exy = ma.ego_xy ? ma.ego_xy + (size_t)inst * 2 : oth;
-        const double g_ox = oth[0], g_oy = oth[1], g_ex = exy[0], g_ey = exy[1];
+        const int osys = ma.other_sys;
+        const double g_ox = ld_other(oth, osys), g_oy = ld_other(oth + 1, osys), g_ex = exy[0], g_ey = exy[1];
         const int jr = j < np1 ? j : np1 - 1;
         float zb[3], o[3];
         // Network input (downwash_nn.py:22-23): columns 0..5 of (other - ego reference), rows 0..N, subtracted in fp64.  Lane
@@ -261,7 +283,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
 #pragma unroll
         for (int t = 0; t < ZR; ++t) {
             const int l3 = lane + 64 * t, r3 = l3 / 3, c3 = l3 - 3 * r3, rc = r3 < np1 ? r3 : np1 - 1;
-            dv[t] = *(const d2_t *)(oth + (size_t)rc * st + 2 * c3);
+            dv[t] = ld_other2(oth + (size_t)rc * st + 2 * c3, osys);
             ev[t] = *(const d2_t *)(io.xr + (size_t)rc * NX + 2 * c3);
         }
         const LdsMap m = make_map(N);
@@ -559,7 +581,7 @@ __device__ __forceinline__ bool gate_open(const double *other_inst, const double
 __global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, const double *__restrict__ other,
                                                   const double *__restrict__ ego, const double *__restrict__ ego_xy,
                                                   float *__restrict__ fout, int rows, int np1, double r2,
-                                                  int other_stride, const int *__restrict__ other_index)
+                                                  int other_stride, const int *__restrict__ other_index, int other_sys)
 {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
@@ -577,12 +599,15 @@ __global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, 
     const int orow = other_index ? other_index[inst] : inst;          // see MlpArgs
     const double *oth = other + (size_t)(orow < 0 ? 0 : orow) * np1 * other_stride;
     bool open = valid && orow >= 0;
-    if (ego_xy) open = open && gate_open(oth, ego_xy + inst * 2, r2);
+    if (ego_xy) {
+        const double oxy[2] = {ld_other(oth, other_sys), ld_other(oth + 1, other_sys)};
+        open = open && gate_open(oxy, ego_xy + inst * 2, r2);
+    }
     // downwash_nn.py:22-23: (other - ego)[:, 0:6] in fp64, cast to fp32
     float zb[3], o[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
-        zb[s] = (float)(oth[(size_t)k * other_stride + 2 * s + h] - ego[(size_t)rowc * NX + 2 * s + h]);
+        zb[s] = (float)(ld_other(oth + (size_t)k * other_stride + 2 * s + h, other_sys) - ego[(size_t)rowc * NX + 2 * s + h]);
     mlp_tile(wl, zb, lane, o);
     if (valid && h == 0) {
 #pragma unroll
@@ -669,7 +694,7 @@ __device__ __forceinline__ void mlp_tile_stream(g_cf32 fr, const float zb[3], in
 __global__ __launch_bounds__(256)
 void mlp_stream_kernel(const float *__restrict__ fr, const double *__restrict__ other, const double *__restrict__ ego,
                        const double *__restrict__ ego_xy, float *__restrict__ fout, float *__restrict__ fout1, int rows, int np1, double r2,
-                       int other_stride, const int *__restrict__ other_index, unsigned long long *proto)
+                       int other_stride, const int *__restrict__ other_index, unsigned long long *proto, int other_sys)
 {
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -688,11 +713,14 @@ void mlp_stream_kernel(const float *__restrict__ fr, const double *__restrict__ 
     const int orow = other_index ? other_index[inst] : inst;
     const double *oth = other + (size_t)(orow < 0 ? 0 : orow) * np1 * other_stride;
     bool open = valid && orow >= 0;
-    if (ego_xy) open = open && gate_open(oth, ego_xy + inst * 2, r2);
+    if (ego_xy) {
+        const double oxy[2] = {ld_other(oth, other_sys), ld_other(oth + 1, other_sys)};
+        open = open && gate_open(oxy, ego_xy + inst * 2, r2);
+    }
     float zb[3], o[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
-        zb[s] = (float)(oth[(size_t)k * other_stride + 2 * s + h] - ego[(size_t)rowc * NX + 2 * s + h]);
+        zb[s] = (float)(ld_other(oth + (size_t)k * other_stride + 2 * s + h, other_sys) - ego[(size_t)rowc * NX + 2 * s + h]);
     mlp_tile_stream(fr, zb, lane, o);
     if (!proto) {
         if (valid && h == 0) {
@@ -1232,6 +1260,22 @@ __global__ void peer_epoch_kernel(PeerPubArgs a)
 // ------------------------------------------------------------------------------------------ C-ABI
 using namespace ndp;
 
+// Address ranges this process mapped from other processes / GPUs (ndp_peer_open): neighbour windows inside one are read with
+// system-scope loads (MlpArgs::other_sys).  A handful of entries, looked up once per launch.
+struct PeerRange { uintptr_t lo, hi; };
+static std::mutex g_peer_mu;
+static std::vector<PeerRange> g_peer_ranges;
+static int peer_mapped(const void *p)
+{
+    if (!p) return 0;
+    const uintptr_t a = (uintptr_t)p;
+    std::lock_guard<std::mutex> lk(g_peer_mu);
+    for (const PeerRange &r : g_peer_ranges)
+        if (a >= r.lo && a < r.hi) return 1;
+    return 0;
+}
+
+
 // RTI_K(...): the rti_kernel instantiation to reference.  -DNDP_DEV_HEADLINE_ONLY (kernel development builds only, never
 // the shipped library) collapses every instantiation but the reference configuration's two onto rti_kernel<3, 4, false, 20>, so
 // that an experiment on the headline kernel compiles in 20 s instead of 3 min; such a library serves N = 20, n_rti = 1 only.
@@ -1492,9 +1536,18 @@ int ndp_peer_alloc(int device, size_t bytes, void **ptr, unsigned char *handle64
     if (!ptr || !handle64 || bytes == 0) return -1;
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "ndp_peer_*: the handle is passed as 64 bytes");
     if (hipSetDevice(device) != hipSuccess) return -2;
+    // Fine-grained device memory: coherent between agents while kernels run (the epoch / acknowledgement words are polled by
+    // running kernels of two GPUs, the slots are written here and read there one launch later).  Ordinary (coarse-grained)
+    // memory if the runtime refuses, or when NDP_PEER_COARSE=1 asks for it; the protocol's accesses are system-scope either way.
     void *p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) return -3;
+    const char *coarse = getenv("NDP_PEER_COARSE");
+    if ((coarse && coarse[0] == '1') || hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return -3;
+    }
     if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return -3; }      // epochs, acknowledgements, counters start at 0
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return -3; }
     hipIpcMemHandle_t hd;
     if (hipIpcGetMemHandle(&hd, p) != hipSuccess) { (void)hipFree(p); return -4; }
     memcpy(handle64, &hd, 64);
@@ -1510,6 +1563,16 @@ int ndp_peer_open(int device, const unsigned char *handle64, void **ptr)
     memcpy(&hd, handle64, 64);
     void *p = nullptr;
     if (hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return -3; }
+    {   // remember the mapped range: windows inside it are read with system-scope loads (see peer_mapped)
+        void *base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, p) != hipSuccess || !base || size == 0) {
+            (void)hipGetLastError();
+            base = p; size = (size_t)1 << 40;       // extent unknown: err on the side of system-scope loads
+        }
+        std::lock_guard<std::mutex> lk(g_peer_mu);
+        g_peer_ranges.push_back({(uintptr_t)base, (uintptr_t)base + size});
+    }
     *ptr = p;
     return 0;
 }
@@ -1518,6 +1581,11 @@ int ndp_peer_close(int device, void *ptr)
 {
     if (!ptr) return -1;
     if (hipSetDevice(device) != hipSuccess) return -2;
+    {
+        std::lock_guard<std::mutex> lk(g_peer_mu);
+        for (size_t i = 0; i < g_peer_ranges.size(); ++i)
+            if ((uintptr_t)ptr >= g_peer_ranges[i].lo && (uintptr_t)ptr < g_peer_ranges[i].hi) { g_peer_ranges.erase(g_peer_ranges.begin() + i); break; }
+    }
     return hipIpcCloseMemHandle(ptr) == hipSuccess ? 0 : -3;
 }
 
@@ -1795,7 +1863,7 @@ static int launch_mlp(ndp_handle *h, const Neigh &nb, const double *d_ego, float
     int rc = begin_timing(h, s, 1);
     if (rc) return rc;
     hipLaunchKernelGGL(mlp_kernel, dim3(grid), dim3(256), FR_TOTAL * sizeof(float), s, (const float *)h->dFrag, nb.other, d_ego, nb.ego_xy, d_f,
-                       rows, np1, h->cfg.r_horiz * h->cfg.r_horiz, nb.stride, nb.index);
+                       rows, np1, h->cfg.r_horiz * h->cfg.r_horiz, nb.stride, nb.index, peer_mapped(nb.other));
     NDP_HIP(h, hipGetLastError());
     return end_timing(h, s);
 }
@@ -1816,7 +1884,7 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
                  so ? so->Xm : nullptr, so ? so->Um : nullptr, d_dbg, h->dStamps};
     const bool fused = nb && nb->other;
     MlpArgs ma{fused ? h->dFrag : nullptr, fused ? nb->other : nullptr, fused ? nb->ego_xy : nullptr, h->dForce,
-               h->cfg.r_horiz * h->cfg.r_horiz, fused ? nb->stride : NX, fused ? nb->index : nullptr};
+               h->cfg.r_horiz * h->cfg.r_horiz, fused ? nb->stride : NX, fused ? nb->index : nullptr, fused ? peer_mapped(nb->other) : 0};
     QueueArgs qa{h->dQctr, h->dQids};
     const int B = h->cfg.batch, W = h->waves;
     LateArgs la{prefetched ? h->dProto : nullptr, {h->dForceAB[0], h->dForceAB[1]}, h->prefetch_timeout_us,
@@ -1999,7 +2067,7 @@ int ndp_downwash_prefetch_device(ndp_handle *h, const void *d_other, int other_s
     hipLaunchKernelGGL(prefetch_gate_kernel, dim3(1), dim3(64), 0, a, h->dProto, h->prefetch_timeout_us, h->pf_groups_rti);
     hipLaunchKernelGGL(mlp_stream_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, a, (const float *)h->dFrag, (const double *)d_other,
                        (const double *)d_ego_ref, (const double *)d_ego_xy, h->dForceAB[0], h->dForceAB[1], rows, np1,
-                       h->cfg.r_horiz * h->cfg.r_horiz, other_stride, (const int *)d_other_index, h->dProto);
+                       h->cfg.r_horiz * h->cfg.r_horiz, other_stride, (const int *)d_other_index, h->dProto, peer_mapped(d_other));
     hipLaunchKernelGGL(prefetch_done_kernel, dim3(1), dim3(64), 0, a, h->dProto);
     NDP_HIP(h, hipGetLastError());
     return 0;
@@ -2245,7 +2313,7 @@ int ndp_debug_downwash_stream_device(ndp_handle *h, const void *d_other, const v
     const int ntiles = (rows + 31) / 32;
     hipLaunchKernelGGL(mlp_stream_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, s, (const float *)h->dFrag, (const double *)d_other,
                        (const double *)d_ego_ref, (const double *)d_ego_xy, (float *)d_f_out, (float *)d_f_out, rows, np1,
-                       h->cfg.r_horiz * h->cfg.r_horiz, NX, (const int *)nullptr, (unsigned long long *)nullptr);
+                       h->cfg.r_horiz * h->cfg.r_horiz, NX, (const int *)nullptr, (unsigned long long *)nullptr, peer_mapped(d_other));
     NDP_HIP(h, hipGetLastError());
     return note_stream(h, s);
 }
