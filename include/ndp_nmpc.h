@@ -289,8 +289,11 @@ int ndp_rollout_device(ndp_handle *h, int ticks, double t0, double dt_tick, int 
  * reader's acknowledgement), bounded waits and their counters: csrc/peer_epoch.hpp.
  *   ndp_peer_layout : bytes of a buffer whose slots hold n_doubles each ([B][N+1][10] windows: n = B*(N+1)*10), the offset
  *                     of slot 0 and the slot stride (bytes).  The first 512 bytes are protocol words.
- *   ndp_peer_alloc  : zeroed device memory on `device` -> *ptr and its IPC handle (64 bytes).
- *   ndp_peer_open   : maps another process's buffer into this process for use on `device` -> *ptr.
+ *   ndp_peer_alloc  : zeroed device memory on `device` -> *ptr and its IPC handle (64 bytes).  Fine-grained (coherent between
+ *                     agents while kernels run); ordinary device memory if the runtime refuses or NDP_PEER_COARSE=1 is set.
+ *   ndp_peer_open   : maps another process's buffer into this process for use on `device` -> *ptr.  The mapped range is
+ *                     remembered: neighbour windows (`other`) that lie inside it are read with system-scope loads by every
+ *                     kernel of this library, so that they are fetched from the owner's memory, not from a stale cache line.
  *   ndp_peer_publish_device : the per-tick launch described above.  d_src: this rank's windows of the tick (n_doubles, device
  *                     memory); own_buf / nb_buf: this rank's buffer and the mapped neighbour buffer (the same pointer with one
  *                     rank); slot = parity of the tick (first tick = 1 -> slot 1, then alternating): the slot whose address
