@@ -735,13 +735,15 @@ def main():
                 e_h.update_end(out=u_pipe)
             tp = (time.perf_counter() - tp) / nh
             e_h.update_end(out=u_pipe)
-            in_b = 8 * (10 + 10 * (N + 1) + 4 * N) + ((8 * 10 * (N + 1) + 16) if downwash else 0)      # host -> device bytes per solve
+            # host -> device bytes per solve as they cross PCIe: x0, xr, ur, and of the caller's 10-column neighbour windows the 6
+            # position / velocity columns the gate and the network read (packed that way into the mirror), ego xy
+            in_b = 8 * (10 + 10 * (N + 1) + 4 * N) + ((8 * 6 * (N + 1) + 16) if downwash else 0)
             out["value_host_inclusive"] = {
                 "value": B / tp, "unit": "solves/s", "ms_per_step": tp * 1e3,
                 "form": "ndp_step_begin / ndp_step_end, two ticks in flight (packing + H2D of tick i+1 under tick i's kernel)",
                 "pcie_GBps_implied": (in_b + 40) * B / tp / 1e9,
                 "one_tick_at_a_time": {"value": B / th, "ms_per_step": th * 1e3, "form": "ndp_step", "pcie_GBps_implied": (in_b + 40) * B / th / 1e9},
-                "note": "pageable numpy arrays in, numpy u0 out: the inputs (%.1f MB per step) are packed into a page-locked mirror (pack threads), the "
+                "note": "pageable numpy arrays in, numpy u0 out: the inputs (%.1f MB per step across PCIe; neighbour windows as their 6 position / velocity columns) are packed into a page-locked mirror (pack threads), the "
                         "kernel reads them over PCIe and writes u0 | status | iterations into a page-locked block itself -- no DMA operation; "
                         "PCIe Gen5 x16 (63 GB/s spec) alone bounds this at %.1f M solves/s" % (in_b * B / 1e6, 63e9 / (in_b + 40) / 1e6)}
             del e_h

@@ -1294,7 +1294,9 @@ struct RtiK { static constexpr auto fn = rti_kernel<3, (WAVES == 2 && NC == 20 ?
 // read; at batch 1024 that is 4.2 MB per step -- 56 us for one core, 26-30 us for eight (measured), against ~100 us for the
 // kernel that then pulls them over PCIe.  The mirror is filled by a few persistent threads and the caller, a chunk
 // (<= PACK_CHUNK bytes) at a time.
-struct PackJob { unsigned char *dst; const unsigned char *src; size_t len; };
+// len bytes as they lie, or -- rows > 0 -- `rows` rows of `len` bytes each taken from rows src_stride bytes apart (the neighbour
+// windows: the 6 position / velocity columns of every 10-column row, all the gate and the network read)
+struct PackJob { unsigned char *dst; const unsigned char *src; size_t len; size_t rows = 0, src_stride = 0; };
 enum : size_t { PACK_CHUNK = (size_t)256 << 10 };
 struct PackPool {
     std::vector<std::thread> th;
@@ -1331,7 +1333,9 @@ struct PackPool {
         const int i = next.fetch_add(1, std::memory_order_acq_rel);
         if (i >= n) return false;
         const PackJob &j = jobs.load(std::memory_order_relaxed)[i];
-        memcpy(j.dst, j.src, j.len);
+        if (j.rows == 0) memcpy(j.dst, j.src, j.len);
+        else
+            for (size_t r = 0; r < j.rows; ++r) memcpy(j.dst + r * j.len, j.src + r * j.src_stride, j.len);
         done[i].store(1, std::memory_order_release);
         return true;
     }
@@ -2154,21 +2158,40 @@ static int step_begin_locked(ndp_handle *h, const double *x0, const double *xr, 
     ndp_handle::HostSlot &sl = h->slot[h->slot_head];
     // the slot's previous use is over: its results were handed out by ndp_step_end (busy is false), so the kernel that read
     // its input mirror and wrote its output mirror has completed and both are free to overwrite
-    struct Seg { size_t off; const void *src; size_t len; };
+    // the block of THIS step: the arrays that were given, one behind the other (256-byte aligned), so that one transfer moves
+    // exactly what the kernel reads; neighbour windows as their 6 position / velocity columns
+    struct Seg { size_t off; const void *src; size_t len; size_t rows, row_len, src_stride; };
     Seg segs[6];
     int ns = 0;
-    segs[ns++] = {h->off_x0, x0, B * NX * 8};
-    segs[ns++] = {h->off_xr, xr, nxs(h) * 8};
-    segs[ns++] = {h->off_ur, ur, nus(h) * 8};
-    if (f) segs[ns++] = {h->off_f, f, nfs(h) * 4};
-    if (other) segs[ns++] = {h->off_other, other, nxs(h) * 8};
-    if (ego_xy) segs[ns++] = {h->off_ego, ego_xy, B * 2 * 8};
+    size_t o = 0;
+    auto up256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    auto add = [&](const void *src, size_t len, size_t rows = 0, size_t row_len = 0, size_t src_stride = 0) {
+        segs[ns] = {o, src, len, rows, row_len, src_stride};
+        o += up256(len);
+        return segs[ns++].off;
+    };
+    const size_t rows_o = B * (size_t)(h->cfg.N + 1);
+    const size_t o_x0 = add(x0, B * NX * 8), o_xr = add(xr, nxs(h) * 8), o_ur = add(ur, nus(h) * 8);
+    const size_t o_f = f ? add(f, nfs(h) * 4) : 0;
+    const size_t o_other = other ? add(other, rows_o * 6 * 8, rows_o, 6 * 8, NX * 8) : 0;
+    const size_t o_ego = ego_xy ? add(ego_xy, B * 2 * 8) : 0;
+    const size_t used = o;          // <= in_bytes (the mirror holds every array at full width)
     std::vector<PackJob> jobs;
-    for (int i = 0; i < ns; ++i)
-        for (size_t o = 0; o < segs[i].len; o += PACK_CHUNK) {
-            const size_t n = segs[i].len - o < PACK_CHUNK ? segs[i].len - o : PACK_CHUNK;
-            jobs.push_back({sl.hIn + segs[i].off + o, (const unsigned char *)segs[i].src + o, n});
+    for (int i = 0; i < ns; ++i) {
+        if (segs[i].rows) {
+            const size_t rows_per = PACK_CHUNK / segs[i].src_stride;
+            for (size_t r = 0; r < segs[i].rows; r += rows_per) {
+                const size_t n = segs[i].rows - r < rows_per ? segs[i].rows - r : rows_per;
+                jobs.push_back({sl.hIn + segs[i].off + r * segs[i].row_len, (const unsigned char *)segs[i].src + r * segs[i].src_stride,
+                                segs[i].row_len, n, segs[i].src_stride});
+            }
+            continue;
         }
+        for (size_t c = 0; c < segs[i].len; c += PACK_CHUNK) {
+            const size_t n = segs[i].len - c < PACK_CHUNK ? segs[i].len - c : PACK_CHUNK;
+            jobs.push_back({sl.hIn + segs[i].off + c, (const unsigned char *)segs[i].src + c, n});
+        }
+    }
     const int nj = (int)jobs.size();
     PackPool &pool = *h->pool;
     const auto tp0 = std::chrono::steady_clock::now();
@@ -2176,17 +2199,22 @@ static int step_begin_locked(ndp_handle *h, const double *x0, const double *xr, 
     for (int i = 0; i < nj; ++i) pool.wait_job(i);
     pool.finish();
     const auto tp1 = std::chrono::steady_clock::now();
-    // the kernel reads the input mirror and writes u0 | status | iterations (| the new iterate, when asked for) into the output
-    // mirror itself: page-locked host memory, device-accessible
+    // Zero-copy: the kernel reads the input mirror itself over PCIe and writes u0 | status | iterations (| the new iterate, when
+    // asked for) into the output mirror itself: page-locked host memory, device-accessible, no DMA operation.  (One transfer of
+    // the block per step into an HBM copy on a stream of its own, beside the previous tick's kernel, was built and measured in
+    // four sessions: 85-103 us per step at batch 1024 against 90-96 this way, 290-343 against 315-342 at 4096 -- between 8 %
+    // better and 10 % worse, one tick at a time always 5 % worse.  PCIe moves ~40-48 GB/s here whoever issues the reads.  Not kept.)
     const unsigned char *ib = sl.hIn;
+    (void)used;
     Neigh nb;
-    nb.other = other ? (const double *)(ib + h->off_other) : nullptr;
-    nb.ego_xy = ego_xy ? (const double *)(ib + h->off_ego) : nullptr;
+    nb.other = other ? (const double *)(ib + o_other) : nullptr;
+    nb.stride = 6;
+    nb.ego_xy = ego_xy ? (const double *)(ib + o_ego) : nullptr;
     StepOut so;
     so.status = (int *)(sl.hOut + h->off_st); so.iters = (int *)(sl.hOut + h->off_it);
     if (want_iter) { so.Xm = (double *)(sl.hOut + h->out_bytes); so.Um = so.Xm + nxs(h); }
-    rc = enqueue_step(h, (const double *)(ib + h->off_x0), (const double *)(ib + h->off_xr), (const double *)(ib + h->off_ur),
-                      f ? (const float *)(ib + h->off_f) : nullptr, nb, (double *)(sl.hOut + h->off_u0), dump ? h->sdbg : nullptr, s, &so);
+    rc = enqueue_step(h, (const double *)(ib + o_x0), (const double *)(ib + o_xr), (const double *)(ib + o_ur),
+                      f ? (const float *)(ib + o_f) : nullptr, nb, (double *)(sl.hOut + h->off_u0), dump ? h->sdbg : nullptr, s, &so);
     if (rc) return rc;
     NDP_HIP(h, hipEventRecord(sl.evOut, s));
     sl.busy = true; sl.want_iter = want_iter; sl.dump = dump;
