@@ -259,7 +259,9 @@ int ndp_ref_window_device(ndp_handle *h, const void *d_t, void *d_xr, void *d_ur
  *                         reference's value although u[3] is an acceleration) or [0, 0, 0, g] (quirk_b1 = 0)
  *   ndp_ref_list_window : t[B] = (ros_t - start_ros_t).to_sec(): get_nmpc_pts (:79-97) = pop, append the point at
  *                         t + T_horizon, return the window; t = NULL: get_nmpc_ref_from_long_list only (:99-103)
- *   *_device            : the two halves separately, on device buffers */
+ *   *_device            : the two halves separately, on device buffers.  The ring's head is host state baked into each
+ *                         launch's arguments: these calls must NOT be captured into a hipGraph (a replay would reuse the
+ *                         slot of the captured tick); ndp_ref_window_device has no such state and is capturable. */
 int ndp_ref_list_reset(ndp_handle *h);
 int ndp_ref_list_fix_pt(ndp_handle *h, const double *x_odom, int quirk_b1);
 int ndp_ref_list_window(ndp_handle *h, const double *t, double *xr, double *ur);
