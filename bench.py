@@ -50,6 +50,27 @@ def algorithmic_bytes_per_solve(N, downwash):
     return b
 
 
+class c_stdout_to_stderr:
+    """RCCL prints a version banner to the C library's stdout when a communicator is created (RCCL 2.26: "RCCL version : ...",
+    HIP / ROCm version, host name, library path).  This program's stdout carries ONE JSON line: while a communicator is being
+    created, file descriptor 1 points at stderr, and the C buffers are flushed before it is put back."""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self._libc = ctypes.CDLL(None)
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def committed_profile(default_cfg, root=None):
     """What the committed rocprofv3 summaries say about the DEFAULT configuration's rti_kernel (batch 1024, N = 20, 1 RTI
     iteration, fused downwash, automatic QP mode, nominal starts): average duration (kernel trace) and HBM bytes per launch
@@ -126,6 +147,8 @@ def main():
                     help="N > 1 (and --config 4): vehicle-major (a formation's vehicles on different GPUs: one all-gather per step, "
                          "the default) or formation-major (all vehicles of a formation on one GPU: no exchange)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of replaying a hipGraph")
+    ap.add_argument("--torch-collective", action="store_true",
+                    help="rccl form: call torch.distributed.all_gather_into_tensor per step instead of the library's own ncclAllGather (ndp_xchg_*)")
     ap.add_argument("--graph-exchange", action="store_true",
                     help="N > 1 with the exchange on: capture gather + kernel of every step into the hipGraph too (default: host launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: bounded sample, about this many seconds")
@@ -176,7 +199,9 @@ def main():
         if same_dev:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            with c_stdout_to_stderr():
+                dist.init_process_group("nccl", device_id=dev)
+                dist.barrier()                # (the communicator is created by the first collective at the latest)
 
     import ndp_nmpc_qd_amd as ndp
     from ndp_nmpc_qd_amd import dist as ndist
@@ -245,12 +270,33 @@ def main():
             modes = [m for m in modes if m != "peer"]
             if not modes:
                 raise
+    xchg, xchg_err = None, None
     if "rccl" in modes:
         gathered = [torch.empty(world * B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev) for _ in range(2)]
         pv_local = torch.empty(B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev)
+        # The all-gather issued by the C-ABI library itself (ndp_xchg_*: pack launch + ncclAllGather on a HIP stream of its own, two
+        # event operations, ~10 us of host time per tick) instead of torch.distributed's all_gather_into_tensor (~25 us of host time
+        # per call: more than a control step lasts).  A real communicator also with ONE rank.  Creation is collective: all ranks
+        # use it or none does (--torch-collective forces the torch.distributed call).
+        if not args.torch_collective and not same_dev:
+            ok_here = 1
+            try:
+                with c_stdout_to_stderr():
+                    xchg = ndist.RcclExchange(B, N, local_rank)
+            except Exception as e:
+                xchg_err, ok_here = f"{type(e).__name__}: {e}"[:200], 0
+            if world > 1:
+                okt = torch.tensor([ok_here], dtype=torch.int64, device=cdev)
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                if int(okt.item()) == 0 and xchg is not None:
+                    xchg.close()
+                    xchg, xchg_err = None, "RcclExchange could not be created on every rank"
+    rccl_form = ("rccl all-gather per step, issued by the library on its own HIP stream (ndp_xchg_*)" + ("" if world > 1 else "; one rank: a real communicator, no xGMI traffic")
+                 if xchg is not None else
+                 "rccl all-gather per step through torch.distributed" + ("" if world > 1 else " (one rank: the pack only, no RCCL call)"))
     mode_names = {"prefetch": "none (one GPU); downwash of tick t+1 on a second stream beside the control step of tick t",
                   "fused": "none (one GPU); gate + MLP fused into the control-step launch",
-                  "none": "none", "rccl": "rccl all-gather per step" + ("" if world > 1 else " (one rank: the pack only, no RCCL call)"),
+                  "none": "none", "rccl": rccl_form,
                   "peer": "peer windows over xGMI: one publish (copy launch + one-wave epoch launch) per step, read by the control-step kernel"}
 
     def host_other(h):
@@ -264,11 +310,14 @@ def main():
     def run_mode(mode, check_parity):
         """Parity spot check, warm-up and EXACTLY --steps timed steps of one exchange form; returns its measurements."""
         exchange = mode == "rccl"
-        pending = {}
+        pending, bound = {}, {}
 
         def prefetch(i):
-            if exchange:
-                pending[i] = ndist.exchange_pv_begin(ticks[i % T]["xr"], pv_local, gathered[i % 2])   # one RCCL all-gather over xGMI
+            if exchange and xchg is not None:
+                xchg.begin(ticks[i % T]["xr"], gathered[i % 2], stream)                              # one RCCL all-gather over xGMI
+                pending[i] = None
+            elif exchange:
+                pending[i] = ndist.exchange_pv_begin(ticks[i % T]["xr"], pv_local, gathered[i % 2])   # the same through torch.distributed
 
         def step(i, first=True, last=True):
             """One control tick.  first / last: position in a chain of consecutive ticks (prefetch form: the chain's first tick
@@ -289,12 +338,24 @@ def main():
                 if exchange:
                     if i not in pending:
                         prefetch(i)
-                    ndist.exchange_pv_end(pending.pop(i))
-                    if cfg4:
-                        other, oidx = gathered[i % 2], d["other_index"]
+                    w = pending.pop(i)
+                    if xchg is not None:
+                        xchg.end(stream)                 # (the gather begun last is tick i's: end(i) always precedes begin(i + 1))
                     else:
-                        other = gathered[i % 2].view(world, B, N + 1, ndist.PV_COLS)[ndist.neighbour_rank(rank, world)]
+                        ndist.exchange_pv_end(w)
                     prefetch(i + 1)
+                    # the step on (tick i % T, gathered buffer i % 2): argument checks once, then one ctypes call per launch -- this
+                    # loop launches from the host at the control step's own pace
+                    key = (i % T, i % 2)
+                    if key not in bound:
+                        if cfg4:
+                            other, oidx = gathered[i % 2], d["other_index"]
+                        else:
+                            other = gathered[i % 2].view(world, B, N + 1, ndist.PV_COLS)[ndist.neighbour_rank(rank, world)]
+                        bound[key] = eng.bind_update_device(d["x0"], d["xr"], d["ur"], u0, other=other, ego_xy=d["ego_xy"], stream=stream,
+                                                            other_index=oidx)
+                    bound[key]()
+                    return
                 elif mode == "peer":
                     other = peer.publish_device(d["xr"], stream)     # this tick's publish launch; the neighbour's slot of this tick
                     oidx = peer_oidx if cfg4 else None
@@ -307,7 +368,10 @@ def main():
 
         def fence():
             for w in list(pending.values()):      # a gather started for a tick that is never solved (end of a phase)
-                ndist.exchange_pv_end(w)
+                if xchg is not None and exchange:
+                    xchg.end(stream)
+                else:
+                    ndist.exchange_pv_end(w)
             pending.clear()
             if world > 1:
                 dist.barrier()
@@ -347,7 +411,7 @@ def main():
         fence()
         if exchange:                              # the first timed tick's windows are in place before the clock starts; every
             prefetch(args.warmup)                 # timed step then starts exactly one gather (the next tick's) and one kernel
-            ndist.exchange_pv_end(pending[args.warmup])
+            ndist.exchange_pv_end(pending[args.warmup])       # (torch form; the library's form is waited for on the device, in step)
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -366,7 +430,9 @@ def main():
                 with torch.cuda.stream(stream_b):
                     gt[2].replay()
             gt[0].replay()
-        want_graph = not args.no_graph and (not exchange or args.graph_exchange or world == 1)
+        # (the library-issued gather runs on its own stream: inside ONE hipGraph such a branch executes in line with the kernels on
+        # ROCm 7.2 -- measured 305 against 281 us per step of 12 288 instances -- so that form is launched from the host)
+        want_graph = not args.no_graph and (not exchange or args.graph_exchange or (world == 1 and xchg is None))
         if want_graph:
             try:
                 base = ((args.warmup + T - 1) // T) * T          # a multiple of T: the replayed cycle starts at tick 0
@@ -387,7 +453,10 @@ def main():
                             else:
                                 step(first + i, first=i == 0, last=i == n_cap - 1)
                         for w in list(pending.values()):         # the last step's prefetch belongs to the captured cycle
-                            ndist.exchange_pv_end(w)
+                            if xchg is not None and exchange:
+                                xchg.end(stream)                 # (joins the exchange stream back into the capture)
+                            else:
+                                ndist.exchange_pv_end(w)
                         pending.clear()
                     torch.cuda.set_stream(stream)
                     gb = None
@@ -667,6 +736,8 @@ def main():
                 out["secondary_form_failed"] = True
             if peer_err:
                 out["exchange"]["peer"] = {"error": peer_err}
+            if xchg_err and "rccl" in out["exchange"]:
+                out["exchange"]["rccl"]["library_collective_unavailable"] = xchg_err
             out["exchange"]["headline"] = modes[0]
         extras = world == 1 and not args.only_timed and not cfg4 and args.perturb == "nominal" and args.qp_mode == 0
         if extras:
@@ -826,6 +897,8 @@ def main():
         print(json.dumps(out), flush=True)
     else:
         fail = False
+    if xchg is not None:
+        xchg.close()
     if peer is not None:
         peer.close()
     if world > 1:

@@ -315,6 +315,31 @@ int ndp_peer_stats(int device, const void *own_buf, unsigned long long *out4);
 int ndp_peer_close(int device, void *ptr);
 int ndp_peer_free(int device, void *ptr);
 
+/* ---- The neighbour exchange as ONE RCCL all-gather per control tick, issued by the library on a HIP stream of its own.
+ * Replaces the same PredXU traffic (nmpc_node.py:116-133,229-230 -> ndp_nmpc_leader_node.py:40,60-76) with the collective the
+ * build contract names: every rank contributes the position / velocity columns of its windows ([B_local][N+1][6] fp64, all the
+ * gate and the network read, downwash_nn.py:22), every rank receives all of them ([world * B_local][N+1][6]; rank r's leaders
+ * read the rows of rank (r+1) % world, or the rows other_index names).  RCCL is bound at run time (rccl_path: the librccl the
+ * process already holds, e.g. torch's -- NULL or "" = the loader's search path); one process per GPU, one ndp_xchg per process.
+ *   ndp_xchg_unique_id : rank 0 draws the communicator's id (128 bytes) and hands it to the others (any channel)
+ *   ndp_xchg_create    : collective -- every rank calls it with the same id; creates the communicator, the exchange stream
+ *                        (its own hardware queue) and two events
+ *   ndp_xchg_begin     : packs this rank's d_xr ([rows][10] doubles, rows = B_local * (N+1)) and starts the all-gather into
+ *                        d_gathered on the exchange stream, ordered behind everything `after_stream` holds so far; returns at
+ *                        once.  The windows are trajectory-generator output (functions of time): the gather of tick i+1 is
+ *                        started before tick i's control step is launched and runs beside it (two gathered buffers).
+ *   ndp_xchg_end       : `stream` waits on the device for the gather started last; the control step launched next on `stream`
+ *                        may read d_gathered.  No host synchronisation anywhere; begin / end / step are capturable together.
+ * All return 0 or a negative error code (-20 / -21: RCCL not found / symbols missing, -22: an RCCL call failed, see
+ * ndp_xchg_last_error). */
+typedef struct ndp_xchg ndp_xchg;
+int ndp_xchg_unique_id(const char *rccl_path, unsigned char *id128);
+int ndp_xchg_create(int device, int rank, int world, const unsigned char *id128, const char *rccl_path, ndp_xchg **out);
+int ndp_xchg_begin(ndp_xchg *x, const void *d_xr, size_t rows, void *d_gathered, void *after_stream);
+int ndp_xchg_end(ndp_xchg *x, void *stream);
+const char *ndp_xchg_last_error(const ndp_xchg *x);
+int ndp_xchg_destroy(ndp_xchg *x);
+
 /* Test hook: number of doubles of the LDS image dump, and a step that also dumps it (B = 1 use). */
 int ndp_debug_lds_doubles(int N);
 /* Test hook: where things sit in that dump: out8 = {XI, MB, CB, MB stride, CB stride, image size, first stamp, 0} (doubles). */

@@ -296,6 +296,12 @@ class BatchedNMPC:
 
         other: [B,N+1,10] neighbour windows, or -- with other_index (int32[B]: row of `other` holding instance i's
         neighbour, < 0 = none) -- any [rows,N+1,10] or [rows,N+1,6] buffer, e.g. what an all-gather over the GPUs left."""
+        self.bind_update_device(x0, xr, ur, u0_out, f=f, other=other, ego_xy=ego_xy, stream=stream, other_index=other_index)()
+
+    def bind_update_device(self, x0, xr, ur, u0_out, f=None, other=None, ego_xy=None, stream=None, other_index=None):
+        """update_device with the argument checks done ONCE: returns a callable that enqueues the step on the same buffers (one
+        ctypes call, ~3 us of host time instead of ~13) -- for loops that launch from the host at the control step's own pace.
+        The tensors must stay alive and in place for as long as the callable is used."""
         import torch
         B, N = self.B, self.N
         stride = 10
@@ -315,11 +321,15 @@ class BatchedNMPC:
             optr = C.c_void_p(other.data_ptr())
         else:
             optr = self._dptr(other, torch.float64, (B, N + 1, 10))
-        self._check(self._lib.ndp_step_device_ex(
-            self._h, self._dptr(x0, torch.float64, (B, 10)), self._dptr(xr, torch.float64, (B, N + 1, 10)),
-            self._dptr(ur, torch.float64, (B, N, 4)), self._dptr(f, torch.float32, (B, N + 1, 3)),
-            optr, stride, self._dptr(other_index, torch.int32, (B,)), self._dptr(ego_xy, torch.float64, (B, 2)),
-            self._dptr(u0_out, torch.float64, (B, 4)), self._stream(stream)), "ndp_step_device")
+        args = (self._h, self._dptr(x0, torch.float64, (B, 10)), self._dptr(xr, torch.float64, (B, N + 1, 10)),
+                self._dptr(ur, torch.float64, (B, N, 4)), self._dptr(f, torch.float32, (B, N + 1, 3)),
+                optr, stride, self._dptr(other_index, torch.int32, (B,)), self._dptr(ego_xy, torch.float64, (B, 2)),
+                self._dptr(u0_out, torch.float64, (B, 4)), self._stream(stream))
+        fn, check = self._lib.ndp_step_device_ex, self._check
+
+        def launch():
+            check(fn(*args), "ndp_step_device")
+        return launch
 
     # ------------------------------------------------------------------ downwash one tick ahead (second stream)
     def downwash_prefetch_device(self, other, ego_ref, ego_xy=None, other_index=None, after_stream=None, on_stream=None):

@@ -16,6 +16,8 @@
 // There is no CPU fallback: every entry point fails (<0) if HIP is unusable.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -1255,6 +1257,17 @@ __global__ void peer_epoch_kernel(PeerPubArgs a)
     if (!PP::wait_epoch(a.nb, t, a.timeout_us)) a.own[PEER_W_STAT + PEER_STAT_EPOCH_TIMEOUT] += 1;
 }
 
+// ------------------------------------------------------------------------------------------ RCCL exchange: the pack
+// rows x [10] reference windows -> rows x [6]: the position / velocity columns, all that travels (downwash_nn.py:22).  One 16-byte
+// piece per thread: piece p of row r = columns 2p, 2p + 1.
+__global__ __launch_bounds__(256) void pack_pv_kernel(const double *__restrict__ xr, double *__restrict__ pv, size_t rows)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 3) return;
+    const size_t r = i / 3, p = i - r * 3;
+    reinterpret_cast<double2 *>(pv)[i] = *reinterpret_cast<const double2 *>(xr + r * NX + 2 * p);
+}
+
 }  // namespace ndp
 
 // ------------------------------------------------------------------------------------------ C-ABI
@@ -1622,6 +1635,131 @@ int ndp_peer_publish_device(int device, const void *d_src, size_t n_doubles, voi
     hipLaunchKernelGGL(peer_publish_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(peer_epoch_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ---- The north star's collective issued by the library itself: one RCCL all-gather per control tick of the ranks' position /
+// velocity windows, on a HIP stream of its own beside the control-step kernel (ordered by events, no host wait).  RCCL is bound at
+// run time (dlopen of the library the process already holds -- torch's -- or the system's): the C-ABI library carries no link-time
+// dependency on it and every other entry point works without it.
+namespace {
+typedef struct { char internal[128]; } rccl_uid;
+typedef int (*fn_uid)(rccl_uid *);
+typedef int (*fn_init)(void **, int, rccl_uid, int);
+typedef int (*fn_ag)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*fn_destroy)(void *);
+typedef const char *(*fn_errstr)(int);
+struct RcclApi {
+    void *lib = nullptr;
+    fn_uid uid = nullptr; fn_init init = nullptr; fn_ag allgather = nullptr; fn_destroy destroy = nullptr; fn_errstr errstr = nullptr;
+};
+std::mutex g_rccl_mu;
+RcclApi g_rccl;
+int rccl_bind(const char *path)
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return 0;
+    void *l = nullptr;
+    if (path && path[0]) l = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!l) l = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!l) l = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!l) return -20;
+    RcclApi a;
+    a.lib = l;
+    a.uid = (fn_uid)dlsym(l, "ncclGetUniqueId"); a.init = (fn_init)dlsym(l, "ncclCommInitRank");
+    a.allgather = (fn_ag)dlsym(l, "ncclAllGather"); a.destroy = (fn_destroy)dlsym(l, "ncclCommDestroy");
+    a.errstr = (fn_errstr)dlsym(l, "ncclGetErrorString");
+    if (!a.uid || !a.init || !a.allgather || !a.destroy) return -21;
+    g_rccl = a;
+    return 0;
+}
+}  // namespace
+
+struct ndp_xchg {
+    int device = 0, rank = 0, world = 1;
+    void *comm = nullptr;
+    hipStream_t cs = nullptr;                 // the exchange's own stream (another priority level: its own hardware queue)
+    hipEvent_t evReady = nullptr, evDone = nullptr;
+    double *send = nullptr;                   // packed windows of this rank
+    size_t send_doubles = 0;
+    std::string err;
+};
+
+int ndp_xchg_unique_id(const char *rccl_path, unsigned char *id128)
+{
+    if (!id128) return -1;
+    int rc = rccl_bind(rccl_path);
+    if (rc) return rc;
+    rccl_uid u;
+    if (g_rccl.uid(&u) != 0) return -22;
+    memcpy(id128, u.internal, 128);
+    return 0;
+}
+
+int ndp_xchg_create(int device, int rank, int world, const unsigned char *id128, const char *rccl_path, ndp_xchg **out)
+{
+    if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return -1;
+    *out = nullptr;
+    int rc = rccl_bind(rccl_path);
+    if (rc) return rc;
+    if (hipSetDevice(device) != hipSuccess) return -2;
+    std::unique_ptr<ndp_xchg> x(new (std::nothrow) ndp_xchg);
+    if (!x) return -4;
+    x->device = device; x->rank = rank; x->world = world;
+    rccl_uid u;
+    memcpy(u.internal, id128, 128);
+    if (g_rccl.init(&x->comm, world, u, rank) != 0) return -22;      // collective: every rank calls it
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&x->cs, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipEventCreateWithFlags(&x->evReady, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&x->evDone, hipEventDisableTiming) != hipSuccess) {
+        (void)g_rccl.destroy(x->comm);
+        return -3;
+    }
+    *out = x.release();
+    return 0;
+}
+
+// rows = B_local * (N + 1) windows rows of d_xr ([rows][10] doubles) -> d_gathered ([world * rows][6]); everything `after_stream`
+// holds so far comes first, nothing waits on the host
+int ndp_xchg_begin(ndp_xchg *x, const void *d_xr, size_t rows, void *d_gathered, void *after_stream)
+{
+    if (!x || !d_xr || !d_gathered || rows == 0) return -1;
+    if (hipSetDevice(x->device) != hipSuccess) return -2;
+    if (x->send_doubles < rows * 6) {
+        if (x->send) { (void)hipStreamSynchronize(x->cs); (void)hipFree(x->send); x->send = nullptr; }
+        if (hipMalloc((void **)&x->send, rows * 6 * sizeof(double)) != hipSuccess) return -3;
+        x->send_doubles = rows * 6;
+    }
+    if (hipEventRecord(x->evReady, (hipStream_t)after_stream) != hipSuccess || hipStreamWaitEvent(x->cs, x->evReady, 0) != hipSuccess) return -3;
+    const size_t pieces = rows * 3;
+    hipLaunchKernelGGL(pack_pv_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, x->cs, (const double *)d_xr, x->send, rows);
+    if (hipGetLastError() != hipSuccess) return -3;
+    const int r = g_rccl.allgather(x->send, d_gathered, rows * 6, /* ncclFloat64 */ 8, x->comm, x->cs);
+    if (r != 0) { x->err = g_rccl.errstr ? g_rccl.errstr(r) : "ncclAllGather failed"; return -22; }
+    return hipEventRecord(x->evDone, x->cs) == hipSuccess ? 0 : -3;
+}
+
+// `stream` waits (on the device) for the gather started last
+int ndp_xchg_end(ndp_xchg *x, void *stream)
+{
+    if (!x) return -1;
+    return hipStreamWaitEvent((hipStream_t)stream, x->evDone, 0) == hipSuccess ? 0 : -3;
+}
+
+const char *ndp_xchg_last_error(const ndp_xchg *x) { return x ? x->err.c_str() : "null exchange"; }
+
+int ndp_xchg_destroy(ndp_xchg *x)
+{
+    if (!x) return -1;
+    (void)hipSetDevice(x->device);
+    if (x->cs) (void)hipStreamSynchronize(x->cs);
+    if (x->comm) (void)g_rccl.destroy(x->comm);
+    if (x->send) (void)hipFree(x->send);
+    if (x->evReady) (void)hipEventDestroy(x->evReady);
+    if (x->evDone) (void)hipEventDestroy(x->evDone);
+    if (x->cs) (void)hipStreamDestroy(x->cs);
+    delete x;
+    return 0;
 }
 
 int ndp_peer_stats(int device, const void *own_buf, unsigned long long *out4)

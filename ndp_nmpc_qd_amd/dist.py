@@ -171,6 +171,77 @@ def exchange_pv_end(work):
         work.wait()
 
 
+# ------------------------------------------------------------------------------------------- RCCL all-gather issued by the library
+def loaded_rccl_path():
+    """The librccl this process already holds (torch's), so that the C-ABI library binds the same one -- or "" (loader's search path)."""
+    try:
+        with open("/proc/self/maps") as fh:
+            for ln in fh:
+                if "librccl" in ln:
+                    return ln.split()[-1]
+    except OSError:
+        pass
+    return ""
+
+
+class RcclExchange:
+    """The per-tick neighbour exchange as ONE RCCL all-gather of the ranks' position / velocity windows, issued by the C-ABI library on
+    a HIP stream of its own (include/ndp_nmpc.h: ndp_xchg_*): pack launch + ncclAllGather + two event operations per tick, no
+    torch.distributed call on the step's path (c10d's all_gather_into_tensor costs ~25 us of host time per call -- more than a control
+    step lasts).  The communicator's id travels once through torch.distributed (any backend), or is local with one rank.
+
+        ex = RcclExchange(B_local, N, device, group)
+        ex.begin(xr_next, gathered[(i + 1) % 2], stream)      # tick i+1's windows: runs beside tick i's control step
+        ex.end(stream)                                        # `stream` waits (on the device) for the gather started last
+    """
+
+    def __init__(self, B_local, N, device, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib
+        self._lib = _lib.load()
+        self.device, self.rows = int(device), int(B_local) * (int(N) + 1)
+        multi = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if multi else 1
+        self.rank = dist.get_rank(group) if multi else 0
+        path = loaded_rccl_path().encode()
+        uid = (C.c_ubyte * 128)()
+        rc = 0
+        if self.rank == 0:
+            rc = self._lib.ndp_xchg_unique_id(path, uid)
+        payload = [(rc, bytes(uid))]
+        if multi:
+            dist.broadcast_object_list(payload, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        rc, raw = payload[0]
+        if rc:
+            raise RuntimeError(f"ndp_xchg_unique_id failed ({rc}): RCCL could not be bound")
+        uid = (C.c_ubyte * 128).from_buffer_copy(raw)
+        h = C.c_void_p()
+        rc = self._lib.ndp_xchg_create(self.device, self.rank, self.world, uid, path, C.byref(h))
+        if rc:
+            raise RuntimeError(f"ndp_xchg_create failed ({rc})")
+        self._h = h
+
+    def begin(self, xr, gathered, stream):
+        """xr: this rank's [B_local, N+1, 10] float64 windows of the tick; gathered: [world * B_local, N+1, 6]."""
+        import ctypes as C
+        assert xr.is_contiguous() and gathered.is_contiguous() and gathered.numel() == self.world * self.rows * PV_COLS
+        rc = self._lib.ndp_xchg_begin(self._h, C.c_void_p(xr.data_ptr()), self.rows, C.c_void_p(gathered.data_ptr()), C.c_void_p(stream.cuda_stream))
+        if rc:
+            raise RuntimeError(f"ndp_xchg_begin failed ({rc}): {self._lib.ndp_xchg_last_error(self._h).decode()}")
+
+    def end(self, stream):
+        import ctypes as C
+        rc = self._lib.ndp_xchg_end(self._h, C.c_void_p(stream.cuda_stream))
+        if rc:
+            raise RuntimeError(f"ndp_xchg_end failed ({rc})")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ndp_xchg_destroy(self._h)
+            self._h = None
+
+
 # ------------------------------------------------------------------------------------------- peer windows (pull model)
 class _DevMem:
     """Raw device memory as an object torch.as_tensor can alias (CUDA array interface, no ownership)."""

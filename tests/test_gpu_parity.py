@@ -1249,3 +1249,68 @@ def test_rccl_exchange_call_path_one_rank_group():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, root, str(port)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+_XCHG_ONE_RANK = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np, torch
+import ndp_nmpc_qd_amd as ndp
+from ndp_nmpc_qd_amd import dist as ndist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+B, N = 96, 20
+b = ndist.make_formation_shard(B, 0, 1, N=N)
+t = {k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur", "ego_xy", "other")}
+stream = torch.cuda.Stream(device=dev)
+torch.cuda.set_stream(stream)
+ex = ndist.RcclExchange(B, N, 0)                     # one rank: no torch.distributed needed, the communicator is real
+gathered = torch.full((B, N + 1, ndist.PV_COLS), float("nan"), dtype=torch.float64, device=dev)
+src = t["other"].clone()
+ex.begin(src, gathered, stream)
+ex.end(stream)
+eng = ndp.BatchedNMPC(B, N=N, disturbance=True)
+u_a = torch.empty(B, 4, dtype=torch.float64, device=dev)
+u_b = torch.empty(B, 4, dtype=torch.float64, device=dev)
+eng.reset_device(t["xr"], t["ur"], stream=stream)
+eng.update_device(t["x0"], t["xr"], t["ur"], u_a, other=gathered, ego_xy=t["ego_xy"], stream=stream)   # no host wait in between
+torch.cuda.synchronize()
+assert torch.equal(gathered, src[:, :, :ndist.PV_COLS])
+eng.reset_device(t["xr"], t["ur"], stream=stream)
+eng.update_device(t["x0"], t["xr"], t["ur"], u_b, other=src, ego_xy=t["ego_xy"], stream=stream)
+torch.cuda.synchronize()
+assert torch.equal(u_a, u_b), float((u_a - u_b).abs().max())
+# begin + end + control step captured into a hipGraph, replayed with other windows
+g = torch.cuda.CUDAGraph()
+eng.reset_device(t["xr"], t["ur"], stream=stream)
+torch.cuda.synchronize()
+with torch.cuda.graph(g, stream=stream, capture_error_mode="relaxed"):
+    ex.begin(src, gathered, stream)
+    ex.end(stream)
+    eng.update_device(t["x0"], t["xr"], t["ur"], u_a, other=gathered, ego_xy=t["ego_xy"], stream=stream)
+torch.cuda.set_stream(stream)
+src[:, :, 2] += 0.25
+eng.reset_device(t["xr"], t["ur"], stream=stream)
+g.replay()
+torch.cuda.synchronize()
+assert torch.equal(gathered, src[:, :, :ndist.PV_COLS])
+eng.reset_device(t["xr"], t["ur"], stream=stream)
+eng.update_device(t["x0"], t["xr"], t["ur"], u_b, other=src, ego_xy=t["ego_xy"], stream=stream)
+torch.cuda.synchronize()
+assert torch.equal(u_a, u_b) and bool(torch.isfinite(u_a).all())
+ex.close()
+print("XCHG-ONE-RANK-OK")
+"""
+
+
+@pytest.mark.gpu
+def test_library_issued_rccl_all_gather_one_rank_communicator():
+    """ndp_xchg_* (the all-gather issued by the C-ABI library on its own stream): a REAL RCCL communicator with one rank -- the gathered
+    buffer equals the packed position / velocity columns, the control step launched behind ndp_xchg_end (no host wait) equals the
+    step given the windows directly, and begin + end + step replay from a hipGraph with new windows.  In a child process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _XCHG_ONE_RANK, root], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "XCHG-ONE-RANK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
