@@ -329,7 +329,8 @@ int ndp_peer_free(int device, void *ptr);
  *                        once.  The windows are trajectory-generator output (functions of time): the gather of tick i+1 is
  *                        started before tick i's control step is launched and runs beside it (two gathered buffers).
  *   ndp_xchg_end       : `stream` waits on the device for the gather started last; the control step launched next on `stream`
- *                        may read d_gathered.  No host synchronisation anywhere; begin / end / step are capturable together.
+ *                        may read d_gathered.  No host synchronisation anywhere; begin / end / step are capturable together
+ *                        (the FIRST ndp_xchg_begin of a given size allocates the send buffer: call it once outside a capture).
  * All return 0 or a negative error code (-20 / -21: RCCL not found / symbols missing, -22: an RCCL call failed, see
  * ndp_xchg_last_error). */
 typedef struct ndp_xchg ndp_xchg;

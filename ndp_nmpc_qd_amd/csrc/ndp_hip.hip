@@ -1684,6 +1684,8 @@ struct ndp_xchg {
     std::string err;
 };
 
+int ndp_xchg_destroy(ndp_xchg *x);
+
 int ndp_xchg_unique_id(const char *rccl_path, unsigned char *id128)
 {
     if (!id128) return -1;
@@ -1712,7 +1714,7 @@ int ndp_xchg_create(int device, int rank, int world, const unsigned char *id128,
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&x->cs, hipStreamNonBlocking, hi) != hipSuccess ||
         hipEventCreateWithFlags(&x->evReady, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&x->evDone, hipEventDisableTiming) != hipSuccess) {
-        (void)g_rccl.destroy(x->comm);
+        (void)ndp_xchg_destroy(x.release());      // (releases whatever exists: communicator, stream, events)
         return -3;
     }
     *out = x.release();
