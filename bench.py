@@ -312,9 +312,24 @@ def main():
         exchange = mode == "rccl"
         pending, bound = {}, {}
 
+        # The gather of tick i + 1 overwrites the buffer tick i - 1 read: it is ordered behind THAT control step -- through the step's own
+        # completion event (ndp_track_steps: no packet on the compute stream; 34 against 38 us per tick) when the steps are launched
+        # from the host, through an event recorded on the compute stream inside a capture.
+        track = exchange and xchg is not None and not args.graph_exchange
+        eng.track_steps(track)
+
         def prefetch(i):
             if exchange and xchg is not None:
-                xchg.begin(ticks[i % T]["xr"], gathered[i % 2], stream)                              # one RCCL all-gather over xGMI
+                ev = None
+                if track:
+                    try:
+                        ev = eng.last_step_event()
+                    except ndp.NdpError:
+                        ev = None                                                                    # no control step launched yet
+                if ev is not None:
+                    xchg.begin(ticks[i % T]["xr"], gathered[i % 2], None, after_event=ev)            # one RCCL all-gather over xGMI
+                else:
+                    xchg.begin(ticks[i % T]["xr"], gathered[i % 2], stream)
                 pending[i] = None
             elif exchange:
                 pending[i] = ndist.exchange_pv_begin(ticks[i % T]["xr"], pv_local, gathered[i % 2])   # the same through torch.distributed

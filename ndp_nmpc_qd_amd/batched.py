@@ -376,6 +376,16 @@ class BatchedNMPC:
             raise NdpError("no force slots: downwash_prefetch_device was never called")
         return torch.as_tensor(_DevMem(ptr, (self.B, self.N + 1, 3), "<f4"), device=torch.device("cuda", self.cfg.device))
 
+    def track_steps(self, on=True):
+        """Every control step launched from now on marks an event at its completion without a packet of its own (ndp_track_steps)."""
+        self._check(self._lib.ndp_track_steps(self._h, 1 if on else 0), "ndp_track_steps")
+
+    def last_step_event(self):
+        """The raw HIP event (ctypes.c_void_p) of the control step launched last (track_steps first)."""
+        ev = C.c_void_p()
+        self._check(self._lib.ndp_last_step_event(self._h, C.byref(ev)), "ndp_last_step_event")
+        return ev
+
     @property
     def work_queue(self):
         """True when this engine's steps send interior-point solves through the in-kernel work queue (cfg.work_queue)."""

@@ -15,6 +15,7 @@
 // read their inputs from, and mirror their outputs to, page-locked host slots over PCIe (zero-copy) -- see step_begin_locked.
 // There is no CPU fallback: every entry point fails (<0) if HIP is unusable.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <dlfcn.h>
 
@@ -1454,6 +1455,11 @@ struct ndp_handle {
         double *dump = nullptr;
     } slot[2];
     bool slots_ready = false;
+    // ndp_track_steps: the completion of every control step marks an event WITHOUT a packet of its own (the dispatch packet's
+    // completion signal, hipExtLaunchKernel) -- what another stream orders itself behind (ndp_xchg_begin's after_event)
+    bool track_steps = false;
+    hipEvent_t stepDone[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned step_seq = 0;
     double host_us[4] = {0, 0, 0, 0};   // last host step: packing | enqueue | wait for the results | copy-out  (ndp_debug_host_timing)
     int slot_head = 0, slot_tail = 0, slots_busy = 0;   // begin fills slot_head, end drains slot_tail
     std::unique_ptr<struct PackPool> pool;
@@ -1637,6 +1643,26 @@ int ndp_peer_publish_device(int device, const void *d_src, size_t n_doubles, voi
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+int ndp_track_steps(ndp_handle *h, int on)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    if (on && !h->stepDone[0])
+        for (auto &e : h->stepDone) NDP_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->track_steps = on != 0;
+    return 0;
+}
+
+int ndp_last_step_event(ndp_handle *h, void **event)
+{
+    if (!h || !event) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->track_steps || h->step_seq == 0) { h->err = "ndp_last_step_event: no tracked step yet (ndp_track_steps first)"; return -14; }
+    *event = (void *)h->stepDone[h->step_seq & 3];
+    return 0;
+}
+
 // ---- The north star's collective issued by the library itself: one RCCL all-gather per control tick of the ranks' position /
 // velocity windows, on a HIP stream of its own beside the control-step kernel (ordered by events, no host wait).  RCCL is bound at
 // run time (dlopen of the library the process already holds -- torch's -- or the system's): the C-ABI library carries no link-time
@@ -1722,8 +1748,8 @@ int ndp_xchg_create(int device, int rank, int world, const unsigned char *id128,
 }
 
 // rows = B_local * (N + 1) windows rows of d_xr ([rows][10] doubles) -> d_gathered ([world * rows][6]); everything `after_stream`
-// holds so far comes first, nothing waits on the host
-int ndp_xchg_begin(ndp_xchg *x, const void *d_xr, size_t rows, void *d_gathered, void *after_stream)
+// holds so far comes first (null: the windows are in place, no ordering needed), nothing waits on the host
+int ndp_xchg_begin(ndp_xchg *x, const void *d_xr, size_t rows, void *d_gathered, void *after_stream, void *after_event)
 {
     if (!x || !d_xr || !d_gathered || rows == 0) return -1;
     if (hipSetDevice(x->device) != hipSuccess) return -2;
@@ -1732,7 +1758,11 @@ int ndp_xchg_begin(ndp_xchg *x, const void *d_xr, size_t rows, void *d_gathered,
         if (hipMalloc((void **)&x->send, rows * 6 * sizeof(double)) != hipSuccess) return -3;
         x->send_doubles = rows * 6;
     }
-    if (hipEventRecord(x->evReady, (hipStream_t)after_stream) != hipSuccess || hipStreamWaitEvent(x->cs, x->evReady, 0) != hipSuccess) return -3;
+    // (every event operation is a packet the queue's command processor retires in order: ~3 us each on the stream that also
+    // carries the control steps -- callers whose windows are in place already pass no stream)
+    if (after_stream && (hipEventRecord(x->evReady, (hipStream_t)after_stream) != hipSuccess || hipStreamWaitEvent(x->cs, x->evReady, 0) != hipSuccess))
+        return -3;
+    if (after_event && hipStreamWaitEvent(x->cs, (hipEvent_t)after_event, 0) != hipSuccess) return -3;
     const size_t pieces = rows * 3;
     hipLaunchKernelGGL(pack_pv_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, x->cs, (const double *)d_xr, x->send, rows);
     if (hipGetLastError() != hipSuccess) return -3;
@@ -1781,7 +1811,7 @@ int ndp_destroy(ndp_handle *h)
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->evLast) (void)hipEventDestroy(h->evLast);
     if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
-    for (hipEvent_t e : {h->evFork, h->evJoin})
+    for (hipEvent_t e : {h->evFork, h->evJoin, h->stepDone[0], h->stepDone[1], h->stepDone[2], h->stepDone[3]})
         if (e) (void)hipEventDestroy(e);
     h->pool.reset();
     void *ptrs[] = {h->dForceAB[0], h->dForceAB[1], h->dProto, h->dRefList, h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dForce, h->dFrag,
@@ -2054,7 +2084,14 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
         NDP_HIP(h, hipGetLastError());
         return end_timing(h, s);
     }
-#define LAUNCH(...) hipLaunchKernelGGL(RTI_K(__VA_ARGS__), grid, block, shm, s, ka)
+    // tracked steps: the LAST launch of the step carries the completion event (in-place kernel, or the work list's reset launch)
+    hipEvent_t stop = nullptr;
+    if (h->track_steps) stop = h->stepDone[++h->step_seq & 3];
+#define LAUNCH(...)                                                                                                  \
+    do {                                                                                                             \
+        if (stop && !q) hipExtLaunchKernelGGL(RTI_K(__VA_ARGS__), grid, block, (std::uint32_t)shm, s, nullptr, stop, 0, ka); \
+        else hipLaunchKernelGGL(RTI_K(__VA_ARGS__), grid, block, shm, s, ka);                                        \
+    } while (0)
     if (q) {
         // work list: producer (every instance, early exit or defer), consumer (the deferred ones, from scratch; with one RTI
         // iteration the consumer goes straight to the interior-point loop, with several it repeats the automatic rule per
@@ -2074,7 +2111,8 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
             hipLaunchKernelGGL(RTI_K(5, 2, false, 40, 0, 2, 2), grid, block, shm, s, kc);
         }
         NDP_HIP(h, hipGetLastError());
-        hipLaunchKernelGGL(queue_reset_kernel, dim3(1), dim3(64), 0, s, h->dQctr);
+        if (stop) hipExtLaunchKernelGGL(queue_reset_kernel, dim3(1), dim3(64), 0, s, nullptr, stop, 0, h->dQctr);
+        else hipLaunchKernelGGL(queue_reset_kernel, dim3(1), dim3(64), 0, s, h->dQctr);
         NDP_HIP(h, hipGetLastError());
         return end_timing(h, s);
     }

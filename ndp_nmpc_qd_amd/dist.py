@@ -222,11 +222,15 @@ class RcclExchange:
             raise RuntimeError(f"ndp_xchg_create failed ({rc})")
         self._h = h
 
-    def begin(self, xr, gathered, stream):
-        """xr: this rank's [B_local, N+1, 10] float64 windows of the tick; gathered: [world * B_local, N+1, 6]."""
+    def begin(self, xr, gathered, stream=None, after_event=None):
+        """xr: this rank's [B_local, N+1, 10] float64 windows of the tick; gathered: [world * B_local, N+1, 6].  stream: whatever
+        produces xr runs there (the gather is ordered behind everything it holds); after_event: a raw HIP event the gather waits for
+        (BatchedNMPC.last_step_event(): the control step that read `gathered` last).  One of the two must cover the last reader of
+        `gathered`."""
         import ctypes as C
         assert xr.is_contiguous() and gathered.is_contiguous() and gathered.numel() == self.world * self.rows * PV_COLS
-        rc = self._lib.ndp_xchg_begin(self._h, C.c_void_p(xr.data_ptr()), self.rows, C.c_void_p(gathered.data_ptr()), C.c_void_p(stream.cuda_stream))
+        rc = self._lib.ndp_xchg_begin(self._h, C.c_void_p(xr.data_ptr()), self.rows, C.c_void_p(gathered.data_ptr()),
+                                      C.c_void_p(stream.cuda_stream) if stream is not None else None, after_event)
         if rc:
             raise RuntimeError(f"ndp_xchg_begin failed ({rc}): {self._lib.ndp_xchg_last_error(self._h).decode()}")
 

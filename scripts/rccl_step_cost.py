@@ -83,6 +83,33 @@ def alone_body(i):
 t_lib = timed(lib_body, lambda: ex.begin(ticks[0]["other"], gathered[0], stream))
 
 
+def lib_body_nodep(i):
+    ex.end(stream)
+    ex.begin(ticks[(i + 1) % T]["other"], gathered[(i + 1) % 2], None)      # the windows are in place: no ordering behind the compute stream
+    bound[(i % T, i % 2)]()
+
+
+t_lib2 = timed(lib_body_nodep, lambda: ex.begin(ticks[0]["other"], gathered[0], None))
+
+eng.track_steps(True)
+bound.clear()
+
+
+def lib_body_event(i):
+    ex.end(stream)
+    # gathered[(i + 1) % 2] was read last by the control step launched last (tick i - 1): the gather waits for ITS completion event
+    ex.begin(ticks[(i + 1) % T]["other"], gathered[(i + 1) % 2], None, after_event=eng.last_step_event() if i else None)
+    key = (i % T, i % 2)
+    if key not in bound:
+        d = ticks[i % T]
+        bound[key] = eng.bind_update_device(d["x0"], d["xr"], d["ur"], u0, other=gathered[i % 2], ego_xy=d["ego_xy"], stream=stream)
+    bound[key]()
+
+
+t_lib3 = timed(lib_body_event, lambda: ex.begin(ticks[0]["other"], gathered[0], None))
+eng.track_steps(False)
+
+
 def prime_torch():
     pend[0] = ndist.exchange_pv_begin(ticks[0]["other"], pv, gathered[0], force_collective=True)
 
@@ -92,6 +119,8 @@ t_alone = timed(alone_body, lambda: None)
 print("batch 1024, one-rank communicator, launched from the host, us per tick:")
 print("  control step alone (bound launch)                                   %6.1f" % t_alone)
 print("  + the library's all-gather of the tick's windows (ndp_xchg_*)       %6.1f" % t_lib)
+print("    the same, NO ordering behind the compute stream (unsafe: the gather may overwrite a buffer still being read) %5.1f" % t_lib2)
+print("    the same, ordered behind the last reader's completion event (ndp_track_steps: no packet on the compute stream) %5.1f" % t_lib3)
 print("  + torch.distributed.all_gather_into_tensor (pack copy + c10d call)  %6.1f" % t_torch)
 ex.close()
 dist.destroy_process_group()

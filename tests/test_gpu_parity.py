@@ -1299,6 +1299,33 @@ eng.reset_device(t["xr"], t["ur"], stream=stream)
 eng.update_device(t["x0"], t["xr"], t["ur"], u_b, other=src, ego_xy=t["ego_xy"], stream=stream)
 torch.cuda.synchronize()
 assert torch.equal(u_a, u_b) and bool(torch.isfinite(u_a).all())
+# the pipelined form bench.py uses: two gathered buffers, the gather of tick i + 1 begun beside tick i's step and ordered behind the
+# step that read its target buffer last through that step's own completion event (ndp_track_steps: no packet on the compute stream)
+eng.track_steps(True)
+bufs = [torch.empty_like(gathered) for _ in range(2)]
+wins = [t["other"] + 0.01 * k for k in range(8)]
+outs = [torch.empty(B, 4, dtype=torch.float64, device=dev) for _ in range(8)]
+eng.reset_device(t["xr"], t["ur"], stream=stream)
+ex.begin(wins[0], bufs[0], stream)
+for i in range(8):
+    ex.end(stream)
+    if i + 1 < 8:
+        try:
+            ev = eng.last_step_event()
+        except ndp.NdpError:
+            ev = None
+        if ev is None:
+            ex.begin(wins[i + 1], bufs[(i + 1) % 2], stream)
+        else:
+            ex.begin(wins[i + 1], bufs[(i + 1) % 2], None, after_event=ev)
+    eng.update_device(t["x0"], t["xr"], t["ur"], outs[i], other=bufs[i % 2], ego_xy=t["ego_xy"], stream=stream)
+torch.cuda.synchronize()
+eng.track_steps(False)
+eng.reset_device(t["xr"], t["ur"], stream=stream)
+for i in range(8):
+    eng.update_device(t["x0"], t["xr"], t["ur"], u_b, other=wins[i], ego_xy=t["ego_xy"], stream=stream)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[i], u_b), (i, float((outs[i] - u_b).abs().max()))
 ex.close()
 print("XCHG-ONE-RANK-OK")
 """
