@@ -2046,6 +2046,7 @@ struct StepOut {               // where a step's status / iteration counts go an
     int *status = nullptr;     // pointers; null = the handle's HBM block / no mirror): the host-array step of small batches points
     int *iters = nullptr;      // them into a page-locked host block
     double *Xm = nullptr, *Um = nullptr;
+    hipEvent_t done = nullptr; // marked by the step's last launch through its own dispatch packet (no event packet behind it), or null
 };
 
 static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, const double *d_ur, const float *d_f,
@@ -2086,7 +2087,8 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     }
     // tracked steps: the LAST launch of the step carries the completion event (in-place kernel, or the work list's reset launch)
     hipEvent_t stop = nullptr;
-    if (h->track_steps) stop = h->stepDone[++h->step_seq & 3];
+    if (so && so->done) stop = so->done;
+    else if (h->track_steps) stop = h->stepDone[++h->step_seq & 3];
 #define LAUNCH(...)                                                                                                  \
     do {                                                                                                             \
         if (stop && !q) hipExtLaunchKernelGGL(RTI_K(__VA_ARGS__), grid, block, (std::uint32_t)shm, s, nullptr, stop, 0, ka); \
@@ -2391,10 +2393,15 @@ static int step_begin_locked(ndp_handle *h, const double *x0, const double *xr, 
     StepOut so;
     so.status = (int *)(sl.hOut + h->off_st); so.iters = (int *)(sl.hOut + h->off_it);
     if (want_iter) { so.Xm = (double *)(sl.hOut + h->out_bytes); so.Um = so.Xm + nxs(h); }
+    // one packet less between the kernel's end and the host seeing it: the completion event rides on the step's last dispatch packet
+    const bool ext_done = !dump && h->cfg.qp_precision == 0 && (!other || can_fuse(h)) && !getenv("NDP_HOST_EVENT_RECORD");
+    if (ext_done) so.done = sl.evOut;
     rc = enqueue_step(h, (const double *)(ib + o_x0), (const double *)(ib + o_xr), (const double *)(ib + o_ur),
                       f ? (const float *)(ib + o_f) : nullptr, nb, (double *)(sl.hOut + h->off_u0), dump ? h->sdbg : nullptr, s, &so);
     if (rc) return rc;
-    NDP_HIP(h, hipEventRecord(sl.evOut, s));
+    // (sl.evOut was marked by the step's own dispatch packet -- so.done -- unless the step ran the separate downwash launch path,
+    // a debug dump or a precision study, where it is recorded behind the launches as usual)
+    if (!ext_done) NDP_HIP(h, hipEventRecord(sl.evOut, s));
     sl.busy = true; sl.want_iter = want_iter; sl.dump = dump;
     h->host_us[0] = std::chrono::duration<double, std::micro>(tp1 - tp0).count();
     h->host_us[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp1).count();
