@@ -551,7 +551,7 @@ def main():
         if mode == "peer":
             peer.tick = peer.stats()["ticks"]
         region_ms = ev_a.elapsed_time(ev_b) if graphs else None
-        if graphs:                # an event pair around EVERY launch of 64 host-launched steps, outside the timed region (kernel_us_event_pairs)
+        if graphs:                # start / stop events carried by EVERY dispatch packet of 64 host-launched steps, outside the timed region (kernel_us_dispatch_events)
             eng.timing_enable(1)
             for i in range(64):
                 step(i, first=i == 0, last=i == 63)
@@ -646,7 +646,7 @@ def main():
         total = B * world * args.steps
         value = total / elapsed
         f_qp, f_mlp = algorithmic_flops_per_solve(N, sweeps, downwash)
-        pair_s = rti_ms * 1e-3 / max(rti_n, 1)       # HIP event pair around each launch (adds the pair's own dispatch gap)
+        pair_s = rti_ms * 1e-3 / max(rti_n, 1)       # HIP start / stop events carried by the launches' own dispatch packets (hipExtLaunchKernel)
         mlp_s = mlp_ms * 1e-3 / max(mlp_n, 1) if mlp_n else 0.0
         # One launch per step on the launch stream (N = 1, no exchange): the kernel's average duration is the HIP-event time over
         # the timed region's launches / steps -- back to back in a replayed graph, so it includes the ~0.1 us between two nodes
@@ -719,8 +719,8 @@ def main():
                          "profile_tag": prof["tag"], "profile_mismatch": profile_mismatch,
                          "kernel_us": rti_s * 1e6, "kernel_us_rocprof": prof["kernel_us"],
                          "kernel_us_source": ("HIP events on the launch stream around the timed region / steps" if one_launch
-                                              else "HIP event pair around each of 64 host-launched steps after the timed region"),
-                         "kernel_us_event_pairs": pair_s * 1e6,
+                                              else "HIP start / stop events on the dispatch packets of host-launched steps"),
+                         "kernel_us_dispatch_events": pair_s * 1e6,
                          "frac_rocprof": (f_qp * B / (prof["kernel_us"] * 1e-6) / 1e12 / F64_MFMA_PEAK_TFLOPS) if prof["kernel_us"] else None,
                          "flops_per_solve_f64": f_qp, "riccati_sweeps_per_solve": sweeps, "frac_interior_point": frac_ipm,
                          "fused_mlp_flops_per_solve": f_mlp if fused else 0.0,

@@ -1981,14 +1981,17 @@ int ndp_set_mlp_weights(ndp_handle *h, const float *blob, size_t n)
 }
 
 // ---- enqueue helpers (no locking, no sync) ----
-static int begin_timing(ndp_handle *h, hipStream_t s, int kind)
+// defer: the caller may hand the pair to the launch itself (hipExtLaunchKernel's start / stop events: the dispatch packet's own
+// timestamps, no event packets around the kernel -- an event pair recorded around a launch adds ~2.5 us of dispatch gap to what it
+// measures); it records ev.a itself if it cannot.
+static int begin_timing(ndp_handle *h, hipStream_t s, int kind, bool defer = false)
 {
     h->timing_open = false;
     if (!h->timing || (h->launch_no[kind]++ % h->timing) != 0) return 0;
     h->timing_open = true;
     ndp_handle::Ev ev; ev.kind = kind;
     NDP_HIP(h, hipEventCreate(&ev.a)); NDP_HIP(h, hipEventCreate(&ev.b));
-    NDP_HIP(h, hipEventRecord(ev.a, s));
+    if (!defer) NDP_HIP(h, hipEventRecord(ev.a, s));
     h->events.push_back(ev);
     return 0;
 }
@@ -2069,8 +2072,11 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     const size_t shm = (size_t)h->lds_per_wave * sizeof(double) * W;
     const int ns = slots_for(h->cfg.N);
     const bool q = h->use_queue && !d_dbg;
-    int rc = begin_timing(h, s, 0);
+    int rc = begin_timing(h, s, 0, true);
     if (rc) return rc;
+    // timed launch of a single-kernel step: the pair rides on the dispatch packet (otherwise recorded around the launches)
+    const bool ext_timing = h->timing_open && !q && !h->cfg.qp_precision && !(so && so->done) && !h->track_steps;
+    if (h->timing_open && !ext_timing) NDP_HIP(h, hipEventRecord(h->events.back().a, s));
     if (h->cfg.qp_precision) {      // BASELINE config 5 (unfused; run ndp_downwash first for a force)
         if (fused) { h->err = "qp_precision != 0 supports f / no disturbance only (run ndp_downwash first)"; return -12; }
         const size_t shm1 = (size_t)h->lds_per_wave * sizeof(double);
@@ -2091,7 +2097,10 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     else if (h->track_steps) stop = h->stepDone[++h->step_seq & 3];
 #define LAUNCH(...)                                                                                                  \
     do {                                                                                                             \
-        if (stop && !q) hipExtLaunchKernelGGL(RTI_K(__VA_ARGS__), grid, block, (std::uint32_t)shm, s, nullptr, stop, 0, ka); \
+        if (ext_timing) {                                                                                            \
+            hipExtLaunchKernelGGL(RTI_K(__VA_ARGS__), grid, block, (std::uint32_t)shm, s, h->events.back().a, h->events.back().b, 0, ka); \
+            h->timing_open = false;                                                                                  \
+        } else if (stop && !q) hipExtLaunchKernelGGL(RTI_K(__VA_ARGS__), grid, block, (std::uint32_t)shm, s, nullptr, stop, 0, ka); \
         else hipLaunchKernelGGL(RTI_K(__VA_ARGS__), grid, block, shm, s, ka);                                        \
     } while (0)
     if (q) {
