@@ -124,6 +124,47 @@ def effective_cores():
     return n
 
 
+def launch_ranks(n, script, script_args, python=None, out=None, err=None):
+    """`bench.py --gpus N` started WITHOUT a torch.distributed environment launches its own N ranks: a CHILD process
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> script args`
+    (never a re-exec; this parent has not imported torch and has not touched the GPU).  Rank 0's JSON line -- the one stdout line that
+    parses as a JSON object holding "metric" -- is relayed to `out`; every other line of the children goes to `err`.  Returns the
+    child's exit code (3 when the ranks exited with 0 but printed no JSON line)."""
+    import socket
+    import subprocess
+    out, err = out or sys.stdout, err or sys.stderr
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(script_args)
+    print("bench.py: no WORLD_SIZE in the environment, launching %d ranks: %s" % (n, " ".join(cmd)), file=err, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    relayed = 0
+    for line in child.stdout:
+        txt = line.strip()
+        is_line = False
+        if txt.startswith("{") and '"metric"' in txt:
+            try:
+                is_line = isinstance(json.loads(txt), dict)
+            except ValueError:
+                is_line = False
+        if is_line and relayed == 0:
+            out.write(txt + "\n")
+            out.flush()
+            relayed += 1
+        else:
+            err.write(line)
+            err.flush()
+    rc = child.wait()
+    if rc == 0 and relayed == 0:
+        print("bench.py: the ranks exited with 0 but printed no JSON line", file=err, flush=True)
+        rc = 3
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +176,9 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=[3, 4],
                     help="BASELINE.json configs[] (1-based): 3 = batch of independent quadrotors (the metric's configuration), "
                          "4 = 4096 three-vehicle formations split over the GPUs")
+    ap.add_argument("--instance-order", default="leaders_first", choices=["leaders_first", "interleaved"],
+                    help="--config 4: a rank's local instance order (dist.config4_gids): its leaders (gate + downwash network) in front of its "
+                         "followers, or ascending global id")
     ap.add_argument("--formations", type=int, default=4096, help="--config 4: number of three-vehicle formations (whole job)")
     ap.add_argument("--qp-mode", type=int, default=0, help="0 auto (exact early exit), 1 interior point always")
     ap.add_argument("--work-queue", type=int, default=0, help="0 automatic, 1 on, 2 off (ndp_cfg.work_queue)")
@@ -149,8 +193,13 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of replaying a hipGraph")
     ap.add_argument("--torch-collective", action="store_true",
                     help="rccl form: call torch.distributed.all_gather_into_tensor per step instead of the library's own ncclAllGather (ndp_xchg_*)")
-    ap.add_argument("--graph-exchange", action="store_true",
-                    help="N > 1 with the exchange on: capture gather + kernel of every step into the hipGraph too (default: host launches)")
+    ap.add_argument("--graph-exchange", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+                    help="rccl form: off = every step launched from the host (gather on the library's stream + kernel); on = gather + kernel "
+                         "of every step captured into the hipGraph; auto (default) = BOTH are timed (host launches first; the captured form "
+                         "under a watchdog, never fatal) and `value` is the faster one that passed its checks -- config.launch says which")
+    ap.add_argument("--leg-timeout-s", type=float, default=240.0,
+                    help="watchdog of every secondary form (captured rccl form, peer form, downwash-ahead form): a leg that has not finished "
+                         "after this long is reported as timed out, the line is printed with the forms that did finish, and the ranks exit")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: bounded sample, about this many seconds")
     ap.add_argument("--exchange", default="both", choices=["both", "peer", "rccl"],
                     help="N > 1 (and --config 4), vehicle-major placement: how a rank gets its neighbours' reference windows, every "
@@ -172,6 +221,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -215,12 +266,12 @@ def main():
 
     def make_tick(B, t0, perturb):
         if cfg4:
-            return ndist.make_config4_shard(rank, world, args.formations, args.placement, N=N, t0=t0)
+            return ndist.make_config4_shard(rank, world, args.formations, args.placement, N=N, t0=t0, order=args.instance_order)
         if perturb == "mixed":
             return synth.make_batch(B, N=N, seed=synth.SEED0 + 40 + rank, downwash=True, t0=t0, **mixed_kw)
         return ndist.make_formation_shard(B, rank, world, N=N, t0=t0)
 
-    B = ndist.config4_gids(rank, world, args.formations, args.placement)[1] if cfg4 else args.batch
+    B = ndist.config4_gids(rank, world, args.formations, args.placement, args.instance_order)[1] if cfg4 else args.batch
     keys = ("x0", "xr", "ur", "ego_xy") + (("other_index",) if cfg4 else ("other",))
     ticks = []
     for t in range(T):
@@ -251,27 +302,39 @@ def main():
     need_exchange = downwash and args.placement == "vehicle" and (world > 1 or cfg4)
     two_forms = (not need_exchange and downwash and world == 1 and not cfg4 and N + 1 <= 32 and args.qp_mode == 0
                  and not eng.work_queue)
+    # rccl form, two launch modes: "rccl" = every step launched from the host, "rccl_graph" = gather + kernel captured (--graph-exchange)
+    rccl_modes = {"auto": ["rccl", "rccl_graph"], "on": ["rccl_graph"], "off": ["rccl"]}[args.graph_exchange]
+    if args.no_graph:
+        rccl_modes = ["rccl"]
+    baseline_modes = []
     if two_forms:
         modes = {"both": ["fused", "prefetch"], "prefetch": ["prefetch"], "fused": ["fused"]}[args.downwash_form]
+        # LIKE-FOR-LIKE baseline of the 1 -> N scaling curve: the N > 1 lines run the per-tick exchange (one library-issued RCCL
+        # all-gather per step); the N = 1 headline above replays a hipGraph with no exchange at all.  The same steps are therefore
+        # ALSO run here in exactly the N > 1 form -- a one-rank communicator, the pack + ncclAllGather on the library's stream per
+        # step, host-launched and captured -- and reported as `scaling_baseline`: efficiency = value(N) / (N * scaling_baseline).
+        if not args.only_timed and args.exchange in ("both", "rccl") and not same_dev:
+            baseline_modes = list(rccl_modes)
+            modes = modes + baseline_modes
     elif not need_exchange:
         modes = ["none"]
     elif same_dev and world > 1:
         modes = ["peer"]                          # RCCL refuses two ranks on one device
     else:
-        modes = {"both": ["rccl", "peer"], "rccl": ["rccl"], "peer": ["peer"]}[args.exchange]
+        modes = {"both": rccl_modes + ["peer"], "rccl": list(rccl_modes), "peer": ["peer"]}[args.exchange]
     peer, peer_err = None, None
     if "peer" in modes:
         try:
             peer = ndist.PeerWindows(B, N, local_rank, timeout_us=args.peer_timeout_us)
             if cfg4:
-                peer_oidx = torch.from_numpy(ndist.config4_other_index(rank, world, args.formations, "vehicle", peer_rows=True)).to(dev)
+                peer_oidx = torch.from_numpy(ndist.config4_other_index(rank, world, args.formations, "vehicle", peer_rows=True, order=args.instance_order)).to(dev)
         except Exception as e:                    # same outcome on every rank (PeerWindows exchanges the result)
             peer_err = f"{type(e).__name__}: {e}"[:200]
             modes = [m for m in modes if m != "peer"]
             if not modes:
                 raise
     xchg, xchg_err = None, None
-    if "rccl" in modes:
+    if any(m in modes for m in ("rccl", "rccl_graph")):
         gathered = [torch.empty(world * B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev) for _ in range(2)]
         pv_local = torch.empty(B, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev)
         # The all-gather issued by the C-ABI library itself (ndp_xchg_*: pack launch + ncclAllGather on a HIP stream of its own, two
@@ -294,7 +357,8 @@ def main():
     rccl_form = ("rccl all-gather per step, issued by the library on its own HIP stream (ndp_xchg_*)" + ("" if world > 1 else "; one rank: a real communicator, no xGMI traffic")
                  if xchg is not None else
                  "rccl all-gather per step through torch.distributed" + ("" if world > 1 else " (one rank: the pack only, no RCCL call)"))
-    mode_names = {"prefetch": "none (one GPU); downwash of tick t+1 on a second stream beside the control step of tick t",
+    mode_names = {"rccl_graph": rccl_form + "; gather + control step of every tick captured into the hipGraph",
+                  "prefetch": "none (one GPU); downwash of tick t+1 on a second stream beside the control step of tick t",
                   "fused": "none (one GPU); gate + MLP fused into the control-step launch",
                   "none": "none", "rccl": rccl_form,
                   "peer": "peer windows over xGMI: one publish (copy launch + one-wave epoch launch) per step, read by the control-step kernel"}
@@ -309,13 +373,14 @@ def main():
 
     def run_mode(mode, check_parity):
         """Parity spot check, warm-up and EXACTLY --steps timed steps of one exchange form; returns its measurements."""
-        exchange = mode == "rccl"
+        exchange = mode in ("rccl", "rccl_graph")
+        graph_x = mode == "rccl_graph"
         pending, bound = {}, {}
 
         # The gather of tick i + 1 overwrites the buffer tick i - 1 read: it is ordered behind THAT control step -- through the step's own
         # completion event (ndp_track_steps: no packet on the compute stream; 34 against 38 us per tick) when the steps are launched
         # from the host, through an event recorded on the compute stream inside a capture.
-        track = exchange and xchg is not None and not args.graph_exchange
+        track = exchange and xchg is not None and not graph_x
         eng.track_steps(track)
 
         def prefetch(i):
@@ -447,7 +512,7 @@ def main():
             gt[0].replay()
         # (the library-issued gather runs on its own stream: inside ONE hipGraph such a branch executes in line with the kernels on
         # ROCm 7.2 -- measured 305 against 281 us per step of 12 288 instances -- so that form is launched from the host)
-        want_graph = not args.no_graph and (not exchange or args.graph_exchange or (world == 1 and xchg is None))
+        want_graph = not args.no_graph and (not exchange or graph_x or (world == 1 and xchg is None and mode == "rccl"))
         if want_graph:
             try:
                 base = ((args.warmup + T - 1) // T) * T          # a multiple of T: the replayed cycle starts at tick 0
@@ -585,20 +650,61 @@ def main():
         return res
 
     results, form_errors = {}, {}
-    for m in modes:
-        if m == "prefetch" and modes[0] != "prefetch":        # the second form: measured beside the headline, never fatal to it
-            try:
-                results[m] = run_mode(m, check_parity=not args.only_timed)
-            except Exception as e:
-                form_errors[m] = f"{type(e).__name__}: {e}"[:300]
-                torch.cuda.set_stream(stream)
-        else:
-            results[m] = run_mode(m, check_parity=not args.only_timed)
-    for m, r in results.items():                  # parity spot checks (CPU oracle, OpenMP): behind every form's timed region
-        fn = r.pop("parity_fn")
+    # Which forms may fail without taking the line away: everything but the first.  A secondary form runs under a watchdog
+    # (--leg-timeout-s): a multi-rank capture of the collective, or the peer form's xGMI leg, has never run on hardware -- if such
+    # a leg does not come back, every rank's timer prints (rank 0) the line from the forms that DID finish and leaves.  With more
+    # than one rank the parity check of a form runs right behind its timed region (so that a finished form is a checked form
+    # when a later one hangs); with one rank all checks run behind all timed regions (the oracle's OpenMP phase in front of a
+    # 20-step timed region costs it 3-6 %).
+    import threading
+    check_now = world > 1
+    wd_lock = threading.Lock()
+    wd_state = {"done": False}
+
+    def watchdog(m):
+        with wd_lock:
+            if wd_state["done"]:
+                return
+            wd_state["done"] = True
+        form_errors[m] = f"did not finish within {args.leg_timeout_s:.0f} s (watchdog): the line carries the forms that did"
+        code = 1
+        try:
+            if rank == 0:
+                code = 1 if finish(partial=True) else 0
+            else:
+                code = 0
+        finally:
+            sys.stdout.flush()
+            os._exit(code)
+
+    def run_checked(m):
+        r = run_mode(m, check_parity=not args.only_timed)
+        if check_now and r.get("parity_fn") is not None:
+            r["parity"] = r.pop("parity_fn")()
+        return r
+
+    for k, m in enumerate(modes):
+        if k == 0:
+            results[m] = run_checked(m)
+            continue
+        timer = threading.Timer(args.leg_timeout_s, watchdog, args=(m,))
+        timer.daemon = True
+        timer.start()
+        try:
+            results[m] = run_checked(m)
+        except Exception as e:
+            form_errors[m] = f"{type(e).__name__}: {e}"[:300]
+            torch.cuda.set_stream(stream)
+        finally:
+            timer.cancel()
+        with wd_lock:
+            if wd_state["done"]:                   # the timer fired while this leg was being torn down: it prints and exits
+                time.sleep(3600)
+    for k, (m, r) in enumerate(list(results.items())):     # parity spot checks (CPU oracle, OpenMP): behind every form's timed region
+        fn = r.pop("parity_fn", None)
         if fn is None:
             continue
-        if m == "prefetch" and modes[0] != "prefetch":
+        if k > 0:
             try:
                 r["parity"] = fn()
             except Exception as e:
@@ -606,312 +712,352 @@ def main():
                 torch.cuda.set_stream(stream)
         else:
             r["parity"] = fn()
-    results = {m: r for m, r in results.items() if m not in form_errors}
-    head = results[modes[0]]                      # the north star's collective when it ran, else the only form
-    elapsed, launch_mode, parity, bad, it = head["elapsed"], head["launch"], head["parity"], head["bad"], head["it"]
-    rti_ms, rti_n, mlp_ms, mlp_n, step = head["rti_ms"], head["rti_n"], head["mlp_ms"], head["mlp_n"], head["step"]
-    exchange_mode = head["name"]
-    # `value` is the headline form's and stands or falls with ITS checks (parity against the oracle, converged instances, no
-    # timed-out wait); every other form carries its own figures and its own verdict ("ok") under exchange / downwash_forms --
-    # a defect there is reported there and in `secondary_form_failed`, it does not take the headline's measurement away.
-    def form_ok(r):
-        ps_ = r.get("peer_stats")
-        return ((r["parity"] is None or r["parity"] <= 1e-5) and r["bad"] == 0
-                and not (ps_ and (ps_["ack_timeouts"] or ps_["epoch_timeouts"] or ps_["slot_mismatches"])))
-    frac_ipm = float((it > 0).mean()) if args.qp_mode == 0 else 1.0
-    sweeps = float(np.mean(np.where(it > 0, 1 + 2 * it, 1))) if args.qp_mode == 0 else float(np.mean(2 * it))
 
-    def timed_leg(e, batch_ticks, n_steps, n_warm=10):
-        """Device-resident steps of another engine / workload: (solves/s, ms per step, ipm fraction, sweeps per solve)."""
-        uu = torch.empty(e.B, 4, dtype=torch.float64, device=dev)
-        e.reset_device(batch_ticks[0]["xr"], batch_ticks[0]["ur"], stream=stream)
+    def finish(partial=False):
+        """Builds and prints the line (rank 0) from the forms that have finished.  partial: called by the watchdog of a secondary form that
+        did not come back -- nothing that touches the GPU or a collective runs then."""
+        nonlocal results
+        results = {m: r for m, r in results.items() if m not in form_errors}
+        # `value` is the first form's (the north star's collective when an exchange runs); its two launch modes -- host launches,
+        # captured -- are one form: the faster one that passed its checks is the headline, config.launch says which
+        def form_ok(r):
+            ps_ = r.get("peer_stats")
+            return ((r["parity"] is None or r["parity"] <= 1e-5) and r["bad"] == 0
+                    and not (ps_ and (ps_["ack_timeouts"] or ps_["epoch_timeouts"] or ps_["slot_mismatches"])))
+        headline = modes[0]
+        if headline in ("rccl", "rccl_graph"):
+            cands = [m for m in ("rccl", "rccl_graph") if m in results and m in modes and form_ok(results[m])]
+            if cands:
+                headline = min(cands, key=lambda m: results[m]["elapsed"])
+        is_rccl = headline in ("rccl", "rccl_graph")
+        head = results[headline]
+        elapsed, launch_mode, parity, bad, it = head["elapsed"], head["launch"], head["parity"], head["bad"], head["it"]
+        rti_ms, rti_n, mlp_ms, mlp_n, step = head["rti_ms"], head["rti_n"], head["mlp_ms"], head["mlp_n"], head["step"]
+        exchange_mode = head["name"]
+        # `value` is the headline form's and stands or falls with ITS checks (parity against the oracle, converged instances, no
+        # timed-out wait); every other form carries its own figures and its own verdict ("ok") under exchange / downwash_forms --
+        # a defect there is reported there and in `secondary_form_failed`, it does not take the headline's measurement away.
+        frac_ipm = float((it > 0).mean()) if args.qp_mode == 0 else 1.0
+        sweeps = float(np.mean(np.where(it > 0, 1 + 2 * it, 1))) if args.qp_mode == 0 else float(np.mean(2 * it))
 
-        def one(i):
-            d = batch_ticks[i % len(batch_ticks)]
-            e.update_device(d["x0"], d["xr"], d["ur"], uu, other=d.get("other"), ego_xy=d.get("ego_xy"), stream=stream)
-        for i in range(n_warm):
-            one(i)
-        torch.cuda.synchronize()
-        ta = time.perf_counter()
-        for i in range(n_steps):
-            one(n_warm + i)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - ta) / n_steps
-        s_, i_ = e.status()
-        return {"value": e.B / dt, "ms_per_step": dt * 1e3, "frac_interior_point": float((i_ > 0).mean()),
-                "riccati_sweeps_per_solve": float(np.mean(np.where(i_ > 0, (0 if e.cfg.qp_mode else 1) + 2 * i_, 1))),
-                "not_converged": int((s_ != 0).sum()), "batch": e.B, "work_queue": e.work_queue}
+        def timed_leg(e, batch_ticks, n_steps, n_warm=10):
+            """Device-resident steps of another engine / workload: (solves/s, ms per step, ipm fraction, sweeps per solve)."""
+            uu = torch.empty(e.B, 4, dtype=torch.float64, device=dev)
+            e.reset_device(batch_ticks[0]["xr"], batch_ticks[0]["ur"], stream=stream)
 
-    if rank == 0:
-        total = B * world * args.steps
-        value = total / elapsed
-        f_qp, f_mlp = algorithmic_flops_per_solve(N, sweeps, downwash)
-        pair_s = rti_ms * 1e-3 / max(rti_n, 1)       # HIP start / stop events carried by the launches' own dispatch packets (hipExtLaunchKernel)
-        mlp_s = mlp_ms * 1e-3 / max(mlp_n, 1) if mlp_n else 0.0
-        # One launch per step on the launch stream (N = 1, no exchange): the kernel's average duration is the HIP-event time over
-        # the timed region's launches / steps -- back to back in a replayed graph, so it includes the ~0.1 us between two nodes
-        # and, once per replay, the graph's start-up on the device.  With more launches per step (exchange forms) the pairs stay.
-        one_launch = head["region_ms"] is not None and modes[0] in ("none", "fused", "prefetch") and mlp_n == 0
-        rti_s = head["region_ms"] * 1e-3 / args.steps if one_launch else pair_s
-        prefetch_form = modes[0] == "prefetch"
-        fused = downwash and mlp_n == 0 and not prefetch_form   # gate + MLP run inside rti_kernel (one launch per step)
-        ach_tf = f_qp * B / rti_s / 1e12
-        abytes = algorithmic_bytes_per_solve(N, downwash)
-        is_default = (not cfg4 and (fused or prefetch_form) and B == 1024 and N == 20 and args.qp_mode == 0 and args.perturb == "nominal" and world == 1)
-        prof = committed_profile(is_default)
-        # the committed profile annotates this run only if it describes it: its kernel duration must agree with the duration
-        # measured live (HIP events) -- otherwise every figure derived from it is withheld and the mismatch is reported
-        profile_mismatch = None
-        if prof["kernel_us"] is not None and not profile_agrees(prof["kernel_us"], rti_s * 1e6):
-            profile_mismatch = {"tag": prof["tag"], "kernel_us_rocprof": prof["kernel_us"], "kernel_us_live": rti_s * 1e6,
-                                "tolerance": PROFILE_TOLERANCE}
-            prof = {"kernel_us": None, "traffic": None, "wave_cycles_per_simd": None, "tag": prof["tag"]}
-        # matrix-pipe occupancy estimate: a v_mfma_f64_16x16x4 / v_mfma_f32_32x32x2 holds the SIMD's pipe 64 cycles, the four-block
-        # v_mfma_f64_4x4x4 16, a v_mfma_f32_32x32x16_f16 32 (scripts/ubench; PMC SQ_VALU_MFMA_BUSY_CYCLES of the committed profile
-        # = 147 * 64 + 119 * 16 + 12 * 64 + 96 * 32 per instance exactly).  One instance per SIMD; per full sweep at horizon N:
-        # 6 + 7 (N-1) + 4 per re-symmetrisation on the 16x16x4 form, 2 (N-1) + 1 + 4 N on the four-block form (a corrector
-        # solve of the interior-point loop is counted as a full sweep here: an upper estimate for those workloads).  The shader
-        # clock is MEASURED: wave-cycles per SIMD of the committed PMC pass over the committed kernel duration when the profile
-        # belongs to this configuration, else the in-kernel stamp span of one launch over its HIP-event duration.
-        n_16 = sweeps * (6 + 7 * (N - 1) + 4 * ((N - 1) // 8))
-        n_4 = sweeps * (2 * (N - 1) + 1 + 4 * N)
-        pipe_cycles = (n_16 * 64 + n_4 * 16 + ((12 * 64 + 96 * 32) if fused else 0)) * -(-B // 1024)      # instances per SIMD (1024 SIMDs), in rounds
-        clock_hz, clock_src = None, None
-        if prof["wave_cycles_per_simd"] and prof["kernel_us"]:
-            clock_hz, clock_src = prof["wave_cycles_per_simd"] / (prof["kernel_us"] * 1e-6), f"profiles/{prof['tag']} PMC SQ_WAVE_CYCLES / kernel trace duration"
-        if clock_hz is None and not args.only_timed:
-            eng.debug_stamps(True)
-            eng.timing_enable(1)
-            step(0)
+            def one(i):
+                d = batch_ticks[i % len(batch_ticks)]
+                e.update_device(d["x0"], d["xr"], d["ur"], uu, other=d.get("other"), ego_xy=d.get("ego_xy"), stream=stream)
+            for i in range(n_warm):
+                one(i)
             torch.cuda.synchronize()
-            sm = eng.debug_stamps(False, read=True)
-            ms1, n1 = eng.timing_read("rti")
-            eng.timing_enable(0)
-            # stamps 12 / 13: s_memrealtime (100 MHz) at kernel entry / exit of every wave, 14 / 15: s_memtime (shader clock) there
-            okw = (sm[:, 13] > sm[:, 12]) & (sm[:, 15] > sm[:, 14])
-            if okw.any():
-                clock_hz = float(np.median((sm[okw, 15] - sm[okw, 14]) / (sm[okw, 13] - sm[okw, 12]))) * 100e6
-                clock_src = "in-kernel s_memtime / s_memrealtime (100 MHz) over one stamped launch, median over waves"
-        out = {
-            "metric": "NMPC solves/sec (N=20, 1 RTI iter + downwash MLP) at batch",
-            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if cfg4 else "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"BASELINE config 4: {args.formations} three-vehicle formations = {3 * args.formations} instances over {world} GPU(s) "
-                                    f"({B}/GPU; vehicle 0 = NDP controller reading vehicle 1, vehicles 1-2 = NMPC followers), N={N}, 1 RTI iter, "
-                                    if cfg4 else f"batch={B}/GPU independent quadrotors, N={N}, 1 RTI iter, ")
-                                   + ("MLP downwash on (NDP controller; the force of tick t+1 predicted by a second launch on a second stream "
-                                      "while tick t is solved, consumed late by the control step)" if prefetch_form else
-                                      "MLP downwash on (NDP controller, gate+MLP fused into the RTI launch)" if fused else
-                                      "MLP downwash on (NDP controller)" if downwash else "no downwash (NMPC controller)")
-                                   + (", neighbour windows all-gathered over RCCL every step" if modes[0] == "rccl" and world > 1 else
-                                      ", neighbour windows published every step into a peer-mapped slot and read over xGMI by the kernel" if modes[0] == "peer" else
-                                      ", vehicle-major placement (position/velocity columns packed for the all-gather; one rank: no RCCL call)" if modes[0] == "rccl" else
-                                      ", formation-major placement (no exchange)" if (world > 1 or cfg4) else "")
-                                   + (", perturbed starts (~20 % of the instances need the interior-point loop)" if args.perturb == "mixed" else ""),
-                       "batch_per_gpu": B, "horizon": N, "n_rti": 1, "qp_mode": "auto" if args.qp_mode == 0 else "ipm_always",
-                       "work_queue": eng.work_queue, "launch": launch_mode, "warmup_untimed_extra_steps": head["extra_warm"],
-                       "neighbour_exchange": exchange_mode,
-                       "parallelism": f"instances sharded x{world}"},
-            "roofline": {"kernel": "rti_kernel", "bound": "mfma", "achieved": ach_tf, "peak": F64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach_tf / F64_MFMA_PEAK_TFLOPS, "traffic": prof["traffic"],
-                         "traffic_note": f"HBM bytes per launch, PMC (profiles/{prof['tag']}_pmc_rti_kernel.json); algorithmic bytes per launch = %d" % (abytes * B),
-                         "profile_tag": prof["tag"], "profile_mismatch": profile_mismatch,
-                         "kernel_us": rti_s * 1e6, "kernel_us_rocprof": prof["kernel_us"],
-                         "kernel_us_source": ("HIP events on the launch stream around the timed region / steps" if one_launch
-                                              else "HIP start / stop events on the dispatch packets of host-launched steps"),
-                         "kernel_us_dispatch_events": pair_s * 1e6,
-                         "frac_rocprof": (f_qp * B / (prof["kernel_us"] * 1e-6) / 1e12 / F64_MFMA_PEAK_TFLOPS) if prof["kernel_us"] else None,
-                         "flops_per_solve_f64": f_qp, "riccati_sweeps_per_solve": sweeps, "frac_interior_point": frac_ipm,
-                         "fused_mlp_flops_per_solve": f_mlp if fused else 0.0,
-                         "shader_clock_ghz_measured": clock_hz / 1e9 if clock_hz else None, "shader_clock_source": clock_src,
-                         "mfma_pipe_busy_est": pipe_cycles / (rti_s * clock_hz) if clock_hz else None,
-                         "hbm_algorithmic_GBps": abytes * B / (rti_s + mlp_s) / 1e9,
-                         "hbm_frac": abytes * B / (rti_s + mlp_s) / 1e9 / HBM_PEAK_GBS,
-                         "mlp_kernel_us": mlp_s * 1e6 if mlp_n else None},
-            "parity_max_rel_vs_oracle": parity, "instances_not_converged": bad,
-        }
-        if two_forms:
-            out["downwash_forms"] = {m: {"value": total / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3, "launch": r["launch"],
-                                         "kernel_us_rti": r["rti_ms"] * 1e3 / max(r["rti_n"], 1),
-                                         "us_per_step_hip_events": (r["region_ms"] * 1e3 / args.steps) if r.get("region_ms") else None,
-                                         "parity_max_rel_vs_oracle": r["parity"], "instances_not_converged": r["bad"],
-                                         **({"prefetch_stats": r["prefetch_stats"]} if "prefetch_stats" in r else {})}
-                                     for m, r in results.items()}
-            for m, e in form_errors.items():
-                out["downwash_forms"][m] = {"error": e}
-            out["downwash_forms"]["headline"] = modes[0]
-        if need_exchange:
-            # both forms of the per-step neighbour exchange, same steps, same inputs (value = whole-job solves/s)
-            out["exchange"] = {m: {"value": total / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3, "launch": r["launch"],
-                                   "parity_max_rel_vs_oracle": r["parity"], "instances_not_converged": r["bad"], "form": r["name"],
-                                   "ok": form_ok(r), **({"peer_stats": r["peer_stats"]} if "peer_stats" in r else {})}
-                               for m, r in results.items()}
-            if any(not form_ok(r) for m, r in results.items() if m != modes[0]):
-                out["secondary_form_failed"] = True
-            if peer_err:
-                out["exchange"]["peer"] = {"error": peer_err}
-            if xchg_err and "rccl" in out["exchange"]:
-                out["exchange"]["rccl"]["library_collective_unavailable"] = xchg_err
-            out["exchange"]["headline"] = modes[0]
-        extras = world == 1 and not args.only_timed and not cfg4 and args.perturb == "nominal" and args.qp_mode == 0
-        if extras:
-            # ---- what the reference's QP solver actually does (HPIPM always iterates): every instance through the interior-point loop
-            e_ipm = ndp.BatchedNMPC(B, N=N, disturbance=downwash, qp_mode=1, device=local_rank)
-            nom = [{k: v for k, v in d.items() if k in ("x0", "xr", "ur", "other", "ego_xy")} for d in ticks]
-            if not downwash:
-                nom = [{k: d[k] for k in ("x0", "xr", "ur")} for d in ticks]
-            out["ipm_always"] = timed_leg(e_ipm, nom, 60)
-            del e_ipm
-            # ---- mixed workload: ~20 % of the instances hit a bound and run the loop, the rest take the early exit.  At
-            # batch = SIMD count the step lasts as long as its slowest instance; with several instances per SIMD the work queue
-            # hands the interior-point solves to whichever wave is free (compare work_queue on / off at the larger batch).
-            def mixed_ticks(bb):
-                tk = []
-                for t in range(4):
-                    m = synth.make_batch(bb, N=N, seed=synth.SEED0 + 40, downwash=downwash, t0=0.02 * t, **mixed_kw)
-                    tk.append({k: torch.from_numpy(m[k]).to(dev) for k in (("x0", "xr", "ur", "other", "ego_xy") if downwash else ("x0", "xr", "ur"))})
-                return tk
-            out["mixed"] = {"perturbation": mixed_kw}
-            mt = mixed_ticks(B)
-            e_m = ndp.BatchedNMPC(B, N=N, disturbance=downwash, device=local_rank)
-            out["mixed"]["batch_%d" % B] = timed_leg(e_m, mt, 60)
-            del e_m, mt
-            for Bq in (2 * B, 8 * B):      # two and eight instances per SIMD
-                mt = mixed_ticks(Bq)
-                e_q = ndp.BatchedNMPC(Bq, N=N, disturbance=downwash, device=local_rank)          # the automatic choice
-                out["mixed"]["batch_%d" % Bq] = timed_leg(e_q, mt, 30)
-                auto_on = e_q.work_queue
-                del e_q
-                for wq, name in ((1, "work_queue_on"), (2, "work_queue_off")):
-                    if (wq == 1) == auto_on:
-                        out["mixed"]["batch_%d_%s" % (Bq, name)] = dict(out["mixed"]["batch_%d" % Bq])
-                        continue
-                    e_q = ndp.BatchedNMPC(Bq, N=N, disturbance=downwash, device=local_rank, work_queue=wq)
-                    out["mixed"]["batch_%d_%s" % (Bq, name)] = timed_leg(e_q, mt, 30)
-                    del e_q
-                del mt
-            # ---- the metric as SURVEY 8d words it: host arrays in, host arrays out (H2D of the inputs and D2H of u0 inside the
-            # time).  Pageable numpy arrays, as the reference's callers hold them (nmpc_body_rate_ctl.py:93-112).  Two forms of the
-            # same C-ABI path: ndp_step (one tick at a time: pack -> H2D -> kernel -> D2H -> wait) and ndp_step_begin / _end with
-            # two ticks in flight (tick i+1's packing and PCIe transfer run under tick i's kernel; x0 comes from odometry, not
-            # from the previous u0: nmpc_node.py:202-226).
-            hb = {k: np.ascontiguousarray(host0[k]) for k in ("x0", "xr", "ur", "other", "ego_xy")}
-            e_h = ndp.BatchedNMPC(B, N=N, disturbance=downwash, device=local_rank)
-            e_h.reset(hb["xr"], hb["ur"])
-            kw = dict(other=hb["other"], ego_xy=hb["ego_xy"]) if downwash else {}
-            u_pipe = np.empty((B, 4))
-            e_h.update_begin(hb["x0"], hb["xr"], hb["ur"], **kw)
-            for _ in range(300):                  # the first ~100 ms of host-array steps run slower (link / clock state): untimed
-                e_h.update_begin(hb["x0"], hb["xr"], hb["ur"], **kw)
-                e_h.update_end(out=u_pipe)
-            e_h.update_end(out=u_pipe)
-            nh = 100
-            th = time.perf_counter()
-            for _ in range(nh):
-                e_h.update(hb["x0"], hb["xr"], hb["ur"], **kw)
-            th = (time.perf_counter() - th) / nh
-            e_h.update_begin(hb["x0"], hb["xr"], hb["ur"], **kw)
-            for _ in range(5):
-                e_h.update_begin(hb["x0"], hb["xr"], hb["ur"], **kw)
-                e_h.update_end(out=u_pipe)
-            tp = time.perf_counter()
-            for _ in range(nh):
-                e_h.update_begin(hb["x0"], hb["xr"], hb["ur"], **kw)
-                e_h.update_end(out=u_pipe)
-            tp = (time.perf_counter() - tp) / nh
-            e_h.update_end(out=u_pipe)
-            # host -> device bytes per solve as they cross PCIe: x0, xr, ur, and of the caller's 10-column neighbour windows the 6
-            # position / velocity columns the gate and the network read (packed that way into the mirror), ego xy
-            in_b = 8 * (10 + 10 * (N + 1) + 4 * N) + ((8 * 6 * (N + 1) + 16) if downwash else 0)
-            out["value_host_inclusive"] = {
-                "value": B / tp, "unit": "solves/s", "ms_per_step": tp * 1e3,
-                "form": "ndp_step_begin / ndp_step_end, two ticks in flight (packing + H2D of tick i+1 under tick i's kernel)",
-                "pcie_GBps_implied": (in_b + 40) * B / tp / 1e9,
-                "one_tick_at_a_time": {"value": B / th, "ms_per_step": th * 1e3, "form": "ndp_step", "pcie_GBps_implied": (in_b + 40) * B / th / 1e9},
-                "note": "pageable numpy arrays in, numpy u0 out: the inputs (%.1f MB per step across PCIe; neighbour windows as their 6 position / velocity columns) are packed into a page-locked mirror (pack threads), the "
-                        "kernel reads them over PCIe and writes u0 | status | iterations into a page-locked block itself -- no DMA operation; "
-                        "PCIe Gen5 x16 (63 GB/s spec) alone bounds this at %.1f M solves/s" % (in_b * B / 1e6, 63e9 / (in_b + 40) / 1e6)}
-            del e_h
-        if not args.no_cpu_baseline and not args.only_timed and world == 1 and not cfg4:
-            from oracle import oracle as O
-            nthr = min(O.num_threads(), effective_cores())
-            blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
+            ta = time.perf_counter()
+            for i in range(n_steps):
+                one(n_warm + i)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - ta) / n_steps
+            s_, i_ = e.status()
+            return {"value": e.B / dt, "ms_per_step": dt * 1e3, "frac_interior_point": float((i_ > 0).mean()),
+                    "riccati_sweeps_per_solve": float(np.mean(np.where(i_ > 0, (0 if e.cfg.qp_mode else 1) + 2 * i_, 1))),
+                    "not_converged": int((s_ != 0).sum()), "batch": e.B, "work_queue": e.work_queue}
 
-            def cpu_rate(qp_mode, seconds):
-                cfgo = O.default_cfg(N=N, use_fd=downwash)
-                cfgo.qp_mode = qp_mode
-                Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
-                O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], None, Xo, Uo, nthreads=nthr)       # warm the thread pool
-                Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
-                n, tc = 0, time.perf_counter()
-                while True:
-                    f = O.downwash_batch(blob, host0["other"], host0["xr"], host0["ego_xy"], nthreads=nthr) if downwash else None
-                    O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], f, Xo, Uo, nthreads=nthr)
-                    n += 1
-                    if time.perf_counter() - tc >= seconds:
-                        break
-                return B * n / (time.perf_counter() - tc), n
-            mode = args.qp_mode
-            v_same, n_same = cpu_rate(mode, args.cpu_seconds)
-            v_ipm, n_ipm = (v_same, n_same) if mode == 1 else cpu_rate(1, args.cpu_seconds * 0.5)
-            out["cpu_baseline"] = {"value": v_same, "unit": "solves/s", "cores": nthr, "kind": "port",
-                                   "qp_mode": "auto (the same early-exit rule as the timed GPU path)" if mode == 0 else "ipm_always",
-                                   "sample": f"{n_same} control ticks of the same batch={B} workload in ~{args.cpu_seconds:.0f} s "
-                                             f"(oracle/ndp_oracle.c: fp64 RTI, fp32 MLP), OpenMP over instances",
-                                   "ipm_always_value": v_ipm,
-                                   "ipm_always_note": f"the same oracle iterating on every instance like HPIPM ({n_ipm} ticks); compare with ipm_always.value"}
-            # BASELINE config 1 (one vehicle, N = 20, no downwash, 1 RTI iteration), the reference's own drop-in shape: the
-            # controller object exactly as nmpc_node.py:202-209 calls it -- numpy x0 / xr / ur in, numpy u0 out, every tick --
-            # next to the CPU restatement on one thread.  The reference's budget per tick is 20 ms (nmpc_node.py:216-220).
-            from ndp_nmpc_qd_amd.nmpc_ctl import NMPCBodyRateController
-            c1 = O.default_cfg(N=N, use_fd=False)
-            x0_1, xr_1, ur_1 = host0["x0"][0].copy(), host0["xr"][0].copy(), host0["ur"][0].copy()
-            n1 = 300
-            lat = {}
-            for qm, nm in ((1, "cpu_restatement_ipm_always_us"), (0, "cpu_restatement_auto_us")):
-                c1.qp_mode = qm
-                X1, U1 = xr_1[None].copy(), ur_1[None].copy()
-                t1 = time.perf_counter()
+        if rank == 0:
+            total = B * world * args.steps
+            value = total / elapsed
+            f_qp, f_mlp = algorithmic_flops_per_solve(N, sweeps, downwash)
+            pair_s = rti_ms * 1e-3 / max(rti_n, 1)       # HIP start / stop events carried by the launches' own dispatch packets (hipExtLaunchKernel)
+            mlp_s = mlp_ms * 1e-3 / max(mlp_n, 1) if mlp_n else 0.0
+            # One launch per step on the launch stream (N = 1, no exchange): the kernel's average duration is the HIP-event time over
+            # the timed region's launches / steps -- back to back in a replayed graph, so it includes the ~0.1 us between two nodes
+            # and, once per replay, the graph's start-up on the device.  With more launches per step (exchange forms) the pairs stay.
+            one_launch = head["region_ms"] is not None and headline in ("none", "fused", "prefetch") and mlp_n == 0
+            rti_s = head["region_ms"] * 1e-3 / args.steps if one_launch else pair_s
+            prefetch_form = headline == "prefetch"
+            fused = downwash and mlp_n == 0 and not prefetch_form   # gate + MLP run inside rti_kernel (one launch per step)
+            ach_tf = f_qp * B / rti_s / 1e12
+            abytes = algorithmic_bytes_per_solve(N, downwash)
+            is_default = (not cfg4 and (fused or prefetch_form) and B == 1024 and N == 20 and args.qp_mode == 0 and args.perturb == "nominal" and world == 1)
+            prof = committed_profile(is_default)
+            # the committed profile annotates this run only if it describes it: its kernel duration must agree with the duration
+            # measured live (HIP events) -- otherwise every figure derived from it is withheld and the mismatch is reported
+            profile_mismatch = None
+            if prof["kernel_us"] is not None and not profile_agrees(prof["kernel_us"], rti_s * 1e6):
+                profile_mismatch = {"tag": prof["tag"], "kernel_us_rocprof": prof["kernel_us"], "kernel_us_live": rti_s * 1e6,
+                                    "tolerance": PROFILE_TOLERANCE}
+                prof = {"kernel_us": None, "traffic": None, "wave_cycles_per_simd": None, "tag": prof["tag"]}
+            # matrix-pipe occupancy estimate: a v_mfma_f64_16x16x4 / v_mfma_f32_32x32x2 holds the SIMD's pipe 64 cycles, the four-block
+            # v_mfma_f64_4x4x4 16, a v_mfma_f32_32x32x16_f16 32 (scripts/ubench; PMC SQ_VALU_MFMA_BUSY_CYCLES of the committed profile
+            # = 147 * 64 + 119 * 16 + 12 * 64 + 96 * 32 per instance exactly).  One instance per SIMD; per full sweep at horizon N:
+            # 6 + 7 (N-1) + 4 per re-symmetrisation on the 16x16x4 form, 2 (N-1) + 1 + 4 N on the four-block form (a corrector
+            # solve of the interior-point loop is counted as a full sweep here: an upper estimate for those workloads).  The shader
+            # clock is MEASURED: wave-cycles per SIMD of the committed PMC pass over the committed kernel duration when the profile
+            # belongs to this configuration, else the in-kernel stamp span of one launch over its HIP-event duration.
+            n_16 = sweeps * (6 + 7 * (N - 1) + 4 * ((N - 1) // 8))
+            n_4 = sweeps * (2 * (N - 1) + 1 + 4 * N)
+            pipe_cycles = (n_16 * 64 + n_4 * 16 + ((12 * 64 + 96 * 32) if fused else 0)) * -(-B // 1024)      # instances per SIMD (1024 SIMDs), in rounds
+            clock_hz, clock_src = None, None
+            if prof["wave_cycles_per_simd"] and prof["kernel_us"]:
+                clock_hz, clock_src = prof["wave_cycles_per_simd"] / (prof["kernel_us"] * 1e-6), f"profiles/{prof['tag']} PMC SQ_WAVE_CYCLES / kernel trace duration"
+            if clock_hz is None and not args.only_timed and not partial:
+                eng.debug_stamps(True)
+                eng.timing_enable(1)
+                step(0)
+                torch.cuda.synchronize()
+                sm = eng.debug_stamps(False, read=True)
+                ms1, n1 = eng.timing_read("rti")
+                eng.timing_enable(0)
+                # stamps 12 / 13: s_memrealtime (100 MHz) at kernel entry / exit of every wave, 14 / 15: s_memtime (shader clock) there
+                okw = (sm[:, 13] > sm[:, 12]) & (sm[:, 15] > sm[:, 14])
+                if okw.any():
+                    clock_hz = float(np.median((sm[okw, 15] - sm[okw, 14]) / (sm[okw, 13] - sm[okw, 12]))) * 100e6
+                    clock_src = "in-kernel s_memtime / s_memrealtime (100 MHz) over one stamped launch, median over waves"
+            out = {
+                "metric": "NMPC solves/sec (N=20, 1 RTI iter + downwash MLP) at batch",
+                "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if cfg4 else "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": (f"BASELINE config 4: {args.formations} three-vehicle formations = {3 * args.formations} instances over {world} GPU(s) "
+                                        f"({B}/GPU; vehicle 0 = NDP controller reading vehicle 1, vehicles 1-2 = NMPC followers), N={N}, 1 RTI iter, "
+                                        if cfg4 else f"batch={B}/GPU independent quadrotors, N={N}, 1 RTI iter, ")
+                                       + ("MLP downwash on (NDP controller; the force of tick t+1 predicted by a second launch on a second stream "
+                                          "while tick t is solved, consumed late by the control step)" if prefetch_form else
+                                          "MLP downwash on (NDP controller, gate+MLP fused into the RTI launch)" if fused else
+                                          "MLP downwash on (NDP controller)" if downwash else "no downwash (NMPC controller)")
+                                       + (", neighbour windows all-gathered over RCCL every step" if is_rccl and world > 1 else
+                                          ", neighbour windows published every step into a peer-mapped slot and read over xGMI by the kernel" if headline == "peer" else
+                                          ", vehicle-major placement (position/velocity columns packed for the all-gather; one rank: no RCCL call)" if is_rccl else
+                                          ", formation-major placement (no exchange)" if (world > 1 or cfg4) else "")
+                                       + (", perturbed starts (~20 % of the instances need the interior-point loop)" if args.perturb == "mixed" else ""),
+                           "batch_per_gpu": B, "horizon": N, "n_rti": 1, "qp_mode": "auto" if args.qp_mode == 0 else "ipm_always",
+                           "work_queue": eng.work_queue, "launch": launch_mode, "warmup_untimed_extra_steps": head["extra_warm"],
+                           "neighbour_exchange": exchange_mode, "instance_order": args.instance_order if cfg4 else None,
+                           "parallelism": f"instances sharded x{world}"},
+                "roofline": {"kernel": "rti_kernel", "bound": "mfma", "achieved": ach_tf, "peak": F64_MFMA_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": ach_tf / F64_MFMA_PEAK_TFLOPS, "traffic": prof["traffic"],
+                             "traffic_note": f"HBM bytes per launch, PMC (profiles/{prof['tag']}_pmc_rti_kernel.json); algorithmic bytes per launch = %d" % (abytes * B),
+                             "profile_tag": prof["tag"], "profile_mismatch": profile_mismatch,
+                             "kernel_us": rti_s * 1e6, "kernel_us_rocprof": prof["kernel_us"],
+                             "kernel_us_source": ("HIP events on the launch stream around the timed region / steps" if one_launch
+                                                  else "HIP start / stop events on the dispatch packets of host-launched steps"),
+                             "kernel_us_dispatch_events": pair_s * 1e6,
+                             "frac_rocprof": (f_qp * B / (prof["kernel_us"] * 1e-6) / 1e12 / F64_MFMA_PEAK_TFLOPS) if prof["kernel_us"] else None,
+                             "flops_per_solve_f64": f_qp, "riccati_sweeps_per_solve": sweeps, "frac_interior_point": frac_ipm,
+                             "fused_mlp_flops_per_solve": f_mlp if fused else 0.0,
+                             "shader_clock_ghz_measured": clock_hz / 1e9 if clock_hz else None, "shader_clock_source": clock_src,
+                             "mfma_pipe_busy_est": pipe_cycles / (rti_s * clock_hz) if clock_hz else None,
+                             "hbm_algorithmic_GBps": abytes * B / (rti_s + mlp_s) / 1e9,
+                             "hbm_frac": abytes * B / (rti_s + mlp_s) / 1e9 / HBM_PEAK_GBS,
+                             "mlp_kernel_us": mlp_s * 1e6 if mlp_n else None},
+                "parity_max_rel_vs_oracle": parity, "instances_not_converged": bad,
+            }
+            if two_forms:
+                out["downwash_forms"] = {m: {"value": total / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3, "launch": r["launch"],
+                                             "kernel_us_rti": r["rti_ms"] * 1e3 / max(r["rti_n"], 1),
+                                             "us_per_step_hip_events": (r["region_ms"] * 1e3 / args.steps) if r.get("region_ms") else None,
+                                             "parity_max_rel_vs_oracle": r["parity"], "instances_not_converged": r["bad"],
+                                             **({"prefetch_stats": r["prefetch_stats"]} if "prefetch_stats" in r else {})}
+                                         for m, r in results.items() if m not in baseline_modes}
+                for m, e in form_errors.items():
+                    if m not in baseline_modes:
+                        out["downwash_forms"][m] = {"error": e}
+                out["downwash_forms"]["headline"] = headline
+                if baseline_modes:
+                    # the N > 1 lines' own form at one rank (see baseline_modes above): what the driver's 1 -> N efficiency should divide by
+                    sb = {m: {"value": total / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3, "launch": r["launch"], "form": r["name"],
+                              "parity_max_rel_vs_oracle": r["parity"], "instances_not_converged": r["bad"], "ok": form_ok(r)}
+                          for m, r in results.items() if m in baseline_modes}
+                    for m, e in form_errors.items():
+                        if m in baseline_modes:
+                            sb[m] = {"error": e}
+                    okm = [m for m in sb if sb[m].get("ok")]
+                    best = max(okm, key=lambda m: sb[m]["value"]) if okm else None
+                    out["scaling_baseline"] = {
+                        "value": sb[best]["value"] if best else None, "ms_per_step": sb[best]["ms_per_step"] if best else None, "form": best,
+                        "forms": sb,
+                        "note": "the SAME steps in the form every N > 1 line runs: one library-issued RCCL all-gather of the position / velocity "
+                                "windows per control step (a real one-rank communicator, no xGMI traffic) + the control-step launch, host-launched "
+                                "('rccl') and captured into the hipGraph ('rccl_graph'); `value` = the faster one, as at N > 1.  Scaling efficiency "
+                                "= value(N) / (N x this); the headline `value` of this line replays a hipGraph with NO exchange and is not the curve's base"}
+            if need_exchange:
+                # both forms of the per-step neighbour exchange, same steps, same inputs (value = whole-job solves/s)
+                out["exchange"] = {m: {"value": total / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3, "launch": r["launch"],
+                                       "parity_max_rel_vs_oracle": r["parity"], "instances_not_converged": r["bad"], "form": r["name"],
+                                       "ok": form_ok(r), **({"peer_stats": r["peer_stats"]} if "peer_stats" in r else {})}
+                                   for m, r in results.items()}
+                if any(not form_ok(r) for m, r in results.items() if m != headline):
+                    out["secondary_form_failed"] = True
+                for m, e in form_errors.items():
+                    out["exchange"][m] = {"error": e}
+                if peer_err:
+                    out["exchange"]["peer"] = {"error": peer_err}
+                if world > 1:
+                    out["scaling_baseline"] = {"compare_with": "the N = 1 line's scaling_baseline.value (the same per-step all-gather + control step with a "
+                                                               "one-rank communicator), not its headline `value` (hipGraph replay, no exchange)",
+                                               "form": headline}
+                if xchg_err and "rccl" in out["exchange"]:
+                    out["exchange"]["rccl"]["library_collective_unavailable"] = xchg_err
+                out["exchange"]["headline"] = headline
+            extras = world == 1 and not args.only_timed and not cfg4 and args.perturb == "nominal" and args.qp_mode == 0 and not partial
+            if extras:
+                # ---- what the reference's QP solver actually does (HPIPM always iterates): every instance through the interior-point loop
+                e_ipm = ndp.BatchedNMPC(B, N=N, disturbance=downwash, qp_mode=1, device=local_rank)
+                nom = [{k: v for k, v in d.items() if k in ("x0", "xr", "ur", "other", "ego_xy")} for d in ticks]
+                if not downwash:
+                    nom = [{k: d[k] for k in ("x0", "xr", "ur")} for d in ticks]
+                out["ipm_always"] = timed_leg(e_ipm, nom, 60)
+                del e_ipm
+                # ---- mixed workload: ~20 % of the instances hit a bound and run the loop, the rest take the early exit.  At
+                # batch = SIMD count the step lasts as long as its slowest instance; with several instances per SIMD the work queue
+                # hands the interior-point solves to whichever wave is free (compare work_queue on / off at the larger batch).
+                def mixed_ticks(bb):
+                    tk = []
+                    for t in range(4):
+                        m = synth.make_batch(bb, N=N, seed=synth.SEED0 + 40, downwash=downwash, t0=0.02 * t, **mixed_kw)
+                        tk.append({k: torch.from_numpy(m[k]).to(dev) for k in (("x0", "xr", "ur", "other", "ego_xy") if downwash else ("x0", "xr", "ur"))})
+                    return tk
+                out["mixed"] = {"perturbation": mixed_kw}
+                mt = mixed_ticks(B)
+                e_m = ndp.BatchedNMPC(B, N=N, disturbance=downwash, device=local_rank)
+                out["mixed"]["batch_%d" % B] = timed_leg(e_m, mt, 60)
+                del e_m, mt
+                for Bq in (2 * B, 8 * B):      # two and eight instances per SIMD
+                    mt = mixed_ticks(Bq)
+                    e_q = ndp.BatchedNMPC(Bq, N=N, disturbance=downwash, device=local_rank)          # the automatic choice
+                    out["mixed"]["batch_%d" % Bq] = timed_leg(e_q, mt, 30)
+                    auto_on = e_q.work_queue
+                    del e_q
+                    for wq, name in ((1, "work_queue_on"), (2, "work_queue_off")):
+                        if (wq == 1) == auto_on:
+                            out["mixed"]["batch_%d_%s" % (Bq, name)] = dict(out["mixed"]["batch_%d" % Bq])
+                            continue
+                        e_q = ndp.BatchedNMPC(Bq, N=N, disturbance=downwash, device=local_rank, work_queue=wq)
+                        out["mixed"]["batch_%d_%s" % (Bq, name)] = timed_leg(e_q, mt, 30)
+                        del e_q
+                    del mt
+                # ---- the metric as SURVEY 8d words it: host arrays in, host arrays out (H2D of the inputs and D2H of u0 inside the
+                # time).  Pageable numpy arrays, as the reference's callers hold them (nmpc_body_rate_ctl.py:93-112).  Two forms of the
+                # same C-ABI path: ndp_step (one tick at a time: pack -> H2D -> kernel -> D2H -> wait) and ndp_step_begin / _end with
+                # two ticks in flight (tick i+1's packing and PCIe transfer run under tick i's kernel; x0 comes from odometry, not
+                # from the previous u0: nmpc_node.py:202-226).
+                hb = {k: np.ascontiguousarray(host0[k]) for k in ("x0", "xr", "ur", "other", "ego_xy")}
+                e_h = ndp.BatchedNMPC(B, N=N, disturbance=downwash, device=local_rank)
+                e_h.reset(hb["xr"], hb["ur"])
+                kw = dict(other=hb["other"], ego_xy=hb["ego_xy"]) if downwash else {}
+                u_pipe = np.empty((B, 4))
+                e_h.update_begin(hb["x0"], hb["xr"], hb["ur"], **kw)
+                for _ in range(300):                  # the first ~100 ms of host-array steps run slower (link / clock state): untimed
+                    e_h.update_begin(hb["x0"], hb["xr"], hb["ur"], **kw)
+                    e_h.update_end(out=u_pipe)
+                e_h.update_end(out=u_pipe)
+                nh = 100
+                th = time.perf_counter()
+                for _ in range(nh):
+                    e_h.update(hb["x0"], hb["xr"], hb["ur"], **kw)
+                th = (time.perf_counter() - th) / nh
+                e_h.update_begin(hb["x0"], hb["xr"], hb["ur"], **kw)
+                for _ in range(5):
+                    e_h.update_begin(hb["x0"], hb["xr"], hb["ur"], **kw)
+                    e_h.update_end(out=u_pipe)
+                tp = time.perf_counter()
+                for _ in range(nh):
+                    e_h.update_begin(hb["x0"], hb["xr"], hb["ur"], **kw)
+                    e_h.update_end(out=u_pipe)
+                tp = (time.perf_counter() - tp) / nh
+                e_h.update_end(out=u_pipe)
+                # host -> device bytes per solve as they cross PCIe: x0, xr, ur, and of the caller's 10-column neighbour windows the 6
+                # position / velocity columns the gate and the network read (packed that way into the mirror), ego xy
+                in_b = 8 * (10 + 10 * (N + 1) + 4 * N) + ((8 * 6 * (N + 1) + 16) if downwash else 0)
+                out["value_host_inclusive"] = {
+                    "value": B / tp, "unit": "solves/s", "ms_per_step": tp * 1e3,
+                    "form": "ndp_step_begin / ndp_step_end, two ticks in flight (packing + H2D of tick i+1 under tick i's kernel)",
+                    "pcie_GBps_implied": (in_b + 40) * B / tp / 1e9,
+                    "one_tick_at_a_time": {"value": B / th, "ms_per_step": th * 1e3, "form": "ndp_step", "pcie_GBps_implied": (in_b + 40) * B / th / 1e9},
+                    "note": "pageable numpy arrays in, numpy u0 out: the inputs (%.1f MB per step across PCIe; neighbour windows as their 6 position / velocity columns) are packed into a page-locked mirror (pack threads), the "
+                            "kernel reads them over PCIe and writes u0 | status | iterations into a page-locked block itself -- no DMA operation; "
+                            "PCIe Gen5 x16 (63 GB/s spec) alone bounds this at %.1f M solves/s" % (in_b * B / 1e6, 63e9 / (in_b + 40) / 1e6)}
+                del e_h
+            if not args.no_cpu_baseline and not args.only_timed and world == 1 and not cfg4 and not partial:
+                from oracle import oracle as O
+                nthr = min(O.num_threads(), effective_cores())
+                blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
+
+                def cpu_rate(qp_mode, seconds):
+                    cfgo = O.default_cfg(N=N, use_fd=downwash)
+                    cfgo.qp_mode = qp_mode
+                    Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
+                    O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], None, Xo, Uo, nthreads=nthr)       # warm the thread pool
+                    Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
+                    n, tc = 0, time.perf_counter()
+                    while True:
+                        f = O.downwash_batch(blob, host0["other"], host0["xr"], host0["ego_xy"], nthreads=nthr) if downwash else None
+                        O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], f, Xo, Uo, nthreads=nthr)
+                        n += 1
+                        if time.perf_counter() - tc >= seconds:
+                            break
+                    return B * n / (time.perf_counter() - tc), n
+                mode = args.qp_mode
+                v_same, n_same = cpu_rate(mode, args.cpu_seconds)
+                v_ipm, n_ipm = (v_same, n_same) if mode == 1 else cpu_rate(1, args.cpu_seconds * 0.5)
+                out["cpu_baseline"] = {"value": v_same, "unit": "solves/s", "cores": nthr, "kind": "port",
+                                       "qp_mode": "auto (the same early-exit rule as the timed GPU path)" if mode == 0 else "ipm_always",
+                                       "sample": f"{n_same} control ticks of the same batch={B} workload in ~{args.cpu_seconds:.0f} s "
+                                                 f"(oracle/ndp_oracle.c: fp64 RTI, fp32 MLP), OpenMP over instances",
+                                       "ipm_always_value": v_ipm,
+                                       "ipm_always_note": f"the same oracle iterating on every instance like HPIPM ({n_ipm} ticks); compare with ipm_always.value"}
+                # BASELINE config 1 (one vehicle, N = 20, no downwash, 1 RTI iteration), the reference's own drop-in shape: the
+                # controller object exactly as nmpc_node.py:202-209 calls it -- numpy x0 / xr / ur in, numpy u0 out, every tick --
+                # next to the CPU restatement on one thread.  The reference's budget per tick is 20 ms (nmpc_node.py:216-220).
+                from ndp_nmpc_qd_amd.nmpc_ctl import NMPCBodyRateController
+                c1 = O.default_cfg(N=N, use_fd=False)
+                x0_1, xr_1, ur_1 = host0["x0"][0].copy(), host0["xr"][0].copy(), host0["ur"][0].copy()
+                n1 = 300
+                lat = {}
+                for qm, nm in ((1, "cpu_restatement_ipm_always_us"), (0, "cpu_restatement_auto_us")):
+                    c1.qp_mode = qm
+                    X1, U1 = xr_1[None].copy(), ur_1[None].copy()
+                    t1 = time.perf_counter()
+                    for _ in range(n1):
+                        O.step_batch(c1, x0_1[None], xr_1[None], ur_1[None], None, X1, U1, nthreads=1)
+                    lat[nm] = (time.perf_counter() - t1) / n1 * 1e6
+                ctl = NMPCBodyRateController(device=local_rank)
+                ctl.reset(xr_1, ur_1)
+                for _ in range(20):
+                    ctl.update(x0_1, xr_1, ur_1)
+                t2 = time.perf_counter()
                 for _ in range(n1):
-                    O.step_batch(c1, x0_1[None], xr_1[None], ur_1[None], None, X1, U1, nthreads=1)
-                lat[nm] = (time.perf_counter() - t1) / n1 * 1e6
-            ctl = NMPCBodyRateController(device=local_rank)
-            ctl.reset(xr_1, ur_1)
-            for _ in range(20):
-                ctl.update(x0_1, xr_1, ur_1)
-            t2 = time.perf_counter()
-            for _ in range(n1):
-                ctl.update(x0_1, xr_1, ur_1)
-            lat["gpu_drop_in_update_us"] = (time.perf_counter() - t2) / n1 * 1e6
-            # the same tick without the Python facade: BatchedNMPC(1).update(full=True) on numpy arrays
-            e1 = ndp.BatchedNMPC(1, N=N, device=local_rank)
-            e1.reset(xr_1[None], ur_1[None])
-            for _ in range(20):
-                e1.update(x0_1[None], xr_1[None], ur_1[None], full=True)
-            t3 = time.perf_counter()
-            for _ in range(n1):
-                e1.update(x0_1[None], xr_1[None], ur_1[None], full=True)
-            lat["gpu_ndp_step_ex_us"] = (time.perf_counter() - t3) / n1 * 1e6
-            lat["deadline_us"] = 20000.0
-            lat["note"] = ("N=%d, no downwash, 1 RTI iteration, host numpy in / numpy out per tick.  gpu_drop_in_update = "
-                           "NMPCBodyRateController.update (reference staged by array assignment + ONE ndp_step_ex: inputs into a page-locked mirror the "
-                           "kernel reads, one launch, u0 + iterate + status written by the kernel into a page-locked block, one sync -- no DMA "
-                           "operation); deadline = the reference's 20 ms warning (nmpc_node.py:216-220)" % N)
-            out["config1_single_vehicle"] = lat
-        ps = head.get("peer_stats")                               # (only when the peer form is the headline)
-        peer_bad = bool(ps and (ps["ack_timeouts"] or ps["epoch_timeouts"] or ps["slot_mismatches"]))
-        pf = results["prefetch"].get("prefetch_stats") if "prefetch" in results else None
-        if pf and (pf["force_timeouts"] or pf["slot_timeouts"]) and modes[0] == "prefetch":
-            peer_bad, ps = True, pf
-        fail = (parity is not None and not parity <= 1e-5) or bad > 0 or peer_bad
-        if fail:
-            out["error"] = (f"parity_max_rel_vs_oracle {parity} (bar 1e-5), instances_not_converged {bad}"
-                            + (f", peer exchange waits timed out / slots mismatched {ps}" if peer_bad else "") + ": value withheld")
-            out["value_unchecked"], out["value"] = out["value"], None
-        print(json.dumps(out), flush=True)
-    else:
-        fail = False
+                    ctl.update(x0_1, xr_1, ur_1)
+                lat["gpu_drop_in_update_us"] = (time.perf_counter() - t2) / n1 * 1e6
+                # the same tick without the Python facade: BatchedNMPC(1).update(full=True) on numpy arrays
+                e1 = ndp.BatchedNMPC(1, N=N, device=local_rank)
+                e1.reset(xr_1[None], ur_1[None])
+                for _ in range(20):
+                    e1.update(x0_1[None], xr_1[None], ur_1[None], full=True)
+                t3 = time.perf_counter()
+                for _ in range(n1):
+                    e1.update(x0_1[None], xr_1[None], ur_1[None], full=True)
+                lat["gpu_ndp_step_ex_us"] = (time.perf_counter() - t3) / n1 * 1e6
+                lat["deadline_us"] = 20000.0
+                lat["note"] = ("N=%d, no downwash, 1 RTI iteration, host numpy in / numpy out per tick.  gpu_drop_in_update = "
+                               "NMPCBodyRateController.update (reference staged by array assignment + ONE ndp_step_ex: inputs into a page-locked mirror the "
+                               "kernel reads, one launch, u0 + iterate + status written by the kernel into a page-locked block, one sync -- no DMA "
+                               "operation); deadline = the reference's 20 ms warning (nmpc_node.py:216-220)" % N)
+                out["config1_single_vehicle"] = lat
+            ps = head.get("peer_stats")                               # (only when the peer form is the headline)
+            peer_bad = bool(ps and (ps["ack_timeouts"] or ps["epoch_timeouts"] or ps["slot_mismatches"]))
+            pf = results["prefetch"].get("prefetch_stats") if "prefetch" in results else None
+            if pf and (pf["force_timeouts"] or pf["slot_timeouts"]) and headline == "prefetch":
+                peer_bad, ps = True, pf
+            fail = (parity is not None and not parity <= 1e-5) or bad > 0 or peer_bad
+            if fail:
+                out["error"] = (f"parity_max_rel_vs_oracle {parity} (bar 1e-5), instances_not_converged {bad}"
+                                + (f", peer exchange waits timed out / slots mismatched {ps}" if peer_bad else "") + ": value withheld")
+                out["value_unchecked"], out["value"] = out["value"], None
+            print(json.dumps(out), flush=True)
+        else:
+            fail = False
+        return fail
+
+    fail = finish()
     if xchg is not None:
         xchg.close()
     if peer is not None:

@@ -376,6 +376,14 @@ class BatchedNMPC:
             raise NdpError("no force slots: downwash_prefetch_device was never called")
         return torch.as_tensor(_DevMem(ptr, (self.B, self.N + 1, 3), "<f4"), device=torch.device("cuda", self.cfg.device))
 
+    def device_force(self):
+        """The force the fused downwash (or ndp_downwash_device) of the last step left in HBM: CUDA tensor view [B, N+1, 3] float32
+        (ndp_device_force); valid once the step's stream has reached it."""
+        import torch
+        from .dist import _DevMem
+        ptr = self._lib.ndp_device_force(self._h)
+        return torch.as_tensor(_DevMem(ptr, (self.B, self.N + 1, 3), "<f4"), device=torch.device("cuda", self.cfg.device))
+
     def track_steps(self, on=True):
         """Every control step launched from now on marks an event at its completion without a packet of its own (ndp_track_steps)."""
         self._check(self._lib.ndp_track_steps(self._h, 1 if on else 0), "ndp_track_steps")

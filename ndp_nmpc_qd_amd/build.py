@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libndp_nmpc_hip.so")
 SOURCES = ["ndp_hip.hip"]
-HEADERS = ["rti_wave.hpp", "wave_gfx950.hpp", "cfg_params.hpp", os.path.join("..", "..", "include", "ndp_nmpc.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "ndp_nmpc.h")]   # every header ndp_hip.hip can include
 
 
 def _stale():

@@ -254,16 +254,42 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     // fused, neighbour rows picked through other_index: the row number is the head of a dependent load chain (index -> window
     // address -> window loads).  Fetch it before anything else is in the wave's in-order load queue and consume it here, so
     // that the one unavoidable wait covers one load, not the seventeen input loads requested next.
+    // wg_nb: does ANY instance of this workgroup have a neighbour?  (Four scalar loads of the workgroup's own index entries, the
+    // same in every wave: no barrier.)  A workgroup of plain NMPC followers -- a rank's local order puts them behind its leaders,
+    // dist.config4_gids -- then skips the 70 KB weight transfer, both barriers and the network's input loads altogether.
     int orow = inst;
+    bool wg_nb = true;
     if (FUSED && ma.other_index) {
+        int any = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const int iw = (int)blockIdx.x * WAVES + w;
+            any |= (ma.other_index[iw < B ? iw : B - 1] >= 0) ? 1 : 0;
+        }
         orow = __builtin_amdgcn_readfirstlane(ma.other_index[inst]);
         asm volatile("" : : "s"(orow));
+        wg_nb = __builtin_amdgcn_readfirstlane(any) != 0;
     }
     typename Prog::InBuf inb;
     double x0v;
     Prog::issue_first(P, io, inb, x0v);      // every global input of the RTI step is now in flight (hidden under the MLP when fused)
     __builtin_amdgcn_sched_barrier(0);       // do not let the scheduler sink those loads behind the MLP
-    if (FUSED) {
+    if (FUSED && !wg_nb) {          // no instance of the workgroup has a neighbour: zero force, nothing of the network runs
+        if (!active) return;
+        const int lane = (int)(threadIdx.x & 63u);
+        const LdsMap m = make_map(N);
+        if (lane < 3 * (N + 1)) {
+            lds[m.TF + lane] = 0.0;
+            ma.force_out[inst * nf + lane] = 0.0f;
+        }
+        if (3 * (N + 1) > 64 && lane + 64 < 3 * (N + 1)) {
+            lds[m.TF + lane + 64] = 0.0;
+            ma.force_out[inst * nf + lane + 64] = 0.0f;
+        }
+        WaveGfx950::sync();
+        io.f = nullptr;
+        io.f_in_lds = 1;
+    } else if (FUSED) {
         const int lane = (int)(threadIdx.x & 63u), j = lane & 31, h = lane >> 5;
         const int np1 = N + 1;
         const int st = ma.other_stride;
@@ -740,10 +766,14 @@ void mlp_stream_kernel(const float *__restrict__ fr, const double *__restrict__ 
             __hip_atomic_store(reinterpret_cast<unsigned *>(fout) + (size_t)row * 3 + c, __float_as_uint(open ? o[c] : 0.0f),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // (the rows were written THROUGH to memory: what is needed is their completion -- s_waitcnt, which a workgroup-scope release
-    // is -- not an agent-scope release, whose buffer_wbl2 writes back the XCD's whole L2, the control step's dirty iterate
-    // included: one per wave, 672 per launch, made the control step beside it 50 % slower)
+    // The rows were written THROUGH to memory (sc1 stores): what is needed before the epoch word goes out is their COMPLETION, i.e.
+    // s_waitcnt vmcnt(0) -- stores of one wave to different addresses / channels may complete out of order.  Not an agent-scope
+    // release: its buffer_wbl2 writes back the XCD's whole L2, the control step's dirty iterate included (one per wave, 672 per
+    // launch, made the control step beside it 50 % slower).  And not a workgroup-scope release fence alone: on gfx950 it emits NO
+    // vmcnt wait (the ISA had the three row stores followed directly by the epoch store) -- the wait is spelled out;
+    // the fence stays as the compiler-level barrier.  scripts/isa_audit.py checks the instruction is there.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0)
         __hip_atomic_store(proto + PF_EPOCH + (m & 1) * (unsigned)ntiles + tile, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

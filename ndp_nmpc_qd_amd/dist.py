@@ -99,29 +99,60 @@ def make_formation_shard(B_local, rank, world, N=20, seed=synth.SEED0 + 4, t0=0.
 PV_COLS = 6
 
 
-def config4_gids(rank, world, n_form, placement):
-    """Global ids of this rank's instances in local order, and B_local."""
+def config4_gids(rank, world, n_form, placement, order="leaders_first"):
+    """Global ids of this rank's instances in LOCAL order, and B_local.
+
+    order: "interleaved" -- ascending global id (every workgroup of four consecutive instances holds one or two leaders);
+    "leaders_first" (default) -- the rank's leaders (NDP controller: gate + downwash network, ~22 us per workgroup) in front of its
+    followers (plain NMPC, ~17.6 us).  Instances are independent, so the local order is free; workgroups are dispatched in order, so
+    with more workgroups than CUs (1 536 instances per GPU at eight GPUs = 384 workgroups on 256 CUs) the long ones start first and
+    the second round consists of short ones only."""
     total = 3 * n_form
     if total % world or (placement == "formation" and (total // world) % 3):
         raise ValueError(f"{total} instances do not split over {world} ranks")
     bl = total // world
     g = np.arange(bl) * world + rank if placement == "vehicle" else rank * bl + np.arange(bl)
+    if order == "leaders_first":
+        g = np.concatenate([g[g % 3 == 0], g[g % 3 != 0]])
+    elif order != "interleaved":
+        raise ValueError(f"unknown instance order {order!r}")
     return g.astype(np.int64), bl
 
 
-def config4_other_index(rank, world, n_form, placement, peer_rows=False):
+_CFG4_MAPS = {}
+
+
+def _config4_maps(world, n_form, placement, order):
+    """owner rank and local row of every global instance."""
+    key = (world, n_form, placement, order)
+    if key not in _CFG4_MAPS:
+        total = 3 * n_form
+        owner, loc = np.empty(total, dtype=np.int64), np.empty(total, dtype=np.int64)
+        for q in range(world):
+            gq, bl = config4_gids(q, world, n_form, placement, order)
+            owner[gq], loc[gq] = q, np.arange(bl)
+        _CFG4_MAPS.clear()
+        _CFG4_MAPS[key] = (owner, loc)
+    return _CFG4_MAPS[key]
+
+
+def config4_other_index(rank, world, n_form, placement, peer_rows=False, order="leaders_first"):
     """int32[B_local]: row of the neighbour buffer holding each local instance's neighbour (-1 = none).  The buffer is the
     all-gathered [W * B_local, N+1, 6] array (vehicle-major), the local xr [B_local, N+1, 10] (formation-major), or -- vehicle-major
     with peer_rows -- the window buffer of rank (r+1) % W (PeerWindows.neighbour: a leader's neighbour g + 1 always lives there)."""
-    g, bl = config4_gids(rank, world, n_form, placement)
-    nb = np.where(g % 3 == 0, g + 1, -1)                   # leaders read vehicle 1 of their formation; followers nobody
+    g, bl = config4_gids(rank, world, n_form, placement, order)
+    owner, loc = _config4_maps(world, n_form, placement, order)
+    lead = g % 3 == 0                                      # leaders read vehicle 1 of their formation; followers nobody
+    nb = np.where(lead, g + 1, 0)
     if placement == "vehicle" and peer_rows:
-        row = nb // world
+        assert (owner[nb[lead]] == neighbour_rank(rank, world)).all()
+        row = loc[nb]
     elif placement == "vehicle":
-        row = (nb % world) * bl + nb // world
+        row = owner[nb] * bl + loc[nb]
     else:
-        row = nb - rank * bl
-    return np.where(nb >= 0, row, -1).astype(np.int32)
+        assert (owner[nb[lead]] == rank).all()
+        row = loc[nb]
+    return np.where(lead, row, -1).astype(np.int32)
 
 
 def make_config4_all(n_form, N=20, seed=synth.SEED0 + 4, t0=0.0):
@@ -142,12 +173,12 @@ def make_config4_all(n_form, N=20, seed=synth.SEED0 + 4, t0=0.0):
     return dict(x0=x0, xr=xr, ur=ur, ego_xy=np.ascontiguousarray(x0[:, 0:2]))
 
 
-def make_config4_shard(rank, world, n_form, placement, N=20, seed=synth.SEED0 + 4, t0=0.0):
-    """This rank's instances of make_config4_all plus `other_index` and `gids`."""
+def make_config4_shard(rank, world, n_form, placement, N=20, seed=synth.SEED0 + 4, t0=0.0, order="leaders_first"):
+    """This rank's instances of make_config4_all (in the local order of config4_gids) plus `other_index` and `gids`."""
     allv = make_config4_all(n_form, N=N, seed=seed, t0=t0)
-    g, _ = config4_gids(rank, world, n_form, placement)
+    g, _ = config4_gids(rank, world, n_form, placement, order)
     out = {k: np.ascontiguousarray(v[g]) for k, v in allv.items()}
-    out["other_index"] = config4_other_index(rank, world, n_form, placement)
+    out["other_index"] = config4_other_index(rank, world, n_form, placement, order=order)
     out["gids"] = g
     return out
 

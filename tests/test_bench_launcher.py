@@ -1,0 +1,91 @@
+"""`bench.py --gpus N` without a torch.distributed environment launches its own N ranks (bench.launch_ranks): a child
+`python -m torch.distributed.run`, rank 0's JSON line relayed, the child's exit code returned.  Driven here with a stub rank
+script on the CPU (two children), and once end to end: the real bench.py on a box without a GPU must fail in its RANKS, not
+in the launcher, and hand the failure back."""
+import io
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+STUB = r'''
+import json, os, sys
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1"
+print(f"noise from rank {rank} of {world}", flush=True)
+print("{not json", flush=True)
+if "--fail" in sys.argv and rank == 1:
+    sys.exit(7)
+if "--silent" in sys.argv:
+    sys.exit(0)
+if rank == 0:
+    print(json.dumps({"metric": "stub", "value": 1.0, "n_gpus": world, "argv": sys.argv[1:],
+                      "ipc": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}), flush=True)
+    print(json.dumps({"metric": "a second line must not reach stdout"}), flush=True)
+'''
+
+
+@pytest.fixture()
+def stub(tmp_path):
+    p = tmp_path / "stub_rank.py"
+    p.write_text(STUB)
+    return str(p)
+
+
+def _env_without_dist(monkeypatch):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+
+
+def test_two_ranks_json_line_relayed(stub, monkeypatch):
+    _env_without_dist(monkeypatch)
+    out, err = io.StringIO(), io.StringIO()
+    rc = bench.launch_ranks(2, stub, ["--gpus", "2", "--steps", "5"], out=out, err=err)
+    assert rc == 0, err.getvalue()
+    lines = [ln for ln in out.getvalue().splitlines() if ln.strip()]
+    assert len(lines) == 1                                  # ONE JSON line on stdout, nothing else
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["argv"] == ["--gpus", "2", "--steps", "5"]      # the same arguments reach the ranks
+    assert rec["ipc"] == "0"                                # dmabuf IPC is set for the children
+    e = err.getvalue()
+    assert "noise from rank 0 of 2" in e and "noise from rank 1 of 2" in e and "a second line" in e
+
+
+def test_failing_rank_sets_the_exit_code(stub, monkeypatch):
+    _env_without_dist(monkeypatch)
+    out, err = io.StringIO(), io.StringIO()
+    rc = bench.launch_ranks(2, stub, ["--fail"], out=out, err=err)
+    assert rc != 0
+
+
+def test_no_json_line_is_an_error(stub, monkeypatch):
+    _env_without_dist(monkeypatch)
+    out, err = io.StringIO(), io.StringIO()
+    assert bench.launch_ranks(2, stub, ["--silent"], out=out, err=err) == 3
+    assert out.getvalue() == ""
+
+
+def test_bench_gpus_2_launches_itself(monkeypatch):
+    """The driver's command shape with N = 2 and no torchrun around it.  There is no GPU here: both ranks must start, say so, and
+    the parent must return their failure -- not die in front of the launch with "launch with torch.distributed.run"."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "launching 2 ranks" in r.stderr
+    assert "needs an MI355X" in r.stderr
+    assert r.stdout.strip() == ""
+
+
+def test_world_size_mismatch_is_still_refused(monkeypatch):
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr

@@ -7,6 +7,7 @@ iterations; the fp64 device path is expected (and asserted) to sit orders of mag
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 import pytest
@@ -787,6 +788,78 @@ def test_config5_qp_on_the_fp32_and_bf16_matrix_instructions(ndp, oracle, N, n_r
     assert err[0] < 1e-8 and err[3] < 1e-5 and 1e-4 < err[4] < 0.5, err
 
 
+@pytest.mark.parametrize("B", [512, 4096])
+def test_config5_shape_with_perturbed_starts_runs_the_interior_point_kernels(ndp, oracle, B):
+    """BASELINE config 5's shape (N = 40, 2 RTI iterations) with PERTURBED starts, so that the instantiations that carry the
+    interior-point loop really execute it (>= 15 % of the instances iterate): qp_mode = 1 in place (rti_kernel<5,2,false,40,0,2,0>),
+    the automatic mode through the work list (producer <..,1> + consumer <..,2>) and the automatic mode in place.  Each against the
+    oracle in the SAME mode on 256 sampled instances (1e-5 bar, status and iteration counts equal on the sample), the three device
+    forms against each other on EVERY instance, and the size-independent properties of test_full_size_batch_1024 at full size."""
+    N, n_rti, NS = 40, 2, 256
+    b = synth.make_batch(B, N=N, seed=synth.SEED0 + 5, pos_sigma=0.5, vel_sigma=1.0, quat_sigma=0.15)
+    sample = np.sort(np.random.default_rng(7).choice(B, NS, replace=False))
+    bs = {k: np.ascontiguousarray(b[k][sample]) for k in ("x0", "xr", "ur")}
+    res = {}
+    for name, qp_mode, wq in (("ipm_in_place", 1, 2), ("auto_work_list", 0, 1), ("auto_in_place", 0, 2)):
+        eng = ndp.BatchedNMPC(B, N=N, n_rti=n_rti, qp_mode=qp_mode, work_queue=wq)
+        assert eng.work_queue == (wq == 1)
+        eng.reset(b["xr"], b["ur"])
+        u0, X, U, st, it = eng.update(b["x0"], b["xr"], b["ur"], raise_on_status=False, full=True)
+        res[name] = (u0, X, U, st, it)
+        cfg = oracle.default_cfg(N=N, n_rti=n_rti)
+        cfg.qp_mode = qp_mode
+        Xo, Uo = bs["xr"].copy(), bs["ur"].copy()
+        uo, sto, ito = oracle.step_batch(cfg, bs["x0"], bs["xr"], bs["ur"], None, Xo, Uo)
+        assert np.array_equal(st[sample], sto), name
+        assert np.array_equal(it[sample], ito), name
+        ok = sto == 0
+        assert ok.mean() > 0.9, name
+        _assert_u(u0[sample][ok], uo[ok], RTOL_U)
+        np.testing.assert_allclose(X[sample][ok], Xo[ok], rtol=0, atol=1e-5)
+        assert (it > 0).mean() >= 0.15, (name, (it > 0).mean())           # the interior-point code really ran
+        good = st == 0
+        # properties at full size: x0 equality after the full step, u0 = U[0], inputs inside the box, velocities inside theirs
+        np.testing.assert_allclose(X[good][:, 0, :], b["x0"][good], atol=1e-9)
+        assert np.array_equal(u0, U[:, 0, :])
+        assert (U[good][..., :3] <= 6 + 1e-7).all() and (U[good][..., :3] >= -6 - 1e-7).all()
+        assert (U[good][..., 3] >= -1e-7).all() and (U[good][..., 3] <= 9.81 / 0.36 + 1e-7).all()
+        assert (np.abs(X[good][:, 1:N, 3:6]) <= 20 + 1e-7).all()
+        eng.close()
+    # one algorithm, three launch forms: the work list only changes WHICH wave solves an instance
+    a, c = res["auto_work_list"], res["auto_in_place"]
+    assert np.array_equal(a[3], c[3]) and np.array_equal(a[4], c[4])
+    np.testing.assert_allclose(a[0], c[0], rtol=0, atol=1e-8)
+    both = (res["ipm_in_place"][3] == 0) & (c[3] == 0)
+    _assert_u(res["ipm_in_place"][0][both], c[0][both], RTOL_U)          # early exit vs always iterating: the north star's bar
+
+
+def test_config2_full_size_without_downwash(ndp, oracle):
+    """BASELINE configs[1] exactly: batch = 1024 independent quadrotors, N = 20, NO downwash (NMPC controller), one RTI iteration
+    -- every instance against the oracle, the properties of the full-size test, and permutation equivariance."""
+    B = 1024
+    b = synth.make_batch(B, seed=synth.SEED0 + 2)
+    eng = ndp.BatchedNMPC(B)
+    eng.reset(b["xr"], b["ur"])
+    u0, X, U, st, it = eng.update(b["x0"], b["xr"], b["ur"], full=True)
+    uo, sto, ito, Xo, Uo = _oracle_batch(oracle, b)
+    assert (st == 0).all() and (sto == 0).all()
+    _assert_u(u0, uo, 1e-8)
+    np.testing.assert_allclose(X, Xo, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(U, Uo, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(X[:, 0, :], b["x0"], atol=1e-9)
+    assert np.array_equal(u0, U[:, 0, :])
+    assert (U[..., :3] <= 6 + 1e-9).all() and (U[..., :3] >= -6 - 1e-9).all()
+    assert (U[..., 3] >= -1e-9).all() and (U[..., 3] <= 9.81 / 0.36 + 1e-9).all()
+    perm = np.random.default_rng(1).permutation(B)
+    eng2 = ndp.BatchedNMPC(B)
+    eng2.reset(b["xr"][perm], b["ur"][perm])
+    assert np.array_equal(eng2.update(b["x0"][perm], b["xr"][perm], b["ur"][perm]), u0[perm])
+    # a second tick on the warm-started iterate (the reference never shifts it, nmpc_body_rate_ctl.py:86-112)
+    u1 = eng.update(b["x0"], b["xr"], b["ur"])
+    u1o, st1, *_ = _oracle_batch(oracle, b, X=Xo, U=Uo)
+    _assert_u(u1, u1o, 1e-8)
+
+
 def test_peer_window_buffer_as_neighbour_source(ndp):
     """dist.PeerWindows on one rank (the neighbour is the rank's own buffer: same launches, same protocol words): per tick ONE
     publish launch puts this tick's windows into the slot of the tick's parity and returns the neighbour's slot as a raw device
@@ -1139,6 +1212,59 @@ def test_downwash_one_tick_ahead_on_the_second_stream(ndp, oracle, mlp_blob):
     f0 = oracle.downwash_batch(mlp_blob, host[0]["other"], host[0]["xr"], host[0]["ego_xy"])
     uo, sto, *_ = _oracle_batch(oracle, host[0], use_fd=True, f=f0)
     _assert_u(want[0][sto == 0], uo[sto == 0], 1e-6)
+
+
+def test_downwash_prediction_enqueued_after_its_control_step_takes_the_epoch_path(ndp):
+    """The LATE path of the downwash-ahead protocol on purpose: every tick's control step is launched BEFORE the
+    prediction it consumes, so its waves find PF_MLP_DONE < t at start, wait on their tiles' epoch words and load the force rows
+    past the L2 -- the path on which an epoch word published before its rows had completed would hand over the force of tick t - 2.
+    The forces differ from tick to tick (the neighbour moves), so a stale row shows as a control error.  Same controls as the
+    fused launch; late waves counted; no timeout."""
+    import torch
+    B, N, T = 512, 20, 8
+    dev = torch.device("cuda", 0)
+    ticks = []
+    for t in range(T):
+        b = synth.make_batch(B, seed=synth.SEED0 + 72, downwash=True, t0=0.02 * t)
+        b["other"][:, :, 0:3] += 0.08 * t          # the neighbour drifts: the force of tick t - 2 is visibly not the force of tick t
+        ticks.append({k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur", "other", "ego_xy")})
+    stream = torch.cuda.Stream(device=dev)
+    fused = ndp.BatchedNMPC(B, disturbance=True)
+    uf = torch.empty(T, B, 4, dtype=torch.float64, device=dev)
+    ff = torch.empty(T, B, N + 1, 3, dtype=torch.float32, device=dev)
+    fused.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
+    for t, d in enumerate(ticks):
+        fused.update_device(d["x0"], d["xr"], d["ur"], uf[t], other=d["other"], ego_xy=d["ego_xy"], stream=stream)
+        with torch.cuda.stream(stream):
+            ff[t].copy_(fused.device_force())
+    fused.synchronize()
+    torch.cuda.synchronize()
+    fh = ff.cpu().numpy()
+    assert np.abs(fh[2:] - fh[:-2]).max() > 1e-2                      # the test can tell tick t's force from tick t - 2's
+    eng = ndp.BatchedNMPC(B, disturbance=True)
+    up = torch.empty(T, B, 4, dtype=torch.float64, device=dev)
+    eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
+    # allocate the protocol state, then start from a clean count: one ordinary pair first
+    d = ticks[0]
+    eng.downwash_prefetch_device(d["other"], d["xr"], ego_xy=d["ego_xy"], after_stream=stream)
+    eng.update_device_prefetched(d["x0"], d["xr"], d["ur"], up[0], stream=stream)
+    eng.prefetch_join(stream)
+    torch.cuda.synchronize()
+    eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=stream)
+    torch.cuda.synchronize()
+    late0 = eng.prefetch_stats()["late_waves"]
+    for t, d in enumerate(ticks):
+        eng.update_device_prefetched(d["x0"], d["xr"], d["ur"], up[t], stream=stream)    # the step first: it has to wait for ...
+        time.sleep(0.002)
+        eng.downwash_prefetch_device(d["other"], d["xr"], ego_xy=d["ego_xy"])           # ... the prediction enqueued behind it
+        eng.prefetch_join(stream)
+        torch.cuda.synchronize()
+    st = eng.prefetch_stats()
+    assert st["force_timeouts"] == 0 and st["slot_timeouts"] == 0, st
+    assert st["late_waves"] - late0 >= T * B // 2, st                 # the epoch path really ran (every wave of every tick, ideally)
+    assert (eng.status()[0] == 0).all()
+    np.testing.assert_allclose(up.cpu().numpy(), uf.cpu().numpy(), rtol=0, atol=1e-9)
+    eng.close()
 
 
 def test_downwash_prefetch_misuse_is_bounded_and_reported(ndp):

@@ -216,9 +216,15 @@ def test_config4_placements_are_consistent():
     from ndp_nmpc_qd_amd import dist as ndist
     F = 40
     allv = ndist.make_config4_all(F)
-    for W in (1, 2, 4, 8):
-        for placement in ("vehicle", "formation"):
-            shards = [ndist.make_config4_shard(r, W, F, placement) for r in range(W)]
+    for W, placement, order in [(w, p, o) for w in (1, 2, 4, 8) for p in ("vehicle", "formation") for o in ("leaders_first", "interleaved")]:
+        if True:
+            shards = [ndist.make_config4_shard(r, W, F, placement, order=order) for r in range(W)]
+            for s in shards:                                  # the local order: leaders in front of followers, or ascending ids
+                lead = s["gids"] % 3 == 0
+                if order == "leaders_first":
+                    assert lead[:lead.sum()].all() and not lead[lead.sum():].any()
+                else:
+                    assert (np.diff(s["gids"]) > 0).all()
             assert sorted(np.concatenate([s["gids"] for s in shards]).tolist()) == list(range(3 * F))
             gathered = np.concatenate([s["xr"][:, :, :ndist.PV_COLS] for s in shards])
             for r, s in enumerate(shards):
@@ -229,7 +235,7 @@ def test_config4_placements_are_consistent():
                 if placement == "vehicle" and W > 1:      # the neighbour really lives on another rank
                     assert ((s["other_index"][lead] // (3 * F // W)) != r).all()
                 if placement == "vehicle":                # peer windows: the neighbour is a row of rank (r + 1) % W's own buffer
-                    prow = ndist.config4_other_index(r, W, F, "vehicle", peer_rows=True)
+                    prow = ndist.config4_other_index(r, W, F, "vehicle", peer_rows=True, order=order)
                     assert (prow[~lead] == -1).all()
                     nxt = shards[ndist.neighbour_rank(r, W)]
                     assert np.array_equal(nxt["xr"][prow[lead]], allv["xr"][s["gids"][lead] + 1])
