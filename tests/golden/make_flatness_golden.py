@@ -25,6 +25,8 @@ Output (committed): tests/golden/flat_golden.npz
 import math
 import os
 import sys
+
+sys.dont_write_bytecode = True    # importing from /root/reference must not leave __pycache__ there (the tree is read-only by contract)
 import types
 
 import numpy as np

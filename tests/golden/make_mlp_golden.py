@@ -11,6 +11,8 @@ Outputs (committed):
 import os
 import sys
 
+sys.dont_write_bytecode = True    # importing from /root/reference must not leave __pycache__ there (the tree is read-only by contract)
+
 import numpy as np
 import torch
 

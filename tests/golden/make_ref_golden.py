@@ -16,6 +16,8 @@ Output (committed): tests/golden/ref_golden.npz, per case c in 0..3:
 import os
 import sys
 
+sys.dont_write_bytecode = True    # importing from /root/reference must not leave __pycache__ there (the tree is read-only by contract)
+
 import numpy as np
 
 sys.path.insert(0, "/root/reference/ndp_nmpc/scripts/pt_pub")

@@ -10,6 +10,8 @@ Output (committed): tests/golden/throttle_golden.npz
 import os
 import sys
 
+sys.dont_write_bytecode = True    # importing from /root/reference must not leave __pycache__ there (the tree is read-only by contract)
+
 import numpy as np
 
 S = "/root/reference/ndp_nmpc/scripts"
