@@ -127,13 +127,17 @@ int ndp_step_device(ndp_handle *h, const void *d_x0, const void *d_xr, const voi
 int ndp_step_ex(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
                 const double *other, const double *ego_xy, double *u0, double *X_out, double *U_out,
                 int32_t *status_out, int32_t *ipm_iters_out);
-/* The same step in two halves, so that a caller can keep two control ticks in flight: ndp_step_begin packs the inputs, enqueues
- * H2D -> kernel -> D2H and returns without waiting; ndp_step_end waits for the OLDEST begun step and hands its results over.
- * With a second ndp_step_begin issued before the first ndp_step_end, the packing and PCIe transfer of tick i+1 run while tick
- * i's kernel does -- the reference's control loop has that freedom too: x0 comes from odometry, not from the previous u0
- * (nmpc_node.py:202-226).  At most two steps may be in flight (a third ndp_step_begin returns -14); steps complete in order;
- * the warm start of tick i+1 is tick i's iterate, as always (stream order).
+/* The same step in two halves, so that a caller can keep two control ticks in flight: ndp_step_begin packs the inputs into a
+ * slot's page-locked mirror, enqueues ONE launch -- whose waves read that mirror over PCIe and write u0 / status / iterations into
+ * the slot's page-locked output block themselves (zero-copy: no H2D / D2H copy operation) -- and returns without waiting;
+ * ndp_step_end waits for the OLDEST begun step and hands its results over.  With a second ndp_step_begin issued before the first
+ * ndp_step_end, the packing of tick i+1 runs while tick i's kernel does -- the reference's control loop has that freedom too: x0
+ * comes from odometry, not from the previous u0 (nmpc_node.py:202-226).  At most two steps may be in flight (a third
+ * ndp_step_begin returns -14); steps complete in order; the warm start of tick i+1 is tick i's iterate, as always (stream order).
  *   flags bit 0: ndp_step_end will be asked for the iterate (X_out / U_out) of this step.
+ * Every begun step must be drained with ndp_step_end BEFORE ndp_reset / ndp_set_iterate (they wait for the device, but the
+ * results of a step still in flight would be lost and its slot stays busy) and before ndp_destroy (which frees the mirrors a
+ * running kernel reads and writes: it synchronises the handle's stream first, but steps begun on it are the caller's to finish).
  * ndp_step / ndp_step_ex = begin + end under one lock. */
 int ndp_step_begin(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
                    const double *other, const double *ego_xy, int flags);
@@ -354,10 +358,11 @@ int ndp_xchg_destroy(ndp_xchg *x);
 int ndp_debug_lds_doubles(int N);
 /* Test hook: where things sit in that dump: out8 = {XI, MB, CB, MB stride, CB stride, image size, first stamp, 0} (doubles). */
 int ndp_debug_lds_layout(int N, int *out8);
-/* Test hook: one v_mfma_f64_16x16x4_f64 on caller-chosen per-lane operands a[64], b[64], c[4][64]; d has 640 doubles:
+/* Test hook: one v_mfma_f64_16x16x4_f64 on caller-chosen per-lane operands a[64], b[64], c[4][64]; d has 832 doubles:
  * d[0..255] = result registers [4][64], d[256..319] = a cross-lane checksum (readlane + wave reductions),
  * d[320..383] = one v_mfma_f64_4x4x4_4b_f64 (four blocks) on a, b with accumulator c[0], d[384..639] = a after the row
- * broadcasts of lanes 0, 4, 8, 12 of every 16-lane row (DPP row_newbcast). */
+ * broadcasts of lanes 0, 4, 8, 12 of every 16-lane row (DPP row_newbcast), d[640..831] = a after the row rotations by 4, 8, 12
+ * lanes (DPP row_ror). */
 int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, double *d);
 /* Test hook: the config-5 instructions through their backends.  mode 0: one v_mfma_f32_16x16x4_f32 on a[0][64], b[0][64];
  * mode 1: one v_mfma_f32_16x16x16_bf16 on four packed contraction steps a[4][64], b[4][64]; c[4][64] -> d[0..255];

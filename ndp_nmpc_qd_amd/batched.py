@@ -96,9 +96,11 @@ class BatchedNMPC:
         return (u0, X, U, st, it) if full else u0
 
     def update_begin(self, x0, xr, ur, f=None, other=None, ego_xy=None, want_iterate=False):
-        """First half of update(): packs the host arrays, enqueues H2D -> kernel -> D2H and returns without waiting
-        (ndp_step_begin).  Up to two steps may be in flight: begin tick i+1 before update_end() of tick i and the packing and
-        PCIe transfer of tick i+1 overlap tick i's kernel.  The arrays may be reused as soon as this returns."""
+        """First half of update(): packs the host arrays into a page-locked mirror, enqueues ONE launch that reads the mirror over
+        PCIe and writes its results into a page-locked block itself (zero-copy: no H2D / D2H copy operation) and returns without
+        waiting (ndp_step_begin).  Up to two steps may be in flight: begin tick i+1 before update_end() of tick i and the packing
+        of tick i+1 overlaps tick i's kernel.  The arrays may be reused as soon as this returns.  Drain every begun step with
+        update_end() before reset() / set_iterate() / close()."""
         x0 = _lib.f64(x0, (self.B, 10))
         xr = _lib.f64(xr, (self.B, self.N + 1, 10))
         ur = _lib.f64(ur, (self.B, self.N, 4))

@@ -388,6 +388,10 @@ __global__ void mfma_probe_kernel(const double *a, const double *b, const double
     d[448 + l] = WaveGfx950::rowb<1>(a[l]);
     d[512 + l] = WaveGfx950::rowb<2>(a[l]);
     d[576 + l] = WaveGfx950::rowb<3>(a[l]);
+    // the row rotations that bring the packed -Lam^-1 of a stage to block 3 (rti_wave.hpp: linv_get)
+    d[640 + l] = WaveGfx950::rowror4<1>(a[l]);
+    d[704 + l] = WaveGfx950::rowror4<2>(a[l]);
+    d[768 + l] = WaveGfx950::rowror4<3>(a[l]);
 }
 
 // test hook: one v_mfma_f32_16x16x4_f32 (mode 0) or one v_mfma_f32_16x16x16_bf16 (mode 1: four packed contraction steps)
@@ -1330,6 +1334,14 @@ template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = 
 #endif
 struct RtiK { static constexpr auto fn = rti_kernel<3, (WAVES == 2 && NC == 20 ? 2 : 4), (FUSED && NC == 20 && QMODE == 0), 20, 0, 1, NDP_DEV_QMODE>; };
 #define RTI_K(...) (RtiK<__VA_ARGS__>::fn)
+#elif defined(NDP_DEV_N40_ONLY)
+// register studies of config 5's shape (scripts/dev_regs.sh): every instantiation collapses onto rti_kernel<5, 2, false, 40, 0, 2, NDP_DEV_QMODE>
+#ifndef NDP_DEV_QMODE
+#define NDP_DEV_QMODE 0
+#endif
+template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), int QMODE = 0>
+struct RtiK { static constexpr auto fn = rti_kernel<5, 2, false, 40, 0, 2, NDP_DEV_QMODE>; };
+#define RTI_K(...) (RtiK<__VA_ARGS__>::fn)
 #else
 #define RTI_K(...) (rti_kernel<__VA_ARGS__>)
 #endif
@@ -1488,6 +1500,7 @@ struct ndp_handle {
     // ndp_track_steps: the completion of every control step marks an event WITHOUT a packet of its own (the dispatch packet's
     // completion signal, hipExtLaunchKernel) -- what another stream orders itself behind (ndp_xchg_begin's after_event)
     bool track_steps = false;
+    bool last_step_tracked = false;   // does stepDone[step_seq & 3] belong to the control step launched LAST?
     hipEvent_t stepDone[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned step_seq = 0;
     double host_us[4] = {0, 0, 0, 0};   // last host step: packing | enqueue | wait for the results | copy-out  (ndp_debug_host_timing)
@@ -1553,13 +1566,13 @@ int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, doub
 {
     double *da = nullptr, *db = nullptr, *dc = nullptr, *dd = nullptr;
     if (hipMalloc((void **)&da, 64 * 8) != hipSuccess || hipMalloc((void **)&db, 64 * 8) != hipSuccess ||
-        hipMalloc((void **)&dc, 256 * 8) != hipSuccess || hipMalloc((void **)&dd, 640 * 8) != hipSuccess)
+        hipMalloc((void **)&dc, 256 * 8) != hipSuccess || hipMalloc((void **)&dd, 832 * 8) != hipSuccess)
         return -1;
     (void)hipMemcpy(da, a, 64 * 8, hipMemcpyHostToDevice);
     (void)hipMemcpy(db, b, 64 * 8, hipMemcpyHostToDevice);
     (void)hipMemcpy(dc, c, 256 * 8, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, 0, da, db, dc, dd);
-    const hipError_t e = hipMemcpy(d, dd, 640 * 8, hipMemcpyDeviceToHost);
+    const hipError_t e = hipMemcpy(d, dd, 832 * 8, hipMemcpyDeviceToHost);
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dd);
     return e == hipSuccess ? 0 : -2;
 }
@@ -1689,6 +1702,12 @@ int ndp_last_step_event(ndp_handle *h, void **event)
     if (!h || !event) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->track_steps || h->step_seq == 0) { h->err = "ndp_last_step_event: no tracked step yet (ndp_track_steps first)"; return -14; }
+    if (!h->last_step_tracked) {
+        h->err = "ndp_last_step_event: the control step launched last carried no completion event (launched while tracking was off, or "
+                 "through a path that does not mark one): ordering a gather behind an OLDER step's event could overwrite a buffer the "
+                 "last step still reads";
+        return -14;
+    }
     *event = (void *)h->stepDone[h->step_seq & 3];
     return 0;
 }
@@ -1724,7 +1743,7 @@ int rccl_bind(const char *path)
     a.uid = (fn_uid)dlsym(l, "ncclGetUniqueId"); a.init = (fn_init)dlsym(l, "ncclCommInitRank");
     a.allgather = (fn_ag)dlsym(l, "ncclAllGather"); a.destroy = (fn_destroy)dlsym(l, "ncclCommDestroy");
     a.errstr = (fn_errstr)dlsym(l, "ncclGetErrorString");
-    if (!a.uid || !a.init || !a.allgather || !a.destroy) return -21;
+    if (!a.uid || !a.init || !a.allgather || !a.destroy) { dlclose(l); return -21; }
     g_rccl = a;
     return 0;
 }
@@ -2102,6 +2121,18 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     const size_t shm = (size_t)h->lds_per_wave * sizeof(double) * W;
     const int ns = slots_for(h->cfg.N);
     const bool q = h->use_queue && !d_dbg;
+    // Tracked steps carry their completion event on a dispatch packet (hipExtLaunchKernel), which a stream capture cannot hold:
+    // refuse instead of launching something the graph would silently drop the event of.
+    h->last_step_tracked = false;
+    if (h->track_steps) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs != hipStreamCaptureStatusNone) {
+            h->err = "tracked control steps (ndp_track_steps) cannot be launched on a stream that is being captured: switch tracking off "
+                     "and order the exchange through the stream (ndp_xchg_begin's after_stream)";
+            return -15;
+        }
+    }
     int rc = begin_timing(h, s, 0, true);
     if (rc) return rc;
     // timed launch of a single-kernel step: the pair rides on the dispatch packet (otherwise recorded around the launches)
@@ -2119,12 +2150,17 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
         else if (pr == 3) hipLaunchKernelGGL(RTI_K(5, 1, false, 0, 3), dim3(B), dim3(64), shm1, s, ka);
         else hipLaunchKernelGGL(RTI_K(5, 1, false, 0, 4), dim3(B), dim3(64), shm1, s, ka);
         NDP_HIP(h, hipGetLastError());
+        if (so && so->done) NDP_HIP(h, hipEventRecord(so->done, s));
+        else if (h->track_steps) {          // (a recorded event here: the precision studies are not on the exchange's fast path)
+            NDP_HIP(h, hipEventRecord(h->stepDone[++h->step_seq & 3], s));
+            h->last_step_tracked = true;
+        }
         return end_timing(h, s);
     }
     // tracked steps: the LAST launch of the step carries the completion event (in-place kernel, or the work list's reset launch)
     hipEvent_t stop = nullptr;
     if (so && so->done) stop = so->done;
-    else if (h->track_steps) stop = h->stepDone[++h->step_seq & 3];
+    else if (h->track_steps) { stop = h->stepDone[++h->step_seq & 3]; h->last_step_tracked = true; }
 #define LAUNCH(...)                                                                                                  \
     do {                                                                                                             \
         if (ext_timing) {                                                                                            \
@@ -2249,13 +2285,14 @@ static int ensure_prefetch(ndp_handle *h)
     if (h->cfg.qp_precision) { h->err = "downwash prefetch serves the fp64 product path only"; return -12; }
     if (h->cfg.N + 1 > 32) { h->err = "downwash prefetch needs N + 1 <= 32 (an instance's rows in at most two 32-row tiles)"; return -12; }
     if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }
+    // (h->aux, created last, marks completion; members a failed earlier call did allocate are reused, not allocated again)
     for (int i = 0; i < 2; ++i) {
-        NDP_HIP(h, hipMalloc((void **)&h->dForceAB[i], nfs(h) * 4));
+        if (!h->dForceAB[i]) NDP_HIP(h, hipMalloc((void **)&h->dForceAB[i], nfs(h) * 4));
         NDP_HIP(h, hipMemset(h->dForceAB[i], 0, nfs(h) * 4));
     }
     h->pf_ntiles = (unsigned)((h->cfg.batch * (h->cfg.N + 1) + 31) / 32);
     const size_t proto_words = (size_t)PF_EPOCH + 2 * (size_t)h->pf_ntiles;
-    NDP_HIP(h, hipMalloc((void **)&h->dProto, proto_words * 8));
+    if (!h->dProto) NDP_HIP(h, hipMalloc((void **)&h->dProto, proto_words * 8));
     NDP_HIP(h, hipMemset(h->dProto, 0, proto_words * 8));
     {
         const unsigned grid_rti = (unsigned)((h->cfg.batch + h->waves - 1) / h->waves);
@@ -2265,9 +2302,9 @@ static int ensure_prefetch(ndp_handle *h)
     // queue would execute behind it).  Streams of another priority level get queues of their own.
     int lo = 0, hi = 0;
     NDP_HIP(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (!h->evFork) NDP_HIP(h, hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
+    if (!h->evJoin) NDP_HIP(h, hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
     NDP_HIP(h, hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, hi));
-    NDP_HIP(h, hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
-    NDP_HIP(h, hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
     return 0;
 }
 
@@ -2346,10 +2383,13 @@ static int ensure_slots(ndp_handle *h)
     if (h->slots_ready) return 0;
     for (int i = 0; i < 2; ++i) {
         ndp_handle::HostSlot &sl = h->slot[i];
-        NDP_HIP(h, hipHostMalloc((void **)&sl.hIn, h->in_bytes, hipHostMallocDefault));
-        NDP_HIP(h, hipHostMalloc((void **)&sl.hOut, h->out_all, hipHostMallocDefault));
-        memset(sl.hOut, 0, h->out_bytes);
-        NDP_HIP(h, hipEventCreateWithFlags(&sl.evOut, hipEventDisableTiming));
+        // (only what is missing: a call that failed part-way left the members it did allocate, and they are reused -- ndp_destroy frees them)
+        if (!sl.hIn) NDP_HIP(h, hipHostMalloc((void **)&sl.hIn, h->in_bytes, hipHostMallocDefault));
+        if (!sl.hOut) {
+            NDP_HIP(h, hipHostMalloc((void **)&sl.hOut, h->out_all, hipHostMallocDefault));
+            memset(sl.hOut, 0, h->out_bytes);
+        }
+        if (!sl.evOut) NDP_HIP(h, hipEventCreateWithFlags(&sl.evOut, hipEventDisableTiming));
     }
     // pack threads: NDP_PACK_THREADS, else half the hardware threads, at most 8; the caller packs too, so small blocks need none
     int nt = 0;

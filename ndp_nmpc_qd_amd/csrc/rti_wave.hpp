@@ -53,10 +53,19 @@ enum { MB_STRIDE = 138, CB_STRIDE = 48 };
 // stage block MB_k: 6x8 [d(p,v)+/d(q,u)] | 4x7 [dq+/d(q,w)] | b(10) | constants 0, 1, h | K~'(12x4, written by the backward sweep)
 // | one dump slot (where the lanes that hold no K~' entry store, so that the sweep's stores need no predicate)
 enum { MB_PV = 0, MB_Q = 48, MB_B = 76, MB_ZERO = 86, MB_ONE = 87, MB_H = 88, MB_KT = 89, MB_DUMP = 137 };
-// cost block CB_k: Qq(4x4) | qe(10) | re(4) | dex(6) | deu(4) | qbv(3) | rb(4) | constant 0
-enum { CB_QQ = 0, CB_QE = 16, CB_RE = 26, CB_DEX = 30, CB_DEU = 36, CB_QBV = 40, CB_RB = 43, CB_ZERO = 47 };
+// cost block CB_k: Qq(4x4) | qe(10) | re(4) | dex(6) | constant 0 | qbv(3) | deu(4) | rb(4)
+enum { CB_QQ = 0, CB_QE = 16, CB_RE = 26, CB_DEX = 30, CB_ZERO = 36, CB_QBV = 37, CB_DEU = 40, CB_RB = 44 };
 // constants area
-enum { KC_ZERO = 0, KC_ONE = 1, KC_H = 2, KC_QD = 4, KC_RD = 14, KC_LBU = 18, KC_UBU = 22, KC_LBV = 26, KC_UBV = 29, KC_SC = 32, KC_DUMP = 48, KC_SIZE = 50 };
+enum { KC_ZERO = 0, KC_ONE = 1, KC_H = 2, KC_QD = 3, KC_RD = 13, KC_LBV = 17, KC_UBV = 21, KC_LBU = 24, KC_UBU = 28, KC_SC = 32, KC_DUMP = 48, KC_SIZE = 50 };
+// A box constraint (interior-point loop) touches eight LDS places: the step variable, the iterate value, the diagonal / gradient /
+// base-gradient entries of its cost block, its two bounds and its weight.  The two layouts above are arranged so that FIVE of them
+// sit at the same distance from another one for input bounds and velocity bounds alike -- three offsets per constraint slot live in
+// registers instead of eight (25 registers per lane at N = 40), the rest are immediates of the DS instructions:
+static_assert(CB_RE - CB_DEU == (CB_QE + 3) - (CB_DEX + 3), "gradient entry: the same distance from the diagonal entry for u and v bounds");
+static_assert(CB_RB - CB_DEU == CB_QBV - (CB_DEX + 3), "base gradient: the same distance from the diagonal entry for u and v bounds");
+static_assert(KC_UBU - KC_LBU == KC_UBV - KC_LBV, "upper bound: the same distance from the lower bound for u and v bounds");
+static_assert(KC_RD - KC_LBU == (KC_QD + 3) - KC_LBV, "weight: the same distance from the lower bound for u and v bounds");
+enum { SL_GE = CB_RE - CB_DEU, SL_GB = CB_RB - CB_DEU, SL_UB = KC_UBU - KC_LBU, SL_DW = KC_RD - KC_LBU };
 
 struct RtiParams {
     int N, n_rti, use_fd, qp_mode, iter_max;
@@ -216,6 +225,58 @@ struct RtiWave {
             return d;
         }
     }
+    // Lane id of the per-iteration phases (inputs, cost, linearisation).  With several RTI iterations per step (unrolled: NR = 2,
+    // config 5) the compiler finds the phases' index arithmetic -- task -> (stage, row) -> LDS address, ~100 values per lane -- common
+    // to the copies, computes it ONCE at the kernel's start and keeps it alive across the first iteration's sweeps and its
+    // interior-point loop: 93 scratch stores in the set-up block, 51 loads in front of the linearisations (profiles/r03_isa_audit.txt).
+    // An opaque lane id per phase makes every copy compute its own (a few hundred integer instructions per iteration).  One-iteration
+    // kernels (the headline) keep the plain id: their code does not change.
+    static NDP_D vi lane_it() { if constexpr (NR == 1) return W::lane(); else return W::lane_here(); }
+    // -Lam_k^-1 of every stage, kept for the second solve (delta_sweep).  On the four-block instruction only the lanes of block 3
+    // (columns 12..15: rows 12..15 of the A operand [K~' ; -Lam^-1 - I]) ever use it, while every block holds a copy when it is
+    // produced: FOUR stages share one register -- the lanes of block b keep stage 4q + b -- and the second solve brings the block it
+    // wants to block 3 with one row rotation (DPP row_ror, no LDS).  N / 4 registers per lane instead of N: at N = 40 the 40
+    // registers (80 VGPRs) were the part of the interior-point state that went to scratch memory, one store and one load per stage.
+    static constexpr bool PACKL = MMA4;
+    static constexpr int linv_regs(int n) { return PACKL ? (n + 3) / 4 : n; }
+    // register q of the pack, reached through CONSTANT indices only (a switch that folds once the stage loops are unrolled): an
+    // index computed from the loop counter keeps the array in private memory -- the compiler promotes it to registers before it
+    // unrolls the loops, and only if every index is a constant by then
+    template <class F>
+    static NDP_D void linv_reg(md *linv, int q, F &&f)
+    {
+        switch (q) {
+#define NDP_LC(i) case i: f(linv[i]); break;
+        NDP_LC(0) NDP_LC(1) NDP_LC(2) NDP_LC(3) NDP_LC(4) NDP_LC(5) NDP_LC(6) NDP_LC(7)
+        NDP_LC(8) NDP_LC(9) NDP_LC(10) NDP_LC(11) NDP_LC(12) NDP_LC(13) NDP_LC(14) NDP_LC(15)
+#undef NDP_LC
+        default: break;
+        }
+    }
+    static_assert(NC <= 64, "linv_reg serves packs of up to 16 registers");
+    static NDP_D void linv_put(md *linv, int k, int N, md v)
+    {
+        if constexpr (PACKL) {
+            // the backward sweep comes down from stage N - 1: the first stage that writes a register fills all its lanes (every
+            // lane then holds a finite value of SOME stage -- the lanes the second solve does not read are multiplied by zero)
+            const bool whole = (k & 3) == 3 || k == N - 1;
+            const vb mine = ((W::lane() >> 2) & 3) == (k & 3);
+            linv_reg(linv, k >> 2, [&](md &r) { r = whole ? v : W::msel(mine, v, r); });
+        } else linv[k] = v;
+    }
+    static NDP_D md linv_get(const md *linv, int k)      // PACKL: valid in the lanes of block 3 only (all the second solve reads)
+    {
+        if constexpr (PACKL) {
+            md v = W::to_m(vd(0.0));
+            linv_reg(const_cast<md *>(linv), k >> 2, [&](md &r) { v = r; });
+            switch (k & 3) {
+            case 0: return W::template rowror4<3>(v);
+            case 1: return W::template rowror4<2>(v);
+            case 2: return W::template rowror4<1>(v);
+            default: return v;
+            }
+        } else return linv[k];
+    }
     static NDP_D int mb(int k) { return k * int(MB_STRIDE); }   // stage offsets (immediates once the stage loops are unrolled)
     static NDP_D int cb(int k) { return k * int(CB_STRIDE); }
     using lp = typename W::lds_ptr;   // pointer into this wave's LDS slice
@@ -241,17 +302,18 @@ struct RtiWave {
         vd cof_sign;              // (-1)^(g + j&3)
         vd adj_a, adj_b;          // cof_sign * [j < 4], -cof_sign * [j >= 12]: minor determinant -> MFMA operand in one multiply
         vb lam_diag;              // g == j&3
-        vd eye[4];                // identity as B operand: chunk c, lane (g,j) = [j == 4c+g]
     };
 
     struct Slots {                // box constraints, 64 per slot
         vb valid[NSLOT];
-        vi zoff[NSLOT];           // where the bounded step variable lives in ZX/ZU
-        vi ioff[NSLOT];           // where the iterate value lives in XI/UI
-        vi de_off[NSLOT], ge_off[NSLOT], gb_off[NSLOT];
-        vi lb_off[NSLOT], ub_off[NSLOT], dw_off[NSLOT];
-        vd lo[NSLOT], hi[NSLOT], tl[NSLOT], tu[NSLOT], ll[NSLOT], lu[NSLOT];
-        vd dtl[NSLOT], dtu[NSLOT], dll[NSLOT], dlu[NSLOT];
+        vi zoff[NSLOT];           // where the bounded step variable lives in ZX/ZU; the iterate value: + io (XI|UI and ZX|ZU are laid out alike)
+        vi de_off[NSLOT];         // diagonal entry of the cost block; gradient: + SL_GE, base gradient: + SL_GB
+        vi lb_off[NSLOT];         // lower bound in the constants area; upper bound: + SL_UB, weight: + SL_DW
+        int io;                   // XI - ZX
+        vd lo[NSLOT], hi[NSLOT];  // step bounds lb - cur, ub - cur: filled by load_bounds for the inside-the-box test; the interior-point
+                                  // loop re-reads them from LDS where it needs them (bounds()) instead of holding 4 NSLOT registers
+        vd tl[NSLOT], tu[NSLOT], ll[NSLOT], lu[NSLOT];
+        vd pl[NSLOT], pu[NSLOT];  // predictor's dlam * dt per bound: all that the corrector keeps of the affine step across its sweep
     };
 
     // ---------------------------------------------------------------- index tables
@@ -309,7 +371,6 @@ struct RtiWave {
         // the 4x4x4 products read the 4x4 operand from every lane (block b = its own copy): no lane mask
         T.adj_a = MMA4 ? T.cof_sign : W::sel(T.lo4, T.cof_sign, vd(0.0));
         T.adj_b = MMA4 ? -T.cof_sign : W::sel(T.kt_pred, -T.cof_sign, vd(0.0));
-        for (int c = 0; c < 4; ++c) T.eye[c] = W::sel(j == g + 4 * c, vd(1.0), vd(0.0));
     }
 
     static NDP_HD void build_tables(const LdsMap &m, Tables &T)
@@ -380,7 +441,7 @@ struct RtiWave {
     static NDP_D void issue_inputs(const RtiParams &P, const RtiIo &io, InBuf &b, bool first)
     {
         const int N = horizon(P);
-        vi lane = W::lane();
+        vi lane = lane_it();
         const int nx = (N + 1) * NX, nu = N * NU, nf = (N + 1) * 3;
         const bool have_f = P.use_fd && io.f && !io.f_in_lds;
         // unconditional loads from a clamped index (a predicated load compiles to a branchy block each);
@@ -406,7 +467,7 @@ struct RtiWave {
     static NDP_D void commit_inputs(const RtiParams &P, const LdsMap &m, const InBuf &b, lp lds, bool first)
     {
         const int N = horizon(P);
-        vi lane = W::lane();
+        vi lane = lane_it();
         const int nx = (N + 1) * NX, nu = N * NU, nf = (N + 1) * 3;
         // the loads came from clamped indices: lanes past the end hold a copy of the last element and store it to the last
         // slot again -- an identical duplicate, so no store needs a predicate (a predicated LDS store is an exec-mask
@@ -434,7 +495,7 @@ struct RtiWave {
     static NDP_D void build_cost(const RtiParams &P, const LdsMap &m, lp lds)
     {
         const int N = horizon(P);
-        vi lane = W::lane();
+        vi lane = lane_it();
         // Three task families, each at most a few 64-lane rounds; lanes past a family's last task repeat that task and store
         // the same values to the same places (no predicates).  Every LDS read of every round is issued before the
         // first result is needed (one wait per family instead of one per round), then computed, then stored.
@@ -572,7 +633,7 @@ struct RtiWave {
     {
         const int N = horizon(P);
         const double h = P.dt, h2 = h * h, hh = 0.5 * h, h6 = P.h_6, hp = P.h2_6;
-        vi lane = W::lane();
+        vi lane = lane_it();
         // ---- d/dq columns: one lane per (stage, j), 4N tasks
         for (int t = 0; t < 4 * N; t += 64) {
             vi task = W::imin(lane + t, 4 * N - 1);       // lanes past the last task repeat it: identical duplicate stores, no predicates
@@ -730,6 +791,9 @@ struct RtiWave {
     // The LDS operands of the next stage are requested one stage ahead, so the LDS latency is paid while the MFMA chain runs (LDS, unlike the wave's own VALU work, does proceed under it).
     // linv (compile-time horizons only, else null): per stage, -Lam^-1 in the lanes j >= 12 (the B operand of the K~' product),
     // kept in registers for delta_sweep.
+    // KEEP (compile time, not "linv != null": the address of a private array compared with null is a RUN-time test after the
+    // address-space cast, a branch around every store, and it keeps the array in scratch memory): store -Lam^-1 of every stage.
+    template <bool KEEP = false>
     static NDP_D bool riccati_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, lp lds,
                                     const RtiIo *io = nullptr, md *linv = nullptr)
     {
@@ -810,7 +874,9 @@ struct RtiWave {
             W::pin();
             dq = dq + W::csum1(dq);                           // the four lanes holding one row of Lam (a quad in the f64 layout)
             vd ladj = cofu * T.adj_a;                         // A operand: adj(Lam)[g][j], j < 4 (sign and lane mask in one factor)
-            vd nahi = cofu * T.adj_b;                         // B operand of K~': -adj[g][j-12] in columns 12..15
+            vd nahi;                                          // B operand of K~': -adj[g][j-12] in columns 12..15
+            if constexpr (MMA4) nahi = -ladj;                 // (four-block form: every block reads its own copy, adj_b = -adj_a; the sign rides on the consumer)
+            else nahi = cofu * T.adj_b;
             W::pin();
             md tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
             md G0;                                            // adj T, lane l: row l >> 4, column l & 15
@@ -836,7 +902,7 @@ struct RtiWave {
             // K~' = H~ux' (-Lam^-1): the 1/det rides in the B operand (one multiply instead of one per result register); lands in
             // column 12+b = rows 12..15 of the forward operand; stored behind the next stage's first MFMAs
             const md nli = W::to_m(nahi * rdet);
-            if (linv) linv[k] = nli;
+            if constexpr (KEEP) linv_put(linv, k, N, nli);
             if constexpr (MMA4) Ktq = mma4(hux, nli, W::to_m(vd(0.0)));     // K~'[4b + i][j] in lane j + 4b + 16i
             else Ktp = mma(hux, nli, W::mzero4());
             kprev = k;
@@ -844,8 +910,12 @@ struct RtiWave {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
                 // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
                 // re-symmetrise every 8th stage (growth x550 in between: 1e-16 -> 5e-14).  H~' = (H~ as A operand) x I costs four MFMAs, no LDS.
-                md ey[4];
-                for (int c = 0; c < 4; ++c) ey[c] = W::to_m(T.eye[c]);
+                md ey[4];          // identity as B operand: chunk c, lane (g, j) = [j == 4c + g] -- made here, every 8th stage, not kept
+                {
+                    vi ln = W::lane_here();
+                    vi gg = ln >> 4, jj = W::lcol(ln);
+                    for (int c = 0; c < 4; ++c) ey[c] = W::to_m(W::sel(jj == gg + 4 * c, vd(1.0), vd(0.0)));
+                }
                 md4 Tp = mman<4>(Hn.r, ey, W::mzero4());
                 for (int r = 0; r < 4; ++r) Hn.r[r] = W::mavg(Hn.r[r], Tp.r[r]);
             }
@@ -864,7 +934,7 @@ struct RtiWave {
             vd cof = lam_cofactor(T, LR);
             vd rdet = lam_rdet(T, LR, cof, ok);
             vd nahi = MMA4 ? -cof : W::sel(T.kt_pred, -cof, vd(0.0));
-            if (linv) linv[0] = W::to_m(nahi * rdet);
+            if constexpr (KEEP) linv_put(linv, 0, N, W::to_m(nahi * rdet));
             if constexpr (MMA4) {
                 W::st(lds, T.kt_st4, W::to_d(mma4(hux, W::to_m(nahi), W::to_m(vd(0.0)))) * rdet);
             } else {
@@ -935,7 +1005,7 @@ struct RtiWave {
     struct DeltaTabs { vi dc_off[4], kta_off, dc_off4, dk_off; md eye12, m12; vb row10, g2; };
     static NDP_D void build_delta_tabs(const LdsMap &m, DeltaTabs &D)
     {
-        vi lane = W::lane();
+        vi lane = W::lane_here();
         vi g = lane >> 4, j = W::lcol(lane);
         vb c0 = j == 0;
         for (int r = 0; r < 4; ++r) {
@@ -977,7 +1047,7 @@ struct RtiWave {
                     nkta = W::to_m(W::ld(lds, D.kta_off + mb(k - 1)));
                 }
                 W::pin();
-                md akl = kta + W::fma(linv[k], D.m12, -D.eye12);
+                md akl = kta + W::fma(linv_get(linv, k), D.m12, -D.eye12);
                 if (k != N - 1)
                     for (int c = 0; c < 3; ++c) Dg = mma4(a[c], vc[c], Dg);
                 md Dp = mma4(akl, W::template rowb<3>(Dg), Dg);
@@ -1028,7 +1098,7 @@ struct RtiWave {
             for (int r = 0; r < 4; ++r) C.r[r] = W::to_m(W::ld(lds, D.dc_off[r] + cb(k)));
             md a[3];
             for (int c = 0; c < 3; ++c) a[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(k)));
-            md akl = W::to_m(W::ld(lds, D.kta_off + mb(k))) + (linv[k] - D.eye12);
+            md akl = W::to_m(W::ld(lds, D.kta_off + mb(k))) + (linv_get(linv, k) - D.eye12);
             md4 Dg = k == N - 1 ? C : mman<3>(a, vc, C);
             md4 Dp = mma(akl, Dg.r[3], Dg);
             dk[k] = Dp.r[3];
@@ -1061,7 +1131,7 @@ struct RtiWave {
     static NDP_D void build_slots(const RtiParams &P, const LdsMap &m, Slots &S)
     {
         const int N = horizon(P), nu = 4 * N, mcon = 7 * N - 3;
-        vi lane = W::lane();
+        vi lane = W::lane_here();      // (computed here, at the interior-point loop's door -- not hoisted to the kernel's start)
         for (int s = 0; s < NSLOT; ++s) {
             vi n = lane + 64 * s;
             S.valid[s] = n < mcon;
@@ -1074,22 +1144,26 @@ struct RtiWave {
             vi i = W::sel(isu, n & 3, iv);
             vi cb = k * int(CB_STRIDE) + m.CB;
             S.zoff[s] = W::sel(isu, k * NU + i + m.ZU, k * NX + i + (m.ZX + 3));
-            S.ioff[s] = W::sel(isu, k * NU + i + m.UI, k * NX + i + (m.XI + 3));
             S.de_off[s] = cb + W::sel(isu, i + int(CB_DEU), i + (int(CB_DEX) + 3));
-            S.ge_off[s] = cb + W::sel(isu, i + int(CB_RE), i + (int(CB_QE) + 3));
-            S.gb_off[s] = cb + W::sel(isu, i + int(CB_RB), i + int(CB_QBV));
             S.lb_off[s] = W::sel(isu, i + (m.KC + KC_LBU), i + (m.KC + KC_LBV));
-            S.ub_off[s] = W::sel(isu, i + (m.KC + KC_UBU), i + (m.KC + KC_UBV));
-            S.dw_off[s] = W::sel(isu, i + (m.KC + KC_RD), i + (m.KC + KC_QD + 3));
         }
+        S.io = m.XI - m.ZX;           // (= UI - ZU: the two pairs of arrays are laid out alike)
+    }
+
+    // the step bounds of slot s, read from LDS (the iterate does not move during a QP solve)
+    static NDP_D void bounds(const Slots &S, lp lds, int s, vd &lo, vd &hi)
+    {
+        vd cur = W::ld(lds, S.zoff[s] + S.io);
+        lo = W::ld(lds, S.lb_off[s]) - cur;
+        hi = W::ld(lds, S.lb_off[s] + int(SL_UB)) - cur;
     }
 
     static NDP_D void load_bounds(const LdsMap &, Slots &S, lp lds)
     {
         for (int s = 0; s < NSLOT; ++s) {
-            vd cur = W::ld(lds, S.ioff[s]);
+            vd cur = W::ld(lds, S.zoff[s] + S.io);
             S.lo[s] = W::ld(lds, S.lb_off[s]) - cur;
-            S.hi[s] = W::ld(lds, S.ub_off[s]) - cur;
+            S.hi[s] = W::ld(lds, S.lb_off[s] + int(SL_UB)) - cur;
         }
     }
 
@@ -1136,14 +1210,16 @@ struct RtiWave {
         vd musum = 0.0, nrm = 1.0;
         for (int s = 0; s < NSLOT; ++s) {
             vb v = S.valid[s];
-            S.tl[s] = W::sel(v, W::vmax(-S.lo[s], vd(P.thr0)), vd(1.0));
-            S.tu[s] = W::sel(v, W::vmax(S.hi[s], vd(P.thr0)), vd(1.0));
+            vd lo, hi;
+            bounds(S, lds, s, lo, hi);
+            S.tl[s] = W::sel(v, W::vmax(-lo, vd(P.thr0)), vd(1.0));
+            S.tu[s] = W::sel(v, W::vmax(hi, vd(P.thr0)), vd(1.0));
             S.ll[s] = W::sel(v, W::rcp(S.tl[s]) * P.mu0, vd(0.0));     // reciprocals (v_rcp_f64 + Newton), not IEEE divides:
             S.lu[s] = W::sel(v, W::rcp(S.tu[s]) * P.mu0, vd(0.0));     // a divide is ~30 VALU instructions, the loop had 14 per slot
-            S.dtl[s] = 0.0; S.dtu[s] = 0.0; S.dll[s] = 0.0; S.dlu[s] = 0.0;
+            S.pl[s] = 0.0; S.pu[s] = 0.0;
             musum = musum + S.ll[s] * S.tl[s] + S.lu[s] * S.tu[s];
             nrm = W::vmax(nrm, W::vmax(S.ll[s], S.lu[s]));
-            vd rdl = W::vabs(-S.lo[s] - S.tl[s]), rdu = W::vabs(S.hi[s] - S.tu[s]);
+            vd rdl = W::vabs(-lo - S.tl[s]), rdu = W::vabs(hi - S.tu[s]);
             nrm = W::vmax(nrm, W::sel(v, W::vmax(rdl, rdu), vd(0.0)));
         }
         double mu = W::wave_sum(musum) * inv2m;
@@ -1171,9 +1247,7 @@ struct RtiWave {
         // corrector as a second solve with the predictor's factorisation (delta_sweep): compile-time horizons (the per-stage
         // -Lam^-1 operands live in registers) on the f64 instruction (in fp32 the interior-point loop converges worse with it)
         constexpr bool DELTA = NC > 0 && NC <= DELTA_MAX_N && W::delta_ok;
-        md linv[DELTA ? NC : 1];
-        DeltaTabs DT;
-        if (DELTA) build_delta_tabs(m, DT);
+        md linv[DELTA ? linv_regs(NC) : 1];
         for (;;) {
             if (mu <= P.tol && rho * norm0 <= P.tol) break;
             if (iters >= P.iter_max) { status = 4; break; }
@@ -1181,40 +1255,49 @@ struct RtiWave {
             double sigma_mu = 0.0;
             for (int pass = 0; pass < 2; ++pass) {
                 for (int s = 0; s < NSLOT; ++s) {
-                    vd sl = pass ? vd(sigma_mu) - S.dll[s] * S.dtl[s] : vd(0.0);
-                    vd su = pass ? vd(sigma_mu) - S.dlu[s] * S.dtu[s] : vd(0.0);
+                    vd sl = pass ? vd(sigma_mu) - S.pl[s] : vd(0.0);
+                    vd su = pass ? vd(sigma_mu) - S.pu[s] : vd(0.0);
                     vd rtl = W::rcp(S.tl[s]), rtu = W::rcp(S.tu[s]);
                     vd gl = S.ll[s] * rtl, gu = S.lu[s] * rtu;
                     vd Gam = gl + gu;
-                    vd gam = -sl * rtl - S.ll[s] - gl * S.lo[s] + su * rtu + S.lu[s] - gu * S.hi[s];
+                    vd lo = 0.0, hi = 0.0;
+                    if (!(DELTA && pass)) bounds(S, lds, s, lo, hi);
+                    vd gam = -sl * rtl - S.ll[s] - gl * lo + su * rtu + S.lu[s] - gu * hi;
                     if (DELTA && pass) {
                         // same diagonal as the predictor; the gradient slot takes the CHANGE of the gradient only
-                        W::stp(lds, S.ge_off[s], su * rtu - sl * rtl, S.valid[s]);
+                        W::stp(lds, S.de_off[s] + int(SL_GE), su * rtu - sl * rtl, S.valid[s]);
                     } else {
-                        vd dbase = P.dt * W::ld(lds, S.dw_off[s]);
+                        vd dbase = P.dt * W::ld(lds, S.lb_off[s] + int(SL_DW));
                         W::stp(lds, S.de_off[s], dbase + Gam, S.valid[s]);
-                        W::stp(lds, S.ge_off[s], W::ld(lds, S.gb_off[s]) + gam, S.valid[s]);
+                        W::stp(lds, S.de_off[s] + int(SL_GE), W::ld(lds, S.de_off[s] + int(SL_GB)) + gam, S.valid[s]);
                     }
                 }
                 W::sync();
                 NDP_FINE(if (fio && fio->dbg && iters == 1) fstamp(*fio, m, 6 + 3 * pass);)
-                if (DELTA && pass) delta_sweep(P, m, T, DT, lds, linv);
-                else ok = riccati_sweep(P, m, T, lds, nullptr, DELTA ? linv : nullptr) && ok;
+                if (DELTA && pass) {
+                    DeltaTabs DT;                    // (a dozen integer instructions: built here, not held across the factorisation sweep)
+                    build_delta_tabs(m, DT);
+                    delta_sweep(P, m, T, DT, lds, linv);
+                }
+                else ok = riccati_sweep<DELTA>(P, m, T, lds, nullptr, linv) && ok;
                 NDP_FINE(if (fio && fio->dbg && iters == 1) fstamp(*fio, m, 7 + 3 * pass);)
                 if (!ok) break;
                 vd amin = 1.0;
+                vd Ddtl[NSLOT], Ddtu[NSLOT], Ddll[NSLOT], Ddlu[NSLOT];   // this pass's step of the slacks / multipliers (not kept across a sweep)
                 for (int s = 0; s < NSLOT; ++s) {
                     vb v = S.valid[s];
                     vd zn = W::ld(lds, S.zoff[s]);
-                    vd sl = pass ? vd(sigma_mu) - S.dll[s] * S.dtl[s] : vd(0.0);
-                    vd su = pass ? vd(sigma_mu) - S.dlu[s] * S.dtu[s] : vd(0.0);
-                    vd dtl = zn - S.lo[s] - S.tl[s], dtu = S.hi[s] - zn - S.tu[s];
+                    vd sl = pass ? vd(sigma_mu) - S.pl[s] : vd(0.0);
+                    vd su = pass ? vd(sigma_mu) - S.pu[s] : vd(0.0);
+                    vd lo, hi;
+                    bounds(S, lds, s, lo, hi);
+                    vd dtl = zn - lo - S.tl[s], dtu = hi - zn - S.tu[s];
                     vd rtl = W::rcp(S.tl[s]), rtu = W::rcp(S.tu[s]);
                     vd dll = sl * rtl - S.ll[s] - S.ll[s] * rtl * dtl;
                     vd dlu = su * rtu - S.lu[s] - S.lu[s] * rtu * dtu;
                     dtl = W::sel(v, dtl, vd(0.0)); dtu = W::sel(v, dtu, vd(0.0));
                     dll = W::sel(v, dll, vd(0.0)); dlu = W::sel(v, dlu, vd(0.0));
-                    S.dtl[s] = dtl; S.dtu[s] = dtu; S.dll[s] = dll; S.dlu[s] = dlu;
+                    Ddtl[s] = dtl; Ddtu[s] = dtu; Ddll[s] = dll; Ddlu[s] = dlu;
                     // ratio test: lanes whose direction does not shrink the variable see a clamped denominator (-1) and are
                     // discarded by the select, so no reciprocal of zero is formed
                     amin = W::vmin(amin, W::sel(dtl < 0.0, -S.tl[s] * W::rcp(W::vmin(dtl, vd(-1e-300))), vd(1.0)));
@@ -1226,9 +1309,12 @@ struct RtiWave {
                 NDP_FINE(if (fio && fio->dbg && iters == 1) fstamp(*fio, m, 8 + 3 * pass);)
                 if (pass == 0) {
                     vd acc = 0.0;
-                    for (int s = 0; s < NSLOT; ++s)
-                        acc = acc + (S.ll[s] + S.dll[s] * alpha) * (S.tl[s] + S.dtl[s] * alpha)
-                                  + (S.lu[s] + S.dlu[s] * alpha) * (S.tu[s] + S.dtu[s] * alpha);
+                    for (int s = 0; s < NSLOT; ++s) {
+                        acc = acc + (S.ll[s] + Ddll[s] * alpha) * (S.tl[s] + Ddtl[s] * alpha)
+                                  + (S.lu[s] + Ddlu[s] * alpha) * (S.tu[s] + Ddtu[s] * alpha);
+                        S.pl[s] = Ddll[s] * Ddtl[s];
+                        S.pu[s] = Ddlu[s] * Ddtu[s];
+                    }
                     const double mu_aff = W::wave_sum(acc) * inv2m;
                     const double r = mu_aff / mu;
                     // Mehrotra's centring target, kept from undershooting the tolerance (slacks are formed by subtraction:
@@ -1244,8 +1330,8 @@ struct RtiWave {
                     }
                     vd acc = 0.0;
                     for (int s = 0; s < NSLOT; ++s) {
-                        S.tl[s] = S.tl[s] + S.dtl[s] * alpha; S.tu[s] = S.tu[s] + S.dtu[s] * alpha;
-                        S.ll[s] = S.ll[s] + S.dll[s] * alpha; S.lu[s] = S.lu[s] + S.dlu[s] * alpha;
+                        S.tl[s] = S.tl[s] + Ddtl[s] * alpha; S.tu[s] = S.tu[s] + Ddtu[s] * alpha;
+                        S.ll[s] = S.ll[s] + Ddll[s] * alpha; S.lu[s] = S.lu[s] + Ddlu[s] * alpha;
                         acc = acc + S.ll[s] * S.tl[s] + S.lu[s] * S.tu[s];
                     }
                     mu = W::wave_sum(acc) * inv2m;
@@ -1329,11 +1415,24 @@ struct RtiWave {
         else build_tables(m, T);
         stamp(io, m, 1);
         const int n_rti = NR ? NR : P.n_rti;
+        // Several RTI iterations per step at a compile-time count (NR >= 2, config 5): the iteration loop stays a LOOP (its body is
+        // 17 k instructions), so inputs requested in front of it and replaced inside it are loop-carried values -- 23 doubles per lane
+        // held (in scratch memory, as it turned out) across the first iteration's sweeps and interior-point loop for nothing.  Those
+        // kernels request every iteration's inputs at the top of the iteration into a buffer that dies at the commit; the
+        // caller's early request (issue_first) is simply not used and disappears.
+        constexpr bool LOCAL_IN = NR >= 2;
         for (int it = 0; it < n_rti; ++it) {
-            if (it > 0) issue_inputs(P, io, inb, false);
+            InBuf lbuf;
+            if constexpr (LOCAL_IN) {
+                RtiIo g = io;
+                g.f_in_lds = 0;
+                x0v = W::gldu(io.x0, W::imin(lane_it(), NX - 1));
+                issue_inputs(P, g, lbuf, it == 0);
+            } else if (it > 0) issue_inputs(P, io, inb, false);
+            InBuf &ib = LOCAL_IN ? lbuf : inb;
             if (io.f_in_lds)
-                for (int t = 0; t < RF; ++t) inb.f[t] = fkeep[t];
-            commit_inputs(P, m, inb, lds, it == 0);
+                for (int t = 0; t < RF; ++t) ib.f[t] = fkeep[t];
+            commit_inputs(P, m, ib, lds, it == 0);
             stamp(io, m, 2);
             build_cost(P, m, lds);
             stamp(io, m, 3);
@@ -1409,6 +1508,7 @@ struct RtiWave {
             {
                 constexpr int RZ = RX + RU;     // rounds that cover X|U contiguously: nzx + nzu <= 64 * RZ
                 const bool last = it + 1 == n_rti;
+                const vi lane = lane_it();      // (shadows the function's: the write-back's global addresses are formed HERE, see lane_it)
                 vd xa[RZ], xc[RZ];
                 for (int t = 0; t < RZ; ++t) {
                     vi i = W::imin(lane + 64 * t, nzx + nzu - 1);

@@ -29,6 +29,10 @@ struct WaveGfx950 {
     typedef double d4_t __attribute__((ext_vector_type(4)));
 
     static NDP_D vi lane() { return (int)(threadIdx.x & 63u); }
+    // the lane id as a value the compiler cannot trace back to the thread id: index arithmetic built on it stays WHERE it is written
+    // instead of being hoisted to the kernel's start and parked in registers / scratch for the whole program (the constraint
+    // slots of the interior-point loop, 50 integers per lane: build_slots)
+    static NDP_D vi lane_here() { int l = (int)(threadIdx.x & 63u); asm volatile("" : "+v"(l)); return l; }
     static NDP_D vd sel(vb p, vd a, vd b) { return p ? a : b; }
     static NDP_D vi sel(vb p, vi a, vi b) { return p ? a : b; }
     static NDP_D vd vmin(vd a, vd b) { return fmin(a, b); }
@@ -221,6 +225,15 @@ struct WaveGfx950 {
     static NDP_D md mfma4(md a, md b, md c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
     // lane 4Q of every 16-lane row to all lanes of the row (DPP row_newbcast): column 0 of block Q of a mfma4 result
     // becomes the B operand "vector element k = l >> 4, the same in every column" of the next one
+    // rotation inside every 16-lane row (DPP row_ror:4n): lane l takes the value of lane (l - 4n) mod 16 of its row, i.e. the four
+    // lanes of block b take block b - n's (pinned on the device: tests/test_gpu_parity.py::test_mfma_register_maps)
+    template <int n>
+    static NDP_D md rowror4(md a)
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), 0x120 + 4 * n, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), 0x120 + 4 * n, 0xF, 0xF, true);
+        return __hiloint2double(hi, lo);
+    }
     template <int Q>
     static NDP_D md rowb(md a)
     {

@@ -259,7 +259,10 @@ class RcclExchange:
         (BatchedNMPC.last_step_event(): the control step that read `gathered` last).  One of the two must cover the last reader of
         `gathered`."""
         import ctypes as C
-        assert xr.is_contiguous() and gathered.is_contiguous() and gathered.numel() == self.world * self.rows * PV_COLS
+        if not (xr.is_contiguous() and gathered.is_contiguous() and xr.numel() == self.rows * 10
+                and gathered.numel() == self.world * self.rows * PV_COLS):
+            raise ValueError(f"RcclExchange.begin: expected contiguous xr [{self.rows // 1} rows x 10] and gathered "
+                             f"[{self.world} x {self.rows} rows x {PV_COLS}], got {tuple(xr.shape)} / {tuple(gathered.shape)}")
         rc = self._lib.ndp_xchg_begin(self._h, C.c_void_p(xr.data_ptr()), self.rows, C.c_void_p(gathered.data_ptr()),
                                       C.c_void_p(stream.cuda_stream) if stream is not None else None, after_event)
         if rc:

@@ -87,6 +87,7 @@ struct Wave {
     static void chk(int i) { if (i < 0 || i >= lds_limit()) __builtin_trap(); }
 
     static vi lane() { vi o; for (int l = 0; l < 64; ++l) o.v[l] = l; return o; }
+    static vi lane_here() { return lane(); }
     static vd sel(const vb &p, const vd &a, const vd &b) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = p.v[l] ? a.v[l] : b.v[l]; return o; }
     static vi sel(const vb &p, const vi &a, const vi &b) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = p.v[l] ? a.v[l] : b.v[l]; return o; }
     static vd vmin(const vd &a, const vd &b) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = std::fmin(a.v[l], b.v[l]); return o; }
@@ -196,6 +197,8 @@ struct Wave {
         }
         return d;
     }
+    template <int n>
+    static vd rowror4(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[(l & 48) | ((l - 4 * n) & 15)]; return o; }   // DPP row_ror:4n
     template <int Q>
     static vd rowb(const vd &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[(l & 48) + 4 * Q]; return o; }   // DPP row_newbcast:4Q
 };

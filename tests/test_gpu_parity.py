@@ -48,7 +48,7 @@ def test_mfma_register_maps(ndp):
     a = np.array([A[l & 15, l >> 4] for l in range(64)])
     b = np.array([Bm[l >> 4, l & 15] for l in range(64)])
     c = np.array([[Cm[(l >> 4) + 4 * r, l & 15] for l in range(64)] for r in range(4)])
-    d = np.zeros(640)
+    d = np.zeros(832)
     assert lib.ndp_debug_mfma_probe(_lib.ptr(a), _lib.ptr(b), _lib.ptr(np.ascontiguousarray(c)), _lib.ptr(d)) == 0
     D = A @ Bm + Cm
     got = d[:256].reshape(4, 64)
@@ -64,6 +64,9 @@ def test_mfma_register_maps(ndp):
     for q in range(4):      # DPP row_newbcast:4q
         for l in range(64):
             assert d[384 + 64 * q + l] == a[(l & 48) + 4 * q], (q, l)
+    for n in (1, 2, 3):     # DPP row_ror:4n -- lane l takes the value of lane (l - 4n) mod 16 of its row (tests/emu/wave_emu.hpp: Wave::rowror4)
+        for l in range(64):
+            assert d[640 + 64 * (n - 1) + l] == a[(l & 48) | ((l - 4 * n) & 15)], (n, l)
 
 
 @pytest.mark.parametrize("qp_mode", [0, 1])

@@ -33,6 +33,29 @@ def test_reference_configuration_kernels_have_no_scratch(co):
         assert k[n]["scratch"] == 0, (n, k[n])
 
 
+def test_config5_kernels_have_no_scratch(co):
+    """BASELINE config 5's shape (N = 40, 2 RTI iterations): the in-place kernel and the work list's consumer -- the instantiations
+    that carry the interior-point loop -- spilled 944 / 912 B per lane through round 3.  What it took: per-iteration
+    lane ids for the input / cost / linearisation / write-back index arithmetic (the compiler had hoisted it out of the iteration
+    loop and parked it), inputs requested inside the iteration loop, constraint slots with 3 instead of 8 offsets (cost block and
+    constants area re-laid out), the corrector's products instead of the predictor's four step arrays, bounds re-read from LDS,
+    -Lam^-1 of four stages packed into one register, and its storage as a compile-time choice instead of a null test."""
+    k = co.kernels()
+    for qmode in (0, 1, 2):
+        n = I.rti_kernel_name(5, 2, False, 40, nrc=2, qmode=qmode)
+        assert n in k, n
+        assert k[n]["scratch"] == 0 and k[n]["spill"] <= 8, (n, k[n])
+
+
+def test_no_rti_kernel_instantiation_uses_scratch_memory(co):
+    """All of them: run-time horizons (which spilled 320-376 B per lane through round 3), the fp32 / bf16 study kernels, every
+    compile-time shape."""
+    k = {n: v for n, v in co.kernels().items() if "rti_kernel" in n}
+    assert len(k) >= 20
+    bad = {n: v for n, v in k.items() if v["scratch"] != 0}
+    assert not bad, bad
+
+
 def test_lds_budget_of_the_reference_configuration():
     """4 instances per workgroup at N = 20 fit the CU's 160 KB; 2 at N = 40."""
     from ndp_nmpc_qd_amd import _lib

@@ -162,13 +162,13 @@ def test_lds_image_matches_oracle_linearisation(oracle):
         np.testing.assert_allclose(blk[76:86], qp["b"][k], atol=1e-13)
     for k in range(N + 1):
         blk = lds[CB + k * CS: CB + (k + 1) * CS]
-        assert blk[47] == 0.0
+        assert blk[36] == 0.0                                             # the block's structural zero (rti_wave.hpp: CB_ZERO)
         np.testing.assert_allclose(blk[0:16].reshape(4, 4), qp["Q"][k][6:10, 6:10], atol=1e-12)
         np.testing.assert_allclose(blk[16:26], qp["q"][k], atol=1e-11)
         np.testing.assert_allclose(blk[30:36], np.diag(qp["Q"][k])[0:6], atol=1e-13)
         if k < N:
             np.testing.assert_allclose(blk[26:30], qp["r"][k], atol=1e-12)
-            np.testing.assert_allclose(blk[36:40], qp["Rd"][k], atol=1e-13)
+            np.testing.assert_allclose(blk[40:44], qp["Rd"][k], atol=1e-13)      # CB_DEU
 
 
 def test_qp_failure_status(oracle):
