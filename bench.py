@@ -124,6 +124,162 @@ def effective_cores():
     return n
 
 
+def baseline_configs_block(ndp, ndist, synth, O, torch, dev, stream, local_rank, steps=40):
+    """Every BASELINE.json config beside the metric's own (configs[2] = the headline), measured in THIS run on one GPU, each with
+    its own parity spot check against the CPU oracle (64 instances, first tick; bar 1e-5):
+      config2          batch = 1024 independent quadrotors, N = 20, NO downwash (configs[1])
+      config4_one_gpu  three-vehicle formations (configs[3]) on ONE GPU: all 4096 formations (12 288 instances) and one rank's share
+                       of the 8-GPU run, 512 formations (1 536 instances) -- formation-major (no exchange) and vehicle-major with
+                       the library-issued RCCL all-gather per step (one-rank communicator); local order leaders-first
+      config5          N = 40, 2 RTI iterations, batch = 4096 (configs[4]): the QP sweeps on the f64 matrix instruction (product
+                       path: work list = the default at this size, and in place), on v_mfma_f32_16x16x4_f32 and on
+                       v_mfma_f32_16x16x16_bf16; nominal and perturbed starts; u0 error against the fp64 oracle
+    Device-resident steps; `steps` timed steps per leg, captured into ONE hipGraph and replayed (host-launched where an exchange
+    stream or the precision studies are involved -- `launch` says which)."""
+    blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
+    out = {}
+
+    def to_dev(b, keys):
+        return {k: torch.from_numpy(np.ascontiguousarray(b[k])).to(dev) for k in keys if k in b}
+
+    def run_leg(eng, enqueue, reset, n_inst, graph=True):
+        """enqueue(i): one control tick on `stream`.  Returns (ms per step, launch mode)."""
+        reset()
+        for i in range(8):
+            enqueue(i)
+        torch.cuda.synchronize()
+        mode = "host launch per step"
+        g = None
+        if graph:
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="relaxed"):
+                    for i in range(steps):
+                        enqueue(8 + i)
+                torch.cuda.set_stream(stream)
+                g.replay()
+                torch.cuda.synchronize()
+                mode = f"hipGraph of {steps} steps"
+            except Exception as e:
+                g, mode = None, f"host launch per step (capture failed: {type(e).__name__})"
+                torch.cuda.set_stream(stream)
+                torch.cuda.synchronize()
+        tw = time.perf_counter()
+        while time.perf_counter() - tw < 0.02:       # clocks up
+            if g is not None:
+                g.replay()
+            else:
+                for i in range(steps):
+                    enqueue(i)
+            torch.cuda.synchronize()
+        ta = time.perf_counter()
+        if g is not None:
+            g.replay()
+        else:
+            for i in range(steps):
+                enqueue(i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - ta) / steps * 1e3, mode
+
+    def parity(u_dev, host, N, n_rti, use_fd, f, ns):
+        cfgo = O.default_cfg(N=N, n_rti=n_rti, use_fd=use_fd)
+        Xo, Uo = host["xr"][:ns].copy(), host["ur"][:ns].copy()
+        u_or, st, _ = O.step_batch(cfgo, host["x0"][:ns], host["xr"][:ns], host["ur"][:ns], f, Xo, Uo)
+        ok = st == 0
+        return float(np.max(np.abs(u_dev[:ns][ok] - u_or[ok]) / np.maximum(1.0, np.abs(u_or[ok])))), u_or, ok
+
+    # ---------------------------------------------------------------- config 2
+    B, N = 1024, 20
+    host = [synth.make_batch(B, N=N, seed=synth.SEED0 + 2, t0=0.02 * t) for t in range(4)]
+    tk = [to_dev(h, ("x0", "xr", "ur")) for h in host]
+    eng = ndp.BatchedNMPC(B, N=N, device=local_rank)
+    u0 = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    rs = lambda: eng.reset_device(tk[0]["xr"], tk[0]["ur"], stream=stream)                                            # noqa: E731
+    en = lambda i: eng.update_device(tk[i % 4]["x0"], tk[i % 4]["xr"], tk[i % 4]["ur"], u0, stream=stream)            # noqa: E731
+    ms, mode = run_leg(eng, en, rs, B)
+    rs(); en(0); torch.cuda.synchronize()
+    par, _, _ = parity(u0.cpu().numpy(), host[0], N, 1, False, None, 64)
+    st, _ = eng.status()
+    out["config2"] = {"workload": "batch=1024 independent quadrotors, N=20, 1 RTI iter, no downwash (NMPC controller)", "value": B / ms * 1e3,
+                      "unit": "solves/s", "ms_per_step": ms, "launch": mode, "parity_max_rel_vs_oracle": par, "instances_not_converged": int((st != 0).sum())}
+    del eng
+    # ---------------------------------------------------------------- config 4 on one GPU
+    c4 = {}
+    for F in (4096, 512):
+        for placement in ("formation", "vehicle"):
+            hs = [ndist.make_config4_shard(0, 1, F, placement, N=N, t0=0.02 * t) for t in range(4)]
+            Bl = hs[0]["x0"].shape[0]
+            tk = [to_dev(h, ("x0", "xr", "ur", "ego_xy", "other_index")) for h in hs]
+            eng = ndp.BatchedNMPC(Bl, N=N, disturbance=True, device=local_rank)
+            u0 = torch.empty(Bl, 4, dtype=torch.float64, device=dev)
+            rs = lambda: eng.reset_device(tk[0]["xr"], tk[0]["ur"], stream=stream)                                    # noqa: E731
+            xchg = None
+            if placement == "formation":
+                en = lambda i: eng.update_device(tk[i % 4]["x0"], tk[i % 4]["xr"], tk[i % 4]["ur"], u0, other=tk[i % 4]["xr"],          # noqa: E731
+                                                 ego_xy=tk[i % 4]["ego_xy"], stream=stream, other_index=tk[i % 4]["other_index"])
+                ms, mode = run_leg(eng, en, rs, Bl)
+                form = "formation-major: no exchange, the kernel reads the neighbour's window out of the local xr"
+            else:
+                try:
+                    with c_stdout_to_stderr():
+                        xchg = ndist.RcclExchange(Bl, N, local_rank)
+                    gathered = [torch.empty(Bl, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev) for _ in range(2)]
+
+                    def en(i, _g=gathered, _x=xchg):
+                        d = tk[i % 4]
+                        _x.begin(d["xr"], _g[i % 2], stream)          # this tick's windows: pack + ncclAllGather on the library's stream
+                        _x.end(stream)
+                        eng.update_device(d["x0"], d["xr"], d["ur"], u0, other=_g[i % 2], ego_xy=d["ego_xy"], stream=stream,
+                                          other_index=d["other_index"])
+                    ms, mode = run_leg(eng, en, rs, Bl, graph=False)
+                    form = "vehicle-major: one library-issued RCCL all-gather of the position / velocity windows per step (one-rank communicator), then the step"
+                except Exception as e:
+                    c4[f"{3 * F}_instances_{placement}_major"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+                    continue
+            rs(); en(0); torch.cuda.synchronize()
+            h0 = hs[0]
+            allv = ndist.make_config4_all(F, N=N, t0=0.0)
+            nb = np.where(h0["gids"] % 3 == 0, h0["gids"] + 1, h0["gids"])
+            ns = 64
+            ego = h0["ego_xy"][:ns].copy()
+            ego[h0["other_index"][:ns] < 0] = 1e9
+            f = O.downwash_batch(blob, allv["xr"][nb][:ns].copy(), h0["xr"][:ns], ego)
+            par, _, _ = parity(u0.cpu().numpy(), h0, N, 1, True, f, ns)
+            st, _ = eng.status()
+            c4[f"{3 * F}_instances_{placement}_major"] = {"value": Bl / ms * 1e3, "unit": "solves/s", "ms_per_step": ms, "launch": mode, "form": form,
+                                                          "parity_max_rel_vs_oracle": par, "instances_not_converged": int((st != 0).sum())}
+            if xchg is not None:
+                xchg.close()
+            del eng
+    c4["note"] = ("1 536 instances = one rank's share of the 8-GPU run (512 formations): 384 workgroups on 256 CUs, leaders (gate + downwash "
+                  "network) dispatched in front of the followers (dist.config4_gids, order leaders_first)")
+    out["config4_one_gpu"] = c4
+    # ---------------------------------------------------------------- config 5
+    B, N, NS = 4096, 40, 64
+    c5 = {"workload": "N=40, 2 RTI iterations, batch=4096, no downwash", "oracle_sample": NS}
+    for label, kw in (("nominal", {}), ("perturbed", dict(pos_sigma=0.5, vel_sigma=1.0, quat_sigma=0.15))):
+        b = synth.make_batch(B, N=N, seed=synth.SEED0 + 5, **kw)
+        t = to_dev(b, ("x0", "xr", "ur"))
+        res = {}
+        for name, prec, wq in (("fp64_work_list", 0, 1), ("fp64_in_place", 0, 2), ("fp32_mfma", 3, 2), ("bf16_mfma", 4, 2)):
+            eng = ndp.BatchedNMPC(B, N=N, n_rti=2, qp_precision=prec, work_queue=wq, device=local_rank)
+            u0 = torch.empty(B, 4, dtype=torch.float64, device=dev)
+            rs = lambda: eng.reset_device(t["xr"], t["ur"], stream=stream)                                            # noqa: E731
+            en = lambda i: eng.update_device(t["x0"], t["xr"], t["ur"], u0, stream=stream)                            # noqa: E731
+            ms, mode = run_leg(eng, en, rs, B, graph=False)
+            rs(); en(0); torch.cuda.synchronize()
+            st, it = eng.status()
+            par, _, ok = parity(u0.cpu().numpy(), b, N, 2, False, None, NS)
+            res[name] = {"value": B / ms * 1e3, "unit": "solves/s", "ms_per_step": ms, "launch": mode, "max_rel_err_vs_oracle": par,
+                         "status_nonzero": int((st != 0).sum()), "frac_interior_point": float((it > 0).mean())}
+            del eng
+        c5[label] = res
+    c5["note"] = ("the QP is not condensed (qp_solver_cond_N = N, nmpc_body_rate_ctl.py:79): 'MFMA on the QP' = the Riccati sweeps' matrix instructions; "
+                  "everything outside the sweeps stays fp64.  fp64_work_list is the product default at this batch size")
+    out["config5"] = c5
+    return out
+
+
 def launch_ranks(n, script, script_args, python=None, out=None, err=None):
     """`bench.py --gpus N` started WITHOUT a torch.distributed environment launches its own N ranks: a CHILD process
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> script args`
@@ -185,6 +341,7 @@ def main():
     ap.add_argument("--perturb", default="nominal", choices=["nominal", "mixed"],
                     help="mixed: 0.5 m / 1 m/s / 0.15 initial errors, ~20 %% of the instances need the interior-point loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs 2, 4-on-one-GPU, 5 measured in this run)")
     ap.add_argument("--only-timed", action="store_true",
                     help="no parity check, no extra legs: just warm-up + the timed steps (profiling runs: nothing but the kernel)")
     ap.add_argument("--placement", default="vehicle", choices=["vehicle", "formation"],
@@ -834,7 +991,9 @@ def main():
                            "parallelism": f"instances sharded x{world}"},
                 "roofline": {"kernel": "rti_kernel", "bound": "mfma", "achieved": ach_tf, "peak": F64_MFMA_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": ach_tf / F64_MFMA_PEAK_TFLOPS, "traffic": prof["traffic"],
-                             "traffic_note": f"HBM bytes per launch, PMC (profiles/{prof['tag']}_pmc_rti_kernel.json); algorithmic bytes per launch = %d" % (abytes * B),
+                             "traffic_note": ((f"HBM bytes per launch, PMC (profiles/{prof['tag']}_pmc_rti_kernel.json)" if prof["traffic"] is not None else
+                                              "no committed PMC pass describes this configuration (traffic null)")
+                                             + "; algorithmic bytes per launch = %d" % (abytes * B)),
                              "profile_tag": prof["tag"], "profile_mismatch": profile_mismatch,
                              "kernel_us": rti_s * 1e6, "kernel_us_rocprof": prof["kernel_us"],
                              "kernel_us_source": ("HIP events on the launch stream around the timed region / steps" if one_launch
@@ -898,6 +1057,17 @@ def main():
                     out["exchange"]["rccl"]["library_collective_unavailable"] = xchg_err
                 out["exchange"]["headline"] = headline
             extras = world == 1 and not args.only_timed and not cfg4 and args.perturb == "nominal" and args.qp_mode == 0 and not partial
+            if extras and B == 1024 and N == 20 and not args.no_configs:
+                try:
+                    from oracle import oracle as O_
+                    tcb = time.perf_counter()
+                    out["configs"] = baseline_configs_block(ndp, ndist, synth, O_, torch, dev, stream, local_rank)
+                    out["configs"]["config3"] = "the headline of this line (value, roofline, cpu_baseline)"
+                    out["configs"]["config1"] = "config1_single_vehicle of this line"
+                    out["configs"]["seconds"] = time.perf_counter() - tcb
+                except Exception as e:                      # never fatal to the headline
+                    out["configs"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    torch.cuda.set_stream(stream)
             if extras:
                 # ---- what the reference's QP solver actually does (HPIPM always iterates): every instance through the interior-point loop
                 e_ipm = ndp.BatchedNMPC(B, N=N, disturbance=downwash, qp_mode=1, device=local_rank)

@@ -62,7 +62,11 @@ typedef struct ndp_cfg {
     int32_t work_queue; /* instances whose QP needs the interior-point loop are re-distributed over all SIMDs through an
                          * work list (producer + consumer launch per step): 0 = automatic (qp_mode AUTO and batch >= 2 x the device's
                          * SIMD count, or the N = 40 / 2-iteration shape at any batch), 1 = on, 2 = off */
-    int32_t reserved0;
+    int32_t ipm_refine; /* interior point: up to this many refinement solves (with the factorisation at hand) per Newton system, applied
+                         * only while a STATE bound's barrier term lambda / t exceeds refine_gamma (default 2; 0 = never).  The
+                         * loop is in absolute form, so an iteration's answer is as accurate as its last solve -- cond ~ lambda / t.
+                         * The reference's velocity box (+-20 m/s, nmpc_body_rate_ctl.py:59-61) is never active in its envelope:
+                         * this only acts on boxes shrunk on purpose.  Compile-time horizons (N = 20, N = 40 / 2 iterations) only. */
     double dt;          /* T_horizon / N_node        params/nmpc_params.py:10,12  */
     double mass;        /* params/fhnp_params.py:9   */
     double gravity;     /* params/fhnp_params.py:12  */
@@ -77,6 +81,7 @@ typedef struct ndp_cfg {
     double ts_nmpc;             /* control period, params/nmpc_params.py:11 (0.02): spacing of the reference list entries */
     double mu_floor;            /* interior point: the centring target sigma*mu never goes below mu_floor * tol (default 0.1) --
                                  * slacks are differences, so driving mu far below tol only loses digits */
+    double refine_gamma;        /* see ipm_refine (default 1e6) */
 } ndp_cfg;
 
 typedef struct ndp_handle ndp_handle;

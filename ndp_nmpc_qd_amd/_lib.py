@@ -23,12 +23,12 @@ class NdpCfg(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("N", C.c_int32), ("n_rti", C.c_int32), ("use_fd", C.c_int32),
         ("qp_mode", C.c_int32), ("iter_max", C.c_int32), ("device", C.c_int32), ("qp_precision", C.c_int32),
-        ("work_queue", C.c_int32), ("reserved0", C.c_int32),
+        ("work_queue", C.c_int32), ("ipm_refine", C.c_int32),
         ("dt", C.c_double), ("mass", C.c_double), ("gravity", C.c_double), ("r_horiz", C.c_double),
         ("Qd", C.c_double * 10), ("Rd", C.c_double * 4),
         ("lbu", C.c_double * 4), ("ubu", C.c_double * 4), ("lbv", C.c_double * 3), ("ubv", C.c_double * 3),
         ("mu0", C.c_double), ("thr0", C.c_double), ("tol", C.c_double), ("tau", C.c_double), ("auto_margin", C.c_double),
-        ("ts_nmpc", C.c_double), ("mu_floor", C.c_double),
+        ("ts_nmpc", C.c_double), ("mu_floor", C.c_double), ("refine_gamma", C.c_double),
     ]
 
 

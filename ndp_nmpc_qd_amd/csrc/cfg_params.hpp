@@ -39,6 +39,8 @@ inline void fill_default_cfg(ndp_cfg *c)
     c->tau = 0.995;
     c->auto_margin = 0.1;
     c->ts_nmpc = 0.02;
+    c->ipm_refine = 2;
+    c->refine_gamma = 1e6;
 }
 
 inline RtiParams to_params(const ndp_cfg &c)
@@ -50,6 +52,7 @@ inline RtiParams to_params(const ndp_cfg &c)
     memcpy(p.lbu, c.lbu, sizeof(p.lbu)); memcpy(p.ubu, c.ubu, sizeof(p.ubu));
     memcpy(p.lbv, c.lbv, sizeof(p.lbv)); memcpy(p.ubv, c.ubv, sizeof(p.ubv));
     p.mu0 = c.mu0; p.thr0 = c.thr0; p.tol = c.tol; p.tau = c.tau; p.auto_margin = c.auto_margin; p.mu_floor = c.mu_floor;
+    p.refine = c.ipm_refine; p.refine_gamma = c.refine_gamma;
     fill_quotients(p);
     return p;
 }

@@ -72,6 +72,8 @@ struct RtiParams {
     double dt, inv_mass, g;
     double Qd[10], Rd[4], lbu[4], ubu[4], lbv[3], ubv[3];
     double mu0, thr0, tol, tau, auto_margin, mu_floor;
+    int refine;             // interior point: refinement solves per Newton system while a state bound's barrier term exceeds refine_gamma
+    double refine_gamma;
     // host-evaluated quotients (an f64 divide is a ~30-instruction VALU sequence on the device, even for uniforms)
     double h_6, h2_6, h4_24, h3_6, h4_12, two_over_h2, inv2m;
 };
@@ -783,6 +785,47 @@ struct RtiWave {
         return W::rcp(det);
     }
 
+    // Lam^-1 for a STIFF Lam (ROBUST sweeps).  A barrier term Gamma on a STATE bound enters Lam = R + B'PB as Gamma b b' with b = dv+/du:
+    // a rank-one part with large off-diagonal entries.  The cofactor expansion above cancels (Gamma |b|^2)^3 down to Gamma |b|^2 --
+    // garbage from Gamma |b|^2 ~ 1e6 on (found with the shrunk-velocity-box problems of tests/test_wave_program_emulated.py: the sweep
+    // reported a failed factorisation where the oracle's Cholesky had none).  Here every lane factorises the 4x4 matrix itself,
+    // Lam = L D L' without square roots, and forms the entry (g, j & 3) of L^-T D^-1 L^-1 it holds: ~100 dependent f64 operations
+    // per stage, run only in the interior-point iterations in which a state bound's barrier term exceeds P.refine_gamma.
+    static NDP_D vd lam_inverse_ldl(const LdsMap &m, const Tables &T, lp lds, vd h3, vb &okv)
+    {
+        W::st(lds, T.lam_w_off, h3);
+        W::sync();
+        auto A = [&](int r, int c) { return W::ld(lds, W::lane() * 0 + (m.SC + 4 * r + c)); };
+        const vd a00 = A(0, 0), a10 = A(1, 0), a11 = A(1, 1), a20 = A(2, 0), a21 = A(2, 1), a22 = A(2, 2),
+                 a30 = A(3, 0), a31 = A(3, 1), a32 = A(3, 2), a33 = A(3, 3);
+        const vd d0 = a00, r0 = W::rcp(d0);
+        const vd l10 = a10 * r0, l20 = a20 * r0, l30 = a30 * r0;
+        const vd d1 = a11 - l10 * a10, r1 = W::rcp(d1);
+        const vd l21 = (a21 - l20 * a10) * r1, l31 = (a31 - l30 * a10) * r1;
+        const vd d2 = a22 - l20 * a20 - l21 * (l21 * d1), r2 = W::rcp(d2);
+        const vd l32 = (a32 - l30 * a20 - l31 * (l21 * d1)) * r2;
+        const vd d3 = a33 - l30 * a30 - l31 * (l31 * d1) - l32 * (l32 * d2), r3 = W::rcp(d3);
+        okv = okv && (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
+        // M = L^-1 (unit lower triangular)
+        const vd m10 = -l10, m21 = -l21, m32 = -l32;
+        const vd m20 = -l20 - l21 * m10, m31 = -l31 - l32 * m21;
+        const vd m30 = -l30 - l31 * m10 - l32 * m20;
+        // column i of M as seen by this lane: i = g for the left factor, i = j & 3 for the right one
+        vi lane = W::lane();
+        vi gi = lane >> 4, ji = W::lcol(lane) & 3;
+        auto col = [&](const vi &i, vd out[4]) {
+            const vd one(1.0), zero(0.0);
+            out[0] = W::sel(i == 0, one, zero);
+            out[1] = W::sel(i == 0, m10, W::sel(i == 1, one, zero));
+            out[2] = W::sel(i == 0, m20, W::sel(i == 1, m21, W::sel(i == 2, one, zero)));
+            out[3] = W::sel(i == 0, m30, W::sel(i == 1, m31, W::sel(i == 2, m32, one)));
+        };
+        vd mi[4], mj[4];
+        col(gi, mi);
+        col(ji, mj);
+        return mi[0] * mj[0] * r0 + mi[1] * mj[1] * r1 + mi[2] * mj[2] * r2 + mi[3] * mj[3] * r3;
+    }
+
     // backward: H~_k = M~_k' P~_{k+1} M~_k + C~_k with P~_{k+1} = H~xx - H~xu Lam^-1 H~ux of stage k+1, P~_N = C~_N.
     // P~ is never formed: the next stage needs only W' = P~ M~' = H~xx M~' - H~xu (Lam^-1 (H~ux M~')), and
     // [H~xx ; H~ux] M~' is ONE product (the accumulator registers of H~ as A operand), which does not depend on
@@ -793,7 +836,9 @@ struct RtiWave {
     // kept in registers for delta_sweep.
     // KEEP (compile time, not "linv != null": the address of a private array compared with null is a RUN-time test after the
     // address-space cast, a branch around every store, and it keeps the array in scratch memory): store -Lam^-1 of every stage.
-    template <bool KEEP = false>
+    // ROBUST (compile time): the 4x4 inverse by lam_inverse_ldl instead of the cofactor expansion -- the interior-point loop's sweeps
+    // while a state bound's barrier term is large.
+    template <bool KEEP = false, bool ROBUST = false>
     static NDP_D bool riccati_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, lp lds,
                                     const RtiIo *io = nullptr, md *linv = nullptr)
     {
@@ -837,6 +882,44 @@ struct RtiWave {
             // nothing can follow (1/det -> scale -> last MFMA) carries the stage's independent instructions, the operand
             // prefetch of stage k-2, between its levels.  Measured: worth ~1 % of the sweep -- what counts is the number of
             // instructions and of chain levels (dropping the second Newton step of 1/det saved 5 %), not their order.
+            if constexpr (ROBUST) {
+                const vd inv = lam_inverse_ldl(m, T, lds, W::to_d(hux), okv);      // Lam^-1[g][j & 3] in every lane
+                md4 Wf = mman<3>(H.r, mk, W::mzero4());
+                if (kprev >= 0) {
+                    if constexpr (MMA4) W::st(lds, T.kt_st4 + mb(kprev), W::to_d(Ktq));
+                    else for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), W::to_d(Ktp.r[c]));
+                }
+                md4 Hb;
+                for (int r = 0; r < 4; ++r) Hb.r[r] = cc[r];
+                Hb = mman<3>(mk, Wf.r, Hb);
+                const vd ladj = MMA4 ? inv : W::sel(T.lo4, inv, vd(0.0));
+                const vd nahi = MMA4 ? -inv : W::sel(T.kt_pred, -inv, vd(0.0));
+                md tt = Wf.r[3];
+                md G0;
+                if constexpr (MMA4) G0 = mma4(W::to_m(ladj), tt, W::to_m(vd(0.0)));
+                else G0 = mma(W::to_m(ladj), tt, W::mzero4()).r[0];
+                for (int c = 0; c < 3; ++c) nmk[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(kp)));
+                for (int r = 0; r < 4; ++r) ncc[r] = W::to_m(W::ld(lds, T.c_off[r] + cb(kp)));
+                md4 Hn = mma(-tt, G0, Hb);
+                const md nli = W::to_m(nahi);
+                if constexpr (KEEP) linv_put(linv, k, N, nli);
+                if constexpr (MMA4) Ktq = mma4(hux, nli, W::to_m(vd(0.0)));
+                else Ktp = mma(hux, nli, W::mzero4());
+                kprev = k;
+                {   // re-symmetrised at EVERY stage here (the oracle does): with entries of 1e10 the antisymmetric rounding part, which
+                    // the open-loop map doubles per stage, reaches the size of the O(1) eigenvalues within a few stages
+                    md ey[4];
+                    vi ln = W::lane_here();
+                    vi gg = ln >> 4, jj = W::lcol(ln);
+                    for (int c = 0; c < 4; ++c) ey[c] = W::to_m(W::sel(jj == gg + 4 * c, vd(1.0), vd(0.0)));
+                    md4 Tp = mman<4>(Hn.r, ey, W::mzero4());
+                    for (int r = 0; r < 4; ++r) Hn.r[r] = W::mavg(Hn.r[r], Tp.r[r]);
+                }
+                H = Hn;
+                for (int c = 0; c < 3; ++c) mk[c] = nmk[c];
+                for (int r = 0; r < 4; ++r) cc[r] = ncc[r];
+                continue;
+            }
             LamRegs LR;
             lam_gather(T, lds, W::to_d(hux), LR);
             W::pin();
@@ -929,10 +1012,16 @@ struct RtiWave {
         }
         {   // stage 0: only the gain is needed
             md hux = H.r[3];
-            LamRegs LR;
-            lam_gather(T, lds, W::to_d(hux), LR);
-            vd cof = lam_cofactor(T, LR);
-            vd rdet = lam_rdet(T, LR, cof, ok);
+            vd cof, rdet;
+            if constexpr (ROBUST) {
+                cof = lam_inverse_ldl(m, T, lds, W::to_d(hux), okv);
+                rdet = vd(1.0);
+            } else {
+                LamRegs LR;
+                lam_gather(T, lds, W::to_d(hux), LR);
+                cof = lam_cofactor(T, LR);
+                rdet = lam_rdet(T, LR, cof, ok);
+            }
             vd nahi = MMA4 ? -cof : W::sel(T.kt_pred, -cof, vd(0.0));
             if constexpr (KEEP) linv_put(linv, 0, N, W::to_m(nahi * rdet));
             if constexpr (MMA4) {
@@ -1002,7 +1091,7 @@ struct RtiWave {
     //   forward:   du_k = K~_k dx_k + dk_k,  dx_{k+1} = A_k dx_k + B_k du_k,  dx_0 = 0      (the 4 MFMAs of the full forward sweep)
     // and ZX|ZU += (dx, du).  No 4x4 inverse, no cost blocks: ~0.55 of a full sweep.  Needs -Lam_k^-1 of every stage (riccati_sweep's
     // linv, in registers: compile-time horizons) and K~' where the sweep left it in LDS.
-    struct DeltaTabs { vi dc_off[4], kta_off, dc_off4, dk_off; md eye12, m12; vb row10, g2; };
+    struct DeltaTabs { vi dc_off[4], kta_off, dc_off4, dk_off, zd_off, zd_str; md eye12, m12; vb row10, g2; };
     static NDP_D void build_delta_tabs(const LdsMap &m, DeltaTabs &D)
     {
         vi lane = W::lane_here();
@@ -1025,8 +1114,46 @@ struct RtiWave {
         // ZD, entry 4k + g -- every lane of row g holds the same value, so all sixteen store it (identical duplicates).  The
         // forward sweeps' own dump stores reach entry 4k + g only at the END of stage k, after dk_k has been read.
         D.dk_off = g + (m.ZD + (m.ZU - m.ZX));
+        // refinement solves (refine_gradient / delta_sweep<true>): the full gradient of stage k waits in the shadow ZD, laid out like
+        // ZX|ZU -- x row i at ZD + 10 k + i, u row i at ZD + (ZU - ZX) + 4 k + i: a per-lane stride, rows 10 / 11 read a structural zero
+        D.zd_off = W::sel(x4 < 10, x4 + m.ZD, W::sel(x4 >= 12, x4 - 12 + (m.ZD + (m.ZU - m.ZX)), vi(m.MB + int(MB_ZERO))));
+        D.zd_str = W::sel(x4 < 10, vi(int(NX)), W::sel(x4 >= 12, vi(int(NU)), vi(0)));
     }
 
+    // Refinement of the solution z = ZX|ZU of the Newton system at hand (oracle: refine_solution).  The gradient of its quadratic at
+    // z, g = qe + Qe z | re + Re du with the effective blocks as they stand in the cost blocks, goes to the shadow ZD; delta_sweep<true>
+    // then solves the same system for that gradient with zero defects and zero initial state -- the factorisation (gains in LDS, -Lam^-1
+    // in registers) is the one at hand -- and adds the result to z.
+    static NDP_D void refine_gradient(const RtiParams &P, const LdsMap &m, lp lds)
+    {
+        const int N = horizon(P);
+        vi lane = W::lane_here();
+        vi e = lane & 15, kq = lane >> 4;
+        vb isx = e < 10, isd = e < 6, isq = isx && !isd, isu = e >= 12;
+        vi a4 = W::sel(isq, (e - 6) * 4, vi(0));
+        for (int t = 0; 4 * t <= N; ++t) {
+            vi k = kq + 4 * t;
+            vb ok = (isx && (k <= N)) || (isu && (k < N));
+            vi kc = W::imin(k, W::sel(isu, vi(N - 1), vi(N)));      // lanes past the end re-read the last stage (their store is masked)
+            vi cbk = kc * int(CB_STRIDE) + m.CB;
+            vi zo = W::sel(isu, kc * int(NU) + (e - 12) + m.ZU, kc * int(NX) + W::sel(isx, e, vi(0)) + m.ZX);
+            vd z = W::ld(lds, zo);
+            vd d = W::ld(lds, cbk + W::sel(isd, e + int(CB_DEX), W::sel(isu, e - 12 + int(CB_DEU), vi(int(CB_ZERO)))));
+            vd ge = W::ld(lds, cbk + W::sel(isx, e + int(CB_QE), W::sel(isu, e - 12 + int(CB_RE), vi(int(CB_ZERO)))));
+            vd acc = d * z + ge;
+            vd qacc = ge;
+            for (int b = 0; b < 4; ++b)
+                qacc = qacc + W::ld(lds, cbk + a4 + (int(CB_QQ) + b)) * W::ld(lds, kc * int(NX) + (m.ZX + 6 + b));
+            vd g = W::sel(isq, qacc, acc);
+            vi so = W::sel(isu, kc * int(NU) + (e - 12) + (m.ZD + (m.ZU - m.ZX)), kc * int(NX) + W::sel(isx, e, vi(0)) + m.ZD);
+            W::stp(lds, so, g, ok);
+        }
+        W::sync();
+    }
+
+    // FROM_ZD: the gradient is the FULL one refine_gradient left in the shadow ZD (all state and input rows, the terminal stage
+    // included) instead of the corrector's change of the bounded rows in the cost blocks.
+    template <bool FROM_ZD = false>
     static NDP_D void delta_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, const DeltaTabs &D, lp lds, const md *linv)
     {
         const int N = horizon(P);
@@ -1035,20 +1162,29 @@ struct RtiWave {
             // every product here is matrix x vector: the 4x4x4 instruction, vectors as chunk registers replicated over the columns.
             // The LDS operands of a stage are requested one stage ahead (as in riccati_sweep): they arrive under the previous
             // stage's dependent chain instead of in front of this one's.
-            md Dg = W::to_m(W::ld(lds, D.dc_off4 + cb(N - 1)));
+            auto dc_at = [&](int k) { return FROM_ZD ? W::ld(lds, D.zd_off + D.zd_str * k) : W::ld(lds, D.dc_off4 + cb(k)); };
+            md Dg = W::to_m(dc_at(N - 1));
             md a[3], kta = W::to_m(W::ld(lds, D.kta_off + mb(N - 1)));
-            for (int c = 0; c < 3; ++c) a[c] = W::to_m(vd(0.0));           // stage N-1 has no successor term
+            for (int c = 0; c < 3; ++c) a[c] = W::to_m(vd(0.0));           // stage N-1 has no successor term ...
+            if constexpr (FROM_ZD) {                                       // ... but for the terminal stage's own gradient
+                vi g4 = W::lane() >> 4;
+                for (int c = 0; c < 3; ++c) {
+                    a[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(N - 1)));
+                    vi row = g4 + 4 * c;
+                    vc[c] = W::to_m(W::ldp(lds, W::sel(row < 10, row, vi(0)) + (m.ZD + N * int(NX)), row < 10));
+                }
+            }
             NDP_UNROLL_STAGES
             for (int k = N - 1; k >= 0; --k) {
                 md nDg = Dg, na[3] = {a[0], a[1], a[2]}, nkta = kta;
                 if (k > 0) {
-                    nDg = W::to_m(W::ld(lds, D.dc_off4 + cb(k - 1)));
+                    nDg = W::to_m(dc_at(k - 1));
                     for (int c = 0; c < 3; ++c) na[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(k - 1)));
                     nkta = W::to_m(W::ld(lds, D.kta_off + mb(k - 1)));
                 }
                 W::pin();
                 md akl = kta + W::fma(linv_get(linv, k), D.m12, -D.eye12);
-                if (k != N - 1)
+                if (FROM_ZD || k != N - 1)
                     for (int c = 0; c < 3; ++c) Dg = mma4(a[c], vc[c], Dg);
                 md Dp = mma4(akl, W::template rowb<3>(Dg), Dg);
                 W::st(lds, D.dk_off + k * int(NU), W::to_d(W::template rowb<3>(Dp)));   // dk_k (kept in LDS: NC registers pairs less)
@@ -1150,12 +1286,19 @@ struct RtiWave {
         S.io = m.XI - m.ZX;           // (= UI - ZU: the two pairs of arrays are laid out alike)
     }
 
-    // the step bounds of slot s, read from LDS (the iterate does not move during a QP solve)
+    // the step bounds of slot s.  Kernels with up to three constraint slots (N <= 27: the reference configuration) hold them in
+    // registers (load_bounds); the five-slot kernels (N = 40) read them from LDS where they are needed -- the iterate does not move
+    // during a QP solve -- which is 20 registers per lane less across the sweeps and costs ~60 LDS reads per interior-point iteration
+    // (measured on the N = 20 kernels, where it is therefore NOT done: interior point on every instance 14.2 against 14.55 M solves/s)
+    static constexpr bool KEEP_BOUNDS = NSLOT <= 3;
     static NDP_D void bounds(const Slots &S, lp lds, int s, vd &lo, vd &hi)
     {
-        vd cur = W::ld(lds, S.zoff[s] + S.io);
-        lo = W::ld(lds, S.lb_off[s]) - cur;
-        hi = W::ld(lds, S.lb_off[s] + int(SL_UB)) - cur;
+        if constexpr (KEEP_BOUNDS) { lo = S.lo[s]; hi = S.hi[s]; }
+        else {
+            vd cur = W::ld(lds, S.zoff[s] + S.io);
+            lo = W::ld(lds, S.lb_off[s]) - cur;
+            hi = W::ld(lds, S.lb_off[s] + int(SL_UB)) - cur;
+        }
     }
 
     static NDP_D void load_bounds(const LdsMap &, Slots &S, lp lds)
@@ -1248,12 +1391,22 @@ struct RtiWave {
         // -Lam^-1 operands live in registers) on the f64 instruction (in fp32 the interior-point loop converges worse with it)
         constexpr bool DELTA = NC > 0 && NC <= DELTA_MAX_N && W::delta_ok;
         md linv[DELTA ? linv_regs(NC) : 1];
+        // Refinement of a Newton system's solution (oracle: refine_solution): a further solve with the factorisation at hand, hence
+        // where the second solve exists (DELTA).  Needed only while a STATE bound's barrier term is large: gmaxv, per iteration.
+        // Both live in the three-slot kernels only (N <= 27: the reference configuration).  In the five-slot kernels (N = 40, config 5)
+        // a third instantiation of the sweep inside the loop brings the registers back over the edge (324 B of scratch per lane) for
+        // a case -- active STATE bounds -- that the reference's +-20 m/s box does not produce; there the loop runs as in round 3.
+        constexpr bool STIFF = NSLOT <= 3;
+        constexpr bool REFINE = DELTA && MMA4 && STIFF;
+        const int nu4 = 4 * N;
         for (;;) {
             if (mu <= P.tol && rho * norm0 <= P.tol) break;
             if (iters >= P.iter_max) { status = 4; break; }
             ++iters;
             double sigma_mu = 0.0;
+            double gmaxv = 0.0;
             for (int pass = 0; pass < 2; ++pass) {
+                vd gmv = 0.0;
                 for (int s = 0; s < NSLOT; ++s) {
                     vd sl = pass ? vd(sigma_mu) - S.pl[s] : vd(0.0);
                     vd su = pass ? vd(sigma_mu) - S.pu[s] : vd(0.0);
@@ -1263,6 +1416,7 @@ struct RtiWave {
                     vd lo = 0.0, hi = 0.0;
                     if (!(DELTA && pass)) bounds(S, lds, s, lo, hi);
                     vd gam = -sl * rtl - S.ll[s] - gl * lo + su * rtu + S.lu[s] - gu * hi;
+                    if (STIFF && pass == 0) gmv = W::vmax(gmv, W::sel(S.valid[s] && (lane + 64 * s >= nu4), Gam, vd(0.0)));
                     if (DELTA && pass) {
                         // same diagonal as the predictor; the gradient slot takes the CHANGE of the gradient only
                         W::stp(lds, S.de_off[s] + int(SL_GE), su * rtu - sl * rtl, S.valid[s]);
@@ -1274,12 +1428,38 @@ struct RtiWave {
                 }
                 W::sync();
                 NDP_FINE(if (fio && fio->dbg && iters == 1) fstamp(*fio, m, 6 + 3 * pass);)
+                if (STIFF && pass == 0 && P.refine > 0) gmaxv = W::wave_max(gmv);
                 if (DELTA && pass) {
                     DeltaTabs DT;                    // (a dozen integer instructions: built here, not held across the factorisation sweep)
                     build_delta_tabs(m, DT);
                     delta_sweep(P, m, T, DT, lds, linv);
                 }
+                else if (STIFF && P.refine > 0 && gmaxv > P.refine_gamma) ok = riccati_sweep<DELTA, STIFF>(P, m, T, lds, nullptr, linv) && ok;
                 else ok = riccati_sweep<DELTA>(P, m, T, lds, nullptr, linv) && ok;
+                if constexpr (REFINE) {
+                    if (ok && P.refine > 0 && gmaxv > P.refine_gamma) {
+                        if (pass) {
+                            // the corrector's second solve left only the CHANGE of the bounded rows' gradient in the cost blocks:
+                            // put the corrector's full gradient there, as the refinement needs the gradient of the whole quadratic
+                            for (int s = 0; s < NSLOT; ++s) {
+                                vd sl = vd(sigma_mu) - S.pl[s], su = vd(sigma_mu) - S.pu[s];
+                                vd rtl = W::rcp(S.tl[s]), rtu = W::rcp(S.tu[s]);
+                                vd gl = S.ll[s] * rtl, gu = S.lu[s] * rtu;
+                                vd lo, hi;
+                                bounds(S, lds, s, lo, hi);
+                                vd gam = -sl * rtl - S.ll[s] - gl * lo + su * rtu + S.lu[s] - gu * hi;
+                                W::stp(lds, S.de_off[s] + int(SL_GE), W::ld(lds, S.de_off[s] + int(SL_GB)) + gam, S.valid[s]);
+                            }
+                            W::sync();
+                        }
+                        DeltaTabs DT;
+                        build_delta_tabs(m, DT);
+                        for (int rf = 0; rf < P.refine; ++rf) {
+                            refine_gradient(P, m, lds);
+                            delta_sweep<true>(P, m, T, DT, lds, linv);
+                        }
+                    }
+                }
                 NDP_FINE(if (fio && fio->dbg && iters == 1) fstamp(*fio, m, 7 + 3 * pass);)
                 if (!ok) break;
                 vd amin = 1.0;

@@ -48,6 +48,8 @@ void orc_default_cfg(orc_cfg *c)
     c->iter_max = 50;
     c->qp_mode = 1;
     c->auto_margin = 0.1;
+    c->refine = 2;
+    c->refine_gamma = 1e6;
 }
 
 /* ---------------------------------------------------------------- dynamics */
@@ -385,8 +387,35 @@ typedef struct {
     ipm_con cn[7 * ORC_NMAX];
     double Qe[(ORC_NMAX + 1) * NX * NX], qe[(ORC_NMAX + 1) * NX], Re[ORC_NMAX * NU], re[ORC_NMAX * NU];
     double zx[(ORC_NMAX + 1) * NX], zu[ORC_NMAX * NU], nx_[(ORC_NMAX + 1) * NX], nu_[ORC_NMAX * NU];
+    double gx[(ORC_NMAX + 1) * NX], gu[ORC_NMAX * NU], cx[(ORC_NMAX + 1) * NX], cu[ORC_NMAX * NU], zb[ORC_NMAX * NX];
     ric_gain G;
 } qp_ws;
+
+/* Iterative refinement of the minimiser (dx, du) of the equality-constrained QP with blocks Qe, qe, Re, re: the gradient of its
+ * objective at (dx, du) is g = qe + Qe dx | re + Re du; the minimiser of the SAME quadratic with gradient g, zero dynamics defects
+ * and zero initial state is exactly (z* - z) -- a correction of the size of the first solve's error, computed to the same RELATIVE
+ * accuracy.  (The gradient of a stiff coordinate, Gamma (dx_v - bound) + ..., is itself only accurate to Gamma * eps -- which moves
+ * that coordinate by eps.)  Why this and not a factored (square-root) recursion: measured on the shrunk-velocity-box problems of
+ * tests/test_oracle_pins.py, propagating a Cholesky / QR factor of P leaves the error where it is (1e-5 .. 1e-2 at tol 1e-10, the
+ * same as the explicit recursion): what is lost is lost in the SOLUTION of an ill-conditioned system (cond ~ Gamma), not in forming
+ * P; two refinement solves bring the same problems to 1e-9 .. 1e-11. */
+static int refine_solution(int N, const double *A, const double *B, const double *Qe, const double *qe, const double *Re,
+                           const double *re, double *dx, double *du, qp_ws *w)
+{
+    const double dx0z[NX] = {0};
+    memset(w->zb, 0, sizeof(double) * (size_t)N * NX);
+    for (int k = 0; k <= N; ++k)
+        for (int i = 0; i < NX; ++i) {
+            double s = qe[k * NX + i];
+            for (int j = 0; j < NX; ++j) s += Qe[(size_t)k * NX * NX + i * NX + j] * dx[k * NX + j];
+            w->gx[k * NX + i] = s;
+        }
+    for (int i = 0; i < N * NU; ++i) w->gu[i] = re[i] + Re[i] * du[i];
+    if (riccati_solve(N, A, B, w->zb, Qe, w->gx, Re, w->gu, dx0z, w->cx, w->cu, &w->G)) return 4;
+    for (int i = 0; i < (N + 1) * NX; ++i) dx[i] += w->cx[i];
+    for (int i = 0; i < N * NU; ++i) du[i] += w->cu[i];
+    return 0;
+}
 
 static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B, const double *b,
                        const double *Q, const double *q, const double *Rd, const double *r,
@@ -474,6 +503,14 @@ static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B
                 }
             }
             if (riccati_solve(N, A, B, b, Qe, qe, Re, re, dx0, nx_, nu_, G)) { status = 4; failed = 1; goto done; }
+            if (c->refine > 0) {
+                double gmax = 0.0;           /* largest barrier term on a STATE bound (input bounds sit on R's diagonal: benign) */
+                for (int i = 0; i < m; ++i)
+                    if (cn[i].idx >= NU) gmax = fmax(gmax, cn[i].ll / cn[i].tl + cn[i].lu / cn[i].tu);
+                if (gmax > c->refine_gamma)
+                    for (int rf = 0; rf < c->refine; ++rf)
+                        if (refine_solution(N, A, B, Qe, qe, Re, re, nx_, nu_, w)) { status = 4; failed = 1; goto done; }
+            }
             /* slack / multiplier steps and the largest feasible step length */
             double alpha = 1.0;
             for (int i = 0; i < m; ++i) {

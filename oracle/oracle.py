@@ -24,6 +24,7 @@ class OrcCfg(C.Structure):
         ("use_fd", C.c_int),
         ("mu0", C.c_double), ("thr0", C.c_double), ("tol", C.c_double), ("tau", C.c_double),
         ("iter_max", C.c_int), ("qp_mode", C.c_int), ("auto_margin", C.c_double), ("mu_floor", C.c_double),
+        ("refine", C.c_int), ("refine_gamma", C.c_double),
     ]
 
 

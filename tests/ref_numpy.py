@@ -217,3 +217,132 @@ def separation(qp, dx, du, active):
     z = np.concatenate([dx.ravel(), du.ravel()])
     margin = min(min(z[v] - lo, hi - z[v]) for (v, lo, hi) in table if v not in active)
     return min(margin, np.abs(mult).min() if len(mult) else np.inf)
+
+
+# ------------------------------------------------------------------------------------------- interior point with a pluggable Riccati
+# The oracle's interior-point loop (absolute form, Mehrotra predictor-corrector, oracle/ndp_oracle.c: qp_solve_ws) restated in numpy
+# with the Newton-system solver as a parameter, to compare formulations of the Riccati recursion on problems with active STATE
+# bounds (tests/test_oracle_pins.py): the explicit recursion, a square-root form (QR factor of P propagated), and either of them
+# followed by refinement solves.
+def _rollout(qp, K, kf):
+    A, B, b, dx0 = qp["A"], qp["B"], qp["b"], qp["dx0"]
+    N = A.shape[0]
+    dx, du = np.zeros((N + 1, NX)), np.zeros((N, NU))
+    dx[0] = dx0
+    for k in range(N):
+        du[k] = kf[k] + K[k] @ dx[k]
+        dx[k + 1] = A[k] @ dx[k] + B[k] @ du[k] + b[k]
+    return dx, du
+
+
+def riccati_explicit(qp, Qe, qe, Re, re):
+    """P = Hxx - Hxu Lam^-1 Hux, the textbook recursion (what oracle and device run)."""
+    A, B, b = qp["A"], qp["B"], qp["b"]
+    N = A.shape[0]
+    P, p = Qe[N].copy(), qe[N].copy()
+    K, kf = [None] * N, [None] * N
+    for k in range(N - 1, -1, -1):
+        Pb, PA, PB = p + P @ b[k], P @ A[k], P @ B[k]
+        Lam, Hux, hu = np.diag(Re[k]) + B[k].T @ PB, B[k].T @ PA, re[k] + B[k].T @ Pb
+        Hxx, hx = Qe[k] + A[k].T @ PA, qe[k] + A[k].T @ Pb
+        L = np.linalg.cholesky(Lam)
+        K[k] = -np.linalg.solve(L.T, np.linalg.solve(L, Hux))
+        kf[k] = -np.linalg.solve(L.T, np.linalg.solve(L, hu))
+        P = Hxx + Hux.T @ K[k]
+        P, p = 0.5 * (P + P.T), hx + Hux.T @ kf[k]
+    return _rollout(qp, K, kf)
+
+
+def _psd_factor(Q):
+    w, V = np.linalg.eigh(Q)
+    return (V * np.sqrt(np.clip(w, 0.0, None))).T          # F with F'F = Q
+
+
+def riccati_sqrt(qp, Qe, qe, Re, re):
+    """Square-root form: an upper-triangular S with P = S'S is propagated through the QR factorisation of
+    [S+ [B A]; sqrt(R) 0; 0 F_Q] -- P is never formed as a difference."""
+    A, B, b = qp["A"], qp["B"], qp["b"]
+    N = A.shape[0]
+    S, p = _psd_factor(Qe[N]), qe[N].copy()
+    K, kf = [None] * N, [None] * N
+    for k in range(N - 1, -1, -1):
+        Z = np.vstack([np.hstack([S @ B[k], S @ A[k]]), np.hstack([np.diag(np.sqrt(Re[k])), np.zeros((NU, NX))]),
+                       np.hstack([np.zeros((NX, NU)), _psd_factor(Qe[k])])])
+        Rf = np.linalg.qr(Z, mode="r")
+        Ruu, Rux, Rxx = Rf[:NU, :NU], Rf[:NU, NU:], Rf[NU:NU + NX, NU:]
+        Pb = p + S.T @ (S @ b[k])
+        hu, hx = re[k] + B[k].T @ Pb, qe[k] + A[k].T @ Pb
+        K[k] = -np.linalg.solve(Ruu, Rux)
+        y = np.linalg.solve(Ruu.T, hu)
+        kf[k] = -np.linalg.solve(Ruu, y)
+        p, S = hx - Rux.T @ y, Rxx
+    return _rollout(qp, K, kf)
+
+
+def refined(base, n):
+    """base followed by n refinement solves: gradient g + H z, zero defects, zero initial state (oracle: refine_solution)."""
+    def ric(qp, Qe, qe, Re, re):
+        dx, du = base(qp, Qe, qe, Re, re)
+        qp0 = dict(qp)
+        qp0["b"], qp0["dx0"] = np.zeros_like(qp["b"]), np.zeros(NX)
+        for _ in range(n):
+            ddx, ddu = base(qp0, Qe, np.einsum("kij,kj->ki", Qe, dx) + qe, Re, Re * du + re)
+            dx, du = dx + ddx, du + ddu
+        return dx, du
+    return ric
+
+
+def ipm_absolute(qp, tol, ric, mu0=10.0, thr0=0.1, tau=0.995, mu_floor=0.1, iter_max=60):
+    N = qp["A"].shape[0]
+    st = np.array([k for k in range(N) for _ in range(NU)] + [k for k in range(1, N) for _ in range(3)])
+    ix = np.array([i for _ in range(N) for i in range(NU)] + [NU + i for _ in range(1, N) for i in range(3)])
+    lo = np.concatenate([qp["lu"].ravel(), qp["lv"][1:N].ravel()])
+    hi = np.concatenate([qp["uu"].ravel(), qp["uv"][1:N].ravel()])
+    m, isu = len(st), ix < NU
+
+    def val(dx, du):
+        return np.where(isu, du[st, np.minimum(ix, NU - 1)], dx[st, 3 + np.maximum(ix - NU, 0)])
+    tl, tu = np.maximum(-lo, thr0), np.maximum(hi, thr0)
+    ll, lu = mu0 / tl, mu0 / tu
+    mu = (ll * tl + lu * tu).sum() / (2 * m)
+    norm0 = max(1.0, ll.max(), lu.max(), np.abs(-lo - tl).max(), np.abs(hi - tu).max(), np.abs(qp["q"]).max(), np.abs(qp["r"]).max(),
+                np.abs(qp["b"]).max(), np.abs(qp["dx0"]).max())
+    rho, it = 1.0, 0
+    zx, zu = np.zeros((N + 1, NX)), np.zeros((N, NU))
+    dll = dlu = dtl = dtu = np.zeros(m)
+    while not (mu <= tol and rho * norm0 <= tol) and it < iter_max:
+        it += 1
+        sig = 0.0
+        for ps in range(2):
+            sl = sig - dll * dtl if ps else np.zeros(m)
+            su = sig - dlu * dtu if ps else np.zeros(m)
+            gl, gu = ll / tl, lu / tu
+            Gam, gam = gl + gu, -sl / tl - ll - gl * lo + su / tu + lu - gu * hi
+            Qe, qe, Re, re = qp["Q"].copy(), qp["q"].copy(), qp["Rd"].copy(), qp["r"].copy()
+            for i in range(m):
+                if isu[i]:
+                    Re[st[i], ix[i]] += Gam[i]
+                    re[st[i], ix[i]] += gam[i]
+                else:
+                    j = 3 + ix[i] - NU
+                    Qe[st[i], j, j] += Gam[i]
+                    qe[st[i], j] += gam[i]
+            nx_, nu_ = ric(qp, Qe, qe, Re, re)
+            zn = val(nx_, nu_)
+            dtl, dtu = zn - lo - tl, hi - zn - tu
+            dll, dlu = sl / tl - ll - ll / tl * dtl, su / tu - lu - lu / tu * dtu
+            al = 1.0
+            for d, v in ((dtl, tl), (dtu, tu), (dll, ll), (dlu, lu)):
+                neg = d < 0
+                if neg.any():
+                    al = min(al, (-v[neg] / d[neg]).min())
+            if ps == 0:
+                mua = ((ll + al * dll) * (tl + al * dtl) + (lu + al * dlu) * (tu + al * dtu)).sum() / (2 * m)
+                sig = max((mua / mu) ** 3 * mu, mu_floor * tol)
+            else:
+                if al < 1:
+                    al *= tau
+                zx, zu = zx + al * (nx_ - zx), zu + al * (nu_ - zu)
+                tl, tu, ll, lu = tl + al * dtl, tu + al * dtu, ll + al * dll, lu + al * dlu
+                mu, rho = (ll * tl + lu * tu).sum() / (2 * m), rho * (1 - al)
+    return zx, zu, it

@@ -321,18 +321,76 @@ def test_input_and_velocity_bounds_active_together(oracle):
         vmax = np.abs(dx_free[4:20, 3:6]).max()
         qp["lv"][:4], qp["uv"][:4] = -1e3, 1e3          # keep the problem feasible near the fixed x0
         qp["lv"][4:], qp["uv"][4:] = -0.7 * vmax, 0.7 * vmax
-        # Default tolerance only.  With ACTIVE STATE bounds the barrier puts lambda / t ~ 1e9 .. 1e11 on the diagonal of Q, and the
-        # classical Riccati recursion (P = Hxx - Hxu Lam^-1 Hux, an explicit difference) loses digits as mu shrinks: pushed to
-        # tol = 1e-10 the answer gets WORSE on some of these problems (1e-3), not better -- HPIPM propagates P in factored form
-        # [acados-knowledge].  The reference's velocity box (+-20 m/s, nmpc_body_rate_ctl.py:59-61) is far outside its flight
-        # envelope, so this only shows on boxes shrunk on purpose as here; at the default tolerance the usual bound holds.
-        active = _check_qp(oracle, cfg, qp, stats, tight=False)
+        # With ACTIVE STATE bounds the barrier puts lambda / t ~ 1e9 .. 1e11 on the diagonal of Q: the Newton systems get a
+        # condition number of that size, and the loop is written in absolute form (an iteration's answer IS its last solve), so
+        # through round 3 the answer got WORSE as the tolerance was tightened (1e-3 at tol = 1e-10 on some of these problems).
+        # Round 4: two refinement solves with the same factorisation whenever a state bound's barrier term exceeds 1e6
+        # (cfg.refine, oracle/ndp_oracle.c: refine_solution) -- and the tight tolerance holds its usual bound here too.  (A factored
+        # / square-root Riccati recursion, which round 3 had named as the remedy, does NOT help: measured, see the test below.)
+        active = _check_qp(oracle, cfg, qp, stats, tight=True)
         nz = 21 * 10
         has_v, has_u = any(v < nz for v in active), any(v >= nz for v in active)
         both += has_v and has_u
     st = np.array(stats)
     assert both >= 30, both
-    assert np.median(st[:, 1]) < 1e-6 and st[:, 1].max() < 1e-3
+    tight, dflt = st[st[:, 0] == 1e-10], st[st[:, 0] != 1e-10]
+    assert np.median(tight[:, 1]) < 1e-9 and tight[:, 1].max() < 2e-6
+    assert np.median(dflt[:, 1]) < 1e-7 and dflt[:, 1].max() < 5e-5
+
+
+def _shrunk_velocity_box(oracle, seed):
+    cfg, qp = _hard_case(oracle, seed, 1.5)
+    cfg.qp_mode = 1
+    dx_free, _, _ = oracle.qp_solve(cfg, qp)
+    vmax = np.abs(dx_free[4:20, 3:6]).max()
+    qp["lv"][:4], qp["uv"][:4] = -1e3, 1e3
+    qp["lv"][4:], qp["uv"][4:] = -0.7 * vmax, 0.7 * vmax
+    return cfg, qp
+
+
+def test_active_state_bounds_at_a_tight_tolerance_need_refinement_not_a_factored_recursion(oracle):
+    """VERDICT r3 #5.  Velocity box shrunk until >= 3 state bounds are active; tol = 1e-10; against the exact (active-set) answer.
+      * refinement off (round 3's oracle): the error GROWS with the tightened tolerance, up to 1e-2;
+      * refinement on (default): the problems with >= 3 active state bounds within 1e-7 (all but at most two whose active set
+        is weakly decided: an interior-point answer stopped at mu <= tol cannot be closer than ~tol / separation), median < 1e-9;
+      * the SAME loop with the Riccati recursion in square-root form (a QR factor of P~ propagated instead of P~: numpy, below)
+        is no better than the explicit form -- the digits are lost in solving a system of condition lambda / t, not in forming P."""
+    rows = []
+    for seed in range(40, 80):
+        cfg, qp = _shrunk_velocity_box(oracle, seed)
+        dxa, dua, active = R.pdas_solve(qp)
+        nv = sum(1 for v in active if v < 21 * 10)
+        sep = min(1.0, R.separation(qp, dxa, dua, active))
+        cfg.tol = 1e-10
+        errs = []
+        for refine in (0, 2):
+            cfg.refine = refine
+            dx, du, st = oracle.qp_solve(cfg, qp)
+            assert st.status == 0
+            errs.append(max(np.abs(du - dua).max(), np.abs(dx - dxa).max()))
+        rows.append((nv, sep, errs[0], errs[1]))
+    r = np.array(rows)
+    many = r[:, 0] >= 3
+    assert many.sum() >= 20
+    assert r[many, 2].max() > 1e-4                                   # what round 3 saw
+    # the usual termination bound of an interior-point answer (see the note above): 4e-6 (tol / 1e-8) / separation, floor 1e-7
+    bar = np.maximum(1e-7, DEFAULT_TOL_CONST * 1e-2 / r[:, 1])
+    assert (r[:, 3] <= bar).all(), (r[:, 3] / bar).max()
+    assert (r[many, 3] <= 1e-7).sum() >= many.sum() - 2              # all but the most weakly decided within 1e-7
+    assert np.median(r[many, 3]) < 1e-9 and r[:, 3].max() < 2e-6
+    # ---- the square-root recursion in the same loop (numpy): not the remedy
+    worse = 0
+    for seed in (40, 46, 50, 76):
+        cfg, qp = _shrunk_velocity_box(oracle, seed)
+        dxa, dua, _ = R.pdas_solve(qp)
+        e = {}
+        for name, ric in (("explicit", R.riccati_explicit), ("sqrt", R.riccati_sqrt), ("explicit+refine", R.refined(R.riccati_explicit, 2))):
+            dx, du, _ = R.ipm_absolute(qp, 1e-10, ric)
+            e[name] = max(np.abs(du - dua).max(), np.abs(dx - dxa).max())
+        assert e["explicit+refine"] < 1e-8, (seed, e)
+        worse += e["sqrt"] > 1e-6
+        assert e["sqrt"] > 100 * e["explicit+refine"], (seed, e)
+    assert worse >= 3
 
 
 def test_long_horizon_two_iterations_against_active_set(oracle):
