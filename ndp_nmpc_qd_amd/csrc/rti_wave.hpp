@@ -1396,7 +1396,11 @@ struct RtiWave {
         // Both live in the three-slot kernels only (N <= 27: the reference configuration).  In the five-slot kernels (N = 40, config 5)
         // a third instantiation of the sweep inside the loop brings the registers back over the edge (324 B of scratch per lane) for
         // a case -- active STATE bounds -- that the reference's +-20 m/s box does not produce; there the loop runs as in round 3.
+#ifdef NDP_DEV_NO_STIFF      // kernel-development hook: the loop as in round 3 (A/B runs of the headline with and without the extra code)
+        constexpr bool STIFF = false;
+#else
         constexpr bool STIFF = NSLOT <= 3;
+#endif
         constexpr bool REFINE = DELTA && MMA4 && STIFF;
         const int nu4 = 4 * N;
         for (;;) {
