@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, datasheet; v_mfma_f64_16x16x4 = 2048 FLOP / 64 clk / SIMD
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_TAGS = ("r03", "r02")  # newest first: profiles/<tag>_kernel_stats_fused_b1024.csv + <tag>_pmc_rti_kernel.json = the DEFAULT configuration's profile
+PROFILE_TAGS = ("r04", "r03", "r02")  # newest first: profiles/<tag>_kernel_stats_fused_b1024.csv + <tag>_pmc_rti_kernel.json = the DEFAULT configuration's profile
 PROFILE_TOLERANCE = 0.25       # a committed profile whose kernel duration is further than this from the live HIP-event duration is refused
 
 
@@ -470,8 +470,8 @@ def main():
         # all-gather per step); the N = 1 headline above replays a hipGraph with no exchange at all.  The same steps are therefore
         # ALSO run here in exactly the N > 1 form -- a one-rank communicator, the pack + ncclAllGather on the library's stream per
         # step, host-launched and captured -- and reported as `scaling_baseline`: efficiency = value(N) / (N * scaling_baseline).
-        if not args.only_timed and args.exchange in ("both", "rccl") and not same_dev:
-            baseline_modes = list(rccl_modes)
+        if not args.only_timed and not same_dev:
+            baseline_modes = (list(rccl_modes) if args.exchange in ("both", "rccl") else []) + (["peer"] if args.exchange in ("both", "peer") else [])
             modes = modes + baseline_modes
     elif not need_exchange:
         modes = ["none"]
@@ -1028,14 +1028,15 @@ def main():
                     for m, e in form_errors.items():
                         if m in baseline_modes:
                             sb[m] = {"error": e}
-                    okm = [m for m in sb if sb[m].get("ok")]
+                    okm = [m for m in sb if sb[m].get("ok") and m != "peer"]          # (the base of the curve is the headline form's: rccl)
                     best = max(okm, key=lambda m: sb[m]["value"]) if okm else None
                     out["scaling_baseline"] = {
                         "value": sb[best]["value"] if best else None, "ms_per_step": sb[best]["ms_per_step"] if best else None, "form": best,
                         "forms": sb,
                         "note": "the SAME steps in the form every N > 1 line runs: one library-issued RCCL all-gather of the position / velocity "
                                 "windows per control step (a real one-rank communicator, no xGMI traffic) + the control-step launch, host-launched "
-                                "('rccl') and captured into the hipGraph ('rccl_graph'); `value` = the faster one, as at N > 1.  Scaling efficiency "
+                                "('rccl') and captured into the hipGraph ('rccl_graph'); `value` = the faster one, as at N > 1 ('peer': the publish / "
+                                "epoch form with the rank's own buffer as neighbour, what exchange.peer of an N > 1 line compares with).  Scaling efficiency "
                                 "= value(N) / (N x this); the headline `value` of this line replays a hipGraph with NO exchange and is not the curve's base"}
             if need_exchange:
                 # both forms of the per-step neighbour exchange, same steps, same inputs (value = whole-job solves/s)

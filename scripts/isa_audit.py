@@ -55,14 +55,17 @@ def main():
               f"{b - a} lines")
         blocks, cur = collections.OrderedDict(), "entry"
         blocks[cur] = []
+        full = {cur: []}
         for ln in lines[a + 1:b]:
             s = ln.strip()
             lab = re.match(r"(\.LBB\w+):", s)
             if lab:
                 cur = lab.group(1)
                 blocks[cur] = []
+                full[cur] = []
             elif s and not s.startswith((";", ".")):
                 blocks[cur].append(s.split()[0])
+                full[cur].append(s)
         tot_l = sum(sum(1 for o in ops if o.startswith("scratch_load")) for ops in blocks.values())
         tot_s = sum(sum(1 for o in ops if o.startswith("scratch_store")) for ops in blocks.values())
         print(f"   scratch instructions in the code: {tot_l} loads, {tot_s} stores; by basic block (blocks holding matrix instructions = the sweeps):")
@@ -77,7 +80,9 @@ def main():
         for k, l, s, n in outside:
             print(f"     {k}: {l} loads, {s} stores in {n} instructions (no matrix instruction: set-up / linearise / interior-point bookkeeping)")
         # instruction mix of the block with the most matrix instructions (the unrolled first sweep of a compile-time horizon)
-        k, ops = max(blocks.items(), key=lambda kv: sum(1 for o in kv[1] if o.startswith("v_mfma")))
+        # (the cofactor-path sweep: one v_rcp_f64 per stage; the interior-point loop's LDL' sweeps hold four and are left aside)
+        cand = {kk: oo for kk, oo in blocks.items() if sum(1 for o in oo if o.startswith("v_rcp")) <= max(1, sum(1 for o in oo if o.startswith("v_mfma_f64_16x16x4")) // 7 + 2)}
+        k, ops = max(cand.items(), key=lambda kv: sum(1 for o in kv[1] if o.startswith("v_mfma")))
         c = collections.Counter(ops)
         nm16 = sum(v for o, v in c.items() if o.startswith("v_mfma_f64_16x16x4"))
         nm4 = sum(v for o, v in c.items() if o.startswith("v_mfma_f64_4x4x4"))
@@ -89,7 +94,85 @@ def main():
               f"{c.get('s_waitcnt', 0)} s_waitcnt, {sum(v for o, v in c.items() if o.startswith('v_accvgpr'))} accvgpr moves")
         top = ", ".join(f"{o} {v}" for o, v in c.most_common(12))
         print(f"     most frequent: {top}")
+        classify_nops(full[k])
+
+
+def _regs(tok):
+    """register numbers named by an operand like v[16:23], v7, -v[2:3]"""
+    m = re.match(r"-?\|?v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"-?\|?v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def classify_nops(lines):
+    """Every s_nop of a block by the hazard it pads: what the instruction in front of it produced and what the instruction behind it
+    consumes (VERDICT r3 #6b).  Wait states = sum of (N + 1) over s_nop N."""
+    import collections
+    ins = [ln.split(";")[0].strip() for ln in lines]
+    ins = [x for x in ins if x]
+    cls = collections.Counter()
+    cyc = collections.Counter()
+    i = 0
+    while i < len(ins):
+        if not ins[i].startswith("s_nop"):
+            i += 1
+            continue
+        j, n = i, 0
+        while j < len(ins) and ins[j].startswith("s_nop"):
+            n += int(ins[j].split()[1]) + 1
+            j += 1
+        prev = next((ins[p] for p in range(i - 1, -1, -1) if not ins[p].startswith(("s_waitcnt", "s_nop", ";"))), "")
+        nxt = ins[j] if j < len(ins) else ""
+        # the producer the pad is for: the nearest matrix / transcendental / VALU instruction in front whose result the next one reads
+        prod = ""
+        use = set()
+        for tok in nxt.replace(",", " ").split()[1:]:
+            use |= _regs(tok)
+        for p in range(i - 1, max(-1, i - 12), -1):
+            ops = ins[p].replace(",", " ").split()
+            if len(ops) > 1 and (_regs(ops[1]) & use):
+                prod = ops[0]
+                break
+        prod = prod or prev.split()[0] if prev else "?"
+        cons = nxt.split()[0] if nxt else "?"
+        if prod.startswith("v_mfma") and cons.startswith("v_mfma"):
+            key = "matrix result -> matrix instruction's A / B operand (dependent chain)"
+        elif prod.startswith("v_mfma") and cons.startswith("ds_"):
+            key = "matrix result -> LDS store"
+        elif prod.startswith("v_mfma"):
+            key = "matrix result -> vector instruction"
+        elif "dpp" in nxt:
+            key = "vector write -> DPP read"
+        elif prod.startswith(("v_rcp", "v_rsq", "v_sqrt")):
+            key = "transcendental result -> use"
+        elif cons.startswith("v_mfma"):
+            key = "vector write -> matrix instruction operand"
+        elif cons.startswith(("v_readlane", "v_readfirstlane", "s_")) or prod.startswith("v_cmp"):
+            key = "vector -> scalar / lane read"
+        else:
+            key = f"other ({prod} -> {cons})"
+        cls[key] += 1
+        cyc[key] += n
+        i = j
+    tot = sum(cyc.values())
+    print(f"   s_nop pads of that block by hazard ({sum(cls.values())} pads, {tot} wait states):")
+    for k2, v in sorted(cyc.items(), key=lambda kv: -kv[1]):
+        print(f"     {v:5d} wait states in {cls[k2]:4d} pads: {k2}")
 
 
 if __name__ == "__main__":
     main()
+    # the shipped library's properties the ISA tests assert (tests/test_isa_properties.py)
+    sys.path.insert(0, ROOT)
+    from ndp_nmpc_qd_amd import build, isa_inspect as I
+    co = I.CodeObject(build.build())
+    kk = co.kernels()
+    sym = [n for n in kk if "mlp_stream_kernel" in n][0]
+    print("\n== shipped library (ndp_nmpc_qd_amd/libndp_nmpc_hip.so)")
+    print("   mlp_stream_kernel epoch store:", I.epoch_store_is_ordered(co.disassemble(sym))[1])
+    print("   rti_kernel instantiations: %d, with scratch: %d" % (sum("rti_kernel" in n for n in kk), sum(1 for n, v in kk.items() if "rti_kernel" in n and v["scratch"])))
+    for n, v in kk.items():
+        if "rti_kernel" in n:
+            print(f"     {n[19:53]:36s} vgpr {v['vgpr']:3d} (acc {v['agpr']:3d}) spilled {v['spill']:3d} scratch {v['scratch']:4d} B")
