@@ -225,10 +225,17 @@ def baseline_configs_block(ndp, ndist, synth, O, torch, dev, stream, local_rank,
                         xchg = ndist.RcclExchange(Bl, N, local_rank)
                     gathered = [torch.empty(Bl, N + 1, ndist.PV_COLS, dtype=torch.float64, device=dev) for _ in range(2)]
 
-                    def en(i, _g=gathered, _x=xchg):
+                    primed = {"tick": None}
+
+                    def en(i, _g=gathered, _x=xchg, _p=primed):
+                        # as the N > 1 steps do it: tick i + 1's windows (functions of time only) are gathered on the library's stream
+                        # while tick i is solved; ordered behind the last reader of the buffer through the compute stream
                         d = tk[i % 4]
-                        _x.begin(d["xr"], _g[i % 2], stream)          # this tick's windows: pack + ncclAllGather on the library's stream
+                        if _p["tick"] != i:
+                            _x.begin(d["xr"], _g[i % 2], stream)
                         _x.end(stream)
+                        _x.begin(tk[(i + 1) % 4]["xr"], _g[(i + 1) % 2], stream)
+                        _p["tick"] = i + 1
                         eng.update_device(d["x0"], d["xr"], d["ur"], u0, other=_g[i % 2], ego_xy=d["ego_xy"], stream=stream,
                                           other_index=d["other_index"])
                     ms, mode = run_leg(eng, en, rs, Bl, graph=False)
@@ -237,6 +244,9 @@ def baseline_configs_block(ndp, ndist, synth, O, torch, dev, stream, local_rank,
                     c4[f"{3 * F}_instances_{placement}_major"] = {"error": f"{type(e).__name__}: {e}"[:200]}
                     continue
             rs(); en(0); torch.cuda.synchronize()
+            if xchg is not None:
+                xchg.end(stream)                     # (the gather begun for a tick that is not solved)
+                torch.cuda.synchronize()
             h0 = hs[0]
             allv = ndist.make_config4_all(F, N=N, t0=0.0)
             nb = np.where(h0["gids"] % 3 == 0, h0["gids"] + 1, h0["gids"])
