@@ -81,7 +81,7 @@ typedef struct ndp_cfg {
     double ts_nmpc;             /* control period, params/nmpc_params.py:11 (0.02): spacing of the reference list entries */
     double mu_floor;            /* interior point: the centring target sigma*mu never goes below mu_floor * tol (default 0.1) --
                                  * slacks are differences, so driving mu far below tol only loses digits */
-    double refine_gamma;        /* see ipm_refine (default 1e6) */
+    double refine_gamma;        /* see ipm_refine (default 1e4) */
 } ndp_cfg;
 
 typedef struct ndp_handle ndp_handle;

@@ -40,7 +40,7 @@ inline void fill_default_cfg(ndp_cfg *c)
     c->auto_margin = 0.1;
     c->ts_nmpc = 0.02;
     c->ipm_refine = 2;
-    c->refine_gamma = 1e6;
+    c->refine_gamma = 1e4;
 }
 
 inline RtiParams to_params(const ndp_cfg &c)

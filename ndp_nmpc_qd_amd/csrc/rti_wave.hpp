@@ -299,7 +299,10 @@ struct RtiWave {
         vb col0;                  // j == 0
         // 4x4 inverse (lam_inverse): LDS scratch SC holds Lam row-major
         vi lam_w_off;             // lanes j >= 12 publish H~[12+g][j] to SC[g*4 + j-12]
-        vi minor_off[9];          // the 3x3 minor of (g, j&3)
+        vi minor_one[3], minor_pair[3];   // the 3x3 minor of (g, j&3), row a: one single element + one ALIGNED pair of adjacent ones
+                                  // (columns {0..3} \ {j&3} always hold the pair (2,3) or (0,1): one 16-byte read instead of two
+                                  // 8-byte ones; the column order (single, pair) is the natural one or a cyclic shift of it --
+                                  // the same determinant)
         vi own_off;               // Lam[g][j&3]
         vd cof_sign;              // (-1)^(g + j&3)
         vd adj_a, adj_b;          // cof_sign * [j < 4], -cof_sign * [j >= 12]: minor determinant -> MFMA operand in one multiply
@@ -393,12 +396,14 @@ struct RtiWave {
         T.zu_st = g + W::sel(T.col0, vi(m.ZU), vi(m.ZD + (m.ZU - m.ZX)));
         vi jc = j & 3;
         T.lam_w_off = W::sel(T.kt_pred, g * 4 + jc + m.SC, vi(m.KC + KC_DUMP));
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) {
-                vi ra = W::sel(g <= a, vi(a + 1), vi(a));    // rows {0..3} \ {g}
-                vi cb = W::sel(jc <= b, vi(b + 1), vi(b));   // cols {0..3} \ {jc}
-                T.minor_off[3 * a + b] = ra * 4 + cb + m.SC;
-            }
+        for (int a = 0; a < 3; ++a) {
+            vi ra = W::sel(g <= a, vi(a + 1), vi(a));        // rows {0..3} \ {g}
+            // cols {0..3} \ {jc}: jc < 2 -> single {1 or 0}, pair (2,3);  jc >= 2 -> pair (0,1), single {3 or 2}
+            vi single = W::sel(jc < 2, W::sel(jc == 0, vi(1), vi(0)), W::sel(jc == 2, vi(3), vi(2)));
+            vi pair0 = W::sel(jc < 2, vi(2), vi(0));
+            T.minor_one[a] = ra * 4 + single + m.SC;
+            T.minor_pair[a] = ra * 4 + pair0 + m.SC;
+        }
         T.own_off = g * 4 + jc + m.SC;
         vi x4 = ((lane >> 2) & 3) * 4 + g, j4 = lane & 3;
         T.kt_st4 = W::sel(x4 < 12, x4 * 4 + j4 + m.KT, vi(m.MB + int(MB_DUMP)));
@@ -417,7 +422,9 @@ struct RtiWave {
         i++;   // pad to a multiple of four fields
         for (int r = 0; r < 4; ++r) f(i++, T.c_off[r]);
         f(i++, T.mu_off); f(i++, T.zu_st); f(i++, T.lam_w_off); f(i++, T.own_off);
-        for (int a = 0; a < 9; ++a) f(i++, T.minor_off[a]);
+        for (int a = 0; a < 3; ++a) f(i++, T.minor_one[a]);
+        for (int a = 0; a < 3; ++a) f(i++, T.minor_pair[a]);
+        i += 3;   // (three fields fewer than the nine single offsets of rounds 1-3: the positions behind stay where they were)
         f(i++, T.kt_st4); f(i++, T.zx_st4);
     }
     // block layout [field / 4][lane][field % 4]: the four fields of a group are one 16-byte load per lane, a
@@ -764,7 +771,10 @@ struct RtiWave {
     {
         W::st(lds, T.lam_w_off, h3);                         // H~[12+g][12+b] -> SC[g*4+b]; lanes j<12 -> dump slot
         W::sync();
-        for (int i = 0; i < 9; ++i) L.mm[i] = W::ld(lds, T.minor_off[i]);
+        for (int a = 0; a < 3; ++a) {
+            L.mm[3 * a] = W::ld(lds, T.minor_one[a]);
+            W::ld2(lds, T.minor_pair[a], L.mm[3 * a + 1], L.mm[3 * a + 2]);
+        }
         L.own = W::ld(lds, T.own_off);
     }
     static NDP_D vd lam_cofactor(const Tables &T, const LamRegs &L)
@@ -1153,10 +1163,14 @@ struct RtiWave {
 
     // FROM_ZD: the gradient is the FULL one refine_gradient left in the shadow ZD (all state and input rows, the terminal stage
     // included) instead of the corrector's change of the bounded rows in the cost blocks.
+    // Returns (FROM_ZD) the largest correction it added, |dx|, |du| over the horizon -- the caller's check that the solves of a stiff
+    // system can still be trusted (REFINE_FAIL) -- else 0.
+    static constexpr double REFINE_FAIL = 1e-5;
     template <bool FROM_ZD = false>
-    static NDP_D void delta_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, const DeltaTabs &D, lp lds, const md *linv)
+    static NDP_D double delta_sweep(const RtiParams &P, const LdsMap &m, const Tables &T, const DeltaTabs &D, lp lds, const md *linv)
     {
         const int N = horizon(P);
+        vd cmax = 0.0;
         md vc[3] = {W::to_m(vd(0.0)), W::to_m(vd(0.0)), W::to_m(vd(0.0))};
         if constexpr (MMA4) {
             // every product here is matrix x vector: the 4x4x4 instruction, vectors as chunk registers replicated over the columns.
@@ -1218,6 +1232,10 @@ struct RtiWave {
                     du = W::template rowb<3>(y) + dkk;
                 }
                 md xn = mma4(mu, du, y);
+                if constexpr (FROM_ZD) {      // rows 0..9 of xn are dx_{k+1} (row x = 4b + i in lane j + 4b + 16i), du: all four rows
+                    vi x4 = ((W::lane() >> 2) & 3) * 4 + (W::lane() >> 4);
+                    cmax = W::vmax(cmax, W::vmax(W::vabs(W::to_d(du)), W::sel(x4 < 10, W::vabs(W::to_d(xn)), vd(0.0))));
+                }
                 W::st(lds, T.zu_st + k * int(NU), zu0 + W::to_d(du));
                 W::st(lds, T.zx_st4 + (k + 1) * int(NX), zx0 + W::to_d(xn));
                 zc[0] = W::template rowb<0>(xn); zc[1] = W::template rowb<1>(xn); zc[2] = W::template rowb<2>(xn);
@@ -1225,7 +1243,8 @@ struct RtiWave {
                 mu = nmu; zu0 = nzu0; zx0 = nzx0; dkk = ndk;
             }
             W::sync();
-            return;
+            if constexpr (FROM_ZD) return W::wave_max(cmax);
+            return 0.0;
         }
         md dk[NC > 0 ? NC : 1];
         NDP_UNROLL_STAGES
@@ -1260,6 +1279,7 @@ struct RtiWave {
             }
         }
         W::sync();
+        return 0.0;
     }
 
     // ---------------------------------------------------------------- box constraints / interior point
@@ -1458,10 +1478,15 @@ struct RtiWave {
                         }
                         DeltaTabs DT;
                         build_delta_tabs(m, DT);
+                        double corr = 0.0;
                         for (int rf = 0; rf < P.refine; ++rf) {
                             refine_gradient(P, m, lds);
-                            delta_sweep<true>(P, m, T, DT, lds, linv);
+                            corr = delta_sweep<true>(P, m, T, DT, lds, linv);
                         }
+                        // a LAST correction still visible at the parity bar: the solves of this system cannot be trusted (barrier
+                        // terms beyond what fp64 carries through the recursion) -- a QP failure, said so, not a silent answer
+                        // (the corrector's solve -- the one the iterate is updated from; the predictor only steers the centring)
+                        if (pass && !(corr <= REFINE_FAIL)) ok = false;
                     }
                 }
                 NDP_FINE(if (fio && fio->dbg && iters == 1) fstamp(*fio, m, 7 + 3 * pass);)

@@ -43,6 +43,13 @@ struct WaveGfx950 {
 
     // LDS (one wave owns its slice; DS operations of one wave execute in order)
     static NDP_D vd ld(lds_ptr lds, vi off) { return lds[off]; }
+    // two adjacent doubles at an even offset: one 16-byte DS read
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    static NDP_D void ld2(lds_ptr lds, vi off, vd &a, vd &b)
+    {
+        const d2_t v = *(const __attribute__((address_space(3))) d2_t *)__builtin_assume_aligned(lds + off, 16);
+        a = v[0]; b = v[1];
+    }
     static NDP_D vd ldp(lds_ptr lds, vi off, vb p) { return p ? lds[off] : 0.0; }
     static NDP_D void stp(lds_ptr lds, vi off, vd v, vb p) { if (p) lds[off] = v; }
     static NDP_D void st(lds_ptr lds, vi off, vd v) { lds[off] = v; }

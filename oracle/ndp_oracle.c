@@ -49,7 +49,7 @@ void orc_default_cfg(orc_cfg *c)
     c->qp_mode = 1;
     c->auto_margin = 0.1;
     c->refine = 2;
-    c->refine_gamma = 1e6;
+    c->refine_gamma = 1e4;
 }
 
 /* ---------------------------------------------------------------- dynamics */
@@ -399,8 +399,9 @@ typedef struct {
  * tests/test_oracle_pins.py, propagating a Cholesky / QR factor of P leaves the error where it is (1e-5 .. 1e-2 at tol 1e-10, the
  * same as the explicit recursion): what is lost is lost in the SOLUTION of an ill-conditioned system (cond ~ Gamma), not in forming
  * P; two refinement solves bring the same problems to 1e-9 .. 1e-11. */
+#define ORC_REFINE_FAIL 1e-5
 static int refine_solution(int N, const double *A, const double *B, const double *Qe, const double *qe, const double *Re,
-                           const double *re, double *dx, double *du, qp_ws *w)
+                           const double *re, double *dx, double *du, qp_ws *w, double *corr_max)
 {
     const double dx0z[NX] = {0};
     memset(w->zb, 0, sizeof(double) * (size_t)N * NX);
@@ -412,8 +413,10 @@ static int refine_solution(int N, const double *A, const double *B, const double
         }
     for (int i = 0; i < N * NU; ++i) w->gu[i] = re[i] + Re[i] * du[i];
     if (riccati_solve(N, A, B, w->zb, Qe, w->gx, Re, w->gu, dx0z, w->cx, w->cu, &w->G)) return 4;
-    for (int i = 0; i < (N + 1) * NX; ++i) dx[i] += w->cx[i];
-    for (int i = 0; i < N * NU; ++i) du[i] += w->cu[i];
+    double cm = 0.0;
+    for (int i = 0; i < (N + 1) * NX; ++i) { dx[i] += w->cx[i]; cm = fmax(cm, fabs(w->cx[i])); }
+    for (int i = 0; i < N * NU; ++i) { du[i] += w->cu[i]; cm = fmax(cm, fabs(w->cu[i])); }
+    if (corr_max) *corr_max = cm;
     return 0;
 }
 
@@ -507,9 +510,15 @@ static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B
                 double gmax = 0.0;           /* largest barrier term on a STATE bound (input bounds sit on R's diagonal: benign) */
                 for (int i = 0; i < m; ++i)
                     if (cn[i].idx >= NU) gmax = fmax(gmax, cn[i].ll / cn[i].tl + cn[i].lu / cn[i].tu);
-                if (gmax > c->refine_gamma)
+                if (gmax > c->refine_gamma) {
+                    double corr = 0.0;
                     for (int rf = 0; rf < c->refine; ++rf)
-                        if (refine_solution(N, A, B, Qe, qe, Re, re, nx_, nu_, w)) { status = 4; failed = 1; goto done; }
+                        if (refine_solution(N, A, B, Qe, qe, Re, re, nx_, nu_, w, &corr)) { status = 4; failed = 1; goto done; }
+                    /* a LAST correction that is still visible at the parity bar means the solves of this system cannot be trusted
+                     * (barrier terms beyond what fp64 carries through the recursion): a QP failure, said so -- not a silent answer */
+                    /* (the corrector's solve -- the one the iterate is updated from; the predictor only steers the centring) */
+                    if (pass && !(corr <= ORC_REFINE_FAIL)) { status = 4; failed = 1; goto done; }
+                }
             }
             /* slack / multiplier steps and the largest feasible step length */
             double alpha = 1.0;

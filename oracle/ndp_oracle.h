@@ -45,7 +45,7 @@ typedef struct {
     double auto_margin; /* qp_mode 0: accept the equality-constrained minimiser only this far inside every bound */
     double mu_floor;    /* the centring target sigma*mu never goes below mu_floor * tol (default 0.1), see orc_qp_solve */
     /* Iterative refinement of a Newton system's solution through further solves with the SAME factorisation (default 2), applied
-     * only when a STATE bound's barrier term Gamma = lambda / t exceeds refine_gamma (default 1e6): the solve is then accurate to
+     * only when a STATE bound's barrier term Gamma = lambda / t exceeds refine_gamma (default 1e4): the solve is then accurate to
      * cond * eps ~ Gamma * 1e-16 only, and the interior-point loop is written in absolute form (every iteration's answer IS the
      * last solve's), so that error is the answer's.  The refinement gradient is g + H z (block-wise), the correction the
      * minimiser of the same QP with that gradient, zero defects and zero initial state: see qp_solve_ws.  HPIPM's BALANCE mode

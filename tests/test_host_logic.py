@@ -44,7 +44,7 @@ def test_default_cfg_carries_the_reference_constants():
     assert list(cfg.lbv) == [CP.v_min] * 3 and list(cfg.ubv) == [CP.v_max] * 3
     assert CP.c_max == 9.81 / 0.36
     assert C.sizeof(_lib.NdpCfg) == 10 * 4 + 8 * (4 + 10 + 4 + 4 + 4 + 3 + 3 + 8)      # (+ refine_gamma, round 4)
-    assert cfg.ipm_refine == 2 and cfg.refine_gamma == 1e6
+    assert cfg.ipm_refine == 2 and cfg.refine_gamma == 1e4
     assert cfg.auto_margin == 0.1 and cfg.qp_precision == 0 and cfg.work_queue == 0 and cfg.ts_nmpc == CP.ts_nmpc == 0.02
     # interior-point constants are the same on both sides
     from oracle import oracle as O
