@@ -817,68 +817,6 @@ def main():
         return res
 
     results, form_errors = {}, {}
-    # Which forms may fail without taking the line away: everything but the first.  A secondary form runs under a watchdog
-    # (--leg-timeout-s): a multi-rank capture of the collective, or the peer form's xGMI leg, has never run on hardware -- if such
-    # a leg does not come back, every rank's timer prints (rank 0) the line from the forms that DID finish and leaves.  With more
-    # than one rank the parity check of a form runs right behind its timed region (so that a finished form is a checked form
-    # when a later one hangs); with one rank all checks run behind all timed regions (the oracle's OpenMP phase in front of a
-    # 20-step timed region costs it 3-6 %).
-    import threading
-    check_now = world > 1
-    wd_lock = threading.Lock()
-    wd_state = {"done": False}
-
-    def watchdog(m):
-        with wd_lock:
-            if wd_state["done"]:
-                return
-            wd_state["done"] = True
-        form_errors[m] = f"did not finish within {args.leg_timeout_s:.0f} s (watchdog): the line carries the forms that did"
-        code = 1
-        try:
-            if rank == 0:
-                code = 1 if finish(partial=True) else 0
-            else:
-                code = 0
-        finally:
-            sys.stdout.flush()
-            os._exit(code)
-
-    def run_checked(m):
-        r = run_mode(m, check_parity=not args.only_timed)
-        if check_now and r.get("parity_fn") is not None:
-            r["parity"] = r.pop("parity_fn")()
-        return r
-
-    for k, m in enumerate(modes):
-        if k == 0:
-            results[m] = run_checked(m)
-            continue
-        timer = threading.Timer(args.leg_timeout_s, watchdog, args=(m,))
-        timer.daemon = True
-        timer.start()
-        try:
-            results[m] = run_checked(m)
-        except Exception as e:
-            form_errors[m] = f"{type(e).__name__}: {e}"[:300]
-            torch.cuda.set_stream(stream)
-        finally:
-            timer.cancel()
-        with wd_lock:
-            if wd_state["done"]:                   # the timer fired while this leg was being torn down: it prints and exits
-                time.sleep(3600)
-    for k, (m, r) in enumerate(list(results.items())):     # parity spot checks (CPU oracle, OpenMP): behind every form's timed region
-        fn = r.pop("parity_fn", None)
-        if fn is None:
-            continue
-        if k > 0:
-            try:
-                r["parity"] = fn()
-            except Exception as e:
-                form_errors[m] = f"{type(e).__name__}: {e}"[:300]
-                torch.cuda.set_stream(stream)
-        else:
-            r["parity"] = fn()
 
     def finish(partial=False):
         """Builds and prints the line (rank 0) from the forms that have finished.  partial: called by the watchdog of a secondary form that
@@ -1019,6 +957,11 @@ def main():
                              "mlp_kernel_us": mlp_s * 1e6 if mlp_n else None},
                 "parity_max_rel_vs_oracle": parity, "instances_not_converged": bad,
             }
+            if partial:
+                out["watchdog"] = {"fired": True, "legs": {m: e for m, e in form_errors.items()},
+                                   "note": "a secondary form did not come back within --leg-timeout-s: this line was built by the watchdog from the forms "
+                                           "that had finished; no extra legs, no CPU baseline"
+                                           + ("" if parity is not None else "; the headline's parity check had not run yet (one rank: the checks run behind all timed regions)")}
             if two_forms:
                 out["downwash_forms"] = {m: {"value": total / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3, "launch": r["launch"],
                                              "kernel_us_rti": r["rti_ms"] * 1e3 / max(r["rti_n"], 1),
@@ -1237,6 +1180,74 @@ def main():
         else:
             fail = False
         return fail
+
+    # Which forms may fail without taking the line away: everything but the first.  A secondary form runs under a watchdog
+    # (--leg-timeout-s): a multi-rank capture of the collective, or the peer form's xGMI leg, has never run on hardware -- if such
+    # a leg does not come back, every rank's timer prints (rank 0) the line from the forms that DID finish and leaves.  With more
+    # than one rank the parity check of a form runs right behind its timed region (so that a finished form is a checked form
+    # when a later one hangs); with one rank all checks run behind all timed regions (the oracle's OpenMP phase in front of a
+    # 20-step timed region costs it 3-6 %).
+    import threading
+    check_now = world > 1
+    wd_lock = threading.Lock()
+    wd_state = {"done": False}
+
+    def watchdog(m):
+        with wd_lock:
+            if wd_state["done"]:
+                return
+            wd_state["done"] = True
+        form_errors[m] = f"did not finish within {args.leg_timeout_s:.0f} s (watchdog): the line carries the forms that did"
+        code = 1
+        try:
+            if rank == 0:
+                code = 1 if finish(partial=True) else 0
+            else:
+                code = 0
+        except BaseException:
+            import traceback
+            traceback.print_exc()
+        finally:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(code)
+
+    def run_checked(m):
+        r = run_mode(m, check_parity=not args.only_timed)
+        if check_now and r.get("parity_fn") is not None:
+            r["parity"] = r.pop("parity_fn")()
+        return r
+
+    for k, m in enumerate(modes):
+        if k == 0:
+            results[m] = run_checked(m)
+            continue
+        timer = threading.Timer(args.leg_timeout_s, watchdog, args=(m,))
+        timer.daemon = True
+        timer.start()
+        try:
+            results[m] = run_checked(m)
+        except Exception as e:
+            form_errors[m] = f"{type(e).__name__}: {e}"[:300]
+            torch.cuda.set_stream(stream)
+        finally:
+            timer.cancel()
+        with wd_lock:
+            if wd_state["done"]:                   # the timer fired while this leg was being torn down: it prints and exits
+                time.sleep(3600)
+    for k, (m, r) in enumerate(list(results.items())):     # parity spot checks (CPU oracle, OpenMP): behind every form's timed region
+        fn = r.pop("parity_fn", None)
+        if fn is None:
+            continue
+        if k > 0:
+            try:
+                r["parity"] = fn()
+            except Exception as e:
+                form_errors[m] = f"{type(e).__name__}: {e}"[:300]
+                torch.cuda.set_stream(stream)
+        else:
+            r["parity"] = fn()
+
 
     fail = finish()
     if xchg is not None:
