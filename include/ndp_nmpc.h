@@ -62,9 +62,11 @@ typedef struct ndp_cfg {
     int32_t work_queue; /* instances whose QP needs the interior-point loop are re-distributed over all SIMDs through an
                          * work list (producer + consumer launch per step): 0 = automatic (qp_mode AUTO and batch >= 2 x the device's
                          * SIMD count, or the N = 40 / 2-iteration shape at any batch), 1 = on, 2 = off */
-    int32_t ipm_refine; /* interior point: up to this many refinement solves (with the factorisation at hand) per Newton system, applied
-                         * only while a STATE bound's barrier term lambda / t exceeds refine_gamma (default 2; 0 = never).  The
-                         * loop is in absolute form, so an iteration's answer is as accurate as its last solve -- cond ~ lambda / t.
+    int32_t ipm_refine; /* interior point: while a STATE bound's barrier term lambda / t exceeds refine_gamma, the 4x4 block is
+                         * factorised L D L' and applied by substitution (an explicit inverse costs the recursion its definiteness
+                         * there) and every Newton system's solution is refined this many times with the factorisation at hand
+                         * (default 2; 0 = never: round 3's loop).  The loop is in absolute form, so an iteration's answer is as
+                         * accurate as its last solve -- cond ~ lambda / t.
                          * The reference's velocity box (+-20 m/s, nmpc_body_rate_ctl.py:59-61) is never active in its envelope:
                          * this only acts on boxes shrunk on purpose.  Compile-time horizons (N = 20, N = 40 / 2 iterations) only. */
     double dt;          /* T_horizon / N_node        params/nmpc_params.py:10,12  */

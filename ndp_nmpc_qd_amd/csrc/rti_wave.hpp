@@ -30,8 +30,10 @@
 // host emulator build ignores it)
 #if defined(__clang__)
 #define NDP_UNROLL_STAGES _Pragma("unroll UNROLL_STAGES")
+#define NDP_UNROLL_SWEEP _Pragma("unroll UNROLL_SWEEP")
 #else
 #define NDP_UNROLL_STAGES
+#define NDP_UNROLL_SWEEP
 #endif
 #ifdef NDP_FINE_STAMPS
 #define NDP_FINE(x) x
@@ -801,7 +803,29 @@ struct RtiWave {
     // reported a failed factorisation where the oracle's Cholesky had none).  Here every lane factorises the 4x4 matrix itself,
     // Lam = L D L' without square roots, and forms the entry (g, j & 3) of L^-T D^-1 L^-1 it holds: ~100 dependent f64 operations
     // per stage, run only in the interior-point iterations in which a state bound's barrier term exceeds P.refine_gamma.
-    static NDP_D vd lam_inverse_ldl(const LdsMap &m, const Tables &T, lp lds, vd h3, vb &okv)
+    struct Ldl4 { vd l10, l20, l30, l21, l31, l32, r0, r1, r2, r3; };
+    // X = Lam^-1 B for a 4 x 16 right-hand side in register-3 form (lane (g, j) holds B[g][j]), by forward / back substitution with the
+    // factors -- a SOLVE, not a multiplication with the explicit inverse: with cond(Lam) ~ 1e8 the explicit inverse carries
+    // cond * eps in its small entries, and Hxx - Hxu (Lam^-1 Hux) formed with it loses the recursion's definiteness within a few stages
+    // (numpy, both forms side by side: the explicit inverse fails on exactly the problems the device failed on, the solve on none --
+    // whichever order the products are taken in).  Each lane gathers its column through a 64-double LDS scratch (the shadow ZD, idle
+    // during a backward sweep), solves it redundantly and keeps row g.
+    static NDP_D vd ldl_solve(const LdsMap &m, const Ldl4 &F, lp lds, vd rhs)
+    {
+        vi lane = W::lane_here();
+        vi g = lane >> 4, j = W::lcol(lane);
+        W::sync();
+        W::st(lds, g * 16 + j + m.ZD, rhs);
+        W::sync();
+        const vd b0 = W::ld(lds, j + m.ZD), b1 = W::ld(lds, j + (m.ZD + 16)), b2 = W::ld(lds, j + (m.ZD + 32)), b3 = W::ld(lds, j + (m.ZD + 48));
+        const vd y0 = b0, y1 = b1 - F.l10 * y0, y2 = b2 - F.l20 * y0 - F.l21 * y1, y3 = b3 - F.l30 * y0 - F.l31 * y1 - F.l32 * y2;
+        const vd x3 = y3 * F.r3;
+        const vd x2 = y2 * F.r2 - F.l32 * x3;
+        const vd x1 = y1 * F.r1 - F.l21 * x2 - F.l31 * x3;
+        const vd x0 = y0 * F.r0 - F.l10 * x1 - F.l20 * x2 - F.l30 * x3;
+        return W::sel(g == 0, x0, W::sel(g == 1, x1, W::sel(g == 2, x2, x3)));
+    }
+    static NDP_D vd lam_inverse_ldl(const LdsMap &m, const Tables &T, lp lds, vd h3, vb &okv, Ldl4 *Fout = nullptr)
     {
         W::st(lds, T.lam_w_off, h3);
         W::sync();
@@ -816,6 +840,8 @@ struct RtiWave {
         const vd l32 = (a32 - l30 * a20 - l31 * (l21 * d1)) * r2;
         const vd d3 = a33 - l30 * a30 - l31 * (l31 * d1) - l32 * (l32 * d2), r3 = W::rcp(d3);
         okv = okv && (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
+        if (Fout) { Fout->l10 = l10; Fout->l20 = l20; Fout->l30 = l30; Fout->l21 = l21; Fout->l31 = l31; Fout->l32 = l32;
+                    Fout->r0 = r0; Fout->r1 = r1; Fout->r2 = r2; Fout->r3 = r3; }
         // M = L^-1 (unit lower triangular)
         const vd m10 = -l10, m21 = -l21, m32 = -l32;
         const vd m20 = -l20 - l21 * m10, m31 = -l31 - l32 * m21;
@@ -853,6 +879,10 @@ struct RtiWave {
                                     const RtiIo *io = nullptr, md *linv = nullptr)
     {
         const int N = horizon(P);
+        // the stage loops of a ROBUST sweep stay loops (a cold path: unrolled, its ten factor registers per stage and two LDS-gathered
+        // solves pushed every N = 20 kernel -- the headline included -- over the register file: 372 B of scratch per lane)
+        constexpr int UNROLL_SWEEP = ROBUST ? 1 : UNROLL_STAGES;
+        (void)UNROLL_SWEEP;
         bool ok = true;
         vi lane = W::lane();
         vi g = lane >> 4, j = W::lcol(lane);
@@ -876,7 +906,7 @@ struct RtiWave {
         md4 Ktp = W::mzero4();
         md Ktq = W::to_m(vd(0.0));     // MMA4: K~' of the previous stage in ONE register
         int kprev = -1;
-        NDP_UNROLL_STAGES
+        NDP_UNROLL_SWEEP
         for (int k = N - 1; k >= 1; --k) {
             md nmk[3], ncc[4];
             const int kp = k >= 2 ? k - 2 : 0;      // prefetch stage k-2; at k = 1 there is none: re-read stage 0 (values unused)
@@ -893,29 +923,31 @@ struct RtiWave {
             // prefetch of stage k-2, between its levels.  Measured: worth ~1 % of the sweep -- what counts is the number of
             // instructions and of chain levels (dropping the second Newton step of 1/det saved 5 %), not their order.
             if constexpr (ROBUST) {
-                const vd inv = lam_inverse_ldl(m, T, lds, W::to_d(hux), okv);      // Lam^-1[g][j & 3] in every lane
+                Ldl4 F;
+                const vd inv = lam_inverse_ldl(m, T, lds, W::to_d(hux), okv, &F);  // Lam^-1[g][j & 3] in every lane (kept for the second solve)
                 md4 Wf = mman<3>(H.r, mk, W::mzero4());
                 if (kprev >= 0) {
                     if constexpr (MMA4) W::st(lds, T.kt_st4 + mb(kprev), W::to_d(Ktq));
                     else for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), W::to_d(Ktp.r[c]));
+                    kprev = -1;
                 }
                 md4 Hb;
                 for (int r = 0; r < 4; ++r) Hb.r[r] = cc[r];
                 Hb = mman<3>(mk, Wf.r, Hb);
-                const vd ladj = MMA4 ? inv : W::sel(T.lo4, inv, vd(0.0));
                 const vd nahi = MMA4 ? -inv : W::sel(T.kt_pred, -inv, vd(0.0));
                 md tt = Wf.r[3];
-                md G0;
-                if constexpr (MMA4) G0 = mma4(W::to_m(ladj), tt, W::to_m(vd(0.0)));
-                else G0 = mma(W::to_m(ladj), tt, W::mzero4()).r[0];
+                const md G0 = W::to_m(ldl_solve(m, F, lds, W::to_d(tt)));            // Lam^-1 T by substitution (see ldl_solve)
                 for (int c = 0; c < 3; ++c) nmk[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(kp)));
                 for (int r = 0; r < 4; ++r) ncc[r] = W::to_m(W::ld(lds, T.c_off[r] + cb(kp)));
                 md4 Hn = mma(-tt, G0, Hb);
                 const md nli = W::to_m(nahi);
                 if constexpr (KEEP) linv_put(linv, k, N, nli);
-                if constexpr (MMA4) Ktq = mma4(hux, nli, W::to_m(vd(0.0)));
-                else Ktp = mma(hux, nli, W::mzero4());
-                kprev = k;
+                {   // K~' = -(Lam^-1 H~ux)': lane (g, j) holds (Lam^-1 H~ux)[g][j] = -K~'[j][g], stored where K~' lives (row-major 12 x 4)
+                    const vd G1 = ldl_solve(m, F, lds, W::to_d(hux));
+                    vi ln = W::lane_here();
+                    vi gg = ln >> 4, jj = W::lcol(ln);
+                    W::st(lds, W::sel(jj < 12, jj * 4 + gg + m.KT, vi(m.MB + int(MB_DUMP))) + mb(k), -G1);
+                }
                 {   // re-symmetrised at EVERY stage here (the oracle does): with entries of 1e10 the antisymmetric rounding part, which
                     // the open-loop map doubles per stage, reaches the size of the O(1) eigenvalues within a few stages
                     md ey[4];
@@ -1024,8 +1056,13 @@ struct RtiWave {
             md hux = H.r[3];
             vd cof, rdet;
             if constexpr (ROBUST) {
-                cof = lam_inverse_ldl(m, T, lds, W::to_d(hux), okv);
+                Ldl4 F;
+                cof = lam_inverse_ldl(m, T, lds, W::to_d(hux), okv, &F);
                 rdet = vd(1.0);
+                const vd G1 = ldl_solve(m, F, lds, W::to_d(hux));
+                vi ln = W::lane_here();
+                vi gg = ln >> 4, jj = W::lcol(ln);
+                W::st(lds, W::sel(jj < 12, jj * 4 + gg + m.KT, vi(m.MB + int(MB_DUMP))), -G1);
             } else {
                 LamRegs LR;
                 lam_gather(T, lds, W::to_d(hux), LR);
@@ -1034,7 +1071,9 @@ struct RtiWave {
             }
             vd nahi = MMA4 ? -cof : W::sel(T.kt_pred, -cof, vd(0.0));
             if constexpr (KEEP) linv_put(linv, 0, N, W::to_m(nahi * rdet));
-            if constexpr (MMA4) {
+            if constexpr (ROBUST) {
+                // (the gain of stage 0 was stored above)
+            } else if constexpr (MMA4) {
                 W::st(lds, T.kt_st4, W::to_d(mma4(hux, W::to_m(nahi), W::to_m(vd(0.0)))) * rdet);
             } else {
                 md4 Kt = mma(hux, W::to_m(nahi), W::mzero4());
@@ -1058,7 +1097,7 @@ struct RtiWave {
         md fw[3], mu;
         for (int c = 0; c < 3; ++c) fw[c] = W::to_m(W::ld(lds, T.fw_off[c]));
         mu = W::to_m(W::ld(lds, T.mu_off));
-        NDP_UNROLL_STAGES
+        NDP_UNROLL_SWEEP
         for (int k = 0; k < N; ++k) {
             md nfw[3], nmu;
             const int kn = k + 1 < N ? k + 1 : k;

@@ -4,7 +4,7 @@ import ndp_nmpc_qd_amd as ndp
 from ndp_nmpc_qd_amd import synth
 from oracle import oracle as O
 from tests import ref_numpy as R
-for seed in (46, 50, 54, 57, 58, 64, 77):
+for seed in (46, 47, 50, 54, 57, 58, 64, 69, 77, 78):
     b = synth.make_batch(1, seed=seed, pos_sigma=1.5, vel_sigma=3.0, quat_sigma=0.2)
     x0, xr, ur = b["x0"][0], b["xr"][0], b["ur"][0]
     cfgo = O.default_cfg(); cfgo.qp_mode = 1

@@ -117,17 +117,15 @@ def test_active_bounds_and_infeasible_start(ndp, oracle):
 
 
 def test_active_state_bounds_at_a_tight_tolerance_on_the_device(ndp, oracle):
-    """VERDICT r3 #5 through the C-ABI: velocity box shrunk until state bounds are active.  While a state bound's barrier term exceeds
-    refine_gamma the kernel factorises with the LDL' 4x4 inverse (+ re-symmetrisation per stage) and refines every solve twice
-    (ndp_cfg.ipm_refine): the step sits within 1e-7 of the exact active-set answer of the same QP (or the termination bound of a weakly
-    decided one) and within 1e-7 of the oracle, same iteration counts -- at tol = 1e-10 on seeds 57 / 58 / 77, at the default tolerance
-    on seeds 57 / 46 / 50, where round 3's loop (ipm_refine = 0) reports a failed factorisation or sits 1e-5 .. 1e-6 off.
-    (tests/test_wave_program_emulated.py holds the CPU twin; scripts/refine_probe.py prints the whole table.  Problems whose
-    barrier terms pass ~1e10 can still end in status 4 on the device -- a failed factorisation, or a corrector solve whose last
-    refinement correction is still visible at 1e-5: reported, iterate untouched, never a silent answer -- where the oracle gets through.)"""
+    """VERDICT r3 #5 through the C-ABI: velocity box shrunk until state bounds are active (barrier terms 1e9 .. 1e13).  While a state
+    bound's barrier term exceeds refine_gamma the kernel factorises Lam = L D L' in every lane, applies Lam^-1 by substitution and
+    refines every solve twice (ndp_cfg.ipm_refine).  On all ten feasible problems of seeds 40..79, at the default tolerance and at
+    1e-10: status 0, the oracle's iteration count, the oracle's step to 1e-9, the exact active-set answer of the same QP within the
+    termination bound.  Round 3's loop (ipm_refine = 0) ends seven of them in status 4 and the rest 4e-6 .. 3e-5 off.
+    (CPU twin on the emulator: tests/test_wave_program_emulated.py; the whole table: scripts/refine_probe.py.)"""
     from tests import ref_numpy as R
     worse = 0
-    for seed, tol in ((57, 1e-10), (58, 1e-10), (77, 1e-10), (57, 1e-8), (46, 1e-8), (50, 1e-8)):
+    for seed in (46, 47, 50, 54, 57, 58, 64, 69, 77, 78):
         b = synth.make_batch(1, seed=seed, pos_sigma=1.5, vel_sigma=3.0, quat_sigma=0.2)
         x0, xr, ur = b["x0"][0], b["xr"][0], b["ur"][0]
         cfgo = oracle.default_cfg()
@@ -135,34 +133,35 @@ def test_active_state_bounds_at_a_tight_tolerance_on_the_device(ndp, oracle):
         qp = oracle.linearize(cfgo, x0, xr, ur, None, xr.copy(), ur.copy())
         dxf, _, _ = oracle.qp_solve(cfgo, qp)
         box = 0.8 * np.abs((xr + dxf)[4:20, 3:6]).max()
-        err = {}
-        for refine in (2, 0):
-            eng = ndp.BatchedNMPC(1, qp_mode=1, tol=tol, ipm_refine=refine, lbv=[-box] * 3, ubv=[box] * 3)
-            eng.reset(b["xr"], b["ur"])
-            u0, X, U, st, it = eng.update(b["x0"], b["xr"], b["ur"], raise_on_status=False, full=True)
-            eng.close()
-            cfgo = oracle.default_cfg()
-            cfgo.qp_mode, cfgo.tol, cfgo.refine = 1, tol, refine
-            for i in range(3):
-                cfgo.lbv[i], cfgo.ubv[i] = -box, box
-            qpb = oracle.linearize(cfgo, x0, xr, ur, None, xr.copy(), ur.copy())
-            dxa, dua, active = R.pdas_solve(qpb)
-            assert sum(1 for v in active if v < 21 * 10) >= 1                     # a state bound IS active at the solution
-            if st[0] != 0:
-                assert refine == 0 and st[0] == 4, (seed, tol, refine, st[0])
-                assert np.array_equal(X[0], xr) and np.array_equal(U[0], ur)      # reported, iterate untouched
-                err[refine] = np.inf
-                continue
-            err[refine] = max(np.abs(X[0] - xr - dxa).max(), np.abs(U[0] - ur - dua).max())
-            if refine:
-                Xo, Uo = xr.copy(), ur.copy()
-                u0o, sto = oracle.step(cfgo, x0, xr, ur, None, Xo, Uo)
-                assert sto.status == 0 and it[0] == sto.ipm_iters, (seed, tol, it[0], sto.ipm_iters)
-                assert max(np.abs(X[0] - Xo).max(), np.abs(U[0] - Uo).max()) <= 1e-7, (seed, tol)
-                sep = min(1.0, R.separation(qpb, dxa, dua, active))
-                assert err[2] <= max(1e-7, 4e-6 * (tol / 1e-8) / sep), (seed, tol, err[2], sep)
-        worse += err[0] > 100 * max(err[2], 1e-11)
-    assert worse >= 4, worse
+        for tol in (1e-8, 1e-10):
+            err = {}
+            for refine in (2, 0):
+                eng = ndp.BatchedNMPC(1, qp_mode=1, tol=tol, ipm_refine=refine, lbv=[-box] * 3, ubv=[box] * 3)
+                eng.reset(b["xr"], b["ur"])
+                u0, X, U, st, it = eng.update(b["x0"], b["xr"], b["ur"], raise_on_status=False, full=True)
+                eng.close()
+                cfgo = oracle.default_cfg()
+                cfgo.qp_mode, cfgo.tol, cfgo.refine = 1, tol, refine
+                for i in range(3):
+                    cfgo.lbv[i], cfgo.ubv[i] = -box, box
+                qpb = oracle.linearize(cfgo, x0, xr, ur, None, xr.copy(), ur.copy())
+                dxa, dua, active = R.pdas_solve(qpb)
+                assert sum(1 for v in active if v < 21 * 10) >= 1                     # a state bound IS active at the solution
+                if st[0] != 0:
+                    assert refine == 0 and st[0] == 4, (seed, tol, refine, st[0])
+                    assert np.array_equal(X[0], xr) and np.array_equal(U[0], ur)      # reported, iterate untouched
+                    err[refine] = np.inf
+                    continue
+                err[refine] = max(np.abs(X[0] - xr - dxa).max(), np.abs(U[0] - ur - dua).max())
+                if refine:
+                    Xo, Uo = xr.copy(), ur.copy()
+                    u0o, sto = oracle.step(cfgo, x0, xr, ur, None, Xo, Uo)
+                    assert sto.status == 0 and it[0] == sto.ipm_iters, (seed, tol, it[0], sto.ipm_iters)
+                    assert max(np.abs(X[0] - Xo).max(), np.abs(U[0] - Uo).max()) <= 1e-9, (seed, tol)
+                    sep = min(1.0, R.separation(qpb, dxa, dua, active))
+                    assert err[2] <= max(1e-7, 40 * 4e-6 * (tol / 1e-8) / sep), (seed, tol, err[2], sep)
+            worse += err[0] > 100 * max(err[2], 1e-11)
+    assert worse >= 14, worse
 
 
 def test_ndp_update_with_force(ndp, oracle):
