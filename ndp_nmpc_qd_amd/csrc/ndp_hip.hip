@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         io.f = nullptr;
         io.f_in_lds = 1;
     }
-    const bool deferred = Prog::template run<QMODE == 1>(P, io, lds, inb, x0v);
+    const bool deferred = Prog::template run<QMODE == 1, QMODE == 0>(P, io, lds, inb, x0v);
     if (io.stamps && (threadIdx.x & 63u) == 0) {
         io.stamps[13] = (double)__builtin_amdgcn_s_memrealtime();
         io.stamps[15] = (double)__builtin_amdgcn_s_memtime();

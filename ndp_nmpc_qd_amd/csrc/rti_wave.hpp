@@ -22,6 +22,10 @@
 //    (same algorithm as oracle/ndp_oracle.c), with an exact early exit when the equality-constrained
 //    minimiser is strictly inside the box.
 #pragma once
+// A branch the wave almost never takes.  More than a layout hint: the register allocator weighs every use by its block's estimated
+// frequency, and a LOOP in a cold branch (x32 per nesting level by default) outweighs the straight-line hot path in front of it --
+// the hot sweep then pays accumulation-register reads for values the cold loops were given registers for.
+#define NDP_RARELY(x) (__builtin_expect_with_probability(!!(x), 0, 0.9999))
 
 #ifndef NDP_D        // wave-program functions: __device__ in the gfx950 build, plain inline under the emulator
 #define NDP_D inline
@@ -803,29 +807,34 @@ struct RtiWave {
     // reported a failed factorisation where the oracle's Cholesky had none).  Here every lane factorises the 4x4 matrix itself,
     // Lam = L D L' without square roots, and forms the entry (g, j & 3) of L^-T D^-1 L^-1 it holds: ~100 dependent f64 operations
     // per stage, run only in the interior-point iterations in which a state bound's barrier term exceeds P.refine_gamma.
-    struct Ldl4 { vd l10, l20, l30, l21, l31, l32, r0, r1, r2, r3; };
+    // The factors are the same in every lane (each lane factorises the whole 4x4 block): they are parked in the block's own LDS image
+    // (strict lower triangle: L, diagonal: 1 / D) and read back where a substitution uses them -- twenty registers that would otherwise
+    // be live across a whole stage of a ROBUST sweep, and through the allocator's live-range splitting cost the (unrelated) hot sweep
+    // sixteen more accumulation-register reads (1.2 % of the headline step, measured A/B).
     // X = Lam^-1 B for a 4 x 16 right-hand side in register-3 form (lane (g, j) holds B[g][j]), by forward / back substitution with the
     // factors -- a SOLVE, not a multiplication with the explicit inverse: with cond(Lam) ~ 1e8 the explicit inverse carries
     // cond * eps in its small entries, and Hxx - Hxu (Lam^-1 Hux) formed with it loses the recursion's definiteness within a few stages
     // (numpy, both forms side by side: the explicit inverse fails on exactly the problems the device failed on, the solve on none --
     // whichever order the products are taken in).  Each lane gathers its column through a 64-double LDS scratch (the shadow ZD, idle
     // during a backward sweep), solves it redundantly and keeps row g.
-    static NDP_D vd ldl_solve(const LdsMap &m, const Ldl4 &F, lp lds, vd rhs)
+    static NDP_D vd ldl_solve(const LdsMap &m, lp lds, vd rhs)
     {
         vi lane = W::lane_here();
         vi g = lane >> 4, j = W::lcol(lane);
+        auto F = [&](int r, int c) { return W::ld(lds, lane * 0 + (m.SC + 4 * r + c)); };
         W::sync();
         W::st(lds, g * 16 + j + m.ZD, rhs);
         W::sync();
         const vd b0 = W::ld(lds, j + m.ZD), b1 = W::ld(lds, j + (m.ZD + 16)), b2 = W::ld(lds, j + (m.ZD + 32)), b3 = W::ld(lds, j + (m.ZD + 48));
-        const vd y0 = b0, y1 = b1 - F.l10 * y0, y2 = b2 - F.l20 * y0 - F.l21 * y1, y3 = b3 - F.l30 * y0 - F.l31 * y1 - F.l32 * y2;
-        const vd x3 = y3 * F.r3;
-        const vd x2 = y2 * F.r2 - F.l32 * x3;
-        const vd x1 = y1 * F.r1 - F.l21 * x2 - F.l31 * x3;
-        const vd x0 = y0 * F.r0 - F.l10 * x1 - F.l20 * x2 - F.l30 * x3;
+        const vd l10 = F(1, 0), l20 = F(2, 0), l21 = F(2, 1), l30 = F(3, 0), l31 = F(3, 1), l32 = F(3, 2);
+        const vd y0 = b0, y1 = b1 - l10 * y0, y2 = b2 - l20 * y0 - l21 * y1, y3 = b3 - l30 * y0 - l31 * y1 - l32 * y2;
+        const vd x3 = y3 * F(3, 3);
+        const vd x2 = y2 * F(2, 2) - l32 * x3;
+        const vd x1 = y1 * F(1, 1) - l21 * x2 - l31 * x3;
+        const vd x0 = y0 * F(0, 0) - l10 * x1 - l20 * x2 - l30 * x3;
         return W::sel(g == 0, x0, W::sel(g == 1, x1, W::sel(g == 2, x2, x3)));
     }
-    static NDP_D vd lam_inverse_ldl(const LdsMap &m, const Tables &T, lp lds, vd h3, vb &okv, Ldl4 *Fout = nullptr)
+    static NDP_D vd lam_inverse_ldl(const LdsMap &m, const Tables &T, lp lds, vd h3, vb &okv, bool park = false)
     {
         W::st(lds, T.lam_w_off, h3);
         W::sync();
@@ -840,8 +849,13 @@ struct RtiWave {
         const vd l32 = (a32 - l30 * a20 - l31 * (l21 * d1)) * r2;
         const vd d3 = a33 - l30 * a30 - l31 * (l31 * d1) - l32 * (l32 * d2), r3 = W::rcp(d3);
         okv = okv && (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
-        if (Fout) { Fout->l10 = l10; Fout->l20 = l20; Fout->l30 = l30; Fout->l21 = l21; Fout->l31 = l31; Fout->l32 = l32;
-                    Fout->r0 = r0; Fout->r1 = r1; Fout->r2 = r2; Fout->r3 = r3; }
+        if (park) {     // every lane writes the same ten values
+            auto put = [&](int r, int c, vd v) { W::st(lds, W::lane() * 0 + (m.SC + 4 * r + c), v); };
+            W::sync();
+            put(0, 0, r0); put(1, 1, r1); put(2, 2, r2); put(3, 3, r3);
+            put(1, 0, l10); put(2, 0, l20); put(2, 1, l21); put(3, 0, l30); put(3, 1, l31); put(3, 2, l32);
+            W::sync();
+        }
         // M = L^-1 (unit lower triangular)
         const vd m10 = -l10, m21 = -l21, m32 = -l32;
         const vd m20 = -l20 - l21 * m10, m31 = -l31 - l32 * m21;
@@ -923,31 +937,25 @@ struct RtiWave {
             // prefetch of stage k-2, between its levels.  Measured: worth ~1 % of the sweep -- what counts is the number of
             // instructions and of chain levels (dropping the second Newton step of 1/det saved 5 %), not their order.
             if constexpr (ROBUST) {
-                Ldl4 F;
-                const vd inv = lam_inverse_ldl(m, T, lds, W::to_d(hux), okv, &F);  // Lam^-1[g][j & 3] in every lane (kept for the second solve)
-                md4 Wf = mman<3>(H.r, mk, W::mzero4());
-                if (kprev >= 0) {
-                    if constexpr (MMA4) W::st(lds, T.kt_st4 + mb(kprev), W::to_d(Ktq));
-                    else for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), W::to_d(Ktp.r[c]));
-                    kprev = -1;
-                }
-                md4 Hb;
-                for (int r = 0; r < 4; ++r) Hb.r[r] = cc[r];
-                Hb = mman<3>(mk, Wf.r, Hb);
-                const vd nahi = MMA4 ? -inv : W::sel(T.kt_pred, -inv, vd(0.0));
-                md tt = Wf.r[3];
-                const md G0 = W::to_m(ldl_solve(m, F, lds, W::to_d(tt)));            // Lam^-1 T by substitution (see ldl_solve)
-                for (int c = 0; c < 3; ++c) nmk[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(kp)));
-                for (int r = 0; r < 4; ++r) ncc[r] = W::to_m(W::ld(lds, T.c_off[r] + cb(kp)));
-                md4 Hn = mma(-tt, G0, Hb);
-                const md nli = W::to_m(nahi);
-                if constexpr (KEEP) linv_put(linv, k, N, nli);
+                // a cold path, written for few live registers (no operand prefetch, nothing carried between stages but H~): what is
+                // live here at its widest is what the allocator parks for the whole kernel, the hot sweep included
+                const vd inv = lam_inverse_ldl(m, T, lds, W::to_d(hux), okv, true);  // Lam^-1[g][j & 3] in every lane; the factors parked in LDS
+                if constexpr (KEEP) linv_put(linv, k, N, W::to_m(MMA4 ? -inv : W::sel(T.kt_pred, -inv, vd(0.0))));
                 {   // K~' = -(Lam^-1 H~ux)': lane (g, j) holds (Lam^-1 H~ux)[g][j] = -K~'[j][g], stored where K~' lives (row-major 12 x 4)
-                    const vd G1 = ldl_solve(m, F, lds, W::to_d(hux));
+                    const vd G1 = ldl_solve(m, lds, W::to_d(hux));
                     vi ln = W::lane_here();
                     vi gg = ln >> 4, jj = W::lcol(ln);
                     W::st(lds, W::sel(jj < 12, jj * 4 + gg + m.KT, vi(m.MB + int(MB_DUMP))) + mb(k), -G1);
                 }
+                md rmk[3];
+                for (int c = 0; c < 3; ++c) rmk[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(k - 1)));
+                md4 Wf = mman<3>(H.r, rmk, W::mzero4());
+                md4 Hb;
+                for (int r = 0; r < 4; ++r) Hb.r[r] = W::to_m(W::ld(lds, T.c_off[r] + cb(k - 1)));
+                Hb = mman<3>(rmk, Wf.r, Hb);
+                md tt = Wf.r[3];
+                const md G0 = W::to_m(ldl_solve(m, lds, W::to_d(tt)));            // Lam^-1 T by substitution (see ldl_solve)
+                md4 Hn = mma(-tt, G0, Hb);
                 {   // re-symmetrised at EVERY stage here (the oracle does): with entries of 1e10 the antisymmetric rounding part, which
                     // the open-loop map doubles per stage, reaches the size of the O(1) eigenvalues within a few stages
                     md ey[4];
@@ -958,8 +966,6 @@ struct RtiWave {
                     for (int r = 0; r < 4; ++r) Hn.r[r] = W::mavg(Hn.r[r], Tp.r[r]);
                 }
                 H = Hn;
-                for (int c = 0; c < 3; ++c) mk[c] = nmk[c];
-                for (int r = 0; r < 4; ++r) cc[r] = ncc[r];
                 continue;
             }
             LamRegs LR;
@@ -1056,10 +1062,9 @@ struct RtiWave {
             md hux = H.r[3];
             vd cof, rdet;
             if constexpr (ROBUST) {
-                Ldl4 F;
-                cof = lam_inverse_ldl(m, T, lds, W::to_d(hux), okv, &F);
+                cof = lam_inverse_ldl(m, T, lds, W::to_d(hux), okv, true);
                 rdet = vd(1.0);
-                const vd G1 = ldl_solve(m, F, lds, W::to_d(hux));
+                const vd G1 = ldl_solve(m, lds, W::to_d(hux));
                 vi ln = W::lane_here();
                 vi gg = ln >> 4, jj = W::lcol(ln);
                 W::st(lds, W::sel(jj < 12, jj * 4 + gg + m.KT, vi(m.MB + int(MB_DUMP))), -G1);
@@ -1497,10 +1502,10 @@ struct RtiWave {
                     build_delta_tabs(m, DT);
                     delta_sweep(P, m, T, DT, lds, linv);
                 }
-                else if (STIFF && P.refine > 0 && gmaxv > P.refine_gamma) ok = riccati_sweep<DELTA, STIFF>(P, m, T, lds, nullptr, linv) && ok;
+                else if (STIFF && NDP_RARELY(P.refine > 0 && gmaxv > P.refine_gamma)) ok = riccati_sweep<DELTA, STIFF>(P, m, T, lds, nullptr, linv) && ok;
                 else ok = riccati_sweep<DELTA>(P, m, T, lds, nullptr, linv) && ok;
                 if constexpr (REFINE) {
-                    if (ok && P.refine > 0 && gmaxv > P.refine_gamma) {
+                    if (NDP_RARELY(ok && P.refine > 0 && gmaxv > P.refine_gamma)) {
                         if (pass) {
                             // the corrector's second solve left only the CHANGE of the bounded rows' gradient in the cost blocks:
                             // put the corrector's full gradient there, as the refinement needs the gradient of the whole quadratic
@@ -1639,7 +1644,9 @@ struct RtiWave {
     // DEFER (producer launch of the work list): when the first QP that needs the interior-point loop shows up, return true at
     // once -- nothing of this instance has been written to global memory then, and the consumer launch redoes the step from
     // the same inputs with DEFER = false.  The interior-point code is not instantiated at all.
-    template <bool DEFER>
+    // IPM_RARE (the in-place kernels): the interior-point loop is the exception -- see NDP_RARELY.  (The work list's consumer runs
+    // nothing else.)
+    template <bool DEFER, bool IPM_RARE = false>
     static NDP_D bool run(const RtiParams &P, const RtiIo &io, lp lds, InBuf &inb, vd x0v)
     {
         const int N = horizon(P);
@@ -1741,7 +1748,7 @@ struct RtiWave {
                 done = (P.qp_mode == QP_AUTO && strictly_inside(S, lds, P.auto_margin)) || !ok;   // then the step is the sweep's solution, read where it lies (ZX|ZU)
             }
             const int zsrc = done ? m.ZX : m.CX;       // ZX|ZU and CX|CU are laid out alike
-            if (!done) {
+            if (IPM_RARE ? NDP_RARELY(!done) : !done) {
                 if (DEFER) return true;
                 Slots S;
                 build_slots(P, m, S);

@@ -15,4 +15,4 @@ import json,glob
 for f in sorted(glob.glob("gpurun_out/r04h/*.json")):
     d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split('/')[-1], round((d["value"] or d.get("value_unchecked") or 0)/1e6,2), round(d["ms_per_step"]*1e3,2))
 PY
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -2
+
