@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     // fp32 / bf16-input matrix instructions (BASELINE config 5)
     using WB = std::conditional_t<PREC == 3, WaveGfx950F32, std::conditional_t<PREC == 4, WaveGfx950BF16, WaveGfx950>>;
     using Prog = RtiWave<WB, NSLOT, NC, true, NRC, (PREC >= 3 ? 0 : PREC)>;   // compile-time horizon and iteration count (NC = 0: both at run time)
-    if (io.stamps && (threadIdx.x & 63u) == 0) {    // profiling hook: real time (100 MHz) and shader clock at entry -> the clock the launch ran at
+    if (NDP_RARELY(io.stamps && (threadIdx.x & 63u) == 0)) {    // profiling hook: real time (100 MHz) and shader clock at entry -> the clock the launch ran at
         io.stamps[12] = (double)__builtin_amdgcn_s_memrealtime();
         io.stamps[14] = (double)__builtin_amdgcn_s_memtime();
     }
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
             ev[t] = *(const d2_t *)(io.xr + (size_t)rc * NX + 2 * c3);
         }
         const LdsMap m = make_map(N);
-        if (io.dbg && lane == 0) io.dbg[m.total + 9] = (double)__builtin_amdgcn_s_memtime();
-        if (io.stamps && lane == 0) io.stamps[9] = (double)__builtin_amdgcn_s_memtime();
+        if (NDP_RARELY(io.dbg && lane == 0)) io.dbg[m.total + 9] = (double)__builtin_amdgcn_s_memtime();
+        if (NDP_RARELY(io.stamps && lane == 0)) io.stamps[9] = (double)__builtin_amdgcn_s_memtime();
         // the whole workgroup's LDS is still unused: park the weight fragments there for the MLP phase
         lds_f32 wl = (lds_f32)smem;
         stage_fragments(ma.frag, wl, (int)threadIdx.x, 64 * WAVES);
@@ -341,15 +341,15 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
                 zb[s] = h ? vy : vx;
             }
         }
-        if (io.stamps && lane == 0) io.stamps[11] = (double)__builtin_amdgcn_s_memtime();
+        if (NDP_RARELY(io.stamps && lane == 0)) io.stamps[11] = (double)__builtin_amdgcn_s_memtime();
         // gate closed (or no neighbour): the force is zero and the reference does not evaluate the network either
         // (ndp_nmpc_leader_node.py:66-76).  The test is the same in every lane: a wave-uniform branch around the tile.
         o[0] = o[1] = o[2] = 0.0f;
         if (__builtin_amdgcn_readfirstlane((int)open)) mlp_tile(wl, zb, lane, o);
         __syncthreads();                              // every wave is done with the weights before LDS becomes RTI state
         if (!active) return;
-        if (io.dbg && lane == 0) io.dbg[m.total + 10] = (double)__builtin_amdgcn_s_memtime();
-        if (io.stamps && lane == 0) io.stamps[10] = (double)__builtin_amdgcn_s_memtime();
+        if (NDP_RARELY(io.dbg && lane == 0)) io.dbg[m.total + 10] = (double)__builtin_amdgcn_s_memtime();
+        if (NDP_RARELY(io.stamps && lane == 0)) io.stamps[10] = (double)__builtin_amdgcn_s_memtime();
         if (j < np1 && h == 0) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         io.f_in_lds = 1;
     }
     const bool deferred = Prog::template run<QMODE == 1, QMODE == 0>(P, io, lds, inb, x0v);
-    if (io.stamps && (threadIdx.x & 63u) == 0) {
+    if (NDP_RARELY(io.stamps && (threadIdx.x & 63u) == 0)) {
         io.stamps[13] = (double)__builtin_amdgcn_s_memrealtime();
         io.stamps[15] = (double)__builtin_amdgcn_s_memtime();
     }

@@ -1611,11 +1611,11 @@ struct RtiWave {
     // debug-path phase stamps (shader clock) written behind the LDS image dump; no-op when io.dbg is null
     static NDP_D void stamp(const RtiIo &io, const LdsMap &m, int idx)
     {
-        if (io.dbg) {
+        if (NDP_RARELY(io.dbg)) {
             vd t = W::clock();
             W::gst(io.dbg, W::lane() * 0 + (m.total + idx), t, W::lane() == 0);
         }
-        if (io.stamps) {
+        if (NDP_RARELY(io.stamps)) {
             vd t = W::clock();
             W::gst(io.stamps, W::lane() * 0 + idx, t, W::lane() == 0);
         }
@@ -1726,7 +1726,7 @@ struct RtiWave {
             // solve_for_x0: dx_0 = x0 - x_0  (nmpc_body_rate_ctl.py:107)
             W::stp(lds, lane + m.ZX, x0v - W::ldp(lds, lane + m.XI, lane < NX), lane < NX);
             W::sync();
-            if (io.dbg && it == 0) {   // test hook: dump the linearisation + cost blocks
+            if (NDP_RARELY(io.dbg && it == 0)) {   // test hook: dump the linearisation + cost blocks
                 for (int t = 0; t < m.total; t += 64) {
                     vi i = lane + t;
                     W::gst(io.dbg, i, W::ldp(lds, i, i < m.total), i < m.total);
@@ -1772,7 +1772,7 @@ struct RtiWave {
                 }
                 vb bad = lane < 0;
                 for (int t = 0; t < RZ; ++t) bad = bad || !(xc[t] == xc[t]);
-                if (!failed && W::any(bad)) {
+                if (NDP_RARELY(!failed && W::any(bad))) {
                     failed = true;
                     if (!status) status = 1;
                 }
