@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, datasheet; v_mfma_f64_16x16x4 = 2048 FLOP / 64 clk / SIMD
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+PEER_FORMS = ("peer", "peer_ahead")   # the publish / subscribe forms of the per-tick neighbour exchange (see mode_names)
 PROFILE_TAGS = ("r04", "r03", "r02")  # newest first: profiles/<tag>_kernel_stats_fused_b1024.csv + <tag>_pmc_rti_kernel.json = the DEFAULT configuration's profile
 PROFILE_TOLERANCE = 0.25       # a committed profile whose kernel duration is further than this from the live HIP-event duration is refused
 
@@ -368,12 +369,13 @@ def main():
                     help="watchdog of every secondary form (captured rccl form, peer form, downwash-ahead form): a leg that has not finished "
                          "after this long is reported as timed out, the line is printed with the forms that did finish, and the ranks exit")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: bounded sample, about this many seconds")
-    ap.add_argument("--exchange", default="both", choices=["both", "peer", "rccl"],
+    ap.add_argument("--exchange", default="both", choices=["both", "peer", "rccl", "peer_ahead"],
                     help="N > 1 (and --config 4), vehicle-major placement: how a rank gets its neighbours' reference windows, every "
                          "step.  rccl: one all-gather of the position/velocity columns per step (the north star's collective); peer: "
                          "one publish launch per step into a peer-mapped slot + epoch word, the control-step kernel reads the "
                          "neighbour's slot over xGMI; both (default): the timed steps are run once in each form, `value` is the rccl "
-                         "form's, `exchange` carries both")
+                         "form's, `exchange` carries both; peer_ahead (opt-in, measured slower on one GPU: five launches per tick on the second stream, "
+                         "49 against 27 us): the publish and the gate / MLP launch of tick t+1 on a second stream beside the control step of tick t")
     ap.add_argument("--downwash-form", default="both", choices=["both", "prefetch", "fused"],
                     help="one GPU, config 3, downwash on: how the MLP runs.  fused: gate + MLP inside the control-step launch (the "
                          "product default); prefetch: the force of tick t+1 is predicted by a second launch on a second stream WHILE "
@@ -481,23 +483,26 @@ def main():
         # ALSO run here in exactly the N > 1 form -- a one-rank communicator, the pack + ncclAllGather on the library's stream per
         # step, host-launched and captured -- and reported as `scaling_baseline`: efficiency = value(N) / (N * scaling_baseline).
         if not args.only_timed and not same_dev:
-            baseline_modes = (list(rccl_modes) if args.exchange in ("both", "rccl") else []) + (["peer"] if args.exchange in ("both", "peer") else [])
+            baseline_modes = ((list(rccl_modes) if args.exchange in ("both", "rccl") else []) + (["peer"] if args.exchange in ("both", "peer") else [])
+                              + (["peer_ahead"] if args.exchange == "peer_ahead" else []))
             modes = modes + baseline_modes
     elif not need_exchange:
         modes = ["none"]
     elif same_dev and world > 1:
-        modes = ["peer"]                          # RCCL refuses two ranks on one device
+        modes = ["peer_ahead"] if args.exchange == "peer_ahead" else ["peer"]      # RCCL refuses two ranks on one device
     else:
-        modes = {"both": rccl_modes + ["peer"], "rccl": list(rccl_modes), "peer": ["peer"]}[args.exchange]
+        modes = {"both": rccl_modes + ["peer"], "rccl": list(rccl_modes), "peer": ["peer"], "peer_ahead": ["peer_ahead"]}[args.exchange]
+    if not (N + 1 <= 32 and args.qp_mode == 0 and not eng.work_queue):
+        modes = [m for m in modes if m != "peer_ahead"]       # (the downwash-ahead launch holds one instance's rows in one 32-row tile)
     peer, peer_err = None, None
-    if "peer" in modes:
+    if any(m in PEER_FORMS for m in modes):
         try:
             peer = ndist.PeerWindows(B, N, local_rank, timeout_us=args.peer_timeout_us)
             if cfg4:
                 peer_oidx = torch.from_numpy(ndist.config4_other_index(rank, world, args.formations, "vehicle", peer_rows=True, order=args.instance_order)).to(dev)
         except Exception as e:                    # same outcome on every rank (PeerWindows exchanges the result)
             peer_err = f"{type(e).__name__}: {e}"[:200]
-            modes = [m for m in modes if m != "peer"]
+            modes = [m for m in modes if m not in PEER_FORMS]
             if not modes:
                 raise
     xchg, xchg_err = None, None
@@ -528,7 +533,9 @@ def main():
                   "prefetch": "none (one GPU); downwash of tick t+1 on a second stream beside the control step of tick t",
                   "fused": "none (one GPU); gate + MLP fused into the control-step launch",
                   "none": "none", "rccl": rccl_form,
-                  "peer": "peer windows over xGMI: one publish (copy launch + one-wave epoch launch) per step, read by the control-step kernel"}
+                  "peer": "peer windows over xGMI: one publish (copy launch + one-wave epoch launch) per step, read by the control-step kernel",
+                  "peer_ahead": "peer windows over xGMI, one tick ahead: publish + gate / MLP launch of tick t+1 (which reads the neighbour's slot over "
+                                "xGMI) on a second stream beside the control step of tick t, which takes the force late -- no xGMI wait on the control steps' chain"}
 
     def host_other(h):
         """The neighbour windows of the host copy of tick 0 (oracle legs)."""
@@ -571,6 +578,20 @@ def main():
             predicts its own force before it starts, every tick but the last predicts the next one's beside its control step)."""
             d = ticks[i % T]
             other, oidx = None, None
+            if mode == "peer_ahead":
+                # stream_b carries, per tick: publish (this rank's windows into its slot, epoch, wait for the neighbour's) and the gate / MLP
+                # launch that reads the neighbour's slot; the protocol's "reader is done with the slot" is stream_b's own order
+                oi = peer_oidx if cfg4 else None
+                if first:
+                    eng.downwash_prefetch_device(peer.publish_device(d["xr"], stream_b), d["xr"], ego_xy=d["ego_xy"], other_index=oi,
+                                                 after_stream=stream, on_stream=stream_b)
+                if not last:
+                    n = ticks[(i + 1) % T]
+                    eng.downwash_prefetch_device(peer.publish_device(n["xr"], stream_b), n["xr"], ego_xy=n["ego_xy"], other_index=oi, on_stream=stream_b)
+                eng.update_device_prefetched(d["x0"], d["xr"], d["ur"], u0, stream=stream)
+                if last:
+                    stream.wait_stream(stream_b)
+                return
             if mode == "prefetch":
                 if first:
                     eng.downwash_prefetch_device(d["other"], d["xr"], ego_xy=d["ego_xy"], after_stream=stream)
@@ -685,7 +706,7 @@ def main():
                 base = ((args.warmup + T - 1) // T) * T          # a multiple of T: the replayed cycle starts at tick 0
                 G = args.steps if args.steps <= 1024 else 1024 // T * T
                 plan = [(G, args.steps // G)] + ([(args.steps % G, 1)] if args.steps % G else [])
-                if mode == "peer":                              # even graphs only
+                if mode in PEER_FORMS:                          # even graphs only
                     plan = [(n - (n & 1), r) for n, r in plan if n - (n & 1) > 0]
                     tail = args.steps - sum(n * r for n, r in plan)
                 fence()
@@ -694,7 +715,7 @@ def main():
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=stream, capture_error_mode="relaxed"):
                         for i in range(n_cap):
-                            if mode == "prefetch":                # the control steps only; the downwash launches: graph gb below
+                            if mode in ("prefetch", "peer_ahead"):  # the control steps only; the downwash launches: graph gb below
                                 d = ticks[(first + i) % T]
                                 eng.update_device_prefetched(d["x0"], d["xr"], d["ur"], u0, stream=stream)
                             else:
@@ -707,7 +728,7 @@ def main():
                         pending.clear()
                     torch.cuda.set_stream(stream)
                     gb = None
-                    if mode == "prefetch":
+                    if mode in ("prefetch", "peer_ahead"):
                         # The downwash launches of the same ticks as a SECOND graph on a second stream (another priority level =
                         # its own hardware queue): the two chains order themselves through the device-side tick words, so the two
                         # graphs are replayed side by side.  (Parallel branches inside ONE hipGraph execute one after the other on
@@ -716,7 +737,11 @@ def main():
                         with torch.cuda.graph(gb, stream=stream_b, capture_error_mode="relaxed"):
                             for i in range(n_cap):
                                 d = ticks[(first + i) % T]
-                                eng.downwash_prefetch_device(d["other"], d["xr"], ego_xy=d["ego_xy"], on_stream=stream_b)
+                                if mode == "peer_ahead":          # (+ the tick's publish in front: copy, epoch, wait for the neighbour's)
+                                    eng.downwash_prefetch_device(peer.publish_device(d["xr"], stream_b), d["xr"], ego_xy=d["ego_xy"],
+                                                                 other_index=peer_oidx if cfg4 else None, on_stream=stream_b)
+                                else:
+                                    eng.downwash_prefetch_device(d["other"], d["xr"], ego_xy=d["ego_xy"], on_stream=stream_b)
                         torch.cuda.set_stream(stream)
                         with torch.cuda.stream(stream_b):
                             gb.replay()
@@ -725,8 +750,9 @@ def main():
                     graphs.append((g, n_rep, gb))
                     first += n_cap * n_rep
                 launch_mode = " + ".join(f"hipGraph of {n} steps x {r}" for n, r in plan) + (f" + {tail} host-launched" if tail else "")
-                if mode == "prefetch":
-                    launch_mode += " (control steps) beside a hipGraph of the same ticks' downwash launches on a second stream"
+                if mode in ("prefetch", "peer_ahead"):
+                    launch_mode += (" (control steps) beside a hipGraph of the same ticks' " + ("publish + " if mode == "peer_ahead" else "")
+                                    + "downwash launches on a second stream")
             except Exception as e:                                # capture unsupported: fall back, say so
                 graphs, tail, launch_mode = [], 0, f"host launch per step (graph capture failed: {type(e).__name__}: {e})"[:300]
                 pending.clear()
@@ -753,7 +779,7 @@ def main():
                     replay(graphs[0])
                     extra += plan[0][0]
                 fence()
-            if mode == "peer":
+            if mode in PEER_FORMS:
                 peer.tick = peer.stats()["ticks"]                 # host mirror of the device-side tick count (capture ran no kernel)
         else:
             extra = 0
@@ -780,7 +806,7 @@ def main():
                 step(args.warmup + i, first=i == 0, last=i == args.steps - 1)
         fence()
         elapsed = time.perf_counter() - t0
-        if mode == "peer":
+        if mode in PEER_FORMS:
             peer.tick = peer.stats()["ticks"]
         region_ms = ev_a.elapsed_time(ev_b) if graphs else None
         if graphs:                # start / stop events carried by EVERY dispatch packet of 64 host-launched steps, outside the timed region (kernel_us_dispatch_events)
@@ -805,9 +831,9 @@ def main():
         res = {"extra_warm": extra, "elapsed": elapsed, "launch": launch_mode, "parity": parity, "bad": bad, "rti_ms": rti_ms, "rti_n": rti_n,
                "mlp_ms": mlp_ms, "mlp_n": mlp_n, "it": it, "step": step, "name": mode_names[mode], "region_ms": region_ms,
                "parity_fn": parity_check if check_parity else None}
-        if mode == "prefetch":
+        if mode in ("prefetch", "peer_ahead"):
             res["prefetch_stats"] = eng.prefetch_stats()
-        if mode == "peer":
+        if mode in PEER_FORMS:
             ps = peer.stats()
             if world > 1:                                         # any rank's timed-out wait shows in the line
                 agg = torch.tensor([ps["ack_timeouts"], ps["epoch_timeouts"], ps["slot_mismatches"]], dtype=torch.int64, device=cdev)
@@ -826,9 +852,10 @@ def main():
         # `value` is the first form's (the north star's collective when an exchange runs); its two launch modes -- host launches,
         # captured -- are one form: the faster one that passed its checks is the headline, config.launch says which
         def form_ok(r):
-            ps_ = r.get("peer_stats")
+            ps_, pf_ = r.get("peer_stats"), r.get("prefetch_stats") if r.get("peer_stats") else None
             return ((r["parity"] is None or r["parity"] <= 1e-5) and r["bad"] == 0
-                    and not (ps_ and (ps_["ack_timeouts"] or ps_["epoch_timeouts"] or ps_["slot_mismatches"])))
+                    and not (ps_ and (ps_["ack_timeouts"] or ps_["epoch_timeouts"] or ps_["slot_mismatches"]))
+                    and not (pf_ and (pf_["force_timeouts"] or pf_["slot_timeouts"])))
         headline = modes[0]
         if headline in ("rccl", "rccl_graph"):
             cands = [m for m in ("rccl", "rccl_graph") if m in results and m in modes and form_ok(results[m])]
@@ -929,7 +956,7 @@ def main():
                                           "MLP downwash on (NDP controller, gate+MLP fused into the RTI launch)" if fused else
                                           "MLP downwash on (NDP controller)" if downwash else "no downwash (NMPC controller)")
                                        + (", neighbour windows all-gathered over RCCL every step" if is_rccl and world > 1 else
-                                          ", neighbour windows published every step into a peer-mapped slot and read over xGMI by the kernel" if headline == "peer" else
+                                          ", neighbour windows published every step into a peer-mapped slot and read over xGMI by the kernel" if headline in PEER_FORMS else
                                           ", vehicle-major placement (position/velocity columns packed for the all-gather; one rank: no RCCL call)" if is_rccl else
                                           ", formation-major placement (no exchange)" if (world > 1 or cfg4) else "")
                                        + (", perturbed starts (~20 % of the instances need the interior-point loop)" if args.perturb == "mixed" else ""),
@@ -981,7 +1008,7 @@ def main():
                     for m, e in form_errors.items():
                         if m in baseline_modes:
                             sb[m] = {"error": e}
-                    okm = [m for m in sb if sb[m].get("ok") and m != "peer"]          # (the base of the curve is the headline form's: rccl)
+                    okm = [m for m in sb if sb[m].get("ok") and m not in PEER_FORMS]          # (the base of the curve is the headline form's: rccl)
                     best = max(okm, key=lambda m: sb[m]["value"]) if okm else None
                     out["scaling_baseline"] = {
                         "value": sb[best]["value"] if best else None, "ms_per_step": sb[best]["ms_per_step"] if best else None, "form": best,
@@ -995,14 +1022,16 @@ def main():
                 # both forms of the per-step neighbour exchange, same steps, same inputs (value = whole-job solves/s)
                 out["exchange"] = {m: {"value": total / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3, "launch": r["launch"],
                                        "parity_max_rel_vs_oracle": r["parity"], "instances_not_converged": r["bad"], "form": r["name"],
-                                       "ok": form_ok(r), **({"peer_stats": r["peer_stats"]} if "peer_stats" in r else {})}
+                                       "ok": form_ok(r), **({"peer_stats": r["peer_stats"]} if "peer_stats" in r else {}),
+                                       **({"prefetch_stats": r["prefetch_stats"]} if "prefetch_stats" in r else {})}
                                    for m, r in results.items()}
                 if any(not form_ok(r) for m, r in results.items() if m != headline):
                     out["secondary_form_failed"] = True
                 for m, e in form_errors.items():
                     out["exchange"][m] = {"error": e}
                 if peer_err:
-                    out["exchange"]["peer"] = {"error": peer_err}
+                    for m in PEER_FORMS:
+                        out["exchange"][m] = {"error": peer_err}
                 if world > 1:
                     out["scaling_baseline"] = {"compare_with": "the N = 1 line's scaling_baseline.value (the same per-step all-gather + control step with a "
                                                                "one-rank communicator), not its headline `value` (hipGraph replay, no exchange)",

@@ -186,7 +186,8 @@ struct KernArgs {
 // FUSED: the wave first predicts its own instance's disturbance force (gate + MLP over the N+1 <= 32 horizon rows,
 // one 32x32 f32 MFMA tile) and leaves it in the LDS staging slot the RTI program reads f from -- no second
 // launch and no trip of f through HBM.
-// QMODE: 0 = the whole step in place; 1 / 2 = producer / consumer of the interior-point work list (see QueueArgs).
+// QMODE: 0 = the whole step in place; 1 / 2 = producer / consumer of the interior-point work list (see QueueArgs); 3 = in place, the
+// lean program (RtiWave's LEAN: no stiff sweeps) -- the late-force step that shares the SIMDs with the next tick's downwash launch.
 #ifndef NDP_RTI_ATTR       // kernel-development hook: extra attributes of rti_kernel (e.g. a register cap for occupancy studies)
 #define NDP_RTI_ATTR
 #endif
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     const int B = ka.B;
     const int wave = (int)(threadIdx.x >> 6);
     __shared__ unsigned wg_done;     // prefetched-force launches: the workgroup's waves that hold their force values (see LateArgs)
-    if (!FUSED && QMODE == 0 && ka.la.proto) {
+    if (!FUSED && (QMODE == 0 || QMODE == 3) && ka.la.proto) {
         if (threadIdx.x == 0) wg_done = 0;
         __syncthreads();             // (before any wave of a ragged last workgroup leaves)
     }
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     const size_t nf = (size_t)(N + 1) * 3;
     RtiIo io;
     bind_instance(io, bp, inst, N);
-    if (!FUSED && QMODE == 0 && ka.la.proto) {
+    if (!FUSED && (QMODE == 0 || QMODE == 3) && ka.la.proto) {
         // this launch is control step number t; its force was written into slot t & 1 by downwash launch t
         const LateArgs &la = ka.la;
         const unsigned long long t = la.proto[PF_RTI_C2] / la.groups_rti + 1;       // (plain load: see LateArgs)
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     // PREC 0: the product path (f64 matrix instruction); 1 / 2: operand-rounding studies on it; 3 / 4: the sweeps on the real
     // fp32 / bf16-input matrix instructions (BASELINE config 5)
     using WB = std::conditional_t<PREC == 3, WaveGfx950F32, std::conditional_t<PREC == 4, WaveGfx950BF16, WaveGfx950>>;
-    using Prog = RtiWave<WB, NSLOT, NC, true, NRC, (PREC >= 3 ? 0 : PREC)>;   // compile-time horizon and iteration count (NC = 0: both at run time)
+    using Prog = RtiWave<WB, NSLOT, NC, true, NRC, (PREC >= 3 ? 0 : PREC), QMODE == 3>;   // compile-time horizon and iteration count (NC = 0: both at run time)
     if (NDP_RARELY(io.stamps && (threadIdx.x & 63u) == 0)) {    // profiling hook: real time (100 MHz) and shader clock at entry -> the clock the launch ran at
         io.stamps[12] = (double)__builtin_amdgcn_s_memrealtime();
         io.stamps[14] = (double)__builtin_amdgcn_s_memtime();
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         io.f = nullptr;
         io.f_in_lds = 1;
     }
-    const bool deferred = Prog::template run<QMODE == 1, QMODE == 0>(P, io, lds, inb, x0v);
+    const bool deferred = Prog::template run<QMODE == 1, QMODE == 0 || QMODE == 3>(P, io, lds, inb, x0v);
     if (NDP_RARELY(io.stamps && (threadIdx.x & 63u) == 0)) {
         io.stamps[13] = (double)__builtin_amdgcn_s_memrealtime();
         io.stamps[15] = (double)__builtin_amdgcn_s_memtime();
@@ -1246,6 +1247,7 @@ __global__ __launch_bounds__(256) void ref_list_window_kernel(const double *__re
 struct PeerDevMem {
     typedef unsigned long long u64;
     static __device__ __forceinline__ u64 load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    static __device__ __forceinline__ u64 peek(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
     static __device__ __forceinline__ void store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     static __device__ __forceinline__ u64 now_us() { return __builtin_amdgcn_s_memrealtime() / 100; }   // 100 MHz constant clock
 };
@@ -1259,21 +1261,22 @@ struct PeerPubArgs {
     unsigned timeout_us;
 };
 
+// No LDS and no barrier: the launch may have to run BESIDE a control step whose workgroups hold the CU's whole LDS (the one-tick-ahead
+// form), where a workgroup that asks for any would wait for a control-step workgroup to leave.  Every wave reads the tick and waits for the
+// slot by itself (the same two words).
 __global__ __launch_bounds__(256) void peer_publish_kernel(PeerPubArgs a)
 {
     typedef PeerProto<PeerDevMem> PP;
     typedef unsigned long long u64;
-    __shared__ u64 tick_s;
-    if (threadIdx.x == 0) {
-        const u64 t = PP::next_tick(a.own);          // (the epochs only change in peer_epoch_kernel, behind this launch)
-        if (blockIdx.x == 0) PP::ack_previous(a.nb, t);
+    u64 t = 0;
+    if ((threadIdx.x & 63u) == 0) {
+        t = PP::next_tick(a.own);                    // (the epochs only change in peer_epoch_kernel, behind this launch)
+        if (blockIdx.x == 0 && threadIdx.x == 0) PP::ack_previous(a.nb, t);
         const bool freed = PP::wait_slot_free(a.own, t, a.timeout_us);
-        if (blockIdx.x == 0 && !freed) a.own[PEER_W_STAT + PEER_STAT_ACK_TIMEOUT] += 1;
-        tick_s = t;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !freed) a.own[PEER_W_STAT + PEER_STAT_ACK_TIMEOUT] += 1;
     }
-    __syncthreads();
-    const u64 t = tick_s;
-    double2 *dst = reinterpret_cast<double2 *>(reinterpret_cast<unsigned char *>(a.own) + peer_slot_offset(a.n, (int)(t & 1)));
+    const unsigned par = (unsigned)__builtin_amdgcn_readfirstlane((int)(t & 1));
+    double2 *dst = reinterpret_cast<double2 *>(reinterpret_cast<unsigned char *>(a.own) + peer_slot_offset(a.n, (int)par));
     const double2 *src = reinterpret_cast<const double2 *>(a.src);
     const size_t n2 = a.n / 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
@@ -1999,6 +2002,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
                          (const void *)RTI_K(3, 4, false, 20), (const void *)RTI_K(3, 4, true, 20),
                          (const void *)RTI_K(3, 2, false, 20), (const void *)RTI_K(3, 2, true, 20),
                          (const void *)RTI_K(3, 4, false, 20, 0, 1, 1), (const void *)RTI_K(3, 4, true, 20, 0, 1, 1), (const void *)RTI_K(3, 4, false, 20, 0, 1, 2),
+                         (const void *)RTI_K(3, 4, false, 20, 0, 1, 3),
                          (const void *)RTI_K(5, 1, false, 0, 1), (const void *)RTI_K(5, 1, false, 0, 2),
                          (const void *)RTI_K(5, 1, false, 0, 3), (const void *)RTI_K(5, 1, false, 0, 4),
                          (const void *)RTI_K(5, 2, false, 40, 3, 2), (const void *)RTI_K(5, 2, false, 40, 4, 2),
@@ -2194,7 +2198,7 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
         return end_timing(h, s);
     }
     if (h->cfg.N == 20 && h->cfg.n_rti == 1 && W == 4) {   // the reference configuration (params/nmpc_params.py:9, 1 RTI iteration): compile-time instantiation
-        if (fused) LAUNCH(3, 4, true, 20); else LAUNCH(3, 4, false, 20);
+        if (fused) LAUNCH(3, 4, true, 20); else if (prefetched) LAUNCH(3, 4, false, 20, 0, 1, 3); else LAUNCH(3, 4, false, 20);
     } else if (h->cfg.N == 20 && h->cfg.n_rti == 1 && W == 2) {   // (NDP_DEV_WAVES = 2: the same program, two instances per workgroup)
         if (fused) LAUNCH(3, 2, true, 20); else LAUNCH(3, 2, false, 20);
     } else if (h->cfg.N == 40 && h->cfg.n_rti == 2 && W == 2 && !fused) {   // BASELINE config 5's shape, compile-time as well

@@ -19,7 +19,7 @@
 // subscriber likewise keeps using the last PredXU it received -- and an owner whose reader is stuck overwrites the slot, as a
 // ROS publisher with a full queue drops the oldest message.  Both are counted (PEER_STAT_*), never silent.
 //
-// The text below is written against a small memory backend M (system-scope acquire loads / release stores + a microsecond
+// The text below is written against a small memory backend M (system-scope acquire loads / release stores, relaxed polls + a microsecond
 // clock) so that tests/emu can run the very same protocol between two CPU processes over POSIX shared memory (gloo ranks).
 #pragma once
 #include <stddef.h>
@@ -44,10 +44,12 @@ template <class M>
 struct PeerProto {
     typedef unsigned long long u64;
 
-    // the tick this publish call is about: one more than the newest tick in the owner's own slots
+    // the tick this publish call is about: one more than the newest tick in the owner's own slots.  (M::peek: a load that orders
+    // nothing behind it -- what follows these polls are the owner's own WRITES; an acquire load costs a cache invalidation per poll,
+    // and every wave of the publish launch polls)
     static NDP_PEER_FN u64 next_tick(const u64 *own)
     {
-        const u64 e0 = M::load(own + PEER_W_EPOCH), e1 = M::load(own + PEER_W_EPOCH + 8);
+        const u64 e0 = M::peek(own + PEER_W_EPOCH), e1 = M::peek(own + PEER_W_EPOCH + 8);
         return (e0 > e1 ? e0 : e1) + 1;
     }
 
@@ -62,9 +64,9 @@ struct PeerProto {
     {
         if (t <= 2) return true;
         const u64 *w = own + PEER_W_ACK + 8 * (t & 1);
-        if (M::load(w) + 2 >= t) return true;
+        if (M::peek(w) + 2 >= t) return true;
         const u64 t0 = M::now_us();
-        while (M::load(w) + 2 < t)
+        while (M::peek(w) + 2 < t)
             if (M::now_us() - t0 > timeout_us) return false;
         return true;
     }

@@ -183,7 +183,9 @@ NDP_HD void fill_kc(const RtiParams &P, double *kc)
 // PREC: precision study of BASELINE config 5 (0 = the product path).  1 / 2 round every operand of every matrix
 // instruction of the Riccati sweeps to fp32 / bf16 and every accumulator to fp32 after each instruction -- the numbers
 // a sweep on v_mfma_f32_16x16x4_f32 / a bf16-input MFMA with fp32 accumulation would see; everything else stays f64.
-template <class W, int NSLOT, int NC = 0, bool HT = false, int NR = 0, int PREC = 0>
+// LEAN: no stiff path in the interior-point loop (see ipm(): STIFF).  For the control step that runs BESIDE the downwash launch of the next
+// tick (late force): the two kernels' waves share a SIMD's 512 registers, 184 of them the downwash launch's -- the stiff sweeps cost 80.
+template <class W, int NSLOT, int NC = 0, bool HT = false, int NR = 0, int PREC = 0, bool LEAN = false>
 struct RtiWave {
     static NDP_D int horizon(const RtiParams &P) { return NC ? NC : P.N; }
     static constexpr int UNROLL_STAGES = NC > 0 ? NC : 1;
@@ -834,46 +836,35 @@ struct RtiWave {
         const vd x0 = y0 * F(0, 0) - l10 * x1 - l20 * x2 - l30 * x3;
         return W::sel(g == 0, x0, W::sel(g == 1, x1, W::sel(g == 2, x2, x3)));
     }
-    static NDP_D vd lam_inverse_ldl(const LdsMap &m, const Tables &T, lp lds, vd h3, vb &okv, bool park = false)
+    static NDP_D void lam_factor_ldl(const LdsMap &m, const Tables &T, lp lds, vd h3, vb &okv)
     {
         W::st(lds, T.lam_w_off, h3);
         W::sync();
-        auto A = [&](int r, int c) { return W::ld(lds, W::lane() * 0 + (m.SC + 4 * r + c)); };
-        const vd a00 = A(0, 0), a10 = A(1, 0), a11 = A(1, 1), a20 = A(2, 0), a21 = A(2, 1), a22 = A(2, 2),
-                 a30 = A(3, 0), a31 = A(3, 1), a32 = A(3, 2), a33 = A(3, 3);
-        const vd d0 = a00, r0 = W::rcp(d0);
+        // entries are read where they are used (broadcast reads of the block's LDS image), the factors written back over them: nothing
+        // but the running column lives in registers
+        auto A = [&](int r, int c) { return W::ld(lds, W::lane_here() * 0 + (m.SC + 4 * r + c)); };
+        auto put = [&](int r, int c, vd v) { W::st(lds, W::lane_here() * 0 + (m.SC + 4 * r + c), v); };   // every lane writes the same value
+        const vd d0 = A(0, 0), r0 = W::rcp(d0);
+        const vd a10 = A(1, 0), a20 = A(2, 0), a30 = A(3, 0);
         const vd l10 = a10 * r0, l20 = a20 * r0, l30 = a30 * r0;
-        const vd d1 = a11 - l10 * a10, r1 = W::rcp(d1);
-        const vd l21 = (a21 - l20 * a10) * r1, l31 = (a31 - l30 * a10) * r1;
-        const vd d2 = a22 - l20 * a20 - l21 * (l21 * d1), r2 = W::rcp(d2);
-        const vd l32 = (a32 - l30 * a20 - l31 * (l21 * d1)) * r2;
-        const vd d3 = a33 - l30 * a30 - l31 * (l31 * d1) - l32 * (l32 * d2), r3 = W::rcp(d3);
+        const vd d1 = A(1, 1) - l10 * a10, r1 = W::rcp(d1);
+        const vd l21 = (A(2, 1) - l20 * a10) * r1, l31 = (A(3, 1) - l30 * a10) * r1;
+        const vd l21d = l21 * d1;
+        const vd d2 = A(2, 2) - l20 * a20 - l21 * l21d, r2 = W::rcp(d2);
+        const vd l32 = (A(3, 2) - l30 * a20 - l31 * l21d) * r2;
+        const vd d3 = A(3, 3) - l30 * a30 - l31 * (l31 * d1) - l32 * (l32 * d2), r3 = W::rcp(d3);
         okv = okv && (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
-        if (park) {     // every lane writes the same ten values
-            auto put = [&](int r, int c, vd v) { W::st(lds, W::lane() * 0 + (m.SC + 4 * r + c), v); };
-            W::sync();
-            put(0, 0, r0); put(1, 1, r1); put(2, 2, r2); put(3, 3, r3);
-            put(1, 0, l10); put(2, 0, l20); put(2, 1, l21); put(3, 0, l30); put(3, 1, l31); put(3, 2, l32);
-            W::sync();
-        }
-        // M = L^-1 (unit lower triangular)
-        const vd m10 = -l10, m21 = -l21, m32 = -l32;
-        const vd m20 = -l20 - l21 * m10, m31 = -l31 - l32 * m21;
-        const vd m30 = -l30 - l31 * m10 - l32 * m20;
-        // column i of M as seen by this lane: i = g for the left factor, i = j & 3 for the right one
-        vi lane = W::lane();
-        vi gi = lane >> 4, ji = W::lcol(lane) & 3;
-        auto col = [&](const vi &i, vd out[4]) {
-            const vd one(1.0), zero(0.0);
-            out[0] = W::sel(i == 0, one, zero);
-            out[1] = W::sel(i == 0, m10, W::sel(i == 1, one, zero));
-            out[2] = W::sel(i == 0, m20, W::sel(i == 1, m21, W::sel(i == 2, one, zero)));
-            out[3] = W::sel(i == 0, m30, W::sel(i == 1, m31, W::sel(i == 2, m32, one)));
-        };
-        vd mi[4], mj[4];
-        col(gi, mi);
-        col(ji, mj);
-        return mi[0] * mj[0] * r0 + mi[1] * mj[1] * r1 + mi[2] * mj[2] * r2 + mi[3] * mj[3] * r3;
+        W::sync();
+        put(0, 0, r0); put(1, 1, r1); put(2, 2, r2); put(3, 3, r3);
+        put(1, 0, l10); put(2, 0, l20); put(2, 1, l21); put(3, 0, l30); put(3, 1, l31); put(3, 2, l32);
+        W::sync();
+    }
+    // Lam^-1[g][j & 3] in every lane -- the layout of the explicit inverse the second-solve sweeps keep (delta_sweep's -Lam^-1) -- as the
+    // solution of Lam X = [I I I I] with the parked factors
+    static NDP_D vd lam_inverse_ldl(const LdsMap &m, lp lds)
+    {
+        vi lane = W::lane_here();
+        return ldl_solve(m, lds, W::sel((W::lcol(lane) & 3) == (lane >> 4), vd(1.0), vd(0.0)));
     }
 
     // backward: H~_k = M~_k' P~_{k+1} M~_k + C~_k with P~_{k+1} = H~xx - H~xu Lam^-1 H~ux of stage k+1, P~_N = C~_N.
@@ -939,8 +930,11 @@ struct RtiWave {
             if constexpr (ROBUST) {
                 // a cold path, written for few live registers (no operand prefetch, nothing carried between stages but H~): what is
                 // live here at its widest is what the allocator parks for the whole kernel, the hot sweep included
-                const vd inv = lam_inverse_ldl(m, T, lds, W::to_d(hux), okv, true);  // Lam^-1[g][j & 3] in every lane; the factors parked in LDS
-                if constexpr (KEEP) linv_put(linv, k, N, W::to_m(MMA4 ? -inv : W::sel(T.kt_pred, -inv, vd(0.0))));
+                lam_factor_ldl(m, T, lds, W::to_d(hux), okv);                        // the factors parked in LDS
+                if constexpr (KEEP) {
+                    const vd inv = lam_inverse_ldl(m, lds);
+                    linv_put(linv, k, N, W::to_m(MMA4 ? -inv : W::sel(T.kt_pred, -inv, vd(0.0))));
+                }
                 {   // K~' = -(Lam^-1 H~ux)': lane (g, j) holds (Lam^-1 H~ux)[g][j] = -K~'[j][g], stored where K~' lives (row-major 12 x 4)
                     const vd G1 = ldl_solve(m, lds, W::to_d(hux));
                     vi ln = W::lane_here();
@@ -1062,7 +1056,8 @@ struct RtiWave {
             md hux = H.r[3];
             vd cof, rdet;
             if constexpr (ROBUST) {
-                cof = lam_inverse_ldl(m, T, lds, W::to_d(hux), okv, true);
+                lam_factor_ldl(m, T, lds, W::to_d(hux), okv);
+                cof = KEEP ? lam_inverse_ldl(m, lds) : vd(0.0);
                 rdet = vd(1.0);
                 const vd G1 = ldl_solve(m, lds, W::to_d(hux));
                 vi ln = W::lane_here();
@@ -1463,9 +1458,13 @@ struct RtiWave {
 #ifdef NDP_DEV_NO_STIFF      // kernel-development hook: the loop as in round 3 (A/B runs of the headline with and without the extra code)
         constexpr bool STIFF = false;
 #else
-        constexpr bool STIFF = NSLOT <= 3;
+        constexpr bool STIFF = NSLOT <= 3 && !LEAN;
 #endif
+#ifdef NDP_DEV_NO_REFINE
+        constexpr bool REFINE = false;
+#else
         constexpr bool REFINE = DELTA && MMA4 && STIFF;
+#endif
         const int nu4 = 4 * N;
         for (;;) {
             if (mu <= P.tol && rho * norm0 <= P.tol) break;
@@ -1502,7 +1501,9 @@ struct RtiWave {
                     build_delta_tabs(m, DT);
                     delta_sweep(P, m, T, DT, lds, linv);
                 }
+#ifndef NDP_DEV_NO_ROBUST
                 else if (STIFF && NDP_RARELY(P.refine > 0 && gmaxv > P.refine_gamma)) ok = riccati_sweep<DELTA, STIFF>(P, m, T, lds, nullptr, linv) && ok;
+#endif
                 else ok = riccati_sweep<DELTA>(P, m, T, lds, nullptr, linv) && ok;
                 if constexpr (REFINE) {
                     if (NDP_RARELY(ok && P.refine > 0 && gmaxv > P.refine_gamma)) {

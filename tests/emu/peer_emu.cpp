@@ -12,6 +12,7 @@ using namespace ndp;
 struct PeerCpuMem {
     typedef unsigned long long u64;
     static u64 load(const u64 *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+    static u64 peek(const u64 *p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
     static void store(u64 *p, u64 v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
     static u64 now_us()
     {

@@ -1300,6 +1300,81 @@ def test_downwash_one_tick_ahead_on_the_second_stream(ndp, oracle, mlp_blob):
     _assert_u(want[0][sto == 0], uo[sto == 0], 1e-6)
 
 
+def test_peer_windows_one_tick_ahead_beside_the_control_steps(ndp):
+    """bench.py's exchange.peer_ahead on one rank: a second stream carries, per tick, the publish of the tick's windows into the peer
+    slot (copy launch, epoch launch that waits for the neighbour's epoch) and the gate / MLP launch that reads the NEIGHBOUR'S SLOT (a
+    raw device address) -- one tick ahead of the control steps on the first stream, which take the force late (the lean instantiation:
+    it shares the SIMDs with the downwash launch).  Host-launched and as two hipGraphs replayed side by side (an even number of ticks:
+    the slot parity is baked into a launch).  Same controls as the fused launch that is handed the windows as a tensor; epochs count the
+    ticks; nothing times out."""
+    import torch
+    from ndp_nmpc_qd_amd import dist as ndist
+    B, N, T = 512, 20, 8
+    dev = torch.device("cuda", 0)
+    ticks = []
+    for t in range(T):
+        b = synth.make_batch(B, seed=synth.SEED0 + 83, downwash=True, t0=0.02 * t)
+        ticks.append({k: torch.from_numpy(b[k]).to(dev) for k in ("x0", "xr", "ur", "other", "ego_xy")})
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1)
+    fused = ndp.BatchedNMPC(B, disturbance=True)
+    uf = torch.empty(T, B, 4, dtype=torch.float64, device=dev)
+    fused.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=sa)
+    for t, d in enumerate(ticks):
+        fused.update_device(d["x0"], d["xr"], d["ur"], uf[t], other=d["other"], ego_xy=d["ego_xy"], stream=sa)
+    fused.synchronize()
+    assert (fused.status()[0] == 0).all()
+    fused.close()
+    pw = ndist.PeerWindows(B, N, 0)
+    try:
+        def ahead(eng, d, first=False):       # "this rank's windows" = the synthetic batch's neighbour windows (one rank: own buffer = neighbour's)
+            eng.downwash_prefetch_device(pw.publish_device(d["other"], sb), d["xr"], ego_xy=d["ego_xy"], on_stream=sb,
+                                         after_stream=sa if first else None)
+        for mode in ("host", "graphs"):
+            eng = ndp.BatchedNMPC(B, disturbance=True)
+            up = torch.empty(T, B, 4, dtype=torch.float64, device=dev)
+            eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=sa)
+            base = pw.stats()["ticks"]
+            pw.tick = base
+            if mode == "host":
+                ahead(eng, ticks[0], first=True)
+                for t, d in enumerate(ticks):
+                    if t + 1 < T:
+                        ahead(eng, ticks[t + 1])
+                    eng.update_device_prefetched(d["x0"], d["xr"], d["ur"], up[t], stream=sa)
+                extra = 0
+            else:
+                ahead(eng, ticks[0], first=True)                        # allocations outside the captures; two ticks: the parity stays
+                ahead(eng, ticks[1])
+                for t in (0, 1):
+                    eng.update_device_prefetched(ticks[t]["x0"], ticks[t]["xr"], ticks[t]["ur"], up[t], stream=sa)
+                torch.cuda.synchronize()
+                eng.reset_device(ticks[0]["xr"], ticks[0]["ur"], stream=sa)
+                torch.cuda.synchronize()
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, stream=sa, capture_error_mode="relaxed"):
+                    for t, d in enumerate(ticks):
+                        eng.update_device_prefetched(d["x0"], d["xr"], d["ur"], up[t], stream=sa)
+                with torch.cuda.graph(gb, stream=sb, capture_error_mode="relaxed"):
+                    for d in ticks:
+                        ahead(eng, d)
+                with torch.cuda.stream(sb):
+                    gb.replay()
+                with torch.cuda.stream(sa):
+                    ga.replay()
+                extra = 2
+            torch.cuda.synchronize()
+            ps = pw.stats()
+            assert ps == dict(ticks=base + T + extra, ack_timeouts=0, epoch_timeouts=0, slot_mismatches=0), (mode, ps)
+            st = eng.prefetch_stats()
+            st.pop("late_waves")
+            assert st == dict(predictions=T + extra, steps=T + extra, force_timeouts=0, slot_timeouts=0), (mode, st)
+            assert (eng.status()[0] == 0).all()
+            np.testing.assert_allclose(up.cpu().numpy(), uf.cpu().numpy(), rtol=0, atol=1e-9)
+            eng.close()
+    finally:
+        pw.close()
+
+
 def test_downwash_prediction_enqueued_after_its_control_step_takes_the_epoch_path(ndp):
     """The LATE path of the downwash-ahead protocol on purpose: every tick's control step is launched BEFORE the
     prediction it consumes, so its waves find PF_MLP_DONE < t at start, wait on their tiles' epoch words and load the force rows

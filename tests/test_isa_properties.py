@@ -56,6 +56,38 @@ def test_no_rti_kernel_instantiation_uses_scratch_memory(co):
     assert not bad, bad
 
 
+def test_late_force_step_and_downwash_launch_share_a_simd(co):
+    """The downwash-one-tick-ahead forms (bench: downwash_forms.prefetch, exchange.peer_ahead) run mlp_stream_kernel of tick t+1 BESIDE the
+    control step of tick t: a wave of each per SIMD, whose 512 registers (allocated in units of 8) they share.  The late-force step is
+    therefore the lean instantiation (QMODE 3: no stiff sweeps -- they cost 80 registers); in round 4 the step grew to 372 registers
+    unnoticed and that form fell from 47 to 23 M solves/s with timed-out force waits."""
+    k = co.kernels()
+    lean = k[I.rti_kernel_name(3, 4, False, 20, qmode=3)]
+    mlp = [v for n, v in k.items() if "mlp_stream_kernel" in n][0]
+    up8 = lambda r: (r + 7) // 8 * 8                                            # noqa: E731
+    assert up8(lean["vgpr"]) + up8(mlp["vgpr"]) <= 512, (lean, mlp)
+    assert lean["scratch"] == 0 and mlp["scratch"] == 0 and mlp["lds"] == 0    # (the control step's workgroups hold the whole LDS)
+
+
+def test_headline_hot_path_has_no_spill_traffic(co):
+    """Up to the end of the first Riccati sweep the headline kernel moves nothing to or from accumulation registers or lane-spill slots:
+    the cold branches (interior-point loop, stiff sweeps, debug hooks) are marked NDP_RARELY, so the register allocator -- which weighs
+    uses by block frequency -- parks values there and not in the straight-line path."""
+    d = co.disassemble(I.rti_kernel_name(3, 4, True, 20))
+    idx = [i for i, l in enumerate(d) if "mfma" in l]
+    clusters, s, p = [], idx[0], idx[0]
+    for i in idx[1:]:
+        if i - p > 150:
+            clusters.append((s, p)); s = i
+        p = i
+    clusters.append((s, p))
+    end = clusters[1][1]                      # cluster 0: the downwash tile, cluster 1: the first backward + forward sweep
+    assert 4000 < end < 6500, clusters
+    hot = [l.split()[0] for l in d[:end] if l.strip()]
+    bad = [o for o in hot if o in ("v_accvgpr_read_b32", "v_accvgpr_write_b32", "v_readlane_b32", "v_writelane_b32") or o.startswith("scratch_")]
+    assert len(bad) <= 4, (len(bad), bad[:8])
+
+
 def test_lds_budget_of_the_reference_configuration():
     """4 instances per workgroup at N = 20 fit the CU's 160 KB; 2 at N = 40."""
     from ndp_nmpc_qd_amd import _lib
