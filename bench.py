@@ -607,11 +607,16 @@ def main():
                     if i not in pending:
                         prefetch(i)
                     w = pending.pop(i)
-                    if xchg is not None:
-                        xchg.end(stream)                 # (the gather begun last is tick i's: end(i) always precedes begin(i + 1))
+                    if xchg is not None and track:
+                        # end(i) + begin(i + 1) in ONE library call (ndp_xchg_tick: two ctypes calls per tick instead of four)
+                        xchg.tick(eng, ticks[(i + 1) % T]["xr"], gathered[(i + 1) % 2], stream)
+                        pending[i + 1] = None
                     else:
-                        ndist.exchange_pv_end(w)
-                    prefetch(i + 1)
+                        if xchg is not None:
+                            xchg.end(stream)             # (the gather begun last is tick i's: end(i) always precedes begin(i + 1))
+                        else:
+                            ndist.exchange_pv_end(w)
+                        prefetch(i + 1)
                     # the step on (tick i % T, gathered buffer i % 2): argument checks once, then one ctypes call per launch -- this
                     # loop launches from the host at the control step's own pace
                     key = (i % T, i % 2)

@@ -358,6 +358,10 @@ int ndp_xchg_begin(ndp_xchg *x, const void *d_xr, size_t rows, void *d_gathered,
 int ndp_track_steps(ndp_handle *h, int on);
 int ndp_last_step_event(ndp_handle *h, void **event);
 int ndp_xchg_end(ndp_xchg *x, void *stream);
+/* The two calls of one tick of the pipelined form in one: ndp_xchg_end(x, stream) for the gather begun last (this tick's windows), then
+ * ndp_xchg_begin of the NEXT tick's windows behind the last reader of d_gathered_next -- the completion event of the control step
+ * launched last for h when its steps are tracked, else (h NULL, or not tracked) everything `stream` holds so far. */
+int ndp_xchg_tick(ndp_xchg *x, ndp_handle *h, void *stream, const void *d_xr_next, size_t rows, void *d_gathered_next);
 const char *ndp_xchg_last_error(const ndp_xchg *x);
 int ndp_xchg_destroy(ndp_xchg *x);
 

@@ -46,7 +46,7 @@ EXPORTS = [
     "ndp_peer_layout", "ndp_peer_publish_device", "ndp_peer_stats", "ndp_debug_host_timing", "ndp_debug_downwash_stream_device",
     "ndp_downwash_prefetch_device", "ndp_step_device_prefetched", "ndp_prefetch_join", "ndp_prefetch_stats", "ndp_device_force_slot",
     "ndp_track_steps", "ndp_last_step_event",
-    "ndp_xchg_unique_id", "ndp_xchg_create", "ndp_xchg_begin", "ndp_xchg_end", "ndp_xchg_last_error", "ndp_xchg_destroy",
+    "ndp_xchg_unique_id", "ndp_xchg_create", "ndp_xchg_begin", "ndp_xchg_end", "ndp_xchg_tick", "ndp_xchg_last_error", "ndp_xchg_destroy",
 ]
 
 _lib = None
@@ -126,6 +126,7 @@ def load():
     lib.ndp_track_steps.argtypes = [vp, C.c_int]
     lib.ndp_last_step_event.argtypes = [vp, C.POINTER(vp)]
     lib.ndp_xchg_end.argtypes = [vp, vp]
+    lib.ndp_xchg_tick.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     lib.ndp_xchg_last_error.argtypes = [vp]
     lib.ndp_xchg_last_error.restype = C.c_char_p
     lib.ndp_xchg_destroy.argtypes = [vp]

@@ -1830,6 +1830,21 @@ int ndp_xchg_end(ndp_xchg *x, void *stream)
     return hipStreamWaitEvent((hipStream_t)stream, x->evDone, 0) == hipSuccess ? 0 : -3;
 }
 
+// One call per control tick of the pipelined form: `stream` waits for the gather begun last (this tick's windows), then the NEXT tick's
+// gather is begun behind the last reader of its buffer -- the completion event of the control step launched last for h when the steps
+// are tracked (ndp_track_steps), else everything `stream` holds so far.
+int ndp_xchg_tick(ndp_xchg *x, ndp_handle *h, void *stream, const void *d_xr_next, size_t rows, void *d_gathered_next)
+{
+    int rc = ndp_xchg_end(x, stream);
+    if (rc) return rc;
+    void *ev = nullptr;
+    if (h) {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (h->track_steps && h->step_seq && h->last_step_tracked) ev = (void *)h->stepDone[h->step_seq & 3];
+    }
+    return ndp_xchg_begin(x, d_xr_next, rows, d_gathered_next, ev ? nullptr : stream, ev);
+}
+
 const char *ndp_xchg_last_error(const ndp_xchg *x) { return x ? x->err.c_str() : "null exchange"; }
 
 int ndp_xchg_destroy(ndp_xchg *x)

@@ -274,6 +274,18 @@ class RcclExchange:
         if rc:
             raise RuntimeError(f"ndp_xchg_end failed ({rc})")
 
+    def tick(self, eng, xr_next, gathered_next, stream):
+        """end(stream) for the gather begun last + begin() of the next tick's behind the last reader of `gathered_next` (the engine's
+        last tracked control step, else `stream`): one call per control tick (ndp_xchg_tick)."""
+        import ctypes as C
+        if not (xr_next.is_contiguous() and gathered_next.is_contiguous() and xr_next.numel() == self.rows * 10
+                and gathered_next.numel() == self.world * self.rows * PV_COLS):
+            raise ValueError("RcclExchange.tick: xr_next / gathered_next of the wrong size or not contiguous")
+        rc = self._lib.ndp_xchg_tick(self._h, eng._h if eng is not None else None, C.c_void_p(stream.cuda_stream),
+                                     C.c_void_p(xr_next.data_ptr()), self.rows, C.c_void_p(gathered_next.data_ptr()))
+        if rc:
+            raise RuntimeError(f"ndp_xchg_tick failed ({rc}): {self._lib.ndp_xchg_last_error(self._h).decode()}")
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.ndp_xchg_destroy(self._h)

@@ -1607,12 +1607,24 @@ for i in range(8):
             ex.begin(wins[i + 1], bufs[(i + 1) % 2], None, after_event=ev)
     eng.update_device(t["x0"], t["xr"], t["ur"], outs[i], other=bufs[i % 2], ego_xy=t["ego_xy"], stream=stream)
 torch.cuda.synchronize()
+# the same ticks with end(i) + begin(i + 1) as ONE call (ndp_xchg_tick picks the last tracked step's event itself)
+outs2 = [torch.empty(B, 4, dtype=torch.float64, device=dev) for _ in range(8)]
+eng.reset_device(t["xr"], t["ur"], stream=stream)
+ex.begin(wins[0], bufs[0], stream)
+for i in range(8):
+    if i + 1 < 8:
+        ex.tick(eng, wins[i + 1], bufs[(i + 1) % 2], stream)
+    else:
+        ex.end(stream)
+    eng.update_device(t["x0"], t["xr"], t["ur"], outs2[i], other=bufs[i % 2], ego_xy=t["ego_xy"], stream=stream)
+torch.cuda.synchronize()
 eng.track_steps(False)
 eng.reset_device(t["xr"], t["ur"], stream=stream)
 for i in range(8):
     eng.update_device(t["x0"], t["xr"], t["ur"], u_b, other=wins[i], ego_xy=t["ego_xy"], stream=stream)
     torch.cuda.synchronize()
     assert torch.equal(outs[i], u_b), (i, float((outs[i] - u_b).abs().max()))
+    assert torch.equal(outs2[i], u_b), (i, float((outs2[i] - u_b).abs().max()))
 ex.close()
 print("XCHG-ONE-RANK-OK")
 """
