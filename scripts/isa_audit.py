@@ -4,7 +4,9 @@ the instruction mix of the backward / forward sweep (the block with the most mat
 
     python scripts/isa_audit.py [extra hipcc flags]  > profiles/rNN_isa_audit.txt
 
-Compiles csrc/ndp_hip.hip with -save-temps into a temporary directory (nothing is written into the tree; no GPU needed).
+Compiles csrc/ndp_hip.hip to device assembly (--cuda-device-only -S) in a temporary directory (nothing is written into the tree; no
+GPU needed).  (-save-temps, used before, round-trips the module through bitcode, which this compiler's reader rejects for the
+current source: "Invalid cast".)
 """
 import collections
 import os
@@ -29,11 +31,10 @@ KERNELS = [   # (mangled template arguments, what it is)
 def main():
     extra = sys.argv[1:]
     with tempfile.TemporaryDirectory() as td:
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-shared",
-               "-save-temps", "-I" + CSRC, "-o", os.path.join(td, "x.so"), os.path.join(CSRC, "ndp_hip.hip")] + extra
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC",
+               "--cuda-device-only", "-S", "-I" + CSRC, "-o", os.path.join(td, "x.s"), os.path.join(CSRC, "ndp_hip.hip")] + extra
         subprocess.run(cmd, cwd=td, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        asm = [f for f in os.listdir(td) if f.endswith("gfx950.s")][0]
-        text = open(os.path.join(td, asm)).read()
+        text = open(os.path.join(td, "x.s")).read()
     print("hipcc " + " ".join(cmd[1:8] + extra))
     meta = {}
     for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", text, re.S):
