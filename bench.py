@@ -368,6 +368,9 @@ def main():
     ap.add_argument("--leg-timeout-s", type=float, default=240.0,
                     help="watchdog of every secondary form (captured rccl form, peer form, downwash-ahead form): a leg that has not finished "
                          "after this long is reported as timed out, the line is printed with the forms that did finish, and the ranks exit")
+    ap.add_argument("--deadline-s", type=float, default=1500.0,
+                    help="whole-run bound: a rank still running after this long (a collective that never returns in set-up or in the "
+                         "headline form, which has no watchdog of its own) says on stderr where it is and exits with code 4")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: bounded sample, about this many seconds")
     ap.add_argument("--exchange", default="both", choices=["both", "peer", "rccl", "peer_ahead"],
                     help="N > 1 (and --config 4), vehicle-major placement: how a rank gets its neighbours' reference windows, every "
@@ -396,6 +399,17 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
+    # whole-run bound (--deadline-s): says where the rank is stuck, then leaves -- never a silent hang
+    import threading as _th
+    stage = {"at": "start-up"}
+
+    def _deadline():
+        print(f"[bench] rank {rank}: not finished after {args.deadline_s:.0f} s, stuck in: {stage['at']} -- giving up (exit 4)", file=sys.stderr, flush=True)
+        os._exit(4)
+    _dl = _th.Timer(args.deadline_s, _deadline)
+    _dl.daemon = True
+    _dl.start()
+
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL and the peer-window mapping alike); must be set before HIP starts
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # the downwash-one-tick-ahead form runs two launches side by side: they need different hardware queues.  The library's second
@@ -419,6 +433,7 @@ def main():
         if same_dev:
             dist.init_process_group("gloo")
         else:
+            stage["at"] = "init_process_group(nccl) + first barrier"
             with c_stdout_to_stderr():
                 dist.init_process_group("nccl", device_id=dev)
                 dist.barrier()                # (the communicator is created by the first collective at the latest)
@@ -496,6 +511,7 @@ def main():
         modes = [m for m in modes if m != "peer_ahead"]       # (the downwash-ahead launch holds one instance's rows in one 32-row tile)
     peer, peer_err = None, None
     if any(m in PEER_FORMS for m in modes):
+        stage["at"] = "PeerWindows: peer-mapped window buffers (IPC handles)"
         try:
             peer = ndist.PeerWindows(B, N, local_rank, timeout_us=args.peer_timeout_us)
             if cfg4:
@@ -515,6 +531,7 @@ def main():
         # use it or none does (--torch-collective forces the torch.distributed call).
         if not args.torch_collective and not same_dev:
             ok_here = 1
+            stage["at"] = "RcclExchange: the library's own RCCL communicator (ncclCommInitRank)"
             try:
                 with c_stdout_to_stderr():
                     xchg = ndist.RcclExchange(B, N, local_rank)
@@ -1253,6 +1270,7 @@ def main():
         return r
 
     for k, m in enumerate(modes):
+        stage["at"] = f"form '{m}' (warm-up, timed steps, checks)"
         if k == 0:
             results[m] = run_checked(m)
             continue
@@ -1283,7 +1301,9 @@ def main():
             r["parity"] = fn()
 
 
+    stage["at"] = "the line's extra legs (configs, interior point always, mixed, host path, CPU baseline)"
     fail = finish()
+    stage["at"] = "teardown"
     if xchg is not None:
         xchg.close()
     if peer is not None:
