@@ -1374,12 +1374,29 @@ struct RtiWave {
     // on an INACTIVE bound, which moves the solution by ~mu / (t * weight); with tol = 1e-8 and t >= 0.1 (the default) that is below
     // 1e-6, whereas a minimiser 1e-4 inside a bound differs from the interior-point answer by 1e-4 -- such instances
     // take the interior-point loop like the reference does.
-    static NDP_D bool strictly_inside(const Slots &S, lp lds, double margin)
+    // Evaluated without the constraint slots (which the interior-point loop needs, the nominal step does not): the 4N input bounds
+    // as they lie in ZU (element e: component e & 3), the 3(N-1) velocity bounds four lanes per stage (component 3 idle) -- no division
+    // by three, a third of the slots' index arithmetic.
+    static NDP_D bool strictly_inside_direct(const RtiParams &P, const LdsMap &m, lp lds, double margin)
     {
-        vb okv = W::lane() >= 0;
-        for (int s = 0; s < NSLOT; ++s) {
-            vd z = W::ld(lds, S.zoff[s]);
-            okv = okv && (!S.valid[s] || ((z > S.lo[s] + margin) && (z < S.hi[s] - margin)));
+        const int N = horizon(P), nzu = N * NU;
+        const vi lane = lane_it();
+        const int io = m.XI - m.ZX;
+        vb okv = lane >= 0;
+        for (int t = 0; t < nzu; t += 64) {
+            vi e = W::imin(lane + t, nzu - 1);                    // lanes past the end repeat the last element
+            vi c = e & 3;
+            vd z = W::ld(lds, e + m.ZU), cur = W::ld(lds, e + (m.ZU + io));
+            vd lo = W::ld(lds, c + (m.KC + int(KC_LBU))) - cur, hi = W::ld(lds, c + (m.KC + int(KC_UBU))) - cur;
+            okv = okv && (z > lo + margin) && (z < hi - margin);
+        }
+        for (int t = 0; t < 4 * (N - 1); t += 64) {
+            vi q = W::imin(lane + t, 4 * (N - 1) - 1);
+            vi k = (q >> 2) + 1, c = W::imin(q & 3, 2);           // component 3 repeats component 2
+            vi zo = k * int(NX) + c + (m.ZX + 3);
+            vd z = W::ld(lds, zo), cur = W::ld(lds, zo + io);
+            vd lo = W::ld(lds, c + (m.KC + int(KC_LBV))) - cur, hi = W::ld(lds, c + (m.KC + int(KC_UBV))) - cur;
+            okv = okv && (z > lo + margin) && (z < hi - margin);
         }
         return W::all(okv);
     }
@@ -1741,12 +1758,9 @@ struct RtiWave {
                 bool ok = riccati_sweep(P, m, T, lds, &io);
                 stamp(io, m, 7);
                 if (!ok) { st = 4; failed = true; }
-                // the constraint slots are built only now: keeping ~90 more registers live across the sweep
-                // forces the MFMA accumulators into AGPRs with copies on every dependency
-                Slots S;
-                build_slots(P, m, S);
-                load_bounds(m, S, lds);
-                done = (P.qp_mode == QP_AUTO && strictly_inside(S, lds, P.auto_margin)) || !ok;   // then the step is the sweep's solution, read where it lies (ZX|ZU)
+                // (the constraint slots are built only at the interior-point loop's door: keeping ~90 more registers live across the
+                // sweep forces the MFMA accumulators into AGPRs with copies on every dependency)
+                done = (P.qp_mode == QP_AUTO && strictly_inside_direct(P, m, lds, P.auto_margin)) || !ok;   // then the step is the sweep's solution, read where it lies (ZX|ZU)
             }
             const int zsrc = done ? m.ZX : m.CX;       // ZX|ZU and CX|CU are laid out alike
             if (IPM_RARE ? NDP_RARELY(!done) : !done) {
