@@ -1379,25 +1379,31 @@ struct RtiWave {
     // by three, a third of the slots' index arithmetic.
     static NDP_D bool strictly_inside_direct(const RtiParams &P, const LdsMap &m, lp lds, double margin)
     {
-        const int N = horizon(P), nzu = N * NU;
+        const int N = horizon(P), nzu = N * NU, nv4 = 4 * (N - 1);
+        constexpr int RUm = NC ? (NC * NU + 63) / 64 : NSLOT, RVm = NC ? (4 * (NC - 1) + 63) / 64 : NSLOT;   // rounds (run-time horizons: 7N - 3 <= 64 NSLOT, so 4N <= 64 NSLOT; surplus rounds repeat the last element)
         const vi lane = lane_it();
         const int io = m.XI - m.ZX;
-        vb okv = lane >= 0;
-        for (int t = 0; t < nzu; t += 64) {
-            vi e = W::imin(lane + t, nzu - 1);                    // lanes past the end repeat the last element
+        // every LDS read of the test is requested before the first comparison (one wait), and the verdicts are combined without
+        // control flow (W::band)
+        vd zu[RUm], cu[RUm], lu[RUm], hu[RUm], zv[RVm], cv[RVm], lv[RVm], hv[RVm];
+        for (int t = 0; t < RUm; ++t) {
+            vi e = W::imin(lane + 64 * t, nzu - 1);               // lanes past the end repeat the last element
             vi c = e & 3;
-            vd z = W::ld(lds, e + m.ZU), cur = W::ld(lds, e + (m.ZU + io));
-            vd lo = W::ld(lds, c + (m.KC + int(KC_LBU))) - cur, hi = W::ld(lds, c + (m.KC + int(KC_UBU))) - cur;
-            okv = okv && (z > lo + margin) && (z < hi - margin);
+            zu[t] = W::ld(lds, e + m.ZU); cu[t] = W::ld(lds, e + (m.ZU + io));
+            lu[t] = W::ld(lds, c + (m.KC + int(KC_LBU))); hu[t] = W::ld(lds, c + (m.KC + int(KC_UBU)));
         }
-        for (int t = 0; t < 4 * (N - 1); t += 64) {
-            vi q = W::imin(lane + t, 4 * (N - 1) - 1);
+        for (int t = 0; t < RVm; ++t) {
+            vi q = W::imin(lane + 64 * t, nv4 - 1);
             vi k = (q >> 2) + 1, c = W::imin(q & 3, 2);           // component 3 repeats component 2
             vi zo = k * int(NX) + c + (m.ZX + 3);
-            vd z = W::ld(lds, zo), cur = W::ld(lds, zo + io);
-            vd lo = W::ld(lds, c + (m.KC + int(KC_LBV))) - cur, hi = W::ld(lds, c + (m.KC + int(KC_UBV))) - cur;
-            okv = okv && (z > lo + margin) && (z < hi - margin);
+            zv[t] = W::ld(lds, zo); cv[t] = W::ld(lds, zo + io);
+            lv[t] = W::ld(lds, c + (m.KC + int(KC_LBV))); hv[t] = W::ld(lds, c + (m.KC + int(KC_UBV)));
         }
+        vb okv = lane >= 0;
+        for (int t = 0; t < RUm; ++t)
+            okv = W::band(okv, W::band(zu[t] > (lu[t] - cu[t]) + margin, zu[t] < (hu[t] - cu[t]) - margin));
+        for (int t = 0; t < RVm; ++t)
+            okv = W::band(okv, W::band(zv[t] > (lv[t] - cv[t]) + margin, zv[t] < (hv[t] - cv[t]) - margin));
         return W::all(okv);
     }
 
@@ -1786,7 +1792,7 @@ struct RtiWave {
                     xc[t] = W::ld(lds, i + zsrc);
                 }
                 vb bad = lane < 0;
-                for (int t = 0; t < RZ; ++t) bad = bad || !(xc[t] == xc[t]);
+                for (int t = 0; t < RZ; ++t) bad = W::bor(bad, !(xc[t] == xc[t]));
                 if (NDP_RARELY(!failed && W::any(bad))) {
                     failed = true;
                     if (!status) status = 1;

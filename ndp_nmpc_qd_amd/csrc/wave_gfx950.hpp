@@ -212,6 +212,10 @@ struct WaveGfx950 {
     static NDP_D double wave_sum(vd a) { return wave_reduce(a, [](double x, double y) { return x + y; }); }
     static NDP_D bool all(vb p) { return __all((int)p) != 0; }
     static NDP_D bool any(vb p) { return __any((int)p) != 0; }
+    // lane-wise and / or WITHOUT C++'s short circuit: `a && b` on per-lane bools is control flow, and the compiler sinks b's operands --
+    // LDS loads included -- into the branch: every test then waits for its own load (seen in the step's tail: eight branches, eight waits)
+    static NDP_D vb band(vb a, vb b) { return (vb)((int)a & (int)b); }
+    static NDP_D vb bor(vb a, vb b) { return (vb)((int)a | (int)b); }
 
     // v_mfma_f64_16x16x4_f64: A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15], D reg r lane l = D[(l>>4)+4r][l&15]
     static NDP_D vd4 zero4() { vd4 z; z.r[0] = z.r[1] = z.r[2] = z.r[3] = 0.0; return z; }

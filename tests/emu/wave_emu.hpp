@@ -173,6 +173,8 @@ struct Wave {
     }
     static bool all(const vb &p) { for (int l = 0; l < 64; ++l) if (!p.v[l]) return false; return true; }
     static bool any(const vb &p) { for (int l = 0; l < 64; ++l) if (p.v[l]) return true; return false; }
+    static vb band(const vb &a, const vb &b) { return a && b; }
+    static vb bor(const vb &a, const vb &b) { return a || b; }
 
     // v_mfma_f64_16x16x4_f64: D = A(16x4) * B(4x16) + C
     static vd4 zero4() { vd4 z; for (int r = 0; r < 4; ++r) z.r[r] = vd(0.0); return z; }
