@@ -1453,11 +1453,14 @@ struct RtiWave {
         // stage, four stages per round -- and ONE wave reduction (a reduction per block was 61 of them: ~9 k cycles per solve).
         {
             vi e = lane & 15, kq = lane >> 4;
+            // (three-slot kernels: branch-free predicated reads, all in flight together -- as exec-masked blocks they were eighteen LDS
+            // round trips one after the other; the five-slot kernels, at 510 registers, keep the serial form: 33 reads in flight spill)
+            auto rd = [&](vi off, vb p) { if constexpr (NSLOT <= 3) return W::ldz(lds, off, p); else return W::ldp(lds, off, p); };
             for (int t = 0; 4 * t <= N; ++t) {
                 vi k = kq + 4 * t;
-                nrm = W::vmax(nrm, W::vabs(W::ldp(lds, k * int(CB_STRIDE) + e + (m.CB + int(CB_QE)), (e < 10) && (k <= N))));
-                nrm = W::vmax(nrm, W::vabs(W::ldp(lds, k * int(CB_STRIDE) + e + (m.CB + int(CB_RB)), (e < 4) && (k < N))));
-                nrm = W::vmax(nrm, W::vabs(W::ldp(lds, k * int(MB_STRIDE) + e + (m.MB + int(MB_B)), (e < 10) && (k < N))));
+                nrm = W::vmax(nrm, W::vabs(rd(k * int(CB_STRIDE) + e + (m.CB + int(CB_QE)), (e < 10) && (k <= N))));
+                nrm = W::vmax(nrm, W::vabs(rd(k * int(CB_STRIDE) + e + (m.CB + int(CB_RB)), (e < 4) && (k < N))));
+                nrm = W::vmax(nrm, W::vabs(rd(k * int(MB_STRIDE) + e + (m.MB + int(MB_B)), (e < 10) && (k < N))));
             }
             nrm = W::vmax(nrm, W::vabs(W::ldp(lds, lane + m.ZX, lane < 10)));
         }

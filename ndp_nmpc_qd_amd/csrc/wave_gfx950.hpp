@@ -51,6 +51,10 @@ struct WaveGfx950 {
         a = v[0]; b = v[1];
     }
     static NDP_D vd ldp(lds_ptr lds, vi off, vb p) { return p ? lds[off] : 0.0; }
+    // predicated read WITHOUT control flow: lanes outside the predicate read the slice's first word and get 0.  (ldp is an exec-masked
+    // block, into which the compiler sinks the value's first use together with the wait for the load: a chain of them is a chain of
+    // LDS round trips.)
+    static NDP_D vd ldz(lds_ptr lds, vi off, vb p) { const vd v = lds[p ? off : 0]; return p ? v : 0.0; }
     static NDP_D void stp(lds_ptr lds, vi off, vd v, vb p) { if (p) lds[off] = v; }
     static NDP_D void st(lds_ptr lds, vi off, vd v) { lds[off] = v; }
     static NDP_D void pin() { __builtin_amdgcn_sched_barrier(0); }   // instruction-scheduling fence only

@@ -104,6 +104,7 @@ struct Wave {
         for (int l = 0; l < 64; ++l) { if (off.v[l] & 1) __builtin_trap(); chk(off.v[l]); chk(off.v[l] + 1); a.v[l] = lds[off.v[l]]; b.v[l] = lds[off.v[l] + 1]; }
     }
     static vd ldp(const double *lds, const vi &off, const vb &p) { vd o; stats().lds_ld++; for (int l = 0; l < 64; ++l) { if (p.v[l]) { chk(off.v[l]); o.v[l] = lds[off.v[l]]; } else o.v[l] = 0.0; } return o; }
+    static vd ldz(const double *lds, const vi &off, const vb &p) { return ldp(lds, off, p); }
     static void stp(double *lds, const vi &off, const vd &val, const vb &p) { stats().lds_st++; for (int l = 0; l < 64; ++l) if (p.v[l]) { chk(off.v[l]); lds[off.v[l]] = val.v[l]; } }
     static void st(double *lds, const vi &off, const vd &val) { stats().lds_st++; for (int l = 0; l < 64; ++l) { chk(off.v[l]); lds[off.v[l]] = val.v[l]; } }
     static void pin() {}
