@@ -941,12 +941,12 @@ def main():
                 prof = {"kernel_us": None, "traffic": None, "wave_cycles_per_simd": None, "tag": prof["tag"]}
             # matrix-pipe occupancy estimate: a v_mfma_f64_16x16x4 / v_mfma_f32_32x32x2 holds the SIMD's pipe 64 cycles, the four-block
             # v_mfma_f64_4x4x4 16, a v_mfma_f32_32x32x16_f16 32 (scripts/ubench; PMC SQ_VALU_MFMA_BUSY_CYCLES of the committed profile
-            # = 147 * 64 + 119 * 16 + 12 * 64 + 96 * 32 per instance exactly).  One instance per SIMD; per full sweep at horizon N:
+            # = 143 * 64 + 119 * 16 + 12 * 64 + 96 * 32 per instance exactly).  One instance per SIMD; per full sweep at horizon N:
             # 6 + 7 (N-1) + 4 per re-symmetrisation on the 16x16x4 form, 2 (N-1) + 1 + 4 N on the four-block form (a corrector
             # solve of the interior-point loop is counted as a full sweep here: an upper estimate for those workloads).  The shader
             # clock is MEASURED: wave-cycles per SIMD of the committed PMC pass over the committed kernel duration when the profile
             # belongs to this configuration, else the in-kernel stamp span of one launch over its HIP-event duration.
-            n_16 = sweeps * (6 + 7 * (N - 1) + 4 * ((N - 1) // 8))
+            n_16 = sweeps * (6 + 7 * (N - 1) + 4 * ((N - 1) // 10))
             n_4 = sweeps * (2 * (N - 1) + 1 + 4 * N)
             pipe_cycles = (n_16 * 64 + n_4 * 16 + ((12 * 64 + 96 * 32) if fused else 0)) * -(-B // 1024)      # instances per SIMD (1024 SIMDs), in rounds
             clock_hz, clock_src = None, None

@@ -189,6 +189,7 @@ template <class W, int NSLOT, int NC = 0, bool HT = false, int NR = 0, int PREC 
 struct RtiWave {
     static NDP_D int horizon(const RtiParams &P) { return NC ? NC : P.N; }
     static constexpr int UNROLL_STAGES = NC > 0 ? NC : 1;
+    static constexpr int RESYM = 10;      // riccati_sweep: stages between two re-symmetrisations of H~
     using vd = typename W::vd;
     using vi = typename W::vi;
     using vb = typename W::vb;
@@ -1031,10 +1032,11 @@ struct RtiWave {
             if constexpr (MMA4) Ktq = mma4(hux, nli, W::to_m(vd(0.0)));     // K~'[4b + i][j] in lane j + 4b + 16i
             else Ktp = mma(hux, nli, W::mzero4());
             kprev = k;
-            if ((k & 7) == 0) {
+            if (k % RESYM == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
                 // therefore propagates with the OPEN-loop map (x2.2 per stage measured) instead of contracting:
-                // re-symmetrise every 8th stage (growth x550 in between: 1e-16 -> 5e-14).  H~' = (H~ as A operand) x I costs four MFMAs, no LDS.
+                // re-symmetrise every RESYM-th stage (10: growth x2.6e3 in between, 1e-16 -> 3e-13; one re-symmetrisation per sweep at N = 20,
+                // three at N = 40).  H~' = (H~ as A operand) x I costs four MFMAs, no LDS.
                 md ey[4];          // identity as B operand: chunk c, lane (g, j) = [j == 4c + g] -- made here, every 8th stage, not kept
                 {
                     vi ln = W::lane_here();

@@ -42,7 +42,7 @@ def test_nominal_batch_matches_oracle(oracle, qp_mode):
         if qp_mode == 0:
             # 16x16x4: prologue 6, 7 per backward stage (19), 2 re-symmetrisations x 4; four-block 4x4x4: adj T and K~' per backward
             # stage, K~' of stage 0, 4 per forward stage (matrix x vector)
-            assert it == 0 and cnt["mfma"] == 6 + 7 * 19 + 2 * 4 and cnt["mfma4"] == 2 * 19 + 1 + 4 * 20
+            assert it == 0 and cnt["mfma"] == 6 + 7 * 19 + 1 * 4 and cnt["mfma4"] == 2 * 19 + 1 + 4 * 20
         else:
             assert it == sto.ipm_iters                      # same algorithm, same iteration count
 
