@@ -922,12 +922,12 @@ struct RtiWave {
             // re-symmetrisation below); rows 12..15 of the result are T = H~ux M~_{k-1}
             //   M~'' H~xu = (H~ux M~')' = T', hence  H~' = [C~' + M~'' (H~xx M~')] - T' Lam^-1 T:
             // the bracket needs no Lam^-1, only two dependent MFMAs (adj T, then the rank-4 correction) follow it.
-            // Issue order (every pin() keeps the compiler from regrouping): a wave issues nothing under its own MFMA, and a
-            // DEPENDENT f64 VALU op waits ~32 cycles for its operand.  The inverse's dependency chain (cofactor 5 levels,
-            // determinant 3, 1/det 2, scale 1) is cut into pieces placed behind the MFMAs that do not need it; the tail that
-            // nothing can follow (1/det -> scale -> last MFMA) carries the stage's independent instructions, the operand
-            // prefetch of stage k-2, between its levels.  Measured: worth ~1 % of the sweep -- what counts is the number of
-            // instructions and of chain levels (dropping the second Newton step of 1/det saved 5 %), not their order.
+            // Issue order: a wave issues nothing under its own MFMA, and a DEPENDENT f64 VALU op waits ~32 cycles for its operand.  The
+            // inverse's dependency chain (cofactor 5 levels, determinant 3, 1/det 2, scale 1) is written in pieces between the MFMAs that
+            // do not need it; what counts is the number of instructions and of chain levels (dropping the second Newton step of 1/det
+            // saved 5 %).  The ORDER is the compiler's: rounds 2-3 pinned it with scheduling fences between the pieces (worth ~1 % then);
+            // once the hot path had its registers to itself (round 4: cold branches marked) the scheduler's own order beat the pinned one
+            // by 3 % (20.65 against 21.30 us per step, interior point always 59.8 against 63.6) and the fences went.
             if constexpr (ROBUST) {
                 // a cold path, written for few live registers (no operand prefetch, nothing carried between stages but H~): what is
                 // live here at its widest is what the allocator parks for the whole kernel, the hot sweep included
@@ -965,65 +965,49 @@ struct RtiWave {
             }
             LamRegs LR;
             lam_gather(T, lds, W::to_d(hux), LR);
-            W::pin();
             md4 Wf = mman<3>(H.r, mk, W::mzero4());
-            W::pin();
             if (kprev >= 0) {
                 if constexpr (MMA4) W::st(lds, T.kt_st4 + mb(kprev), W::to_d(Ktq));
                 else for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), W::to_d(Ktp.r[c]));
             }
-            W::pin();
             const vd *mm = LR.mm;
             vd p0 = mm[4] * mm[8], p1 = mm[3] * mm[8], p2 = mm[3] * mm[7];
             vd os = LR.own * T.cof_sign;
-            W::pin();
             md4 Hb;
             for (int r = 0; r < 4; ++r) Hb.r[r] = cc[r];
             if constexpr (!W::packed_k) Hb = mma(mk[0], Wf.r[0], Hb);
-            W::pin();
             vd d0 = p0 - mm[5] * mm[7], d1 = p1 - mm[5] * mm[6], d2 = p2 - mm[4] * mm[6];
-            W::pin();
             if constexpr (!W::packed_k) Hb = mma(mk[1], Wf.r[1], Hb);
-            W::pin();
             vd cx = mm[0] * d0, cy = mm[1] * d1;
-            W::pin();
             if constexpr (W::packed_k) Hb = mman<3>(mk, Wf.r, Hb);
             else Hb = mma(mk[2], Wf.r[2], Hb);
-            W::pin();
             vd cz = cx + mm[2] * d2;
             vd oy = os * cy;
-            W::pin();
             // unsigned cofactor cz - cy (the 3x3 minor's determinant) and, one level earlier than through it, this lane's
             // term of the row expansion of det: own * sign * (cz - cy)
             vd dq = os * cz - oy;
             vd cofu = cz - cy;
-            W::pin();
             dq = dq + W::csum1(dq);                           // the four lanes holding one row of Lam (a quad in the f64 layout)
             vd ladj = cofu * T.adj_a;                         // A operand: adj(Lam)[g][j], j < 4 (sign and lane mask in one factor)
             vd nahi;                                          // B operand of K~': -adj[g][j-12] in columns 12..15
             if constexpr (MMA4) nahi = -ladj;                 // (four-block form: every block reads its own copy, adj_b = -adj_a; the sign rides on the consumer)
             else nahi = cofu * T.adj_b;
-            W::pin();
             md tt = Wf.r[3];                                  // T = H~ux M~' (rows 12..15 of Wf)
             md G0;                                            // adj T, lane l: row l >> 4, column l & 15
             if constexpr (MMA4) G0 = mma4(W::to_m(ladj), tt, W::to_m(vd(0.0)));
             else G0 = mma(W::to_m(ladj), tt, W::mzero4()).r[0];
-            W::pin();
             vd det = dq + W::csum2(dq);
             vd r0 = W::rcp_seed(det);
             for (int c = 0; c < 3; ++c) nmk[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(kp)));
-            W::pin();
             // 1/det = r0 (2 - det r0): v_rcp_f64 seed (4.5e-8) + ONE Newton step = 2.2e-15 (profiles/r01_ubench_mfma_latency.txt),
             // below the cofactors' own cond * eps.  The scale of Lam^-1 T is applied as (G r0) e0 so that G r0 runs beside e0.
             vd e0 = W::fma(-det, r0, vd(2.0));
             vd g0 = W::to_d(G0) * r0;
             for (int r = 0; r < 2; ++r) ncc[r] = W::to_m(W::ld(lds, T.c_off[r] + cb(kp)));
-            W::pin();
             vd gs = g0 * e0;                                  // Lam^-1 T
             vd rdet = r0 * e0;
             for (int r = 2; r < 4; ++r) ncc[r] = W::to_m(W::ld(lds, T.c_off[r] + cb(kp)));
             okv = okv && (det > 0.0) && (!T.lam_diag || (cofu > 0.0));   // on the diagonal the cofactor's sign factor is +1
-            W::pin();
             md4 Hn = mma(-tt, W::to_m(gs), Hb);               // - T' Lam^-1 T on top of the bracket
             // K~' = H~ux' (-Lam^-1): the 1/det rides in the B operand (one multiply instead of one per result register); lands in
             // column 12+b = rows 12..15 of the forward operand; stored behind the next stage's first MFMAs
@@ -1105,7 +1089,6 @@ struct RtiWave {
             const int kn = k + 1 < N ? k + 1 : k;
             for (int c = 0; c < 3; ++c) nfw[c] = W::to_m(W::ld(lds, T.fw_off[c] + mb(kn)));
             nmu = W::to_m(W::ld(lds, T.mu_off + mb(kn)));
-            W::pin();   // keep the prefetch ahead of this stage's MFMAs (the scheduler otherwise sinks it behind them)
             if constexpr (MMA4) {
                 // four 4x4x4 products (a matrix-VECTOR product needs one column): y[4b + i] in lane j + 4b + 16i, any j
                 md y = mma4(fw[0], zc[0], W::to_m(vd(0.0)));
@@ -1237,7 +1220,6 @@ struct RtiWave {
                     for (int c = 0; c < 3; ++c) na[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(k - 1)));
                     nkta = W::to_m(W::ld(lds, D.kta_off + mb(k - 1)));
                 }
-                W::pin();
                 md akl = kta + W::fma(linv_get(linv, k), D.m12, -D.eye12);
                 if (FROM_ZD || k != N - 1)
                     for (int c = 0; c < 3; ++c) Dg = mma4(a[c], vc[c], Dg);
@@ -1266,7 +1248,6 @@ struct RtiWave {
                     nzx0 = W::ld(lds, T.zx_st4 + (k + 2) * int(NX));
                     ndk = W::to_m(W::ld(lds, D.dk_off + (k + 1) * int(NU)));
                 }
-                W::pin();
                 md y = W::to_m(vd(0.0)), du = dkk;
                 if (k != 0) {
                     for (int c = 0; c < 3; ++c) y = mma4(fw[c], zc[c], y);
