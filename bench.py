@@ -1098,7 +1098,7 @@ def main():
                 for Bq in (2 * B, 8 * B):      # two and eight instances per SIMD
                     mt = mixed_ticks(Bq)
                     e_q = ndp.BatchedNMPC(Bq, N=N, disturbance=downwash, device=local_rank)          # the automatic choice
-                    out["mixed"]["batch_%d" % Bq] = timed_leg(e_q, mt, 30)
+                    out["mixed"]["batch_%d" % Bq] = timed_leg(e_q, mt, 30, n_warm=40)     # (the automatic rule decides within 16-24 steps)
                     auto_on = e_q.work_queue
                     del e_q
                     for wq, name in ((1, "work_queue_on"), (2, "work_queue_off")):
@@ -1106,7 +1106,7 @@ def main():
                             out["mixed"]["batch_%d_%s" % (Bq, name)] = dict(out["mixed"]["batch_%d" % Bq])
                             continue
                         e_q = ndp.BatchedNMPC(Bq, N=N, disturbance=downwash, device=local_rank, work_queue=wq)
-                        out["mixed"]["batch_%d_%s" % (Bq, name)] = timed_leg(e_q, mt, 30)
+                        out["mixed"]["batch_%d_%s" % (Bq, name)] = timed_leg(e_q, mt, 30, n_warm=40)
                         del e_q
                     del mt
                 # ---- the metric as SURVEY 8d words it: host arrays in, host arrays out (H2D of the inputs and D2H of u0 inside the

@@ -60,8 +60,12 @@ typedef struct ndp_cfg {
                            * 3 / 4 run the Riccati sweeps on the fp32 / bf16-input matrix instructions (everything else stays
                            * fp64); 1 / 2 are the first round's operand-rounding studies on the fp64 kernel */
     int32_t work_queue; /* instances whose QP needs the interior-point loop are re-distributed over all SIMDs through an
-                         * work list (producer + consumer launch per step): 0 = automatic (qp_mode AUTO and batch >= 2 x the device's
-                         * SIMD count, or the N = 40 / 2-iteration shape at any batch), 1 = on, 2 = off */
+                         * work list (producer + consumer launch per step): 0 = automatic, 1 = on, 2 = off.  Automatic: the N = 40 /
+                         * 2-iteration shape always takes the list; the reference shape (N = 20, 1 iteration) with qp_mode AUTO and a
+                         * batch >= 2 x the device's SIMD count starts in place and switches by what its steps do -- the list on when
+                         * >= 4 % of the instances of a window of 8 steps went into the interior-point loop, off at <= 1.5 % (the list
+                         * costs a step that lists nothing 8-15 %, and gains 70 % when a fifth of the instances iterate); decided at
+                         * launch time, so a captured graph keeps its form */
     int32_t ipm_refine; /* interior point: while a STATE bound's barrier term lambda / t exceeds refine_gamma, the 4x4 block is
                          * factorised L D L' and applied by substitution (an explicit inverse costs the recursion its definiteness
                          * there) and every Newton system's solution is refined this many times with the factorisation at hand
@@ -212,7 +216,7 @@ void *ndp_device_iterate_x(ndp_handle *h);
 void *ndp_device_iterate_u(ndp_handle *h);
 void *ndp_device_force(ndp_handle *h);   /* [B][N+1][3] fp32 written by the fused downwash */
 int ndp_synchronize(ndp_handle *h);
-int ndp_work_queue_enabled(ndp_handle *h);   /* 1 if this handle's steps run the interior-point work queue (cfg.work_queue) */
+int ndp_work_queue_enabled(ndp_handle *h);   /* 1 if the handle's NEXT step runs the interior-point work list (cfg.work_queue; the automatic rule's current state) */
 
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on:
  * on = n > 0 brackets every n-th launch of each kernel (n = 1: every launch), on = 0 stops and clears.

@@ -115,6 +115,9 @@ __device__ __forceinline__ ndp_d2 ld_other2(const double *p, int sys)
 struct QueueArgs {
     unsigned *count;        // entries of ids
     int *ids;               // [B]
+    unsigned long long *ipm_total;   // [0] monotonic: instances that needed the interior-point loop (in place: counted by the kernel; work
+                                     // list: added up by the reset launch); [1] monotonic: control steps executed (one count per launch) --
+                                     // the pair the handle's automatic work-list rule looks at (queue_policy)
 };
 
 typedef __attribute__((address_space(3))) float *lds_f32;
@@ -220,6 +223,9 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     const size_t nf = (size_t)(N + 1) * 3;
     RtiIo io;
     bind_instance(io, bp, inst, N);
+    if (NSLOT <= 3 && (QMODE == 0 || QMODE == 3)) io.ipm_ctr = qa.ipm_total;
+    if (NSLOT <= 3 && QMODE != 2 && blockIdx.x == 0 && threadIdx.x == 0 && qa.ipm_total)
+        __hip_atomic_fetch_add(qa.ipm_total + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!FUSED && (QMODE == 0 || QMODE == 3) && ka.la.proto) {
         // this launch is control step number t; its force was written into slot t & 1 by downwash launch t
         const LateArgs &la = ka.la;
@@ -417,9 +423,12 @@ __global__ void mfma_probe32_kernel(const float *a, const float *b, const float 
 }
 
 // behind the work list's consumer launch: the list is empty again for the next step's producer
-__global__ void queue_reset_kernel(unsigned *count)
+__global__ void queue_reset_kernel(unsigned *count, unsigned long long *ipm_total)
 {
-    if (threadIdx.x == 0) *count = 0u;
+    if (threadIdx.x == 0) {
+        *ipm_total += *count;
+        *count = 0u;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ MLP kernel
@@ -1453,6 +1462,12 @@ struct ndp_handle {
     int waves = 4;             // instances per workgroup
     int n_simd = 1024;         // SIMDs of the device (4 per CU)
     bool use_queue = false;    // interior-point solves through the work list: producer + consumer launch per step (QueueArgs)
+    // cfg.work_queue = 0 at (N, n_rti) = (20, 1), batch >= 2 instances per SIMD: the list is switched by what the steps do (queue_policy)
+    bool queue_auto = false;
+    unsigned long long *hIpm = nullptr;      // page-locked [2]: the device's monotonic counts (interior-point instances, steps executed),
+                                             // copied behind every QP_WINDOW-th launch
+    unsigned long long ipm_seen = 0, steps_seen = 0;   // the snapshot the last decision was taken on
+    unsigned queue_launches = 0;             // launches since the last copy was enqueued
     hipStream_t stream = nullptr;
     // persistent device state
     double *dX = nullptr, *dU = nullptr;
@@ -1890,6 +1905,10 @@ int ndp_destroy(ndp_handle *h)
         if (sl.hOut) (void)hipHostFree(sl.hOut);
         if (sl.evOut) (void)hipEventDestroy(sl.evOut);
     }
+    if (h->hIpm) {                          // (a copy into it may still be queued on a caller's stream)
+        (void)hipDeviceSynchronize();
+        (void)hipHostFree(h->hIpm);
+    }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -1942,11 +1961,8 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         if ((e = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
         h->n_simd = 4 * prop.multiProcessorCount;
     }
-    // work list: by default when the batch holds at least two instances per SIMD and the QP mode has an early exit to defer
-    // from.  With one instance per SIMD nothing can be re-balanced; above that the list's fixed cost per step (a consumer
-    // launch whose workgroups read the counter and leave when nothing was listed, and a one-wave reset launch) is a few per
-    // cent of a step that needs no interior-point solve, against +20 % .. 2x when a fifth of the instances do -- callers who
-    // know their workload set cfg.work_queue = 1 / 2.
+    // work list: with one instance per SIMD nothing can be re-balanced; with two or more it is switched by what the steps do
+    // (queue_policy) -- callers who know their workload set cfg.work_queue = 1 / 2.
     // The N = 40 / 2-iteration shape always takes the list: its producer kernel carries no interior-point code and does not
     // spill, which is worth 17 % even when nothing is listed (the in-place kernel of that shape uses 0.9 KB of scratch per lane)
     if (cfg->work_queue == 1 && !(queue_shape(h) && cfg->qp_mode == NDP_QP_AUTO)) {
@@ -1954,8 +1970,14 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         delete h;
         return -2;
     }
-    h->use_queue = cfg->work_queue == 1 ||
-                   (cfg->work_queue == 0 && queue_shape(h) && cfg->qp_mode == NDP_QP_AUTO && (cfg->batch >= 2 * h->n_simd || cfg->N == 40));
+    // reference shape, two or more instances per SIMD, cfg.work_queue = 0: in place to begin with, the list when the steps ask for it
+    // (queue_policy)
+    h->queue_auto = cfg->work_queue == 0 && queue_shape(h) && cfg->qp_mode == NDP_QP_AUTO && cfg->N == 20 && cfg->batch >= 2 * h->n_simd;
+    h->use_queue = cfg->work_queue == 1 || (cfg->work_queue == 0 && queue_shape(h) && cfg->qp_mode == NDP_QP_AUTO && cfg->N == 40);
+    if (h->queue_auto) {
+        if ((e = hipHostMalloc((void **)&h->hIpm, 64, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc (work-list counter)", e);
+        h->hIpm[0] = h->hIpm[1] = 0;
+    }
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&h->evLast, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     const size_t B = cfg->batch;
@@ -2120,6 +2142,31 @@ struct StepOut {               // where a step's status / iteration counts go an
     hipEvent_t done = nullptr; // marked by the step's last launch through its own dispatch packet (no event packet behind it), or null
 };
 
+// The automatic work-list rule (cfg.work_queue = 0, reference shape, at least two instances per SIMD).  The list re-balances interior-
+// point solves over all SIMDs (+70 % at batch 4096 when a fifth of the instances iterate) but costs a step that lists nothing two more
+// launches and a slower producer kernel: 8-15 % (batch 2048: 45.4 against 39.5 us; 16 384: 332 against 309 us).  So the handle starts in
+// place and looks at what the steps do: the device keeps two monotonic counts -- instances that went into the interior-point loop (counted
+// by the in-place kernel, added up by the list's reset launch) and control steps executed -- and a 16-byte copy of the pair is enqueued
+// behind every QP_WINDOW-th launch.  Whenever a snapshot that covers QP_WINDOW more executed steps has LANDED (the host may be many
+// launches ahead of the device), the fraction over those steps switches the list on at >= 4 %, off at <= 1.5 %.  Evaluated at launch
+// time: a captured graph keeps the form it was captured in.
+enum { QP_WINDOW = 8 };
+static void queue_policy(ndp_handle *h, hipStream_t s)
+{
+    if (!h->queue_auto) return;
+    const unsigned long long steps_now = ((volatile unsigned long long *)h->hIpm)[1], ipm_now = ((volatile unsigned long long *)h->hIpm)[0];
+    if (steps_now >= h->steps_seen + QP_WINDOW && ipm_now >= h->ipm_seen) {
+        const double frac = (double)(ipm_now - h->ipm_seen) / ((double)(steps_now - h->steps_seen) * (double)h->cfg.batch);
+        if (frac >= 0.04) h->use_queue = true;
+        else if (frac <= 0.015) h->use_queue = false;
+        h->ipm_seen = ipm_now;
+        h->steps_seen = steps_now;
+    }
+    if (++h->queue_launches < QP_WINDOW) return;
+    h->queue_launches = 0;
+    if (hipMemcpyAsync(h->hIpm, reinterpret_cast<unsigned long long *>(h->dQctr + 16), 16, hipMemcpyDeviceToHost, s) != hipSuccess) (void)hipGetLastError();
+}
+
 static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, const double *d_ur, const float *d_f,
                       double *d_u0, double *d_dbg, hipStream_t s, const Neigh *nb = nullptr, const StepOut *so = nullptr,
                       bool prefetched = false)
@@ -2131,7 +2178,7 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     const bool fused = nb && nb->other;
     MlpArgs ma{fused ? h->dFrag : nullptr, fused ? nb->other : nullptr, fused ? nb->ego_xy : nullptr, h->dForce,
                h->cfg.r_horiz * h->cfg.r_horiz, fused ? nb->stride : NX, fused ? nb->index : nullptr, fused ? peer_mapped(nb->other) : 0};
-    QueueArgs qa{h->dQctr, h->dQids};
+    QueueArgs qa{h->dQctr, h->dQids, reinterpret_cast<unsigned long long *>(h->dQctr + 16)};
     const int B = h->cfg.batch, W = h->waves;
     LateArgs la{prefetched ? h->dProto : nullptr, {h->dForceAB[0], h->dForceAB[1]}, h->prefetch_timeout_us,
                 h->pf_groups_rti, h->pf_ntiles};
@@ -2139,7 +2186,7 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     const dim3 grid((B + W - 1) / W), block(64 * W);
     const size_t shm = (size_t)h->lds_per_wave * sizeof(double) * W;
     const int ns = slots_for(h->cfg.N);
-    const bool q = h->use_queue && !d_dbg;
+    const bool q = h->use_queue && !d_dbg && !prefetched;      // (the late-force step is in place: its launch is the lean instantiation)
     // Tracked steps carry their completion event on a dispatch packet (hipExtLaunchKernel), which a stream capture cannot hold:
     // refuse instead of launching something the graph would silently drop the event of.
     h->last_step_tracked = false;
@@ -2207,10 +2254,10 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
             hipLaunchKernelGGL(RTI_K(5, 2, false, 40, 0, 2, 2), grid, block, shm, s, kc);
         }
         NDP_HIP(h, hipGetLastError());
-        if (stop) hipExtLaunchKernelGGL(queue_reset_kernel, dim3(1), dim3(64), 0, s, nullptr, stop, 0, h->dQctr);
-        else hipLaunchKernelGGL(queue_reset_kernel, dim3(1), dim3(64), 0, s, h->dQctr);
+        if (stop) hipExtLaunchKernelGGL(queue_reset_kernel, dim3(1), dim3(64), 0, s, nullptr, stop, 0, h->dQctr, qa.ipm_total);
+        else hipLaunchKernelGGL(queue_reset_kernel, dim3(1), dim3(64), 0, s, h->dQctr, qa.ipm_total);
         NDP_HIP(h, hipGetLastError());
-        return end_timing(h, s);
+        { const int rce = end_timing(h, s); queue_policy(h, s); return rce; }
     }
     if (h->cfg.N == 20 && h->cfg.n_rti == 1 && W == 4) {   // the reference configuration (params/nmpc_params.py:9, 1 RTI iteration): compile-time instantiation
         if (fused) LAUNCH(3, 4, true, 20); else if (prefetched) LAUNCH(3, 4, false, 20, 0, 1, 3); else LAUNCH(3, 4, false, 20);
@@ -2223,7 +2270,7 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     else { if (W == 4) LAUNCH(5, 4, false); else if (W == 2) LAUNCH(5, 2, false); else LAUNCH(5, 1, false); }
 #undef LAUNCH
     NDP_HIP(h, hipGetLastError());
-    return end_timing(h, s);
+    { const int rce = end_timing(h, s); queue_policy(h, s); return rce; }
 }
 
 // downwash inside the RTI launch when one 32-row tile covers the horizon; otherwise mlp_kernel first
@@ -2300,7 +2347,7 @@ static int ensure_prefetch(ndp_handle *h)
 {
     if (h->aux) return 0;
     if (!h->cfg.use_fd) { h->err = "downwash prefetch needs use_fd = 1 (NDP model)"; return -8; }
-    if (h->use_queue) { h->err = "downwash prefetch is not combined with the interior-point work list (set cfg.work_queue = 2)"; return -16; }
+    if (h->use_queue && !h->queue_auto) { h->err = "downwash prefetch is not combined with the interior-point work list (set cfg.work_queue = 2)"; return -16; }
     if (h->cfg.qp_precision) { h->err = "downwash prefetch serves the fp64 product path only"; return -12; }
     if (h->cfg.N + 1 > 32) { h->err = "downwash prefetch needs N + 1 <= 32 (an instance's rows in at most two 32-row tiles)"; return -12; }
     if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }

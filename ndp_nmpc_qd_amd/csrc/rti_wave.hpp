@@ -116,6 +116,8 @@ struct RtiIo {            // global-memory views of ONE instance
     int late_ready = 0;            // 1: the prediction was complete before this launch started -- no wait, ordinary (cached) loads
     unsigned late_timeout_us = 0;
     int *late_missed = nullptr;    // counts waves whose wait timed out (the step then runs with zero force and status 5)
+    unsigned long long *ipm_ctr = nullptr;   // counts (monotonic) the instances whose QP went into the interior-point loop IN PLACE: what the
+                                             // handle's automatic work-list rule looks at (ndp_hip.hip: queue_policy)
     int *late_slow = nullptr;      // counts waves that started before their prediction was complete (epoch path)
     // "done reading" accounting of the force slot (the launch that refills it two ticks later waits for it), see W::late_count
     unsigned *late_cnt = nullptr;          // this workgroup's group counter (monotonic)
@@ -1757,6 +1759,7 @@ struct RtiWave {
             const int zsrc = done ? m.ZX : m.CX;       // ZX|ZU and CX|CU are laid out alike
             if (IPM_RARE ? NDP_RARELY(!done) : !done) {
                 if (DEFER) return true;
+                if constexpr (NSLOT <= 3) { if (io.ipm_ctr && it == 0) W::count64(io.ipm_ctr); }   // (the five-slot kernels sit at the register limit and have no automatic rule)
                 Slots S;
                 build_slots(P, m, S);
                 load_bounds(m, S, lds);

@@ -104,6 +104,7 @@ struct WaveGfx950 {
         return (double)__uint_as_float(bits);
     }
     static NDP_D void count(int *ctr) { if (lane() == 0) atomicAdd(ctr, 1); }
+    static NDP_D void count64(unsigned long long *ctr) { if (lane() == 0) __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     // "this wave has its force values".  Three levels, because an agent-scope atomic on ONE address costs 30-60 ns and they
     // serialise (the eight XCDs' L2s are not coherent: such atomics execute at the memory side) -- one per wave made the launch
     // 36 us instead of 18, one per workgroup (256) still 35: (1) the waves of a workgroup count themselves in an LDS word; (2) the

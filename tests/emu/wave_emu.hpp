@@ -124,6 +124,7 @@ struct Wave {
     static bool wait_ge(const unsigned long long *flag, const unsigned long long *flag2, unsigned long long want, unsigned) { return *flag >= want && *flag2 >= want; }
     static vd gldf_fresh(const float *g, const vi &off) { return gldfu(g, off); }
     static void count(int *ctr) { ++*ctr; }
+    static void count64(unsigned long long *ctr) { ++*ctr; }
     typedef unsigned late_t;
     static late_t late_none() { return 0xffffffffu; }
     static late_t late_count(unsigned *cnt, void *, unsigned) { return cnt ? (*cnt)++ : 0xffffffffu; }

@@ -689,9 +689,49 @@ def test_work_queue_gives_the_same_answers(ndp, oracle, mlp_blob):
         uo, sto, *_ = _oracle_batch(oracle, b, use_fd=disturbance, f=f)
         assert np.array_equal(st, sto)
         _assert_u(u0[sto == 0], uo[sto == 0])
-    # automatic choice: on from two instances per SIMD (and an early-exit QP mode to defer from)
+    # the automatic rule: never below two instances per SIMD; from there on IN PLACE to begin with (the N = 40 / 2-iteration shape: always
+    # the list) -- what the steps do then switches it (test_work_list_switches_itself_on_when_the_steps_iterate)
     assert not ndp.BatchedNMPC(1024).work_queue and not ndp.BatchedNMPC(2047).work_queue
-    assert ndp.BatchedNMPC(2048).work_queue and ndp.BatchedNMPC(4096).work_queue and not ndp.BatchedNMPC(4096, qp_mode=1).work_queue
+    assert not ndp.BatchedNMPC(2048).work_queue and not ndp.BatchedNMPC(4096, qp_mode=1).work_queue
+    assert ndp.BatchedNMPC(256, N=40, n_rti=2).work_queue
+
+
+def test_work_list_switches_itself_on_when_the_steps_iterate(ndp, oracle):
+    """cfg.work_queue = 0 at two instances per SIMD: the handle starts in place; the device's counts of interior-point instances and of
+    executed steps come back every 8th launch, and the list goes on once >= 4 % of a window's instances iterated, off again at <= 1.5 %.
+    Same answers in either form (status, iteration counts equal; controls to rounding) -- here: perturbed starts (a fifth iterate) switch
+    it on within 24 steps, nominal starts switch it off again, and the controls of the automatic engine equal those of the forced forms."""
+    B = 2048
+    hard = synth.make_batch(B, seed=57, downwash=False, pos_sigma=0.5, vel_sigma=1.0, quat_sigma=0.15)
+    easy = synth.make_batch(B, seed=57, downwash=False)
+    eng = ndp.BatchedNMPC(B)
+    ref = {wq: ndp.BatchedNMPC(B, work_queue=wq) for wq in (1, 2)}
+    assert not eng.work_queue and ref[1].work_queue and not ref[2].work_queue
+
+    def run(b, n):
+        states = []
+        for e in (eng, ref[1], ref[2]):
+            e.reset(b["xr"], b["ur"])
+        for _ in range(n):
+            outs = [e.update(b["x0"], b["xr"], b["ur"], raise_on_status=False, full=True) for e in (eng, ref[1], ref[2])]
+            for o in outs[1:]:
+                assert np.array_equal(outs[0][3], o[3]) and np.array_equal(outs[0][4], o[4])
+                np.testing.assert_allclose(outs[0][0], o[0], rtol=0, atol=1e-8)
+            states.append(eng.work_queue)
+            for e in (eng, ref[1], ref[2]):       # every tick from the same start: the workload stays what it is
+                e.reset(b["xr"], b["ur"])
+        return states, outs[0]
+
+    states, out = run(hard, 28)
+    assert 0.05 < (out[4] > 0).mean() < 0.6
+    assert not states[0] and states[-1] and sum(states) >= 4, states
+    first_on = states.index(True)
+    assert 8 <= first_on <= 24 and all(states[first_on:]), states
+    states, out = run(easy, 28)
+    assert (out[4] > 0).mean() < 0.01
+    assert states[0] and not states[-1] and not any(states[states.index(False):]), states
+    for e in (eng, ref[1], ref[2]):
+        e.close()
 
 
 def test_neighbour_rows_by_index_and_six_column_windows(ndp):
@@ -1456,8 +1496,8 @@ def test_downwash_prefetch_misuse_is_bounded_and_reported(ndp):
     assert st["predictions"] == 5 and st["slot_timeouts"] >= 1, st
     with pytest.raises(ndp.batched.NdpError):
         ndp.BatchedNMPC(B).downwash_prefetch_device(d["other"], d["xr"])           # plain NMPC model: no force input
-    big = ndp.BatchedNMPC(4096, disturbance=True)                                  # work list on (two instances per SIMD and more): not combined
-    with pytest.raises(ndp.batched.NdpError):
+    big = ndp.BatchedNMPC(4096, disturbance=True, work_queue=1)                    # work list forced on: not combined (the automatic rule
+    with pytest.raises(ndp.batched.NdpError):                                      # keeps the late-force step in place instead)
         big.downwash_prefetch_device(d["other"], torch.zeros(4096, 21, 10, dtype=torch.float64, device=dev),
                                      other_index=torch.zeros(4096, dtype=torch.int32, device=dev))
 
