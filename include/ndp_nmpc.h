@@ -39,6 +39,13 @@ extern "C" {
 #define NDP_NU 4
 #define NDP_MLP_NPARAM 17859 /* 6-128-64-128-3 with biases, nn_net.py:7-18 */
 
+/* Version of this interface: bumped whenever an exported signature or the layout of ndp_cfg changes.  A binding built against
+ * another header must refuse to run: ndp_abi_version() is what the loaded library was built with, ndp_cfg_size() its
+ * sizeof(ndp_cfg) (ndp_create / ndp_default_cfg read and write that many bytes of the caller's struct). */
+#define NDP_ABI_VERSION 5
+int ndp_abi_version(void);
+size_t ndp_cfg_size(void);
+
 #define NDP_QP_AUTO 0       /* exact early exit when no bound is active, else interior point */
 #define NDP_QP_IPM_ALWAYS 1 /* always run the interior-point loop (what HPIPM does) */
 
@@ -72,7 +79,12 @@ typedef struct ndp_cfg {
                          * (default 2; 0 = never: round 3's loop).  The loop is in absolute form, so an iteration's answer is as
                          * accurate as its last solve -- cond ~ lambda / t.
                          * The reference's velocity box (+-20 m/s, nmpc_body_rate_ctl.py:59-61) is never active in its envelope:
-                         * this only acts on boxes shrunk on purpose.  Compile-time horizons (N = 20, N = 40 / 2 iterations) only. */
+                         * this only acts on boxes shrunk on purpose.
+                         * WHERE IT ACTS: the three-slot kernels only (N <= 27: run-time and compile-time horizons alike), in place and
+                         * through the work list.  The five-slot kernels (N >= 28, e.g. config 5's N = 40) and the lean late-force step
+                         * (ndp_step_device_prefetched) carry no stiff sweep and no second solve -- they sit at the register limit -- and
+                         * IGNORE ipm_refine / refine_gamma: a strongly active state bound at a tight tolerance ends in status 4 there,
+                         * never in a silent answer.  ndp_refine_active() tells which of the two a handle is. */
     double dt;          /* T_horizon / N_node        params/nmpc_params.py:10,12  */
     double mass;        /* params/fhnp_params.py:9   */
     double gravity;     /* params/fhnp_params.py:12  */
@@ -138,6 +150,13 @@ int ndp_step_device(ndp_handle *h, const void *d_x0, const void *d_xr, const voi
 int ndp_step_ex(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
                 const double *other, const double *ego_xy, double *u0, double *X_out, double *U_out,
                 int32_t *status_out, int32_t *ipm_iters_out);
+/* ndp_step_ex with the disturbance force in DOUBLE precision, f[B][N+1][3] fp64 (or NULL).  The reference concatenates the force
+ * into a float64 parameter vector (p_k = [q_r, f_k], ndp_nmpc_body_rate_ctl.py:97-99) and hands that to acados: its own caller
+ * only ever supplies DownwashNN's fp32 values (downwash_nn.py:28), for which this call and ndp_step_ex agree bit
+ * for bit, but any other caller of the same Python API gets its float64 force to the last digit only through this entry (the
+ * fp32 form would round it: 6e-8 relative).  The drop-in class's .solver facade always takes this one. */
+int ndp_step_ex_f64(ndp_handle *h, const double *x0, const double *xr, const double *ur, const double *f, double *u0,
+                    double *X_out, double *U_out, int32_t *status_out, int32_t *ipm_iters_out);
 /* The same step in two halves, so that a caller can keep two control ticks in flight: ndp_step_begin packs the inputs into a
  * slot's page-locked mirror, enqueues ONE launch -- whose waves read that mirror over PCIe and write u0 / status / iterations into
  * the slot's page-locked output block themselves (zero-copy: no H2D / D2H copy operation) -- and returns without waiting;
@@ -216,6 +235,7 @@ void *ndp_device_iterate_x(ndp_handle *h);
 void *ndp_device_iterate_u(ndp_handle *h);
 void *ndp_device_force(ndp_handle *h);   /* [B][N+1][3] fp32 written by the fused downwash */
 int ndp_synchronize(ndp_handle *h);
+int ndp_refine_active(ndp_handle *h);        /* 1: cfg.ipm_refine > 0 and this handle's control steps carry the refinement path (see ndp_cfg.ipm_refine); 0: ignored */
 int ndp_work_queue_enabled(ndp_handle *h);   /* 1 if the handle's NEXT step runs the interior-point work list (cfg.work_queue; the automatic rule's current state) */
 
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on:
@@ -274,14 +294,57 @@ int ndp_ref_window_device(ndp_handle *h, const void *d_t, void *d_xr, void *d_ur
  *                         reference's value although u[3] is an acceleration) or [0, 0, 0, g] (quirk_b1 = 0)
  *   ndp_ref_list_window : t[B] = (ros_t - start_ros_t).to_sec(): get_nmpc_pts (:79-97) = pop, append the point at
  *                         t + T_horizon, return the window; t = NULL: get_nmpc_ref_from_long_list only (:99-103)
- *   *_device            : the two halves separately, on device buffers.  The ring's head is host state baked into each
+ *   *_device            : the two halves separately, on device buffers.  The list position is host state baked into each
  *                         launch's arguments: these calls must NOT be captured into a hipGraph (a replay would reuse the
- *                         slot of the captured tick); ndp_ref_window_device has no such state and is capturable. */
+ *                         position of the captured tick); ndp_ref_window_device has no such state and is capturable.
+ * Device layout: phase-major, every entry stored twice, so that every window is contiguous (csrc/ndp_hip.hip: RingGeom) -- the
+ * stand-alone window call is a dense copy and ndp_tick's control step reads its windows in place. */
 int ndp_ref_list_reset(ndp_handle *h);
 int ndp_ref_list_fix_pt(ndp_handle *h, const double *x_odom, int quirk_b1);
 int ndp_ref_list_window(ndp_handle *h, const double *t, double *xr, double *ur);
 int ndp_ref_list_advance_device(ndp_handle *h, const void *d_t, void *stream);
 int ndp_ref_list_window_device(ndp_handle *h, void *d_xr, void *d_ur, void *stream);
+
+/* ---- The node's control tick, end to end on the device: odometry in, actuator command out, references resident.
+ * Replaces, per vehicle and control period, ControllerNode.nmpc_callback + hover_throttle_callback (nmpc_node.py:211-231,251-253):
+ *     nmpc_x_ref, nmpc_u_ref = ref_pub.get_nmpc_pts(now)        (:162; pt_pub/pt_publisher.py:78-103)   -- f1, the list on the device
+ *     k_throttle = hv_th_estimator.update(vz, body_rate_cmd.thrust)   (:251-253)                         -- f3
+ *     u0 = nmpc_ctl.update(x0, nmpc_x_ref, nmpc_u_ref[, disturb_force])   (:202-209,223-224)            -- a5 / a6, a7, a8
+ *     body_rate_cmd = nmpc_u_2_att_tgt(*u0)                    (:225,273-283)                            -- f3
+ * with the downwash force predicted from the NEIGHBOUR's window of the same tick (ndp_nmpc_leader_node.py:60-76; the neighbour
+ * is another instance of this handle: its window is read out of its list, nothing is copied) and gated on the ego ODOMETRY xy
+ * (:65-74).  Only what is new information crosses PCIe: 80 bytes of odometry per vehicle and tick (+ 8 each for t,
+ * vz, throttle when given) in, 32 bytes of command (+ 4 status) out -- against 3.4 KB per vehicle for ndp_step's x0 + xr + ur +
+ * neighbour columns.  Two launches per tick: tick_pre_kernel (list advance + estimator) and the control step, which reads its
+ * window -- and the neighbour's -- straight out of the list (the phase-major layout makes every window contiguous) and writes the
+ * actuator command itself, beside u0.
+ *   ndp_tick_config : other_index[B] = the instance whose window is vehicle i's neighbour (< 0: none, plain NMPC vehicle), or NULL
+ *                     = no vehicle has one; gate_on_odometry = 1: the r_horiz gate of ndp_nmpc_leader_node.py:65-74, 0: always open.
+ *                     Neighbours need use_fd = 1 and ndp_set_mlp_weights.
+ *   ndp_tick_reset  : nmpc_ctl.reset(*ref_pub.get_nmpc_ref_from_long_list()) (nmpc_node.py:92,151-152): iterate := the list's
+ *                     current window.  Call after ndp_ref_list_fix_pt (start-up) / ndp_ref_list_reset (a new trajectory).
+ *   ndp_tick_begin  : x_odom[B][10] = odom_2_nmpc_x(px4_odom) of every vehicle; t[B] = (ros_t - start_ros_t).to_sec() -> the
+ *                     list is advanced (get_nmpc_pts), or NULL -> the list stays (hover at the fixed point; a vehicle whose
+ *                     trajectory has ended keeps being advanced: its points are final_pt); vz[B] or NULL = x_odom[:,5];
+ *                     throttle[B] or NULL = the thrust this handle commanded on the previous tick (0 before the first).
+ *                     flags bit 0: run the estimator this tick (the reference stops its timer while a trajectory is tracked,
+ *                     nmpc_node.py:146,196); bit 1: ndp_tick_end will be asked for u0 as well.  Returns without waiting; at most two
+ *                     ticks (or steps) in flight, drained in order, as with ndp_step_begin.
+ *   ndp_tick_end    : waits for the oldest tick: cmd[B][4] = [wx, wy, wz, thrust]; u0[B][4], status[B], ipm_iters[B] or NULL.
+ *                     Returns the worst status.
+ *   ndp_tick        : begin + end under one lock.
+ *   ndp_tick_device : the same launches on device pointers and a caller's stream; d_u0 may be NULL; status: ndp_get_status.
+ *                     The list position is host state baked into the launches: not capturable into a hipGraph. */
+#define NDP_TICK_ESTIMATE 1
+#define NDP_TICK_WANT_U0 2
+int ndp_tick_config(ndp_handle *h, const int32_t *other_index, int gate_on_odometry);
+int ndp_tick_reset(ndp_handle *h);
+int ndp_tick_begin(ndp_handle *h, const double *x_odom, const double *t, const double *vz, const double *throttle, int flags);
+int ndp_tick_end(ndp_handle *h, double *cmd, double *u0, int32_t *status_out, int32_t *ipm_iters_out);
+int ndp_tick(ndp_handle *h, const double *x_odom, const double *t, const double *vz, const double *throttle, int flags,
+             double *cmd, double *u0, int32_t *status_out, int32_t *ipm_iters_out);
+int ndp_tick_device(ndp_handle *h, const void *d_x_odom, const void *d_t, const void *d_vz, const void *d_throttle, int flags,
+                    void *d_cmd, void *d_u0, void *stream);
 
 /* ---- "next" row f4: plant step for closed-loop rollouts on the device (dop_sim is absent from the reference).
  * x[B][10] in/out, u[B][4], f[B][3] force or NULL; RK4 with `substeps` over dt, quaternion renormalised. */

@@ -16,6 +16,8 @@ WEIGHTS_PATH = os.path.join(_HERE, "weights", "downwash_sn4.bin")
 NX, NU = 10, 4
 MLP_NPARAM = 17859
 QP_AUTO, QP_IPM_ALWAYS = 0, 1
+ABI_VERSION = 5          # include/ndp_nmpc.h: NDP_ABI_VERSION (checked against the loaded library in load())
+TICK_ESTIMATE, TICK_WANT_U0 = 1, 2
 
 
 class NdpCfg(C.Structure):
@@ -47,6 +49,8 @@ EXPORTS = [
     "ndp_downwash_prefetch_device", "ndp_step_device_prefetched", "ndp_prefetch_join", "ndp_prefetch_stats", "ndp_device_force_slot",
     "ndp_track_steps", "ndp_last_step_event",
     "ndp_xchg_unique_id", "ndp_xchg_create", "ndp_xchg_begin", "ndp_xchg_end", "ndp_xchg_tick", "ndp_xchg_last_error", "ndp_xchg_destroy",
+    "ndp_abi_version", "ndp_cfg_size",
+    "ndp_step_ex_f64", "ndp_refine_active", "ndp_tick_config", "ndp_tick_reset", "ndp_tick_begin", "ndp_tick_end", "ndp_tick", "ndp_tick_device",
 ]
 
 _lib = None
@@ -69,6 +73,14 @@ def load():
         pass
     lib = C.CDLL(LIB_PATH)
     vp, i32p = C.c_void_p, C.POINTER(C.c_int32)
+    # A stale library (or one built from another header) would read / write past NdpCfg: refuse it.
+    if not hasattr(lib, "ndp_abi_version"):
+        raise RuntimeError(f"{LIB_PATH} predates the interface version check (include/ndp_nmpc.h: NDP_ABI_VERSION): rebuild it")
+    lib.ndp_cfg_size.restype = C.c_size_t
+    if lib.ndp_abi_version() != ABI_VERSION or lib.ndp_cfg_size() != C.sizeof(NdpCfg):
+        raise RuntimeError(
+            f"{LIB_PATH}: interface version {lib.ndp_abi_version()} / sizeof(ndp_cfg) {lib.ndp_cfg_size()}, this binding expects "
+            f"{ABI_VERSION} / {C.sizeof(NdpCfg)}: rebuild the library (python -m ndp_nmpc_qd_amd.build)")
     lib.ndp_default_cfg.argtypes = [C.POINTER(NdpCfg)]
     lib.ndp_create.argtypes = [C.POINTER(NdpCfg), C.POINTER(vp)]
     lib.ndp_destroy.argtypes = [vp]
@@ -80,6 +92,7 @@ def load():
     lib.ndp_step.argtypes = [vp] * 8
     lib.ndp_step_device.argtypes = [vp] * 9
     lib.ndp_step_ex.argtypes = [vp] * 12
+    lib.ndp_step_ex_f64.argtypes = [vp] * 10
     lib.ndp_step_begin.argtypes = [vp] * 7 + [C.c_int]
     lib.ndp_step_end.argtypes = [vp] * 6
     lib.ndp_debug_host_timing.argtypes = [vp, vp]
@@ -92,6 +105,13 @@ def load():
     lib.ndp_device_force_slot.restype = vp
     lib.ndp_step_device_ex.argtypes = [vp] * 6 + [C.c_int] + [vp] * 4
     lib.ndp_work_queue_enabled.argtypes = [vp]
+    lib.ndp_refine_active.argtypes = [vp]
+    lib.ndp_tick_config.argtypes = [vp, vp, C.c_int]
+    lib.ndp_tick_reset.argtypes = [vp]
+    lib.ndp_tick_begin.argtypes = [vp] * 5 + [C.c_int]
+    lib.ndp_tick_end.argtypes = [vp] * 5
+    lib.ndp_tick.argtypes = [vp] * 5 + [C.c_int] + [vp] * 4
+    lib.ndp_tick_device.argtypes = [vp] * 5 + [C.c_int] + [vp] * 3
     lib.ndp_ref_list_reset.argtypes = [vp]
     lib.ndp_ref_list_fix_pt.argtypes = [vp, vp, C.c_int]
     lib.ndp_ref_list_window.argtypes = [vp] * 4

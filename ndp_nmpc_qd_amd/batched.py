@@ -77,10 +77,23 @@ class BatchedNMPC:
         x0 = _lib.f64(x0, (self.B, 10))
         xr = _lib.f64(xr, (self.B, self.N + 1, 10))
         ur = _lib.f64(ur, (self.B, self.N, 4))
+        u0 = np.empty((self.B, 4), dtype=np.float64)
+        if f is not None and other is None and np.asarray(f).dtype == np.float64:
+            # a float64 force goes to the device as it is (ndp_step_ex_f64): the reference hands acados a float64 p
+            # (ndp_nmpc_body_rate_ctl.py:97-99); DownwashNN's float32 output takes the fp32 entry below -- the same numbers
+            f64 = _lib.f64(f, (self.B, self.N + 1, 3))
+            X = U = st = it = None
+            if full:
+                X, U = np.empty((self.B, self.N + 1, 10)), np.empty((self.B, self.N, 4))
+                st, it = np.empty(self.B, dtype=np.int32), np.empty(self.B, dtype=np.int32)
+            rc = self._check(self._lib.ndp_step_ex_f64(self._h, _lib.ptr(x0), _lib.ptr(xr), _lib.ptr(ur), _lib.ptr(f64), _lib.ptr(u0),
+                                                       _lib.ptr(X), _lib.ptr(U), _lib.ptr(st), _lib.ptr(it)), "ndp_step_ex_f64")
+            if rc != 0 and raise_on_status:
+                raise Exception("acados acados_ocp_solver returned status {}. Exiting.".format(rc))
+            return (u0, X, U, st, it) if full else u0
         f32 = None if f is None else np.ascontiguousarray(f, dtype=np.float32).reshape(self.B, self.N + 1, 3)
         other = _lib.f64(other, (self.B, self.N + 1, 10))
         ego_xy = _lib.f64(ego_xy, (self.B, 2))
-        u0 = np.empty((self.B, 4), dtype=np.float64)
         if full:
             X, U = np.empty((self.B, self.N + 1, 10)), np.empty((self.B, self.N, 4))
             st, it = np.empty(self.B, dtype=np.int32), np.empty(self.B, dtype=np.int32)
@@ -242,6 +255,64 @@ class BatchedNMPC:
             self._h, self._dptr(t, torch.float64, (self.B,)), self._dptr(xr_out, torch.float64, (self.B, self.N + 1, 10)),
             self._dptr(ur_out, torch.float64, (self.B, self.N, 4)), self._stream(stream)), "ndp_ref_window_device")
 
+    # ------------------------------------------------------------------ the node's control tick (odometry in, command out)
+    def tick_config(self, other_index=None, gate=True):
+        """Who is whose neighbour (int32[B], < 0 / None: none) and whether the r_horiz gate on the ego odometry applies
+        (ndp_nmpc_leader_node.py:40,60-76)."""
+        oi = None if other_index is None else np.ascontiguousarray(other_index, dtype=np.int32).reshape(self.B)
+        self._check(self._lib.ndp_tick_config(self._h, _lib.ptr(oi), 1 if gate else 0), "ndp_tick_config")
+
+    def tick_reset(self):
+        """nmpc_ctl.reset(*ref_pub.get_nmpc_ref_from_long_list()) (nmpc_node.py:92,151-152) on the device."""
+        self._check(self._lib.ndp_tick_reset(self._h), "ndp_tick_reset")
+
+    def _tick_in(self, x_odom, t, vz, throttle, estimate, want_u0):
+        flags = (_lib.TICK_ESTIMATE if estimate else 0) | (_lib.TICK_WANT_U0 if want_u0 else 0)
+        return (_lib.f64(x_odom, (self.B, 10)), _lib.f64(t, (self.B,)), _lib.f64(vz, (self.B,)), _lib.f64(throttle, (self.B,)), flags)
+
+    def tick_begin(self, x_odom, t=None, vz=None, throttle=None, estimate=False, want_u0=False):
+        """First half of tick(): ndp_tick_begin -- only x_odom[B,10] (+ t, vz, throttle [B]) cross PCIe; returns without waiting.
+        Up to two ticks in flight."""
+        x, t, vz, th, flags = self._tick_in(x_odom, t, vz, throttle, estimate, want_u0)
+        self._check(self._lib.ndp_tick_begin(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(vz), _lib.ptr(th), flags), "ndp_tick_begin")
+
+    def tick_end(self, raise_on_status=True, full=False, out=None):
+        """Second half: cmd[B,4] = [wx, wy, wz, thrust] of the oldest tick (full=True: (cmd, u0, status, ipm_iters); u0 only if the
+        tick was begun with want_u0)."""
+        cmd = np.empty((self.B, 4)) if out is None else out
+        u0 = st = it = None
+        if full:
+            u0, st, it = np.empty((self.B, 4)), np.empty(self.B, dtype=np.int32), np.empty(self.B, dtype=np.int32)
+        rc = self._check(self._lib.ndp_tick_end(self._h, _lib.ptr(cmd), _lib.ptr(u0), _lib.ptr(st), _lib.ptr(it)), "ndp_tick_end")
+        if rc != 0 and raise_on_status:
+            raise Exception("acados acados_ocp_solver returned status {}. Exiting.".format(rc))
+        return (cmd, u0, st, it) if full else cmd
+
+    def tick(self, x_odom, t=None, vz=None, throttle=None, estimate=False, raise_on_status=True, full=False):
+        """One control period of ControllerNode (nmpc_node.py:211-231,251-253) for every vehicle: reference list advance ->
+        estimator -> control step (downwash from the neighbour's window) -> actuator command.  Returns cmd[B,4]
+        (full=True: (cmd, u0, status, ipm_iters))."""
+        x, t, vz, th, flags = self._tick_in(x_odom, t, vz, throttle, estimate, full)
+        cmd = np.empty((self.B, 4))
+        u0 = st = it = None
+        if full:
+            u0, st, it = np.empty((self.B, 4)), np.empty(self.B, dtype=np.int32), np.empty(self.B, dtype=np.int32)
+        rc = self._check(self._lib.ndp_tick(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(vz), _lib.ptr(th), flags, _lib.ptr(cmd),
+                                            _lib.ptr(u0), _lib.ptr(st), _lib.ptr(it)), "ndp_tick")
+        if rc != 0 and raise_on_status:
+            raise Exception("acados acados_ocp_solver returned status {}. Exiting.".format(rc))
+        return (cmd, u0, st, it) if full else cmd
+
+    def tick_device(self, x_odom, cmd_out, t=None, vz=None, throttle=None, estimate=False, u0_out=None, stream=None):
+        """The tick's launches on CUDA tensors and a caller's stream (ndp_tick_device); no synchronisation."""
+        import torch
+        B = self.B
+        self._check(self._lib.ndp_tick_device(
+            self._h, self._dptr(x_odom, torch.float64, (B, 10)), self._dptr(t, torch.float64, (B,)),
+            self._dptr(vz, torch.float64, (B,)), self._dptr(throttle, torch.float64, (B,)), _lib.TICK_ESTIMATE if estimate else 0,
+            self._dptr(cmd_out, torch.float64, (B, 4)), self._dptr(u0_out, torch.float64, (B, 4)), self._stream(stream)),
+            "ndp_tick_device")
+
     # ------------------------------------------------------------------ f4: plant step (closed-loop rollouts)
     def plant_step(self, x, u, f=None, dt=CP.ts_nmpc, substeps=4):
         x = _lib.f64(x, (self.B, 10)).copy()
@@ -395,6 +466,12 @@ class BatchedNMPC:
         ev = C.c_void_p()
         self._check(self._lib.ndp_last_step_event(self._h, C.byref(ev)), "ndp_last_step_event")
         return ev
+
+    @property
+    def refine_active(self):
+        """True when cfg.ipm_refine acts on this engine's control steps (three-slot kernels, N <= 27); the five-slot kernels and the
+        late-force step ignore it (include/ndp_nmpc.h: ndp_cfg.ipm_refine)."""
+        return self._lib.ndp_refine_active(self._h) == 1
 
     @property
     def work_queue(self):

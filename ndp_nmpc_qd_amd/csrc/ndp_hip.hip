@@ -64,6 +64,16 @@ struct BatchPtrs {
     double *Xm, *Um;        // mirror of the new iterate ([B][N+1][10] | [B][N][4], page-locked host memory) or null
     double *dbg;
     double *stamps;         // [B][16] phase stamps of every instance (ndp_debug_stamps), or null
+    size_t xr_pitch, ur_pitch;   // doubles from one instance's reference window to the next: (N+1) 10 / 4 N for dense [B][N+1][10] / [B][N][4]
+                                 // arrays; RingGeom::px / pu when the windows are read straight out of the reference list (ndp_tick)
+    size_t x0_pitch;             // doubles from one instance's x0 to the next (10)
+    // ndp_tick: the actuator command written beside u0 (RtiIo::cmd): cmd[B][4], k_throttle[B] (the estimator's state row), the thrust
+    // kept for the next estimator update [B]; null cmd = a plain control step
+    double *cmd;
+    const double *kthr;
+    double *thrust_keep;
+    double cmd_mass;
+    int f_f64;                   // 1: f holds doubles, [B][N+1][3] (ndp_step_ex_f64)
 };
 
 struct MlpArgs {            // fused downwash (null frag = not fused)
@@ -76,6 +86,8 @@ struct MlpArgs {            // fused downwash (null frag = not fused)
     const int *other_index; // [B] row of `other` that holds instance i's neighbour (multi-GPU: a row of the gathered buffer);
                             // < 0 = no neighbour (force 0: the plain NMPC followers of a formation); null = row i
     int other_sys;          // 1: `other` is another process's / GPU's memory mapped through ndp_peer_open -- read it with system-scope loads
+    size_t other_pitch;     // doubles from one row of `other` to the next: (N+1) other_stride when dense; RingGeom::px for windows in the list
+    size_t ego_pitch;       // doubles from one instance's ego xy to the next: 2 ([B][2]), or 10 when the gate reads the odometry rows x0[B][10]
 };
 
 // Neighbour windows that live in ANOTHER agent's memory (peer windows over xGMI) are read with system-scope loads: such lines are
@@ -129,10 +141,11 @@ __device__ __forceinline__ bool gate_open(const double *other_inst, const double
 __device__ __forceinline__ void bind_instance(RtiIo &io, const BatchPtrs &bp, int inst, int N)
 {
     const size_t nx = (size_t)(N + 1) * NX, nu = (size_t)N * NU, nf = (size_t)(N + 1) * 3;
-    io.x0 = bp.x0 + (size_t)inst * NX;
-    io.xr = bp.xr + inst * nx;
-    io.ur = bp.ur + inst * nu;
-    io.f = bp.f ? bp.f + inst * nf : nullptr;
+    io.x0 = bp.x0 + (size_t)inst * bp.x0_pitch;
+    io.xr = bp.xr + inst * bp.xr_pitch;
+    io.ur = bp.ur + inst * bp.ur_pitch;
+    io.f = bp.f ? bp.f + inst * nf * (bp.f_f64 ? 2 : 1) : nullptr;
+    io.f_is_f64 = bp.f_f64;
     io.X = bp.X + inst * nx;
     io.U = bp.U + inst * nu;
     io.Xm = bp.Xm ? bp.Xm + inst * nx : nullptr;
@@ -145,6 +158,12 @@ __device__ __forceinline__ void bind_instance(RtiIo &io, const BatchPtrs &bp, in
     io.kc = bp.kc;
     io.tables = bp.tables;
     io.stamps = bp.stamps ? bp.stamps + (size_t)inst * 16 : nullptr;
+    if (NDP_RARELY(bp.cmd != nullptr)) {
+        io.cmd = bp.cmd + (size_t)inst * NU;
+        io.thrust_keep = bp.thrust_keep + inst;
+        io.kthr = bp.kthr[inst];            // (requested here, used at the step's very end)
+        io.cmd_mass = bp.cmd_mass;
+    }
 }
 
 // Downwash predicted one tick ahead by mlp_stream_kernel on a second stream (ndp_downwash_prefetch_device), consumed by the
@@ -300,10 +319,10 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         const int lane = (int)(threadIdx.x & 63u), j = lane & 31, h = lane >> 5;
         const int np1 = N + 1;
         const int st = ma.other_stride;
-        const double *oth = ma.other + (size_t)(orow < 0 ? 0 : orow) * np1 * st;
+        const double *oth = ma.other + (size_t)(orow < 0 ? 0 : orow) * ma.other_pitch;
         // the gate's four numbers are only REQUESTED here; the comparison comes after the barrier (consuming them here would
         // park the wave on the whole in-order load queue -- s_waitcnt vmcnt(0) -- before the weight transfer is even issued)
-        const double *exy = ma.ego_xy ? ma.ego_xy + (size_t)inst * 2 : oth;
+        const double *exy = ma.ego_xy ? ma.ego_xy + (size_t)inst * ma.ego_pitch : oth;
         const int osys = ma.other_sys;
         const double g_ox = ld_other(oth, osys), g_oy = ld_other(oth + 1, osys), g_ex = exy[0], g_ey = exy[1];
         const int jr = j < np1 ? j : np1 - 1;
@@ -624,7 +643,8 @@ __device__ __forceinline__ bool gate_open(const double *other_inst, const double
 __global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, const double *__restrict__ other,
                                                   const double *__restrict__ ego, const double *__restrict__ ego_xy,
                                                   float *__restrict__ fout, int rows, int np1, double r2,
-                                                  int other_stride, const int *__restrict__ other_index, int other_sys)
+                                                  int other_stride, const int *__restrict__ other_index, int other_sys,
+                                                  size_t other_pitch, size_t ego_pitch, size_t ego_xy_pitch)     // doubles per row of other / per instance of ego, ego_xy (see MlpArgs)
 {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
@@ -640,17 +660,17 @@ __global__ __launch_bounds__(256) void mlp_kernel(const float *__restrict__ fr, 
     const int rowc = valid ? row : rows - 1;
     const int inst = rowc / np1, k = rowc - inst * np1;
     const int orow = other_index ? other_index[inst] : inst;          // see MlpArgs
-    const double *oth = other + (size_t)(orow < 0 ? 0 : orow) * np1 * other_stride;
+    const double *oth = other + (size_t)(orow < 0 ? 0 : orow) * other_pitch;
     bool open = valid && orow >= 0;
     if (ego_xy) {
         const double oxy[2] = {ld_other(oth, other_sys), ld_other(oth + 1, other_sys)};
-        open = open && gate_open(oxy, ego_xy + inst * 2, r2);
+        open = open && gate_open(oxy, ego_xy + (size_t)inst * ego_xy_pitch, r2);
     }
     // downwash_nn.py:22-23: (other - ego)[:, 0:6] in fp64, cast to fp32
     float zb[3], o[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
-        zb[s] = (float)(ld_other(oth + (size_t)k * other_stride + 2 * s + h, other_sys) - ego[(size_t)rowc * NX + 2 * s + h]);
+        zb[s] = (float)(ld_other(oth + (size_t)k * other_stride + 2 * s + h, other_sys) - ego[(size_t)inst * ego_pitch + (size_t)k * NX + 2 * s + h]);
     mlp_tile(wl, zb, lane, o);
     if (valid && h == 0) {
 #pragma unroll
@@ -895,13 +915,9 @@ static void make_fragments(const float *blob, std::vector<float> &fr)
 // expressions (hover_throttle_estimator.py:38-51) so results agree to rounding.
 struct ThrCfg { double a1, a2, hm, g, R, Q0, Q1, mass; };
 
-__global__ __launch_bounds__(256) void throttle_kernel(ThrCfg c, double *__restrict__ st, const double *__restrict__ vz,
-                                                       const double *__restrict__ throttle, double *__restrict__ k_out, int B)
+// one estimator update of vehicle v (state SoA [8][S]); returns k_throttle
+__device__ __forceinline__ double throttle_update_one(const ThrCfg &c, double *__restrict__ st, size_t S, int v, double vzv, double th)
 {
-    const int v = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (v >= B) return;
-    const size_t S = (size_t)B;
-    const double vzv = vz[v], th = throttle[v];
     const double az = nc_add(nc_mul(c.a1, st[7 * S + v]), nc_mul(c.a2, vzv - st[6 * S + v]));   // differentiator.py:21
     st[6 * S + v] = vzv;
     st[7 * S + v] = az;
@@ -925,7 +941,15 @@ __global__ __launch_bounds__(256) void throttle_kernel(ThrCfg c, double *__restr
         st[4 * S + v] = nc_add(nc_mul(i10, p00), p10);
         st[5 * S + v] = nc_add(nc_mul(i10, p01), p11);
     }
-    k_out[v] = x1;
+    return x1;
+}
+
+__global__ __launch_bounds__(256) void throttle_kernel(ThrCfg c, double *__restrict__ st, const double *__restrict__ vz,
+                                                       const double *__restrict__ throttle, double *__restrict__ k_out, int B)
+{
+    const int v = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (v >= B) return;
+    k_out[v] = throttle_update_one(c, st, (size_t)B, v, vz[v], throttle[v]);
 }
 
 __global__ __launch_bounds__(256) void throttle_reset_kernel(double *st, double k_init, int B)
@@ -939,6 +963,7 @@ __global__ __launch_bounds__(256) void throttle_reset_kernel(double *st, double 
 }
 
 // nmpc_u_2_att_tgt (nmpc_node.py:273-283): body rates pass through, thrust = c * mass / k_throttle (0 if k == 0)
+__device__ __forceinline__ double thrust_cmd(double c, double mass, double k) { return k != 0.0 ? nc_mul(c, mass) / k : 0.0; }
 __global__ __launch_bounds__(256) void actuator_kernel(const double *__restrict__ u0, const double *__restrict__ k,
                                                        double *__restrict__ cmd, double mass, int B)
 {
@@ -947,7 +972,7 @@ __global__ __launch_bounds__(256) void actuator_kernel(const double *__restrict_
     const double2 a = reinterpret_cast<const double2 *>(u0)[2 * v], b = reinterpret_cast<const double2 *>(u0)[2 * v + 1];
     const double kk = k[v];
     double2 o0 = a, o1 = b;
-    o1.y = kk != 0.0 ? nc_mul(b.y, mass) / kk : 0.0;
+    o1.y = thrust_cmd(b.y, mass, kk);
     reinterpret_cast<double2 *>(cmd)[2 * v] = o0;
     reinterpret_cast<double2 *>(cmd)[2 * v + 1] = o1;
 }
@@ -1064,9 +1089,11 @@ __device__ __forceinline__ double horner_d(const double *__restrict__ c, double 
 
 // One reference point: trajectory of vehicle b at trajectory time t -> x[10] = [p, v, qw, qx, qy, qz], u[4] = [wx, wy, wz, c]
 // (get_traj_pt, base_pt_publisher.py:81-133; diff_flatness, pt_publisher.py:188-248; traj_full_pt_2_x_u, :115-146)
+// seg_hint (or null): the vehicle's segment at its previous point -- control ticks move forward 20 ms at a time, so it is nearly always
+// still the one: two loads confirm it instead of a search over time_cum; updated here.
 __device__ __forceinline__ void ref_point(const RefCfg &cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
                                           const double *__restrict__ tseg, const double *__restrict__ fpt, int b, double t,
-                                          double xv[10], double uv[4])
+                                          double xv[10], double uv[4], int *__restrict__ seg_hint = nullptr)
 {
     const double *tc = tcum + (size_t)b * (cf.n_seg + 1);
     double pvaj[12], yaw = 0.0, yawd = 0.0;
@@ -1075,9 +1102,27 @@ __device__ __forceinline__ void ref_point(const RefCfg &cf, const double *__rest
     if (t >= tc[cf.n_seg]) {                              // base_pt_publisher.py:93-94: hover at final_pt after the end
         for (int i = 0; i < 3; ++i) pvaj[i] = fpt[(size_t)b * 3 + i];
     } else {
-        int idx = 0;                                      // :100: first i with time_cum[i] > t, minus one
-        while (idx < cf.n_seg && !(tc[idx] > t)) ++idx;
-        idx = idx > 0 ? idx - 1 : 0;
+        // :100: first i with time_cum[i] > t, minus one -- time_cum ascends, so that is (entries of 0 .. n_seg-1 not above t) - 1.
+        // Counted eight independent loads at a time: a search loop is a chain of dependent global loads, ~0.6 us each.
+        int idx = 0;
+        bool found = false;
+        if (seg_hint) {
+            const int hi = seg_hint[b];
+            idx = hi < 0 ? 0 : (hi >= cf.n_seg ? cf.n_seg - 1 : hi);
+            found = (idx == 0 || !(tc[idx] > t)) && tc[idx + 1] > t;
+        }
+        if (!found) {
+            idx = 0;
+            for (int i = 0; i < cf.n_seg; i += 8) {
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tc[i + j < cf.n_seg ? i + j : cf.n_seg];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) idx += (i + j < cf.n_seg && !(v[j] > t)) ? 1 : 0;
+            }
+            idx = idx > 0 ? idx - 1 : 0;
+        }
+        if (seg_hint) seg_hint[b] = idx;
         const double its = 1.0 / tseg[(size_t)b * cf.n_seg + idx], its2 = its * its;     // one divide per point
         const double *c = coeff + ((size_t)b * cf.n_seg + idx) * 28;
         const double s = (t - tc[idx]) * its;             // :102-103
@@ -1178,66 +1223,127 @@ __global__ __launch_bounds__(REF_ROWS) void ref_window_kernel(RefCfg cf, const d
     for (int i = lane; i < nu * 4; i += REF_ROWS) ug[i] = su[i];
 }
 
-// ---- f1, the reference's own bookkeeping: NMPCRefPublisher keeps a list of `ring` = 5N+1 reference points per vehicle,
-// ts_nmpc apart (pt_publisher.py:36-38, params/nmpc_params.py:40-43); every control tick drops the oldest and appends the
-// point at ros_t + T_horizon (:78-97); the controller's window is every 5th entry (:99-103).  On the device the list is a
-// ring [B][ring][14] (x(10) | u(4)); `head` (the same for every vehicle) lives on the host.
-// Fills list entries: point i of vehicle b at trajectory time (tq ? tq[b] : 0) + toff + i * tstep goes to slot
-// (slot0 + i) % ring; dup0 also copies point 0 to slot (slot0 - 1) % ring (_gen_long_list_w_traj's duplicate, :73-74).
+// ---- f1, the reference's own bookkeeping: NMPCRefPublisher keeps a list of `ring` = step N + 1 reference points per vehicle,
+// ts_nmpc apart (pt_publisher.py:36-38, params/nmpc_params.py:40-43; step = 5); every control tick drops the oldest and appends
+// the point at ros_t + T_horizon (:78-97); the controller's window is every step-th entry (:99-103).
+// Device layout (round 5): the window of tick n is the list entries with ABSOLUTE index n, n + step, .., n + step N (entry j =
+// the j-th point ever put into the list) -- all of one residue class mod step.  So the list is kept PHASE-MAJOR, a short ring of
+// N + 1 positions per phase, every entry stored twice, N + 1 positions apart:
+//     x ring [B][step][2 (N+1)][10]      u ring [B][step][2 (N+1)][4]
+//     entry j -> phase j % step, positions (j / step) % (N+1) and + (N+1)
+// and every window is N + 1 CONTIGUOUS x rows (N u rows) starting at position (n / step) % (N+1) of phase n % step: the control
+// step reads its reference window -- and a neighbour's -- straight out of the list (instance pitch = RingGeom::px / pu doubles),
+// there is no window copy on the control tick's path, and the stand-alone window call is a dense copy.  `n` lives on the host
+// (ndp_handle::list_n) and is baked into each launch's arguments.
+struct RingGeom {
+    int step, np1;                 // list entries per node spacing; N + 1
+    __host__ __device__ int ring() const { return step * (np1 - 1) + 1; }
+    __host__ __device__ size_t px() const { return (size_t)step * 2 * np1 * 10; }     // doubles per vehicle, x ring
+    __host__ __device__ size_t pu() const { return (size_t)step * 2 * np1 * 4; }
+    __host__ __device__ size_t slot(unsigned long long j) const { return (size_t)(j % step) * 2 * np1 + (size_t)((j / step) % np1); }
+};
+
+__device__ __forceinline__ void ring_store(const RingGeom &rg, double *__restrict__ rx, double *__restrict__ ru, int b,
+                                           unsigned long long j, const double xv[10], const double uv[4])
+{
+    const size_t s = rg.slot(j);
+    double2 *x0 = reinterpret_cast<double2 *>(rx + (size_t)b * rg.px() + s * 10), *x1 = x0 + (size_t)rg.np1 * 5;
+    double2 *u0 = reinterpret_cast<double2 *>(ru + (size_t)b * rg.pu() + s * 4), *u1 = u0 + (size_t)rg.np1 * 2;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) { const double2 v = make_double2(xv[2 * c], xv[2 * c + 1]); x0[c] = v; x1[c] = v; }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { const double2 v = make_double2(uv[2 * c], uv[2 * c + 1]); u0[c] = v; u1[c] = v; }
+}
+
+// Fills list entries: point i of vehicle b at trajectory time (tq ? tq[b] : 0) + toff + i * tstep becomes entry j0 + i;
+// dup0 also makes point 0 entry j0 - 1 (_gen_long_list_w_traj's duplicate, :73-74).
 __global__ __launch_bounds__(256) void ref_list_fill_kernel(RefCfg cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
                                                             const double *__restrict__ tseg, const double *__restrict__ fpt,
-                                                            const double *__restrict__ tq, double tstep, int npts, int slot0, int ring,
-                                                            int dup0, double *__restrict__ list)
+                                                            const double *__restrict__ tq, double tstep, int npts, unsigned long long j0,
+                                                            RingGeom rg, int dup0, double *__restrict__ rx, double *__restrict__ ru)
 {
     const int id = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (id >= cf.B * npts) return;
     const int b = id / npts, i = id - b * npts;
     double xv[10], uv[4];
-    ref_point(cf, coeff, tcum, tseg, fpt, b, (tq ? tq[b] : 0.0) + cf.toff + i * tstep, xv, uv);
-    double *d = list + ((size_t)b * ring + (slot0 + i) % ring) * 14;
-#pragma unroll
-    for (int c = 0; c < 10; ++c) d[c] = xv[c];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) d[10 + c] = uv[c];
-    if (dup0 && i == 0) {
-        double *e = list + ((size_t)b * ring + (slot0 + ring - 1) % ring) * 14;
-#pragma unroll
-        for (int c = 0; c < 10; ++c) e[c] = xv[c];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) e[10 + c] = uv[c];
-    }
+    // one point per vehicle = the per-tick advance: the segment hint applies (it lives behind final_pt, see ndp_ref_set_trajectory)
+    int *hint = npts == 1 ? reinterpret_cast<int *>(const_cast<double *>(fpt + (size_t)cf.B * 3)) : nullptr;
+    ref_point(cf, coeff, tcum, tseg, fpt, b, (tq ? tq[b] : 0.0) + cf.toff + i * tstep, xv, uv, hint);
+    ring_store(rg, rx, ru, b, j0 + (unsigned long long)i, xv, uv);
+    if (dup0 && i == 0) ring_store(rg, rx, ru, b, j0 - 1, xv, uv);
 }
 
-// gen_fix_pt_ref (pt_publisher.py:40-55): every entry = the odometry state, u = [0, 0, 0, c_hover]
-__global__ __launch_bounds__(256) void ref_list_fix_kernel(const double *__restrict__ x_odom, double c_hover, int B, int ring, double *__restrict__ list)
+// gen_fix_pt_ref (pt_publisher.py:40-55): every entry = the odometry state, u = [0, 0, 0, c_hover]; one thread per stored row
+__global__ __launch_bounds__(256) void ref_list_fix_kernel(const double *__restrict__ x_odom, double c_hover, int B, RingGeom rg,
+                                                           double *__restrict__ rx, double *__restrict__ ru)
 {
+    const int per = rg.step * 2 * rg.np1;
     const int id = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (id >= B * ring) return;
-    const int b = id / ring;
-    double *d = list + (size_t)id * 14;
+    if (id >= B * per) return;
+    const int b = id / per;
+    const double2 *s = reinterpret_cast<const double2 *>(x_odom) + (size_t)b * 5;
+    double2 *dx = reinterpret_cast<double2 *>(rx) + (size_t)id * 5, *du = reinterpret_cast<double2 *>(ru) + (size_t)id * 2;
 #pragma unroll
-    for (int c = 0; c < 10; ++c) d[c] = x_odom[(size_t)b * 10 + c];
-    d[10] = 0.0; d[11] = 0.0; d[12] = 0.0; d[13] = c_hover;
+    for (int c = 0; c < 5; ++c) dx[c] = s[c];
+    du[0] = make_double2(0.0, 0.0);
+    du[1] = make_double2(0.0, c_hover);
 }
 
-// get_nmpc_ref_from_long_list (:99-103): entries head, head + step, ... -> xr[B][N+1][10], ur[B][N][4]
-__global__ __launch_bounds__(256) void ref_list_window_kernel(const double *__restrict__ list, int head, int ring, int step, int B, int N,
-                                                              double *__restrict__ xr, double *__restrict__ ur)
+// get_nmpc_ref_from_long_list (:99-103) as a stand-alone call: the window of tick n -> xr[B][N+1][10], ur[B][N][4].  Both sides
+// are contiguous per vehicle (see RingGeom): a dense copy, 16 bytes per lane -- 5 (N+1) + 2 N pieces per vehicle.
+__global__ __launch_bounds__(256) void ref_list_window_kernel(const double *__restrict__ rx, const double *__restrict__ ru, RingGeom rg,
+                                                              unsigned long long n, int B, double *__restrict__ xr, double *__restrict__ ur)
 {
-    const int id = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (id >= B * (N + 1)) return;
-    const int b = id / (N + 1), k = id - b * (N + 1);
-    const double *s = list + ((size_t)b * ring + (head + k * step) % ring) * 14;
-    double *x = xr + (size_t)id * 10;
-#pragma unroll
-    for (int c = 0; c < 10; ++c) x[c] = s[c];
-    if (k < N) {
-        double *u = ur + ((size_t)b * N + k) * 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) u[c] = s[10 + c];
-    }
+    const int N = rg.np1 - 1, nxp = 5 * rg.np1, per = nxp + 2 * N;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)B * per) return;
+    const int b = (int)(id / per), e = (int)(id - (size_t)b * per);
+    const size_t s = rg.slot(n);
+    if (e < nxp) reinterpret_cast<double2 *>(xr)[(size_t)b * nxp + e] = reinterpret_cast<const double2 *>(rx + (size_t)b * rg.px() + s * 10)[e];
+    else reinterpret_cast<double2 *>(ur)[(size_t)b * 2 * N + (e - nxp)] = reinterpret_cast<const double2 *>(ru + (size_t)b * rg.pu() + s * 4)[e - nxp];
 }
 
+
+// ------------------------------------------------------------------------------------------ the node's control tick (ndp_tick)
+// nmpc_node.py:211-231 for every vehicle of the handle, on the device, references resident: per tick the host hands over the
+// odometry states (80 B per vehicle) and a few scalars; everything else the tick needs is already in HBM.
+//   tick_pre_kernel  (one thread per vehicle): the reference list's advance -- the point at t + T_horizon becomes the list's newest
+//                    entry (get_nmpc_pts, pt_publisher.py:79-97), which is also node N of this tick's window -- and the hover-
+//                    throttle estimator's update (hover_throttle_callback, nmpc_node.py:251-253) from vz and the thrust command of
+//                    the previous tick
+//   rti_kernel       the control step: x0 = the odometry rows, xr / ur / the neighbour's window straight out of the list; its last
+//                    store is nmpc_u_2_att_tgt (:273-283): [wx, wy, wz, c mass / k_throttle] where the host reads it (RtiIo::cmd),
+//                    the thrust kept on the device for the next estimator update.  (A third launch for that -- tick_post_kernel,
+//                    the first form -- cost 4.6 us per tick in the trace for 32 bytes per vehicle.)
+struct TickPre {
+    RefCfg cf;
+    const double *coeff, *tcum, *tseg, *fpt;
+    int *seg_hint;                     // [B] the segment each vehicle's last point lay in (ref_point)
+    const double *t;                   // [B] trajectory time of the tick, or null: the list is not advanced
+    unsigned long long j_new;          // absolute index of the entry the new point becomes
+    RingGeom rg;
+    double *rx, *ru;
+    ThrCfg thr;
+    double *st;                        // estimator state, SoA [8][B]
+    const double *vz;                  // vz of vehicle b at vz[b * vz_pitch]: a [B] array (pitch 1) or column 5 of the odometry rows (pitch 10)
+    size_t vz_pitch;
+    const double *throttle;            // [B]: the thrust command sent last tick (caller's array, or the one the control step kept)
+    int est;                           // run the estimator this tick
+};
+
+__global__ __launch_bounds__(64) void tick_pre_kernel(TickPre a)
+{
+    const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (b >= a.cf.B) return;
+    double vzv = 0.0, th = 0.0;
+    if (a.est) { vzv = a.vz[(size_t)b * a.vz_pitch]; th = a.throttle[b]; }      // (requested before the polynomial work)
+    if (a.t) {
+        double xv[10], uv[4];
+        ref_point(a.cf, a.coeff, a.tcum, a.tseg, a.fpt, b, a.t[b] + a.cf.toff, xv, uv, a.seg_hint);
+        ring_store(a.rg, a.rx, a.ru, b, a.j_new, xv, uv);
+    }
+    if (a.est) (void)throttle_update_one(a.thr, a.st, (size_t)a.cf.B, b, vzv, th);
+}
 
 // ------------------------------------------------------------------------------------------ peer windows: per-tick publish
 // peer_epoch.hpp's protocol on the device.  TWO launches per control tick and rank, in front of the control-step launch:
@@ -1476,10 +1582,16 @@ struct ndp_handle {
     int *dTables = nullptr;    // per-lane index tables of the Riccati sweep (fill_tables)
     double *dThr = nullptr;    // hover-throttle estimator state, SoA [8][B]
     double *dStamps = nullptr; // [B][16] whole-batch phase stamps (ndp_debug_stamps)
-    double *dTraj = nullptr;   // f1: [B][n_seg][28] coeff | [B][n_seg+1] time_cum | [B][n_seg] time_seg | [B][3] final_pt
+    double *dTraj = nullptr;   // f1: [B][n_seg][28] coeff | [B][n_seg+1] time_cum | [B][n_seg] time_seg | [B][3] final_pt | int[B] segment hints
     int traj_seg = 0;
-    double *dRefList = nullptr; // f1: the reference's sliding list of reference points, ring [B][5N+1][14] (allocated on first use)
-    int list_head = 0, list_step = 5;
+    double *dRingX = nullptr, *dRingU = nullptr;   // f1: the reference's sliding list of reference points, phase-major (RingGeom), one allocation (first use)
+    unsigned long long list_n = 0;                 // absolute index of the list's oldest entry = control ticks since the list was built
+    int list_step = 5;
+    // ndp_tick: the node's control tick on the device (tick_pre_kernel / tick_post_kernel)
+    int *dTickIndex = nullptr;       // [B] neighbour instance of every vehicle (< 0: none), or null: no vehicle has one
+    double *dTickThrust = nullptr;   // [B] the thrust command of the previous tick (what hover_throttle_callback reads off body_rate_cmd)
+    bool tick_gate = true;           // gate the downwash on |neighbour window node 0 xy - ego odometry xy| < r_horiz (ndp_nmpc_leader_node.py:65-74)
+    struct TickSlot { bool busy = false, want_u0 = false; } tslot[2];
     double *dRelay = nullptr;  // follower relay: [B][4] = filtered offset xyz + initialised flag
     double *sThr = nullptr;    // staging of the f1-f4 host entry points: 11 B doubles
     // downwash one tick ahead on a second stream (LateArgs): force slots, protocol words, the stream, its fork / join events
@@ -1561,6 +1673,9 @@ static bool queue_shape(const ndp_handle *h)
 }
 
 extern "C" {
+
+int ndp_abi_version(void) { return NDP_ABI_VERSION; }
+size_t ndp_cfg_size(void) { return sizeof(ndp_cfg); }
 
 int ndp_default_cfg(ndp_cfg *cfg)
 {
@@ -1896,8 +2011,8 @@ int ndp_destroy(ndp_handle *h)
     for (hipEvent_t e : {h->evFork, h->evJoin, h->stepDone[0], h->stepDone[1], h->stepDone[2], h->stepDone[3]})
         if (e) (void)hipEventDestroy(e);
     h->pool.reset();
-    void *ptrs[] = {h->dForceAB[0], h->dForceAB[1], h->dProto, h->dRefList, h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dForce, h->dFrag,
-                    h->dIn, h->dOut, h->sdbg, h->dQctr, h->dQids};
+    void *ptrs[] = {h->dForceAB[0], h->dForceAB[1], h->dProto, h->dRingX, h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dForce, h->dFrag,
+                    h->dIn, h->dOut, h->sdbg, h->dQctr, h->dQids, h->dTickIndex, h->dTickThrust};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &sl : h->slot) {
@@ -2004,7 +2119,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         h->off_x0 = o; o += up256(B * NX * 8);
         h->off_xr = o; o += up256(nxs(h) * 8);
         h->off_ur = o; o += up256(nus(h) * 8);
-        h->off_f = o; o += up256(nfs(h) * 4);
+        h->off_f = o; o += up256(nfs(h) * 8);        // (fp32 forces, or fp64 ones: ndp_step_ex_f64)
         h->off_other = o; o += up256(nxs(h) * 8);
         h->off_ego = o; o += up256(B * 2 * 8);
         h->in_bytes = o;
@@ -2119,9 +2234,11 @@ struct Neigh {                 // neighbour windows of a step (device pointers)
     int stride = NX;           // doubles per node: 10 or 6
     const int *index = nullptr;
     const double *ego_xy = nullptr;
+    size_t pitch = 0;          // doubles between rows of `other`; 0 = dense, (N+1) stride
+    size_t ego_pitch = 0;      // doubles between instances of ego_xy; 0 = dense, 2
 };
 
-static int launch_mlp(ndp_handle *h, const Neigh &nb, const double *d_ego, float *d_f, hipStream_t s)
+static int launch_mlp(ndp_handle *h, const Neigh &nb, const double *d_ego, float *d_f, hipStream_t s, size_t ego_pitch = 0)
 {
     if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }
     const int np1 = h->cfg.N + 1, rows = h->cfg.batch * np1;
@@ -2130,7 +2247,8 @@ static int launch_mlp(ndp_handle *h, const Neigh &nb, const double *d_ego, float
     int rc = begin_timing(h, s, 1);
     if (rc) return rc;
     hipLaunchKernelGGL(mlp_kernel, dim3(grid), dim3(256), FR_TOTAL * sizeof(float), s, (const float *)h->dFrag, nb.other, d_ego, nb.ego_xy, d_f,
-                       rows, np1, h->cfg.r_horiz * h->cfg.r_horiz, nb.stride, nb.index, peer_mapped(nb.other));
+                       rows, np1, h->cfg.r_horiz * h->cfg.r_horiz, nb.stride, nb.index, peer_mapped(nb.other),
+                       nb.pitch ? nb.pitch : (size_t)np1 * nb.stride, ego_pitch ? ego_pitch : (size_t)np1 * NX, nb.ego_pitch ? nb.ego_pitch : (size_t)2);
     NDP_HIP(h, hipGetLastError());
     return end_timing(h, s);
 }
@@ -2140,6 +2258,11 @@ struct StepOut {               // where a step's status / iteration counts go an
     int *iters = nullptr;      // them into a page-locked host block
     double *Xm = nullptr, *Um = nullptr;
     hipEvent_t done = nullptr; // marked by the step's last launch through its own dispatch packet (no event packet behind it), or null
+    size_t xr_pitch = 0, ur_pitch = 0;   // doubles between the instances' reference windows; 0 = dense arrays (see BatchPtrs)
+    double *cmd = nullptr;               // ndp_tick: the actuator command written by the control step itself (BatchPtrs::cmd) ...
+    const double *kthr = nullptr;        // ... from k_throttle[B]
+    double *thrust_keep = nullptr;
+    bool f_f64 = false;                  // d_f holds doubles (ndp_step_ex_f64)
 };
 
 // The automatic work-list rule (cfg.work_queue = 0, reference shape, at least two instances per SIMD).  The list re-balances interior-
@@ -2174,10 +2297,13 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     int *d_status = so && so->status ? so->status : h->dStatus, *d_iters = so && so->iters ? so->iters : h->dIters;
     h->lastStatus = d_status; h->lastIters = d_iters;
     BatchPtrs bp{h->dKC, h->dTables, d_x0, d_xr, d_ur, d_f, h->dX, h->dU, d_u0, d_status, d_iters,
-                 so ? so->Xm : nullptr, so ? so->Um : nullptr, d_dbg, h->dStamps};
+                 so ? so->Xm : nullptr, so ? so->Um : nullptr, d_dbg, h->dStamps,
+                 so && so->xr_pitch ? so->xr_pitch : (size_t)(h->cfg.N + 1) * NX, so && so->ur_pitch ? so->ur_pitch : (size_t)h->cfg.N * NU, (size_t)NX,
+                 so ? so->cmd : nullptr, so ? so->kthr : nullptr, so ? so->thrust_keep : nullptr, h->cfg.mass, so && so->f_f64 ? 1 : 0};
     const bool fused = nb && nb->other;
     MlpArgs ma{fused ? h->dFrag : nullptr, fused ? nb->other : nullptr, fused ? nb->ego_xy : nullptr, h->dForce,
-               h->cfg.r_horiz * h->cfg.r_horiz, fused ? nb->stride : NX, fused ? nb->index : nullptr, fused ? peer_mapped(nb->other) : 0};
+               h->cfg.r_horiz * h->cfg.r_horiz, fused ? nb->stride : NX, fused ? nb->index : nullptr, fused ? peer_mapped(nb->other) : 0,
+               fused && nb->pitch ? nb->pitch : (size_t)(h->cfg.N + 1) * (fused ? nb->stride : NX), fused && nb->ego_pitch ? nb->ego_pitch : (size_t)2};
     QueueArgs qa{h->dQctr, h->dQids, reinterpret_cast<unsigned long long *>(h->dQctr + 16)};
     const int B = h->cfg.batch, W = h->waves;
     LateArgs la{prefetched ? h->dProto : nullptr, {h->dForceAB[0], h->dForceAB[1]}, h->prefetch_timeout_us,
@@ -2290,7 +2416,7 @@ static int enqueue_step(ndp_handle *h, const double *d_x0, const double *d_xr, c
         if (nb.stride != 10 && nb.stride != 6) { h->err = "ndp_step: other_stride must be 10 or 6"; return -13; }
         if (!h->have_mlp) { h->err = "downwash requested but ndp_set_mlp_weights was never called"; return -6; }
         if (can_fuse(h)) return launch_rti(h, d_x0, d_xr, d_ur, nullptr, d_u0, d_dbg, s, &nb, so);
-        int rc = launch_mlp(h, nb, d_xr, h->dForce, s);
+        int rc = launch_mlp(h, nb, d_xr, h->dForce, s, so ? so->xr_pitch : 0);
         if (rc) return rc;
         d_f = h->dForce;
     }
@@ -2471,7 +2597,7 @@ static int ensure_slots(ndp_handle *h)
 }
 
 static int step_begin_locked(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
-                             const double *other, const double *ego_xy, bool want_iter, double *dump)
+                             const double *other, const double *ego_xy, bool want_iter, double *dump, bool f_f64 = false)
 {
     const size_t B = h->cfg.batch;
     hipStream_t s = h->stream;
@@ -2497,7 +2623,7 @@ static int step_begin_locked(ndp_handle *h, const double *x0, const double *xr, 
     };
     const size_t rows_o = B * (size_t)(h->cfg.N + 1);
     const size_t o_x0 = add(x0, B * NX * 8), o_xr = add(xr, nxs(h) * 8), o_ur = add(ur, nus(h) * 8);
-    const size_t o_f = f ? add(f, nfs(h) * 4) : 0;
+    const size_t o_f = f ? add(f, nfs(h) * (f_f64 ? 8 : 4)) : 0;
     const size_t o_other = other ? add(other, rows_o * 6 * 8, rows_o, 6 * 8, NX * 8) : 0;
     const size_t o_ego = ego_xy ? add(ego_xy, B * 2 * 8) : 0;
     const size_t used = o;          // <= in_bytes (the mirror holds every array at full width)
@@ -2538,6 +2664,7 @@ static int step_begin_locked(ndp_handle *h, const double *x0, const double *xr, 
     StepOut so;
     so.status = (int *)(sl.hOut + h->off_st); so.iters = (int *)(sl.hOut + h->off_it);
     if (want_iter) { so.Xm = (double *)(sl.hOut + h->out_bytes); so.Um = so.Xm + nxs(h); }
+    so.f_f64 = f_f64;
     // one packet less between the kernel's end and the host seeing it: the completion event rides on the step's last dispatch packet
     const bool ext_done = !dump && h->cfg.qp_precision == 0 && (!other || can_fuse(h)) && !getenv("NDP_HOST_EVENT_RECORD");
     if (ext_done) so.done = sl.evOut;
@@ -2559,6 +2686,7 @@ static int step_end_locked(ndp_handle *h, double *u0, double *X_out, double *U_o
 {
     const size_t B = h->cfg.batch;
     if (h->slots_busy == 0) { h->err = "ndp_step_end: no step in flight (ndp_step_begin first)"; return -14; }
+    if (h->tslot[h->slot_tail].busy) { h->err = "ndp_step_end: the oldest call in flight is a tick (ndp_tick_end it)"; return -14; }
     ndp_handle::HostSlot &sl = h->slot[h->slot_tail];
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     if ((X_out || U_out) && !sl.want_iter) { h->err = "ndp_step_end: the iterate was not requested at ndp_step_begin (flags bit 0)"; return -15; }
@@ -2614,12 +2742,12 @@ int ndp_step_end(ndp_handle *h, double *u0, double *X_out, double *U_out, int32_
 // The synchronous form: begin + end under ONE lock (a concurrent caller cannot slip a step in between).
 static int step_host(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
                      const double *other, const double *ego_xy, double *u0, double *X_out, double *U_out,
-                     int32_t *status_out, int32_t *iters_out, double *dump)
+                     int32_t *status_out, int32_t *iters_out, double *dump, bool f_f64 = false)
 {
     if (!h || !x0 || !xr || !ur || !u0) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
     if (h->slots_busy) { h->err = "ndp_step: steps begun with ndp_step_begin are still in flight (ndp_step_end them first)"; return -14; }
-    int rc = step_begin_locked(h, x0, xr, ur, f, other, ego_xy, X_out || U_out, dump);
+    int rc = step_begin_locked(h, x0, xr, ur, f, other, ego_xy, X_out || U_out, dump, f_f64);
     if (rc) return rc;
     return step_end_locked(h, u0, X_out, U_out, status_out, iters_out);
 }
@@ -2635,6 +2763,12 @@ int ndp_step_ex(ndp_handle *h, const double *x0, const double *xr, const double 
                 int32_t *status_out, int32_t *iters_out)
 {
     return step_host(h, x0, xr, ur, f, other, ego_xy, u0, X_out, U_out, status_out, iters_out, nullptr);
+}
+
+int ndp_step_ex_f64(ndp_handle *h, const double *x0, const double *xr, const double *ur, const double *f, double *u0,
+                    double *X_out, double *U_out, int32_t *status_out, int32_t *iters_out)
+{
+    return step_host(h, x0, xr, ur, reinterpret_cast<const float *>(f), nullptr, nullptr, u0, X_out, U_out, status_out, iters_out, nullptr, f != nullptr);
 }
 
 int ndp_step_debug(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
@@ -2926,8 +3060,9 @@ int ndp_ref_set_trajectory(ndp_handle *h, int n_seg, const double *coeff_x, cons
     int rc = wait_all(h);
     if (rc) return rc;
     if (h->dTraj) { (void)hipFree(h->dTraj); h->dTraj = nullptr; }
-    NDP_HIP(h, hipMalloc((void **)&h->dTraj, total * 8));
+    NDP_HIP(h, hipMalloc((void **)&h->dTraj, total * 8 + B * 4));                   // (+ the segment hints, int[B], see ref_point)
     NDP_HIP(h, hipMemcpy(h->dTraj, host.data(), total * 8, hipMemcpyHostToDevice));
+    NDP_HIP(h, hipMemset(h->dTraj + total, 0, B * 4));
     h->traj_seg = n_seg;
     return 0;
 }
@@ -2970,13 +3105,16 @@ int ndp_ref_window(ndp_handle *h, const double *t, double *xr, double *ur)
     return 0;
 }
 
-// ---- f1, the reference's sliding list (ref_list_* kernels)
-static int list_ring(const ndp_handle *h) { return h->cfg.N * h->list_step + 1; }
+// ---- f1, the reference's sliding list (ref_list_* kernels; layout: RingGeom)
+static RingGeom ring_geom(const ndp_handle *h) { return RingGeom{h->list_step, h->cfg.N + 1}; }
+static int list_ring(const ndp_handle *h) { return ring_geom(h).ring(); }
 
 static int list_alloc(ndp_handle *h)
 {
-    if (h->dRefList) return 0;
-    NDP_HIP(h, hipMalloc((void **)&h->dRefList, (size_t)h->cfg.batch * list_ring(h) * 14 * 8));
+    if (h->dRingX) return 0;
+    const RingGeom rg = ring_geom(h);
+    NDP_HIP(h, hipMalloc((void **)&h->dRingX, (size_t)h->cfg.batch * (rg.px() + rg.pu()) * 8));
+    h->dRingU = h->dRingX + (size_t)h->cfg.batch * rg.px();
     return 0;
 }
 
@@ -2985,14 +3123,16 @@ static RefCfg ref_cfg(const ndp_handle *h, double toff)
     return RefCfg{h->cfg.batch, h->cfg.N, h->traj_seg, h->cfg.dt, h->cfg.mass, h->cfg.gravity, toff};
 }
 
-static int launch_list_fill(ndp_handle *h, const double *d_t, double toff, int npts, int slot0, int dup0, hipStream_t s)
+// points at (d_t ? d_t[b] : 0) + toff + i * ts_nmpc, i = 0 .. npts-1, become list entries j0 + i (dup0: point 0 also entry j0 - 1)
+static int launch_list_fill(ndp_handle *h, const double *d_t, double toff, int npts, unsigned long long j0, int dup0, hipStream_t s)
 {
     if (!h->dTraj) { h->err = "ndp_ref_list: ndp_ref_set_trajectory was never called"; return -11; }
     const size_t B = h->cfg.batch, S = (size_t)h->traj_seg;
     const double *coeff = h->dTraj, *cum = coeff + B * S * 28, *seg = cum + B * (S + 1), *fpt = seg + B * S;
     const int n = h->cfg.batch * npts;
-    hipLaunchKernelGGL(ref_list_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ref_cfg(h, toff), coeff, cum, seg, fpt, d_t,
-                       h->cfg.ts_nmpc, npts, slot0, list_ring(h), dup0, h->dRefList);
+    const int bs = npts == 1 ? 64 : 256;        // one point per vehicle (the per-tick advance): small blocks spread over the CUs
+    hipLaunchKernelGGL(ref_list_fill_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, s, ref_cfg(h, toff), coeff, cum, seg, fpt, d_t,
+                       h->cfg.ts_nmpc, npts, j0, ring_geom(h), dup0, h->dRingX, h->dRingU);
     NDP_HIP(h, hipGetLastError());
     return 0;
 }
@@ -3004,8 +3144,9 @@ int ndp_ref_list_reset(ndp_handle *h)
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     int rc = list_alloc(h);
     if (rc) return rc;
-    h->list_head = 0;
-    // points at i * ts_nmpc, i = 0 .. ring-2, in slots 1 .. ring-1, the first one duplicated into slot 0 (:62-76)
+    if ((rc = wait_all(h))) return rc;
+    h->list_n = 0;
+    // entries 1 .. ring-1 = the points at i * ts_nmpc, i = 0 .. ring-2; the first one duplicated as entry 0 (:62-76)
     rc = launch_list_fill(h, nullptr, 0.0, list_ring(h) - 1, 1, 1, h->stream);
     if (rc) return rc;
     NDP_HIP(h, hipStreamSynchronize(h->stream));
@@ -3019,11 +3160,13 @@ int ndp_ref_list_fix_pt(ndp_handle *h, const double *x_odom, int quirk_b1)
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     int rc = list_alloc(h);
     if (rc) return rc;
-    h->list_head = 0;
+    if ((rc = wait_all(h))) return rc;
+    h->list_n = 0;
     NDP_HIP(h, hipMemcpyAsync(h->sThr, x_odom, (size_t)h->cfg.batch * 80, hipMemcpyHostToDevice, h->stream));
-    const int n = h->cfg.batch * list_ring(h);
-    hipLaunchKernelGGL(ref_list_fix_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const double *)h->sThr,
-                       quirk_b1 ? h->cfg.mass * h->cfg.gravity : h->cfg.gravity, h->cfg.batch, list_ring(h), h->dRefList);
+    const RingGeom rg = ring_geom(h);
+    const size_t n = (size_t)h->cfg.batch * rg.step * 2 * rg.np1;
+    hipLaunchKernelGGL(ref_list_fix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const double *)h->sThr,
+                       quirk_b1 ? h->cfg.mass * h->cfg.gravity : h->cfg.gravity, h->cfg.batch, rg, h->dRingX, h->dRingU);
     NDP_HIP(h, hipGetLastError());
     NDP_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -3032,11 +3175,10 @@ int ndp_ref_list_fix_pt(ndp_handle *h, const double *x_odom, int quirk_b1)
 // pop the oldest entry, append the point at trajectory time t + T_horizon (get_nmpc_pts, :79-93)
 static int list_advance(ndp_handle *h, const double *d_t, hipStream_t s)
 {
-    if (!h->dRefList) { h->err = "ndp_ref_list_advance: no list (ndp_ref_list_reset / ndp_ref_list_fix_pt first)"; return -11; }
-    const int ring = list_ring(h), tail = h->list_head;          // the popped slot becomes the new last entry
-    const int rc = launch_list_fill(h, d_t, h->cfg.N * h->cfg.dt, 1, tail, 0, s);
-    if (rc) return rc;                                             // nothing was launched (e.g. no trajectory): the ring keeps its head
-    h->list_head = (h->list_head + 1) % ring;
+    if (!h->dRingX) { h->err = "ndp_ref_list_advance: no list (ndp_ref_list_reset / ndp_ref_list_fix_pt first)"; return -11; }
+    const int rc = launch_list_fill(h, d_t, h->cfg.N * h->cfg.dt, 1, h->list_n + (unsigned long long)list_ring(h), 0, s);
+    if (rc) return rc;                                             // nothing was launched (e.g. no trajectory): the list stays as it is
+    ++h->list_n;
     return 0;
 }
 
@@ -3052,10 +3194,10 @@ int ndp_ref_list_advance_device(ndp_handle *h, const void *d_t, void *stream)
 
 static int launch_list_window(ndp_handle *h, double *d_xr, double *d_ur, hipStream_t s)
 {
-    if (!h->dRefList) { h->err = "ndp_ref_list_window: no list (ndp_ref_list_reset / ndp_ref_list_fix_pt first)"; return -11; }
-    const int n = h->cfg.batch * (h->cfg.N + 1);
-    hipLaunchKernelGGL(ref_list_window_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double *)h->dRefList, h->list_head,
-                       list_ring(h), h->list_step, h->cfg.batch, h->cfg.N, d_xr, d_ur);
+    if (!h->dRingX) { h->err = "ndp_ref_list_window: no list (ndp_ref_list_reset / ndp_ref_list_fix_pt first)"; return -11; }
+    const size_t n = (size_t)h->cfg.batch * (5 * (h->cfg.N + 1) + 2 * h->cfg.N);
+    hipLaunchKernelGGL(ref_list_window_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const double *)h->dRingX,
+                       (const double *)h->dRingU, ring_geom(h), h->list_n, h->cfg.batch, d_xr, d_ur);
     NDP_HIP(h, hipGetLastError());
     return 0;
 }
@@ -3086,6 +3228,209 @@ int ndp_ref_list_window(ndp_handle *h, const double *t, double *xr, double *ur)
     NDP_HIP(h, hipMemcpyAsync(ur, h->sur, nus(h) * 8, hipMemcpyDeviceToHost, h->stream));
     NDP_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
+}
+
+// ---- the node's control tick, end to end on the device (nmpc_node.py:211-231; kernels: tick_pre_kernel, rti_kernel, tick_post_kernel)
+static int ensure_tick(ndp_handle *h)
+{
+    if (h->dTickThrust) return 0;
+    NDP_HIP(h, hipMalloc((void **)&h->dTickThrust, (size_t)h->cfg.batch * 8));
+    NDP_HIP(h, hipMemsetAsync(h->dTickThrust, 0, (size_t)h->cfg.batch * 8, h->stream));     // AttitudeTarget(): thrust 0 (nmpc_node.py:104)
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ndp_tick_config(ndp_handle *h, const int32_t *other_index, int gate_on_odometry)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = wait_all(h);
+    if (rc) return rc;
+    if ((rc = ensure_tick(h))) return rc;
+    const size_t B = h->cfg.batch;
+    bool any = false;
+    if (other_index)
+        for (size_t i = 0; i < B; ++i) {
+            if (other_index[i] >= (int32_t)B) { h->err = "ndp_tick_config: other_index names an instance outside the handle"; return -2; }
+            any = any || other_index[i] >= 0;
+        }
+    if (any && !h->cfg.use_fd) { h->err = "ndp_tick_config: neighbours (downwash) need use_fd = 1 (NDP model)"; return -8; }
+    if (any && !h->have_mlp) { h->err = "ndp_tick_config: neighbours given but ndp_set_mlp_weights was never called"; return -6; }
+    if (any) {
+        if (!h->dTickIndex) NDP_HIP(h, hipMalloc((void **)&h->dTickIndex, B * 4));
+        NDP_HIP(h, hipMemcpy(h->dTickIndex, other_index, B * 4, hipMemcpyHostToDevice));
+    } else if (h->dTickIndex) {
+        (void)hipFree(h->dTickIndex);
+        h->dTickIndex = nullptr;
+    }
+    h->tick_gate = gate_on_odometry != 0;
+    return 0;
+}
+
+// nmpc_ctl.reset(*ref_pub.get_nmpc_ref_from_long_list()) (nmpc_node.py:92,151-152): the iterate := the list's current window
+int ndp_tick_reset(ndp_handle *h)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    if (h->slots_busy) { h->err = "ndp_tick_reset: ticks are still in flight (ndp_tick_end them first)"; return -14; }
+    int rc = wait_all(h);
+    if (rc) return rc;
+    if ((rc = launch_list_window(h, h->dX, h->dU, h->stream))) return rc;
+    NDP_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+enum { TICK_ESTIMATE = 1, TICK_WANT_U0 = 2 };
+
+// One tick's launches on `s`.  Every pointer is device-accessible (HBM or page-locked host memory): x_odom[B][10]; t[B] or null (the
+// list is not advanced: hover at a fixed point, or a vehicle between two trajectories); vz[B] or null (column 5 of x_odom);
+// throttle[B] or null (the thrust this handle commanded last tick); cmd[B][4]; u0_copy[B][4] or null.
+static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, const double *t, const double *vz, const double *throttle,
+                        int flags, double *cmd, double *u0_copy, StepOut so)
+{
+    int rc = ensure_tick(h);
+    if (rc) return rc;
+    if (!h->dRingX) { h->err = "ndp_tick: no reference list (ndp_ref_list_fix_pt, or ndp_ref_set_trajectory + ndp_ref_list_reset, first)"; return -11; }
+    if (t && !h->dTraj) { h->err = "ndp_tick: a trajectory time was given but ndp_ref_set_trajectory was never called"; return -11; }
+    const int B = h->cfg.batch;
+    const RingGeom rg = ring_geom(h);
+    const bool est = (flags & TICK_ESTIMATE) != 0;
+    if (t || est) {
+        TickPre a{};
+        a.cf = ref_cfg(h, h->cfg.N * h->cfg.dt);
+        if (t) {
+            const size_t Bs = (size_t)B, S = (size_t)h->traj_seg;
+            a.coeff = h->dTraj; a.tcum = a.coeff + Bs * S * 28; a.tseg = a.tcum + Bs * (S + 1); a.fpt = a.tseg + Bs * S;
+            a.seg_hint = reinterpret_cast<int *>(const_cast<double *>(a.fpt + Bs * 3));
+        }
+        a.t = t;
+        a.j_new = h->list_n + (unsigned long long)rg.ring();
+        a.rg = rg; a.rx = h->dRingX; a.ru = h->dRingU;
+        a.thr = thr_cfg(h); a.st = h->dThr;
+        a.vz = vz ? vz : x_odom + 5; a.vz_pitch = vz ? 1 : NX;
+        a.throttle = throttle ? throttle : h->dTickThrust;
+        a.est = est ? 1 : 0;
+        hipLaunchKernelGGL(tick_pre_kernel, dim3((B + 63) / 64), dim3(64), 0, s, a);
+        NDP_HIP(h, hipGetLastError());
+        if (t) ++h->list_n;
+    }
+    const size_t slot = rg.slot(h->list_n);
+    Neigh nb;
+    if (h->dTickIndex) {
+        nb.other = h->dRingX + slot * 10; nb.stride = NX; nb.index = h->dTickIndex; nb.pitch = rg.px();
+        if (h->tick_gate) { nb.ego_xy = x_odom; nb.ego_pitch = NX; }
+    }
+    so.xr_pitch = rg.px(); so.ur_pitch = rg.pu();
+    // nmpc_u_2_att_tgt is the control step's own last store (RtiIo::cmd): no third launch.  k_throttle = row 1 of the estimator's state
+    // (k_throttle_init until the estimator has run)
+    so.cmd = cmd; so.kthr = h->dThr + (size_t)B; so.thrust_keep = h->dTickThrust;
+    return enqueue_step(h, x_odom, h->dRingX + slot * 10, h->dRingU + slot * 4, nullptr, nb, u0_copy ? u0_copy : h->su0, nullptr, s, &so);
+}
+
+int ndp_tick_device(ndp_handle *h, const void *d_x_odom, const void *d_t, const void *d_vz, const void *d_throttle, int flags,
+                    void *d_cmd, void *d_u0, void *stream)
+{
+    if (!h || !d_x_odom || !d_cmd) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = tick_enqueue(h, s, (const double *)d_x_odom, (const double *)d_t, (const double *)d_vz, (const double *)d_throttle, flags,
+                          (double *)d_cmd, (double *)d_u0, StepOut());
+    return rc ? rc : note_stream(h, s);
+}
+
+// host arrays: the inputs of a tick are packed into a slot's page-locked input mirror -- x_odom | t | vz | throttle, 80 + 24 bytes per
+// vehicle at most -- which the tick's kernels read over PCIe themselves; cmd | status | iterations (| u0) are written into the
+// slot's page-locked output mirror by the kernels (the same two slots, the same zero-copy scheme as ndp_step_begin / _end)
+static int tick_begin_locked(ndp_handle *h, const double *x_odom, const double *t, const double *vz, const double *throttle, int flags)
+{
+    const size_t B = h->cfg.batch;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_slots(h);
+    if (rc) return rc;
+    if (h->slots_busy == 2) { h->err = "ndp_tick_begin: two ticks are already in flight (call ndp_tick_end first)"; return -14; }
+    if (h->ev_pending && (rc = wait_all(h))) return rc;
+    ndp_handle::HostSlot &sl = h->slot[h->slot_head];
+    const auto tp0 = std::chrono::steady_clock::now();
+    unsigned char *ib = sl.hIn;
+    const size_t o_t = up256(B * NX * 8), o_vz = o_t + up256(B * 8), o_th = o_vz + up256(B * 8);    // (<= in_bytes: the mirror holds a whole step's inputs)
+    memcpy(ib, x_odom, B * NX * 8);
+    if (t) memcpy(ib + o_t, t, B * 8);
+    if (vz) memcpy(ib + o_vz, vz, B * 8);
+    if (throttle) memcpy(ib + o_th, throttle, B * 8);
+    const auto tp1 = std::chrono::steady_clock::now();
+    StepOut so;
+    so.status = (int *)(sl.hOut + h->off_st); so.iters = (int *)(sl.hOut + h->off_it);
+    so.done = sl.evOut;
+    const bool want_u0 = (flags & TICK_WANT_U0) != 0;
+    rc = tick_enqueue(h, h->stream, (const double *)ib, t ? (const double *)(ib + o_t) : nullptr, vz ? (const double *)(ib + o_vz) : nullptr,
+                      throttle ? (const double *)(ib + o_th) : nullptr, flags, (double *)(sl.hOut + h->off_u0),
+                      want_u0 ? (double *)(sl.hOut + h->out_bytes) : nullptr, so);
+    if (rc) return rc;
+    sl.busy = true; sl.want_iter = false; sl.dump = nullptr;
+    h->tslot[h->slot_head].busy = true; h->tslot[h->slot_head].want_u0 = want_u0;
+    h->host_us[0] = std::chrono::duration<double, std::micro>(tp1 - tp0).count();
+    h->host_us[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp1).count();
+    h->slot_head ^= 1;
+    ++h->slots_busy;
+    return 0;
+}
+
+static int tick_end_locked(ndp_handle *h, double *cmd, double *u0, int32_t *status_out, int32_t *iters_out)
+{
+    const size_t B = h->cfg.batch;
+    if (h->slots_busy == 0 || !h->tslot[h->slot_tail].busy) { h->err = "ndp_tick_end: no tick in flight (ndp_tick_begin first)"; return -14; }
+    ndp_handle::HostSlot &sl = h->slot[h->slot_tail];
+    if (u0 && !h->tslot[h->slot_tail].want_u0) { h->err = "ndp_tick_end: u0 was not requested at ndp_tick_begin (flags bit 1)"; return -15; }
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    const auto tw0 = std::chrono::steady_clock::now();
+    hipError_t e = hipErrorNotReady;
+    for (int spin = 0; spin < 4000 && e == hipErrorNotReady; ++spin) e = hipEventQuery(sl.evOut);
+    if (e == hipErrorNotReady) e = hipEventSynchronize(sl.evOut);
+    sl.busy = false;
+    h->tslot[h->slot_tail].busy = false;
+    h->slot_tail ^= 1;
+    --h->slots_busy;
+    NDP_HIP(h, e);
+    const auto tw1 = std::chrono::steady_clock::now();
+    const unsigned char *ho = sl.hOut;
+    memcpy(cmd, ho + h->off_u0, B * NU * 8);
+    if (u0) memcpy(u0, ho + h->out_bytes, B * NU * 8);
+    const int32_t *st = (const int32_t *)(ho + h->off_st);
+    if (status_out) memcpy(status_out, st, B * 4);
+    if (iters_out) memcpy(iters_out, ho + h->off_it, B * 4);
+    int w = 0;
+    for (size_t i = 0; i < B; ++i) w = st[i] > w ? st[i] : w;
+    h->host_us[2] = std::chrono::duration<double, std::micro>(tw1 - tw0).count();
+    h->host_us[3] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw1).count();
+    return w;
+}
+
+int ndp_tick_begin(ndp_handle *h, const double *x_odom, const double *t, const double *vz, const double *throttle, int flags)
+{
+    if (!h || !x_odom) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    return tick_begin_locked(h, x_odom, t, vz, throttle, flags);
+}
+
+int ndp_tick_end(ndp_handle *h, double *cmd, double *u0, int32_t *status_out, int32_t *ipm_iters_out)
+{
+    if (!h || !cmd) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    return tick_end_locked(h, cmd, u0, status_out, ipm_iters_out);
+}
+
+int ndp_tick(ndp_handle *h, const double *x_odom, const double *t, const double *vz, const double *throttle, int flags,
+             double *cmd, double *u0, int32_t *status_out, int32_t *ipm_iters_out)
+{
+    if (!h || !x_odom || !cmd) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->slots_busy) { h->err = "ndp_tick: steps / ticks begun earlier are still in flight (end them first)"; return -14; }
+    int rc = tick_begin_locked(h, x_odom, t, vz, throttle, flags | (u0 ? TICK_WANT_U0 : 0));
+    if (rc) return rc;
+    return tick_end_locked(h, cmd, u0, status_out, ipm_iters_out);
 }
 
 // ---- f4: plant step
@@ -3170,6 +3515,7 @@ void *ndp_device_iterate_x(ndp_handle *h) { return h ? h->dX : nullptr; }
 void *ndp_device_iterate_u(ndp_handle *h) { return h ? h->dU : nullptr; }
 void *ndp_device_force(ndp_handle *h) { return h ? h->dForce : nullptr; }
 int ndp_work_queue_enabled(ndp_handle *h) { return h ? (int)h->use_queue : -1; }
+int ndp_refine_active(ndp_handle *h) { return h ? (int)(h->cfg.ipm_refine > 0 && slots_for(h->cfg.N) <= 3 && h->cfg.qp_precision == 0) : -1; }
 
 int ndp_synchronize(ndp_handle *h)
 {

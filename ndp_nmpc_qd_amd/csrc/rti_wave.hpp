@@ -125,6 +125,11 @@ struct RtiIo {            // global-memory views of ONE instance
     unsigned late_gsize = 1;               // workgroups per group and launch
     void *late_group = nullptr;            // backend-specific counter shared by the waves of a workgroup, or null
     unsigned late_group_size = 1;
+    // ndp_tick: the actuator command nmpc_u_2_att_tgt makes of u_0 (nmpc_node.py:273-283), written by the control step itself beside
+    // u_0: cmd[4] = [wx, wy, wz, c mass / k_throttle]; the thrust is also kept for the next estimator update.  Null = not a tick.
+    double *cmd = nullptr, *thrust_keep = nullptr;
+    double kthr = 0.0, cmd_mass = 0.0;
+    int f_is_f64 = 0;     // 1: f points at doubles (the reference hands acados a float64 p, ndp_nmpc_body_rate_ctl.py:97-99); 0: fp32, what DownwashNN returns
 };
 
 struct LdsMap {
@@ -478,7 +483,7 @@ struct RtiWave {
         }
         for (int t = 0; t < RF; ++t) {
             vi i = W::imin(lane + 64 * t, nf - 1);
-            b.f[t] = have_f ? W::gldfu(io.f, i) : vd(0.0);
+            b.f[t] = have_f ? (NDP_RARELY(io.f_is_f64 != 0) ? W::gldu(reinterpret_cast<const double *>(io.f), i) : W::gldfu(io.f, i)) : vd(0.0);
         }
         b.kc = first ? W::gldu(io.kc, W::imin(lane, KC_SC - 1)) : vd(0.0);
     }
@@ -1798,11 +1803,13 @@ struct RtiWave {
                         if (t == (nzx >> 6)) {   // the round that holds u_0 = U[0..3] (wave-uniform test)
                             vb pu = (i >= nzx) && (i < nzx + NU);
                             W::gst(io.u0, i - nzx, xn, pu);
+                            if (NDP_RARELY(io.cmd != nullptr)) W::cmd_store(io.cmd, io.thrust_keep, io.kthr, io.cmd_mass, i - nzx, xn, pu);
                             if (W::any(pu && !(xn == xn))) status = 1;
                         }
                         if (nzx + NU > 64 * ((nzx >> 6) + 1) && t == (nzx >> 6) + 1) {   // u_0 straddles two rounds
                             vb pu = (i >= nzx) && (i < nzx + NU);
                             W::gst(io.u0, i - nzx, xn, pu);
+                            if (NDP_RARELY(io.cmd != nullptr)) W::cmd_store(io.cmd, io.thrust_keep, io.kthr, io.cmd_mass, i - nzx, xn, pu);
                             if (W::any(pu && !(xn == xn))) status = 1;
                         }
                     }

@@ -77,6 +77,24 @@ struct WaveGfx950 {
     // element i of the concatenation [a (n elements) | b]: one store through a per-lane pointer instead of two predicated ones
     static NDP_D void gst2(double *a, double *b, vi i, int n, vd v) { (i < n ? a + i : b + (i - n))[0] = v; }
     static NDP_D void gsti(int *g, int v) { if (g && lane() == 0) *g = v; }
+    // ndp_tick: element idx (0..3) of the actuator command made of u_0's element v (RtiIo::cmd): body rates pass through, thrust =
+    // c * mass / k_throttle, 0 if k == 0 (nmpc_u_2_att_tgt, nmpc_node.py:281) -- the product rounded by itself, then an IEEE divide,
+    // as Python evaluates it (and as actuator_kernel does)
+    static NDP_D void cmd_store(double *cmd, double *keep, double k, double mass, vi idx, vd v, vb p)
+    {
+        if (p) {
+            if (idx == 3) {
+                double cm;
+                {
+#pragma clang fp contract(off)
+                    cm = v * mass;
+                }
+                v = k != 0.0 ? cm / k : 0.0;
+                *keep = v;
+            }
+            cmd[idx] = v;
+        }
+    }
     // late-force protocol (rti_wave.hpp: RtiIo::f_late): wait until both words have reached `want` (agent-scope acquire), at most
     // timeout_us.  The words differ from instance to instance (per-tile epochs of the downwash launch): 1024 waves reading ONE
     // word at agent scope serialise at the memory side (the XCDs' L2s are not coherent with each other: such loads bypass them) --

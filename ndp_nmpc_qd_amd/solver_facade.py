@@ -78,7 +78,8 @@ class SolverFacade:
             # reads the reference quaternion from xr, so a differing p is not representable.
             if not np.array_equal(self._p[:, 0:4], xr[:, 6:10]):
                 raise Exception("this drop-in requires p[0:4] == yref[6:10] (as nmpc_body_rate_ctl.py:99-104 sets it)")
-            f = self._p[:, 4:7].astype(np.float32)[None] if self._np == 7 else None
+            # the force stays float64, as the reference's p is (ndp_nmpc_body_rate_ctl.py:97-99): ndp_step_ex_f64
+            f = np.ascontiguousarray(self._p[:, 4:7])[None] if self._np == 7 else None
             # one C-ABI call: inputs in, u0 + new iterate + status out (ndp_step_ex); nothing else touches the device per tick
             u0, X, U, st, _ = self._eng.update(np.asarray(x0, dtype=np.float64)[None], xr[None], ur[None], f=f,
                                                raise_on_status=False, full=True)

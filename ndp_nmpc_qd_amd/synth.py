@@ -63,6 +63,38 @@ def figure_eight(omega, phi, t):
     return pos, vel, acc, jerk
 
 
+def figure_eight_traj(B, seed=SEED0, n_seg=40, t_seg=0.5, omega_range=(0.5, 1.5)):
+    """The figure-eights of make_batch(B, seed=seed) (same omega, phi per instance) as TrajCoefficients.msg arrays: piecewise septic
+    polynomials in the reference's normalised segment time (base_pt_publisher.py:100-133: s = (t - time_cum[i]) / time_seg[i],
+    derivative d scaled by time_seg^-d) that match position, velocity, acceleration and jerk of the analytic curve at both ends of
+    every segment.  Yaw = 0.
+    Returns dict coeff_x / coeff_y / coeff_z [B, n_seg*8], coeff_yaw [B, n_seg*4], time_cum [B, n_seg+1], time_seg [B, n_seg],
+    final_pt [B, 3] (what BatchedNMPC.ref_set_trajectory takes) + omega, phi."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    omega = rng.uniform(*omega_range, size=B)
+    phi = rng.uniform(0.0, 2 * np.pi, size=B)
+    tk = t_seg * np.arange(n_seg + 1)
+    pos, vel, acc, jerk = figure_eight(omega[:, None], phi[:, None], tk[None, :])            # [B, n_seg+1, 3]
+    # rows: p(0), p'(0), p''(0), p'''(0), p(1), p'(1), p''(1), p'''(1) of sum c_i s^i
+    A = np.zeros((8, 8))
+    for d in range(4):
+        for i in range(d, 8):
+            fac = float(np.prod(np.arange(i - d + 1, i + 1))) if d else 1.0
+            A[d, i] = fac if i == d else 0.0
+            A[4 + d, i] = fac
+    Ainv = np.linalg.inv(A)
+    der = [pos, vel * t_seg, acc * t_seg ** 2, jerk * t_seg ** 3]
+    rhs = np.stack([d_[:, :-1] for d_ in der] + [d_[:, 1:] for d_ in der], axis=-1)         # [B, n_seg, 3, 8]
+    c = np.einsum("ij,bsaj->bsai", Ainv, rhs)                                                  # [B, n_seg, 3, 8]
+    out = {"coeff_" + ax: np.ascontiguousarray(c[:, :, a, :].reshape(B, n_seg * 8)) for a, ax in enumerate("xyz")}
+    out["coeff_yaw"] = np.zeros((B, n_seg * 4))
+    out["time_cum"] = np.tile(tk, (B, 1))
+    out["time_seg"] = np.full((B, n_seg), t_seg)
+    out["final_pt"] = np.ascontiguousarray(pos[:, -1, :])
+    out["omega"], out["phi"] = omega, phi
+    return out
+
+
 def hover_reference(N=CP.N_node, pos=(0.0, 0.0, 1.0), quirk_b1=False):
     """gen_fix_pt_ref (pt_publisher.py:40-55).  quirk_b1 reproduces u_r[3] = mass*g."""
     xr = np.tile(np.array([*pos, 0, 0, 0, 1, 0, 0, 0], dtype=np.float64), (N + 1, 1))

@@ -115,6 +115,15 @@ struct Wave {
     static vd gld(const double *g, const vi &off, const vb &p) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = p.v[l] ? g[off.v[l]] : 0.0; return o; }
     static vd gldf(const float *g, const vi &off, const vb &p) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = p.v[l] ? (double)g[off.v[l]] : 0.0; return o; }
     static void gst(double *g, const vi &off, const vd &val, const vb &p) { for (int l = 0; l < 64; ++l) if (p.v[l]) g[off.v[l]] = val.v[l]; }
+    static void cmd_store(double *cmd, double *keep, double k, double mass, const vi &idx, const vd &val, const vb &p)
+    {
+        for (int l = 0; l < 64; ++l)
+            if (p.v[l]) {
+                double v = val.v[l];
+                if (idx.v[l] == 3) { v = k != 0.0 ? v * mass / k : 0.0; *keep = v; }
+                cmd[idx.v[l]] = v;
+            }
+    }
     static vd gldu(const double *g, const vi &off) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = g[off.v[l]]; return o; }
     static vd gldfu(const float *g, const vi &off) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)g[off.v[l]]; return o; }
     static vi gldi(const int *g, const vi &off) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = g[off.v[l]]; return o; }

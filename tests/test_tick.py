@@ -1,0 +1,348 @@
+"""The node's control tick end to end on the device (ndp_tick: odometry in, actuator command out, references resident) --
+ControllerNode.nmpc_callback + hover_throttle_callback, nmpc_node.py:211-231,251-253, for every vehicle of a handle.
+
+What pins it:
+  * the tick-by-tick composition of the calls that existed before it (reference list advance + window, estimator update,
+    control step with the neighbour's window, actuator command): bit-equal u0 / cmd / status over 60 ticks;
+  * the fixtures made by running the reference's own code: the 60-tick window sequence of NMPCRefPublisher (flat_golden.npz),
+    the estimator sequence of HoverThrottleEstimator (throttle_golden.npz);
+  * the CPU oracle (control step + downwash) on the same inputs.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from ndp_nmpc_qd_amd.params import nmpc_params as CP
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def flat():
+    return np.load(os.path.join(ROOT, "tests", "golden", "flat_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def thr_gold():
+    return np.load(os.path.join(ROOT, "tests", "golden", "throttle_golden.npz"))
+
+
+def _cum(tseg):
+    return np.concatenate([np.zeros((tseg.shape[0], 1)), np.cumsum(tseg, axis=1)], axis=1)
+
+
+def _seq_traj(gold, flat, reps=1):
+    """The five trajectories of the reference-run window sequence, `reps` times over (vehicle V r + v flies trajectory v)."""
+    c = int(flat["seq_case"])
+    coeff, tseg, wpts = gold[f"coeff_{c}"], flat["seq_tseg"], gold[f"wpts_{c}"]
+    coeff, tseg, fpt = (np.tile(a, (reps,) + (1,) * (a.ndim - 1)) for a in (coeff, tseg, wpts[:, 0:3, -1].copy()))
+    return coeff, tseg, _cum(tseg), fpt
+
+
+def _set_traj(eng, coeff, tseg, cum, fpt):
+    eng.ref_set_trajectory(coeff[:, :, 0:8], coeff[:, :, 8:16], coeff[:, :, 16:24], coeff[:, :, 24:28], cum, tseg, fpt)
+
+
+def _odometry(rng, xr):
+    """x0 = node 0 of the window + measurement noise (SURVEY 8d's recipe), quaternion normalised."""
+    x = xr[:, 0, :].copy()
+    x[:, 0:3] += rng.normal(0, 0.1, (x.shape[0], 3))
+    x[:, 3:6] += rng.normal(0, 0.2, (x.shape[0], 3))
+    x[:, 6:10] += rng.normal(0, 0.03, (x.shape[0], 4))
+    x[:, 6:10] /= np.linalg.norm(x[:, 6:10], axis=1, keepdims=True)
+    return x
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
+def test_tick_equals_the_composition_the_fixtures_and_the_oracle(oracle, gold, flat, mlp_blob):
+    import torch
+    import ndp_nmpc_qd_amd as ndp
+    V, reps = 5, 2
+    B = V * reps
+    coeff, tseg, cum, fpt = _seq_traj(gold, flat, reps)
+    fpt[V:, 1] += 0.6                      # (the second set lands 0.6 m beside the first: final points differ)
+    # vehicles 0..4: NDP leaders whose neighbour is the next vehicle of the set (ring); 5..9: plain vehicles (no neighbour).
+    other_index = np.array([(v + 1) % V for v in range(V)] + [-1] * V, dtype=np.int32)
+    dev = torch.device("cuda", 0)
+
+    tk = ndp.BatchedNMPC(B, disturbance=True)          # the tick
+    cp = ndp.BatchedNMPC(B, disturbance=True)          # the composition of the existing calls
+    for e in (tk, cp):
+        _set_traj(e, coeff, tseg, cum, fpt)
+        e.ref_list_reset()
+        e.throttle_reset()
+    tk.tick_config(other_index, gate=True)
+    tk.tick_reset()
+    xr0, ur0 = cp.ref_list_window(None)
+    np.testing.assert_allclose(xr0[:V], flat["seq_xr0"], rtol=0, atol=1e-7)
+    cp.reset(xr0, ur0)
+    Xt, Ut = tk.get_iterate()
+    assert np.array_equal(Xt, xr0) and np.array_equal(Ut, ur0)       # tick_reset = reset(window of the list)
+
+    cfg = oracle.default_cfg(use_fd=True)
+    Xo, Uo = xr0.copy(), ur0.copy()
+    tcfg = oracle.thr_default_cfg()
+    tst = oracle.thr_reset(tcfg, B)
+    ko = np.full(B, float(tcfg.k_init))
+    idx_t = torch.from_numpy(other_index).to(dev)
+    u0_t = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(11)
+    thrust_prev = np.zeros(B)
+    k_prev = np.full(B, 50.0)
+    worst_u0 = worst_f = 0.0
+    n_open = n_ipm = n_bad = 0
+    for i, t in enumerate(flat["seq_t"]):
+        tt = np.full(B, float(t))
+        est = i % 3 != 2                                  # the estimator's timer is not the control timer: skip every third tick
+        # ---- the composition, call by call
+        xr, ur = cp.ref_list_window(tt)
+        np.testing.assert_allclose(xr[:V], flat["seq_xr"][i], rtol=0, atol=1e-7)       # the reference's own windows
+        np.testing.assert_allclose(ur[:V], flat["seq_ur"][i], rtol=0, atol=1e-7)
+        x0 = _odometry(rng, xr)
+        k = cp.throttle_update(x0[:, 5].copy(), thrust_prev) if est else k_prev
+        cp.update_device(torch.from_numpy(x0).to(dev), torch.from_numpy(xr).to(dev), torch.from_numpy(ur).to(dev), u0_t,
+                         other=torch.from_numpy(xr).to(dev), other_index=idx_t, ego_xy=torch.from_numpy(x0[:, 0:2].copy()).to(dev))
+        cp.synchronize()
+        u0_c = u0_t.cpu().numpy()
+        st_c, it_c = cp.status()
+        cmd_c = cp.actuator_cmd(u0_c, k)
+        # ---- the tick
+        cmd, u0, st, it = tk.tick(x0, t=tt, estimate=est, full=True, raise_on_status=False)
+        assert np.array_equal(u0, u0_c), (i, np.max(np.abs(u0 - u0_c)))
+        assert np.array_equal(cmd, cmd_c), (i, np.max(np.abs(cmd - cmd_c)))
+        assert np.array_equal(st, st_c) and np.array_equal(it, it_c)
+        # ---- the oracle: gate + network on the neighbour's window, the control step, estimator + thrust
+        nb = np.where(other_index >= 0, other_index, 0)
+        f = oracle.downwash_batch(mlp_blob, xr[nb], xr, x0[:, 0:2].copy())
+        f[other_index < 0] = 0.0
+        n_open += int(np.any(f[:V] != 0.0, axis=(1, 2)).sum())
+        u_or, st_o, it_o = oracle.step_batch(cfg, x0, xr, ur, f, Xo, Uo)
+        # trajectory 0 of the fixture saturates the thrust at both bounds; with this noise two of its ticks exhaust the interior-point
+        # iterations -- on the device exactly where the oracle does (status 4 = acados' QP failure, never a silent answer)
+        assert np.array_equal(st, st_o), (i, st, st_o)
+        ok = st == 0
+        n_bad += int((~ok).sum())
+        n_ipm += int((it > 0).sum())
+        worst_u0 = max(worst_u0, _rel(u0[ok], u_or[ok]))
+        worst_f = max(worst_f, _rel(tk.device_force().cpu().numpy(), f))
+        if est:
+            ko = oracle.thr_update(tcfg, tst, x0[:, 5].copy(), thrust_prev)
+        thrust_o = oracle.att_thrust(tcfg, u_or[:, 3], ko)
+        assert np.max(np.abs(cmd[ok, 3] - thrust_o[ok]) / np.maximum(0.1, np.abs(thrust_o[ok]))) < 1e-5     # (a thrust of ~0.3; 0 when c sits on its lower bound)
+        thrust_prev, k_prev = cmd[:, 3].copy(), k
+    assert worst_u0 < 1e-5 and worst_f < 1e-5, (worst_u0, worst_f)
+    assert n_open > 20                                     # the gate was open for some leaders, closed for others
+    assert n_ipm > 60 and n_bad <= 6, (n_ipm, n_bad)        # active bounds were exercised through the tick
+    Xt, Ut = tk.get_iterate()
+    Xc, Uc = cp.get_iterate()
+    assert np.array_equal(Xt, Xc) and np.array_equal(Ut, Uc)
+    assert np.all(np.abs(tk.throttle_state() - tst) <= 1e-6 * np.maximum(1.0, np.abs(tst)))      # (the oracle's estimator saw the oracle's thrusts)
+    assert np.array_equal(tk.throttle_state(), cp.throttle_state())
+
+
+def test_tick_estimator_follows_the_reference_fixture(thr_gold):
+    """260 ticks of HoverThrottleEstimator.update as the reference computed them (throttle_golden.npz), driven through the tick:
+    vz and throttle handed in, the reference list at a fixed point (t = None: it is not advanced)."""
+    import ndp_nmpc_qd_amd as ndp
+    T, V = thr_gold["vz"].shape
+    eng = ndp.BatchedNMPC(V, load_mlp=False)
+    x = np.tile(np.array([0, 0, 1.0, 0, 0, 0, 1, 0, 0, 0]), (V, 1))
+    eng.ref_list_fix_pt(x)
+    eng.tick_reset()
+    eng.throttle_reset()
+    for i in range(T):
+        cmd, u0, st, _ = eng.tick(x, vz=thr_gold["vz"][i], throttle=thr_gold["throttle"][i], estimate=True, full=True)
+        s = eng.throttle_state() if (i % 20 == 0 or i in (50, 55, 60, 200, 201, T - 1)) else None
+        if s is not None:
+            assert np.all(np.abs(s[:, 1] - thr_gold["k"][i]) <= 1e-12 * np.abs(thr_gold["k"][i]))
+            assert np.all(np.abs(s[:, 2:6] - thr_gold["P"][i].reshape(-1, 4)) <= 1e-12 * np.maximum(1.0, np.abs(thr_gold["P"][i].reshape(-1, 4))))
+            # nmpc_u_2_att_tgt on the tick's own u0 with the reference's k
+            assert np.all(np.abs(cmd[:, 3] - u0[:, 3] * float(thr_gold["mass"]) / thr_gold["k"][i]) <= 1e-12 * np.abs(cmd[:, 3]))
+        assert np.array_equal(cmd[:, :3], u0[:, :3])
+        if i == 0:   # hover at the fixed point with the reference's u_r[3] = mass * g: c below g, the same for every vehicle
+            assert abs(u0[0, 3] - 9.79359713) < 1e-6 and np.allclose(u0, u0[0], rtol=0, atol=1e-12)
+
+
+def test_tick_throttle_default_is_the_previous_command(gold, flat):
+    """throttle = None: the estimator reads the thrust this handle commanded one tick earlier (body_rate_cmd.thrust, nmpc_node.py:253),
+    vz = None: column 5 of the odometry."""
+    import ndp_nmpc_qd_amd as ndp
+    coeff, tseg, cum, fpt = _seq_traj(gold, flat)
+    B = coeff.shape[0]
+    a, b = ndp.BatchedNMPC(B, load_mlp=False), ndp.BatchedNMPC(B, load_mlp=False)
+    for e in (a, b):
+        _set_traj(e, coeff, tseg, cum, fpt)
+        e.ref_list_reset()
+        e.tick_reset()
+    rng = np.random.default_rng(3)
+    prev = np.zeros(B)
+    for i, t in enumerate(flat["seq_t"][:25]):
+        x0 = _odometry(rng, a.ref_list_window(None)[0])
+        x0[:, 5] = rng.normal(0, 0.3, B)
+        tt = np.full(B, float(t))
+        ca = a.tick(x0, t=tt, estimate=True)
+        cb = b.tick(x0, t=tt, vz=x0[:, 5].copy(), throttle=prev, estimate=True)
+        assert np.array_equal(ca, cb)
+        prev = cb[:, 3].copy()
+    assert np.array_equal(a.throttle_state(), b.throttle_state())
+    assert not np.array_equal(a.throttle_state()[:, 6], np.zeros(B))          # the differentiator did run
+
+
+def test_two_ticks_in_flight_and_misuse(gold, flat):
+    import ndp_nmpc_qd_amd as ndp
+    coeff, tseg, cum, fpt = _seq_traj(gold, flat, 3)
+    B = coeff.shape[0]
+    seq, pipe = ndp.BatchedNMPC(B, load_mlp=False), ndp.BatchedNMPC(B, load_mlp=False)
+    for e in (seq, pipe):
+        _set_traj(e, coeff, tseg, cum, fpt)
+        e.ref_list_reset()
+        e.tick_reset()
+    rng = np.random.default_rng(5)
+    xs = [_odometry(rng, seq.ref_list_window(None)[0]) for _ in range(8)]
+    ts = [np.full(B, float(t)) for t in flat["seq_t"][:8]]
+    want = [seq.tick(x, t=t, estimate=True) for x, t in zip(xs, ts)]
+    got = []
+    pipe.tick_begin(xs[0], t=ts[0], estimate=True)
+    for i in range(1, 8):
+        pipe.tick_begin(xs[i], t=ts[i], estimate=True)            # tick i is enqueued while tick i-1 may still run
+        got.append(pipe.tick_end())
+    with pytest.raises(ndp.NdpError, match="no step in flight|is a tick"):
+        pipe.update_end()                                          # a tick is drained with tick_end, not update_end
+    got.append(pipe.tick_end())
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    with pytest.raises(ndp.NdpError, match="no tick in flight"):
+        pipe.tick_end()
+    pipe.tick_begin(xs[0]); pipe.tick_begin(xs[1])
+    with pytest.raises(ndp.NdpError, match="already in flight"):
+        pipe.tick_begin(xs[2])
+    with pytest.raises(ndp.NdpError, match="in flight"):
+        pipe.tick_reset()
+    pipe.tick_end(); pipe.tick_end()
+    with pytest.raises(ndp.NdpError, match="u0 was not requested"):
+        pipe.tick_begin(xs[0])
+        pipe.tick_end(full=True)
+    # no list yet / neighbours without the NDP model: refused with a message
+    fresh = ndp.BatchedNMPC(4, load_mlp=False)
+    with pytest.raises(ndp.NdpError, match="no reference list"):
+        fresh.tick(np.zeros((4, 10)))
+    with pytest.raises(ndp.NdpError, match="use_fd"):
+        fresh.tick_config(np.array([1, 0, -1, -1]))
+    with pytest.raises(ndp.NdpError, match="outside the handle"):
+        ndp.BatchedNMPC(4, disturbance=True).tick_config(np.array([1, 0, 4, -1]))
+
+
+def test_tick_device_equals_host_tick(gold, flat):
+    import torch
+    import ndp_nmpc_qd_amd as ndp
+    coeff, tseg, cum, fpt = _seq_traj(gold, flat, 2)
+    B = coeff.shape[0]
+    other_index = np.array([(i + 1) % B for i in range(B)], dtype=np.int32)
+    host, devh = ndp.BatchedNMPC(B, disturbance=True), ndp.BatchedNMPC(B, disturbance=True)
+    for e in (host, devh):
+        _set_traj(e, coeff, tseg, cum, fpt)
+        e.ref_list_reset()
+        e.tick_config(other_index, gate=False)                     # gate always open: every vehicle evaluates the network
+        e.tick_reset()
+    dev = torch.device("cuda", 0)
+    cmd_t = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    u0_t = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(9)
+    for i, t in enumerate(flat["seq_t"][:12]):
+        x0 = _odometry(rng, host.ref_list_window(None)[0])
+        tt = np.full(B, float(t))
+        cmd, u0, st, it = host.tick(x0, t=tt, estimate=True, full=True)
+        devh.tick_device(torch.from_numpy(x0).to(dev), cmd_t, t=torch.from_numpy(tt).to(dev), estimate=True, u0_out=u0_t)
+        devh.synchronize()
+        assert np.array_equal(cmd_t.cpu().numpy(), cmd) and np.array_equal(u0_t.cpu().numpy(), u0)
+        st_d, it_d = devh.status()
+        assert np.array_equal(st_d, st) and np.array_equal(it_d, it)
+    assert np.any(host.device_force().cpu().numpy() != 0.0)
+
+
+def test_tick_long_horizon_goes_through_the_separate_downwash_launch(oracle, gold, flat, mlp_blob):
+    """N = 40 (T = 4 s): the network does not fit the fused tile (N + 1 > 32) -- mlp_kernel reads the neighbour's window out of the
+    list through the same pitches; the tick still equals the composition and the oracle."""
+    import torch
+    import ndp_nmpc_qd_amd as ndp
+    N = 40
+    coeff, tseg, cum, fpt = _seq_traj(gold, flat)
+    B = coeff.shape[0]
+    other_index = np.array([1, 0, 3, 2, -1], dtype=np.int32)
+    tk = ndp.BatchedNMPC(B, N=N, disturbance=True)
+    cp = ndp.BatchedNMPC(B, N=N, disturbance=True)
+    for e in (tk, cp):
+        _set_traj(e, coeff, tseg, cum, fpt)
+        e.ref_list_reset()
+    tk.tick_config(other_index, gate=True)
+    tk.tick_reset()
+    xr0, ur0 = cp.ref_list_window(None)
+    assert xr0.shape == (B, N + 1, 10)
+    cp.reset(xr0, ur0)
+    cfg = oracle.default_cfg(use_fd=True, N=N)
+    Xo, Uo = xr0.copy(), ur0.copy()
+    dev = torch.device("cuda", 0)
+    u0_t = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    idx_t = torch.from_numpy(other_index).to(dev)
+    rng = np.random.default_rng(2)
+    for i, t in enumerate(flat["seq_t"][:10]):
+        tt = np.full(B, float(t))
+        xr, ur = cp.ref_list_window(tt)
+        x0 = _odometry(rng, xr)
+        cp.update_device(torch.from_numpy(x0).to(dev), torch.from_numpy(xr).to(dev), torch.from_numpy(ur).to(dev), u0_t,
+                         other=torch.from_numpy(xr).to(dev), other_index=idx_t, ego_xy=torch.from_numpy(x0[:, 0:2].copy()).to(dev))
+        cp.synchronize()
+        cmd, u0, st, it = tk.tick(x0, t=tt, full=True)
+        assert np.array_equal(u0, u0_t.cpu().numpy())
+        nb = np.where(other_index >= 0, other_index, 0)
+        f = oracle.downwash_batch(mlp_blob, xr[nb], xr, x0[:, 0:2].copy())
+        f[other_index < 0] = 0.0
+        u_or, st_o, _ = oracle.step_batch(cfg, x0, xr, ur, f, Xo, Uo)
+        assert _rel(u0, u_or) < 1e-5 and not st.any() and not st_o.any()
+
+
+def test_tick_fixed_point_then_trajectory_like_the_node(oracle, gold, flat):
+    """The node's life cycle (nmpc_node.py:87-92,148-152,158-162): hover at gen_fix_pt_ref(odom) -> a trajectory arrives:
+    reset the list and the controller -> track it tick by tick -> past its end the list fills with final_pt."""
+    import ndp_nmpc_qd_amd as ndp
+    coeff, tseg, cum, fpt = _seq_traj(gold, flat)
+    B = coeff.shape[0]
+    eng = ndp.BatchedNMPC(B, load_mlp=False)
+    x_odom = flat["fix_x"].copy()
+    eng.ref_list_fix_pt(x_odom)
+    xr, ur = eng.ref_list_window(None)
+    assert np.array_equal(xr, flat["fix_xr"]) and np.array_equal(ur, flat["fix_ur"])
+    eng.tick_reset()
+    cfg = oracle.default_cfg()
+    X, U = xr.copy(), ur.copy()
+    for _ in range(3):
+        cmd, u0, st, _ = eng.tick(x_odom, full=True)                 # t = None: the list stays where it is
+        u_or, _, _ = oracle.step_batch(cfg, x_odom, xr, ur, None, X, U)
+        assert _rel(u0, u_or) < 1e-6
+        assert np.allclose(cmd[:, 3], u0[:, 3] * CP.mass / 50.0, rtol=1e-15)
+    _set_traj(eng, coeff, tseg, cum, fpt)
+    eng.ref_list_reset()
+    eng.tick_reset()
+    xr, ur = eng.ref_list_window(None)
+    np.testing.assert_allclose(xr, flat["seq_xr0"], rtol=0, atol=1e-7)
+    X, U = xr.copy(), ur.copy()
+    rng = np.random.default_rng(1)
+    t_end = float(cum.max()) + 0.5
+    for i in range(12):
+        t = np.full(B, i * t_end / 11)
+        x0 = _odometry(rng, xr)
+        cmd, u0, st, _ = eng.tick(x0, t=t, full=True)
+        xr, ur = eng.ref_list_window(None)
+        u_or, _, _ = oracle.step_batch(cfg, x0, xr, ur, None, X, U)
+        assert _rel(u0, u_or) < 1e-5 and not st.any()
+    assert np.allclose(xr[:, -1, 0:3], fpt) and np.allclose(xr[:, -1, 3:10], [0, 0, 0, 1, 0, 0, 0])    # the newest entry: hover at final_pt
