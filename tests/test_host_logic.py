@@ -110,7 +110,9 @@ def test_solver_facade_marshals_like_acados_template():
     assert kinds == ["set_iterate", "update"]                      # reset is pushed lazily, right before the solve; the solve is ONE engine call
     _, x0s, xrs, urs, fs = ctl._engine.calls[1]
     assert np.array_equal(x0s[0], x0) and np.array_equal(xrs[0], xr) and np.array_equal(urs[0], ur)
-    assert fs.dtype == np.float32 and np.array_equal(fs[0], f)
+    # the force reaches the engine as float64 -- the reference's p is a float64 vector (ndp_nmpc_body_rate_ctl.py:97-99) -- holding
+    # DownwashNN's float32 values exactly
+    assert fs.dtype == np.float64 and np.array_equal(fs[0], f.astype(np.float64))
     np.testing.assert_array_equal(ctl.solver.get(3, "x"), xr[3] + 1.0)   # iterate mirrored back after the solve
     g = ctl.solver.get(3, "x")
     g[:] = 0
