@@ -281,6 +281,7 @@ def test_reset_and_update_call_sequences_of_the_reference_and_the_drop_in_stagin
         (call,) = eng.updates
         assert np.array_equal(call["x0"][0], x0) and np.array_equal(call["xr"][0], xr) and np.array_equal(call["ur"][0], ur)
         if ndp:
-            assert call["f"].dtype == np.float32 and np.array_equal(call["f"][0], f)
+            # float64 all the way, like the reference's p (ndp_nmpc_body_rate_ctl.py:97-99): the fp32 values, promoted exactly
+            assert call["f"].dtype == np.float64 and np.array_equal(call["f"][0], f.astype(np.float64))
         else:
             assert call["f"] is None
