@@ -315,9 +315,10 @@ int ndp_ref_list_window_device(ndp_handle *h, void *d_xr, void *d_ur, void *stre
  * is another instance of this handle: its window is read out of its list, nothing is copied) and gated on the ego ODOMETRY xy
  * (:65-74).  Only what is new information crosses PCIe: 80 bytes of odometry per vehicle and tick (+ 8 each for t,
  * vz, throttle when given) in, 32 bytes of command (+ 4 status) out -- against 3.4 KB per vehicle for ndp_step's x0 + xr + ur +
- * neighbour columns.  Two launches per tick: tick_pre_kernel (list advance + estimator) and the control step, which reads its
- * window -- and the neighbour's -- straight out of the list (the phase-major layout makes every window contiguous) and writes the
- * actuator command itself, beside u0.
+ * neighbour columns.  ONE launch per tick at the reference configuration (N = 20, 1 RTI iteration): the control step's wave first
+ * makes its vehicle's newest list entry -- node N of its window -- and the neighbour's, runs the estimator, reads the rest of both
+ * windows straight out of the list (the phase-major layout makes every window contiguous), and writes the actuator command itself,
+ * beside u0.  Other shapes: a small launch (tick_pre_kernel: list advance + estimator) in front of the control step.
  *   ndp_tick_config : other_index[B] = the instance whose window is vehicle i's neighbour (< 0: none, plain NMPC vehicle), or NULL
  *                     = no vehicle has one; gate_on_odometry = 1: the r_horiz gate of ndp_nmpc_leader_node.py:65-74, 0: always open.
  *                     Neighbours need use_fd = 1 and ndp_set_mlp_weights.
@@ -328,7 +329,7 @@ int ndp_ref_list_window_device(ndp_handle *h, void *d_xr, void *d_ur, void *stre
  *                     trajectory has ended keeps being advanced: its points are final_pt); vz[B] or NULL = x_odom[:,5];
  *                     throttle[B] or NULL = the thrust this handle commanded on the previous tick (0 before the first).
  *                     flags bit 0: run the estimator this tick (the reference stops its timer while a trajectory is tracked,
- *                     nmpc_node.py:146,196); bit 1: ndp_tick_end will be asked for u0 as well.  Returns without waiting; at most two
+ *                     nmpc_node.py:146,196); bit 1: ndp_tick_end will be asked for u0 as well; bit 2: NDP_TICK_T_UNIFORM.  Returns without waiting; at most two
  *                     ticks (or steps) in flight, drained in order, as with ndp_step_begin.
  *   ndp_tick_end    : waits for the oldest tick: cmd[B][4] = [wx, wy, wz, thrust]; u0[B][4], status[B], ipm_iters[B] or NULL.
  *                     Returns the worst status.
@@ -337,6 +338,9 @@ int ndp_ref_list_window_device(ndp_handle *h, void *d_xr, void *d_ur, void *stre
  *                     The list position is host state baked into the launches: not capturable into a hipGraph. */
 #define NDP_TICK_ESTIMATE 1
 #define NDP_TICK_WANT_U0 2
+#define NDP_TICK_T_UNIFORM 4   /* t points at ONE double (host memory, also for ndp_tick_device): the trajectory time of every vehicle
+                                * (one host, one clock, the trajectories started together).  It travels in the kernel arguments: no
+                                * vehicle's first load of the tick has to cross PCIe. */
 int ndp_tick_config(ndp_handle *h, const int32_t *other_index, int gate_on_odometry);
 int ndp_tick_reset(ndp_handle *h);
 int ndp_tick_begin(ndp_handle *h, const double *x_odom, const double *t, const double *vz, const double *throttle, int flags);

@@ -268,7 +268,11 @@ class BatchedNMPC:
 
     def _tick_in(self, x_odom, t, vz, throttle, estimate, want_u0):
         flags = (_lib.TICK_ESTIMATE if estimate else 0) | (_lib.TICK_WANT_U0 if want_u0 else 0)
-        return (_lib.f64(x_odom, (self.B, 10)), _lib.f64(t, (self.B,)), _lib.f64(vz, (self.B,)), _lib.f64(throttle, (self.B,)), flags)
+        if t is not None and np.ndim(t) == 0:            # one clock for every vehicle: a scalar (NDP_TICK_T_UNIFORM)
+            t, flags = np.array([float(t)]), flags | _lib.TICK_T_UNIFORM
+        else:
+            t = _lib.f64(t, (self.B,))
+        return (_lib.f64(x_odom, (self.B, 10)), t, _lib.f64(vz, (self.B,)), _lib.f64(throttle, (self.B,)), flags)
 
     def tick_begin(self, x_odom, t=None, vz=None, throttle=None, estimate=False, want_u0=False):
         """First half of tick(): ndp_tick_begin -- only x_odom[B,10] (+ t, vz, throttle [B]) cross PCIe; returns without waiting.
@@ -307,9 +311,15 @@ class BatchedNMPC:
         """The tick's launches on CUDA tensors and a caller's stream (ndp_tick_device); no synchronisation."""
         import torch
         B = self.B
+        flags = _lib.TICK_ESTIMATE if estimate else 0
+        if t is not None and not isinstance(t, torch.Tensor):       # a scalar: one time for every vehicle, read by the call
+            t_host = np.array([float(t)])
+            tp, flags = _lib.ptr(t_host), flags | _lib.TICK_T_UNIFORM
+        else:
+            tp = self._dptr(t, torch.float64, (B,))
         self._check(self._lib.ndp_tick_device(
-            self._h, self._dptr(x_odom, torch.float64, (B, 10)), self._dptr(t, torch.float64, (B,)),
-            self._dptr(vz, torch.float64, (B,)), self._dptr(throttle, torch.float64, (B,)), _lib.TICK_ESTIMATE if estimate else 0,
+            self._h, self._dptr(x_odom, torch.float64, (B, 10)), tp,
+            self._dptr(vz, torch.float64, (B,)), self._dptr(throttle, torch.float64, (B,)), flags,
             self._dptr(cmd_out, torch.float64, (B, 4)), self._dptr(u0_out, torch.float64, (B, 4)), self._stream(stream)),
             "ndp_tick_device")
 

@@ -196,6 +196,44 @@ struct LateArgs {
 };
 __device__ __host__ inline unsigned pf_group_size(unsigned n, unsigned groups, unsigned g) { return n / groups + (g < n % groups ? 1u : 0u); }
 
+struct ThrCfg { double a1, a2, hm, g, R, Q0, Q1, mass; };
+
+// layout of the reference list in HBM (see the f1 list kernels below)
+struct RingGeom {
+    int step, np1;                 // list entries per node spacing; N + 1
+    __host__ __device__ int ring() const { return step * (np1 - 1) + 1; }
+    __host__ __device__ size_t px() const { return (size_t)step * 2 * np1 * 10; }     // doubles per vehicle, x ring
+    __host__ __device__ size_t pu() const { return (size_t)step * 2 * np1 * 4; }
+    __host__ __device__ size_t slot(unsigned long long j) const { return (size_t)(j % step) * 2 * np1 + (size_t)((j / step) % np1); }
+};
+
+// ndp_tick in ONE launch (rti_kernel<..., TICK = true>): what tick_pre_kernel does -- the reference list's newest entry, which is node
+// N of this tick's window, and the hover-throttle estimator's update -- done by the control step's own wave in front of its work, so
+// that a control tick is a single dispatch.  (As a launch of its own that part cost 7-8.5 us + a 4.5 us gap per tick in the kernel
+// trace against 24.8 us for the control step: a third of the tick for 112 bytes per vehicle.)
+struct TickArgs {
+    const double *coeff, *tcum, *tseg, *fpt;   // the trajectories (ndp_ref_set_trajectory)
+    int *seg_hint;                             // [B] segment of each vehicle's previous point
+    int n_seg;
+    const double *t;                           // [B] trajectory time of the tick, or null: t_all for every vehicle
+    double t_all;
+    int advance;                               // 0: the list is not advanced in this tick
+    double toff, mass, g;                      // T_horizon; flatness constants
+    unsigned long long j_new;                  // absolute index of the list entry the new point becomes
+    RingGeom rg;
+    double *rx, *ru;
+    ThrCfg thr;                                // estimator
+    double *st;
+    const double *vz;
+    size_t vz_pitch;
+    const double *throttle;
+    int est;
+};
+struct TickEarly { double tv; int hint, v; };    // what tick_new_point needs first, requested at the kernel's very top (tick_early)
+__device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, int orow, int lane);
+__device__ __forceinline__ void tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, double xv[10], double uv[4], double nbv[6]);
+__device__ __forceinline__ double tick_estimator(const TickArgs &ta, int inst, int B, int lane);
+
 struct KernArgs {
     RtiParams P;
     BatchPtrs bp;
@@ -203,6 +241,7 @@ struct KernArgs {
     MlpArgs ma;
     QueueArgs qa;
     LateArgs la;
+    TickArgs ta;            // read by the TICK instantiations only
 };
 
 // FUSED: the wave first predicts its own instance's disturbance force (gate + MLP over the N+1 <= 32 horizon rows,
@@ -213,10 +252,13 @@ struct KernArgs {
 #ifndef NDP_RTI_ATTR       // kernel-development hook: extra attributes of rti_kernel (e.g. a register cap for occupancy studies)
 #define NDP_RTI_ATTR
 #endif
-template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), int QMODE = 0>
+// TICK: the launch is a whole control tick of ndp_tick (see TickArgs): the wave makes its window's newest node -- and its neighbour's --
+// itself and runs the estimator; instantiated for the reference configuration's in-place and producer forms only.
+template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), int QMODE = 0, bool TICK = false>
 __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs ka)
 {
     static_assert(!(FUSED && QMODE == 2), "the consumer reads the force the producer left in global memory");
+    static_assert(!TICK || (QMODE <= 1 && NC > 0 && PREC == 0), "the one-launch tick exists for the compile-time horizon's in-place and producer forms");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const RtiParams &P = ka.P;
     const BatchPtrs &bp = ka.bp;
@@ -296,10 +338,26 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         asm volatile("" : : "s"(orow));
         wg_nb = __builtin_amdgcn_readfirstlane(any) != 0;
     }
+    const bool advance = TICK && ka.ta.advance != 0;
+    TickEarly te{};
+    if (TICK && advance) {
+        te = tick_early(ka.ta, inst, FUSED && wg_nb ? orow : -1, (int)(threadIdx.x & 63u));
+        __builtin_amdgcn_sched_barrier(0);   // (these two loads lead the wave's in-order load queue)
+    }
     typename Prog::InBuf inb;
     double x0v;
     Prog::issue_first(P, io, inb, x0v);      // every global input of the RTI step is now in flight (hidden under the MLP when fused)
     __builtin_amdgcn_sched_barrier(0);       // do not let the scheduler sink those loads behind the MLP
+    // TICK: the newest list entry of this vehicle (x_new / u_new) and the position / velocity part of the neighbour's (nb_new).  Row N of
+    // both windows is NOT read from the list in this launch (the neighbour's wave writes its entry while this one runs): the ego's goes
+    // into the staged window through RtiIo::xrN, the pair into the network's input below.
+    double x_new[10], u_new[4], nb_new[6];
+    if (TICK && !(FUSED && wg_nb) && advance) {      // (fused with neighbours: made below, under the weight transfer)
+        tick_new_point(ka.ta, te, inst, (int)(threadIdx.x & 63u), x_new, u_new, nb_new);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) io.xrN[i] = x_new[i];
+        io.have_xrN = 1;
+    }
     if (FUSED && !wg_nb) {          // no instance of the workgroup has a neighbour: zero force, nothing of the network runs
         if (!active) return;
         const int lane = (int)(threadIdx.x & 63u);
@@ -347,6 +405,22 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         // the whole workgroup's LDS is still unused: park the weight fragments there for the MLP phase
         lds_f32 wl = (lds_f32)smem;
         stage_fragments(ma.frag, wl, (int)threadIdx.x, 64 * WAVES);
+        if (TICK && advance) {                    // the polynomial work runs while the weights stream into LDS
+            tick_new_point(ka.ta, te, inst, lane, x_new, u_new, nb_new);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) io.xrN[i] = x_new[i];
+            io.have_xrN = 1;
+#pragma unroll
+            for (int t = 0; t < ZR; ++t) {        // row N of the network's input: the two new entries (downwash_nn.py:22: columns 0..5)
+                const int l3 = lane + 64 * t, r3 = l3 / 3, c3 = l3 - 3 * r3;
+                if (r3 == N) {
+                    dv[t][0] = c3 == 0 ? nb_new[0] : (c3 == 1 ? nb_new[2] : nb_new[4]);
+                    dv[t][1] = c3 == 0 ? nb_new[1] : (c3 == 1 ? nb_new[3] : nb_new[5]);
+                    ev[t][0] = c3 == 0 ? x_new[0] : (c3 == 1 ? x_new[2] : x_new[4]);
+                    ev[t][1] = c3 == 0 ? x_new[1] : (c3 == 1 ? x_new[3] : x_new[5]);
+                }
+            }
+        }
         __syncthreads();
         const double g_o[2] = {g_ox, g_oy}, g_e[2] = {g_ex, g_ey};
         const bool open = orow >= 0 && (ma.ego_xy ? gate_open(g_o, g_e, ma.r2) : true);
@@ -388,6 +462,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         io.f = nullptr;
         io.f_in_lds = 1;
     }
+    if (TICK && ka.ta.est && active) io.kthr = tick_estimator(ka.ta, inst, B, (int)(threadIdx.x & 63u));
     const bool deferred = Prog::template run<QMODE == 1, QMODE == 0 || QMODE == 3>(P, io, lds, inb, x0v);
     if (NDP_RARELY(io.stamps && (threadIdx.x & 63u) == 0)) {
         io.stamps[13] = (double)__builtin_amdgcn_s_memrealtime();
@@ -913,7 +988,6 @@ static void make_fragments(const float *blob, std::vector<float> &fr)
 // per vehicle.  Elementwise and HBM-bound: state is SoA ([8][B] doubles) so every access is a coalesced 512-B wave
 // load/store; 152 algorithmic bytes per vehicle and tick.  Operation order follows the reference's numpy
 // expressions (hover_throttle_estimator.py:38-51) so results agree to rounding.
-struct ThrCfg { double a1, a2, hm, g, R, Q0, Q1, mass; };
 
 // one estimator update of vehicle v (state SoA [8][S]); returns k_throttle
 __device__ __forceinline__ double throttle_update_one(const ThrCfg &c, double *__restrict__ st, size_t S, int v, double vzv, double th)
@@ -1087,75 +1161,113 @@ __device__ __forceinline__ double horner_d(const double *__restrict__ c, double 
     return acc;
 }
 
-// One reference point: trajectory of vehicle b at trajectory time t -> x[10] = [p, v, qw, qx, qy, qz], u[4] = [wx, wy, wz, c]
-// (get_traj_pt, base_pt_publisher.py:81-133; diff_flatness, pt_publisher.py:188-248; traj_full_pt_2_x_u, :115-146)
+// ---- one reference point, in three pieces shared by every kernel that makes one (so that they all make the SAME point, bit for bit:
+// the control step that computes its window's newest node itself -- rti_kernel<..., TICK> -- must agree with the list kernels):
+//   seg_locate   which polynomial segment holds trajectory time t (base_pt_publisher.py:93-100)
+//   traj_chain   one of the 14 polynomial values of a trajectory point: p / v / a / j of one axis, yaw, yaw rate (:102-133)
+//   flatness_xu  the differential-flatness map of the point (pt_publisher.py:188-248) and the x / u packing (:115-146)
 // seg_hint (or null): the vehicle's segment at its previous point -- control ticks move forward 20 ms at a time, so it is nearly always
-// still the one: two loads confirm it instead of a search over time_cum; updated here.
-__device__ __forceinline__ void ref_point(const RefCfg &cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
-                                          const double *__restrict__ tseg, const double *__restrict__ fpt, int b, double t,
-                                          double xv[10], double uv[4], int *__restrict__ seg_hint = nullptr)
+// still the one: two loads confirm it instead of a search over time_cum.  Returns -1 past the end of the trajectory.
+__device__ __forceinline__ int seg_locate(int n_seg, const double *__restrict__ tc, double t, int hint)
 {
-    const double *tc = tcum + (size_t)b * (cf.n_seg + 1);
-    double pvaj[12], yaw = 0.0, yawd = 0.0;
+    if (t >= tc[n_seg]) return -1;                        // base_pt_publisher.py:93-94: hover at final_pt after the end
+    int idx = hint < 0 ? 0 : (hint >= n_seg ? n_seg - 1 : hint);
+    if ((idx == 0 || !(tc[idx] > t)) && tc[idx + 1] > t) return idx;
+    // :100: first i with time_cum[i] > t, minus one -- time_cum ascends, so that is (entries of 0 .. n_seg-1 not above t) - 1.
+    // Counted eight independent loads at a time: a search loop is a chain of dependent global loads, ~0.6 us each.
+    idx = 0;
+    for (int i = 0; i < n_seg; i += 8) {
+        double v[8];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) pvaj[i] = 0.0;
-    if (t >= tc[cf.n_seg]) {                              // base_pt_publisher.py:93-94: hover at final_pt after the end
-        for (int i = 0; i < 3; ++i) pvaj[i] = fpt[(size_t)b * 3 + i];
-    } else {
-        // :100: first i with time_cum[i] > t, minus one -- time_cum ascends, so that is (entries of 0 .. n_seg-1 not above t) - 1.
-        // Counted eight independent loads at a time: a search loop is a chain of dependent global loads, ~0.6 us each.
-        int idx = 0;
-        bool found = false;
-        if (seg_hint) {
-            const int hi = seg_hint[b];
-            idx = hi < 0 ? 0 : (hi >= cf.n_seg ? cf.n_seg - 1 : hi);
-            found = (idx == 0 || !(tc[idx] > t)) && tc[idx + 1] > t;
-        }
-        if (!found) {
-            idx = 0;
-            for (int i = 0; i < cf.n_seg; i += 8) {
-                double v[8];
+        for (int j = 0; j < 8; ++j) v[j] = tc[i + j < n_seg ? i + j : n_seg];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = tc[i + j < cf.n_seg ? i + j : cf.n_seg];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) idx += (i + j < cf.n_seg && !(v[j] > t)) ? 1 : 0;
-            }
-            idx = idx > 0 ? idx - 1 : 0;
-        }
-        if (seg_hint) seg_hint[b] = idx;
-        const double its = 1.0 / tseg[(size_t)b * cf.n_seg + idx], its2 = its * its;     // one divide per point
-        const double *c = coeff + ((size_t)b * cf.n_seg + idx) * 28;
-        const double s = (t - tc[idx]) * its;             // :102-103
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            pvaj[a] = horner_d<8, 0>(c + 8 * a, s);
-            pvaj[3 + a] = horner_d<8, 1>(c + 8 * a, s) * its;
-            pvaj[6 + a] = horner_d<8, 2>(c + 8 * a, s) * its2;
-            pvaj[9 + a] = horner_d<8, 3>(c + 8 * a, s) * (its2 * its);
-        }
-        yaw = horner_d<4, 0>(c + 24, s);
-        yawd = horner_d<4, 1>(c + 24, s) * its;
+        for (int j = 0; j < 8; ++j) idx += (i + j < n_seg && !(v[j] > t)) ? 1 : 0;
     }
-    // differential flatness (pt_publisher.py:188-248)
-    const double td[3] = {pvaj[6], pvaj[7], pvaj[8] + cf.g};
-    const double tn = sqrt(td[0] * td[0] + td[1] * td[1] + td[2] * td[2]);
-    const double rtn = 1.0 / tn;
+    return idx > 0 ? idx - 1 : 0;
+}
+
+// value number c of a trajectory point at normalised segment time s; its = 1 / time_seg: c = 3 d + axis (d = derivative 0..3,
+// axis 0..2) for c < 12, c = 12: yaw, c = 13: yaw rate.  ca = the value's own polynomial: chain_base(c) doubles into the segment's
+// record of 28 coefficients, x(8) y(8) z(8) yaw(4).
+__device__ __forceinline__ int chain_base(int c) { return c >= 12 ? 24 : 8 * (c % 3); }
+__device__ __forceinline__ double traj_chain(const double *__restrict__ ca, int c, double s, double its)
+{
+#pragma clang fp contract(off)
+    const double its2 = its * its;
+    if (c >= 12) return c == 12 ? horner_d<4, 0>(ca, s) : horner_d<4, 1>(ca, s) * its;
+    const int d = c / 3;
+    switch (d) {
+    case 0: return horner_d<8, 0>(ca, s);
+    case 1: return horner_d<8, 1>(ca, s) * its;
+    case 2: return horner_d<8, 2>(ca, s) * its2;
+    default: return horner_d<8, 3>(ca, s) * (its2 * its);
+    }
+}
+
+// ---- f64 helpers of the flatness map.  An IEEE divide or square root is a ~30-instruction dependent chain on gfx950 and the map
+// has four and three of them, one behind the other, plus a library sincos (~150 instructions with its large-argument path): measured
+// in the one-launch tick, where a single wave runs the map with nothing to overlap it, ~4 000 cycles of a 7 300-cycle prologue; in the
+// list / window kernels the same chains are why "HBM-bound" kernels sat at 0.4 of the HBM roof.  These are seed + Newton forms
+// (v_rcp_f64 / v_rsq_f64: 2^-26 relative or better; two steps -> ~1e-16, not correctly rounded) and a Cody-Waite sincos with the
+// fdlibm kernel polynomials (|error| < 1 ulp for |x| < 1e5) -- deterministic, shared by every kernel that makes a reference point.
+__device__ __forceinline__ double rcp_n(double a)
+{
+    double r = __builtin_amdgcn_rcp(a);
+    r = fma(fma(-a, r, 1.0), r, r);
+    r = fma(fma(-a, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double rsqrt_n(double a)
+{
+#pragma clang fp contract(off)
+    double y = __builtin_amdgcn_rsq(a);
+    y = fma(y * 0.5, fma(-a * y, y, 1.0), y);
+    y = fma(y * 0.5, fma(-a * y, y, 1.0), y);
+    return y;
+}
+__device__ __forceinline__ void sincos_n(double x, double *sn, double *cs)
+{
+#pragma clang fp contract(off)
+    const double k = rint(x * 6.36619772367581382433e-01);            // x * 2 / pi
+    double r = fma(-k, 1.57079632673412561417e+00, x);                // pi / 2 in three pieces (fdlibm e_rem_pio2: pio2_1, pio2_2, pio2_3)
+    r = fma(-k, 6.07710050630396597660e-11, r);
+    r = fma(-k, 2.02226624871116645580e-21, r);
+    const double z = r * r;
+    // fdlibm k_sin / k_cos on |r| <= pi / 4
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                        -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double s0 = fma(z * r, ps, r);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                        2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    const double s1 = (q & 1) ? c0 : s0, c1 = (q & 1) ? s0 : c0;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
+// Every product-sum below is written out (fma where one is wanted, contraction off otherwise): the compiler's own choice of which
+// multiplies to fuse depends on the surrounding code, and two kernels must not differ in the last bit of a reference point.
+__device__ __forceinline__ void flatness_xu(double mass, double g, const double pvaj[12], double yaw, double yawd, double xv[10], double uv[4])
+{
+#pragma clang fp contract(off)
+    const double td[3] = {pvaj[6], pvaj[7], pvaj[8] + g};
+    const double tn2 = fma(td[0], td[0], fma(td[1], td[1], td[2] * td[2]));
+    const double rtn = rsqrt_n(tn2), tn = tn2 * rtn;
     const double zb[3] = {td[0] * rtn, td[1] * rtn, td[2] * rtn};
-    const double u1 = tn * cf.mass;
     double sy, cy;
-    sincos(yaw, &sy, &cy);
-    const double xc[3] = {cy, sy, 0.0};
-    const double zx[3] = {zb[1] * xc[2] - zb[2] * xc[1], zb[2] * xc[0] - zb[0] * xc[2], zb[0] * xc[1] - zb[1] * xc[0]};
-    const double nzx = sqrt(zx[0] * zx[0] + zx[1] * zx[1] + zx[2] * zx[2]);
-    const double rnzx = 1.0 / nzx;
+    sincos_n(yaw, &sy, &cy);
+    // z_b x x_c with x_c = [cos yaw, sin yaw, 0]
+    const double zx[3] = {-(zb[2] * sy), zb[2] * cy, fma(zb[0], sy, -(zb[1] * cy))};
+    const double rnzx = rsqrt_n(fma(zx[0], zx[0], fma(zx[1], zx[1], zx[2] * zx[2])));
     const double yb[3] = {zx[0] * rnzx, zx[1] * rnzx, zx[2] * rnzx};
-    const double xb[3] = {yb[1] * zb[2] - yb[2] * zb[1], yb[2] * zb[0] - yb[0] * zb[2], yb[0] * zb[1] - yb[1] * zb[0]};
-    const double zj = zb[0] * pvaj[9] + zb[1] * pvaj[10] + zb[2] * pvaj[11];
+    const double xb[3] = {fma(yb[1], zb[2], -(yb[2] * zb[1])), fma(yb[2], zb[0], -(yb[0] * zb[2])), fma(yb[0], zb[1], -(yb[1] * zb[0]))};
+    const double zj = fma(zb[0], pvaj[9], fma(zb[1], pvaj[10], zb[2] * pvaj[11]));
     double ho[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) ho[i] = rtn * (pvaj[9 + i] - zj * zb[i]);      // mass / u1 = 1 / |t_des|
-    const double wp = -(ho[0] * yb[0] + ho[1] * yb[1] + ho[2] * yb[2]);
-    const double wq = ho[0] * xb[0] + ho[1] * xb[1] + ho[2] * xb[2];
+    for (int i = 0; i < 3; ++i) ho[i] = rtn * fma(-zj, zb[i], pvaj[9 + i]);      // mass / u1 = 1 / |t_des|
+    const double wp = -fma(ho[0], yb[0], fma(ho[1], yb[1], ho[2] * yb[2]));
+    const double wq = fma(ho[0], xb[0], fma(ho[1], xb[1], ho[2] * xb[2]));
     const double wr = yawd * zb[2];
     // tf.transformations.quaternion_from_matrix on [x_b y_b z_b] (ROS geometry; restated): R[i][0..2] = xb[i], yb[i], zb[i]
     const double R[3][3] = {{xb[0], yb[0], zb[0]}, {xb[1], yb[1], zb[1]}, {xb[2], yb[2], zb[2]}};
@@ -1177,12 +1289,41 @@ __device__ __forceinline__ void ref_point(const RefCfg &cf, const double *__rest
         q2 = c2 ? t2 : (c1 ? s12 : s20);
         q3 = c2 ? d10 : (c1 ? d02 : d21);      // q[3] = R[k][j] - R[j][k]
     }
-    const double q[4] = {q0, q1, q2, q3};
-    const double qs = 0.5 / sqrt(tt);
+    const double qs = 0.5 * rsqrt_n(tt);
     // [qw, qx, qy, qz] (pt_publisher.py:237-240, :115-128); u = [p, q, r, collective_force / mass] (:138-145)
     xv[0] = pvaj[0]; xv[1] = pvaj[1]; xv[2] = pvaj[2]; xv[3] = pvaj[3]; xv[4] = pvaj[4]; xv[5] = pvaj[5];
-    xv[6] = q[3] * qs; xv[7] = q[0] * qs; xv[8] = q[1] * qs; xv[9] = q[2] * qs;
-    uv[0] = wp; uv[1] = wq; uv[2] = wr; uv[3] = u1 / cf.mass;
+    xv[6] = q3 * qs; xv[7] = q0 * qs; xv[8] = q1 * qs; xv[9] = q2 * qs;
+    uv[0] = wp; uv[1] = wq; uv[2] = wr; uv[3] = tn;            // collective_force / mass = (|t_des| mass) / mass (:138-145)
+}
+
+// One reference point: trajectory of vehicle b at trajectory time t -> x[10] = [p, v, qw, qx, qy, qz], u[4] = [wx, wy, wz, c]
+// (get_traj_pt, base_pt_publisher.py:81-133; diff_flatness, pt_publisher.py:188-248; traj_full_pt_2_x_u, :115-146)
+__device__ __forceinline__ void ref_point(const RefCfg &cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
+                                          const double *__restrict__ tseg, const double *__restrict__ fpt, int b, double t,
+                                          double xv[10], double uv[4], int *__restrict__ seg_hint = nullptr)
+{
+    const double *tc = tcum + (size_t)b * (cf.n_seg + 1);
+    double pvaj[12], yaw = 0.0, yawd = 0.0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pvaj[i] = 0.0;
+    const int idx = seg_locate(cf.n_seg, tc, t, seg_hint ? seg_hint[b] : 0);
+    if (idx < 0) {
+        for (int i = 0; i < 3; ++i) pvaj[i] = fpt[(size_t)b * 3 + i];
+    } else {
+        if (seg_hint) seg_hint[b] = idx;
+        const double its = rcp_n(tseg[(size_t)b * cf.n_seg + idx]);
+        const double *rec = coeff + ((size_t)b * cf.n_seg + idx) * 28;
+        double s;
+        {
+#pragma clang fp contract(off)
+            s = (t - tc[idx]) * its;                      // :102-103
+        }
+#pragma unroll
+        for (int c = 0; c < 12; ++c) pvaj[c] = traj_chain(rec + chain_base(c), c, s, its);
+        yaw = traj_chain(rec + chain_base(12), 12, s, its);
+        yawd = traj_chain(rec + chain_base(13), 13, s, its);
+    }
+    flatness_xu(cf.mass, cf.g, pvaj, yaw, yawd, xv, uv);
 }
 
 #define REF_ROWS 64     // rows (vehicle, node) per workgroup = one wave: small batches spread over all CUs
@@ -1235,13 +1376,6 @@ __global__ __launch_bounds__(REF_ROWS) void ref_window_kernel(RefCfg cf, const d
 // step reads its reference window -- and a neighbour's -- straight out of the list (instance pitch = RingGeom::px / pu doubles),
 // there is no window copy on the control tick's path, and the stand-alone window call is a dense copy.  `n` lives on the host
 // (ndp_handle::list_n) and is baked into each launch's arguments.
-struct RingGeom {
-    int step, np1;                 // list entries per node spacing; N + 1
-    __host__ __device__ int ring() const { return step * (np1 - 1) + 1; }
-    __host__ __device__ size_t px() const { return (size_t)step * 2 * np1 * 10; }     // doubles per vehicle, x ring
-    __host__ __device__ size_t pu() const { return (size_t)step * 2 * np1 * 4; }
-    __host__ __device__ size_t slot(unsigned long long j) const { return (size_t)(j % step) * 2 * np1 + (size_t)((j / step) % np1); }
-};
 
 __device__ __forceinline__ void ring_store(const RingGeom &rg, double *__restrict__ rx, double *__restrict__ ru, int b,
                                            unsigned long long j, const double xv[10], const double uv[4])
@@ -1319,7 +1453,9 @@ struct TickPre {
     RefCfg cf;
     const double *coeff, *tcum, *tseg, *fpt;
     int *seg_hint;                     // [B] the segment each vehicle's last point lay in (ref_point)
-    const double *t;                   // [B] trajectory time of the tick, or null: the list is not advanced
+    const double *t;                   // [B] trajectory time of the tick, or null: t_all for every vehicle
+    double t_all;
+    int advance;                       // 0: the list is not advanced
     unsigned long long j_new;          // absolute index of the entry the new point becomes
     RingGeom rg;
     double *rx, *ru;
@@ -1337,12 +1473,113 @@ __global__ __launch_bounds__(64) void tick_pre_kernel(TickPre a)
     if (b >= a.cf.B) return;
     double vzv = 0.0, th = 0.0;
     if (a.est) { vzv = a.vz[(size_t)b * a.vz_pitch]; th = a.throttle[b]; }      // (requested before the polynomial work)
-    if (a.t) {
+    if (a.advance) {
         double xv[10], uv[4];
-        ref_point(a.cf, a.coeff, a.tcum, a.tseg, a.fpt, b, a.t[b] + a.cf.toff, xv, uv, a.seg_hint);
+        ref_point(a.cf, a.coeff, a.tcum, a.tseg, a.fpt, b, (a.t ? a.t[b] : a.t_all) + a.cf.toff, xv, uv, a.seg_hint);
         ring_store(a.rg, a.rx, a.ru, b, a.j_new, xv, uv);
     }
     if (a.est) (void)throttle_update_one(a.thr, a.st, (size_t)a.cf.B, b, vzv, th);
+}
+
+// ---- the one-launch tick's prologue (rti_kernel<..., TICK>, see TickArgs), one wave per vehicle
+// Lanes 0..13 evaluate the 14 polynomial values of the ego's new point (value c on lane c: the same traj_chain a list kernel calls),
+// lanes 16..21 the position / velocity values of the neighbour's (orow >= 0); the values are collected with v_readlane and every lane
+// runs the flatness map on them (uniform values: as long as one lane's work).  Lanes 0..13 then store the entry into the list (both
+// copies), for the ticks to come.  x_new / u_new / nb_new are the same in every lane.
+__device__ __forceinline__ double uniform_lane(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// The segment hint heads a chain of dependent loads (hint -> segment record -> value) and a wave's loads return in order: requested
+// behind the step's 17 input loads and the 70 KB weight transfer it came back ~2 000 cycles late, and the records another memory
+// round trip after that.  So hint and time are the FIRST loads of the launch; the records are requested as soon as the hint is there.
+__device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, int orow, int lane)
+{
+    TickEarly te;
+    te.v = ((lane >> 4) & 1) && orow >= 0 ? orow : inst;
+    te.hint = ta.seg_hint[te.v];
+    te.tv = ta.t ? ta.t[te.v] : ta.t_all;
+    return te;
+}
+
+__device__ __forceinline__ void tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, double xv[10], double uv[4], double nbv[6])
+{
+    const int c = (lane & 15) < 14 ? (lane & 15) : 13;
+    const int v = te.v;
+    const int S = ta.n_seg;
+    const double *tc = ta.tcum + (size_t)v * (S + 1);
+    // Everything the value needs is requested BEFORE the time is looked at (the time may come across PCIe: ~2.5 us): the hinted
+    // segment and the one behind it -- a vehicle moves on to the next segment every time_seg / 20 ms ticks, and in a batch of a
+    // thousand some vehicle does so in every tick.  Anything else (a jump, the first tick after a reset) is the slow path.
+    const double tv = te.tv;
+    const int hint = te.hint;
+    const int i0 = hint < 0 ? 0 : (hint >= S ? S - 1 : hint), i1 = i0 + 1 < S ? i0 + 1 : i0;
+    const double tc0 = tc[i0], tc1 = tc[i0 + 1], tc2 = tc[i1 + 1], tce = tc[S];
+    const double ts0 = ta.tseg[(size_t)v * S + i0], ts1 = ta.tseg[(size_t)v * S + i1];
+    const int cb = chain_base(c);
+    const double *r0 = ta.coeff + ((size_t)v * S + i0) * 28 + cb, *r1 = ta.coeff + ((size_t)v * S + i1) * 28 + cb;
+    double ca[8], cn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ca[i] = r0[c >= 12 ? (i & 3) : i]; cn[i] = r1[c >= 12 ? (i & 3) : i]; }
+    const double fp = ta.fpt[(size_t)v * 3 + (c < 3 ? c : 0)];
+    const double t = tv + ta.toff;
+    const bool past = t >= tce;                                       // base_pt_publisher.py:93-94: hover at final_pt after the end
+    const bool in0 = (i0 == 0 || !(tc0 > t)) && tc1 > t, in1 = !in0 && i1 != i0 && !(tc1 > t) && tc2 > t;
+    int idx = in0 ? i0 : i1;
+    double tcs = in0 ? tc0 : tc1, tsg = in0 ? ts0 : ts1;
+    if (in1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ca[i] = cn[i];
+    }
+    if (!past && !in0 && !in1) {                                      // (rare; per lane)
+        idx = seg_locate(S, tc, t, -1);
+        tcs = tc[idx]; tsg = ta.tseg[(size_t)v * S + idx];
+        const double *r = ta.coeff + ((size_t)v * S + idx) * 28 + cb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ca[i] = r[c >= 12 ? (i & 3) : i];
+    }
+    double val = 0.0;
+    if (past) {
+        if (c < 3) val = fp;
+    } else {
+        const double its = rcp_n(tsg);
+        double s;
+        {
+#pragma clang fp contract(off)
+            s = (t - tcs) * its;
+        }
+        val = traj_chain(ca, c, s, its);
+        if (lane == 0) ta.seg_hint[inst] = idx;          // (a vehicle's hint is written by its own wave only)
+    }
+    double pvaj[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pvaj[i] = uniform_lane(val, i);
+    const double yaw = uniform_lane(val, 12), yawd = uniform_lane(val, 13);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) nbv[i] = uniform_lane(val, 16 + i);
+    flatness_xu(ta.mass, ta.g, pvaj, yaw, yawd, xv, uv);
+    // the entry, for the windows of the ticks to come: element l of x | u from lane l
+    double e = uv[3];
+#pragma unroll
+    for (int i = 2; i >= 0; --i) e = lane == 10 + i ? uv[i] : e;
+#pragma unroll
+    for (int i = 9; i >= 0; --i) e = lane == i ? xv[i] : e;
+    if (lane < 14) {
+        const size_t sl = ta.rg.slot(ta.j_new);
+        double *d = lane < 10 ? ta.rx + (size_t)inst * ta.rg.px() + sl * 10 + lane : ta.ru + (size_t)inst * ta.rg.pu() + sl * 4 + (lane - 10);
+        d[0] = e;
+        d[(size_t)ta.rg.np1 * (lane < 10 ? 10 : 4)] = e;
+    }
+}
+
+// hover_throttle_callback (nmpc_node.py:251-253) of this vehicle, by lane 0; returns k_throttle to every lane
+__device__ __forceinline__ double tick_estimator(const TickArgs &ta, int inst, int B, int lane)
+{
+    double k = 0.0;
+    if (lane == 0) k = throttle_update_one(ta.thr, ta.st, (size_t)B, inst, ta.vz[(size_t)inst * ta.vz_pitch], ta.throttle[inst]);
+    return uniform_lane(k, 0);
 }
 
 // ------------------------------------------------------------------------------------------ peer windows: per-tick publish
@@ -1446,18 +1683,18 @@ static int peer_mapped(const void *p)
 // the shipped library) collapses every instantiation but the reference configuration's two onto rti_kernel<3, 4, false, 20>, so
 // that an experiment on the headline kernel compiles in 20 s instead of 3 min; such a library serves N = 20, n_rti = 1 only.
 #ifdef NDP_DEV_HEADLINE_ONLY
-template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), int QMODE = 0>
+template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), int QMODE = 0, bool TICK = false>
 #ifndef NDP_DEV_QMODE      // 1: study the work list's producer form (no interior-point code) in place of the in-place kernel
 #define NDP_DEV_QMODE 0
 #endif
-struct RtiK { static constexpr auto fn = rti_kernel<3, (WAVES == 2 && NC == 20 ? 2 : 4), (FUSED && NC == 20 && QMODE == 0), 20, 0, 1, NDP_DEV_QMODE>; };
+struct RtiK { static constexpr auto fn = rti_kernel<3, (WAVES == 2 && NC == 20 ? 2 : 4), (FUSED && NC == 20 && QMODE == 0), 20, 0, 1, NDP_DEV_QMODE, (TICK && NC == 20 && QMODE == 0)>; };
 #define RTI_K(...) (RtiK<__VA_ARGS__>::fn)
 #elif defined(NDP_DEV_N40_ONLY)
 // register studies of config 5's shape (scripts/dev_regs.sh): every instantiation collapses onto rti_kernel<5, 2, false, 40, 0, 2, NDP_DEV_QMODE>
 #ifndef NDP_DEV_QMODE
 #define NDP_DEV_QMODE 0
 #endif
-template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), int QMODE = 0>
+template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), int QMODE = 0, bool TICK = false>
 struct RtiK { static constexpr auto fn = rti_kernel<5, 2, false, 40, 0, 2, NDP_DEV_QMODE>; };
 #define RTI_K(...) (RtiK<__VA_ARGS__>::fn)
 #else
@@ -2155,6 +2392,8 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
                          (const void *)RTI_K(3, 2, false, 20), (const void *)RTI_K(3, 2, true, 20),
                          (const void *)RTI_K(3, 4, false, 20, 0, 1, 1), (const void *)RTI_K(3, 4, true, 20, 0, 1, 1), (const void *)RTI_K(3, 4, false, 20, 0, 1, 2),
                          (const void *)RTI_K(3, 4, false, 20, 0, 1, 3),
+                         (const void *)RTI_K(3, 4, true, 20, 0, 1, 0, true), (const void *)RTI_K(3, 4, false, 20, 0, 1, 0, true),
+                         (const void *)RTI_K(3, 4, true, 20, 0, 1, 1, true), (const void *)RTI_K(3, 4, false, 20, 0, 1, 1, true),
                          (const void *)RTI_K(5, 1, false, 0, 1), (const void *)RTI_K(5, 1, false, 0, 2),
                          (const void *)RTI_K(5, 1, false, 0, 3), (const void *)RTI_K(5, 1, false, 0, 4),
                          (const void *)RTI_K(5, 2, false, 40, 3, 2), (const void *)RTI_K(5, 2, false, 40, 4, 2),
@@ -2263,6 +2502,7 @@ struct StepOut {               // where a step's status / iteration counts go an
     const double *kthr = nullptr;        // ... from k_throttle[B]
     double *thrust_keep = nullptr;
     bool f_f64 = false;                  // d_f holds doubles (ndp_step_ex_f64)
+    const TickArgs *tick = nullptr;      // the launch is a whole control tick (rti_kernel<..., TICK>): list advance + estimator inside
 };
 
 // The automatic work-list rule (cfg.work_queue = 0, reference shape, at least two instances per SIMD).  The list re-balances interior-
@@ -2308,7 +2548,8 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     const int B = h->cfg.batch, W = h->waves;
     LateArgs la{prefetched ? h->dProto : nullptr, {h->dForceAB[0], h->dForceAB[1]}, h->prefetch_timeout_us,
                 h->pf_groups_rti, h->pf_ntiles};
-    KernArgs ka{h->P, bp, B, h->lds_per_wave, ma, qa, la};
+    KernArgs ka{h->P, bp, B, h->lds_per_wave, ma, qa, la, so && so->tick ? *so->tick : TickArgs{}};
+    const bool tick1 = so && so->tick;   // (tick_enqueue hands a TickArgs over only for the shapes the TICK kernels exist for)
     const dim3 grid((B + W - 1) / W), block(64 * W);
     const size_t shm = (size_t)h->lds_per_wave * sizeof(double) * W;
     const int ns = slots_for(h->cfg.N);
@@ -2371,7 +2612,8 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
         kc.ma.frag = nullptr; kc.ma.other = nullptr;
         if (h->cfg.n_rti == 1) kc.P.qp_mode = QP_IPM_ALWAYS;
         if (h->cfg.N == 20) {
-            if (fused) LAUNCH(3, 4, true, 20, 0, 1, 1); else LAUNCH(3, 4, false, 20, 0, 1, 1);
+            if (tick1) { if (fused) LAUNCH(3, 4, true, 20, 0, 1, 1, true); else LAUNCH(3, 4, false, 20, 0, 1, 1, true); }
+            else if (fused) LAUNCH(3, 4, true, 20, 0, 1, 1); else LAUNCH(3, 4, false, 20, 0, 1, 1);
             NDP_HIP(h, hipGetLastError());
             hipLaunchKernelGGL(RTI_K(3, 4, false, 20, 0, 1, 2), grid, block, shm, s, kc);
         } else {
@@ -2386,7 +2628,8 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
         { const int rce = end_timing(h, s); queue_policy(h, s); return rce; }
     }
     if (h->cfg.N == 20 && h->cfg.n_rti == 1 && W == 4) {   // the reference configuration (params/nmpc_params.py:9, 1 RTI iteration): compile-time instantiation
-        if (fused) LAUNCH(3, 4, true, 20); else if (prefetched) LAUNCH(3, 4, false, 20, 0, 1, 3); else LAUNCH(3, 4, false, 20);
+        if (tick1) { if (fused) LAUNCH(3, 4, true, 20, 0, 1, 0, true); else LAUNCH(3, 4, false, 20, 0, 1, 0, true); }
+        else if (fused) LAUNCH(3, 4, true, 20); else if (prefetched) LAUNCH(3, 4, false, 20, 0, 1, 3); else LAUNCH(3, 4, false, 20);
     } else if (h->cfg.N == 20 && h->cfg.n_rti == 1 && W == 2) {   // (NDP_DEV_WAVES = 2: the same program, two instances per workgroup)
         if (fused) LAUNCH(3, 2, true, 20); else LAUNCH(3, 2, false, 20);
     } else if (h->cfg.N == 40 && h->cfg.n_rti == 2 && W == 2 && !fused) {   // BASELINE config 5's shape, compile-time as well
@@ -3282,30 +3525,54 @@ int ndp_tick_reset(ndp_handle *h)
     return 0;
 }
 
-enum { TICK_ESTIMATE = 1, TICK_WANT_U0 = 2 };
+enum { TICK_ESTIMATE = NDP_TICK_ESTIMATE, TICK_WANT_U0 = NDP_TICK_WANT_U0, TICK_T_UNIFORM = NDP_TICK_T_UNIFORM };
 
 // One tick's launches on `s`.  Every pointer is device-accessible (HBM or page-locked host memory): x_odom[B][10]; t[B] or null (the
 // list is not advanced: hover at a fixed point, or a vehicle between two trajectories); vz[B] or null (column 5 of x_odom);
 // throttle[B] or null (the thrust this handle commanded last tick); cmd[B][4]; u0_copy[B][4] or null.
-static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, const double *t, const double *vz, const double *throttle,
-                        int flags, double *cmd, double *u0_copy, StepOut so)
+// adv: the list is advanced; its times are t[B] (device-accessible), or t_all for every vehicle when t is null.
+static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, bool adv, const double *t, double t_all, const double *vz,
+                        const double *throttle, int flags, double *cmd, double *u0_copy, StepOut so)
 {
     int rc = ensure_tick(h);
     if (rc) return rc;
     if (!h->dRingX) { h->err = "ndp_tick: no reference list (ndp_ref_list_fix_pt, or ndp_ref_set_trajectory + ndp_ref_list_reset, first)"; return -11; }
-    if (t && !h->dTraj) { h->err = "ndp_tick: a trajectory time was given but ndp_ref_set_trajectory was never called"; return -11; }
+    if (adv && !h->dTraj) { h->err = "ndp_tick: a trajectory time was given but ndp_ref_set_trajectory was never called"; return -11; }
     const int B = h->cfg.batch;
     const RingGeom rg = ring_geom(h);
     const bool est = (flags & TICK_ESTIMATE) != 0;
-    if (t || est) {
+    // ONE launch per tick (rti_kernel<..., TICK>: list advance and estimator inside the control step's waves) for the reference
+    // configuration's compile-time kernels; any other shape: tick_pre_kernel in front of the control step.  NDP_TICK_FORM=pre forces
+    // the two-launch form (A/B measurements).
+    static const bool force_pre = [] { const char *e = getenv("NDP_TICK_FORM"); return e && !strcmp(e, "pre"); }();
+    const bool one_launch = !force_pre && h->cfg.N == 20 && h->cfg.n_rti == 1 && h->waves == 4 && h->cfg.qp_precision == 0;
+    TickArgs ta{};
+    if (one_launch && (adv || est)) {
+        if (adv) {
+            const size_t Bs = (size_t)B, S = (size_t)h->traj_seg;
+            ta.coeff = h->dTraj; ta.tcum = ta.coeff + Bs * S * 28; ta.tseg = ta.tcum + Bs * (S + 1); ta.fpt = ta.tseg + Bs * S;
+            ta.seg_hint = reinterpret_cast<int *>(const_cast<double *>(ta.fpt + Bs * 3));
+            ta.n_seg = h->traj_seg;
+        }
+        ta.t = t; ta.t_all = t_all; ta.advance = adv ? 1 : 0;
+        ta.toff = h->cfg.N * h->cfg.dt; ta.mass = h->cfg.mass; ta.g = h->cfg.gravity;
+        ta.j_new = h->list_n + (unsigned long long)rg.ring();
+        ta.rg = rg; ta.rx = h->dRingX; ta.ru = h->dRingU;
+        ta.thr = thr_cfg(h); ta.st = h->dThr;
+        ta.vz = vz ? vz : x_odom + 5; ta.vz_pitch = vz ? 1 : NX;
+        ta.throttle = throttle ? throttle : h->dTickThrust;
+        ta.est = est ? 1 : 0;
+        so.tick = &ta;
+        if (adv) ++h->list_n;
+    } else if (adv || est) {
         TickPre a{};
         a.cf = ref_cfg(h, h->cfg.N * h->cfg.dt);
-        if (t) {
+        if (adv) {
             const size_t Bs = (size_t)B, S = (size_t)h->traj_seg;
             a.coeff = h->dTraj; a.tcum = a.coeff + Bs * S * 28; a.tseg = a.tcum + Bs * (S + 1); a.fpt = a.tseg + Bs * S;
             a.seg_hint = reinterpret_cast<int *>(const_cast<double *>(a.fpt + Bs * 3));
         }
-        a.t = t;
+        a.t = t; a.t_all = t_all; a.advance = adv ? 1 : 0;
         a.j_new = h->list_n + (unsigned long long)rg.ring();
         a.rg = rg; a.rx = h->dRingX; a.ru = h->dRingU;
         a.thr = thr_cfg(h); a.st = h->dThr;
@@ -3314,7 +3581,7 @@ static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, cons
         a.est = est ? 1 : 0;
         hipLaunchKernelGGL(tick_pre_kernel, dim3((B + 63) / 64), dim3(64), 0, s, a);
         NDP_HIP(h, hipGetLastError());
-        if (t) ++h->list_n;
+        if (adv) ++h->list_n;
     }
     const size_t slot = rg.slot(h->list_n);
     Neigh nb;
@@ -3336,8 +3603,9 @@ int ndp_tick_device(ndp_handle *h, const void *d_x_odom, const void *d_t, const 
     std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    int rc = tick_enqueue(h, s, (const double *)d_x_odom, (const double *)d_t, (const double *)d_vz, (const double *)d_throttle, flags,
-                          (double *)d_cmd, (double *)d_u0, StepOut());
+    const bool uni = d_t && (flags & TICK_T_UNIFORM);       // (then d_t is HOST memory: one double, read here)
+    int rc = tick_enqueue(h, s, (const double *)d_x_odom, d_t != nullptr, uni ? nullptr : (const double *)d_t, uni ? *(const double *)d_t : 0.0,
+                          (const double *)d_vz, (const double *)d_throttle, flags, (double *)d_cmd, (double *)d_u0, StepOut());
     return rc ? rc : note_stream(h, s);
 }
 
@@ -3357,7 +3625,8 @@ static int tick_begin_locked(ndp_handle *h, const double *x_odom, const double *
     unsigned char *ib = sl.hIn;
     const size_t o_t = up256(B * NX * 8), o_vz = o_t + up256(B * 8), o_th = o_vz + up256(B * 8);    // (<= in_bytes: the mirror holds a whole step's inputs)
     memcpy(ib, x_odom, B * NX * 8);
-    if (t) memcpy(ib + o_t, t, B * 8);
+    const bool uni = t && (flags & TICK_T_UNIFORM);         // one time for every vehicle: it travels in the kernel arguments
+    if (t && !uni) memcpy(ib + o_t, t, B * 8);
     if (vz) memcpy(ib + o_vz, vz, B * 8);
     if (throttle) memcpy(ib + o_th, throttle, B * 8);
     const auto tp1 = std::chrono::steady_clock::now();
@@ -3365,7 +3634,8 @@ static int tick_begin_locked(ndp_handle *h, const double *x_odom, const double *
     so.status = (int *)(sl.hOut + h->off_st); so.iters = (int *)(sl.hOut + h->off_it);
     so.done = sl.evOut;
     const bool want_u0 = (flags & TICK_WANT_U0) != 0;
-    rc = tick_enqueue(h, h->stream, (const double *)ib, t ? (const double *)(ib + o_t) : nullptr, vz ? (const double *)(ib + o_vz) : nullptr,
+    rc = tick_enqueue(h, h->stream, (const double *)ib, t != nullptr, t && !uni ? (const double *)(ib + o_t) : nullptr, uni ? t[0] : 0.0,
+                      vz ? (const double *)(ib + o_vz) : nullptr,
                       throttle ? (const double *)(ib + o_th) : nullptr, flags, (double *)(sl.hOut + h->off_u0),
                       want_u0 ? (double *)(sl.hOut + h->out_bytes) : nullptr, so);
     if (rc) return rc;

@@ -129,6 +129,10 @@ struct RtiIo {            // global-memory views of ONE instance
     // u_0: cmd[4] = [wx, wy, wz, c mass / k_throttle]; the thrust is also kept for the next estimator update.  Null = not a tick.
     double *cmd = nullptr, *thrust_keep = nullptr;
     double kthr = 0.0, cmd_mass = 0.0;
+    // ndp_tick in one launch: node N of the reference window as the caller's wave made it (the list's newest entry; its slot in the
+    // list is being written during this launch) -- staged over what was loaded for that row
+    int have_xrN = 0;
+    double xrN[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int f_is_f64 = 0;     // 1: f points at doubles (the reference hands acados a float64 p, ndp_nmpc_body_rate_ctl.py:97-99); 0: fp32, what DownwashNN returns
 };
 
@@ -489,7 +493,7 @@ struct RtiWave {
     }
 
     // land them in LDS (first use of the loaded values: the wait sits here)
-    static NDP_D void commit_inputs(const RtiParams &P, const LdsMap &m, const InBuf &b, lp lds, bool first)
+    static NDP_D void commit_inputs(const RtiParams &P, const LdsMap &m, const InBuf &b, lp lds, bool first, const RtiIo &io)
     {
         const int N = horizon(P);
         vi lane = lane_it();
@@ -501,6 +505,11 @@ struct RtiWave {
             vi i = W::imin(lane + 64 * t, nx - 1);
             W::st(lds, i + m.TXR, b.xr[t]);
             if (first) W::st(lds, i + m.XI, b.xi[t]);
+        }
+        if (NDP_RARELY(io.have_xrN != 0)) {       // (DS operations of a wave execute in order: this lands on top of row N's loaded values)
+            vd v = vd(io.xrN[9]);
+            for (int i = 8; i >= 0; --i) v = W::sel(lane == i, vd(io.xrN[i]), v);
+            W::stp(lds, lane + (m.TXR + N * int(NX)), v, lane < int(NX));
         }
         for (int t = 0; t < RU; ++t) {
             vi i = W::imin(lane + 64 * t, nu - 1);
@@ -1704,7 +1713,7 @@ struct RtiWave {
             InBuf &ib = LOCAL_IN ? lbuf : inb;
             if (io.f_in_lds)
                 for (int t = 0; t < RF; ++t) ib.f[t] = fkeep[t];
-            commit_inputs(P, m, ib, lds, it == 0);
+            commit_inputs(P, m, ib, lds, it == 0, io);
             stamp(io, m, 2);
             build_cost(P, m, lds);
             stamp(io, m, 3);

@@ -73,9 +73,9 @@ class CodeObject:
         return out
 
 
-def rti_kernel_name(nslot, waves, fused, nc=0, prec=0, nrc=None, qmode=0):
+def rti_kernel_name(nslot, waves, fused, nc=0, prec=0, nrc=None, qmode=0, tick=False):
     nrc = (1 if nc else 0) if nrc is None else nrc
-    return (f"_ZN3ndp10rti_kernelILi{nslot}ELi{waves}ELb{1 if fused else 0}ELi{nc}ELi{prec}ELi{nrc}ELi{qmode}EEEvNS_8KernArgsE")
+    return (f"_ZN3ndp10rti_kernelILi{nslot}ELi{waves}ELb{1 if fused else 0}ELi{nc}ELi{prec}ELi{nrc}ELi{qmode}ELb{1 if tick else 0}EEEvNS_8KernArgsE")
 
 
 def epoch_store_is_ordered(insns):

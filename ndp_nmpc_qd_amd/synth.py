@@ -63,18 +63,25 @@ def figure_eight(omega, phi, t):
     return pos, vel, acc, jerk
 
 
-def figure_eight_traj(B, seed=SEED0, n_seg=40, t_seg=0.5, omega_range=(0.5, 1.5)):
+def figure_eight_traj(B, seed=SEED0, n_seg=40, t_seg=0.5, omega_range=(0.5, 1.5), pairs=False):
     """The figure-eights of make_batch(B, seed=seed) (same omega, phi per instance) as TrajCoefficients.msg arrays: piecewise septic
     polynomials in the reference's normalised segment time (base_pt_publisher.py:100-133: s = (t - time_cum[i]) / time_seg[i],
     derivative d scaled by time_seg^-d) that match position, velocity, acceleration and jerk of the analytic curve at both ends of
     every segment.  Yaw = 0.
     Returns dict coeff_x / coeff_y / coeff_z [B, n_seg*8], coeff_yaw [B, n_seg*4], time_cum [B, n_seg+1], time_seg [B, n_seg],
-    final_pt [B, 3] (what BatchedNMPC.ref_set_trajectory takes) + omega, phi."""
+    final_pt [B, 3] (what BatchedNMPC.ref_set_trajectory takes) + omega, phi.
+    pairs: vehicle 2k+1 flies vehicle 2k's curve shifted like make_batch's neighbour windows (phase +-0.2 rad, offset U[-1.5, 1.5]^2 x
+    U[0.3, 1.5] m): with other_index = i ^ 1 about a third of the r_horiz gates are open, as in the metric's workload."""
     rng = np.random.Generator(np.random.PCG64(seed))
     omega = rng.uniform(*omega_range, size=B)
     phi = rng.uniform(0.0, 2 * np.pi, size=B)
+    offs = np.zeros((B, 3))
+    if pairs:
+        omega[1::2], phi[1::2] = omega[0:B - B % 2:2], phi[0:B - B % 2:2] + rng.uniform(-0.2, 0.2, size=B // 2)
+        offs[1::2] = np.concatenate([rng.uniform(-1.5, 1.5, size=(B // 2, 2)), rng.uniform(0.3, 1.5, size=(B // 2, 1))], axis=1)
     tk = t_seg * np.arange(n_seg + 1)
     pos, vel, acc, jerk = figure_eight(omega[:, None], phi[:, None], tk[None, :])            # [B, n_seg+1, 3]
+    pos = pos + offs[:, None, :]
     # rows: p(0), p'(0), p''(0), p'''(0), p(1), p'(1), p''(1), p'''(1) of sum c_i s^i
     A = np.zeros((8, 8))
     for d in range(4):

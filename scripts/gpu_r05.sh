@@ -14,7 +14,8 @@ tick)
   timeout 900 python -m pytest tests/test_tick.py tests/test_round5_gpu.py tests/test_ref_window_row.py tests/test_throttle_row.py tests/test_relay_and_plant_rows.py -m gpu -q --timeout 600 -x 2>&1 | tail -30 > $O/tests.txt; tail -15 $O/tests.txt
   timeout 300 python3 scripts/tick_rate.py 2> $O/tick_rate.err | tee $O/tick_rate.txt; tail -3 $O/tick_rate.err
   timeout 300 python3 scripts/tick_rate.py --no-estimator 2>> $O/tick_rate.err | head -3 | tee -a $O/tick_rate.txt
-  R=$PWD; for m in est noest; do rm -rf $O/trace_$m; (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/trace_$m -- python3 $R/scripts/tick_trace.py run $m > $O/trace_$m.log 2>&1); python3 scripts/tick_trace.py summarise $O/trace_$m | tee -a $O/tick_rate.txt; done
+  timeout 300 python3 scripts/tick_rate.py --no-estimator --uniform-t 2>> $O/tick_rate.err | head -3 | tee -a $O/tick_rate.txt
+  R=$PWD; for m in noest noest_uni; do rm -rf $O/trace_$m; (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/trace_$m -- python3 $R/scripts/tick_trace.py run $m > $O/trace_$m.log 2>&1); python3 scripts/tick_trace.py summarise $O/trace_$m | tee -a $O/tick_rate.txt; done
   timeout 300 python3 bench.py --only-timed --steps 300 --warmup 30 --downwash-form fused 2> $O/bench300.err | tee $O/bench300.json | hl
   ;;
 tests)

@@ -19,7 +19,7 @@ from ndp_nmpc_qd_amd import synth                  # noqa: E402
 def setup(B, pairs=True, seed=synth.SEED0 + 3):
     """B vehicles on SURVEY 8d's figure-eights (synth.figure_eight_traj: 20 s of trajectory = 1000 control ticks), the reference list
     built, vehicle i's neighbour = vehicle i ^ 1 (gate on the odometry), the controller reset to the first window."""
-    tr = synth.figure_eight_traj(B, seed=seed, n_seg=80, t_seg=0.25)
+    tr = synth.figure_eight_traj(B, seed=seed, n_seg=80, t_seg=0.25, pairs=pairs and B % 2 == 0)
     eng = ndp.BatchedNMPC(B, disturbance=True)
     eng.ref_set_trajectory(tr["coeff_x"], tr["coeff_y"], tr["coeff_z"], tr["coeff_yaw"], tr["time_cum"], tr["time_seg"], tr["final_pt"])
     eng.ref_list_reset()
@@ -33,6 +33,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--ticks", type=int, default=300)
+    ap.add_argument("--uniform-t", action="store_true", help="one clock for every vehicle: t as a scalar (NDP_TICK_T_UNIFORM)")
     ap.add_argument("--no-estimator", action="store_true", help="the reference stops the estimator's timer while a trajectory is tracked")
     args = ap.parse_args()
     B, n = args.batch, args.ticks
@@ -44,6 +45,7 @@ def main():
     nt = 32 + n1 + n + 1
     assert nt <= 890, "the trajectories last 1000 ticks; the list looks 100 ticks ahead"
     ts = [np.full(B, 0.02 * i) for i in range(nt)]
+    tk = [float(t[0]) for t in ts] if args.uniform_t else ts          # what the tick is handed
     xs = []
     for i in range(nt):
         x = eng.ref_window(ts[i])[0][:, 0, :].copy()
@@ -55,24 +57,25 @@ def main():
     it = iter(range(nt))
     for _ in range(32):                               # warm: link, clocks, mirrors
         i = next(it)
-        eng.tick(xs[i], t=ts[i], estimate=est)
+        eng.tick(xs[i], t=tk[i], estimate=est)
     t0 = time.perf_counter()
     for _ in range(n1):
         i = next(it)
-        eng.tick(xs[i], t=ts[i], estimate=est)
+        eng.tick(xs[i], t=tk[i], estimate=est)
     one = (time.perf_counter() - t0) / n1
     i = next(it)
-    eng.tick_begin(xs[i], t=ts[i], estimate=est)
+    eng.tick_begin(xs[i], t=tk[i], estimate=est)
     t0 = time.perf_counter()
     for _ in range(n):
         i = next(it)
-        eng.tick_begin(xs[i], t=ts[i], estimate=est)
+        eng.tick_begin(xs[i], t=tk[i], estimate=est)
         eng.tick_end(out=cmd)
     two = (time.perf_counter() - t0) / n
     _, _, st, itn = eng.tick_end(full=False), None, *eng.status()
-    print(f"  last tick: {int((st != 0).sum())} instances not converged, {float((itn > 0).mean()):.3f} in the interior-point loop")
+    print(f"  last tick: {int((st != 0).sum())} instances not converged, {float((itn > 0).mean()):.3f} in the interior-point loop, "
+          f"{float(np.any(eng.device_force().cpu().numpy() != 0, axis=(1, 2)).mean()):.2f} of the gates open")
     in_b = 80 + 8
-    print(f"ndp_tick batch {B} (estimator {'on' if est else 'off'}): two ticks in flight {two * 1e6:8.2f} us/tick = {B / two / 1e6:7.3f} M solves/s "
+    print(f"ndp_tick batch {B} (estimator {'on' if est else 'off'}, t {'scalar' if args.uniform_t else 'per vehicle'}): two ticks in flight {two * 1e6:8.2f} us/tick = {B / two / 1e6:7.3f} M solves/s "
           f"(PCIe {B * (in_b + 36) / two / 1e9:.2f} GB/s implied); one at a time {one * 1e6:8.2f} us = {B / one / 1e6:7.3f} M solves/s")
     print("  host us of the last tick (pack, enqueue, wait, copy-out):", [round(v, 1) for v in host_timing(eng)])
     # ---- the same workload through ndp_step_begin / _end: everything across PCIe

@@ -27,7 +27,9 @@ def run():
         x[:, 3:6] += rng.normal(0, 0.2, (B, 3))
         xs.append(x)
     cmd = np.empty((B, 4))
-    est = len(sys.argv) < 3 or sys.argv[2] != "noest"
+    est = len(sys.argv) < 3 or "noest" not in sys.argv[2]
+    if len(sys.argv) >= 3 and "uni" in sys.argv[2]:
+        ts = [float(t[0]) for t in ts]
     eng.tick_begin(xs[0], t=ts[0], estimate=est)
     for i in range(1, n + 1):
         eng.tick_begin(xs[i], t=ts[i], estimate=est)

@@ -27,7 +27,10 @@ def test_reference_configuration_kernels_have_no_scratch(co):
     k = co.kernels()
     names = [I.rti_kernel_name(3, 4, True, 20), I.rti_kernel_name(3, 4, False, 20), I.rti_kernel_name(3, 4, True, 20, qmode=1),
              I.rti_kernel_name(3, 4, False, 20, qmode=1), I.rti_kernel_name(3, 4, False, 20, qmode=2),
-             I.rti_kernel_name(5, 2, False, 40, nrc=2, qmode=1)]
+             I.rti_kernel_name(5, 2, False, 40, nrc=2, qmode=1),
+             # the one-launch control tick (ndp_tick): in place and work-list producer, with and without the fused downwash
+             I.rti_kernel_name(3, 4, True, 20, tick=True), I.rti_kernel_name(3, 4, False, 20, tick=True),
+             I.rti_kernel_name(3, 4, True, 20, qmode=1, tick=True), I.rti_kernel_name(3, 4, False, 20, qmode=1, tick=True)]
     for n in names:
         assert n in k, n
         assert k[n]["scratch"] == 0, (n, k[n])

@@ -242,6 +242,60 @@ def test_two_ticks_in_flight_and_misuse(gold, flat):
         ndp.BatchedNMPC(4, disturbance=True).tick_config(np.array([1, 0, 4, -1]))
 
 
+def test_one_clock_for_all_vehicles_and_the_two_launch_form(gold, flat, monkeypatch):
+    """t as a scalar (NDP_TICK_T_UNIFORM: it travels in the kernel arguments) = t as an array of equal entries; and the one-launch
+    tick (the control step's wave makes the list's newest entry itself) = the two-launch form (tick_pre_kernel in front), bit for
+    bit, across segment boundaries and past the end of a trajectory."""
+    import subprocess
+    import sys
+    import ndp_nmpc_qd_amd as ndp
+    coeff, tseg, cum, fpt = _seq_traj(gold, flat, 2)
+    B = coeff.shape[0]
+    other_index = np.array([(i + 3) % B for i in range(B)], dtype=np.int32)
+    a, b = ndp.BatchedNMPC(B, disturbance=True), ndp.BatchedNMPC(B, disturbance=True)
+    for e in (a, b):
+        _set_traj(e, coeff, tseg, cum, fpt)
+        e.ref_list_reset()
+        e.tick_config(other_index, gate=True)
+        e.tick_reset()
+    rng = np.random.default_rng(21)
+    t_end = float(cum.max()) + 1.0
+    xs, ts, outs = [], [], []
+    for i in range(40):
+        t = i * t_end / 39                                            # big steps: segment changes of more than one, then past the end
+        x0 = _odometry(rng, a.ref_list_window(None)[0])
+        ca = a.tick(x0, t=float(t), estimate=True, full=True, raise_on_status=False)
+        cb = b.tick(x0, t=np.full(B, t), estimate=True, full=True, raise_on_status=False)
+        for u, v in zip(ca, cb):
+            assert np.array_equal(u, v)
+        xs.append(x0); ts.append(t); outs.append(ca[0])
+    Xa, Ua = a.get_iterate()
+    wa = a.ref_list_window(None)
+    # the same ticks through the two-launch form, in a child process (the form is chosen once per process: NDP_TICK_FORM)
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ndp_tick_ab_%d.npz" % os.getpid())
+    np.savez(path, xs=np.array(xs), ts=np.array(ts), coeff=coeff, tseg=tseg, cum=cum, fpt=fpt, oi=other_index)
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import ndp_nmpc_qd_amd as ndp\n"
+        "d = np.load(%r)\n"
+        "c = d['coeff']; B = c.shape[0]\n"
+        "e = ndp.BatchedNMPC(B, disturbance=True)\n"
+        "e.ref_set_trajectory(c[:, :, 0:8], c[:, :, 8:16], c[:, :, 16:24], c[:, :, 24:28], d['cum'], d['tseg'], d['fpt'])\n"
+        "e.ref_list_reset(); e.tick_config(d['oi'], gate=True); e.tick_reset()\n"
+        "out = [e.tick(x, t=float(t), estimate=True, raise_on_status=False) for x, t in zip(d['xs'], d['ts'])]\n"
+        "X, U = e.get_iterate(); w = e.ref_list_window(None)\n"
+        "np.savez(%r, out=np.array(out), X=X, U=U, wx=w[0], wu=w[1])\n" % (ROOT, path, path + ".out.npz"))
+    env = dict(os.environ, NDP_TICK_FORM="pre")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(path + ".out.npz")
+    assert np.array_equal(got["out"], np.array(outs))
+    assert np.array_equal(got["X"], Xa) and np.array_equal(got["U"], Ua)
+    assert np.array_equal(got["wx"], wa[0]) and np.array_equal(got["wu"], wa[1])
+    os.remove(path); os.remove(path + ".out.npz")
+
+
 def test_tick_device_equals_host_tick(gold, flat):
     import torch
     import ndp_nmpc_qd_amd as ndp
