@@ -1145,20 +1145,25 @@ __global__ __launch_bounds__(256) void plant_kernel(double *__restrict__ x, cons
 // coefficients (224 contiguous bytes, shared by the neighbouring nodes of the vehicle), writes 80 + 32 contiguous bytes.
 struct RefCfg { int B, N, n_seg; double dt, mass, g, toff; };   // toff: added to every vehicle's node-0 time (rollouts)
 
-// Derivative d of sum_i c[i] s^i by Horner's rule, the factors i (i-1) .. (i-d+1) applied on the fly (get_poly_params +
-// _get_output_value, base_pt_publisher.py:102-133, polym_optimizer.py:104-139, evaluate every power, factor and term separately:
-// ~160 multiplies and adds per reference point; this is 2 per coefficient for the derivatives, 1 for the value: ~120).
+// Value and first ND - 1 derivatives of sum_i c[i] s^i at s by repeated synthetic division (the Taylor shift): pass k divides the
+// previous pass's quotient by (x - s) once more and leaves p^(k)(s) / k! -- NC_ - 1 - k fused multiply-adds, 22 for the four values of
+// a septic against 43 when every derivative is a Horner pass of its own with the factors i (i-1) .. applied on the way
+// (get_poly_params + _get_output_value, base_pt_publisher.py:102-133, polym_optimizer.py:104-139, evaluate every power, factor and
+// term separately: ~160 multiplies and adds per reference point).  out[k] = p^(k)(s) / k!.
 // Measured (round 3): folding factors and 1 / tseg^d into per-derivative coefficient blocks on the host (1 operation per
-// coefficient, but 85 instead of 28 loads per point) made the kernel SLOWER -- 1.32 ms against 0.97 ms per million windows: it
-// is bound by its loads, not by its f64 work.
-template <int NC_, int D>
-__device__ __forceinline__ double horner_d(const double *__restrict__ c, double s)
+// coefficient, but 85 instead of 28 loads per point) made the kernel SLOWER: the loads cost more than the arithmetic saved.
+template <int NC_, int ND>
+__device__ __forceinline__ void taylor_shift(const double *__restrict__ c, double s, double out[ND])
 {
-    auto fac = [](int i) { double f = 1.0; for (int j = 0; j < D; ++j) f *= (double)(i - j); return f; };
-    double acc = fac(NC_ - 1) * c[NC_ - 1];
+    double b[NC_];
 #pragma unroll
-    for (int i = NC_ - 2; i >= D; --i) acc = fma(acc, s, fac(i) * c[i]);
-    return acc;
+    for (int i = 0; i < NC_; ++i) b[i] = c[i];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+#pragma unroll
+        for (int i = NC_ - 2; i >= k; --i) b[i] = fma(b[i + 1], s, b[i]);
+        out[k] = b[k];
+    }
 }
 
 // ---- one reference point, in three pieces shared by every kernel that makes one (so that they all make the SAME point, bit for bit:
@@ -1190,18 +1195,33 @@ __device__ __forceinline__ int seg_locate(int n_seg, const double *__restrict__ 
 // axis 0..2) for c < 12, c = 12: yaw, c = 13: yaw rate.  ca = the value's own polynomial: chain_base(c) doubles into the segment's
 // record of 28 coefficients, x(8) y(8) z(8) yaw(4).
 __device__ __forceinline__ int chain_base(int c) { return c >= 12 ? 24 : 8 * (c % 3); }
-__device__ __forceinline__ double traj_chain(const double *__restrict__ ca, int c, double s, double its)
+// p, v, a, j of one axis (ca: its 8 coefficients) / yaw, yaw rate (ca: the 4 yaw coefficients): derivative d carries d! / time_seg^d
+__device__ __forceinline__ void traj_axis(const double *__restrict__ ca, double s, double its, double out[4])
 {
 #pragma clang fp contract(off)
+    double tl[4];
+    taylor_shift<8, 4>(ca, s, tl);
     const double its2 = its * its;
-    if (c >= 12) return c == 12 ? horner_d<4, 0>(ca, s) : horner_d<4, 1>(ca, s) * its;
-    const int d = c / 3;
-    switch (d) {
-    case 0: return horner_d<8, 0>(ca, s);
-    case 1: return horner_d<8, 1>(ca, s) * its;
-    case 2: return horner_d<8, 2>(ca, s) * its2;
-    default: return horner_d<8, 3>(ca, s) * (its2 * its);
+    out[0] = tl[0]; out[1] = tl[1] * its; out[2] = tl[2] * (2.0 * its2); out[3] = tl[3] * (6.0 * (its2 * its));
+}
+__device__ __forceinline__ void traj_yaw(const double *__restrict__ ca, double s, double its, double out[2])
+{
+#pragma clang fp contract(off)
+    double tl[2];
+    taylor_shift<4, 2>(ca, s, tl);
+    out[0] = tl[0]; out[1] = tl[1] * its;
+}
+__device__ __forceinline__ double traj_chain(const double *__restrict__ ca, int c, double s, double its)
+{
+    if (c >= 12) {
+        double y[2];
+        traj_yaw(ca, s, its, y);
+        return c == 12 ? y[0] : y[1];
     }
+    double v[4];
+    traj_axis(ca, s, its, v);
+    const int d = c / 3;
+    return d == 0 ? v[0] : (d == 1 ? v[1] : (d == 2 ? v[2] : v[3]));
 }
 
 // ---- f64 helpers of the flatness map.  An IEEE divide or square root is a ~30-instruction dependent chain on gfx950 and the map
@@ -1319,22 +1339,33 @@ __device__ __forceinline__ void ref_point(const RefCfg &cf, const double *__rest
             s = (t - tc[idx]) * its;                      // :102-103
         }
 #pragma unroll
-        for (int c = 0; c < 12; ++c) pvaj[c] = traj_chain(rec + chain_base(c), c, s, its);
-        yaw = traj_chain(rec + chain_base(12), 12, s, its);
-        yawd = traj_chain(rec + chain_base(13), 13, s, its);
+        for (int a = 0; a < 3; ++a) {
+            double v[4];
+            traj_axis(rec + 8 * a, s, its, v);
+            pvaj[a] = v[0]; pvaj[3 + a] = v[1]; pvaj[6 + a] = v[2]; pvaj[9 + a] = v[3];
+        }
+        double y[2];
+        traj_yaw(rec + 24, s, its, y);
+        yaw = y[0]; yawd = y[1];
     }
     flatness_xu(cf.mass, cf.g, pvaj, yaw, yawd, xv, uv);
 }
 
 #define REF_ROWS 64     // rows (vehicle, node) per workgroup = one wave: small batches spread over all CUs
-__global__ __launch_bounds__(REF_ROWS) void ref_window_kernel(RefCfg cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
-                                                         const double *__restrict__ tseg, const double *__restrict__ fpt,
-                                                         const double *__restrict__ tq, double *__restrict__ xr, double *__restrict__ ur)
+// A wave's life here is a chain of dependent memory round trips (time -> segment -> 28 coefficients -> ... -> stores): the kernel
+// runs at (resident waves) / (one wave's latency), not at a VALU or HBM limit -- PMC, round 5: VALU 27 % busy, HBM 49 %, 4.9 waves per
+// SIMD of 11 us each.  Hence ONE 5 KB staging buffer used twice (x rows, then u rows: 7 KB per wave had capped a CU at 22
+// workgroups; the 76 registers allow 6 waves per SIMD).  Forcing 64 registers (8 waves) spills 20 bytes per lane and is slower (0.38
+// against 0.44 of the HBM roof).
+__global__ __launch_bounds__(REF_ROWS)
+void ref_window_kernel(RefCfg cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
+                       const double *__restrict__ tseg, const double *__restrict__ fpt,
+                       const double *__restrict__ tq, double *__restrict__ xr, double *__restrict__ ur)
 {
     // Each lane produces 80 + 32 contiguous bytes; written directly that is a 16-byte store at an 80-byte lane stride
     // (one fifth of every cache line per instruction).  The wave's rows are contiguous in xr (and, minus the node-N
-    // rows, in ur), so the outputs are transposed through LDS and leave as dense 512-byte wave stores.
-    __shared__ double sx[REF_ROWS * 10], su[REF_ROWS * 4];
+    // rows, in ur), so the outputs are transposed through LDS and leave as dense 1024-byte wave stores.
+    __shared__ __attribute__((aligned(16))) double sx[REF_ROWS * 10];
     const int lane = (int)threadIdx.x;
     const int row0 = (int)blockIdx.x * REF_ROWS;
     const int np1 = cf.N + 1, nrows = cf.B * np1;
@@ -1344,24 +1375,32 @@ __global__ __launch_bounds__(REF_ROWS) void ref_window_kernel(RefCfg cf, const d
     double xv[10], uv[4];
     ref_point(cf, coeff, tcum, tseg, fpt, b, t, xv, uv);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) sx[lane * 10 + i] = xv[i];
-    // ur has no node-N rows: the number of u rows before row (b, k) is b N + k = row - b
-    const int ufirst = row0 - row0 / np1;
-    const int uslot = (row - b) - ufirst;
-    if (k < cf.N && row0 + lane < nrows) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) su[uslot * 4 + i] = uv[i];
-    }
+    for (int i = 0; i < 5; ++i) reinterpret_cast<double2 *>(sx)[lane * 5 + i] = make_double2(xv[2 * i], xv[2 * i + 1]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const int rows_here = nrows - row0 < REF_ROWS ? nrows - row0 : REF_ROWS;
-    double *xg = xr + (size_t)row0 * 10;
-    for (int i = lane; i < rows_here * 10; i += REF_ROWS) xg[i] = sx[i];
+    // 16 bytes per lane and store (rows are 80 / 32 bytes: both arrays stay 16-byte aligned at every row)
+    double2 *xg = reinterpret_cast<double2 *>(xr + (size_t)row0 * 10);
+    const double2 *s2 = reinterpret_cast<const double2 *>(sx);
+    for (int i = lane; i < rows_here * 5; i += REF_ROWS) xg[i] = s2[i];
+    // ur has no node-N rows: the number of u rows before row (b, k) is b N + k = row - b
+    const int ufirst = row0 - row0 / np1;
+    const int uslot = (row - b) - ufirst;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();                                        // every lane has read its x pieces: the buffer is free
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (k < cf.N && row0 + lane < nrows) {
+        reinterpret_cast<double2 *>(sx)[uslot * 2] = make_double2(uv[0], uv[1]);
+        reinterpret_cast<double2 *>(sx)[uslot * 2 + 1] = make_double2(uv[2], uv[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const int rend = row0 + rows_here;
     const int nu = (rend - rend / np1) - ufirst;                                 // u rows among [row0, rend)
-    double *ug = ur + (size_t)ufirst * 4;
-    for (int i = lane; i < nu * 4; i += REF_ROWS) ug[i] = su[i];
+    double2 *ug = reinterpret_cast<double2 *>(ur + (size_t)ufirst * 4);
+    for (int i = lane; i < nu * 2; i += REF_ROWS) ug[i] = s2[i];
 }
 
 // ---- f1, the reference's own bookkeeping: NMPCRefPublisher keeps a list of `ring` = step N + 1 reference points per vehicle,
@@ -1425,16 +1464,29 @@ __global__ __launch_bounds__(256) void ref_list_fix_kernel(const double *__restr
 
 // get_nmpc_ref_from_long_list (:99-103) as a stand-alone call: the window of tick n -> xr[B][N+1][10], ur[B][N][4].  Both sides
 // are contiguous per vehicle (see RingGeom): a dense copy, 16 bytes per lane -- 5 (N+1) + 2 N pieces per vehicle.
+enum { WIN_UNROLL = 4 };      // 16-byte pieces per thread, a block apart: four loads in flight per lane before the first store
 __global__ __launch_bounds__(256) void ref_list_window_kernel(const double *__restrict__ rx, const double *__restrict__ ru, RingGeom rg,
                                                               unsigned long long n, int B, double *__restrict__ xr, double *__restrict__ ur)
 {
     const int N = rg.np1 - 1, nxp = 5 * rg.np1, per = nxp + 2 * N;
-    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (size_t)B * per) return;
-    const int b = (int)(id / per), e = (int)(id - (size_t)b * per);
-    const size_t s = rg.slot(n);
-    if (e < nxp) reinterpret_cast<double2 *>(xr)[(size_t)b * nxp + e] = reinterpret_cast<const double2 *>(rx + (size_t)b * rg.px() + s * 10)[e];
-    else reinterpret_cast<double2 *>(ur)[(size_t)b * 2 * N + (e - nxp)] = reinterpret_cast<const double2 *>(ru + (size_t)b * rg.pu() + s * 4)[e - nxp];
+    const size_t total = (size_t)B * per, s = rg.slot(n);
+    const size_t id0 = (size_t)blockIdx.x * (256 * WIN_UNROLL) + threadIdx.x;
+    double2 v[WIN_UNROLL];
+    double2 *dst[WIN_UNROLL];
+#pragma unroll
+    for (int j = 0; j < WIN_UNROLL; ++j) {
+        const size_t id = id0 + (size_t)j * 256;
+        const size_t idc = id < total ? id : total - 1;
+        const int b = (int)(idc / per), e = (int)(idc - (size_t)b * per);
+        const double2 *src = e < nxp ? reinterpret_cast<const double2 *>(rx + (size_t)b * rg.px() + s * 10) + e
+                                     : reinterpret_cast<const double2 *>(ru + (size_t)b * rg.pu() + s * 4) + (e - nxp);
+        dst[j] = id < total ? (e < nxp ? reinterpret_cast<double2 *>(xr) + (size_t)b * nxp + e
+                                       : reinterpret_cast<double2 *>(ur) + (size_t)b * 2 * N + (e - nxp)) : nullptr;
+        v[j] = *src;
+    }
+#pragma unroll
+    for (int j = 0; j < WIN_UNROLL; ++j)
+        if (dst[j]) *dst[j] = v[j];
 }
 
 
@@ -3438,8 +3490,8 @@ int ndp_ref_list_advance_device(ndp_handle *h, const void *d_t, void *stream)
 static int launch_list_window(ndp_handle *h, double *d_xr, double *d_ur, hipStream_t s)
 {
     if (!h->dRingX) { h->err = "ndp_ref_list_window: no list (ndp_ref_list_reset / ndp_ref_list_fix_pt first)"; return -11; }
-    const size_t n = (size_t)h->cfg.batch * (5 * (h->cfg.N + 1) + 2 * h->cfg.N);
-    hipLaunchKernelGGL(ref_list_window_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const double *)h->dRingX,
+    const size_t n = (size_t)h->cfg.batch * (5 * (h->cfg.N + 1) + 2 * h->cfg.N), per_block = 256 * WIN_UNROLL;
+    hipLaunchKernelGGL(ref_list_window_kernel, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(256), 0, s, (const double *)h->dRingX,
                        (const double *)h->dRingU, ring_geom(h), h->list_n, h->cfg.batch, d_xr, d_ur);
     NDP_HIP(h, hipGetLastError());
     return 0;
