@@ -124,11 +124,42 @@ static void vde_stage(const orc_cfg *c, const double *xs, const double *u, const
 /* acados sim_erk: classical RK4 tableau, num_stages=4, num_steps=1 (options
  * not set by nmpc_body_rate_ctl.py:71-80, so acados defaults), forward
  * sensitivities from the variational equation with the same tableau.       */
+/* ---- [acados-knowledge] assumptions as switches, for the sensitivity study only (scripts/acados_sensitivity.py): what u0 would be if
+ * acados did one of the things SURVEY A.4 assumes it does not.  0 = the restatement as the tests pin it.  A process-wide test switch,
+ * not part of orc_cfg (whose layout the Python binding mirrors); not thread-safe against concurrent changes. */
+static int g_variant = 0;
+void orc_set_variant(int bits) { g_variant = bits; }
+int orc_get_variant(void) { return g_variant; }
+
+static void rk4_sens_h(const orc_cfg *c, double h, const double *x, const double *u, const double *fd,
+                       double *xn, double *A, double *B);
+
 void orc_rk4_sens(const orc_cfg *c, const double *x, const double *u, const double *fd,
                   double *xn, double *A, double *B)
 {
+    if (!(g_variant & ORC_VAR_ERK_2_STEPS)) { rk4_sens_h(c, c->dt, x, u, fd, xn, A, B); return; }
+    /* sim_method_num_steps = 2: two RK4 steps of h / 2; sensitivities chained: A = A2 A1, B = A2 B1 + B2 */
+    double xm[NX], A1[NX * NX], B1[NX * NU], A2[NX * NX], B2[NX * NU];
+    rk4_sens_h(c, 0.5 * c->dt, x, u, fd, xm, A1, B1);
+    rk4_sens_h(c, 0.5 * c->dt, xm, u, fd, xn, A2, B2);
+    for (int i = 0; i < NX; ++i) {
+        for (int j = 0; j < NX; ++j) {
+            double s = 0.0;
+            for (int l = 0; l < NX; ++l) s += A2[i * NX + l] * A1[l * NX + j];
+            A[i * NX + j] = s;
+        }
+        for (int j = 0; j < NU; ++j) {
+            double s = B2[i * NU + j];
+            for (int l = 0; l < NX; ++l) s += A2[i * NX + l] * B1[l * NU + j];
+            B[i * NU + j] = s;
+        }
+    }
+}
+
+static void rk4_sens_h(const orc_cfg *c, double h, const double *x, const double *u, const double *fd,
+                       double *xn, double *A, double *B)
+{
     enum { NS = NX + NU };
-    const double h = c->dt;
     double S0[NX * NS], St[NX * NS], xs[NX];
     double k1[NX], k2[NX], k3[NX], k4[NX];
     double K1[NX * NS], K2[NX * NS], K3[NX * NS], K4[NX * NS];
@@ -441,7 +472,7 @@ static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B
             cn[n].stage = k; cn[n].idx = i;
             cn[n].lo = lu[k * NU + i]; cn[n].hi = uu[k * NU + i];
         }
-    for (int k = 1; k < N; ++k)
+    for (int k = 1; k < N + ((g_variant & ORC_VAR_BOUNDS_STAGE_N) ? 1 : 0); ++k)
         for (int i = 0; i < 3; ++i, ++n) {
             cn[n].stage = k; cn[n].idx = NU + i;
             cn[n].lo = lv[k * 3 + i]; cn[n].hi = uv[k * 3 + i];
@@ -622,7 +653,7 @@ void orc_linearize(const orc_cfg *c, const double *x0, const double *xr, const d
         if (c->use_fd && f) { fdk[0] = f[k * 3]; fdk[1] = f[k * 3 + 1]; fdk[2] = f[k * 3 + 2]; }
         orc_rk4_sens(c, xk, uk, fdk, xn, A + (size_t)k * NX * NX, B + (size_t)k * NX * NU);
         for (int i = 0; i < NX; ++i) b[k * NX + i] = xn[i] - X[(size_t)(k + 1) * NX + i];
-        orc_cost_stage(c, c->dt, xk, uk, xr + (size_t)k * NX, ur + (size_t)k * NU,
+        orc_cost_stage(c, (g_variant & ORC_VAR_NO_DT_SCALING) ? 1.0 : c->dt, xk, uk, xr + (size_t)k * NX, ur + (size_t)k * NU,
                        Q + (size_t)k * NX * NX, q + (size_t)k * NX, Rd + (size_t)k * NU, r + (size_t)k * NU);
         for (int i = 0; i < NU; ++i) {
             lu[k * NU + i] = c->lbu[i] - uk[i];
@@ -634,9 +665,13 @@ void orc_linearize(const orc_cfg *c, const double *x0, const double *xr, const d
         }
     }
     /* terminal: yref_N = xr_N, W_e = Q unscaled (nmpc_body_rate_ctl.py:53,101-104) */
-    orc_cost_stage(c, 1.0, X + (size_t)N * NX, NULL, xr + (size_t)N * NX, NULL,
+    orc_cost_stage(c, (g_variant & ORC_VAR_TERMINAL_TIMES_DT) ? c->dt : 1.0, X + (size_t)N * NX, NULL, xr + (size_t)N * NX, NULL,
                    Q + (size_t)N * NX * NX, q + (size_t)N * NX, NULL, NULL);
-    for (int i = 0; i < 3; ++i) { lv[N * 3 + i] = -1e30; uv[N * 3 + i] = 1e30; }
+    for (int i = 0; i < 3; ++i) {
+        const int on = (g_variant & ORC_VAR_BOUNDS_STAGE_N) != 0;
+        lv[N * 3 + i] = on ? c->lbv[i] - X[(size_t)N * NX + 3 + i] : -1e30;
+        uv[N * 3 + i] = on ? c->ubv[i] - X[(size_t)N * NX + 3 + i] : 1e30;
+    }
     /* solve_for_x0: lbx_0 = ubx_0 = x0 (nmpc_body_rate_ctl.py:107) */
     for (int i = 0; i < NX; ++i) dx0[i] = x0[i] - X[i];
 }

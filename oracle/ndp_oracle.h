@@ -63,6 +63,14 @@ typedef struct {
 
 void orc_default_cfg(orc_cfg *c);
 
+/* Sensitivity study of SURVEY A.4's [acados-knowledge] list (scripts/acados_sensitivity.py): a process-wide switch, 0 = off. */
+#define ORC_VAR_TERMINAL_TIMES_DT 1 /* terminal cost scaled by the interval like the stage costs              */
+#define ORC_VAR_BOUNDS_STAGE_N 2    /* the velocity box also on the terminal state                            */
+#define ORC_VAR_ERK_2_STEPS 4       /* sim_method_num_steps = 2: two RK4 steps per shooting interval          */
+#define ORC_VAR_NO_DT_SCALING 8     /* stage costs NOT scaled by the interval (terminal by 1 either way)      */
+void orc_set_variant(int bits);
+int orc_get_variant(void);
+
 /* a1: continuous dynamics, nmpc_body_rate_ctl.py:147-158 */
 void orc_dynamics(const orc_cfg *c, const double *x, const double *u, const double *fd, double *xdot);
 /* analytic Jacobians of a1, row-major A[10][10], B[10][4] */

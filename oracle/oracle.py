@@ -73,6 +73,14 @@ def default_cfg(N=20, n_rti=1, use_fd=False, T=None):
     return c
 
 
+VAR_TERMINAL_TIMES_DT, VAR_BOUNDS_STAGE_N, VAR_ERK_2_STEPS, VAR_NO_DT_SCALING = 1, 2, 4, 8
+
+
+def set_variant(bits):
+    """[acados-knowledge] assumptions as switches (ndp_oracle.h: ORC_VAR_*), for scripts/acados_sensitivity.py only; 0 = off."""
+    lib().orc_set_variant(int(bits))
+
+
 def dynamics(cfg, x, u, fd=None):
     x, u, fd = _f64(x), _f64(u), _f64(fd)
     out = np.zeros(NX)
