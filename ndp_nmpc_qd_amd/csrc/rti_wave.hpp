@@ -979,9 +979,14 @@ struct RtiWave {
                 H = Hn;
                 continue;
             }
+            // -DNDP_FINE_STAMPS (B = 1, debug path): the timeline of ONE stage (k = N / 2) -- the clock when each result is available
+            // (every stamp waits for its operand: the stamped stage runs a little slower than the others).  scripts/sweep_stage_timeline.py
+            NDP_FINE(const bool fst = io && io->dbg && k == N / 2; if (fst) fstamp(*io, m, 0, W::to_d(H.r[0]));)
             LamRegs LR;
             lam_gather(T, lds, W::to_d(hux), LR);
+            NDP_FINE(if (fst) fstamp(*io, m, 1, LR.own);)                          // Lam's entries gathered
             md4 Wf = mman<3>(H.r, mk, W::mzero4());
+            NDP_FINE(if (fst) fstamp(*io, m, 2, W::to_d(Wf.r[3]));)               // W = [H~xx ; H~ux] M~' (3 matrix instructions)
             if (kprev >= 0) {
                 if constexpr (MMA4) W::st(lds, T.kt_st4 + mb(kprev), W::to_d(Ktq));
                 else for (int c = 0; c < 3; ++c) W::st(lds, T.kt_st[c] + mb(kprev), W::to_d(Ktp.r[c]));
@@ -1012,6 +1017,8 @@ struct RtiWave {
             md G0;                                            // adj T, lane l: row l >> 4, column l & 15
             if constexpr (MMA4) G0 = mma4(W::to_m(ladj), tt, W::to_m(vd(0.0)));
             else G0 = mma(W::to_m(ladj), tt, W::mzero4()).r[0];
+            NDP_FINE(if (fst) fstamp(*io, m, 3, W::to_d(Hb.r[0]));)               // bracket C~' + M~'' (H~xx M~') (3 matrix instructions)
+            NDP_FINE(if (fst) fstamp(*io, m, 4, W::to_d(G0));)                    // adj(Lam) T (one four-block instruction) -- after the cofactors
             vd det = dq + W::csum2(dq);
             vd r0 = W::rcp_seed(det);
             for (int c = 0; c < 3; ++c) nmk[c] = W::to_m(W::ld(lds, T.mk_off[c] + mb(kp)));
@@ -1024,6 +1031,7 @@ struct RtiWave {
             vd rdet = r0 * e0;
             for (int r = 2; r < 4; ++r) ncc[r] = W::to_m(W::ld(lds, T.c_off[r] + cb(kp)));
             okv = okv && (det > 0.0) && (!T.lam_diag || (cofu > 0.0));   // on the diagonal the cofactor's sign factor is +1
+            NDP_FINE(if (fst) fstamp(*io, m, 5, gs);)                             // Lam^-1 T scaled (1 / det ready)
             md4 Hn = mma(-tt, W::to_m(gs), Hb);               // - T' Lam^-1 T on top of the bracket
             // K~' = H~ux' (-Lam^-1): the 1/det rides in the B operand (one multiply instead of one per result register); lands in
             // column 12+b = rows 12..15 of the forward operand; stored behind the next stage's first MFMAs
@@ -1031,6 +1039,7 @@ struct RtiWave {
             if constexpr (KEEP) linv_put(linv, k, N, nli);
             if constexpr (MMA4) Ktq = mma4(hux, nli, W::to_m(vd(0.0)));     // K~'[4b + i][j] in lane j + 4b + 16i
             else Ktp = mma(hux, nli, W::mzero4());
+            NDP_FINE(if (fst) { fstamp(*io, m, 13, W::to_d(Hn.r[0])); fstamp(*io, m, 14, W::to_d(MMA4 ? Ktq : Ktp.r[0])); })   // H~_k; K~'
             kprev = k;
             if (k % RESYM == 0) {
                 // H~ re-enters the next stage as an A operand, i.e. transposed.  Its antisymmetric rounding part
