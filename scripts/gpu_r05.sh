@@ -3,7 +3,9 @@
 #   tick     : tests of the tick and the list it reads + scripts/tick_rate.py + the headline's --only-timed run (regression check)
 #   tests    : the whole -m gpu suite
 #   bench    : the driver-shaped line (bench.py --steps 20 --warmup 5) + a 300-step run
-#   profile  : scripts/profile_round.sh r05 (kernel trace + PMC passes of the headline), scripts/profile_rows.sh r05
+#   profile  : scripts/profile_round.sh r05 (kernel trace + PMC passes of the headline), scripts/profile_rows.sh r05, HBM ceilings, tick stamps
+#   side     : 50 Hz cadence, host latency, stress parity
+# then: bash scripts/collect_profiles.sh r05  (gpurun_out/ -> profiles/)
 # Everything lands in gpurun_out/r05_<stage>/.
 STAGE=${1:-tick}; shift
 export TMPDIR=/tmp
@@ -27,7 +29,14 @@ bench)
   ;;
 profile)
   bash scripts/profile_round.sh r05 "$@"
-  [ -f scripts/profile_rows.sh ] && bash scripts/profile_rows.sh r05
+  bash scripts/profile_rows.sh r05
+  python3 scripts/hbm_ceiling.py 2>/dev/null | tee $O/hbm_ceiling.txt
+  python3 scripts/tick_stamps.py uniform 2>/dev/null | tee $O/tick_stamps.txt
+  ;;
+side)
+  timeout 600 python3 scripts/cadence_50hz.py --ticks 300 --wake 2>/dev/null | tee $O/cadence_50hz.txt
+  timeout 300 python3 scripts/host_latency.py 2>/dev/null | tee $O/host_latency.txt
+  timeout 900 python3 scripts/stress_parity.py 2>/dev/null | tee $O/stress_parity.txt | tail -3
   ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
