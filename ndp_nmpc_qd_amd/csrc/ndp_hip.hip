@@ -213,7 +213,7 @@ struct RingGeom {
 // trace against 24.8 us for the control step: a third of the tick for 112 bytes per vehicle.)
 struct TickArgs {
     const double *coeff, *tcum, *tseg, *fpt;   // the trajectories (ndp_ref_set_trajectory)
-    int *seg_hint;                             // [B] segment of each vehicle's previous point
+    double *segc;                              // [B][64] the vehicles' current / next segment records (see tick_early)
     int n_seg;
     const double *t;                           // [B] trajectory time of the tick, or null: t_all for every vehicle
     double t_all;
@@ -229,9 +229,13 @@ struct TickArgs {
     const double *throttle;
     int est;
 };
-struct TickEarly { double tv; int hint, v; };    // what tick_new_point needs first, requested at the kernel's very top (tick_early)
+// what tick_new_point works on, all of it requested at the kernel's very top (tick_early): the time, and the lane's share of the
+// vehicle's two cached segment records (see tick_early)
+struct TickEarly { double tv, lo0, hi0, ts0, i0, lo1, hi1, ts1, i1, tend, fp, ca[8], cn[8]; int v; };
 __device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, int orow, int lane);
-__device__ __forceinline__ void tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, double xv[10], double uv[4], double nbv[6]);
+__device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, double xv[10], double uv[4],
+                                                 double nbv[6], int &refill);
+__device__ __forceinline__ void tick_cache_store(const TickArgs &ta, int inst, int lane, int refill, double fill);
 __device__ __forceinline__ double tick_estimator(const TickArgs &ta, int inst, int B, int lane);
 
 struct KernArgs {
@@ -351,9 +355,10 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     // TICK: the newest list entry of this vehicle (x_new / u_new) and the position / velocity part of the neighbour's (nb_new).  Row N of
     // both windows is NOT read from the list in this launch (the neighbour's wave writes its entry while this one runs): the ego's goes
     // into the staged window through RtiIo::xrN, the pair into the network's input below.
-    double x_new[10], u_new[4], nb_new[6];
+    double x_new[10], u_new[4], nb_new[6], seg_fill = 0.0;
+    int seg_refill = 0;
     if (TICK && !(FUSED && wg_nb) && advance) {      // (fused with neighbours: made below, under the weight transfer)
-        tick_new_point(ka.ta, te, inst, (int)(threadIdx.x & 63u), x_new, u_new, nb_new);
+        seg_fill = tick_new_point(ka.ta, te, inst, (int)(threadIdx.x & 63u), x_new, u_new, nb_new, seg_refill);
 #pragma unroll
         for (int i = 0; i < 10; ++i) io.xrN[i] = x_new[i];
         io.have_xrN = 1;
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         lds_f32 wl = (lds_f32)smem;
         stage_fragments(ma.frag, wl, (int)threadIdx.x, 64 * WAVES);
         if (TICK && advance) {                    // the polynomial work runs while the weights stream into LDS
-            tick_new_point(ka.ta, te, inst, lane, x_new, u_new, nb_new);
+            seg_fill = tick_new_point(ka.ta, te, inst, lane, x_new, u_new, nb_new, seg_refill);
 #pragma unroll
             for (int i = 0; i < 10; ++i) io.xrN[i] = x_new[i];
             io.have_xrN = 1;
@@ -462,6 +467,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         io.f = nullptr;
         io.f_in_lds = 1;
     }
+    if (TICK && advance && active) tick_cache_store(ka.ta, inst, (int)(threadIdx.x & 63u), seg_refill, seg_fill);   // (requested in the prologue: long there)
     if (TICK && ka.ta.est && active) io.kthr = tick_estimator(ka.ta, inst, B, (int)(threadIdx.x & 63u));
     const bool deferred = Prog::template run<QMODE == 1, QMODE == 0 || QMODE == 3>(P, io, lds, inb, x0v);
     if (NDP_RARELY(io.stamps && (threadIdx.x & 63u) == 0)) {
@@ -1440,7 +1446,7 @@ __global__ __launch_bounds__(256) void ref_list_fill_kernel(RefCfg cf, const dou
     const int b = id / npts, i = id - b * npts;
     double xv[10], uv[4];
     // one point per vehicle = the per-tick advance: the segment hint applies (it lives behind final_pt, see ndp_ref_set_trajectory)
-    int *hint = npts == 1 ? reinterpret_cast<int *>(const_cast<double *>(fpt + (size_t)cf.B * 3)) : nullptr;
+    int *hint = npts == 1 ? reinterpret_cast<int *>(const_cast<double *>(fpt + (size_t)cf.B * 3 + (size_t)cf.B * 64)) : nullptr;
     ref_point(cf, coeff, tcum, tseg, fpt, b, (tq ? tq[b] : 0.0) + cf.toff + i * tstep, xv, uv, hint);
     ring_store(rg, rx, ru, b, j0 + (unsigned long long)i, xv, uv);
     if (dup0 && i == 0) ring_store(rg, rx, ru, b, j0 - 1, xv, uv);
@@ -1544,48 +1550,55 @@ __device__ __forceinline__ double uniform_lane(double v, int l)
     return __hiloint2double(hi, lo);
 }
 
-// The segment hint heads a chain of dependent loads (hint -> segment record -> value) and a wave's loads return in order: requested
-// behind the step's 17 input loads and the 70 KB weight transfer it came back ~2 000 cycles late, and the records another memory
-// round trip after that.  So hint and time are the FIRST loads of the launch; the records are requested as soon as the hint is there.
+// A per-vehicle cache of the trajectory's CURRENT and NEXT segment records, 2 x 32 doubles at segc + 64 v:
+//     [0] time_cum[i]  [1] time_cum[i + 1]  [2] time_seg[i]  [3] i  [4 .. 31] the 28 coefficients of segment i
+// Found through the trajectory arrays a point costs two dependent memory round trips (segment index -> record), ~1 700 cycles
+// each and nothing in the wave to hide them under; the cache's address depends on the vehicle only, so its loads are the launch's
+// first and arrive under the weight transfer.  A vehicle moves on to its next segment every time_seg / 20 ms ticks (and in a batch
+// of a thousand some vehicle does in every tick): that is slot 1, valid from the moment slot 0 was; the wave that crosses re-fills
+// both slots -- one load per lane, requested in the prologue, stored behind the MLP phase (tick_cache_store), off everybody's
+// critical path.  Anything else (the first tick after ndp_ref_set_trajectory -- the cache starts as NaNs --, a jump in time) takes
+// seg_locate and the trajectory arrays, and re-fills the cache the same way.
+enum { SEGC_SLOT = 32, SEGC_PER = 64 };
 __device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, int orow, int lane)
 {
     TickEarly te;
+    const int c = (lane & 15) < 14 ? (lane & 15) : 13, cb = chain_base(c);
     te.v = ((lane >> 4) & 1) && orow >= 0 ? orow : inst;
-    te.hint = ta.seg_hint[te.v];
-    te.tv = ta.t ? ta.t[te.v] : ta.t_all;
+    const double *s0 = ta.segc + (size_t)te.v * SEGC_PER, *s1 = s0 + SEGC_SLOT;
+    te.lo0 = s0[0]; te.hi0 = s0[1]; te.ts0 = s0[2]; te.i0 = s0[3];
+    te.lo1 = s1[0]; te.hi1 = s1[1]; te.ts1 = s1[2]; te.i1 = s1[3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { te.ca[i] = s0[4 + cb + (c >= 12 ? (i & 3) : i)]; te.cn[i] = s1[4 + cb + (c >= 12 ? (i & 3) : i)]; }
+    te.tend = ta.tcum[(size_t)te.v * (ta.n_seg + 1) + ta.n_seg];
+    te.fp = ta.fpt[(size_t)te.v * 3 + (c < 3 ? c : 0)];
+    te.tv = ta.t_all;                      // (written as a branch: as a select the compiler picks between two ADDRESSES -- the argument's
+    if (ta.t) te.tv = ta.t[te.v];          // copy parked in scratch memory for it -- and loads through a flat pointer)
     return te;
 }
 
-__device__ __forceinline__ void tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, double xv[10], double uv[4], double nbv[6])
+// returns (in every lane) the value lane l must store into the ego's cache word l behind the MLP phase, valid if refill != 0
+__device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, double xv[10], double uv[4],
+                                                 double nbv[6], int &refill)
 {
     const int c = (lane & 15) < 14 ? (lane & 15) : 13;
     const int v = te.v;
     const int S = ta.n_seg;
     const double *tc = ta.tcum + (size_t)v * (S + 1);
-    // Everything the value needs is requested BEFORE the time is looked at (the time may come across PCIe: ~2.5 us): the hinted
-    // segment and the one behind it -- a vehicle moves on to the next segment every time_seg / 20 ms ticks, and in a batch of a
-    // thousand some vehicle does so in every tick.  Anything else (a jump, the first tick after a reset) is the slow path.
-    const double tv = te.tv;
-    const int hint = te.hint;
-    const int i0 = hint < 0 ? 0 : (hint >= S ? S - 1 : hint), i1 = i0 + 1 < S ? i0 + 1 : i0;
-    const double tc0 = tc[i0], tc1 = tc[i0 + 1], tc2 = tc[i1 + 1], tce = tc[S];
-    const double ts0 = ta.tseg[(size_t)v * S + i0], ts1 = ta.tseg[(size_t)v * S + i1];
-    const int cb = chain_base(c);
-    const double *r0 = ta.coeff + ((size_t)v * S + i0) * 28 + cb, *r1 = ta.coeff + ((size_t)v * S + i1) * 28 + cb;
-    double ca[8], cn[8];
+    const double t = te.tv + ta.toff;
+    const bool past = t >= te.tend;                                   // base_pt_publisher.py:93-94: hover at final_pt after the end
+    // (the same tests as seg_locate's: segment 0 also serves times in front of time_cum[0]; a NaN bound -- the empty cache -- fails both)
+    const bool in0 = (te.i0 == 0.0 || !(te.lo0 > t)) && te.hi0 > t, in1 = !in0 && !(te.lo1 > t) && te.hi1 > t;
+    int idx = (int)(in0 ? te.i0 : te.i1);
+    double tcs = in0 ? te.lo0 : te.lo1, tsg = in0 ? te.ts0 : te.ts1;
+    // (opaque to the optimiser: left visible as "a loaded value or, on the slow path, another load", it parks the cached values in
+    // scratch memory to select between ADDRESSES and load through a flat pointer)
+    asm volatile("" : "+v"(tcs), "+v"(tsg));
+    double ca[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { ca[i] = r0[c >= 12 ? (i & 3) : i]; cn[i] = r1[c >= 12 ? (i & 3) : i]; }
-    const double fp = ta.fpt[(size_t)v * 3 + (c < 3 ? c : 0)];
-    const double t = tv + ta.toff;
-    const bool past = t >= tce;                                       // base_pt_publisher.py:93-94: hover at final_pt after the end
-    const bool in0 = (i0 == 0 || !(tc0 > t)) && tc1 > t, in1 = !in0 && i1 != i0 && !(tc1 > t) && tc2 > t;
-    int idx = in0 ? i0 : i1;
-    double tcs = in0 ? tc0 : tc1, tsg = in0 ? ts0 : ts1;
-    if (in1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ca[i] = cn[i];
-    }
+    for (int i = 0; i < 8; ++i) ca[i] = in1 ? te.cn[i] : te.ca[i];
     if (!past && !in0 && !in1) {                                      // (rare; per lane)
+        const int cb = chain_base(c);
         idx = seg_locate(S, tc, t, -1);
         tcs = tc[idx]; tsg = ta.tseg[(size_t)v * S + idx];
         const double *r = ta.coeff + ((size_t)v * S + idx) * 28 + cb;
@@ -1594,7 +1607,7 @@ __device__ __forceinline__ void tick_new_point(const TickArgs &ta, const TickEar
     }
     double val = 0.0;
     if (past) {
-        if (c < 3) val = fp;
+        if (c < 3) val = te.fp;
     } else {
         const double its = rcp_n(tsg);
         double s;
@@ -1603,7 +1616,17 @@ __device__ __forceinline__ void tick_new_point(const TickArgs &ta, const TickEar
             s = (t - tcs) * its;
         }
         val = traj_chain(ca, c, s, its);
-        if (lane == 0) ta.seg_hint[inst] = idx;          // (a vehicle's hint is written by its own wave only)
+    }
+    // the ego's cache: re-filled by this wave when its point did not come out of slot 0 (lane 0 belongs to the ego's group)
+    refill = __builtin_amdgcn_readlane((!past && !in0) ? 1 : 0, 0);
+    double fill = 0.0;
+    if (refill) {
+        const int ie = __builtin_amdgcn_readlane(idx, 0);
+        const int sl = lane >> 5, f = lane & 31, i = ie + sl < S ? ie + sl : S - 1;
+        const double *tce = ta.tcum + (size_t)inst * (S + 1);
+        fill = f == 0 ? tce[i] : (f == 1 ? tce[i + 1] : (f == 2 ? ta.tseg[(size_t)inst * S + i] : (f == 3 ? (double)i
+                 : ta.coeff[((size_t)inst * S + i) * 28 + (f - 4)])));
+        if (ie + sl >= S && f == 1) fill = -1.0e300;                  // no segment behind the last one: slot 1 never matches (hi <= any t)
     }
     double pvaj[12];
 #pragma unroll
@@ -1624,6 +1647,12 @@ __device__ __forceinline__ void tick_new_point(const TickArgs &ta, const TickEar
         d[0] = e;
         d[(size_t)ta.rg.np1 * (lane < 10 ? 10 : 4)] = e;
     }
+    return fill;
+}
+
+__device__ __forceinline__ void tick_cache_store(const TickArgs &ta, int inst, int lane, int refill, double fill)
+{
+    if (refill) ta.segc[(size_t)inst * SEGC_PER + lane] = fill;
 }
 
 // hover_throttle_callback (nmpc_node.py:251-253) of this vehicle, by lane 0; returns k_throttle to every lane
@@ -1871,7 +1900,7 @@ struct ndp_handle {
     int *dTables = nullptr;    // per-lane index tables of the Riccati sweep (fill_tables)
     double *dThr = nullptr;    // hover-throttle estimator state, SoA [8][B]
     double *dStamps = nullptr; // [B][16] whole-batch phase stamps (ndp_debug_stamps)
-    double *dTraj = nullptr;   // f1: [B][n_seg][28] coeff | [B][n_seg+1] time_cum | [B][n_seg] time_seg | [B][3] final_pt | int[B] segment hints
+    double *dTraj = nullptr;   // f1: [B][n_seg][28] coeff | [B][n_seg+1] time_cum | [B][n_seg] time_seg | [B][3] final_pt | [B][64] segment cache | int[B] segment hints
     int traj_seg = 0;
     double *dRingX = nullptr, *dRingU = nullptr;   // f1: the reference's sliding list of reference points, phase-major (RingGeom), one allocation (first use)
     unsigned long long list_n = 0;                 // absolute index of the list's oldest entry = control ticks since the list was built
@@ -3355,9 +3384,11 @@ int ndp_ref_set_trajectory(ndp_handle *h, int n_seg, const double *coeff_x, cons
     int rc = wait_all(h);
     if (rc) return rc;
     if (h->dTraj) { (void)hipFree(h->dTraj); h->dTraj = nullptr; }
-    NDP_HIP(h, hipMalloc((void **)&h->dTraj, total * 8 + B * 4));                   // (+ the segment hints, int[B], see ref_point)
+    // (+ the one-launch tick's segment cache, [B][64] doubles, empty = NaNs: tick_early; + the segment hints, int[B]: ref_point)
+    NDP_HIP(h, hipMalloc((void **)&h->dTraj, total * 8 + B * 64 * 8 + B * 4));
     NDP_HIP(h, hipMemcpy(h->dTraj, host.data(), total * 8, hipMemcpyHostToDevice));
-    NDP_HIP(h, hipMemset(h->dTraj + total, 0, B * 4));
+    NDP_HIP(h, hipMemset(h->dTraj + total, 0xFF, B * 64 * 8));
+    NDP_HIP(h, hipMemset(h->dTraj + total + B * 64, 0, B * 4));
     h->traj_seg = n_seg;
     return 0;
 }
@@ -3603,7 +3634,7 @@ static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, bool
         if (adv) {
             const size_t Bs = (size_t)B, S = (size_t)h->traj_seg;
             ta.coeff = h->dTraj; ta.tcum = ta.coeff + Bs * S * 28; ta.tseg = ta.tcum + Bs * (S + 1); ta.fpt = ta.tseg + Bs * S;
-            ta.seg_hint = reinterpret_cast<int *>(const_cast<double *>(ta.fpt + Bs * 3));
+            ta.segc = const_cast<double *>(ta.fpt + Bs * 3);
             ta.n_seg = h->traj_seg;
         }
         ta.t = t; ta.t_all = t_all; ta.advance = adv ? 1 : 0;
@@ -3622,7 +3653,7 @@ static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, bool
         if (adv) {
             const size_t Bs = (size_t)B, S = (size_t)h->traj_seg;
             a.coeff = h->dTraj; a.tcum = a.coeff + Bs * S * 28; a.tseg = a.tcum + Bs * (S + 1); a.fpt = a.tseg + Bs * S;
-            a.seg_hint = reinterpret_cast<int *>(const_cast<double *>(a.fpt + Bs * 3));
+            a.seg_hint = reinterpret_cast<int *>(const_cast<double *>(a.fpt + Bs * 3 + Bs * 64));
         }
         a.t = t; a.t_all = t_all; a.advance = adv ? 1 : 0;
         a.j_new = h->list_n + (unsigned long long)rg.ring();
