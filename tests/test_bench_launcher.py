@@ -89,3 +89,37 @@ def test_world_size_mismatch_is_still_refused(monkeypatch):
     env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_launcher_refuses_under_a_profiler_preload(stub, monkeypatch):
+    """rocprofv3's preloaded library initialises the GPU in the parent: starting ranks from there is an exec chain out of a
+    GPU-initialised process (ADVICE r4).  Refused with a message and a non-zero code; nothing is launched."""
+    _env_without_dist(monkeypatch)
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    out, err = io.StringIO(), io.StringIO()
+    assert bench.launch_ranks(2, stub, ["--gpus", "2"], out=out, err=err) == 6
+    assert out.getvalue() == "" and "profiler preload" in err.getvalue() and "launching" not in err.getvalue()
+
+
+def test_the_line_is_compacted_and_the_legend_covers_its_blocks():
+    line = {"value": 47190568.11407378, "ms_per_step": 0.02169925137422979, "n": 3, "ok": True, "none": None, "nan": float("nan"),
+            "nested": {"a": [1.23456789e-7, 2, "text"], "b": (0.1 + 0.2,)}}
+    c = bench.compact(line)
+    assert c["value"] == 47191000.0 and c["ms_per_step"] == 0.021699 and c["n"] == 3 and c["ok"] is True and c["none"] is None
+    assert c["nan"] != c["nan"] and c["nested"]["a"] == [1.2346e-07, 2, "text"] and c["nested"]["b"] == [0.3]
+    assert len(json.dumps(c, separators=(",", ":"))) < len(json.dumps(line))
+    for block in ("roofline", "forms", "scaling_baseline", "configs", "ipm_always", "mixed", "host", "tick", "cpu_baseline", "config1", "rows"):
+        assert block in bench.LEGEND and len(bench.LEGEND[block]) > 40
+
+
+def test_the_committed_line_fits_the_drivers_record():
+    """VERDICT r4 weak #5: the driver keeps the tail of stdout (~8 KB); the line must come through whole."""
+    tag = bench.committed_profile(True)["tag"]
+    with open(os.path.join(ROOT, "profiles", f"{tag}_bench_b1024_fused.json")) as fh:
+        raw = fh.read().strip()
+    assert len(raw) <= 6144, len(raw)
+    d = json.loads(raw)
+    for block in ("roofline", "cpu_baseline", "tick", "rows", "config1", "configs", "host", "mixed", "ipm_always", "scaling_baseline"):
+        assert block in d, block
+    assert d["tick"]["launches_per_tick"] == 1 and d["tick"]["parity"] <= 1e-5 and d["tick"]["value_host_inclusive_x0_only"] > 3.0e7
+    assert list(d).index("configs") < list(d).index("mixed")
