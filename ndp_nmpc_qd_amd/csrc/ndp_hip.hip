@@ -233,8 +233,8 @@ struct TickArgs {
 // vehicle's two cached segment records (see tick_early)
 struct TickEarly { double tv, lo0, hi0, ts0, i0, lo1, hi1, ts1, i1, tend, fp, ca[8], cn[8]; int v; };
 __device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, int orow, int lane);
-__device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, double xv[10], double uv[4],
-                                                 double nbv[6], int &refill);
+__device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, bool store, double xv[10],
+                                                 double uv[4], double nbv[6], int &refill);
 __device__ __forceinline__ void tick_cache_store(const TickArgs &ta, int inst, int lane, int refill, double fill);
 __device__ __forceinline__ double tick_estimator(const TickArgs &ta, int inst, int B, int lane);
 
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     double x_new[10], u_new[4], nb_new[6], seg_fill = 0.0;
     int seg_refill = 0;
     if (TICK && !(FUSED && wg_nb) && advance) {      // (fused with neighbours: made below, under the weight transfer)
-        seg_fill = tick_new_point(ka.ta, te, inst, (int)(threadIdx.x & 63u), x_new, u_new, nb_new, seg_refill);
+        seg_fill = tick_new_point(ka.ta, te, inst, (int)(threadIdx.x & 63u), active, x_new, u_new, nb_new, seg_refill);
 #pragma unroll
         for (int i = 0; i < 10; ++i) io.xrN[i] = x_new[i];
         io.have_xrN = 1;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         lds_f32 wl = (lds_f32)smem;
         stage_fragments(ma.frag, wl, (int)threadIdx.x, 64 * WAVES);
         if (TICK && advance) {                    // the polynomial work runs while the weights stream into LDS
-            seg_fill = tick_new_point(ka.ta, te, inst, lane, x_new, u_new, nb_new, seg_refill);
+            seg_fill = tick_new_point(ka.ta, te, inst, lane, active, x_new, u_new, nb_new, seg_refill);
 #pragma unroll
             for (int i = 0; i < 10; ++i) io.xrN[i] = x_new[i];
             io.have_xrN = 1;
@@ -1578,8 +1578,9 @@ __device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, in
 }
 
 // returns (in every lane) the value lane l must store into the ego's cache word l behind the MLP phase, valid if refill != 0
-__device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, double xv[10], double uv[4],
-                                                 double nbv[6], int &refill)
+// store: false in the idle waves of a ragged last workgroup (they shadow the last instance for the barriers' sake and must not write)
+__device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, bool store, double xv[10],
+                                                 double uv[4], double nbv[6], int &refill)
 {
     const int c = (lane & 15) < 14 ? (lane & 15) : 13;
     const int v = te.v;
@@ -1641,7 +1642,7 @@ __device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickE
     for (int i = 2; i >= 0; --i) e = lane == 10 + i ? uv[i] : e;
 #pragma unroll
     for (int i = 9; i >= 0; --i) e = lane == i ? xv[i] : e;
-    if (lane < 14) {
+    if (store && lane < 14) {
         const size_t sl = ta.rg.slot(ta.j_new);
         double *d = lane < 10 ? ta.rx + (size_t)inst * ta.rg.px() + sl * 10 + lane : ta.ru + (size_t)inst * ta.rg.pu() + sl * 4 + (lane - 10);
         d[0] = e;

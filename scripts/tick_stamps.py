@@ -21,7 +21,8 @@ def report(title, t):
     clk = np.median((t[:, 15] - t[:, 14]) / np.maximum(1.0, t[:, 13] - t[:, 12])) * 100e6
     print(f"{title}: median cycles per phase (shader clock {clk / 1e9:.2f} GHz); whole wave {np.median(t[:, 15] - t[:, 14]):.0f} cycles = "
           f"{np.median(t[:, 15] - t[:, 14]) / clk * 1e6:.2f} us, slowest wave {np.max(t[:, 15] - t[:, 14]) / clk * 1e6:.2f} us")
-    print("   " + " | ".join(f"{LABEL[b]} {np.median(t[:, b] - t[:, a]):.0f}" for a, b in zip(ids[:-1], ids[1:])))
+    print(f"   entry -> first stamp {np.median(t[:, ids[0]] - t[:, 14]):.0f} | " + " | ".join(f"{LABEL[b]} {np.median(t[:, b] - t[:, a]):.0f}" for a, b in zip(ids[:-1], ids[1:]))
+          + f" | last stamp -> exit {np.median(t[:, 15] - t[:, 8]):.0f}")
 
 
 def main():
