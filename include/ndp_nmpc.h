@@ -42,7 +42,7 @@ extern "C" {
 /* Version of this interface: bumped whenever an exported signature or the layout of ndp_cfg changes.  A binding built against
  * another header must refuse to run: ndp_abi_version() is what the loaded library was built with, ndp_cfg_size() its
  * sizeof(ndp_cfg) (ndp_create / ndp_default_cfg read and write that many bytes of the caller's struct). */
-#define NDP_ABI_VERSION 5
+#define NDP_ABI_VERSION 6
 int ndp_abi_version(void);
 size_t ndp_cfg_size(void);
 
@@ -451,7 +451,8 @@ int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, doub
  * d[256..319] = the four-lane row sum of a[0] (lanes 4 apart inside each 16-lane row). */
 int ndp_debug_mfma_probe_f32(const float *a, const float *b, const float *c, float *d, int mode);
 /* Profiling hook: enable = 1 makes every instance of the following steps write 16 phase stamps (shader clock);
- * out (or NULL) receives the [B][16] stamps of the last step before the switch is applied. */
+ * out (or NULL) receives the [B][24] stamps of the last step before the switch is applied (0-8: the wave program's phases, 9-15: the
+ * kernel's -- downwash tile, entry / exit clocks --, 16-21: the one-launch tick's prologue). */
 int ndp_debug_stamps(ndp_handle *h, int enable, double *out);
 /* Measurement hook: ndp_downwash_device through the LDS-free form of the downwash kernel (weights streamed from L2, at most 192
  * registers per lane: it can be resident on a CU beside the control-step kernel). */

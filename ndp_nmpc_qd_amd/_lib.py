@@ -16,7 +16,7 @@ WEIGHTS_PATH = os.path.join(_HERE, "weights", "downwash_sn4.bin")
 NX, NU = 10, 4
 MLP_NPARAM = 17859
 QP_AUTO, QP_IPM_ALWAYS = 0, 1
-ABI_VERSION = 5          # include/ndp_nmpc.h: NDP_ABI_VERSION (checked against the loaded library in load())
+ABI_VERSION = 6          # include/ndp_nmpc.h: NDP_ABI_VERSION (checked against the loaded library in load())
 TICK_ESTIMATE, TICK_WANT_U0, TICK_T_UNIFORM = 1, 2, 4
 
 

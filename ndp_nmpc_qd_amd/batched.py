@@ -506,8 +506,8 @@ class BatchedNMPC:
         self._check(self._lib.ndp_synchronize(self._h), "ndp_synchronize")
 
     def debug_stamps(self, enable=True, read=False):
-        """Whole-batch phase stamps (profiling hook): returns [B,16] of the last step when read=True."""
-        out = np.zeros((self.B, 16)) if read else None
+        """Whole-batch phase stamps (profiling hook): returns [B,24] of the last step when read=True."""
+        out = np.zeros((self.B, 24)) if read else None
         self._check(self._lib.ndp_debug_stamps(self._h, int(bool(enable)), _lib.ptr(out)), "ndp_debug_stamps")
         return out
 

@@ -63,7 +63,7 @@ struct BatchPtrs {
     int *status, *iters;
     double *Xm, *Um;        // mirror of the new iterate ([B][N+1][10] | [B][N][4], page-locked host memory) or null
     double *dbg;
-    double *stamps;         // [B][16] phase stamps of every instance (ndp_debug_stamps), or null
+    double *stamps;         // [B][NDP_NSTAMP] phase stamps of every instance (ndp_debug_stamps), or null
     size_t xr_pitch, ur_pitch;   // doubles from one instance's reference window to the next: (N+1) 10 / 4 N for dense [B][N+1][10] / [B][N][4]
                                  // arrays; RingGeom::px / pu when the windows are read straight out of the reference list (ndp_tick)
     size_t x0_pitch;             // doubles from one instance's x0 to the next (10)
@@ -157,7 +157,7 @@ __device__ __forceinline__ void bind_instance(RtiIo &io, const BatchPtrs &bp, in
     io.f_in_lds = 0;
     io.kc = bp.kc;
     io.tables = bp.tables;
-    io.stamps = bp.stamps ? bp.stamps + (size_t)inst * 16 : nullptr;
+    io.stamps = bp.stamps ? bp.stamps + (size_t)inst * NDP_NSTAMP : nullptr;
     if (NDP_RARELY(bp.cmd != nullptr)) {
         io.cmd = bp.cmd + (size_t)inst * NU;
         io.thrust_keep = bp.thrust_keep + inst;
@@ -211,6 +211,7 @@ struct RingGeom {
 // N of this tick's window, and the hover-throttle estimator's update -- done by the control step's own wave in front of its work, so
 // that a control tick is a single dispatch.  (As a launch of its own that part cost 7-8.5 us + a 4.5 us gap per tick in the kernel
 // trace against 24.8 us for the control step: a third of the tick for 112 bytes per vehicle.)
+enum { SEGC_SLOT = 32, SEGC_PER = 72 };      // doubles per slot / per vehicle of the tick's segment cache (tick_early)
 struct TickArgs {
     const double *coeff, *tcum, *tseg, *fpt;   // the trajectories (ndp_ref_set_trajectory)
     double *segc;                              // [B][64] the vehicles' current / next segment records (see tick_early)
@@ -234,7 +235,7 @@ struct TickArgs {
 struct TickEarly { double tv, lo0, hi0, ts0, i0, lo1, hi1, ts1, i1, tend, fp, ca[8], cn[8]; int v; };
 __device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, int orow, int lane);
 __device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, bool store, double xv[10],
-                                                 double uv[4], double nbv[6], int &refill);
+                                                 double uv[4], double nbv[6], int &refill, double *stamps);
 __device__ __forceinline__ void tick_cache_store(const TickArgs &ta, int inst, int lane, int refill, double fill);
 __device__ __forceinline__ double tick_estimator(const TickArgs &ta, int inst, int B, int lane);
 
@@ -264,6 +265,18 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     static_assert(!(FUSED && QMODE == 2), "the consumer reads the force the producer left in global memory");
     static_assert(!TICK || (QMODE <= 1 && NC > 0 && PREC == 0), "the one-launch tick exists for the compile-time horizon's in-place and producer forms");
     extern __shared__ __attribute__((aligned(16))) double smem[];
+#ifndef NDP_NO_KERNARG_WARM
+    {   // The argument block is ~1.2 KB = 19 scalar-cache lines, and the compiler fetches each field next to its first use, waiting for it
+        // there: every first touch of a line is a memory round trip of its own, one behind the other through the whole prologue.
+        // One dword of every line, requested together at the very top: one round trip, the later fetches hit the scalar cache.
+        typedef const __attribute__((address_space(4))) unsigned *kptr;
+        kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+        unsigned acc = 0;
+#pragma unroll
+        for (unsigned o = 0; o < (unsigned)sizeof(KernArgs); o += 64) acc |= kp[o / 4];
+        asm volatile("" : : "s"(acc));
+    }
+#endif
     const RtiParams &P = ka.P;
     const BatchPtrs &bp = ka.bp;
     const MlpArgs &ma = ka.ma;
@@ -344,6 +357,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     }
     const bool advance = TICK && ka.ta.advance != 0;
     TickEarly te{};
+    if (TICK && NDP_RARELY(io.stamps && (threadIdx.x & 63u) == 0)) io.stamps[16] = (double)__builtin_amdgcn_s_memtime();   // neighbour index known
     if (TICK && advance) {
         te = tick_early(ka.ta, inst, FUSED && wg_nb ? orow : -1, (int)(threadIdx.x & 63u));
         __builtin_amdgcn_sched_barrier(0);   // (these two loads lead the wave's in-order load queue)
@@ -358,7 +372,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     double x_new[10], u_new[4], nb_new[6], seg_fill = 0.0;
     int seg_refill = 0;
     if (TICK && !(FUSED && wg_nb) && advance) {      // (fused with neighbours: made below, under the weight transfer)
-        seg_fill = tick_new_point(ka.ta, te, inst, (int)(threadIdx.x & 63u), active, x_new, u_new, nb_new, seg_refill);
+        seg_fill = tick_new_point(ka.ta, te, inst, (int)(threadIdx.x & 63u), active, x_new, u_new, nb_new, seg_refill, io.stamps);
 #pragma unroll
         for (int i = 0; i < 10; ++i) io.xrN[i] = x_new[i];
         io.have_xrN = 1;
@@ -411,7 +425,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         lds_f32 wl = (lds_f32)smem;
         stage_fragments(ma.frag, wl, (int)threadIdx.x, 64 * WAVES);
         if (TICK && advance) {                    // the polynomial work runs while the weights stream into LDS
-            seg_fill = tick_new_point(ka.ta, te, inst, lane, active, x_new, u_new, nb_new, seg_refill);
+            seg_fill = tick_new_point(ka.ta, te, inst, lane, active, x_new, u_new, nb_new, seg_refill, io.stamps);
 #pragma unroll
             for (int i = 0; i < 10; ++i) io.xrN[i] = x_new[i];
             io.have_xrN = 1;
@@ -1446,7 +1460,7 @@ __global__ __launch_bounds__(256) void ref_list_fill_kernel(RefCfg cf, const dou
     const int b = id / npts, i = id - b * npts;
     double xv[10], uv[4];
     // one point per vehicle = the per-tick advance: the segment hint applies (it lives behind final_pt, see ndp_ref_set_trajectory)
-    int *hint = npts == 1 ? reinterpret_cast<int *>(const_cast<double *>(fpt + (size_t)cf.B * 3 + (size_t)cf.B * 64)) : nullptr;
+    int *hint = npts == 1 ? reinterpret_cast<int *>(const_cast<double *>(fpt + (size_t)cf.B * 3 + (size_t)cf.B * SEGC_PER)) : nullptr;
     ref_point(cf, coeff, tcum, tseg, fpt, b, (tq ? tq[b] : 0.0) + cf.toff + i * tstep, xv, uv, hint);
     ring_store(rg, rx, ru, b, j0 + (unsigned long long)i, xv, uv);
     if (dup0 && i == 0) ring_store(rg, rx, ru, b, j0 - 1, xv, uv);
@@ -1559,7 +1573,6 @@ __device__ __forceinline__ double uniform_lane(double v, int l)
 // both slots -- one load per lane, requested in the prologue, stored behind the MLP phase (tick_cache_store), off everybody's
 // critical path.  Anything else (the first tick after ndp_ref_set_trajectory -- the cache starts as NaNs --, a jump in time) takes
 // seg_locate and the trajectory arrays, and re-fills the cache the same way.
-enum { SEGC_SLOT = 32, SEGC_PER = 64 };
 __device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, int orow, int lane)
 {
     TickEarly te;
@@ -1570,8 +1583,8 @@ __device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, in
     te.lo1 = s1[0]; te.hi1 = s1[1]; te.ts1 = s1[2]; te.i1 = s1[3];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { te.ca[i] = s0[4 + cb + (c >= 12 ? (i & 3) : i)]; te.cn[i] = s1[4 + cb + (c >= 12 ? (i & 3) : i)]; }
-    te.tend = ta.tcum[(size_t)te.v * (ta.n_seg + 1) + ta.n_seg];
-    te.fp = ta.fpt[(size_t)te.v * 3 + (c < 3 ? c : 0)];
+    te.tend = s0[64];
+    te.fp = s0[65 + (c < 3 ? c : 0)];
     te.tv = ta.t_all;                      // (written as a branch: as a select the compiler picks between two ADDRESSES -- the argument's
     if (ta.t) te.tv = ta.t[te.v];          // copy parked in scratch memory for it -- and loads through a flat pointer)
     return te;
@@ -1580,35 +1593,52 @@ __device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, in
 // returns (in every lane) the value lane l must store into the ego's cache word l behind the MLP phase, valid if refill != 0
 // store: false in the idle waves of a ragged last workgroup (they shadow the last instance for the barriers' sake and must not write)
 __device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, bool store, double xv[10],
-                                                 double uv[4], double nbv[6], int &refill)
+                                                 double uv[4], double nbv[6], int &refill, double *stamps)
 {
+    // profiling hook (ndp_debug_stamps): slots 17.. = the prologue's own timeline; each stamp waits for the value it names
+    auto stamp_after = [&](int idx, double dep) {
+        if (NDP_RARELY(stamps != nullptr)) {
+            unsigned long long tk;
+            asm volatile("s_nop 0\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk) : "v"(dep) : "memory");
+            if (lane == 0) stamps[idx] = (double)tk;
+        }
+    };
     const int c = (lane & 15) < 14 ? (lane & 15) : 13;
     const int v = te.v;
     const int S = ta.n_seg;
     const double *tc = ta.tcum + (size_t)v * (S + 1);
+    stamp_after(17, te.lo0 + te.cn[7] + te.fp);                       // the cached records are there
     const double t = te.tv + ta.toff;
-    const bool past = t >= te.tend;                                   // base_pt_publisher.py:93-94: hover at final_pt after the end
-    // (the same tests as seg_locate's: segment 0 also serves times in front of time_cum[0]; a NaN bound -- the empty cache -- fails both)
+    stamp_after(18, t);                                               // the time is there
+    bool past = t >= te.tend;                                         // base_pt_publisher.py:93-94: hover at final_pt after the end
+    // (the same tests as seg_locate's: segment 0 also serves times in front of time_cum[0]; a NaN bound -- the empty cache -- fails all three)
     const bool in0 = (te.i0 == 0.0 || !(te.lo0 > t)) && te.hi0 > t, in1 = !in0 && !(te.lo1 > t) && te.hi1 > t;
+    const bool slow = !past && !in0 && !in1;
     int idx = (int)(in0 ? te.i0 : te.i1);
-    double tcs = in0 ? te.lo0 : te.lo1, tsg = in0 ? te.ts0 : te.ts1;
+    double tcs = in0 ? te.lo0 : te.lo1, tsg = in0 ? te.ts0 : te.ts1, fp = te.fp;
     // (opaque to the optimiser: left visible as "a loaded value or, on the slow path, another load", it parks the cached values in
     // scratch memory to select between ADDRESSES and load through a flat pointer)
-    asm volatile("" : "+v"(tcs), "+v"(tsg));
+    asm volatile("" : "+v"(tcs), "+v"(tsg), "+v"(fp));
     double ca[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) ca[i] = in1 ? te.cn[i] : te.ca[i];
-    if (!past && !in0 && !in1) {                                      // (rare; per lane)
+    if (slow) {                                                       // (rare; per lane) through the trajectory arrays
         const int cb = chain_base(c);
         idx = seg_locate(S, tc, t, -1);
-        tcs = tc[idx]; tsg = ta.tseg[(size_t)v * S + idx];
-        const double *r = ta.coeff + ((size_t)v * S + idx) * 28 + cb;
+        if (idx < 0) {                                                // (an empty cache does not know where the trajectory ends)
+            past = true;
+            idx = S - 1;
+            fp = ta.fpt[(size_t)v * 3 + (c < 3 ? c : 0)];
+        } else {
+            tcs = tc[idx]; tsg = ta.tseg[(size_t)v * S + idx];
+            const double *r = ta.coeff + ((size_t)v * S + idx) * 28 + cb;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ca[i] = r[c >= 12 ? (i & 3) : i];
+            for (int i = 0; i < 8; ++i) ca[i] = r[c >= 12 ? (i & 3) : i];
+        }
     }
     double val = 0.0;
     if (past) {
-        if (c < 3) val = te.fp;
+        if (c < 3) val = fp;
     } else {
         const double its = rcp_n(tsg);
         double s;
@@ -1619,29 +1649,38 @@ __device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickE
         val = traj_chain(ca, c, s, its);
     }
     // the ego's cache: re-filled by this wave when its point did not come out of slot 0 (lane 0 belongs to the ego's group)
-    refill = __builtin_amdgcn_readlane((!past && !in0) ? 1 : 0, 0);
+    refill = __builtin_amdgcn_readlane((in1 || slow) ? 1 : 0, 0);
     double fill = 0.0;
     if (refill) {
         const int ie = __builtin_amdgcn_readlane(idx, 0);
         const int sl = lane >> 5, f = lane & 31, i = ie + sl < S ? ie + sl : S - 1;
         const double *tce = ta.tcum + (size_t)inst * (S + 1);
+        if (lane < 4) ta.segc[(size_t)inst * SEGC_PER + 64 + lane] = lane == 0 ? tce[S] : ta.fpt[(size_t)inst * 3 + lane - 1];   // (constants of the trajectory)
         fill = f == 0 ? tce[i] : (f == 1 ? tce[i + 1] : (f == 2 ? ta.tseg[(size_t)inst * S + i] : (f == 3 ? (double)i
                  : ta.coeff[((size_t)inst * S + i) * 28 + (f - 4)])));
         if (ie + sl >= S && f == 1) fill = -1.0e300;                  // no segment behind the last one: slot 1 never matches (hi <= any t)
     }
+    stamp_after(19, val);                                             // the lane's polynomial value
     double pvaj[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) pvaj[i] = uniform_lane(val, i);
     const double yaw = uniform_lane(val, 12), yawd = uniform_lane(val, 13);
 #pragma unroll
     for (int i = 0; i < 6; ++i) nbv[i] = uniform_lane(val, 16 + i);
+    stamp_after(20, pvaj[11] + nbv[5] + yawd);                        // collected over the lanes
     flatness_xu(ta.mass, ta.g, pvaj, yaw, yawd, xv, uv);
+    stamp_after(21, xv[9] + uv[0]);                                   // flatness map done
     // the entry, for the windows of the ticks to come: element l of x | u from lane l
-    double e = uv[3];
+    // (v_writelane of the uniform values: written as a chain of selects on the lane id the compiler builds a table in scratch memory)
+    int elo = 0, ehi = 0;
 #pragma unroll
-    for (int i = 2; i >= 0; --i) e = lane == 10 + i ? uv[i] : e;
-#pragma unroll
-    for (int i = 9; i >= 0; --i) e = lane == i ? xv[i] : e;
+    for (int i = 0; i < 14; ++i) {
+        const double w = i < 10 ? xv[i] : uv[i - 10];
+        const int wl = __builtin_amdgcn_readfirstlane(__double2loint(w)), wh = __builtin_amdgcn_readfirstlane(__double2hiint(w));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(elo) : "s"(wl), "n"(i));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(ehi) : "s"(wh), "n"(i));
+    }
+    const double e = __hiloint2double(ehi, elo);
     if (store && lane < 14) {
         const size_t sl = ta.rg.slot(ta.j_new);
         double *d = lane < 10 ? ta.rx + (size_t)inst * ta.rg.px() + sl * 10 + lane : ta.ru + (size_t)inst * ta.rg.pu() + sl * 4 + (lane - 10);
@@ -1900,7 +1939,7 @@ struct ndp_handle {
     double *dKC = nullptr;     // constants block of the LDS image (fill_kc)
     int *dTables = nullptr;    // per-lane index tables of the Riccati sweep (fill_tables)
     double *dThr = nullptr;    // hover-throttle estimator state, SoA [8][B]
-    double *dStamps = nullptr; // [B][16] whole-batch phase stamps (ndp_debug_stamps)
+    double *dStamps = nullptr; // [B][NDP_NSTAMP] whole-batch phase stamps (ndp_debug_stamps)
     double *dTraj = nullptr;   // f1: [B][n_seg][28] coeff | [B][n_seg+1] time_cum | [B][n_seg] time_seg | [B][3] final_pt | [B][64] segment cache | int[B] segment hints
     int traj_seg = 0;
     double *dRingX = nullptr, *dRingU = nullptr;   // f1: the reference's sliding list of reference points, phase-major (RingGeom), one allocation (first use)
@@ -3386,10 +3425,10 @@ int ndp_ref_set_trajectory(ndp_handle *h, int n_seg, const double *coeff_x, cons
     if (rc) return rc;
     if (h->dTraj) { (void)hipFree(h->dTraj); h->dTraj = nullptr; }
     // (+ the one-launch tick's segment cache, [B][64] doubles, empty = NaNs: tick_early; + the segment hints, int[B]: ref_point)
-    NDP_HIP(h, hipMalloc((void **)&h->dTraj, total * 8 + B * 64 * 8 + B * 4));
+    NDP_HIP(h, hipMalloc((void **)&h->dTraj, total * 8 + B * SEGC_PER * 8 + B * 4));
     NDP_HIP(h, hipMemcpy(h->dTraj, host.data(), total * 8, hipMemcpyHostToDevice));
-    NDP_HIP(h, hipMemset(h->dTraj + total, 0xFF, B * 64 * 8));
-    NDP_HIP(h, hipMemset(h->dTraj + total + B * 64, 0, B * 4));
+    NDP_HIP(h, hipMemset(h->dTraj + total, 0xFF, B * SEGC_PER * 8));
+    NDP_HIP(h, hipMemset(h->dTraj + total + B * SEGC_PER, 0, B * 4));
     h->traj_seg = n_seg;
     return 0;
 }
@@ -3654,7 +3693,7 @@ static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, bool
         if (adv) {
             const size_t Bs = (size_t)B, S = (size_t)h->traj_seg;
             a.coeff = h->dTraj; a.tcum = a.coeff + Bs * S * 28; a.tseg = a.tcum + Bs * (S + 1); a.fpt = a.tseg + Bs * S;
-            a.seg_hint = reinterpret_cast<int *>(const_cast<double *>(a.fpt + Bs * 3 + Bs * 64));
+            a.seg_hint = reinterpret_cast<int *>(const_cast<double *>(a.fpt + Bs * 3 + Bs * SEGC_PER));
         }
         a.t = t; a.t_all = t_all; a.advance = adv ? 1 : 0;
         a.j_new = h->list_n + (unsigned long long)rg.ring();
@@ -3845,7 +3884,7 @@ int ndp_rollout_device(ndp_handle *h, int ticks, double t0, double dt_tick, int 
     return note_stream(h, s);
 }
 
-// test/profiling hook: every instance writes its phase stamps (shader clock) to [B][16] doubles
+// test/profiling hook: every instance writes its phase stamps (shader clock) to [B][NDP_NSTAMP] doubles
 int ndp_debug_stamps(ndp_handle *h, int enable, double *out)
 {
     if (!h) return -1;
@@ -3853,7 +3892,7 @@ int ndp_debug_stamps(ndp_handle *h, int enable, double *out)
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     NDP_HIP(h, hipStreamSynchronize(h->stream));
     NDP_HIP(h, hipDeviceSynchronize());
-    const size_t bytes = (size_t)h->cfg.batch * 16 * 8;
+    const size_t bytes = (size_t)h->cfg.batch * NDP_NSTAMP * 8;
     if (out && h->dStamps) NDP_HIP(h, hipMemcpy(out, h->dStamps, bytes, hipMemcpyDeviceToHost));
     if (enable && !h->dStamps) {
         NDP_HIP(h, hipMalloc((void **)&h->dStamps, bytes));

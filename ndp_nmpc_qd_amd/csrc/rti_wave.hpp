@@ -92,6 +92,8 @@ NDP_HD void fill_quotients(RtiParams &p)
     p.inv2m = 1.0 / (2.0 * (7 * p.N - 3));
 }
 
+enum { NDP_NSTAMP = 24 };  // doubles per instance of the whole-batch phase stamps (ndp_debug_stamps): 0-8 the program's phases, 9-15 the kernel's, 16-23 the tick prologue's
+
 struct RtiIo {            // global-memory views of ONE instance
     const double *x0;     // [10]
     const double *xr;     // [(N+1)*10]

@@ -23,6 +23,10 @@ def report(title, t):
           f"{np.median(t[:, 15] - t[:, 14]) / clk * 1e6:.2f} us, slowest wave {np.max(t[:, 15] - t[:, 14]) / clk * 1e6:.2f} us")
     print(f"   entry -> first stamp {np.median(t[:, ids[0]] - t[:, 14]):.0f} | " + " | ".join(f"{LABEL[b]} {np.median(t[:, b] - t[:, a]):.0f}" for a, b in zip(ids[:-1], ids[1:]))
           + f" | last stamp -> exit {np.median(t[:, 15] - t[:, 8]):.0f}")
+    if t.shape[1] > 21 and np.median(t[:, 21]) > 0:          # the one-launch tick's prologue, since kernel entry (each stamp waits for its value)
+        names = ("neighbour index known", "cached segment records arrived", "time arrived", "polynomial value", "values collected (v_readlane)", "flatness map done")
+        print("   tick prologue since entry: " + " | ".join(f"{n} {np.median(t[:, 16 + i] - t[:, 14]):.0f}" for i, n in enumerate(names))
+              + f" | first phase stamp {np.median(t[:, 9] - t[:, 14]):.0f} | weights + barrier done {np.median(t[:, 11] - t[:, 14]):.0f}")
 
 
 def main():
