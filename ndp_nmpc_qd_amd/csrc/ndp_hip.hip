@@ -221,6 +221,7 @@ struct TickArgs {
     int advance;                               // 0: the list is not advanced in this tick
     double toff, mass, g;                      // T_horizon; flatness constants
     unsigned long long j_new;                  // absolute index of the list entry the new point becomes
+    size_t new_slot;                           // rg.slot(j_new), from the host (two 64-bit divisions otherwise, in front of the barrier)
     RingGeom rg;
     double *rx, *ru;
     ThrCfg thr;                                // estimator
@@ -232,10 +233,14 @@ struct TickArgs {
 };
 // what tick_new_point works on, all of it requested at the kernel's very top (tick_early): the time, and the lane's share of the
 // vehicle's two cached segment records (see tick_early)
-struct TickEarly { double tv, lo0, hi0, ts0, i0, lo1, hi1, ts1, i1, tend, fp, ca[8], cn[8]; int v; };
+typedef double tick_d2 __attribute__((ext_vector_type(2)));
+// h0 / h1: (time_cum[i], time_cum[i + 1]), (time_seg[i], i) of slot 0 / 1; ca / cn: the lane's 8 coefficients in slot 0 / 1; tf: (end of the
+// trajectory, the lane's component of final_pt)
+struct TickEarly { double tv; tick_d2 h0[2], h1[2], ca[4], cn[4], tf; int v; };
 __device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, int orow, int lane);
 __device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, bool store, double xv[10],
                                                  double uv[4], double nbv[6], int &refill, double *stamps);
+__device__ __forceinline__ void tick_arrived(TickEarly &te);
 __device__ __forceinline__ void tick_cache_store(const TickArgs &ta, int inst, int lane, int refill, double fill);
 __device__ __forceinline__ double tick_estimator(const TickArgs &ta, int inst, int B, int lane);
 
@@ -248,6 +253,31 @@ struct KernArgs {
     LateArgs la;
     TickArgs ta;            // read by the TICK instantiations only
 };
+
+// Arguments a kernel needs LATE (the tick's estimator constants, the list's geometry for the new entry's store, the trajectory arrays
+// of the rare slow path), fetched where they are used.  Read as ordinary members of `ka` the compiler requests every argument at the
+// kernel's top and keeps it in scalar registers until its use: the tick kernels ran out of them (160 spills to / 740 reloads from
+// vector-register lanes against 19 / 82 in the plain step -- with one wave per SIMD every one of those is time on the clock).  The
+// pointer goes through an empty asm so that the loads cannot move up; they hit the scalar cache (the block was touched at the top).
+struct KernargLate {
+    const __attribute__((address_space(4))) unsigned *kp;
+    __device__ __forceinline__ KernargLate()
+    {
+        kp = (const __attribute__((address_space(4))) unsigned *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+    }
+    template <class T> __device__ __forceinline__ T get(unsigned off) const
+    {
+        static_assert(sizeof(T) % 4 == 0 && std::is_trivially_copyable<T>::value, "plain words only");
+        unsigned w[sizeof(T) / 4];
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = kp[off / 4 + i];
+        T t;
+        __builtin_memcpy(&t, w, sizeof(T));
+        return t;
+    }
+};
+#define NDP_TA_LATE(L, f) ((L).template get<decltype(TickArgs::f)>((unsigned)(offsetof(KernArgs, ta) + offsetof(TickArgs, f))))
 
 // FUSED: the wave first predicts its own instance's disturbance force (gate + MLP over the N+1 <= 32 horizon rows,
 // one 32x32 f32 MFMA tile) and leaves it in the LDS staging slot the RTI program reads f from -- no second
@@ -356,22 +386,25 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         wg_nb = __builtin_amdgcn_readfirstlane(any) != 0;
     }
     const bool advance = TICK && ka.ta.advance != 0;
-    TickEarly te{};
+    TickEarly te;                            // (left as it is without `advance`: nothing looks at it then)
     if (TICK && NDP_RARELY(io.stamps && (threadIdx.x & 63u) == 0)) io.stamps[16] = (double)__builtin_amdgcn_s_memtime();   // neighbour index known
     if (TICK && advance) {
         te = tick_early(ka.ta, inst, FUSED && wg_nb ? orow : -1, (int)(threadIdx.x & 63u));
         __builtin_amdgcn_sched_barrier(0);   // (these two loads lead the wave's in-order load queue)
     }
+    if (TICK && NDP_RARELY(io.stamps && (threadIdx.x & 63u) == 0)) io.stamps[22] = (double)__builtin_amdgcn_s_memtime();   // cache loads issued
     typename Prog::InBuf inb;
     double x0v;
     Prog::issue_first(P, io, inb, x0v);      // every global input of the RTI step is now in flight (hidden under the MLP when fused)
     __builtin_amdgcn_sched_barrier(0);       // do not let the scheduler sink those loads behind the MLP
+    if (TICK && NDP_RARELY(io.stamps && (threadIdx.x & 63u) == 0)) io.stamps[23] = (double)__builtin_amdgcn_s_memtime();   // input loads issued
     // TICK: the newest list entry of this vehicle (x_new / u_new) and the position / velocity part of the neighbour's (nb_new).  Row N of
     // both windows is NOT read from the list in this launch (the neighbour's wave writes its entry while this one runs): the ego's goes
     // into the staged window through RtiIo::xrN, the pair into the network's input below.
     double x_new[10], u_new[4], nb_new[6], seg_fill = 0.0;
     int seg_refill = 0;
     if (TICK && !(FUSED && wg_nb) && advance) {      // (fused with neighbours: made below, under the weight transfer)
+        tick_arrived(te);
         seg_fill = tick_new_point(ka.ta, te, inst, (int)(threadIdx.x & 63u), active, x_new, u_new, nb_new, seg_refill, io.stamps);
 #pragma unroll
         for (int i = 0; i < 10; ++i) io.xrN[i] = x_new[i];
@@ -423,6 +456,8 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         if (NDP_RARELY(io.stamps && lane == 0)) io.stamps[9] = (double)__builtin_amdgcn_s_memtime();
         // the whole workgroup's LDS is still unused: park the weight fragments there for the MLP phase
         lds_f32 wl = (lds_f32)smem;
+        if (TICK) tick_arrived(te);               // (see there: the one wait of the prologue, in FRONT of the weight transfer; not under
+                                                  // `advance`: a path around it leaves the values pending in the compiler's books)
         stage_fragments(ma.frag, wl, (int)threadIdx.x, 64 * WAVES);
         if (TICK && advance) {                    // the polynomial work runs while the weights stream into LDS
             seg_fill = tick_new_point(ka.ta, te, inst, lane, active, x_new, u_new, nb_new, seg_refill, io.stamps);
@@ -561,7 +596,9 @@ typedef float f16_t __attribute__((ext_vector_type(16)));
 // The blob is moved by LDS-DMA in 1-KB pieces (one global_load_lds_dwordx4 per wave): its size is a multiple of 256 floats.
 enum { FR_L1 = 0, FR_B1 = FR_L1 + 12 * 64, FR_B2 = FR_B1 + 128, FR_B3 = FR_B2 + 64, FR_W4 = FR_B3 + 128,
        FR_B4 = FR_W4 + 4 * 128, FR_HF = FR_B4 + 4, FR_REC = 2 * 64 * 8 / 2 /* floats per record */,
-       FR_USED = FR_HF + 32 * FR_REC, FR_CHUNKS = (FR_USED + 255) / 256, FR_TOTAL = FR_CHUNKS * 256 };
+       FR_USED = FR_HF + 32 * FR_REC,
+       // (a multiple of 8 pieces: every wave of a 1- / 2- / 4- / 8-wave workgroup moves the SAME number of them -- see stage_fragments)
+       FR_CHUNKS = (FR_USED + 2047) / 2048 * 8, FR_TOTAL = FR_CHUNKS * 256 };
 static_assert(FR_HF % 4 == 0 && FR_W4 % 4 == 0, "16-byte alignment of the LDS image");
 
 __device__ __forceinline__ int f0(int r) { return (r & 3) + 8 * (r >> 2); }
@@ -579,12 +616,15 @@ __device__ __forceinline__ void stage_fragments(const float *__restrict__ fr, ld
 {
     // the wave index is uniform: keep the piece loop scalar (derived from threadIdx it would run under an exec mask), a
     // compile-time number of rounds with a uniform guard on the last one
+    // The number of pieces per wave must not depend on the wave: with a guarded last round the compiler cannot count the transfers
+    // in flight and makes the NEXT wait of the wave -- whatever it is for -- a wait for all of them (s_waitcnt vmcnt(0)); the one-launch
+    // tick's polynomial work, meant to run under the transfer, then started behind it (+2 600 cycles per tick).
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nthreads >> 6;
 #pragma unroll
     for (int i = 0; i < FR_CHUNKS; ++i) {
         if (i * nw >= FR_CHUNKS) break;
         const int c = wave + i * nw;
-        if (c < FR_CHUNKS)
+        if ((i + 1) * nw <= FR_CHUNKS || c < FR_CHUNKS)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fr + c * 256 + lane * 4),
                                              (__attribute__((address_space(3))) void *)(dst + c * 256), 16, 0, 0);
     }
@@ -1564,8 +1604,9 @@ __device__ __forceinline__ double uniform_lane(double v, int l)
     return __hiloint2double(hi, lo);
 }
 
-// A per-vehicle cache of the trajectory's CURRENT and NEXT segment records, 2 x 32 doubles at segc + 64 v:
+// A per-vehicle cache of the trajectory's CURRENT and NEXT segment records, 2 x 32 doubles at segc + SEGC_PER v:
 //     [0] time_cum[i]  [1] time_cum[i + 1]  [2] time_seg[i]  [3] i  [4 .. 31] the 28 coefficients of segment i
+// and behind them [64 + 2 a], [65 + 2 a] = (time_cum[n_seg], final_pt[a]) for the axes a = 0..2 (one 16-byte load per lane)
 // Found through the trajectory arrays a point costs two dependent memory round trips (segment index -> record), ~1 700 cycles
 // each and nothing in the wave to hide them under; the cache's address depends on the vehicle only, so its loads are the launch's
 // first and arrive under the weight transfer.  A vehicle moves on to its next segment every time_seg / 20 ms ticks (and in a batch
@@ -1576,18 +1617,38 @@ __device__ __forceinline__ double uniform_lane(double v, int l)
 __device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, int orow, int lane)
 {
     TickEarly te;
-    const int c = (lane & 15) < 14 ? (lane & 15) : 13, cb = chain_base(c);
+    const int c = (lane & 15) < 14 ? (lane & 15) : 13, q = (4 + chain_base(c)) >> 1;
     te.v = ((lane >> 4) & 1) && orow >= 0 ? orow : inst;
-    const double *s0 = ta.segc + (size_t)te.v * SEGC_PER, *s1 = s0 + SEGC_SLOT;
-    te.lo0 = s0[0]; te.hi0 = s0[1]; te.ts0 = s0[2]; te.i0 = s0[3];
-    te.lo1 = s1[0]; te.hi1 = s1[1]; te.ts1 = s1[2]; te.i1 = s1[3];
+    // The load unit takes 16 cycles per instruction and wave of 64 (four lanes a cycle, whatever the width), and the four waves of a
+    // compute unit share it: as 35 8-byte loads by all 64 lanes these requests alone kept it busy for 2 200 cycles.  Hence 16-byte
+    // loads (13 of them) and only the 24 lanes whose values are looked at (lanes 0..13 ego, 16..21 neighbour).
+    const tick_d2 *s0 = reinterpret_cast<const tick_d2 *>(ta.segc + (size_t)te.v * SEGC_PER);
+    te.tv = ta.t_all;
+    if (lane < 24) {
+        te.h0[0] = s0[0]; te.h0[1] = s0[1]; te.h1[0] = s0[SEGC_SLOT / 2]; te.h1[1] = s0[SEGC_SLOT / 2 + 1];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { te.ca[i] = s0[4 + cb + (c >= 12 ? (i & 3) : i)]; te.cn[i] = s1[4 + cb + (c >= 12 ? (i & 3) : i)]; }
-    te.tend = s0[64];
-    te.fp = s0[65 + (c < 3 ? c : 0)];
-    te.tv = ta.t_all;                      // (written as a branch: as a select the compiler picks between two ADDRESSES -- the argument's
-    if (ta.t) te.tv = ta.t[te.v];          // copy parked in scratch memory for it -- and loads through a flat pointer)
+        for (int k = 0; k < 4; ++k) {
+            const int o = q + (c >= 12 ? (k & 1) : k);
+            te.ca[k] = s0[o]; te.cn[k] = s0[SEGC_SLOT / 2 + o];
+        }
+        te.tf = s0[SEGC_SLOT + (c < 3 ? c : 0)];
+        // (written as a branch: as a select the compiler picks between two ADDRESSES -- the argument's copy parked in scratch memory
+        // for it -- and loads through a flat pointer)
+        if (ta.t) te.tv = ta.t[te.v];
+    }
     return te;
+}
+
+// Consume everything tick_early requested, HERE.  While an LDS-DMA transfer (global_load_lds) is in flight the compiler cannot use the
+// in-order load counter: the instruction counts as "may touch memory AND LDS", and from its issue to the next full drain every wait of
+// the wave -- for whatever value -- is emitted as s_waitcnt vmcnt(0), i.e. a wait for the whole 72-KB weight transfer.  Left to its
+// first use inside tick_new_point the cached records therefore "arrived" only when the transfer was complete (6 400 cycles after
+// entry; requested at 1 000) and the polynomial work ran BEHIND the transfer instead of under it.  Waiting for them in front of the
+// transfer costs the transfer a later start (the records' own latency) and takes the polynomial work off the critical path.
+__device__ __forceinline__ void tick_arrived(TickEarly &te)
+{
+    asm volatile("" : "+v"(te.tv), "+v"(te.h0[0]), "+v"(te.h0[1]), "+v"(te.h1[0]), "+v"(te.h1[1]), "+v"(te.tf));
+    asm volatile("" : "+v"(te.ca[0]), "+v"(te.ca[1]), "+v"(te.ca[2]), "+v"(te.ca[3]), "+v"(te.cn[0]), "+v"(te.cn[1]), "+v"(te.cn[2]), "+v"(te.cn[3]));
 }
 
 // returns (in every lane) the value lane l must store into the ego's cache word l behind the MLP phase, valid if refill != 0
@@ -1606,32 +1667,35 @@ __device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickE
     const int c = (lane & 15) < 14 ? (lane & 15) : 13;
     const int v = te.v;
     const int S = ta.n_seg;
-    const double *tc = ta.tcum + (size_t)v * (S + 1);
-    stamp_after(17, te.lo0 + te.cn[7] + te.fp);                       // the cached records are there
+    const double lo0 = te.h0[0][0], hi0 = te.h0[0][1], ts0 = te.h0[1][0], i0 = te.h0[1][1];
+    const double lo1 = te.h1[0][0], hi1 = te.h1[0][1], ts1 = te.h1[1][0], i1 = te.h1[1][1];
+    stamp_after(17, lo0 + te.cn[3][1] + te.tf[1]);                    // the cached records are there
     const double t = te.tv + ta.toff;
     stamp_after(18, t);                                               // the time is there
-    bool past = t >= te.tend;                                         // base_pt_publisher.py:93-94: hover at final_pt after the end
+    bool past = t >= te.tf[0];                                        // base_pt_publisher.py:93-94: hover at final_pt after the end
     // (the same tests as seg_locate's: segment 0 also serves times in front of time_cum[0]; a NaN bound -- the empty cache -- fails all three)
-    const bool in0 = (te.i0 == 0.0 || !(te.lo0 > t)) && te.hi0 > t, in1 = !in0 && !(te.lo1 > t) && te.hi1 > t;
-    const bool slow = !past && !in0 && !in1;
-    int idx = (int)(in0 ? te.i0 : te.i1);
-    double tcs = in0 ? te.lo0 : te.lo1, tsg = in0 ? te.ts0 : te.ts1, fp = te.fp;
+    const bool in0 = (i0 == 0.0 || !(lo0 > t)) && hi0 > t, in1 = !in0 && !(lo1 > t) && hi1 > t;
+    const bool slow = lane < 24 && !past && !in0 && !in1;            // (lanes 24..63 hold nothing: tick_early)
+    int idx = (int)(in0 ? i0 : i1);
+    double tcs = in0 ? lo0 : lo1, tsg = in0 ? ts0 : ts1, fp = te.tf[1];
     // (opaque to the optimiser: left visible as "a loaded value or, on the slow path, another load", it parks the cached values in
     // scratch memory to select between ADDRESSES and load through a flat pointer)
     asm volatile("" : "+v"(tcs), "+v"(tsg), "+v"(fp));
     double ca[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ca[i] = in1 ? te.cn[i] : te.ca[i];
+    for (int i = 0; i < 8; ++i) ca[i] = in1 ? te.cn[i >> 1][i & 1] : te.ca[i >> 1][i & 1];
     if (slow) {                                                       // (rare; per lane) through the trajectory arrays
+        const KernargLate L;
+        const double *tc = NDP_TA_LATE(L, tcum) + (size_t)v * (S + 1);
         const int cb = chain_base(c);
         idx = seg_locate(S, tc, t, -1);
         if (idx < 0) {                                                // (an empty cache does not know where the trajectory ends)
             past = true;
             idx = S - 1;
-            fp = ta.fpt[(size_t)v * 3 + (c < 3 ? c : 0)];
+            fp = NDP_TA_LATE(L, fpt)[(size_t)v * 3 + (c < 3 ? c : 0)];
         } else {
-            tcs = tc[idx]; tsg = ta.tseg[(size_t)v * S + idx];
-            const double *r = ta.coeff + ((size_t)v * S + idx) * 28 + cb;
+            tcs = tc[idx]; tsg = NDP_TA_LATE(L, tseg)[(size_t)v * S + idx];
+            const double *r = NDP_TA_LATE(L, coeff) + ((size_t)v * S + idx) * 28 + cb;
 #pragma unroll
             for (int i = 0; i < 8; ++i) ca[i] = r[c >= 12 ? (i & 3) : i];
         }
@@ -1654,10 +1718,11 @@ __device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickE
     if (refill) {
         const int ie = __builtin_amdgcn_readlane(idx, 0);
         const int sl = lane >> 5, f = lane & 31, i = ie + sl < S ? ie + sl : S - 1;
-        const double *tce = ta.tcum + (size_t)inst * (S + 1);
-        if (lane < 4) ta.segc[(size_t)inst * SEGC_PER + 64 + lane] = lane == 0 ? tce[S] : ta.fpt[(size_t)inst * 3 + lane - 1];   // (constants of the trajectory)
-        fill = f == 0 ? tce[i] : (f == 1 ? tce[i + 1] : (f == 2 ? ta.tseg[(size_t)inst * S + i] : (f == 3 ? (double)i
-                 : ta.coeff[((size_t)inst * S + i) * 28 + (f - 4)])));
+        const KernargLate L;
+        const double *tce = NDP_TA_LATE(L, tcum) + (size_t)inst * (S + 1), *fpt = NDP_TA_LATE(L, fpt);
+        if (lane < 6) ta.segc[(size_t)inst * SEGC_PER + 2 * SEGC_SLOT + lane] = (lane & 1) ? fpt[(size_t)inst * 3 + (lane >> 1)] : tce[S];   // (constants of the trajectory)
+        fill = f == 0 ? tce[i] : (f == 1 ? tce[i + 1] : (f == 2 ? NDP_TA_LATE(L, tseg)[(size_t)inst * S + i] : (f == 3 ? (double)i
+                 : NDP_TA_LATE(L, coeff)[((size_t)inst * S + i) * 28 + (f - 4)])));
         if (ie + sl >= S && f == 1) fill = -1.0e300;                  // no segment behind the last one: slot 1 never matches (hi <= any t)
     }
     stamp_after(19, val);                                             // the lane's polynomial value
@@ -1682,10 +1747,12 @@ __device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickE
     }
     const double e = __hiloint2double(ehi, elo);
     if (store && lane < 14) {
-        const size_t sl = ta.rg.slot(ta.j_new);
-        double *d = lane < 10 ? ta.rx + (size_t)inst * ta.rg.px() + sl * 10 + lane : ta.ru + (size_t)inst * ta.rg.pu() + sl * 4 + (lane - 10);
+        const KernargLate L;
+        const size_t sl = NDP_TA_LATE(L, new_slot);
+        const RingGeom rg = NDP_TA_LATE(L, rg);
+        double *d = lane < 10 ? NDP_TA_LATE(L, rx) + (size_t)inst * rg.px() + sl * 10 + lane : NDP_TA_LATE(L, ru) + (size_t)inst * rg.pu() + sl * 4 + (lane - 10);
         d[0] = e;
-        d[(size_t)ta.rg.np1 * (lane < 10 ? 10 : 4)] = e;
+        d[(size_t)rg.np1 * (lane < 10 ? 10 : 4)] = e;
     }
     return fill;
 }
@@ -1699,7 +1766,9 @@ __device__ __forceinline__ void tick_cache_store(const TickArgs &ta, int inst, i
 __device__ __forceinline__ double tick_estimator(const TickArgs &ta, int inst, int B, int lane)
 {
     double k = 0.0;
-    if (lane == 0) k = throttle_update_one(ta.thr, ta.st, (size_t)B, inst, ta.vz[(size_t)inst * ta.vz_pitch], ta.throttle[inst]);
+    const KernargLate L;
+    if (lane == 0) k = throttle_update_one(NDP_TA_LATE(L, thr), NDP_TA_LATE(L, st), (size_t)B, inst, NDP_TA_LATE(L, vz)[(size_t)inst * NDP_TA_LATE(L, vz_pitch)],
+                                           NDP_TA_LATE(L, throttle)[inst]);
     return uniform_lane(k, 0);
 }
 
@@ -3680,6 +3749,7 @@ static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, bool
         ta.t = t; ta.t_all = t_all; ta.advance = adv ? 1 : 0;
         ta.toff = h->cfg.N * h->cfg.dt; ta.mass = h->cfg.mass; ta.g = h->cfg.gravity;
         ta.j_new = h->list_n + (unsigned long long)rg.ring();
+        ta.new_slot = rg.slot(ta.j_new);
         ta.rg = rg; ta.rx = h->dRingX; ta.ru = h->dRingU;
         ta.thr = thr_cfg(h); ta.st = h->dThr;
         ta.vz = vz ? vz : x_odom + 5; ta.vz_pitch = vz ? 1 : NX;

@@ -26,7 +26,8 @@ def report(title, t):
     if t.shape[1] > 21 and np.median(t[:, 21]) > 0:          # the one-launch tick's prologue, since kernel entry (each stamp waits for its value)
         names = ("neighbour index known", "cached segment records arrived", "time arrived", "polynomial value", "values collected (v_readlane)", "flatness map done")
         print("   tick prologue since entry: " + " | ".join(f"{n} {np.median(t[:, 16 + i] - t[:, 14]):.0f}" for i, n in enumerate(names))
-              + f" | first phase stamp {np.median(t[:, 9] - t[:, 14]):.0f} | weights + barrier done {np.median(t[:, 11] - t[:, 14]):.0f}")
+              + f" | first phase stamp {np.median(t[:, 9] - t[:, 14]):.0f} | weights + barrier done {np.median(t[:, 11] - t[:, 14]):.0f}"
+              + (f" | cache loads issued {np.median(t[:, 22] - t[:, 14]):.0f} | input loads issued {np.median(t[:, 23] - t[:, 14]):.0f}" if t.shape[1] > 23 and np.median(t[:, 23]) > 0 else ""))
 
 
 def main():
