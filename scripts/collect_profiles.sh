@@ -11,4 +11,6 @@ cp -v $G/prof_rows_$TAG/summary/${TAG}_kernel_stats_rows.csv $G/prof_rows_$TAG/s
 [ -f $G/${TAG}_bench/bench300.json ] && cp -v $G/${TAG}_bench/bench300.json profiles/${TAG}_bench_b1024_fused_300steps.json
 [ -f $G/${TAG}_tick/tick_rate.txt ] && cp -v $G/${TAG}_tick/tick_rate.txt profiles/${TAG}_tick_rate.txt
 [ -f $G/${TAG}_tests/tests.txt ] && cp -v $G/${TAG}_tests/tests.txt profiles/${TAG}_gpu_tests.txt
+for f in hbm_ceiling tick_stamps; do [ -f $G/${TAG}_profile/$f.txt ] && cp -v $G/${TAG}_profile/$f.txt profiles/${TAG}_$f.txt; done
+for f in cadence_50hz host_latency stress_parity; do [ -f $G/${TAG}_side/$f.txt ] && cp -v $G/${TAG}_side/$f.txt profiles/${TAG}_$f.txt; done
 true
