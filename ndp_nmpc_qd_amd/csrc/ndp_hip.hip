@@ -1049,6 +1049,23 @@ static void make_fragments(const float *blob, std::vector<float> &fr)
 // load/store; 152 algorithmic bytes per vehicle and tick.  Operation order follows the reference's numpy
 // expressions (hover_throttle_estimator.py:38-51) so results agree to rounding.
 
+// Streaming (non-temporal) accesses of the rows' kernels: outputs nobody reads again in the same launch, inputs read once.  With plain
+// stores ref_window_kernel ran at 0.45 of the HBM roof although its loads + arithmetic alone take 75 us and its arithmetic + stores
+// alone 111 us of the 187 (knock-out builds, round 5): the 616 MB of window rows went through L2 as ordinary dirty lines and every
+// wave's dependent load rounds queued behind them.  `nt`: 137 us (0.62).
+typedef double nt_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_stream(double2 *p, const double2 &v)
+{
+    const nt_d2 t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_d2 *>(p));
+}
+__device__ __forceinline__ void st_stream(double *p, double v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ double2 ld_stream(const double2 *p)
+{
+    const nt_d2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_d2 *>(p));
+    return make_double2(t.x, t.y);
+}
+
 // one estimator update of vehicle v (state SoA [8][S]); returns k_throttle
 __device__ __forceinline__ double throttle_update_one(const ThrCfg &c, double *__restrict__ st, size_t S, int v, double vzv, double th)
 {
@@ -1138,9 +1155,10 @@ __global__ __launch_bounds__(256) void relay_reference_kernel(const double *__re
     const double ox = st[inst * 4], oy = st[inst * 4 + 1], oz = st[inst * 4 + 2];
     const double2 *src = reinterpret_cast<const double2 *>(xr_lead) + (size_t)r * 5;
     double2 *dst = reinterpret_cast<double2 *>(xr_out) + (size_t)r * 5;
-    double2 a = src[0], b = src[1];
+    double2 a = ld_stream(src), b = ld_stream(src + 1);
+    const double2 c = ld_stream(src + 2), d = ld_stream(src + 3), e = ld_stream(src + 4);
     a.x += ox; a.y += oy; b.x += oz;
-    dst[0] = a; dst[1] = b; dst[2] = src[2]; dst[3] = src[3]; dst[4] = src[4];
+    st_stream(dst, a); st_stream(dst + 1, b); st_stream(dst + 2, c); st_stream(dst + 3, d); st_stream(dst + 4, e);
 }
 
 // ------------------------------------------------------------------------------------------ f4 kernel
@@ -1392,7 +1410,14 @@ __device__ __forceinline__ void ref_point(const RefCfg &cf, const double *__rest
     } else {
         if (seg_hint) seg_hint[b] = idx;
         const double its = rcp_n(tseg[(size_t)b * cf.n_seg + idx]);
-        const double *rec = coeff + ((size_t)b * cf.n_seg + idx) * 28;
+        // the record as 14 16-byte loads (it starts at a multiple of 224 bytes): the load unit's time per instruction does not depend
+        // on the width, and these rows are bound by the number of load instructions (see ref_window_kernel)
+        double rec[28];
+        {
+            const double2 *r2 = reinterpret_cast<const double2 *>(coeff + ((size_t)b * cf.n_seg + idx) * 28);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) { const double2 v = r2[i]; rec[2 * i] = v.x; rec[2 * i + 1] = v.y; }
+        }
         double s;
         {
 #pragma clang fp contract(off)
@@ -1412,11 +1437,14 @@ __device__ __forceinline__ void ref_point(const RefCfg &cf, const double *__rest
 }
 
 #define REF_ROWS 64     // rows (vehicle, node) per workgroup = one wave: small batches spread over all CUs
-// A wave's life here is a chain of dependent memory round trips (time -> segment -> 28 coefficients -> ... -> stores): the kernel
-// runs at (resident waves) / (one wave's latency), not at a VALU or HBM limit -- PMC, round 5: VALU 27 % busy, HBM 49 %, 4.9 waves per
-// SIMD of 11 us each.  Hence ONE 5 KB staging buffer used twice (x rows, then u rows: 7 KB per wave had capped a CU at 22
-// workgroups; the 76 registers allow 6 waves per SIMD).  Forcing 64 registers (8 waves) spills 20 bytes per lane and is slower (0.38
-// against 0.44 of the HBM roof).
+// What binds it (round 5, knock-out builds at 262 144 windows, 187 us as it stood): loads + arithmetic alone 75 us, arithmetic + stores
+// alone 111 us (5.5 TB/s of writes: the device's fill ceiling), loads + stores WITHOUT the arithmetic 168 us -- the two memory phases
+// did not overlap across waves: the 616 MB of output went through L2 as ordinary dirty lines and the dependent load rounds of the
+// other waves (time -> segment -> coefficients) queued behind them.  Streaming stores (st_stream): 127-137 us, 0.62-0.68 of the roof.
+// Not what binds it, each measured: the number of load instructions (coefficients as 14 16-byte loads: +2.6 %; from the scalar
+// cache instead, a timing experiment: nothing), the number of dependent rounds (a branch-free scan that merges two of the three rounds
+// but requests six more time_cum entries: 13 % SLOWER), occupancy (64 registers for 8 waves spills and is slower).  ONE 5 KB staging
+// buffer used twice (x rows, then u rows): 7 KB per wave had capped a CU at 22 workgroups.
 __global__ __launch_bounds__(REF_ROWS)
 void ref_window_kernel(RefCfg cf, const double *__restrict__ coeff, const double *__restrict__ tcum,
                        const double *__restrict__ tseg, const double *__restrict__ fpt,
@@ -1443,7 +1471,7 @@ void ref_window_kernel(RefCfg cf, const double *__restrict__ coeff, const double
     // 16 bytes per lane and store (rows are 80 / 32 bytes: both arrays stay 16-byte aligned at every row)
     double2 *xg = reinterpret_cast<double2 *>(xr + (size_t)row0 * 10);
     const double2 *s2 = reinterpret_cast<const double2 *>(sx);
-    for (int i = lane; i < rows_here * 5; i += REF_ROWS) xg[i] = s2[i];
+    for (int i = lane; i < rows_here * 5; i += REF_ROWS) st_stream(xg + i, s2[i]);
     // ur has no node-N rows: the number of u rows before row (b, k) is b N + k = row - b
     const int ufirst = row0 - row0 / np1;
     const int uslot = (row - b) - ufirst;
@@ -1460,7 +1488,7 @@ void ref_window_kernel(RefCfg cf, const double *__restrict__ coeff, const double
     const int rend = row0 + rows_here;
     const int nu = (rend - rend / np1) - ufirst;                                 // u rows among [row0, rend)
     double2 *ug = reinterpret_cast<double2 *>(ur + (size_t)ufirst * 4);
-    for (int i = lane; i < nu * 2; i += REF_ROWS) ug[i] = s2[i];
+    for (int i = lane; i < nu * 2; i += REF_ROWS) st_stream(ug + i, s2[i]);
 }
 
 // ---- f1, the reference's own bookkeeping: NMPCRefPublisher keeps a list of `ring` = step N + 1 reference points per vehicle,
@@ -1485,7 +1513,7 @@ __device__ __forceinline__ void ring_store(const RingGeom &rg, double *__restric
 #pragma unroll
     for (int c = 0; c < 5; ++c) { const double2 v = make_double2(xv[2 * c], xv[2 * c + 1]); x0[c] = v; x1[c] = v; }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) { const double2 v = make_double2(uv[2 * c], uv[2 * c + 1]); u0[c] = v; u1[c] = v; }
+    for (int c = 0; c < 2; ++c) { const double2 v = make_double2(uv[2 * c], uv[2 * c + 1]); u0[c] = v; u1[c] = v; }   // (plain: 80- / 32-byte pieces, partial lines -- streamed they cost the list advance a quarter of its rate)
 }
 
 // Fills list entries: point i of vehicle b at trajectory time (tq ? tq[b] : 0) + toff + i * tstep becomes entry j0 + i;
@@ -1546,7 +1574,7 @@ __global__ __launch_bounds__(256) void ref_list_window_kernel(const double *__re
     }
 #pragma unroll
     for (int j = 0; j < WIN_UNROLL; ++j)
-        if (dst[j]) *dst[j] = v[j];
+        if (dst[j]) st_stream(dst[j], v[j]);
 }
 
 
