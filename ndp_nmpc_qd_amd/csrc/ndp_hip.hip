@@ -1144,21 +1144,38 @@ __global__ __launch_bounds__(256) void relay_formation_kernel(double alpha, doub
     st[v * 4 + 3] = 1.0;
 }
 
-// follower reference = leader window with the filtered offset added to the positions; one thread per state row
-// (80 contiguous bytes in, 80 out: five double2 accesses), HBM-bound: 3360 B per instance at N = 20
+// follower reference = leader window with the filtered offset added to the positions.  HBM-bound: 3360 B per instance at N = 20.
+// A dense copy in 16-byte pieces (piece p: row p / 5, doubles 2 (p % 5) and + 1 of it), the offset added to pieces 0 (x, y) and 1 (z):
+// every instruction of a wave covers 1 KB of contiguous memory on both sides, the output streams (st_stream).  As one thread per ROW
+// -- five pieces at an 80-byte lane stride -- each instruction touched 40 lines a fifth each: 195 us for 262 144 windows (0.58 of the
+// roof); that form with streaming loads / stores: 685 us, every partial line fetched again by each of its five instructions.
+enum { RELAY_UNROLL = 4 };
 __global__ __launch_bounds__(256) void relay_reference_kernel(const double *__restrict__ st, const double *__restrict__ xr_lead,
                                                               double *__restrict__ xr_out, int rows, int np1)
 {
-    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (r >= rows) return;
-    const int inst = r / np1;
-    const double ox = st[inst * 4], oy = st[inst * 4 + 1], oz = st[inst * 4 + 2];
-    const double2 *src = reinterpret_cast<const double2 *>(xr_lead) + (size_t)r * 5;
-    double2 *dst = reinterpret_cast<double2 *>(xr_out) + (size_t)r * 5;
-    double2 a = ld_stream(src), b = ld_stream(src + 1);
-    const double2 c = ld_stream(src + 2), d = ld_stream(src + 3), e = ld_stream(src + 4);
-    a.x += ox; a.y += oy; b.x += oz;
-    st_stream(dst, a); st_stream(dst + 1, b); st_stream(dst + 2, c); st_stream(dst + 3, d); st_stream(dst + 4, e);
+    const size_t total = (size_t)rows * 5;
+    const size_t p0 = (size_t)blockIdx.x * (256 * RELAY_UNROLL) + threadIdx.x;
+    const double2 *src = reinterpret_cast<const double2 *>(xr_lead);
+    double2 *dst = reinterpret_cast<double2 *>(xr_out);
+    double2 v[RELAY_UNROLL], o[RELAY_UNROLL];
+#pragma unroll
+    for (int j = 0; j < RELAY_UNROLL; ++j) {
+        const size_t p = p0 + (size_t)j * 256, pc = p < total ? p : total - 1;
+        const int r = (int)(pc / 5), c = (int)(pc - (size_t)r * 5), inst = r / np1;
+        v[j] = src[pc];
+        o[j] = make_double2(0.0, 0.0);
+        if (c == 0) o[j] = *reinterpret_cast<const double2 *>(st + (size_t)inst * 4);        // (ox, oy)
+        else if (c == 1) o[j].x = st[(size_t)inst * 4 + 2];                                   // (oz, -)
+    }
+#pragma unroll
+    for (int j = 0; j < RELAY_UNROLL; ++j) {
+        const size_t p = p0 + (size_t)j * 256;
+        const int c = (int)(p % 5);
+        double2 w = v[j];
+        if (c == 0) { w.x += o[j].x; w.y += o[j].y; }
+        else if (c == 1) w.x += o[j].x;
+        if (p < total) st_stream(dst + p, w);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ f4 kernel
@@ -3467,7 +3484,8 @@ int ndp_relay_formation(ndp_handle *h, const double *form, double *offset_out)
 static int launch_relay_reference(ndp_handle *h, const double *d_xr_lead, double *d_xr_out, hipStream_t s)
 {
     const int np1 = h->cfg.N + 1, rows = h->cfg.batch * np1;
-    hipLaunchKernelGGL(relay_reference_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, (const double *)h->dRelay, d_xr_lead, d_xr_out, rows, np1);
+    const size_t pieces = (size_t)rows * 5, per_block = 256 * RELAY_UNROLL;
+    hipLaunchKernelGGL(relay_reference_kernel, dim3((unsigned)((pieces + per_block - 1) / per_block)), dim3(256), 0, s, (const double *)h->dRelay, d_xr_lead, d_xr_out, rows, np1);
     NDP_HIP(h, hipGetLastError());
     return 0;
 }
