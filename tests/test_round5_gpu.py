@@ -99,3 +99,41 @@ def test_refine_getter_says_where_ipm_refine_acts():
     assert ndp.BatchedNMPC(8, load_mlp=False).refine_active                       # N = 20: three-slot kernels
     assert not ndp.BatchedNMPC(8, N=40, load_mlp=False).refine_active             # five-slot kernels ignore it
     assert not ndp.BatchedNMPC(8, load_mlp=False, ipm_refine=0).refine_active
+
+
+@pytest.mark.parametrize("B", [1, 49, 1000])
+def test_relay_reference_dense_piece_copy_at_ragged_sizes(B):
+    """relay_reference_kernel is a dense copy in 16-byte pieces, four per thread: batches whose piece count is not a multiple of a
+    block's 1024 (and one below a single wave) against the definition -- positions + the filtered offset, everything else untouched
+    (nmpc_follower_node.py:58-74), bit for bit."""
+    import ndp_nmpc_qd_amd as ndp
+    rng = np.random.default_rng(B)
+    eng = ndp.BatchedNMPC(B, load_mlp=False)
+    form = rng.normal(size=(B, 3))
+    off = eng.relay_formation(form)                       # first message: alpha u + (1 - alpha) u (alpha_filter.py:19), u to a rounding
+    np.testing.assert_allclose(off, form, rtol=1e-15, atol=0)
+    lead = rng.normal(size=(B, eng.N + 1, 10))
+    want = lead.copy()
+    want[:, :, 0:3] += off[:, None, :]
+    assert np.array_equal(eng.relay_reference(lead), want)
+
+
+@pytest.mark.parametrize("B", [1, 3, 61, 1000])
+def test_reference_windows_with_streaming_stores_at_ragged_sizes(B):
+    """ref_window_kernel transposes 64 rows through LDS and streams them out; B (N + 1) not a multiple of 64, and fewer rows than one
+    wave: against the list path's windows (ring fill + dense copy), which share the point evaluation bit for bit."""
+    import ndp_nmpc_qd_amd as ndp
+    from ndp_nmpc_qd_amd import synth
+    tr = synth.figure_eight_traj(B, seed=7 + B, n_seg=12, t_seg=0.5)
+    eng = ndp.BatchedNMPC(B, load_mlp=False)
+    eng.ref_set_trajectory(tr["coeff_x"], tr["coeff_y"], tr["coeff_z"], tr["coeff_yaw"], tr["time_cum"], tr["time_seg"], tr["final_pt"])
+    t = np.linspace(0.0, 3.0, B)
+    xr, ur = eng.ref_window(t)
+    assert np.isfinite(xr).all() and np.isfinite(ur).all()
+    # the same points one at a time (rows of other windows): node k of the window at t = node 0 of the window at t + k dt
+    k = eng.N // 2
+    from ndp_nmpc_qd_amd.params import nmpc_params as CP
+    xr_k, ur_k = eng.ref_window(t + k * CP.th_pred)
+    # (the node time is (t + T_offset) + k dt in the kernel and (t + k dt) + T_offset here: an ulp of time, hence not array_equal)
+    np.testing.assert_allclose(xr[:, k, :], xr_k[:, 0, :], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(ur[:, k, :], ur_k[:, 0, :], rtol=0, atol=1e-9)
