@@ -277,6 +277,8 @@ struct KernargLate {
         return t;
     }
 };
+static_assert(std::is_standard_layout<KernArgs>::value && std::is_trivially_copyable<KernArgs>::value,
+              "KernargLate addresses members of the one kernel argument by offsetof");
 #define NDP_TA_LATE(L, f) ((L).template get<decltype(TickArgs::f)>((unsigned)(offsetof(KernArgs, ta) + offsetof(TickArgs, f))))
 // (A pointer fetched this way has lost what the compiler knows of pointers in the argument block -- that they point to global memory --
 // and is dereferenced with FLAT instructions, which also count as LDS operations and turn the waits behind them into full drains:
