@@ -3,7 +3,8 @@
 puts under rocprofv3 (kernel trace, then PMC passes).  No oracle, no child processes.
     python3 scripts/rows_driver.py [--batch 262144] [--reps 30]
 Kernels: ref_window_kernel, ref_list_fill_kernel (advance), ref_list_window_kernel, throttle_kernel, actuator_kernel, plant_kernel,
-relay_reference_kernel, mlp_kernel, mlp_stream_kernel, pack_pv_kernel, peer_publish_kernel + peer_epoch_kernel, tick_pre_kernel."""
+relay_reference_kernel, mlp_kernel, mlp_stream_kernel, pack_pv_kernel, peer_publish_kernel + peer_epoch_kernel, tick_pre_kernel, and the
+one-launch tick (rti_kernel<..., TICK>) at batch 1024."""
 import argparse
 import ctypes as C
 import os
@@ -95,6 +96,14 @@ def main():
     cm = torch.empty(Bt, 4, dtype=torch.float64, device=dev)
     for i in range(R):
         e10.tick_device(xo, cm, t=0.02 * i, estimate=True, stream=st)
+    torch.cuda.synchronize()
+    # the ONE-launch tick (rti_kernel<3, 4, true, 20, 0, 1, 0, true>) on the metric's workload: batch 1024, vehicle pairs, 36 % of the gates open
+    from tick_rate import setup
+    e1k = setup(1024)
+    x1 = [torch.from_numpy(e1k.ref_window(np.full(1024, 0.02 * i))[0][:, 0, :].copy()).to(dev) for i in range(3 * R)]
+    c1 = torch.empty(1024, 4, dtype=torch.float64, device=dev)
+    for i in range(3 * R):
+        e1k.tick_device(x1[i], c1, t=0.02 * i, estimate=True, stream=st)
     torch.cuda.synchronize()
     print("rows_driver done: batch", B, "reps", R)
 

@@ -1,4 +1,4 @@
-"""Summarises scripts/profile_rows.sh: per kernel the duration statistics of its launches (the first three of each kernel dropped:
+"""Summarises scripts/profile_rows.sh: per kernel the duration statistics of its launches AT ITS LARGEST GRID (the first three dropped:
 clocks, caches) and the per-launch mean of every counter -> <out>/summary/<tag>_kernel_stats_rows.csv, <tag>_pmc_rows.json.
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB units; the gfx950 note of MI355X_MICROARCH.md)."""
 import csv
@@ -19,21 +19,37 @@ def short(name):
     return n.split("(")[0][:60]
 
 
+def pick_grid(grids):
+    """A kernel's launches are summarised at ONE grid size: the largest one launched at least five times (the driver's helpers launch
+    some kernels at batch 1024 as well, and the list's reset fills 101 entries per vehicle once)."""
+    from collections import Counter
+    c = Counter(grids)
+    often = [g for g, n in c.items() if n >= 5]
+    return max(often) if often else max(c, key=lambda g: (c[g], g))
+
+
 stats = {}
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
     per = {}
     for r in csv.DictReader(open(f)):
-        per.setdefault(short(r["Kernel_Name"]), []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        per.setdefault(short(r["Kernel_Name"]), []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"])))
     for k, v in per.items():
-        v.sort()
+        g = pick_grid([x[2] for x in v])
+        v = sorted(x for x in v if x[2] == g)
         d = np.array([x[1] for x in v][3:] or [x[1] for x in v], dtype=float)
         stats[k] = {"calls": len(d), "avg_us": d.mean() / 1e3, "min_us": d.min() / 1e3, "max_us": d.max() / 1e3}
 pmc = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_f64"):
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
-        per = {}
-        for r in csv.DictReader(open(f)):
+        per, grid = {}, {}
+        rows = list(csv.DictReader(open(f)))
+        for r in rows:                              # (one row per dispatch AND counter: count dispatches)
+            grid.setdefault(short(r["Kernel_Name"]), {})[r["Dispatch_Id"]] = int(r["Grid_Size"])
+        grid = {k: pick_grid(list(g.values())) for k, g in grid.items()}
+        for r in rows:
             k = short(r["Kernel_Name"])
+            if int(r["Grid_Size"]) != grid[k]:
+                continue
             per.setdefault(k, {}).setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
             per[k][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
         for k, cs in per.items():
