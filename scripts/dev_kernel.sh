@@ -4,5 +4,5 @@
 # with NDP_NMPC_LIB=$PWD/ndp_nmpc_qd_amd/libndp_nmpc_hip_dev.so.  Extra hipcc flags: "$@".
 set -e
 cd "$(dirname "$0")/../ndp_nmpc_qd_amd/csrc"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DNDP_DEV_HEADLINE_ONLY -fPIC -shared "$@" \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-schedule-relaxed-occupancy=true -DNDP_DEV_HEADLINE_ONLY -fPIC -shared "$@" \
     -o ../libndp_nmpc_hip_dev.so ndp_hip.hip

@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../ndp_nmpc_qd_amd/csrc"
 OUT=${TMPDIR:-/tmp}/ndp_dev_regs.s
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DNDP_DEV_N40_ONLY --cuda-device-only -S "$@" -o $OUT ndp_hip.hip 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-schedule-relaxed-occupancy=true -DNDP_DEV_N40_ONLY --cuda-device-only -S "$@" -o $OUT ndp_hip.hip 2>/dev/null
 python3 - "$OUT" <<'PY'
 import re, sys
 t = open(sys.argv[1]).read()
