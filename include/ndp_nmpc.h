@@ -42,7 +42,7 @@ extern "C" {
 /* Version of this interface: bumped whenever an exported signature or the layout of ndp_cfg changes.  A binding built against
  * another header must refuse to run: ndp_abi_version() is what the loaded library was built with, ndp_cfg_size() its
  * sizeof(ndp_cfg) (ndp_create / ndp_default_cfg read and write that many bytes of the caller's struct). */
-#define NDP_ABI_VERSION 6
+#define NDP_ABI_VERSION 7
 int ndp_abi_version(void);
 size_t ndp_cfg_size(void);
 
@@ -100,6 +100,20 @@ typedef struct ndp_cfg {
     double mu_floor;            /* interior point: the centring target sigma*mu never goes below mu_floor * tol (default 0.1) --
                                  * slacks are differences, so driving mu far below tol only loses digits */
     double refine_gamma;        /* see ipm_refine (default 1e4) */
+    /* NDP_QP_AUTO, active set on the INPUT bounds (nmpc_body_rate_ctl.py:56-58 -- the only bounds ever active in the reference's
+     * envelope): when the equality-constrained minimiser leaves the box, inputs beyond a bound are pinned there, pins whose
+     * multiplier has the wrong sign are released, and the QP is solved again -- ONE Riccati sweep per iteration -- until the set
+     * reproduces itself; the KKT conditions of the box-constrained QP then hold: it IS the solution HPIPM iterates towards
+     * (any method converging the same strictly convex QP is parity-equivalent).  The set is kept per instance between control steps
+     * (the warm start the reference leaves off, nmpc_body_rate_ctl.py:73-74): a step whose set still holds costs one sweep.
+     * as_iter_max: sweeps with pins allowed behind the first one (default 8; 0 = off: rounds 1-5's behaviour, early exit only
+     * auto_margin inside every bound, else the interior-point loop).  A violated VELOCITY bound, a set that does not settle, a failed
+     * factorisation: the interior-point loop takes the QP, as before.  ndp_reset / ndp_set_iterate empty the kept sets.
+     * as_gamma: the weight that holds a pinned input on its bound (default 1e12: the input is then within multiplier / 1e12 of
+     * the bound and set onto it exactly). */
+    int32_t as_iter_max;
+    int32_t reserved0;
+    double as_gamma;
 } ndp_cfg;
 
 typedef struct ndp_handle ndp_handle;
@@ -228,6 +242,12 @@ int ndp_set_iterate(ndp_handle *h, const double *X, const double *U);
 /* Replaces solver.status (nmpc_body_rate_ctl.py:109): per-instance status of the last step and the
  * interior-point iterations it took (0 = early exit).  Either pointer may be NULL. */
 int ndp_get_status(ndp_handle *h, int32_t *status, int32_t *ipm_iters);
+
+/* What NDP_QP_AUTO's active-set iterations did in the last step (cfg.as_iter_max; no counterpart in the reference, whose HPIPM is
+ * cold-started every call, nmpc_body_rate_ctl.py:71-74): sweeps[B] = Riccati sweeps the step's QPs took before the interior-point
+ * loop, if that ran at all (1 = the first solve's set held); act[B][4N] = the set kept for the next step, element 4k + i = input i of
+ * stage k: +1 on its upper bound, -1 on its lower, 0 free.  Either pointer may be NULL. */
+int ndp_get_active_set(ndp_handle *h, int32_t *sweeps, int8_t *act);
 
 /* Device views for callers that keep everything in HBM (bench, multi-GPU driver).  The getters above and
  * ndp_synchronize also wait for the last stream a *_device call was given. */

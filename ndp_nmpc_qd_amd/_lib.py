@@ -16,7 +16,7 @@ WEIGHTS_PATH = os.path.join(_HERE, "weights", "downwash_sn4.bin")
 NX, NU = 10, 4
 MLP_NPARAM = 17859
 QP_AUTO, QP_IPM_ALWAYS = 0, 1
-ABI_VERSION = 6          # include/ndp_nmpc.h: NDP_ABI_VERSION (checked against the loaded library in load())
+ABI_VERSION = 7          # include/ndp_nmpc.h: NDP_ABI_VERSION (checked against the loaded library in load())
 TICK_ESTIMATE, TICK_WANT_U0, TICK_T_UNIFORM = 1, 2, 4
 
 
@@ -31,6 +31,7 @@ class NdpCfg(C.Structure):
         ("lbu", C.c_double * 4), ("ubu", C.c_double * 4), ("lbv", C.c_double * 3), ("ubv", C.c_double * 3),
         ("mu0", C.c_double), ("thr0", C.c_double), ("tol", C.c_double), ("tau", C.c_double), ("auto_margin", C.c_double),
         ("ts_nmpc", C.c_double), ("mu_floor", C.c_double), ("refine_gamma", C.c_double),
+        ("as_iter_max", C.c_int32), ("reserved0", C.c_int32), ("as_gamma", C.c_double),
     ]
 
 
@@ -50,7 +51,7 @@ EXPORTS = [
     "ndp_track_steps", "ndp_last_step_event",
     "ndp_xchg_unique_id", "ndp_xchg_create", "ndp_xchg_begin", "ndp_xchg_end", "ndp_xchg_tick", "ndp_xchg_last_error", "ndp_xchg_destroy",
     "ndp_abi_version", "ndp_cfg_size",
-    "ndp_step_ex_f64", "ndp_refine_active", "ndp_tick_config", "ndp_tick_reset", "ndp_tick_begin", "ndp_tick_end", "ndp_tick", "ndp_tick_device",
+    "ndp_step_ex_f64", "ndp_refine_active", "ndp_get_active_set", "ndp_tick_config", "ndp_tick_reset", "ndp_tick_begin", "ndp_tick_end", "ndp_tick", "ndp_tick_device",
 ]
 
 _lib = None

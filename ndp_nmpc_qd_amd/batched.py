@@ -357,6 +357,14 @@ class BatchedNMPC:
         self._check(self._lib.ndp_get_status(self._h, _lib.ptr(st), _lib.ptr(it)), "ndp_get_status")
         return st, it
 
+    def active_set(self):
+        """(sweeps[B], act[B,N,4]) of the last step's QPs (ndp_get_active_set): Riccati sweeps taken by QP_AUTO's active-set
+        iterations, and the set kept for the next step (+1 / -1: input on its upper / lower bound)."""
+        sw = np.zeros(self.B, dtype=np.int32)
+        act = np.zeros((self.B, self.N, 4), dtype=np.int8)
+        self._check(self._lib.ndp_get_active_set(self._h, _lib.ptr(sw), _lib.ptr(act)), "ndp_get_active_set")
+        return sw, act
+
     # ------------------------------------------------------------------ HBM-resident API (torch CUDA tensors)
     @staticmethod
     def _dptr(t, dtype, shape):

@@ -41,6 +41,8 @@ inline void fill_default_cfg(ndp_cfg *c)
     c->ts_nmpc = 0.02;
     c->ipm_refine = 2;
     c->refine_gamma = 1e4;
+    c->as_iter_max = 8;
+    c->as_gamma = 1e12;
 }
 
 inline RtiParams to_params(const ndp_cfg &c)
@@ -53,6 +55,7 @@ inline RtiParams to_params(const ndp_cfg &c)
     memcpy(p.lbv, c.lbv, sizeof(p.lbv)); memcpy(p.ubv, c.ubv, sizeof(p.ubv));
     p.mu0 = c.mu0; p.thr0 = c.thr0; p.tol = c.tol; p.tau = c.tau; p.auto_margin = c.auto_margin; p.mu_floor = c.mu_floor;
     p.refine = c.ipm_refine; p.refine_gamma = c.refine_gamma;
+    p.as_iter_max = c.as_iter_max; p.as_gamma = c.as_gamma;
     fill_quotients(p);
     return p;
 }

@@ -74,6 +74,7 @@ struct BatchPtrs {
     double *thrust_keep;
     double cmd_mass;
     int f_f64;                   // 1: f holds doubles, [B][N+1][3] (ndp_step_ex_f64)
+    signed char *act;            // [B][act_pitch(N)] the instances' kept active sets (RtiIo::act), or null: no warm start of the QP's active set
 };
 
 struct MlpArgs {            // fused downwash (null frag = not fused)
@@ -158,6 +159,7 @@ __device__ __forceinline__ void bind_instance(RtiIo &io, const BatchPtrs &bp, in
     io.kc = bp.kc;
     io.tables = bp.tables;
     io.stamps = bp.stamps ? bp.stamps + (size_t)inst * NDP_NSTAMP : nullptr;
+    io.act = bp.act ? bp.act + (size_t)inst * act_pitch(N) : nullptr;
     if (NDP_RARELY(bp.cmd != nullptr)) {
         io.cmd = bp.cmd + (size_t)inst * NU;
         io.thrust_keep = bp.thrust_keep + inst;
@@ -2066,6 +2068,7 @@ struct ndp_handle {
     float *dForce = nullptr, *dFrag = nullptr;
     double *dKC = nullptr;     // constants block of the LDS image (fill_kc)
     int *dTables = nullptr;    // per-lane index tables of the Riccati sweep (fill_tables)
+    signed char *dAct = nullptr;   // [B][act_pitch(N)] QP_AUTO's active sets, kept between control steps (RtiIo::act); emptied by reset / set_iterate
     double *dThr = nullptr;    // hover-throttle estimator state, SoA [8][B]
     double *dStamps = nullptr; // [B][NDP_NSTAMP] whole-batch phase stamps (ndp_debug_stamps)
     double *dTraj = nullptr;   // f1: [B][n_seg][28] coeff | [B][n_seg+1] time_cum | [B][n_seg] time_seg | [B][3] final_pt | [B][64] segment cache | int[B] segment hints
@@ -2150,6 +2153,7 @@ static size_t nxs(const ndp_handle *h) { return (size_t)h->cfg.batch * (h->cfg.N
 static size_t nus(const ndp_handle *h) { return (size_t)h->cfg.batch * h->cfg.N * NU; }
 static size_t nfs(const ndp_handle *h) { return (size_t)h->cfg.batch * (h->cfg.N + 1) * 3; }
 static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
+static size_t act_bytes(const ndp_handle *h) { return (size_t)h->cfg.batch * (size_t)act_pitch(h->cfg.N); }
 
 // the shapes the work-queue form of rti_kernel is instantiated for (compile-time horizon and iteration count)
 static bool queue_shape(const ndp_handle *h)
@@ -2498,7 +2502,7 @@ int ndp_destroy(ndp_handle *h)
         if (e) (void)hipEventDestroy(e);
     h->pool.reset();
     void *ptrs[] = {h->dForceAB[0], h->dForceAB[1], h->dProto, h->dRingX, h->dTraj, h->dTables, h->dStamps, h->dRelay, h->dThr, h->sThr, h->dKC, h->dForce, h->dFrag,
-                    h->dIn, h->dOut, h->sdbg, h->dQctr, h->dQids, h->dTickIndex, h->dTickThrust};
+                    h->dIn, h->dOut, h->sdbg, h->dQctr, h->dQids, h->dTickIndex, h->dTickThrust, h->dAct};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &sl : h->slot) {
@@ -2588,6 +2592,8 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     ALLOC(h->dThr, B * 8 * 8); ALLOC(h->sThr, B * 11 * 8);
     ALLOC(h->dRelay, B * 4 * 8);
     ALLOC(h->dQctr, 256); ALLOC(h->dQids, B * 4);
+    ALLOC(h->dAct, B * (size_t)act_pitch(cfg->N));
+    (void)hipMemsetAsync(h->dAct, 0, B * (size_t)act_pitch(cfg->N), h->stream);
     (void)hipMemsetAsync(h->dRelay, 0, B * 4 * 8, h->stream);
     (void)hipMemsetAsync(h->dQctr, 0, 256, h->stream);
     {
@@ -2788,7 +2794,8 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
     BatchPtrs bp{h->dKC, h->dTables, d_x0, d_xr, d_ur, d_f, h->dX, h->dU, d_u0, d_status, d_iters,
                  so ? so->Xm : nullptr, so ? so->Um : nullptr, d_dbg, h->dStamps,
                  so && so->xr_pitch ? so->xr_pitch : (size_t)(h->cfg.N + 1) * NX, so && so->ur_pitch ? so->ur_pitch : (size_t)h->cfg.N * NU, (size_t)NX,
-                 so ? so->cmd : nullptr, so ? so->kthr : nullptr, so ? so->thrust_keep : nullptr, h->cfg.mass, so && so->f_f64 ? 1 : 0};
+                 so ? so->cmd : nullptr, so ? so->kthr : nullptr, so ? so->thrust_keep : nullptr, h->cfg.mass, so && so->f_f64 ? 1 : 0,
+                 h->dAct};
     const bool fused = nb && nb->other;
     MlpArgs ma{fused ? h->dFrag : nullptr, fused ? nb->other : nullptr, fused ? nb->ego_xy : nullptr, h->dForce,
                h->cfg.r_horiz * h->cfg.r_horiz, fused ? nb->stride : NX, fused ? nb->index : nullptr, fused ? peer_mapped(nb->other) : 0,
@@ -2923,6 +2930,7 @@ int ndp_reset_device(ndp_handle *h, const void *d_xr, const void *d_ur, void *st
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     NDP_HIP(h, hipMemcpyAsync(h->dX, d_xr, nxs(h) * 8, hipMemcpyDefault, s));
     NDP_HIP(h, hipMemcpyAsync(h->dU, d_ur, nus(h) * 8, hipMemcpyDefault, s));
+    NDP_HIP(h, hipMemsetAsync(h->dAct, 0, act_bytes(h), s));      // a new iterate: the QPs start from an empty active set
     return note_stream(h, s);
 }
 
@@ -2935,6 +2943,7 @@ int ndp_reset(ndp_handle *h, const double *xr, const double *ur)
     if (rc) return rc;
     NDP_HIP(h, hipMemcpyAsync(h->dX, xr, nxs(h) * 8, hipMemcpyDefault, h->stream));
     NDP_HIP(h, hipMemcpyAsync(h->dU, ur, nus(h) * 8, hipMemcpyDefault, h->stream));
+    NDP_HIP(h, hipMemsetAsync(h->dAct, 0, act_bytes(h), h->stream));
     NDP_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -3342,6 +3351,24 @@ int ndp_set_iterate(ndp_handle *h, const double *X, const double *U)
     if (rc) return rc;
     if (X) NDP_HIP(h, hipMemcpy(h->dX, X, nxs(h) * 8, hipMemcpyDefault));
     if (U) NDP_HIP(h, hipMemcpy(h->dU, U, nus(h) * 8, hipMemcpyDefault));
+    NDP_HIP(h, hipMemset(h->dAct, 0, act_bytes(h)));
+    return 0;
+}
+
+int ndp_get_active_set(ndp_handle *h, int32_t *sweeps, int8_t *act)
+{
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = wait_all(h);
+    if (rc) return rc;
+    const size_t B = (size_t)h->cfg.batch, pitch = (size_t)act_pitch(h->cfg.N), na = 4 * (size_t)h->cfg.N;
+    std::vector<signed char> rec(B * pitch);
+    NDP_HIP(h, hipMemcpy(rec.data(), h->dAct, rec.size(), hipMemcpyDefault));
+    for (size_t i = 0; i < B; ++i) {
+        if (sweeps) memcpy(&sweeps[i], &rec[i * pitch], 4);
+        if (act) memcpy(act + i * na, &rec[i * pitch + ACT_HDR], na);
+    }
     return 0;
 }
 
@@ -3773,6 +3800,7 @@ int ndp_tick_reset(ndp_handle *h)
     int rc = wait_all(h);
     if (rc) return rc;
     if ((rc = launch_list_window(h, h->dX, h->dU, h->stream))) return rc;
+    NDP_HIP(h, hipMemsetAsync(h->dAct, 0, act_bytes(h), h->stream));      // reset(): the QPs start from an empty active set
     NDP_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
 }

@@ -80,6 +80,10 @@ struct RtiParams {
     double mu0, thr0, tol, tau, auto_margin, mu_floor;
     int refine;             // interior point: refinement solves per Newton system while a state bound's barrier term exceeds refine_gamma
     double refine_gamma;
+    // QP_AUTO: active-set iterations on the INPUT bounds (see RtiWave::as_check): at most as_iter_max sweeps with pinned inputs behind the
+    // first one (0 = none: the equality-constrained minimiser or the interior-point loop, as in rounds 1-5); as_gamma = weight of a pin
+    int as_iter_max;
+    double as_gamma;
     // host-evaluated quotients (an f64 divide is a ~30-instruction VALU sequence on the device, even for uniforms)
     double h_6, h2_6, h4_24, h3_6, h4_12, two_over_h2, inv2m;
 };
@@ -136,10 +140,16 @@ struct RtiIo {            // global-memory views of ONE instance
     int have_xrN = 0;
     double xrN[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int f_is_f64 = 0;     // 1: f points at doubles (the reference hands acados a float64 p, ndp_nmpc_body_rate_ctl.py:97-99); 0: fp32, what DownwashNN returns
+    // QP_AUTO's active set of this instance, kept between control steps (the warm start of the next step's QP): ACT_HDR bytes of header
+    // -- an int32: sweeps the last step's QPs took -- then one signed byte per input bound, element 4k + i = input i of stage k:
+    // +1 pinned at its upper bound, -1 at its lower, 0 free.  Null = no warm start, nothing kept.
+    signed char *act = nullptr;
 };
+enum { ACT_HDR = 4 };
+NDP_HD int act_pitch(int N) { return ACT_HDR + 4 * N; }      // bytes per instance of the active-set record (a multiple of four)
 
 struct LdsMap {
-    int KC, SC, XI, UI, ZX, ZU, CX, CU, ZD, MB, CB, KT, TXR, TUR, TF, total;
+    int KC, SC, XI, UI, ZX, ZU, CX, CU, ZD, MB, CB, KT, TXR, TUR, TF, AS, total;
 };
 
 NDP_HD LdsMap make_map(int N)
@@ -157,6 +167,9 @@ NDP_HD LdsMap make_map(int N)
     m.ZD = o; o += (N + 1) * NX + N * NU;   // shadow of ZX|ZU: where the lanes that hold no forward-sweep result store
     m.MB = o; o += N * MB_STRIDE;
     m.CB = o; o += (N + 1) * CB_STRIDE;
+    // the active set of the input bounds (RtiWave::ActSet) where the five-slot kernels keep it (they sit at the register limit and park
+    // the set here instead of holding it across the sweeps; the three-slot kernels hold it in registers and leave the area alone)
+    m.AS = o; o += N * NU;
     m.total = o;
     m.KT = m.MB + MB_KT;   // K~' of stage 0; stage k at + k * MB_STRIDE
     // staged inputs (17N + 13 doubles) alias ZX|ZU|CX|CU|ZD (42N + 30), which are dead until the first sweep / step
@@ -1379,26 +1392,118 @@ struct RtiWave {
         }
     }
 
-    // Inside the box by at least `margin` on every bounded variable.  The margin is what keeps QP_AUTO within ~1e-6 of an
-    // interior-point solve stopped at mu <= tol (HPIPM, the oracle): at a slack t the barrier leaves a multiplier mu / t
-    // on an INACTIVE bound, which moves the solution by ~mu / (t * weight); with tol = 1e-8 and t >= 0.1 (the default) that is below
-    // 1e-6, whereas a minimiser 1e-4 inside a bound differs from the interior-point answer by 1e-4 -- such instances
-    // take the interior-point loop like the reference does.
-    // Evaluated without the constraint slots (which the interior-point loop needs, the nominal step does not): the 4N input bounds
-    // as they lie in ZU (element e: component e & 3), the 3(N-1) velocity bounds four lanes per stage (component 3 idle) -- no division
-    // by three, a third of the slots' index arithmetic.
-    static NDP_D bool strictly_inside_direct(const RtiParams &P, const LdsMap &m, lp lds, double margin)
+    // ---------------------------------------------------------------- active set on the input bounds (QP_AUTO)
+    // The reference's QP solver iterates on every QP (HPIPM, cold start: nmpc_body_rate_ctl.py:71-74); any method that converges the
+    // same strictly convex QP is parity-equivalent, and the bounds that are ever active in the reference's envelope are
+    // the INPUT bounds (nmpc_body_rate_ctl.py:56-58).  Primal-dual active set (Hintermueller / Ito / Kunisch) on those: with the set
+    // A of pinned inputs (du = its step bound d), solve the equality-constrained QP, then
+    //     pinned, multiplier of the wrong sign      -> released          inactive, beyond a bound -> pinned there
+    // all at once; a set that reproduces itself satisfies the KKT conditions of the box-constrained QP -- it IS the solution.  One
+    // Riccati sweep per iteration (the interior-point loop: ~1.55 per iteration, 5-9 iterations); typically two or three sweeps from
+    // an empty set, ONE when the previous control step's set still holds (RtiIo::act: the warm start HPIPM is not given).
+    // A pin is a weight: the stage's R entry + as_gamma and the gradient - as_gamma d, i.e. the term as_gamma/2 (du - d)^2 -- it rides on
+    // the diagonal of Lam exactly where the interior-point loop's barrier terms ride (up to 1e10 in its last iterations), costs the sweep
+    // nothing, leaves du within lambda / as_gamma of d (then set to d exactly) and hands back the multiplier lambda = as_gamma (du - d).
+    // Velocity bounds are not pinned (a weight on a STATE makes the recursion stiff: see ROBUST): a violated one, a set that does not
+    // settle within as_iter_max sweeps, or a failed factorisation hand the QP to the interior-point loop, which starts from the base
+    // cost blocks whatever the pins did to them.
+#ifdef NDP_DEV_NO_AS5
+    static constexpr bool ASET = NSLOT <= 3;
+#else
+    static constexpr bool ASET = true;
+#endif
+    static constexpr int RUA = NC ? (NC * NU + 63) / 64 : NSLOT;     // 64-lane rounds over the 4N input bounds as they lie in ZU
+    // The set: one value per input bound, +1 pinned at its upper bound, -1 at its lower, 0 free.  Three-slot kernels: RUA registers per
+    // lane.  Five-slot kernels (N = 40: 500 of 512 registers before this existed): parked in LDS (LdsMap::AS, as doubles) once the kept
+    // set has arrived, read where it is looked at.
+    static constexpr bool A_LDS = NSLOT > 3;
+    struct ActSet { vi a[RUA]; };
+    static NDP_D vi a_get(const ActSet &A, const LdsMap &m, lp lds, int t, vi e)
+    {
+        if constexpr (A_LDS) return W::d2i(W::ld(lds, e + m.AS));
+        else return A.a[t];
+    }
+    static NDP_D void a_put(ActSet &A, const LdsMap &m, lp lds, int t, vi e, vi v)
+    {
+        if constexpr (A_LDS) W::st(lds, e + m.AS, W::i2d(v));
+        else A.a[t] = v;
+    }
+    // element index of round t (lanes past the end repeat the last element: identical duplicates everywhere)
+    static NDP_D vi a_elem(const RtiParams &P, vi lane, int t) { return W::imin(lane + 64 * t, horizon(P) * NU - 1); }
+    // A_LDS: the kept set (requested by as_issue) -> its LDS area; called where the step waits for its inputs anyway
+    static NDP_D void as_park(const RtiParams &P, const LdsMap &m, lp lds, ActSet &A)
+    {
+        if constexpr (A_LDS) {
+            vi lane = W::lane_here();
+            for (int t = 0; t < RUA; ++t) W::st(lds, a_elem(P, lane, t) + m.AS, W::i2d(A.a[t]));
+            W::sync();
+        }
+    }
+    static NDP_D void as_clear(const RtiParams &P, const LdsMap &m, lp lds, ActSet &A)
+    {
+        vi lane = W::lane_here();
+        for (int t = 0; t < RUA; ++t) a_put(A, m, lds, t, a_elem(P, lane, t), vi(0));
+        if constexpr (A_LDS) W::sync();
+    }
+
+    // request the instance's kept set (no wait here)
+    static NDP_D void as_issue(const RtiParams &P, const RtiIo &io, ActSet &A)
+    {
+        const int nzu = horizon(P) * NU;
+        vi lane = W::lane();
+        for (int t = 0; t < RUA; ++t)
+            A.a[t] = io.act ? W::gld_i8(io.act, W::imin(lane + 64 * t, nzu - 1) + int(ACT_HDR)) : vi(0);
+    }
+    static NDP_D bool as_any(const RtiParams &P, const LdsMap &m, lp lds, const ActSet &A)
+    {
+        vi lane = W::lane_here();
+        vb nz = lane < 0;
+        for (int t = 0; t < RUA; ++t) nz = W::bor(nz, !(a_get(A, m, lds, t, a_elem(P, lane, t)) == 0));
+        return W::any(nz);
+    }
+    // cost blocks of the input rows <- base blocks + the pins of A (every input row is rewritten: released pins disappear)
+    static NDP_D void as_apply(const RtiParams &P, const LdsMap &m, lp lds, const ActSet &A)
+    {
+        const int nzu = horizon(P) * NU;
+        vi lane = W::lane_here();
+        for (int t = 0; t < RUA; ++t) {
+            vi e = W::imin(lane + 64 * t, nzu - 1);               // lanes past the end repeat the last element (identical duplicate stores)
+            vi c = e & 3;
+            vi cbk = (e >> 2) * int(CB_STRIDE) + c + m.CB;
+            vd cu = W::ld(lds, e + m.UI);
+            const vi at = a_get(A, m, lds, t, e);
+            vb up = at > 0, on = !(at == 0);
+            vd d = W::ld(lds, c + (m.KC + int(KC_LBU)) + W::sel(up, vi(int(SL_UB)), vi(0))) - cu;
+            vd w = W::sel(on, vd(P.as_gamma), vd(0.0));
+            W::st(lds, cbk + int(CB_DEU), P.dt * W::ld(lds, c + (m.KC + int(KC_RD))) + w);
+            W::st(lds, cbk + int(CB_RE), W::ld(lds, cbk + int(CB_RB)) - w * d);
+        }
+        W::sync();
+    }
+    // The sweep's solution (ZX|ZU) against the set it was made with.  Returns 0: the set reproduces itself, every free input and every
+    // velocity is inside its box (velocities by `vmargin`) -- the QP is solved, pinned inputs are set onto their bounds; 1: the set
+    // changed (A updated); 2: a velocity bound is violated or closer than vmargin -- not this method's case.
+    // With as_iter_max = 0 the test is rounds 1-5's: accepted only if inside EVERY bound by umargin = auto_margin -- what keeps the early
+    // exit within ~1e-6 of an interior-point solve stopped at mu <= tol (HPIPM, the oracle's qp_mode 1): at a slack t the barrier leaves a
+    // multiplier mu / t on an INACTIVE bound, which moves the solution by ~mu / (t * weight).  With the active set on, umargin = 0: the
+    // answer is the QP's exact solution, and an interior-point answer is compared with it at ITS accuracy (tests: the oracle at a tight
+    // tolerance).  The velocity margin stays: a velocity bound that close belongs to the interior-point loop.
+    // Evaluated without the constraint slots (which the interior-point loop needs, this does not): the 4N input bounds as they lie in
+    // ZU (element e: component e & 3), the 3(N-1) velocity bounds four lanes per stage (component 3 idle) -- no division by three.
+    // update = false (as_iter_max = 0): the set stays empty whatever the verdict (it is looked at again by the next RTI iteration).
+    static NDP_D int as_check(const RtiParams &P, const LdsMap &m, lp lds, ActSet &A, double umargin, double vmargin, bool update)
     {
         const int N = horizon(P), nzu = N * NU, nv4 = 4 * (N - 1);
-        constexpr int RUm = NC ? (NC * NU + 63) / 64 : NSLOT, RVm = NC ? (4 * (NC - 1) + 63) / 64 : NSLOT;   // rounds (run-time horizons: 7N - 3 <= 64 NSLOT, so 4N <= 64 NSLOT; surplus rounds repeat the last element)
+        constexpr int RVm = NC ? (4 * (NC - 1) + 63) / 64 : NSLOT;
         const vi lane = lane_it();
         const int io = m.XI - m.ZX;
-        // every LDS read of the test is requested before the first comparison (one wait), and the verdicts are combined without
-        // control flow (W::band)
-        vd zu[RUm], cu[RUm], lu[RUm], hu[RUm], zv[RVm], cv[RVm], lv[RVm], hv[RVm];
-        for (int t = 0; t < RUm; ++t) {
-            vi e = W::imin(lane + 64 * t, nzu - 1);               // lanes past the end repeat the last element
+        // every LDS read of the test is requested before the first comparison (one wait), the verdicts are combined without control flow
+        vd zu[RUA], cu[RUA], lu[RUA], hu[RUA], zv[RVm], cv[RVm], lv[RVm], hv[RVm];
+        vi at[RUA];
+        for (int t = 0; t < RUA; ++t) {
+            vi e = W::imin(lane + 64 * t, nzu - 1);
             vi c = e & 3;
+            at[t] = a_get(A, m, lds, t, e);
             zu[t] = W::ld(lds, e + m.ZU); cu[t] = W::ld(lds, e + (m.ZU + io));
             lu[t] = W::ld(lds, c + (m.KC + int(KC_LBU))); hu[t] = W::ld(lds, c + (m.KC + int(KC_UBU)));
         }
@@ -1409,12 +1514,47 @@ struct RtiWave {
             zv[t] = W::ld(lds, zo); cv[t] = W::ld(lds, zo + io);
             lv[t] = W::ld(lds, c + (m.KC + int(KC_LBV))); hv[t] = W::ld(lds, c + (m.KC + int(KC_UBV)));
         }
-        vb okv = lane >= 0;
-        for (int t = 0; t < RUm; ++t)
-            okv = W::band(okv, W::band(zu[t] > (lu[t] - cu[t]) + margin, zu[t] < (hu[t] - cu[t]) - margin));
+        vb vok = lane >= 0, same = lane >= 0, pinned = lane < 0;
+        vi na[RUA];
+        for (int t = 0; t < RUA; ++t) {
+            const vd lo = lu[t] - cu[t], hi = hu[t] - cu[t];
+            const vb up = at[t] > 0, dn = at[t] < 0, on = W::bor(up, dn);
+            // pinned: multiplier as_gamma (du - d) for an upper, as_gamma (d - du) for a lower bound; released when negative
+            const vb keep = W::band(on, W::sel(up, zu[t] - hi, lo - zu[t]) >= 0.0);
+            const vb vhi = W::band(!on, zu[t] > hi - umargin), vlo = W::band(!on, zu[t] < lo + umargin);
+            na[t] = W::sel(keep, at[t], W::sel(vhi, vi(1), W::sel(vlo, vi(-1), vi(0))));
+            same = W::band(same, na[t] == at[t]);
+            pinned = W::bor(pinned, on);
+        }
         for (int t = 0; t < RVm; ++t)
-            okv = W::band(okv, W::band(zv[t] > (lv[t] - cv[t]) + margin, zv[t] < (hv[t] - cv[t]) - margin));
-        return W::all(okv);
+            vok = W::band(vok, W::band(zv[t] > (lv[t] - cv[t]) + vmargin, zv[t] < (hv[t] - cv[t]) - vmargin));
+        if (NDP_RARELY(!W::all(vok))) return 2;
+        if (W::all(same)) {
+            if (NDP_RARELY(W::any(pinned))) {
+                for (int t = 0; t < RUA; ++t) {
+                    vi e = W::imin(lane + 64 * t, nzu - 1);
+                    W::stp(lds, e + m.ZU, W::sel(at[t] > 0, hu[t], lu[t]) - cu[t], !(at[t] == 0));
+                }
+                W::sync();
+            }
+            return 0;
+        }
+        if (update) {
+            for (int t = 0; t < RUA; ++t) a_put(A, m, lds, t, W::imin(lane + 64 * t, nzu - 1), na[t]);
+            if constexpr (A_LDS) W::sync();
+        }
+        return 1;
+    }
+    // keep the set for the next control step (and the sweep count for ndp_get_active_set)
+    static NDP_D void as_store(const RtiParams &P, const LdsMap &m, lp lds, const RtiIo &io, const ActSet &A, int sweeps)
+    {
+        const int nzu = horizon(P) * NU;
+        vi lane = W::lane_here();
+        for (int t = 0; t < RUA; ++t) {
+            vi e = lane + 64 * t;
+            W::gst_i8(io.act, e + int(ACT_HDR), a_get(A, m, lds, t, a_elem(P, lane, t)), e < nzu);
+        }
+        W::gsti(reinterpret_cast<int *>(io.act), sweeps);
     }
 
     static NDP_D double absmax(lp lds, int off, int n)
@@ -1707,6 +1847,13 @@ struct RtiWave {
         else build_tables(m, T);
         stamp(io, m, 1);
         const int n_rti = NR ? NR : P.n_rti;
+        // QP_AUTO's active set (as_check), kept from the previous control step and across this step's RTI iterations
+        const bool as_on = ASET && P.qp_mode == QP_AUTO && P.as_iter_max > 0;
+        ActSet A;
+        if (as_on) as_issue(P, io, A);       // (in flight under the cost / linearisation phases)
+        else for (int t = 0; t < RUA; ++t) A.a[t] = vi(0);
+        bool act_dirty = false;
+        int sweeps = 0;
         // Several RTI iterations per step at a compile-time count (NR >= 2, config 5): the iteration loop stays a LOOP (its body is
         // 17 k instructions), so inputs requested in front of it and replaced inside it are loop-carried values -- 23 doubles per lane
         // held (in scratch memory, as it turned out) across the first iteration's sweeps and interior-point loop for nothing.  Those
@@ -1725,6 +1872,7 @@ struct RtiWave {
             if (io.f_in_lds)
                 for (int t = 0; t < RF; ++t) ib.f[t] = fkeep[t];
             commit_inputs(P, m, ib, lds, it == 0, io);
+            if (A_LDS && it == 0) { if (as_on) as_park(P, m, lds, A); else as_clear(P, m, lds, A); }
             stamp(io, m, 2);
             build_cost(P, m, lds);
             stamp(io, m, 3);
@@ -1772,18 +1920,40 @@ struct RtiWave {
             bool done = false, failed = false;
             int st = 0;
             if (DEFER || P.qp_mode == QP_AUTO) {
-                // equality-constrained minimiser strictly inside the box => it IS the QP solution (all multipliers 0)
-                stamp(io, m, 5);
-                bool ok = riccati_sweep(P, m, T, lds, &io);
-                stamp(io, m, 7);
-                if (!ok) { st = 4; failed = true; }
-                // (the constraint slots are built only at the interior-point loop's door: keeping ~90 more registers live across the
-                // sweep forces the MFMA accumulators into AGPRs with copies on every dependency)
-                done = (P.qp_mode == QP_AUTO && strictly_inside_direct(P, m, lds, P.auto_margin)) || !ok;   // then the step is the sweep's solution, read where it lies (ZX|ZU)
+                // Equality-constrained minimiser inside the box => it IS the QP solution (all multipliers 0).  Otherwise, and when the
+                // previous step left a set: active-set iterations on the input bounds (as_check) -- each one this same sweep again.
+                if (NDP_RARELY(as_on && as_any(P, m, lds, A))) as_apply(P, m, lds, A);          // warm start: the kept set's pins
+                const int sweeps0 = sweeps;            // (as_iter_max counts per QP, `sweeps` over the step's RTI iterations)
+                for (;;) {
+                    stamp(io, m, 5);
+                    bool ok = riccati_sweep(P, m, T, lds, &io);
+                    stamp(io, m, 7);
+                    ++sweeps;
+                    if (NDP_RARELY(!ok)) {
+                        // the plain sweep failed: no usable step (as in rounds 1-5); a sweep WITH pins failed: the interior-point loop's case
+                        if (!(as_on && as_any(P, m, lds, A))) { st = 4; failed = true; done = true; }
+                        break;
+                    }
+                    if (P.qp_mode != QP_AUTO) break;
+                    // (the constraint slots are built only at the interior-point loop's door: keeping ~90 more registers live across the
+                    // sweep forces the MFMA accumulators into AGPRs with copies on every dependency)
+                    const int verdict = as_check(P, m, lds, A, as_on ? 0.0 : P.auto_margin, P.auto_margin, as_on);
+                    if (verdict == 0) { done = true; break; }      // then the step is the sweep's solution, read where it lies (ZX|ZU)
+                    if (NDP_RARELY(as_on && verdict == 1 && sweeps - sweeps0 <= P.as_iter_max)) {
+                        act_dirty = true;
+                        as_apply(P, m, lds, A);
+                        continue;
+                    }
+                    break;
+                }
             }
             const int zsrc = done ? m.ZX : m.CX;       // ZX|ZU and CX|CU are laid out alike
             if (IPM_RARE ? NDP_RARELY(!done) : !done) {
                 if (DEFER) return true;
+                if (as_on) {                           // the interior-point loop's answer carries no set: the next step starts cold
+                    act_dirty = true;
+                    as_clear(P, m, lds, A);
+                }
                 if constexpr (NSLOT <= 3) { if (io.ipm_ctr && it == 0) W::count64(io.ipm_ctr); }   // (the five-slot kernels sit at the register limit and have no automatic rule)
                 Slots S;
                 build_slots(P, m, S);
@@ -1840,6 +2010,10 @@ struct RtiWave {
         stamp(io, m, 8);
         W::gsti(io.status, status);
         W::gsti(io.iters, iters);
+        if (as_on && io.act) {
+            if (NDP_RARELY(act_dirty)) as_store(P, m, lds, io, A, sweeps);
+            else W::gsti(reinterpret_cast<int *>(io.act), sweeps);
+        }
         if (io.f_late) W::late_publish(late_prev, io.late_gsize, io.late_done_word);
         return false;
     }

@@ -72,6 +72,10 @@ struct WaveGfx950 {
     static NDP_D vd gldu(const double *g, vi off) { return g[off]; }
     static NDP_D vd gldfu(const float *g, vi off) { return (double)g[off]; }
     static NDP_D vi gldi(const int *g, vi off) { return g[off]; }
+    static NDP_D vi gld_i8(const signed char *g, vi off) { return (int)g[off]; }
+    static NDP_D vi d2i(vd a) { return (int)a; }
+    static NDP_D vd i2d(vi a) { return (double)a; }
+    static NDP_D void gst_i8(signed char *g, vi off, vi v, vb p) { if (p) g[off] = (signed char)v; }
     static NDP_D vi imin(vi a, vi b) { return a < b ? a : b; }
     static NDP_D void gst(double *g, vi off, vd v, vb p) { if (p) g[off] = v; }
     // element i of the concatenation [a (n elements) | b]: one store through a per-lane pointer instead of two predicated ones

@@ -50,6 +50,8 @@ void orc_default_cfg(orc_cfg *c)
     c->auto_margin = 0.1;
     c->refine = 2;
     c->refine_gamma = 1e4;
+    c->as_iter_max = 8;
+    c->as_gamma = 1e12;
 }
 
 /* ---------------------------------------------------------------- dynamics */
@@ -451,11 +453,12 @@ static int refine_solution(int N, const double *A, const double *B, const double
     return 0;
 }
 
+/* act: the kept active set of the input bounds (qp_mode 0, as_iter_max > 0), [4N] signed bytes in / out, or NULL */
 static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B, const double *b,
                        const double *Q, const double *q, const double *Rd, const double *r,
                        const double *dx0, const double *lu, const double *uu,
                        const double *lv, const double *uv,
-                       double *dx, double *du, orc_stats *st, qp_ws *w)
+                       double *dx, double *du, orc_stats *st, qp_ws *w, signed char *act)
 {
     const int m = NU * N + 3 * (N - 1);
     ipm_con *cn = w->cn;
@@ -478,20 +481,62 @@ static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B
             cn[n].lo = lv[k * 3 + i]; cn[n].hi = uv[k * 3 + i];
         }
 
-    /* qp_mode 0 (the device's QP_AUTO): the equality-constrained minimiser, if it lies auto_margin inside every bound,
-     * IS the QP solution (all multipliers zero) -- no interior-point iterations.  qp_mode 1 (default): HPIPM-like, always iterate. */
+    /* qp_mode 0 (the device's QP_AUTO; qp_mode 1, the default, is HPIPM-like: always iterate).  as_iter_max = 0: the
+     * equality-constrained minimiser, if it lies auto_margin inside every bound, IS the QP solution (all multipliers zero).
+     * as_iter_max > 0: primal-dual active-set iterations on the INPUT bounds, the device's rule (rti_wave.hpp: as_check) --
+     * inputs beyond a bound are pinned there by the weight as_gamma, pins whose multiplier as_gamma (du - d) has the wrong sign are
+     * released, all at once, one Riccati solve per iteration, until the set reproduces itself: the KKT conditions of the
+     * box-constrained QP then hold.  A velocity bound violated (or closer than auto_margin), a set that does not settle, a failed
+     * factorisation with pins: the interior-point loop below takes the QP. */
+    int sweeps = 0;
     if (c->qp_mode == 0) {
-        if (riccati_solve(N, A, B, b, Q, q, Rd, r, dx0, nx_, nu_, G)) { status = 4; failed = 1; goto done; }
-        int inside = 1;
-        for (int i = 0; i < m && inside; ++i) {
-            const double zn = con_value(&cn[i], nx_, nu_);
-            inside = zn > cn[i].lo + c->auto_margin && zn < cn[i].hi - c->auto_margin;
+        const int as_on = c->as_iter_max > 0;
+        const double um = as_on ? 0.0 : c->auto_margin;
+        const int nu = NU * N;
+        signed char a[NU * ORC_NMAX], na[NU * ORC_NMAX];
+        for (int i = 0; i < nu; ++i) a[i] = (as_on && act) ? act[i] : 0;
+        for (;;) {
+            int any = 0;
+            memcpy(Re, Rd, sizeof(double) * (size_t)nu);
+            memcpy(re, r, sizeof(double) * (size_t)nu);
+            for (int i = 0; i < nu; ++i)
+                if (a[i]) {
+                    Re[i] += c->as_gamma;
+                    re[i] -= c->as_gamma * (a[i] > 0 ? cn[i].hi : cn[i].lo);
+                    any = 1;
+                }
+            const int rc = riccati_solve(N, A, B, b, Q, q, Re, re, dx0, nx_, nu_, G);
+            ++sweeps;
+            if (rc) {
+                if (!any) { status = 4; failed = 1; goto done; }
+                break;
+            }
+            int vok = 1, same = 1;
+            for (int i = nu; i < m; ++i) {
+                const double zn = con_value(&cn[i], nx_, nu_);
+                vok = vok && zn > cn[i].lo + c->auto_margin && zn < cn[i].hi - c->auto_margin;
+            }
+            if (!vok) break;
+            for (int i = 0; i < nu; ++i) {
+                const double zn = nu_[i];
+                /* pinned: kept while its multiplier as_gamma (du - d) has the right sign, else released (not re-pinned in this pass);
+                 * free: beyond a bound -> pinned there */
+                if (a[i]) na[i] = ((a[i] > 0 ? zn - cn[i].hi : cn[i].lo - zn) >= 0.0) ? a[i] : 0;
+                else na[i] = zn > cn[i].hi - um ? 1 : (zn < cn[i].lo + um ? -1 : 0);
+                same = same && na[i] == a[i];
+            }
+            if (same) {
+                for (int i = 0; i < nu; ++i)
+                    if (a[i]) nu_[i] = a[i] > 0 ? cn[i].hi : cn[i].lo;       /* onto the bound exactly */
+                memcpy(zx, nx_, sizeof(double) * (size_t)(N + 1) * NX);
+                memcpy(zu, nu_, sizeof(double) * (size_t)N * NU);
+                if (as_on && act) memcpy(act, a, (size_t)nu);
+                goto done;
+            }
+            memcpy(a, na, (size_t)nu);
+            if (!(as_on && sweeps <= c->as_iter_max)) break;
         }
-        if (inside) {
-            memcpy(zx, nx_, sizeof(double) * (size_t)(N + 1) * NX);
-            memcpy(zu, nu_, sizeof(double) * (size_t)N * NU);
-            goto done;
-        }
+        if (as_on && act) memset(act, 0, (size_t)nu);          /* the interior-point loop's answer carries no set */
     }
     /* cold start (qp_solver_warm_start left at 0, nmpc_body_rate_ctl.py:73-74) */
     for (int i = 0; i < m; ++i) {
@@ -615,6 +660,7 @@ done:
         st->n_active = 0;
         for (int i = 0; i < m; ++i)
             st->n_active += (cn[i].ll > 1e-6) + (cn[i].lu > 1e-6);
+        st->as_sweeps = sweeps;
     }
     return status;
 }
@@ -625,8 +671,17 @@ int orc_qp_solve(const orc_cfg *c, int N, const double *A, const double *B, cons
                  const double *lv, const double *uv,
                  double *dx, double *du, orc_stats *st)
 {
+    return orc_qp_solve_as(c, N, A, B, b, Q, q, Rd, r, dx0, lu, uu, lv, uv, dx, du, st, NULL);
+}
+
+int orc_qp_solve_as(const orc_cfg *c, int N, const double *A, const double *B, const double *b,
+                    const double *Q, const double *q, const double *Rd, const double *r,
+                    const double *dx0, const double *lu, const double *uu,
+                    const double *lv, const double *uv,
+                    double *dx, double *du, orc_stats *st, signed char *act)
+{
     qp_ws *w = (qp_ws *)malloc(sizeof(qp_ws));
-    const int rc = qp_solve_ws(c, N, A, B, b, Q, q, Rd, r, dx0, lu, uu, lv, uv, dx, du, st, w);
+    const int rc = qp_solve_ws(c, N, A, B, b, Q, q, Rd, r, dx0, lu, uu, lv, uv, dx, du, st, w, act);
     free(w);
     return rc;
 }
@@ -682,7 +737,7 @@ typedef struct {
 } step_ws;
 
 static int step_ws_run(const orc_cfg *c, const double *x0, const double *xr, const double *ur,
-                       const double *f, double *X, double *U, double *u0, orc_stats *st, step_ws *ws)
+                       const double *f, double *X, double *U, double *u0, orc_stats *st, step_ws *ws, signed char *act)
 {
     const int N = c->N;
     double *w = ws->lin;
@@ -691,15 +746,16 @@ static int step_ws_run(const orc_cfg *c, const double *x0, const double *xr, con
     double *Q = uu + (size_t)N * NU, *q = Q + (size_t)(N + 1) * NX * NX;
     double *lv = q + (size_t)(N + 1) * NX, *uv = lv + (size_t)(N + 1) * 3;
     double *dx = uv + (size_t)(N + 1) * 3, *dx0 = dx + (size_t)(N + 1) * NX, *du = dx0 + NX;
-    orc_stats acc = {0, 0, 0, 0.0};
+    orc_stats acc = {0, 0, 0, 0.0, 0};
     for (int it = 0; it < c->n_rti; ++it) {
         orc_stats s1;
         orc_linearize(c, x0, xr, ur, f, X, U, A, B, b, Q, q, Rd, r, dx0, lu, uu, lv, uv);
-        qp_solve_ws(c, N, A, B, b, Q, q, Rd, r, dx0, lu, uu, lv, uv, dx, du, &s1, &ws->qp);
+        qp_solve_ws(c, N, A, B, b, Q, q, Rd, r, dx0, lu, uu, lv, uv, dx, du, &s1, &ws->qp, act);
         /* full step, no line search */
         for (int i = 0; i < (N + 1) * NX; ++i) X[i] += dx[i];
         for (int i = 0; i < N * NU; ++i) U[i] += du[i];
         acc.ipm_iters += s1.ipm_iters;
+        acc.as_sweeps += s1.as_sweeps;
         acc.n_active = s1.n_active;
         acc.mu = s1.mu;
         if (s1.status && !acc.status) acc.status = s1.status;
@@ -717,7 +773,7 @@ int orc_step(const orc_cfg *c, const double *x0, const double *xr, const double 
 {
     if (c->N > ORC_NMAX) return -1;
     step_ws *ws = (step_ws *)malloc(sizeof(step_ws));
-    const int rc = step_ws_run(c, x0, xr, ur, f, X, U, u0, st, ws);
+    const int rc = step_ws_run(c, x0, xr, ur, f, X, U, u0, st, ws, NULL);
     free(ws);
     return rc;
 }
@@ -734,6 +790,13 @@ int orc_num_threads(void)
 int orc_step_batch(const orc_cfg *c, int B, const double *x0, const double *xr, const double *ur,
                    const double *f, double *X, double *U, double *u0, int *status, int *ipm_iters,
                    int nthreads)
+{
+    return orc_step_batch_as(c, B, x0, xr, ur, f, X, U, u0, status, ipm_iters, nthreads, NULL, NULL);
+}
+
+int orc_step_batch_as(const orc_cfg *c, int B, const double *x0, const double *xr, const double *ur,
+                      const double *f, double *X, double *U, double *u0, int *status, int *ipm_iters,
+                      int nthreads, signed char *act, int *sweeps)
 {
     const int N = c->N;
     int worst = 0;
@@ -752,7 +815,8 @@ int orc_step_batch(const orc_cfg *c, int B, const double *x0, const double *xr, 
             orc_stats s;
             step_ws_run(c, x0 + (size_t)i * NX, xr + (size_t)i * (N + 1) * NX, ur + (size_t)i * N * NU,
                         f ? f + (size_t)i * (N + 1) * 3 : NULL, X + (size_t)i * (N + 1) * NX,
-                        U + (size_t)i * N * NU, u0 + (size_t)i * NU, &s, ws);
+                        U + (size_t)i * N * NU, u0 + (size_t)i * NU, &s, ws, act ? act + (size_t)i * N * NU : NULL);
+            if (sweeps) sweeps[i] = s.as_sweeps;
             if (status) status[i] = s.status;
             if (ipm_iters) ipm_iters[i] = s.ipm_iters;
             if (s.status > worst) worst = s.status;

@@ -52,6 +52,11 @@ typedef struct {
      * (nmpc_body_rate_ctl.py:72) refines its KKT solves likewise [acados-knowledge]. */
     int refine;
     double refine_gamma;
+    /* qp_mode 0 only -- NOT part of the reference's algorithm (HPIPM iterates on every QP, cold-started): the device's active-set
+     * iterations on the input bounds (ndp_cfg.as_iter_max, rti_wave.hpp: as_check), restated so that the device's default mode has a
+     * CPU twin doing the same arithmetic.  The parity claim against the reference's QP solver is made against qp_mode 1. */
+    int as_iter_max;    /* sweeps with pinned inputs allowed behind the first one (default 8; 0 = the early exit only) */
+    double as_gamma;    /* weight of a pin (default 1e12) */
 } orc_cfg;
 
 typedef struct {
@@ -59,6 +64,7 @@ typedef struct {
     int ipm_iters;    /* summed over rti iterations */
     int n_active;     /* bounds active at the last QP solution */
     double mu;        /* final complementarity */
+    int as_sweeps;    /* qp_mode 0: Riccati sweeps of the active-set iterations, summed over rti iterations */
 } orc_stats;
 
 void orc_default_cfg(orc_cfg *c);
@@ -116,6 +122,17 @@ int orc_step(const orc_cfg *c, const double *x0, const double *xr, const double 
 int orc_step_batch(const orc_cfg *c, int B, const double *x0, const double *xr, const double *ur,
                    const double *f, double *X, double *U, double *u0, int *status, int *ipm_iters,
                    int nthreads);
+/* the same with the instances' kept active sets (qp_mode 0, as_iter_max > 0): act[B][4N] signed bytes, in = the previous step's
+ * sets (the warm start), out = this step's; sweeps[B] out.  Either may be NULL (no warm start / not reported). */
+int orc_step_batch_as(const orc_cfg *c, int B, const double *x0, const double *xr, const double *ur,
+                      const double *f, double *X, double *U, double *u0, int *status, int *ipm_iters,
+                      int nthreads, signed char *act, int *sweeps);
+/* orc_qp_solve with an active set handed in and out (act[4N], or NULL) */
+int orc_qp_solve_as(const orc_cfg *c, int N, const double *A, const double *B, const double *b,
+                    const double *Q, const double *q, const double *Rd, const double *r,
+                    const double *dx0, const double *lu, const double *uu,
+                    const double *lv, const double *uv,
+                    double *dx, double *du, orc_stats *st, signed char *act);
 int orc_num_threads(void);
 
 /* a7: MLP 6-128-64-128-3, fp32 (nn_net.py:7-18). blob = W1(128x6) b1 W2(64x128) b2

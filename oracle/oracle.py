@@ -25,11 +25,12 @@ class OrcCfg(C.Structure):
         ("mu0", C.c_double), ("thr0", C.c_double), ("tol", C.c_double), ("tau", C.c_double),
         ("iter_max", C.c_int), ("qp_mode", C.c_int), ("auto_margin", C.c_double), ("mu_floor", C.c_double),
         ("refine", C.c_int), ("refine_gamma", C.c_double),
+        ("as_iter_max", C.c_int), ("as_gamma", C.c_double),
     ]
 
 
 class OrcStats(C.Structure):
-    _fields_ = [("status", C.c_int), ("ipm_iters", C.c_int), ("n_active", C.c_int), ("mu", C.c_double)]
+    _fields_ = [("status", C.c_int), ("ipm_iters", C.c_int), ("n_active", C.c_int), ("mu", C.c_double), ("as_sweeps", C.c_int)]
 
 
 def build(force=False):
@@ -124,6 +125,18 @@ def qp_solve(cfg, qp):
     return dx, du, st
 
 
+def qp_solve_as(cfg, qp, act=None):
+    """qp_solve with the active set of the input bounds handed in and out (act: int8[N,4] or None); qp_mode 0."""
+    N = qp["A"].shape[0]
+    dx, du = np.zeros((N + 1, NX)), np.zeros((N, NU))
+    st = OrcStats()
+    assert act is None or (act.dtype == np.int8 and act.flags.c_contiguous and act.size == N * NU)
+    lib().orc_qp_solve_as(C.byref(cfg), C.c_int(N),
+                          *[_p(_f64(qp[k])) for k in ("A", "B", "b", "Q", "q", "Rd", "r", "dx0", "lu", "uu", "lv", "uv")],
+                          _p(dx), _p(du), C.byref(st), _p(act))
+    return dx, du, st
+
+
 def qp_riccati(qp):
     N = qp["A"].shape[0]
     dx, du = np.zeros((N + 1, NX)), np.zeros((N, NU))
@@ -152,6 +165,22 @@ def step_batch(cfg, x0, xr, ur, f, X, U, nthreads=0):
     lib().orc_step_batch(C.byref(cfg), C.c_int(B), _p(x0), _p(xr), _p(ur), _p(f), _p(X), _p(U), _p(u0),
                          _p(status), _p(iters), C.c_int(nthreads))
     return u0, status, iters
+
+
+def step_batch_as(cfg, x0, xr, ur, f, X, U, act, nthreads=0):
+    """step_batch with the instances' kept active sets (act: int8[B,N,4], updated in place; qp_mode 0): returns u0, status,
+    ipm_iters, sweeps."""
+    B = x0.shape[0]
+    assert X.dtype == np.float64 and U.dtype == np.float64 and X.flags.c_contiguous and U.flags.c_contiguous
+    assert act is None or (act.dtype == np.int8 and act.flags.c_contiguous and act.shape == (B, cfg.N, NU))
+    x0, xr, ur, f = _f64(x0), _f64(xr), _f64(ur), _f64(f)
+    u0 = np.zeros((B, NU))
+    status = np.zeros(B, dtype=np.int32)
+    iters = np.zeros(B, dtype=np.int32)
+    sweeps = np.zeros(B, dtype=np.int32)
+    lib().orc_step_batch_as(C.byref(cfg), C.c_int(B), _p(x0), _p(xr), _p(ur), _p(f), _p(X), _p(U), _p(u0),
+                            _p(status), _p(iters), C.c_int(nthreads), _p(act), _p(sweeps))
+    return u0, status, iters, sweeps
 
 
 def num_threads():

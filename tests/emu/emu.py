@@ -28,10 +28,13 @@ def lib():
     return _lib
 
 
-def default_cfg(N=20, n_rti=1, use_fd=False, qp_mode=0):
+def default_cfg(N=20, n_rti=1, use_fd=False, qp_mode=0, as_iter_max=None):
+    """as_iter_max: None = the product's default (active-set iterations on); 0 = rounds 1-5's QP_AUTO (early exit or interior point)."""
     c = NdpCfg()
     lib().emu_default_cfg(C.byref(c))
     c.N, c.n_rti, c.use_fd, c.qp_mode = N, n_rti, int(use_fd), qp_mode
+    if as_iter_max is not None:
+        c.as_iter_max = int(as_iter_max)
     return c
 
 
@@ -45,7 +48,12 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def rti_step(cfg, x0, xr, ur, f, X, U, dump=False):
+def act_record(N):
+    """An empty kept-active-set record of one instance (RtiIo::act): int32 sweeps + one signed byte per input bound."""
+    return np.zeros(lib().emu_act_pitch(int(N)), dtype=np.int8)
+
+
+def rti_step(cfg, x0, xr, ur, f, X, U, dump=False, act=None):
     x0, xr, ur = (np.ascontiguousarray(a, dtype=np.float64) for a in (x0, xr, ur))
     f = None if f is None else np.ascontiguousarray(f, dtype=np.float32)
     assert X.dtype == np.float64 and U.dtype == np.float64 and X.flags.c_contiguous and U.flags.c_contiguous
@@ -54,11 +62,17 @@ def rti_step(cfg, x0, xr, ur, f, X, U, dump=False):
     counters = (C.c_long * 5)()
     n = lib().emu_lds_doubles(cfg.N)
     lds = np.zeros(n) if dump else None
-    rc = lib().emu_rti_step(C.byref(cfg), _p(x0), _p(xr), _p(ur), _p(f), _p(X), _p(U), _p(u0),
-                            C.byref(status), C.byref(iters), _p(lds), counters)
+    assert act is None or (act.dtype == np.int8 and act.flags.c_contiguous)
+    rc = lib().emu_rti_step_act(C.byref(cfg), _p(x0), _p(xr), _p(ur), _p(f), _p(X), _p(U), _p(u0),
+                                C.byref(status), C.byref(iters), _p(lds), counters, _p(act))
     assert rc == 0
     return u0, status.value, iters.value, lds, dict(mfma=counters[0], lds_ld=counters[1], lds_st=counters[2],
                                                    readlane=counters[3], mfma4=counters[4])
+
+
+def act_view(act):
+    """(sweeps, set[N,4]) of a kept-active-set record."""
+    return int(act[:4].view(np.int32)[0]), act[4:].reshape(-1, 4)
 
 
 def rti_step_defer(cfg, x0, xr, ur, f, X, U):

@@ -14,8 +14,20 @@ int emu_lds_doubles(int N) { return ndp::lds_doubles(N) + ndp::DBG_EXTRA; }
 int emu_lds_layout(int N, int *out8) { ndp::lds_layout(N, out8); return 0; }
 
 // One instance, one emulated wave.  counters: [mfma (16x16x4), lds_ld, lds_st, readlane, mfma4 (4x4x4, four blocks)]
+// act: the instance's kept active-set record (RtiIo::act: ndp::act_pitch(N) bytes), or null
+int emu_rti_step_act(const ndp_cfg *cfg, const double *x0, const double *xr, const double *ur, const float *f,
+                     double *X, double *U, double *u0, int *status, int *iters, double *lds_dump, long *counters, signed char *act);
+
+int emu_act_pitch(int N) { return ndp::act_pitch(N); }
+
 int emu_rti_step(const ndp_cfg *cfg, const double *x0, const double *xr, const double *ur, const float *f,
                  double *X, double *U, double *u0, int *status, int *iters, double *lds_dump, long *counters)
+{
+    return emu_rti_step_act(cfg, x0, xr, ur, f, X, U, u0, status, iters, lds_dump, counters, nullptr);
+}
+
+int emu_rti_step_act(const ndp_cfg *cfg, const double *x0, const double *xr, const double *ur, const float *f,
+                     double *X, double *U, double *u0, int *status, int *iters, double *lds_dump, long *counters, signed char *act)
 {
     ndp::RtiParams P = ndp::to_params(*cfg);
     const int n = ndp::lds_doubles(P.N);
@@ -28,6 +40,7 @@ int emu_rti_step(const ndp_cfg *cfg, const double *x0, const double *xr, const d
     std::vector<int> tb(ndp::TB_WORDS);
     ndp::fill_tables(P.N, tb.data(), cfg->qp_precision >= 3 ? 1 : 0);
     io.tables = tb.data();
+    io.act = act;
     const int ns = ndp::slots_for(P.N);
     // horizon 20 and the 5-slot form run as the product does (host-built tables; N = 20 also compile-time horizon);
     // the other horizons build the tables in the wave program

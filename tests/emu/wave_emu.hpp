@@ -127,6 +127,10 @@ struct Wave {
     static vd gldu(const double *g, const vi &off) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = g[off.v[l]]; return o; }
     static vd gldfu(const float *g, const vi &off) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)g[off.v[l]]; return o; }
     static vi gldi(const int *g, const vi &off) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = g[off.v[l]]; return o; }
+    static vi d2i(const vd &a) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = (int)a.v[l]; return o; }
+    static vd i2d(const vi &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)a.v[l]; return o; }
+    static vi gld_i8(const signed char *g, const vi &off) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = (int)g[off.v[l]]; return o; }
+    static void gst_i8(signed char *g, const vi &off, const vi &val, const vb &p) { for (int l = 0; l < 64; ++l) if (p.v[l]) g[off.v[l]] = (signed char)val.v[l]; }
     static vi imin(const vi &a, const vi &b) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return o; }
     static void gst2(double *a, double *b, const vi &i, int n, const vd &val) { for (int l = 0; l < 64; ++l) (i.v[l] < n ? a + i.v[l] : b + (i.v[l] - n))[0] = val.v[l]; }
     static void gsti(int *g, int val) { if (g) *g = val; }

@@ -17,6 +17,10 @@ from ndp_nmpc_qd_amd import synth
 pytestmark = pytest.mark.gpu
 
 RTOL_U = 1e-5
+# QP_AUTO as rounds 1-5 had it (early exit auto_margin inside the box, else the interior-point loop) -- the tests below that are ABOUT
+# the interior-point code in the automatic mode (iteration counts against the always-iterating oracle, the work list that re-balances
+# interior-point solves) switch the active-set iterations off; tests/test_active_set_gpu.py covers the default.
+LEGACY = dict(as_iter_max=0)
 
 
 def _assert_u(u, uo, tol=RTOL_U):
@@ -99,7 +103,7 @@ def test_active_bounds_and_infeasible_start(ndp, oracle):
     U0 = b["ur"].copy()
     U0[::4, :, 0] = 7.5         # > w_max for a quarter of the instances
     U0[1::4, 3, 3] = -1.0       # < c_min
-    eng = ndp.BatchedNMPC(B)
+    eng = ndp.BatchedNMPC(B, **LEGACY)
     eng.set_iterate(b["xr"], U0)
     u0 = eng.update(b["x0"], b["xr"], b["ur"], raise_on_status=False)
     u0o, sto, ito, Xo, Uo = _oracle_batch(oracle, b, U=U0.copy())
@@ -559,7 +563,7 @@ def test_auto_mode_against_the_interior_point_oracle_under_large_perturbations(n
     B = 768
     for seed, kw in ((2, dict(pos_sigma=0.5, vel_sigma=1.0, quat_sigma=0.15)), (4, dict(pos_sigma=1.0, vel_sigma=2.0, quat_sigma=0.3))):
         b = synth.make_batch(B, seed=seed, **kw)
-        eng = ndp.BatchedNMPC(B)
+        eng = ndp.BatchedNMPC(B, **LEGACY)
         cfg = oracle.default_cfg()
         eng.reset(b["xr"], b["ur"])
         X, U = b["xr"].copy(), b["ur"].copy()
@@ -576,7 +580,7 @@ def test_auto_mode_against_the_interior_point_oracle_under_large_perturbations(n
         assert n_ipm > 100
         # the oracle's own early-exit mode (cfg.qp_mode = 0) is the same decision rule: identical iteration counts
         cfg0 = oracle.default_cfg()
-        cfg0.qp_mode = 0
+        cfg0.qp_mode, cfg0.as_iter_max = 0, 0
         X0, U0 = b["xr"].copy(), b["ur"].copy()
         eng.reset(b["xr"], b["ur"])
         u0 = eng.update(b["x0"], b["xr"], b["ur"], raise_on_status=False)
@@ -647,7 +651,7 @@ def test_step_ex_returns_iterate_and_status_from_the_same_call(ndp, oracle):
     read after solve_for_x0: solver.get / solver.status), through the packed pinned path (small batch) and the direct path."""
     for B in (3, 700):                                  # 3: inputs fit the 1 MiB pinned mirror; 700: they do not
         b = synth.make_batch(B, seed=31, pos_sigma=0.5, vel_sigma=1.0, quat_sigma=0.15)
-        eng = ndp.BatchedNMPC(B)
+        eng = ndp.BatchedNMPC(B, **LEGACY)
         eng.reset(b["xr"], b["ur"])
         u0, X, U, st, it = eng.update(b["x0"], b["xr"], b["ur"], raise_on_status=False, full=True)
         X2, U2 = eng.get_iterate()
@@ -672,7 +676,7 @@ def test_work_queue_gives_the_same_answers(ndp, oracle, mlp_blob):
         kw = dict(other=b["other"], ego_xy=b["ego_xy"]) if disturbance else {}
         res = {}
         for wq in (1, 2):
-            eng = ndp.BatchedNMPC(B, disturbance=disturbance, work_queue=wq)
+            eng = ndp.BatchedNMPC(B, disturbance=disturbance, work_queue=wq, **LEGACY)
             assert eng.work_queue == (wq == 1)
             eng.reset(b["xr"], b["ur"])
             outs = []
@@ -704,8 +708,8 @@ def test_work_list_switches_itself_on_when_the_steps_iterate(ndp, oracle):
     B = 2048
     hard = synth.make_batch(B, seed=57, downwash=False, pos_sigma=0.5, vel_sigma=1.0, quat_sigma=0.15)
     easy = synth.make_batch(B, seed=57, downwash=False)
-    eng = ndp.BatchedNMPC(B)
-    ref = {wq: ndp.BatchedNMPC(B, work_queue=wq) for wq in (1, 2)}
+    eng = ndp.BatchedNMPC(B, **LEGACY)
+    ref = {wq: ndp.BatchedNMPC(B, work_queue=wq, **LEGACY) for wq in (1, 2)}
     assert not eng.work_queue and ref[1].work_queue and not ref[2].work_queue
 
     def run(b, n):
@@ -924,13 +928,13 @@ def test_config5_shape_with_perturbed_starts_runs_the_interior_point_kernels(ndp
     bs = {k: np.ascontiguousarray(b[k][sample]) for k in ("x0", "xr", "ur")}
     res = {}
     for name, qp_mode, wq in (("ipm_in_place", 1, 2), ("auto_work_list", 0, 1), ("auto_in_place", 0, 2)):
-        eng = ndp.BatchedNMPC(B, N=N, n_rti=n_rti, qp_mode=qp_mode, work_queue=wq)
+        eng = ndp.BatchedNMPC(B, N=N, n_rti=n_rti, qp_mode=qp_mode, work_queue=wq, **LEGACY)
         assert eng.work_queue == (wq == 1)
         eng.reset(b["xr"], b["ur"])
         u0, X, U, st, it = eng.update(b["x0"], b["xr"], b["ur"], raise_on_status=False, full=True)
         res[name] = (u0, X, U, st, it)
         cfg = oracle.default_cfg(N=N, n_rti=n_rti)
-        cfg.qp_mode = qp_mode
+        cfg.qp_mode, cfg.as_iter_max = qp_mode, 0
         Xo, Uo = bs["xr"].copy(), bs["ur"].copy()
         uo, sto, ito = oracle.step_batch(cfg, bs["x0"], bs["xr"], bs["ur"], None, Xo, Uo)
         assert np.array_equal(st[sample], sto), name

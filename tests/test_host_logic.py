@@ -43,7 +43,8 @@ def test_default_cfg_carries_the_reference_constants():
     assert list(cfg.lbu) == [CP.w_min] * 3 + [CP.c_min] and list(cfg.ubu) == [CP.w_max] * 3 + [CP.c_max]
     assert list(cfg.lbv) == [CP.v_min] * 3 and list(cfg.ubv) == [CP.v_max] * 3
     assert CP.c_max == 9.81 / 0.36
-    assert C.sizeof(_lib.NdpCfg) == 10 * 4 + 8 * (4 + 10 + 4 + 4 + 4 + 3 + 3 + 8)      # (+ refine_gamma, round 4)
+    assert C.sizeof(_lib.NdpCfg) == 12 * 4 + 8 * (4 + 10 + 4 + 4 + 4 + 3 + 3 + 9)      # (+ as_iter_max, a pad word, as_gamma: round 6)
+    assert (cfg.as_iter_max, cfg.as_gamma) == (8, 1e12)
     assert cfg.ipm_refine == 2 and cfg.refine_gamma == 1e4
     assert cfg.auto_margin == 0.1 and cfg.qp_precision == 0 and cfg.work_queue == 0 and cfg.ts_nmpc == CP.ts_nmpc == 0.02
     # interior-point constants are the same on both sides

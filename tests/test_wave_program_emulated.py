@@ -18,9 +18,16 @@ def _assert_u(u, uo, tol=RTOL_U):
     assert np.all(np.abs(u - uo) <= tol * np.maximum(1.0, np.abs(uo))), (u, uo)
 
 
-def _run_pair(oracle, b, i, N=20, n_rti=1, use_fd=False, f=None, qp_mode=0, X0=None, U0=None):
-    cfg = E.default_cfg(N=N, n_rti=n_rti, use_fd=use_fd, qp_mode=qp_mode)
+# QP_AUTO as rounds 1-5 had it (early exit auto_margin inside the box, else the interior-point loop): the interior-point code is still
+# the product's qp_mode 1 and the fallback of the active-set iterations, and these tests keep checking it iteration for iteration
+LEGACY = 0
+
+
+def _run_pair(oracle, b, i, N=20, n_rti=1, use_fd=False, f=None, qp_mode=0, X0=None, U0=None, as_iter_max=None, tol=None):
+    cfg = E.default_cfg(N=N, n_rti=n_rti, use_fd=use_fd, qp_mode=qp_mode, as_iter_max=as_iter_max)
     cfgo = oracle.default_cfg(N=N, n_rti=n_rti, use_fd=use_fd)
+    if tol is not None:
+        cfgo.tol = tol
     X = (b["xr"][i] if X0 is None else X0).copy()
     U = (b["ur"][i] if U0 is None else U0).copy()
     Xo, Uo = X.copy(), U.copy()
@@ -50,7 +57,7 @@ def test_nominal_batch_matches_oracle(oracle, qp_mode):
 @pytest.mark.parametrize("seed,scale", [(2, 1.0), (3, 2.0), (4, 3.0), (9, 2.0)])
 def test_active_bounds_match_oracle(oracle, seed, scale):
     b = synth.make_batch(1, seed=seed, pos_sigma=scale, vel_sigma=2 * scale, quat_sigma=0.2)
-    (u0, st, it, X, U, _), (u0o, sto, Xo, Uo) = _run_pair(oracle, b, 0)
+    (u0, st, it, X, U, _), (u0o, sto, Xo, Uo) = _run_pair(oracle, b, 0, as_iter_max=LEGACY)
     assert sto.n_active > 0 and it > 0          # the early exit was refused, interior point ran
     assert st == 0 and sto.status == 0
     assert it == sto.ipm_iters
@@ -67,7 +74,7 @@ def test_iterate_outside_bounds_is_pulled_back(oracle):
     U0 = b["ur"][0].copy()
     U0[:, 0] = 7.5       # > w_max
     U0[3, 3] = -1.0      # < c_min
-    (u0, st, it, X, U, _), (u0o, sto, Xo, Uo) = _run_pair(oracle, b, 0, U0=U0)
+    (u0, st, it, X, U, _), (u0o, sto, Xo, Uo) = _run_pair(oracle, b, 0, U0=U0, as_iter_max=LEGACY)
     assert st == 0 and sto.status == 0 and it > 0
     _assert_u(u0, u0o, 1e-7)
     assert U[:, 0].max() <= 6 + 1e-6 and U[3, 3] >= -1e-6
@@ -219,7 +226,7 @@ def test_auto_margin_switches_between_early_exit_and_interior_point(oracle):
     uo, sto, ito = oracle.step_batch(cfgo, b["x0"], b["xr"], b["ur"], None, Xo, Uo)
     res = {}
     for margin in (0.0, 0.1, 100.0):
-        cfg = E.default_cfg()
+        cfg = E.default_cfg(as_iter_max=LEGACY)
         cfg.auto_margin = margin
         X, U = b["xr"][0].copy(), b["ur"][0].copy()
         u0, st, it, *_ = E.rti_step(cfg, b["x0"][0], b["xr"][0], b["ur"][0], None, X, U)
@@ -245,7 +252,7 @@ def test_auto_mode_inside_1e_5_of_the_interior_point_oracle_at_default_settings(
         for _ in range(2):
             uo, sto, ito = oracle.step_batch(cfgo, b["x0"], b["xr"], b["ur"], None, X, U)
             for i in range(B):
-                u0, st, it, *_ = E.rti_step(E.default_cfg(), b["x0"][i], b["xr"][i], b["ur"][i], None, Xe[i], Ue[i])
+                u0, st, it, *_ = E.rti_step(E.default_cfg(as_iter_max=LEGACY), b["x0"][i], b["xr"][i], b["ur"][i], None, Xe[i], Ue[i])
                 assert st == sto[i]
                 if st == 0:
                     assert np.all(np.abs(u0 - uo[i]) <= 1e-5 * np.maximum(1.0, np.abs(uo[i]))), (seed, i)
@@ -285,9 +292,9 @@ def test_work_list_producer_defers_without_writing(oracle):
     for i in range(48):
         X0, U0 = b["xr"][i].copy(), b["ur"][i].copy()
         Xd, Ud = X0.copy(), U0.copy()
-        deferred, u0d, std, itd = E.rti_step_defer(E.default_cfg(), b["x0"][i], b["xr"][i], b["ur"][i], None, Xd, Ud)
+        deferred, u0d, std, itd = E.rti_step_defer(E.default_cfg(as_iter_max=LEGACY), b["x0"][i], b["xr"][i], b["ur"][i], None, Xd, Ud)
         Xi, Ui = X0.copy(), U0.copy()
-        u0i, sti, iti, *_ = E.rti_step(E.default_cfg(), b["x0"][i], b["xr"][i], b["ur"][i], None, Xi, Ui)
+        u0i, sti, iti, *_ = E.rti_step(E.default_cfg(as_iter_max=LEGACY), b["x0"][i], b["xr"][i], b["ur"][i], None, Xi, Ui)
         assert deferred == (iti > 0)
         if deferred:
             n_def += 1
@@ -310,7 +317,7 @@ def test_any_horizon_matches_oracle(oracle, N):
     for qp_mode in (0, 1):
         for seed, kw in ((1, {}), (2, dict(pos_sigma=0.6, vel_sigma=1.2, quat_sigma=0.2))):
             b = synth.make_batch(1, N=N, seed=seed, **kw)
-            (u0, st, it, X, U, cnt), (u0o, sto, Xo, Uo) = _run_pair(oracle, b, 0, N=N, qp_mode=qp_mode)
+            (u0, st, it, X, U, cnt), (u0o, sto, Xo, Uo) = _run_pair(oracle, b, 0, N=N, qp_mode=qp_mode, as_iter_max=LEGACY)
             assert st == sto.status
             _assert_u(u0, u0o, 1e-8)
             np.testing.assert_allclose(X, Xo, atol=1e-8)
