@@ -279,6 +279,7 @@ struct KernargLate {
         return t;
     }
 };
+static_assert(offsetof(KernArgs, P) == 0, "WaveGfx950::late_params reads the parameter block at the start of the argument segment");
 static_assert(std::is_standard_layout<KernArgs>::value && std::is_trivially_copyable<KernArgs>::value,
               "KernargLate addresses members of the one kernel argument by offsetof");
 #define NDP_TA_LATE(L, f) ((L).template get<decltype(TickArgs::f)>((unsigned)(offsetof(KernArgs, ta) + offsetof(TickArgs, f))))
@@ -2154,6 +2155,11 @@ static size_t nus(const ndp_handle *h) { return (size_t)h->cfg.batch * h->cfg.N 
 static size_t nfs(const ndp_handle *h) { return (size_t)h->cfg.batch * (h->cfg.N + 1) * 3; }
 static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
 static size_t act_bytes(const ndp_handle *h) { return (size_t)h->cfg.batch * (size_t)act_pitch(h->cfg.N); }
+// the step's iteration words (RtiIo::iters) -> the caller's interior-point iteration counts
+static void copy_ipm_iters(int32_t *dst, const int32_t *src, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) dst[i] = src[i] & ITERS_IPM_MASK;
+}
 
 // the shapes the work-queue form of rti_kernel is instantiated for (compile-time horizon and iteration count)
 static bool queue_shape(const ndp_handle *h)
@@ -3207,7 +3213,7 @@ static int step_end_locked(ndp_handle *h, double *u0, double *X_out, double *U_o
     if (u0) memcpy(u0, ho + h->off_u0, B * NU * 8);
     const int32_t *st = (const int32_t *)(ho + h->off_st);
     if (status_out) memcpy(status_out, st, B * 4);
-    if (iters_out) memcpy(iters_out, ho + h->off_it, B * 4);
+    if (iters_out) copy_ipm_iters(iters_out, reinterpret_cast<const int32_t *>(ho + h->off_it), B);
     if (X_out) memcpy(X_out, ho + h->out_bytes, nxs(h) * 8);
     if (U_out) memcpy(U_out, ho + h->out_bytes + nxs(h) * 8, nus(h) * 8);
     int w = 0;
@@ -3362,13 +3368,12 @@ int ndp_get_active_set(ndp_handle *h, int32_t *sweeps, int8_t *act)
     NDP_HIP(h, hipSetDevice(h->cfg.device));
     int rc = wait_all(h);
     if (rc) return rc;
-    const size_t B = (size_t)h->cfg.batch, pitch = (size_t)act_pitch(h->cfg.N), na = 4 * (size_t)h->cfg.N;
-    std::vector<signed char> rec(B * pitch);
-    NDP_HIP(h, hipMemcpy(rec.data(), h->dAct, rec.size(), hipMemcpyDefault));
-    for (size_t i = 0; i < B; ++i) {
-        if (sweeps) memcpy(&sweeps[i], &rec[i * pitch], 4);
-        if (act) memcpy(act + i * na, &rec[i * pitch + ACT_HDR], na);
+    const size_t B = (size_t)h->cfg.batch;
+    if (sweeps) {
+        NDP_HIP(h, hipMemcpy(sweeps, h->lastIters, B * 4, hipMemcpyDefault));
+        for (size_t i = 0; i < B; ++i) sweeps[i] = (int32_t)((uint32_t)sweeps[i] >> ITERS_SWEEP_SHIFT);
     }
+    if (act) NDP_HIP(h, hipMemcpy(act, h->dAct, act_bytes(h), hipMemcpyDefault));
     return 0;
 }
 
@@ -3380,7 +3385,10 @@ int ndp_get_status(ndp_handle *h, int32_t *status, int32_t *ipm_iters)
     int rc = wait_all(h);
     if (rc) return rc;
     if (status) NDP_HIP(h, hipMemcpy(status, h->lastStatus, (size_t)h->cfg.batch * 4, hipMemcpyDefault));
-    if (ipm_iters) NDP_HIP(h, hipMemcpy(ipm_iters, h->lastIters, (size_t)h->cfg.batch * 4, hipMemcpyDefault));
+    if (ipm_iters) {
+        NDP_HIP(h, hipMemcpy(ipm_iters, h->lastIters, (size_t)h->cfg.batch * 4, hipMemcpyDefault));
+        copy_ipm_iters(ipm_iters, ipm_iters, (size_t)h->cfg.batch);
+    }
     return 0;
 }
 
@@ -3951,7 +3959,7 @@ static int tick_end_locked(ndp_handle *h, double *cmd, double *u0, int32_t *stat
     if (u0) memcpy(u0, ho + h->out_bytes, B * NU * 8);
     const int32_t *st = (const int32_t *)(ho + h->off_st);
     if (status_out) memcpy(status_out, st, B * 4);
-    if (iters_out) memcpy(iters_out, ho + h->off_it, B * 4);
+    if (iters_out) copy_ipm_iters(iters_out, reinterpret_cast<const int32_t *>(ho + h->off_it), B);
     int w = 0;
     for (size_t i = 0; i < B; ++i) w = st[i] > w ? st[i] : w;
     h->host_us[2] = std::chrono::duration<double, std::micro>(tw1 - tw0).count();

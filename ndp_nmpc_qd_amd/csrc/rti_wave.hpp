@@ -140,13 +140,14 @@ struct RtiIo {            // global-memory views of ONE instance
     int have_xrN = 0;
     double xrN[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int f_is_f64 = 0;     // 1: f points at doubles (the reference hands acados a float64 p, ndp_nmpc_body_rate_ctl.py:97-99); 0: fp32, what DownwashNN returns
-    // QP_AUTO's active set of this instance, kept between control steps (the warm start of the next step's QP): ACT_HDR bytes of header
-    // -- an int32: sweeps the last step's QPs took -- then one signed byte per input bound, element 4k + i = input i of stage k:
-    // +1 pinned at its upper bound, -1 at its lower, 0 free.  Null = no warm start, nothing kept.
+    // QP_AUTO's active set of this instance, kept between control steps (the warm start of the next step's QP): one signed byte per
+    // input bound, element 4k + i = input i of stage k: +1 pinned at its upper bound, -1 at its lower, 0 free.  Null = no warm start,
+    // nothing kept.  (The sweeps a step's QPs took ride in the high half of the iteration word: ITERS_SWEEP_SHIFT.)
     signed char *act = nullptr;
 };
-enum { ACT_HDR = 4 };
-NDP_HD int act_pitch(int N) { return ACT_HDR + 4 * N; }      // bytes per instance of the active-set record (a multiple of four)
+NDP_HD int act_pitch(int N) { return 4 * N; }      // bytes per instance of the active-set record
+// *RtiIo::iters = interior-point iterations of the step (low half) + Riccati sweeps its QP_AUTO solves took before them (high half)
+enum { ITERS_SWEEP_SHIFT = 16, ITERS_IPM_MASK = 0xffff };
 
 struct LdsMap {
     int KC, SC, XI, UI, ZX, ZU, CX, CU, ZD, MB, CB, KT, TXR, TUR, TF, AS, total;
@@ -1452,7 +1453,7 @@ struct RtiWave {
         const int nzu = horizon(P) * NU;
         vi lane = W::lane();
         for (int t = 0; t < RUA; ++t)
-            A.a[t] = io.act ? W::gld_i8(io.act, W::imin(lane + 64 * t, nzu - 1) + int(ACT_HDR)) : vi(0);
+            A.a[t] = io.act ? W::gld_i8(io.act, W::imin(lane + 64 * t, nzu - 1)) : vi(0);
     }
     static NDP_D bool as_any(const RtiParams &P, const LdsMap &m, lp lds, const ActSet &A)
     {
@@ -1474,7 +1475,7 @@ struct RtiWave {
             const vi at = a_get(A, m, lds, t, e);
             vb up = at > 0, on = !(at == 0);
             vd d = W::ld(lds, c + (m.KC + int(KC_LBU)) + W::sel(up, vi(int(SL_UB)), vi(0))) - cu;
-            vd w = W::sel(on, vd(P.as_gamma), vd(0.0));
+            vd w = W::sel(on, vd(W::late_params(P)->as_gamma), vd(0.0));
             W::st(lds, cbk + int(CB_DEU), P.dt * W::ld(lds, c + (m.KC + int(KC_RD))) + w);
             W::st(lds, cbk + int(CB_RE), W::ld(lds, cbk + int(CB_RB)) - w * d);
         }
@@ -1491,19 +1492,22 @@ struct RtiWave {
     // Evaluated without the constraint slots (which the interior-point loop needs, this does not): the 4N input bounds as they lie in
     // ZU (element e: component e & 3), the 3(N-1) velocity bounds four lanes per stage (component 3 idle) -- no division by three.
     // update = false (as_iter_max = 0): the set stays empty whatever the verdict (it is looked at again by the next RTI iteration).
-    static NDP_D int as_check(const RtiParams &P, const LdsMap &m, lp lds, ActSet &A, double umargin, double vmargin, bool update)
+    // (A NaN makes every comparison false: the QP then goes the interior-point loop's way, which reports it.)
+    // pinned = false: the sweep was made with an empty set (the usual case: the caller knows) -- the test is then the handful of
+    // comparisons rounds 1-5 made, and everything that deals with pins sits behind a branch the wave almost never takes.
+    static NDP_D int as_check(const RtiParams &P, const LdsMap &m, lp lds, ActSet &A, double umargin, double vmargin, bool update, bool pinned)
     {
         const int N = horizon(P), nzu = N * NU, nv4 = 4 * (N - 1);
         constexpr int RVm = NC ? (4 * (NC - 1) + 63) / 64 : NSLOT;
-        const vi lane = lane_it();
+        // (an opaque lane id: this sits in a loop now, and index arithmetic the compiler can trace to the thread id is loop-invariant --
+        // hoisted in front of the sweep and held across it)
+        const vi lane = W::lane_here();
         const int io = m.XI - m.ZX;
         // every LDS read of the test is requested before the first comparison (one wait), the verdicts are combined without control flow
         vd zu[RUA], cu[RUA], lu[RUA], hu[RUA], zv[RVm], cv[RVm], lv[RVm], hv[RVm];
-        vi at[RUA];
         for (int t = 0; t < RUA; ++t) {
             vi e = W::imin(lane + 64 * t, nzu - 1);
             vi c = e & 3;
-            at[t] = a_get(A, m, lds, t, e);
             zu[t] = W::ld(lds, e + m.ZU); cu[t] = W::ld(lds, e + (m.ZU + io));
             lu[t] = W::ld(lds, c + (m.KC + int(KC_LBU))); hu[t] = W::ld(lds, c + (m.KC + int(KC_UBU)));
         }
@@ -1514,29 +1518,33 @@ struct RtiWave {
             zv[t] = W::ld(lds, zo); cv[t] = W::ld(lds, zo + io);
             lv[t] = W::ld(lds, c + (m.KC + int(KC_LBV))); hv[t] = W::ld(lds, c + (m.KC + int(KC_UBV)));
         }
-        vb vok = lane >= 0, same = lane >= 0, pinned = lane < 0;
-        vi na[RUA];
+        vb vok = lane >= 0, uok = lane >= 0;
+        for (int t = 0; t < RUA; ++t)
+            uok = W::band(uok, W::band(zu[t] > (lu[t] - cu[t]) + umargin, zu[t] < (hu[t] - cu[t]) - umargin));
+        for (int t = 0; t < RVm; ++t)
+            vok = W::band(vok, W::band(zv[t] > (lv[t] - cv[t]) + vmargin, zv[t] < (hv[t] - cv[t]) - vmargin));
+        if (!pinned && W::all(W::band(uok, vok))) return 0;         // empty set, everything inside: the QP's solution
+        if (!W::all(vok)) return 2;
+        // ---- the rare part: pins in play, or a free input beyond a bound
+        vb same = lane >= 0;
+        vi at[RUA], na[RUA];
         for (int t = 0; t < RUA; ++t) {
+            at[t] = a_get(A, m, lds, t, W::imin(lane + 64 * t, nzu - 1));
             const vd lo = lu[t] - cu[t], hi = hu[t] - cu[t];
             const vb up = at[t] > 0, dn = at[t] < 0, on = W::bor(up, dn);
             // pinned: multiplier as_gamma (du - d) for an upper, as_gamma (d - du) for a lower bound; released when negative
             const vb keep = W::band(on, W::sel(up, zu[t] - hi, lo - zu[t]) >= 0.0);
-            const vb vhi = W::band(!on, zu[t] > hi - umargin), vlo = W::band(!on, zu[t] < lo + umargin);
+            // free: beyond a bound (or, as_iter_max = 0, closer to it than umargin) -> pinned there
+            const vb vhi = W::band(!on, !(zu[t] < hi - umargin)), vlo = W::band(!on, !(zu[t] > lo + umargin));
             na[t] = W::sel(keep, at[t], W::sel(vhi, vi(1), W::sel(vlo, vi(-1), vi(0))));
             same = W::band(same, na[t] == at[t]);
-            pinned = W::bor(pinned, on);
         }
-        for (int t = 0; t < RVm; ++t)
-            vok = W::band(vok, W::band(zv[t] > (lv[t] - cv[t]) + vmargin, zv[t] < (hv[t] - cv[t]) - vmargin));
-        if (NDP_RARELY(!W::all(vok))) return 2;
         if (W::all(same)) {
-            if (NDP_RARELY(W::any(pinned))) {
-                for (int t = 0; t < RUA; ++t) {
-                    vi e = W::imin(lane + 64 * t, nzu - 1);
-                    W::stp(lds, e + m.ZU, W::sel(at[t] > 0, hu[t], lu[t]) - cu[t], !(at[t] == 0));
-                }
-                W::sync();
+            for (int t = 0; t < RUA; ++t) {
+                vi e = W::imin(lane + 64 * t, nzu - 1);
+                W::stp(lds, e + m.ZU, W::sel(at[t] > 0, hu[t], lu[t]) - cu[t], !(at[t] == 0));       // onto the bound exactly
             }
+            W::sync();
             return 0;
         }
         if (update) {
@@ -1545,16 +1553,15 @@ struct RtiWave {
         }
         return 1;
     }
-    // keep the set for the next control step (and the sweep count for ndp_get_active_set)
-    static NDP_D void as_store(const RtiParams &P, const LdsMap &m, lp lds, const RtiIo &io, const ActSet &A, int sweeps)
+    // keep the set for the next control step
+    static NDP_D void as_store(const RtiParams &P, const LdsMap &m, lp lds, const RtiIo &io, const ActSet &A)
     {
         const int nzu = horizon(P) * NU;
         vi lane = W::lane_here();
         for (int t = 0; t < RUA; ++t) {
             vi e = lane + 64 * t;
-            W::gst_i8(io.act, e + int(ACT_HDR), a_get(A, m, lds, t, a_elem(P, lane, t)), e < nzu);
+            W::gst_i8(io.act, e, a_get(A, m, lds, t, a_elem(P, lane, t)), e < nzu);
         }
-        W::gsti(reinterpret_cast<int *>(io.act), sweeps);
     }
 
     static NDP_D double absmax(lp lds, int off, int n)
@@ -1578,7 +1585,12 @@ struct RtiWave {
     {
         const int N = horizon(P);
         const int nzx = (N + 1) * NX, nzu = N * NU;
-        const double inv2m = P.inv2m;
+        // The loop's own constants (start values, tolerances, refinement switches) are read HERE, through a view of the parameter block
+        // the compiler cannot connect with the kernel's arguments: read as plain members it fetches all fourteen words in front of the
+        // nominal sweep -- the loop is entered from there -- and with the scalar registers as full as they are, each fetch then waits
+        // for itself and is spilled (three load-wait-spill rounds on the hot path, ~300 cycles per step, measured with phase stamps).
+        const auto *Q = W::late_params(P);
+        const double inv2m = Q->inv2m;
         vi lane = W::lane();
         int status = 0, iters = 0;
         // cold start at dz = 0
@@ -1587,10 +1599,10 @@ struct RtiWave {
             vb v = S.valid[s];
             vd lo, hi;
             bounds(S, lds, s, lo, hi);
-            S.tl[s] = W::sel(v, W::vmax(-lo, vd(P.thr0)), vd(1.0));
-            S.tu[s] = W::sel(v, W::vmax(hi, vd(P.thr0)), vd(1.0));
-            S.ll[s] = W::sel(v, W::rcp(S.tl[s]) * P.mu0, vd(0.0));     // reciprocals (v_rcp_f64 + Newton), not IEEE divides:
-            S.lu[s] = W::sel(v, W::rcp(S.tu[s]) * P.mu0, vd(0.0));     // a divide is ~30 VALU instructions, the loop had 14 per slot
+            S.tl[s] = W::sel(v, W::vmax(-lo, vd(Q->thr0)), vd(1.0));
+            S.tu[s] = W::sel(v, W::vmax(hi, vd(Q->thr0)), vd(1.0));
+            S.ll[s] = W::sel(v, W::rcp(S.tl[s]) * Q->mu0, vd(0.0));     // reciprocals (v_rcp_f64 + Newton), not IEEE divides:
+            S.lu[s] = W::sel(v, W::rcp(S.tu[s]) * Q->mu0, vd(0.0));     // a divide is ~30 VALU instructions, the loop had 14 per slot
             S.pl[s] = 0.0; S.pu[s] = 0.0;
             musum = musum + S.ll[s] * S.tl[s] + S.lu[s] * S.tu[s];
             nrm = W::vmax(nrm, W::vmax(S.ll[s], S.lu[s]));
@@ -1643,8 +1655,8 @@ struct RtiWave {
 #endif
         const int nu4 = 4 * N;
         for (;;) {
-            if (mu <= P.tol && rho * norm0 <= P.tol) break;
-            if (iters >= P.iter_max) { status = 4; break; }
+            if (mu <= Q->tol && rho * norm0 <= Q->tol) break;
+            if (iters >= Q->iter_max) { status = 4; break; }
             ++iters;
             double sigma_mu = 0.0;
             double gmaxv = 0.0;
@@ -1671,18 +1683,18 @@ struct RtiWave {
                 }
                 W::sync();
                 NDP_FINE(if (fio && fio->dbg && iters == 1) fstamp(*fio, m, 6 + 3 * pass);)
-                if (STIFF && pass == 0 && P.refine > 0) gmaxv = W::wave_max(gmv);
+                if (STIFF && pass == 0 && Q->refine > 0) gmaxv = W::wave_max(gmv);
                 if (DELTA && pass) {
                     DeltaTabs DT;                    // (a dozen integer instructions: built here, not held across the factorisation sweep)
                     build_delta_tabs(m, DT);
                     delta_sweep(P, m, T, DT, lds, linv);
                 }
 #ifndef NDP_DEV_NO_ROBUST
-                else if (STIFF && NDP_RARELY(P.refine > 0 && gmaxv > P.refine_gamma)) ok = riccati_sweep<DELTA, STIFF>(P, m, T, lds, nullptr, linv) && ok;
+                else if (STIFF && NDP_RARELY(Q->refine > 0 && gmaxv > Q->refine_gamma)) ok = riccati_sweep<DELTA, STIFF>(P, m, T, lds, nullptr, linv) && ok;
 #endif
                 else ok = riccati_sweep<DELTA>(P, m, T, lds, nullptr, linv) && ok;
                 if constexpr (REFINE) {
-                    if (NDP_RARELY(ok && P.refine > 0 && gmaxv > P.refine_gamma)) {
+                    if (NDP_RARELY(ok && Q->refine > 0 && gmaxv > Q->refine_gamma)) {
                         if (pass) {
                             // the corrector's second solve left only the CHANGE of the bounded rows' gradient in the cost blocks:
                             // put the corrector's full gradient there, as the refinement needs the gradient of the whole quadratic
@@ -1700,7 +1712,7 @@ struct RtiWave {
                         DeltaTabs DT;
                         build_delta_tabs(m, DT);
                         double corr = 0.0;
-                        for (int rf = 0; rf < P.refine; ++rf) {
+                        for (int rf = 0; rf < Q->refine; ++rf) {
                             refine_gradient(P, m, lds);
                             corr = delta_sweep<true>(P, m, T, DT, lds, linv);
                         }
@@ -1749,9 +1761,9 @@ struct RtiWave {
                     const double r = mu_aff / mu;
                     // Mehrotra's centring target, kept from undershooting the tolerance (slacks are formed by subtraction:
                     // their relative accuracy, and the Newton systems', is eps / t) -- same rule as the oracle
-                    sigma_mu = fmax_u(r * r * r * mu, P.mu_floor * P.tol);
+                    sigma_mu = fmax_u(r * r * r * mu, Q->mu_floor * Q->tol);
                 } else {
-                    if (alpha < 1.0) alpha *= P.tau;
+                    if (alpha < 1.0) alpha *= Q->tau;
                     for (int t = 0; t < nzx + nzu; t += 64) {   // (ZX,ZU) and (CX,CU) are laid out alike
                         vi i = lane + t;
                         vb p = i < nzx + nzu;
@@ -1922,7 +1934,8 @@ struct RtiWave {
             if (DEFER || P.qp_mode == QP_AUTO) {
                 // Equality-constrained minimiser inside the box => it IS the QP solution (all multipliers 0).  Otherwise, and when the
                 // previous step left a set: active-set iterations on the input bounds (as_check) -- each one this same sweep again.
-                if (NDP_RARELY(as_on && as_any(P, m, lds, A))) as_apply(P, m, lds, A);          // warm start: the kept set's pins
+                bool pinned = false;                   // does the sweep at hand carry pins?
+                if (NDP_RARELY(as_on && as_any(P, m, lds, A))) { as_apply(P, m, lds, A); pinned = true; }   // warm start: the kept set's pins
                 const int sweeps0 = sweeps;            // (as_iter_max counts per QP, `sweeps` over the step's RTI iterations)
                 for (;;) {
                     stamp(io, m, 5);
@@ -1931,17 +1944,18 @@ struct RtiWave {
                     ++sweeps;
                     if (NDP_RARELY(!ok)) {
                         // the plain sweep failed: no usable step (as in rounds 1-5); a sweep WITH pins failed: the interior-point loop's case
-                        if (!(as_on && as_any(P, m, lds, A))) { st = 4; failed = true; done = true; }
+                        if (!pinned) { st = 4; failed = true; done = true; }
                         break;
                     }
                     if (P.qp_mode != QP_AUTO) break;
                     // (the constraint slots are built only at the interior-point loop's door: keeping ~90 more registers live across the
                     // sweep forces the MFMA accumulators into AGPRs with copies on every dependency)
-                    const int verdict = as_check(P, m, lds, A, as_on ? 0.0 : P.auto_margin, P.auto_margin, as_on);
+                    const int verdict = as_check(P, m, lds, A, as_on ? 0.0 : P.auto_margin, P.auto_margin, as_on, pinned);
                     if (verdict == 0) { done = true; break; }      // then the step is the sweep's solution, read where it lies (ZX|ZU)
                     if (NDP_RARELY(as_on && verdict == 1 && sweeps - sweeps0 <= P.as_iter_max)) {
                         act_dirty = true;
                         as_apply(P, m, lds, A);
+                        pinned = true;                 // (an update that only releases may leave no pin: the general test handles an empty set too)
                         continue;
                     }
                     break;
@@ -2009,11 +2023,8 @@ struct RtiWave {
         }
         stamp(io, m, 8);
         W::gsti(io.status, status);
-        W::gsti(io.iters, iters);
-        if (as_on && io.act) {
-            if (NDP_RARELY(act_dirty)) as_store(P, m, lds, io, A, sweeps);
-            else W::gsti(reinterpret_cast<int *>(io.act), sweeps);
-        }
+        W::gsti(io.iters, iters + (sweeps << int(ITERS_SWEEP_SHIFT)));
+        if (NDP_RARELY(as_on && io.act && act_dirty)) as_store(P, m, lds, io, A);
         if (io.f_late) W::late_publish(late_prev, io.late_gsize, io.late_done_word);
         return false;
     }

@@ -72,6 +72,19 @@ struct WaveGfx950 {
     static NDP_D vd gldu(const double *g, vi off) { return g[off]; }
     static NDP_D vd gldfu(const float *g, vi off) { return (double)g[off]; }
     static NDP_D vi gldi(const int *g, vi off) { return g[off]; }
+    // The step's parameter block for code that runs RARELY: the same bytes through a pointer into the kernel's argument segment that has
+    // passed an empty asm, so that the fetches stay where they are written (constant-address-space scalar loads, scalar-cache hits)
+    // instead of being hoisted to wherever the compiler first sees a path to them.  The block is the FIRST member of the kernel's one
+    // argument (ndp_hip.hip: KernArgs::P, asserted there).  (Taking the parameter's address instead would make the compiler copy the
+    // whole argument to scratch memory.)
+    template <class T>
+    static NDP_D const __attribute__((address_space(4))) T *late_params(const T &)
+    {
+        typedef const __attribute__((address_space(4))) T *kptr;
+        kptr base = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(base));
+        return base;
+    }
     static NDP_D vi gld_i8(const signed char *g, vi off) { return (int)g[off]; }
     static NDP_D vi d2i(vd a) { return (int)a; }
     static NDP_D vd i2d(vi a) { return (double)a; }

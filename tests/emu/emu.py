@@ -49,8 +49,9 @@ def _p(a):
 
 
 def act_record(N):
-    """An empty kept-active-set record of one instance (RtiIo::act): int32 sweeps + one signed byte per input bound."""
-    return np.zeros(lib().emu_act_pitch(int(N)), dtype=np.int8)
+    """An empty kept-active-set record of one instance as the tests carry it: an int32 (sweeps of the last step, filled in by rti_step
+    from the step's iteration word) followed by RtiIo::act -- one signed byte per input bound."""
+    return np.zeros(4 + lib().emu_act_pitch(int(N)), dtype=np.int8)
 
 
 def rti_step(cfg, x0, xr, ur, f, X, U, dump=False, act=None):
@@ -64,8 +65,11 @@ def rti_step(cfg, x0, xr, ur, f, X, U, dump=False, act=None):
     lds = np.zeros(n) if dump else None
     assert act is None or (act.dtype == np.int8 and act.flags.c_contiguous)
     rc = lib().emu_rti_step_act(C.byref(cfg), _p(x0), _p(xr), _p(ur), _p(f), _p(X), _p(U), _p(u0),
-                                C.byref(status), C.byref(iters), _p(lds), counters, _p(act))
+                                C.byref(status), C.byref(iters), _p(lds), counters, _p(None if act is None else act[4:]))
     assert rc == 0
+    if act is not None:
+        act[:4].view(np.int32)[0] = iters.value >> 16          # rti_wave.hpp: ITERS_SWEEP_SHIFT
+    iters.value &= 0xffff
     return u0, status.value, iters.value, lds, dict(mfma=counters[0], lds_ld=counters[1], lds_st=counters[2],
                                                    readlane=counters[3], mfma4=counters[4])
 
@@ -84,7 +88,7 @@ def rti_step_defer(cfg, x0, xr, ur, f, X, U):
     status, iters = C.c_int(-7), C.c_int(-7)
     rc = lib().emu_rti_step_defer(C.byref(cfg), _p(x0), _p(xr), _p(ur), _p(f), _p(X), _p(U), _p(u0), C.byref(status), C.byref(iters))
     assert rc in (0, 1), rc
-    return bool(rc), u0, status.value, iters.value
+    return bool(rc), u0, status.value, (iters.value & 0xffff) if iters.value >= 0 else iters.value
 
 
 def rti_step_late(cfg, x0, xr, ur, f, X, U, ready=True):
@@ -96,4 +100,4 @@ def rti_step_late(cfg, x0, xr, ur, f, X, U, ready=True):
     rc = lib().emu_rti_step_late(C.byref(cfg), _p(x0), _p(xr), _p(ur), _p(f), int(bool(ready)), _p(X), _p(U), _p(u0),
                                  C.byref(status), C.byref(iters), C.byref(missed))
     assert rc == 0
-    return u0, status.value, iters.value, missed.value
+    return u0, status.value, iters.value & 0xffff, missed.value

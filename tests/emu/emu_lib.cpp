@@ -14,7 +14,7 @@ int emu_lds_doubles(int N) { return ndp::lds_doubles(N) + ndp::DBG_EXTRA; }
 int emu_lds_layout(int N, int *out8) { ndp::lds_layout(N, out8); return 0; }
 
 // One instance, one emulated wave.  counters: [mfma (16x16x4), lds_ld, lds_st, readlane, mfma4 (4x4x4, four blocks)]
-// act: the instance's kept active-set record (RtiIo::act: ndp::act_pitch(N) bytes), or null
+// act: the instance's kept active set (RtiIo::act: ndp::act_pitch(N) bytes), or null; *iters = the step's raw iteration word
 int emu_rti_step_act(const ndp_cfg *cfg, const double *x0, const double *xr, const double *ur, const float *f,
                      double *X, double *U, double *u0, int *status, int *iters, double *lds_dump, long *counters, signed char *act);
 

@@ -127,6 +127,7 @@ struct Wave {
     static vd gldu(const double *g, const vi &off) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = g[off.v[l]]; return o; }
     static vd gldfu(const float *g, const vi &off) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)g[off.v[l]]; return o; }
     static vi gldi(const int *g, const vi &off) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = g[off.v[l]]; return o; }
+    template <class T> static const T *late_params(const T &ref) { return &ref; }
     static vi d2i(const vd &a) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = (int)a.v[l]; return o; }
     static vd i2d(const vi &a) { vd o; for (int l = 0; l < 64; ++l) o.v[l] = (double)a.v[l]; return o; }
     static vi gld_i8(const signed char *g, const vi &off) { vi o; for (int l = 0; l < 64; ++l) o.v[l] = (int)g[off.v[l]]; return o; }
