@@ -37,6 +37,9 @@ PROFILE_TAGS = ("r05", "r04", "r03", "r02")  # newest first: profiles/<tag>_kern
 PROFILE_TOLERANCE = 0.25       # a committed profile whose kernel duration is further than this from the live HIP-event duration is refused
 
 
+REPEATS = 12          # extra timed passes over the same K steps behind the timed region (see run_mode)
+
+
 def compact(o, digits=5):
     """The line must fit the driver's record (the tail of stdout it keeps is ~8 KB): floats to `digits` significant digits, recursively."""
     if isinstance(o, float):
@@ -73,7 +76,11 @@ LEGEND = {
                "config5 = N 40, 2 RTI, batch 4096: sweeps on the f64 / fp32 / bf16 matrix instructions, nominal and perturbed starts; "
                "err = max rel u0 error vs the fp64 oracle, ipm = fraction of instances in the interior-point loop, bad = status != 0",
     "ipm_always": "qp_mode 1: every instance runs the interior-point loop like HPIPM does",
-    "mixed": "perturbed starts (0.5 m / 1 m/s / 0.15): ~20 % of the instances need the interior-point loop; wq = work list on / off / automatic",
+    "mixed": "perturbed starts (0.5 m / 1 m/s / 0.15): ~20 % of the instances have inputs on their bounds (constrained = the fraction at the last tick); "
+             "value = the default mode (active-set iterations, sets kept between ticks; ipm = fraction that still needed the interior-point loop), "
+             "value_as_off = as_iter_max 0 (rounds 1-5: the interior-point loop on those instances); wq = work list on / off / automatic",
+    "constrained": "the mixed workload's constrained instances ONLY (every instance has an input on its bound at tick 0, picked by one tick of the device "
+                   "itself from a pool of 8 x batch); value / value_as_off as in `mixed`; sweeps_* = Riccati sweeps of the last tick's QPs, pins_mean = inputs on a bound per instance",
     "host": "SURVEY 8d's host-inclusive metric through ndp_step: pageable numpy x0 + xr + ur + neighbour columns + ego xy in (3.4 KB per "
             "solve across PCIe), u0 out; two = ndp_step_begin / _end with two ticks in flight, one = ndp_step",
     "tick": "the node's control tick on the device (ndp_tick: nmpc_node.py:211-231,251-253): odometry x0[B,10] (+ t) in, actuator command "
@@ -484,9 +491,12 @@ def main():
     ap.add_argument("--formations", type=int, default=4096, help="--config 4: number of three-vehicle formations (whole job)")
     ap.add_argument("--qp-mode", type=int, default=0, help="0 auto (exact early exit), 1 interior point always")
     ap.add_argument("--work-queue", type=int, default=0, help="0 automatic, 1 on, 2 off (ndp_cfg.work_queue)")
+    ap.add_argument("--as-iter-max", type=int, default=None,
+                    help="ndp_cfg.as_iter_max of the timed engine (default: the library's, 8); 0 = QP_AUTO as rounds 1-5 had it: early exit or interior point")
     ap.add_argument("--perturb", default="nominal", choices=["nominal", "mixed"],
                     help="mixed: 0.5 m / 1 m/s / 0.15 initial errors, ~20 %% of the instances need the interior-point loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-repeats", action="store_true", help="skip the extra timed passes over the same steps behind the timed region (`repeat`)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs 2, 4-on-one-GPU, 5 measured in this run)")
     ap.add_argument("--only-timed", action="store_true",
                     help="no parity check, no extra legs: just warm-up + the timed steps (profiling runs: nothing but the kernel)")
@@ -601,7 +611,8 @@ def main():
         ticks.append({k: torch.from_numpy(b[k]).to(dev) for k in keys})
     host0 = make_tick(B, 0.0, args.perturb)
 
-    eng = ndp.BatchedNMPC(B, N=N, disturbance=downwash, qp_mode=args.qp_mode, device=local_rank, work_queue=args.work_queue)
+    as_kw = {} if args.as_iter_max is None else {"as_iter_max": args.as_iter_max}
+    eng = ndp.BatchedNMPC(B, N=N, disturbance=downwash, qp_mode=args.qp_mode, device=local_rank, work_queue=args.work_queue, **as_kw)
     # an explicit non-default stream: torch's default stream has handle 0, which the C-ABI reads as "use the
     # library's own stream" -- with a real handle the exchange (N > 1) and the kernel are ordered on ONE stream
     stream = torch.cuda.Stream(device=dev)
@@ -970,6 +981,19 @@ def main():
         if mode in PEER_FORMS:
             peer.tick = peer.stats()["ticks"]
         region_ms = ev_a.elapsed_time(ev_b) if graphs else None
+        # The timed region above is ONE pass over the K steps (the contract); a 20-step pass is 0.45 ms, so the same graph(s) are replayed
+        # REPEATS more times, each pass timed on its own (synchronise, clock, replay, synchronise): min / median / max say how much of
+        # `value` is the box's mood.  One rank, graph launches only; not part of `value`.
+        repeat_ms = []
+        if graphs and world == 1 and not tail and not args.no_repeats:
+            for _ in range(REPEATS):
+                torch.cuda.synchronize()
+                tr = time.perf_counter()
+                for gt in graphs:
+                    for _ in range(gt[1]):
+                        replay(gt)
+                torch.cuda.synchronize()
+                repeat_ms.append((time.perf_counter() - tr) * 1e3)
         if graphs:                # start / stop events carried by EVERY dispatch packet of 64 host-launched steps, outside the timed region (kernel_us_dispatch_events)
             eng.timing_enable(1)
             for i in range(64):
@@ -990,7 +1014,7 @@ def main():
             dist.all_reduce(agg)
             bad = int(agg.item())
         res = {"extra_warm": extra, "elapsed": elapsed, "launch": launch_mode, "parity": parity, "bad": bad, "rti_ms": rti_ms, "rti_n": rti_n,
-               "mlp_ms": mlp_ms, "mlp_n": mlp_n, "it": it, "step": step, "name": mode_names[mode], "region_ms": region_ms,
+               "mlp_ms": mlp_ms, "mlp_n": mlp_n, "it": it, "step": step, "name": mode_names[mode], "region_ms": region_ms, "repeat_ms": repeat_ms,
                "parity_fn": parity_check if check_parity else None}
         if mode in ("prefetch", "peer_ahead"):
             res["prefetch_stats"] = eng.prefetch_stats()
@@ -1130,12 +1154,23 @@ def main():
                              "hbm_frac": abytes * B / (rti_s + mlp_s) / 1e9 / HBM_PEAK_GBS,
                              **({"mlp_kernel_us": mlp_s * 1e6} if mlp_n else {})},
                 "parity_max_rel_vs_oracle": parity, "instances_not_converged": bad,
+                # SURVEY 8d words the metric over ndp_step calls INCLUDING the H2D of the inputs and the D2H of u0; `value` is the
+                # device-resident rate (inputs in HBM when the clock starts, the contract's reading).  The host-inclusive rates of the same
+                # run stand beside it: value_host_inclusive (ndp_step_begin / _end, two ticks in flight, all inputs across PCIe) and
+                # value_tick (ndp_tick: only what is new per control period crosses PCIe) -- filled in below when those legs ran.
+                "metric_variant": "device_resident", "value_host_inclusive": None, "value_tick": None,
             }
+            rp = head.get("repeat_ms") or []
+            if rp:
+                out["repeat"] = {"n": len(rp), "ms_per_step": [min(rp) / args.steps, float(np.median(rp)) / args.steps, max(rp) / args.steps],
+                                 "value_median": total / (float(np.median(rp)) * 1e-3)}
             legend = dict(LEGEND)
             legend["config.neighbour_exchange." + headline] = exchange_mode
             legend["roofline.kernel_us"] = ("HIP events on the launch stream around the timed region / steps" if one_launch
                                             else "HIP start / stop events on the dispatch packets of host-launched steps")
             legend["roofline.clock_ghz"] = clock_src
+            legend["repeat"] = (f"{REPEATS} more passes over the same {args.steps} steps (same graph) behind the timed region, each timed alone: "
+                                "ms_per_step = [min, median, max]; value_median = solves/s at the median pass; `value` itself is the contract's one pass")
             if partial:
                 out["watchdog"] = {"fired": True, "legs": {m: e[:80] for m, e in form_errors.items()}, "headline_parity_checked": parity is not None}
                 legend["watchdog"] = ("a secondary form did not come back within --leg-timeout-s: this line was built by the watchdog from the forms that had "
@@ -1213,7 +1248,41 @@ def main():
                 mt = mixed_ticks(B)
                 e_m = ndp.BatchedNMPC(B, N=N, disturbance=downwash, device=local_rank)
                 out["mixed"]["b%d" % B] = timed_leg(e_m, mt, 60)
-                del e_m, mt
+                sw_m, act_m = e_m.active_set()
+                out["mixed"]["b%d" % B].update({"constrained": float(act_m.any(axis=(1, 2)).mean()), "sweeps_max": int(sw_m.max())})
+                del e_m
+                e_m = ndp.BatchedNMPC(B, N=N, disturbance=downwash, device=local_rank, as_iter_max=0)     # rounds 1-5: early exit or interior point
+                out["mixed"]["b%d" % B]["value_as_off"] = timed_leg(e_m, mt, 60)["value"]
+                del e_m
+                # ---- every instance on an input bound: the mixed workload's CONSTRAINED instances only.  A pool of 8 B perturbed starts,
+                # one control tick of the device itself, the first B instances whose QP solution has an input on its bound (no oracle in a
+                # timed leg's way); then the same four ticks as above.  as_off: the same through the interior-point loop (what HPIPM does).
+                pool = synth.make_batch(8 * B, N=N, seed=synth.SEED0 + 41, downwash=downwash, **mixed_kw)
+                e_p = ndp.BatchedNMPC(8 * B, N=N, disturbance=downwash, device=local_rank)
+                e_p.reset(pool["xr"], pool["ur"])
+                e_p.update(pool["x0"], pool["xr"], pool["ur"], raise_on_status=False,
+                           **(dict(other=pool["other"], ego_xy=pool["ego_xy"]) if downwash else {}))
+                pick = np.flatnonzero(e_p.active_set()[1].any(axis=(1, 2)))[:B]
+                del e_p
+                if len(pick) == B:
+                    ct = []
+                    for t in range(4):
+                        m = synth.make_batch(8 * B, N=N, seed=synth.SEED0 + 41, downwash=downwash, t0=0.02 * t, **mixed_kw)
+                        ct.append({k: torch.from_numpy(np.ascontiguousarray(m[k][pick])).to(dev)
+                                   for k in (("x0", "xr", "ur", "other", "ego_xy") if downwash else ("x0", "xr", "ur"))})
+                    e_c = ndp.BatchedNMPC(B, N=N, disturbance=downwash, device=local_rank)
+                    out["constrained"] = timed_leg(e_c, ct, 60)
+                    sw_c, act_c = e_c.active_set()
+                    out["constrained"].update({"constrained": float(act_c.any(axis=(1, 2)).mean()), "sweeps_max": int(sw_c.max()),
+                                               "sweeps_mean": float(sw_c.mean()), "pins_mean": float((act_c != 0).sum(axis=(1, 2)).mean())})
+                    del e_c
+                    e_c = ndp.BatchedNMPC(B, N=N, disturbance=downwash, device=local_rank, as_iter_max=0)
+                    lg = timed_leg(e_c, ct, 60)
+                    out["constrained"].update({"value_as_off": lg["value"], "as_off_ipm": lg["ipm"], "as_off_bad": lg["bad"]})
+                    del e_c, ct
+                else:
+                    out["constrained"] = {"error": f"only {len(pick)} constrained instances in the pool"}
+                del mt
                 for Bq in (2 * B, 8 * B):      # two and eight instances per SIMD
                     mt = mixed_ticks(Bq)
                     e_q = ndp.BatchedNMPC(Bq, N=N, disturbance=downwash, device=local_rank)          # the automatic choice
@@ -1259,11 +1328,13 @@ def main():
                 # position / velocity columns the gate and the network read (packed that way into the mirror), ego xy
                 in_b = 8 * (10 + 10 * (N + 1) + 4 * N) + ((8 * 6 * (N + 1) + 16) if downwash else 0)
                 out["host"] = {"two": {"value": B / tp, "us": tp * 1e6, "pcie_GBps_implied": (in_b + 40) * B / tp / 1e9},
-                               "one": {"value": B / th, "us": th * 1e6}, "bytes_in_per_solve": in_b}
+                               "one": {"value": B / th, "us": th * 1e6}, "bytes_in_per_solve": in_b, **e_h.host_info()}
+                out["value_host_inclusive"] = B / tp
                 del e_h
                 # ---- the same metric when only what is NEW crosses PCIe: the node's control tick on the device (ndp_tick)
                 try:
                     out["tick"] = tick_block(ndp, synth, B, N, local_rank)
+                    out["value_tick"] = out["tick"].get("value_host_inclusive_x0_only")
                 except Exception as e:                      # never fatal to the headline
                     out["tick"] = {"error": f"{type(e).__name__}: {e}"[:200]}
                 try:
@@ -1284,18 +1355,22 @@ def main():
                     Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
                     O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], None, Xo, Uo, nthreads=nthr)       # warm the thread pool
                     Xo, Uo = host0["xr"].copy(), host0["ur"].copy()
-                    n, tc = 0, time.perf_counter()
+                    n, t_mlp, tc = 0, 0.0, time.perf_counter()
                     while True:
+                        tm = time.perf_counter()
                         f = O.downwash_batch(blob, host0["other"], host0["xr"], host0["ego_xy"], nthreads=nthr) if downwash else None
+                        t_mlp += time.perf_counter() - tm
                         O.step_batch(cfgo, host0["x0"], host0["xr"], host0["ur"], f, Xo, Uo, nthreads=nthr)
                         n += 1
                         if time.perf_counter() - tc >= seconds:
                             break
-                    return B * n / (time.perf_counter() - tc), n
+                    tt = time.perf_counter() - tc
+                    return B * n / tt, n, t_mlp / tt
                 mode = args.qp_mode
-                v_same, n_same = cpu_rate(mode, args.cpu_seconds)
-                v_ipm, n_ipm = (v_same, n_same) if mode == 1 else cpu_rate(1, args.cpu_seconds * 0.5)
-                out["cpu_baseline"] = {"value": v_same, "unit": "solves/s", "cores": nthr, "kind": "port",
+                v_same, n_same, mlp_share = cpu_rate(mode, args.cpu_seconds)
+                v_ipm, n_ipm, _ = (v_same, n_same, mlp_share) if mode == 1 else cpu_rate(1, args.cpu_seconds * 0.5)
+                out["cpu_baseline"] = {"value": v_same, "unit": "solves/s", "cores": nthr, "kind": "port", "per_core": v_same / nthr,
+                                       "mlp_share": mlp_share,
                                        "qp_mode": "auto" if mode == 0 else "ipm_always",
                                        "sample": f"{n_same} ticks of the same batch={B} workload, ~{args.cpu_seconds:.0f} s",
                                        "ipm_always_value": v_ipm}

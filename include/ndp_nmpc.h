@@ -481,6 +481,9 @@ int ndp_debug_downwash_stream_device(ndp_handle *h, const void *d_other, const v
 /* Profiling hook: where the last host-array step spent its time on the CPU, microseconds: out4 = {packing the inputs into the
  * page-locked mirror, enqueueing (launches / copies), waiting for the results, copying them out}. */
 int ndp_debug_host_timing(ndp_handle *h, double *out4);
+/* ... and what the host path runs on: out3 = {hardware threads of the machine, cores this process may really use (affinity mask and
+ * cgroup CPU quota), pack threads the handle started (-1: no host-array step yet)}. */
+int ndp_debug_host_info(ndp_handle *h, int32_t *out3);
 int ndp_step_debug(ndp_handle *h, const double *x0, const double *xr, const double *ur, const float *f,
                    const double *other, const double *ego_xy, double *u0, double *lds_dump);
 

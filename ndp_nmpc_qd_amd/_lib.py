@@ -51,7 +51,7 @@ EXPORTS = [
     "ndp_track_steps", "ndp_last_step_event",
     "ndp_xchg_unique_id", "ndp_xchg_create", "ndp_xchg_begin", "ndp_xchg_end", "ndp_xchg_tick", "ndp_xchg_last_error", "ndp_xchg_destroy",
     "ndp_abi_version", "ndp_cfg_size",
-    "ndp_step_ex_f64", "ndp_refine_active", "ndp_get_active_set", "ndp_tick_config", "ndp_tick_reset", "ndp_tick_begin", "ndp_tick_end", "ndp_tick", "ndp_tick_device",
+    "ndp_step_ex_f64", "ndp_refine_active", "ndp_get_active_set", "ndp_debug_host_info", "ndp_tick_config", "ndp_tick_reset", "ndp_tick_begin", "ndp_tick_end", "ndp_tick", "ndp_tick_device",
 ]
 
 _lib = None

@@ -357,6 +357,12 @@ class BatchedNMPC:
         self._check(self._lib.ndp_get_status(self._h, _lib.ptr(st), _lib.ptr(it)), "ndp_get_status")
         return st, it
 
+    def host_info(self):
+        """{hw_threads, usable_cores, pack_threads} of the host-array path (ndp_debug_host_info)."""
+        out = np.zeros(3, dtype=np.int32)
+        self._check(self._lib.ndp_debug_host_info(self._h, _lib.ptr(out)), "ndp_debug_host_info")
+        return {"hw_threads": int(out[0]), "usable_cores": int(out[1]), "pack_threads": int(out[2])}
+
     def active_set(self):
         """(sweeps[B], act[B,N,4]) of the last step's QPs (ndp_get_active_set): Riccati sweeps taken by QP_AUTO's active-set
         iterations, and the set kept for the next step (+1 / -1: input on its upper / lower bound)."""

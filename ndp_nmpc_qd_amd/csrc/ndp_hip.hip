@@ -18,6 +18,8 @@
 #include <hip/hip_ext.h>
 
 #include <dlfcn.h>
+#include <sched.h>
+#include <stdio.h>
 
 #include <atomic>
 #include <chrono>
@@ -2124,6 +2126,7 @@ struct ndp_handle {
     hipEvent_t stepDone[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned step_seq = 0;
     double host_us[4] = {0, 0, 0, 0};   // last host step: packing | enqueue | wait for the results | copy-out  (ndp_debug_host_timing)
+    int host_cores = 0, pack_threads = 0;   // what ensure_slots found and started (ndp_debug_host_info)
     int slot_head = 0, slot_tail = 0, slots_busy = 0;   // begin fills slot_head, end drains slot_tail
     std::unique_ptr<struct PackPool> pool;
     // the last foreign stream a *_device call enqueued on: the getters wait for it (hipEvent)
@@ -2154,6 +2157,23 @@ static size_t nxs(const ndp_handle *h) { return (size_t)h->cfg.batch * (h->cfg.N
 static size_t nus(const ndp_handle *h) { return (size_t)h->cfg.batch * h->cfg.N * NU; }
 static size_t nfs(const ndp_handle *h) { return (size_t)h->cfg.batch * (h->cfg.N + 1) * 3; }
 static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
+// host cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota (cpu.max: "<quota> <period>" or "max ...")
+static int usable_cores()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0 && a < n) n = a; }
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        double period = 0.0;
+        if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0.0) {
+            const int c = (int)(atof(q) / period);
+            if (c >= 1 && c < n) n = c;
+        }
+        fclose(f);
+    }
+    return n < 1 ? 1 : n;
+}
 static size_t act_bytes(const ndp_handle *h) { return (size_t)h->cfg.batch * (size_t)act_pitch(h->cfg.N); }
 // the step's iteration words (RtiIo::iters) -> the caller's interior-point iteration counts
 static void copy_ipm_iters(int32_t *dst, const int32_t *src, size_t n)
@@ -2865,14 +2885,16 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
         else hipLaunchKernelGGL(RTI_K(__VA_ARGS__), grid, block, shm, s, ka);                                        \
     } while (0)
     if (q) {
-        // work list: producer (every instance, early exit or defer), consumer (the deferred ones, from scratch; with one RTI
-        // iteration the consumer goes straight to the interior-point loop, with several it repeats the automatic rule per
+        // work list: producer (every instance: one solve with the kept set's pins, done or defer), consumer (the deferred ones, from
+        // scratch: active-set iterations, then the interior-point loop if need be; several RTI iterations: the automatic rule per
         // iteration), a one-wave launch that empties the list for the next step.  The consumer reads the fused producer's
         // force from dForce.
         KernArgs kc = ka;
         kc.bp.f = fused ? h->dForce : d_f;
         kc.ma.frag = nullptr; kc.ma.other = nullptr;
-        if (h->cfg.n_rti == 1) kc.P.qp_mode = QP_IPM_ALWAYS;
+        // (active-set iterations off: a listed instance needs the interior-point loop, the consumer goes straight to it; on: the
+        // producer lists every instance whose first solve -- with the kept set's pins -- did not settle, the consumer iterates on the set)
+        if (h->cfg.n_rti == 1 && h->cfg.as_iter_max <= 0) kc.P.qp_mode = QP_IPM_ALWAYS;
         if (h->cfg.N == 20) {
             if (tick1) { if (fused) LAUNCH(3, 4, true, 20, 0, 1, 1, true); else LAUNCH(3, 4, false, 20, 0, 1, 1, true); }
             else if (fused) LAUNCH(3, 4, true, 20, 0, 1, 1); else LAUNCH(3, 4, false, 20, 0, 1, 1);
@@ -3090,14 +3112,16 @@ static int ensure_slots(ndp_handle *h)
         }
         if (!sl.evOut) NDP_HIP(h, hipEventCreateWithFlags(&sl.evOut, hipEventDisableTiming));
     }
-    // pack threads: NDP_PACK_THREADS, else half the hardware threads, at most 8; the caller packs too, so small blocks need none
+    // pack threads: NDP_PACK_THREADS, else half the cores this process may really use, at most 8; the caller packs too, so small blocks
+    // need none.  (Rounds 3-5 counted the machine's hardware threads: in a container whose CPU quota is a fraction of the machine that
+    // put seven spinning threads on two or three cores' worth of time -- the same ndp_step_begin / _end leg measured 4.5 M solves/s on one
+    // box and 11.5 M on another.)
     int nt = 0;
+    h->host_cores = usable_cores();
     if (const char *e = getenv("NDP_PACK_THREADS")) nt = atoi(e);
-    else if (h->in_bytes > 2 * PACK_CHUNK) {
-        const unsigned hw = std::thread::hardware_concurrency();
-        nt = (int)(hw / 2 > 8 ? 8 : hw / 2) - 1;
-    }
-    h->pool.reset(new (std::nothrow) PackPool(nt > 0 ? (nt > 64 ? 64 : nt) : 0));
+    else if (h->in_bytes > 2 * PACK_CHUNK) nt = (h->host_cores / 2 > 8 ? 8 : h->host_cores / 2) - 1;
+    h->pack_threads = nt > 0 ? (nt > 64 ? 64 : nt) : 0;
+    h->pool.reset(new (std::nothrow) PackPool(h->pack_threads));
     if (!h->pool) { h->err = "ensure_slots: out of memory"; return -4; }
     h->slots_ready = true;
     return 0;
@@ -3221,6 +3245,16 @@ static int step_end_locked(ndp_handle *h, double *u0, double *X_out, double *U_o
     h->host_us[2] = std::chrono::duration<double, std::micro>(tw1 - tw0).count();
     h->host_us[3] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw1).count();
     return w;
+}
+
+int ndp_debug_host_info(ndp_handle *h, int32_t *out3)
+{
+    if (!h || !out3) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    out3[0] = (int32_t)std::thread::hardware_concurrency();
+    out3[1] = h->slots_ready ? h->host_cores : usable_cores();
+    out3[2] = h->slots_ready ? h->pack_threads : -1;
+    return 0;
 }
 
 int ndp_debug_host_timing(ndp_handle *h, double *out4)

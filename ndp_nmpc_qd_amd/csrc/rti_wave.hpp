@@ -1830,9 +1830,10 @@ struct RtiWave {
     }
 
 
-    // DEFER (producer launch of the work list): when the first QP that needs the interior-point loop shows up, return true at
-    // once -- nothing of this instance has been written to global memory then, and the consumer launch redoes the step from
-    // the same inputs with DEFER = false.  The interior-point code is not instantiated at all.
+    // DEFER (producer launch of the work list): when the first QP shows up whose first solve -- with the kept set's pins -- does not
+    // settle it, return true at once: nothing of this instance has been written to global memory then, and the consumer launch redoes
+    // the step from the same inputs with DEFER = false.  Neither the interior-point code nor the active set's re-solve loop is
+    // instantiated: the producer stays the straight-line kernel it was (160 registers; with the loop's back edge 464 and a scratch slot).
     // IPM_RARE (the in-place kernels): the interior-point loop is the exception -- see NDP_RARELY.  (The work list's consumer runs
     // nothing else.)
     template <bool DEFER, bool IPM_RARE = false>
@@ -1864,7 +1865,6 @@ struct RtiWave {
         ActSet A;
         if (as_on) as_issue(P, io, A);       // (in flight under the cost / linearisation phases)
         else for (int t = 0; t < RUA; ++t) A.a[t] = vi(0);
-        bool act_dirty = false;
         int sweeps = 0;
         // Several RTI iterations per step at a compile-time count (NR >= 2, config 5): the iteration loop stays a LOOP (its body is
         // 17 k instructions), so inputs requested in front of it and replaced inside it are loop-carried values -- 23 doubles per lane
@@ -1952,8 +1952,7 @@ struct RtiWave {
                     // sweep forces the MFMA accumulators into AGPRs with copies on every dependency)
                     const int verdict = as_check(P, m, lds, A, as_on ? 0.0 : P.auto_margin, P.auto_margin, as_on, pinned);
                     if (verdict == 0) { done = true; break; }      // then the step is the sweep's solution, read where it lies (ZX|ZU)
-                    if (NDP_RARELY(as_on && verdict == 1 && sweeps - sweeps0 <= P.as_iter_max)) {
-                        act_dirty = true;
+                    if (!DEFER && NDP_RARELY(as_on && verdict == 1 && sweeps - sweeps0 <= P.as_iter_max)) {
                         as_apply(P, m, lds, A);
                         pinned = true;                 // (an update that only releases may leave no pin: the general test handles an empty set too)
                         continue;
@@ -1965,8 +1964,8 @@ struct RtiWave {
             if (IPM_RARE ? NDP_RARELY(!done) : !done) {
                 if (DEFER) return true;
                 if (as_on) {                           // the interior-point loop's answer carries no set: the next step starts cold
-                    act_dirty = true;
                     as_clear(P, m, lds, A);
+                    if (io.act) as_store(P, m, lds, io, A);
                 }
                 if constexpr (NSLOT <= 3) { if (io.ipm_ctr && it == 0) W::count64(io.ipm_ctr); }   // (the five-slot kernels sit at the register limit and have no automatic rule)
                 Slots S;
@@ -2024,7 +2023,8 @@ struct RtiWave {
         stamp(io, m, 8);
         W::gsti(io.status, status);
         W::gsti(io.iters, iters + (sweeps << int(ITERS_SWEEP_SHIFT)));
-        if (NDP_RARELY(as_on && io.act && act_dirty)) as_store(P, m, lds, io, A);
+        // the kept set changed <=> a QP took more than its one sweep (a set that holds reproduces itself in the first one)
+        if (NDP_RARELY(as_on && io.act && sweeps != n_rti)) as_store(P, m, lds, io, A);
         if (io.f_late) W::late_publish(late_prev, io.late_gsize, io.late_done_word);
         return false;
     }

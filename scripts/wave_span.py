@@ -19,7 +19,7 @@ for _ in range(50):
     eng.update_device(d["x0"], d["xr"], d["ur"], u0, **kw)
 eng.synchronize()
 res = []
-for rep in range(5):
+for rep in range(15):
     eng.debug_stamps(True)
     eng.update_device(d["x0"], d["xr"], d["ur"], u0, **kw)
     eng.synchronize()
@@ -29,7 +29,9 @@ for rep in range(5):
     span_rt = (t[:, 13].max() - t[:, 12].min()) * 10.0      # ns
     pro = t[:, 9] - t[:, 14]                                   # entry -> the "kernel entry" phase stamp
     epi = t[:, 15] - t[:, 8]                                   # last phase stamp -> exit
-    res.append((np.median(wave), wave.max(), span, span_rt, np.median(pro), pro.max(), np.median(epi), epi.max(), np.ptp(t[:, 14])))
+    res.append((np.median(wave), wave.max(), span, span_rt, np.median(pro), pro.max(), np.median(epi), epi.max(), np.ptp(t[:, 12]) * 10.0,
+                np.ptp(t[:, 13]) * 10.0, np.median(t[:, 13] - t[:, 12]) * 10.0, (t[:, 13] - t[:, 12]).max() * 10.0))
 r = np.median(np.array(res), axis=0)
-print("wave entry->exit median %d max %d | launch span %d cycles (%.0f ns real time) | prologue median %d max %d | epilogue median %d max %d | entry skew %d"
-      % tuple(r))
+print("wave entry->exit median %d max %d cycles | launch span (first entry -> last exit) %.0f ns | prologue median %d max %d | epilogue median %d max %d cycles | "
+      "entry times spread %.0f ns, exit times spread %.0f ns | wave entry->exit real time median %.0f max %.0f ns"
+      % (r[0], r[1], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11]))

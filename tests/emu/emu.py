@@ -79,14 +79,15 @@ def act_view(act):
     return int(act[:4].view(np.int32)[0]), act[4:].reshape(-1, 4)
 
 
-def rti_step_defer(cfg, x0, xr, ur, f, X, U):
+def rti_step_defer(cfg, x0, xr, ur, f, X, U, act=None):
     """The work list's producer view (run<DEFER = true>): returns (deferred, u0, status, iters); u0 / status / iters / X / U
     are meaningful only when deferred is False."""
     x0, xr, ur = (np.ascontiguousarray(a, dtype=np.float64) for a in (x0, xr, ur))
     f = None if f is None else np.ascontiguousarray(f, dtype=np.float32)
     u0 = np.full(4, np.nan)
     status, iters = C.c_int(-7), C.c_int(-7)
-    rc = lib().emu_rti_step_defer(C.byref(cfg), _p(x0), _p(xr), _p(ur), _p(f), _p(X), _p(U), _p(u0), C.byref(status), C.byref(iters))
+    rc = lib().emu_rti_step_defer_act(C.byref(cfg), _p(x0), _p(xr), _p(ur), _p(f), _p(X), _p(U), _p(u0), C.byref(status), C.byref(iters),
+                                      _p(None if act is None else act[4:]))
     assert rc in (0, 1), rc
     return bool(rc), u0, status.value, (iters.value & 0xffff) if iters.value >= 0 else iters.value
 

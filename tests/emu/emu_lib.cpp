@@ -86,8 +86,15 @@ int emu_rti_step_late(const ndp_cfg *cfg, const double *x0, const double *xr, co
 // The producer launch's view of one instance (work list, QMODE 1): RtiWave::run<DEFER = true> on the reference configuration's
 // instantiation.  Returns 1 if the instance was deferred (needs the interior-point loop: nothing may have been written),
 // 0 if it was solved by the early exit, < 0 on misuse.
+int emu_rti_step_defer_act(const ndp_cfg *cfg, const double *x0, const double *xr, const double *ur, const float *f,
+                           double *X, double *U, double *u0, int *status, int *iters, signed char *act);
 int emu_rti_step_defer(const ndp_cfg *cfg, const double *x0, const double *xr, const double *ur, const float *f,
                        double *X, double *U, double *u0, int *status, int *iters)
+{
+    return emu_rti_step_defer_act(cfg, x0, xr, ur, f, X, U, u0, status, iters, nullptr);
+}
+int emu_rti_step_defer_act(const ndp_cfg *cfg, const double *x0, const double *xr, const double *ur, const float *f,
+                           double *X, double *U, double *u0, int *status, int *iters, signed char *act)
 {
     ndp::RtiParams P = ndp::to_params(*cfg);
     if (P.N != 20 || P.n_rti != 1 || cfg->qp_precision != 0) return -1;
@@ -100,6 +107,7 @@ int emu_rti_step_defer(const ndp_cfg *cfg, const double *x0, const double *xr, c
     std::vector<int> tb(ndp::TB_WORDS);
     ndp::fill_tables(P.N, tb.data(), 0);
     io.tables = tb.data();
+    io.act = act;
     using Prog = ndp::RtiWave<emu::Wave, 3, 20, true, 1>;
     Prog::InBuf inb;
     emu::vd x0v;

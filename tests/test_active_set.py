@@ -230,23 +230,37 @@ def test_two_rti_iterations_carry_the_set(oracle):
     assert n >= 3
 
 
-def test_work_list_producer_runs_the_iterations_itself(oracle):
-    """The work list's producer (run<DEFER = true>) solves an instance whose input bounds are active in place -- only a QP that needs
-    the interior-point loop is deferred, untouched."""
+def test_work_list_producer_defers_what_its_first_solve_does_not_settle(oracle):
+    """The work list's producer (run<DEFER = true>) makes ONE solve, with the kept set's pins: an instance that settles it is finished
+    in place exactly as the in-place kernel finishes it (a constrained instance whose set still holds included); any other is handed
+    back untouched -- the consumer (run<false>) then iterates on the set, and on to the interior-point loop if need be."""
     b = synth.make_batch(24, seed=synth.SEED0 + 40, **MIXED)
-    n_as = 0
+    n_def = n_warm = 0
     for i in range(24):
         X0, U0 = b["xr"][i].copy(), b["ur"][i].copy()
+        act = E.act_record(20)
+        Xi, Ui = X0.copy(), U0.copy()
+        u0i, sti, iti, *_ = E.rti_step(E.default_cfg(), b["x0"][i], b["xr"][i], b["ur"][i], None, Xi, Ui, act=act)
+        sw = E.act_view(act)[0]
         Xd, Ud = X0.copy(), U0.copy()
         deferred, u0d, std, itd = E.rti_step_defer(E.default_cfg(), b["x0"][i], b["xr"][i], b["ur"][i], None, Xd, Ud)
-        Xi, Ui = X0.copy(), U0.copy()
-        act = E.act_record(20)
-        u0i, sti, iti, *_ = E.rti_step(E.default_cfg(), b["x0"][i], b["xr"][i], b["ur"][i], None, Xi, Ui, act=act)
-        assert deferred == (iti > 0)
-        if not deferred:
+        assert deferred == (sw > 1 or iti > 0)                            # (no kept set here: cold)
+        if deferred:
+            n_def += 1
+            assert np.array_equal(Xd, X0) and np.array_equal(Ud, U0) and np.isnan(u0d).all() and (std, itd) == (-7, -7)
+        else:
             assert (std, itd) == (0, 0) and np.array_equal(Ud, Ui) and np.array_equal(Xd, Xi)
-            n_as += E.act_view(act)[0] > 1
-    assert n_as >= 3
+        if E.act_view(act)[1].any():                                      # second tick, the set kept: the producer finishes it itself
+            Xw, Uw = Xi.copy(), Ui.copy()
+            Xp, Up = Xi.copy(), Ui.copy()
+            actw = act.copy()
+            u0w, stw, itw, *_ = E.rti_step(E.default_cfg(), b["x0"][i], b["xr"][i], b["ur"][i], None, Xw, Uw, act=actw)
+            dfr, u0p, stp, itp = E.rti_step_defer(E.default_cfg(), b["x0"][i], b["xr"][i], b["ur"][i], None, Xp, Up, act=act.copy())
+            assert dfr == (E.act_view(actw)[0] > 1 or itw > 0)
+            if not dfr:
+                n_warm += 1
+                assert np.array_equal(Up, Uw) and np.array_equal(u0p, u0w)
+    assert n_def >= 3 and n_warm >= 2
 
 
 def test_switched_off_is_rounds_1_to_5(oracle):
