@@ -1834,6 +1834,8 @@ struct RtiWave {
     // settle it, return true at once: nothing of this instance has been written to global memory then, and the consumer launch redoes
     // the step from the same inputs with DEFER = false.  Neither the interior-point code nor the active set's re-solve loop is
     // instantiated: the producer stays the straight-line kernel it was (160 registers; with the loop's back edge 464 and a scratch slot).
+    // The five-slot producer (N = 40, 2 RTI iterations: 256 + 20 registers) does not even apply a kept set's pins -- an instance that
+    // carries one is handed over before its first sweep (with the pins' code in it the kernel needed a scratch slot).
     // IPM_RARE (the in-place kernels): the interior-point loop is the exception -- see NDP_RARELY.  (The work list's consumer runs
     // nothing else.)
     template <bool DEFER, bool IPM_RARE = false>
@@ -1935,7 +1937,11 @@ struct RtiWave {
                 // Equality-constrained minimiser inside the box => it IS the QP solution (all multipliers 0).  Otherwise, and when the
                 // previous step left a set: active-set iterations on the input bounds (as_check) -- each one this same sweep again.
                 bool pinned = false;                   // does the sweep at hand carry pins?
-                if (NDP_RARELY(as_on && as_any(P, m, lds, A))) { as_apply(P, m, lds, A); pinned = true; }   // warm start: the kept set's pins
+                if (NDP_RARELY(as_on && as_any(P, m, lds, A))) {    // warm start: the kept set's pins
+                    if (DEFER && A_LDS) return true;                // (the five-slot producer hands an instance with a kept set straight over: see DEFER)
+                    as_apply(P, m, lds, A);
+                    pinned = true;
+                }
                 const int sweeps0 = sweeps;            // (as_iter_max counts per QP, `sweeps` over the step's RTI iterations)
                 for (;;) {
                     stamp(io, m, 5);

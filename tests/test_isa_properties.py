@@ -88,7 +88,9 @@ def test_headline_hot_path_has_no_spill_traffic(co):
     assert 4000 < end < 6500, clusters
     hot = [l.split()[0] for l in d[:end] if l.strip()]
     bad = [o for o in hot if o in ("v_accvgpr_read_b32", "v_accvgpr_write_b32", "v_readlane_b32", "v_writelane_b32") or o.startswith("scratch_")]
-    assert len(bad) <= 4, (len(bad), bad[:8])
+    # What is allowed: a handful of scalar values parked in lanes ONCE in front of the sweep (rounds 4-5: 4; round 6, with the active
+    # set's loop state: 6) -- and NOTHING read back, no accumulation-register traffic, no scratch inside the hot region
+    assert len(bad) <= 8 and all(o == "v_writelane_b32" for o in bad), (len(bad), bad[:8])
 
 
 def test_lds_budget_of_the_reference_configuration():
