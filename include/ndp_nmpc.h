@@ -82,9 +82,11 @@ typedef struct ndp_cfg {
                          * this only acts on boxes shrunk on purpose.
                          * WHERE IT ACTS: the three-slot kernels only (N <= 27: run-time and compile-time horizons alike), in place and
                          * through the work list.  The five-slot kernels (N >= 28, e.g. config 5's N = 40) and the lean late-force step
-                         * (ndp_step_device_prefetched) carry no stiff sweep and no second solve -- they sit at the register limit -- and
-                         * IGNORE ipm_refine / refine_gamma: a strongly active state bound at a tight tolerance ends in status 4 there,
-                         * never in a silent answer.  ndp_refine_active() tells which of the two a handle is. */
+                         * (ndp_step_device_prefetched) carry no stiff sweep and no second solve -- they sit at the register limit.
+                         * ndp_create REFUSES ipm_refine > 0 for a shape whose kernels have no such path (N >= 28, or qp_precision != 0:
+                         * error -2; set ipm_refine = 0 -- a strongly active state bound at a tight tolerance then ends in status 4,
+                         * never in a silent answer).  The lean late-force step of an N <= 27 handle runs without it as well
+                         * (ndp_refine_active() = what the handle's ordinary steps do). */
     double dt;          /* T_horizon / N_node        params/nmpc_params.py:10,12  */
     double mass;        /* params/fhnp_params.py:9   */
     double gravity;     /* params/fhnp_params.py:12  */
@@ -299,7 +301,11 @@ int ndp_relay_reference_device(ndp_handle *h, const void *d_xr_lead, void *d_xr_
  *       coeff_x/y/z[B][n_seg*8] (minimum snap), coeff_yaw[B][n_seg*4] (minimum acceleration),
  *       time_cum[B][n_seg+1], time_seg[B][n_seg], final_pt[B][3]
  *   ndp_ref_window        : t[B] = trajectory time of node 0 ((ros_t - start_ros_t).to_sec()) ->
- *       xr[B][N+1][10], ur[B][N][4], node k at t + k*dt.  The device form writes buffers that ndp_step_device reads. */
+ *       xr[B][N+1][10], ur[B][N][4], node k at t + k*dt.  The device form writes buffers that ndp_step_device reads.
+ *   Accuracy / range contract of the flatness map on the device: reciprocals and the thrust norm by hardware seeds + two Newton steps,
+ *   sin / cos of the yaw by Cody-Waite reduction -- within a few 1e-16 of the Python publisher (held to 1e-12 by
+ *   tests/test_ref_window_row.py), for FINITE yaw with |yaw| < 1e5 rad; a trajectory whose yaw polynomial leaves that range (or is
+ *   not finite) is outside what these calls serve. */
 int ndp_ref_set_trajectory(ndp_handle *h, int n_seg, const double *coeff_x, const double *coeff_y, const double *coeff_z,
                            const double *coeff_yaw, const double *time_cum, const double *time_seg, const double *final_pt);
 int ndp_ref_window(ndp_handle *h, const double *t, double *xr, double *ur);
@@ -355,6 +361,8 @@ int ndp_ref_list_window_device(ndp_handle *h, void *d_xr, void *d_ur, void *stre
  *                     Returns the worst status.
  *   ndp_tick        : begin + end under one lock.
  *   ndp_tick_device : the same launches on device pointers and a caller's stream; d_u0 may be NULL; status: ndp_get_status.
+ *                     d_t: device-accessible [B] doubles -- EXCEPT with NDP_TICK_T_UNIFORM, where d_t is a HOST pointer to one double
+ *                     that is read inside the call (before it returns), not by the device.
  *                     The list position is host state baked into the launches: not capturable into a hipGraph. */
 #define NDP_TICK_ESTIMATE 1
 #define NDP_TICK_WANT_U0 2
@@ -470,9 +478,9 @@ int ndp_debug_mfma_probe(const double *a, const double *b, const double *c, doub
  * mode 1: one v_mfma_f32_16x16x16_bf16 on four packed contraction steps a[4][64], b[4][64]; c[4][64] -> d[0..255];
  * d[256..319] = the four-lane row sum of a[0] (lanes 4 apart inside each 16-lane row). */
 int ndp_debug_mfma_probe_f32(const float *a, const float *b, const float *c, float *d, int mode);
-/* Profiling hook: enable = 1 makes every instance of the following steps write 16 phase stamps (shader clock);
- * out (or NULL) receives the [B][24] stamps of the last step before the switch is applied (0-8: the wave program's phases, 9-15: the
- * kernel's -- downwash tile, entry / exit clocks --, 16-21: the one-launch tick's prologue). */
+/* Profiling hook: enable = 1 makes every instance of the following steps write its 24 phase stamps (shader clock; NDP_NSTAMP in
+ * rti_wave.hpp); out (or NULL) receives the [B][24] stamps of the last step before the switch is applied (0-8: the wave program's
+ * phases, 9-15: the kernel's -- downwash tile, entry / exit clocks --, 16-23: the one-launch tick's prologue). */
 int ndp_debug_stamps(ndp_handle *h, int enable, double *out);
 /* Measurement hook: ndp_downwash_device through the LDS-free form of the downwash kernel (weights streamed from L2, at most 192
  * registers per lane: it can be resident on a CU beside the control-step kernel). */

@@ -23,6 +23,10 @@ class BatchedNMPC:
     def __init__(self, batch, N=CP.N_node, disturbance=False, n_rti=1, qp_mode=_lib.QP_AUTO, device=0,
                  dt=CP.th_pred, load_mlp=None, **cfg_overrides):
         self._lib = _lib.load()
+        # ndp_create refuses ipm_refine > 0 (the library default: 2) for shapes whose kernels carry no refinement path (N >= 28, the
+        # precision studies): such engines are created with ipm_refine = 0 unless the caller says otherwise (and is then told no)
+        if "ipm_refine" not in cfg_overrides and (7 * int(N) - 3 > 192 or cfg_overrides.get("qp_precision", 0)):
+            cfg_overrides = dict(cfg_overrides, ipm_refine=0)
         self.cfg = _lib.default_cfg(batch=int(batch), N=int(N), n_rti=int(n_rti), use_fd=int(bool(disturbance)),
                                     qp_mode=int(qp_mode), device=int(device), dt=float(dt), r_horiz=DP.r_horiz,
                                     **cfg_overrides)

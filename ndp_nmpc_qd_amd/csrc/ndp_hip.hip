@@ -218,7 +218,8 @@ struct RingGeom {
 enum { SEGC_SLOT = 32, SEGC_PER = 72 };      // doubles per slot / per vehicle of the tick's segment cache (tick_early)
 struct TickArgs {
     const double *coeff, *tcum, *tseg, *fpt;   // the trajectories (ndp_ref_set_trajectory)
-    double *segc;                              // [B][64] the vehicles' current / next segment records (see tick_early)
+    const double *segc;                        // [B][SEGC_PER] the vehicles' current / next segment records (see tick_early): the copy this launch READS
+    double *segc_wr;                           // ... and the copy it WRITES (every vehicle's record, re-filled or carried over): the next tick's `segc`
     int n_seg;
     const double *t;                           // [B] trajectory time of the tick, or null: t_all for every vehicle
     double t_all;
@@ -240,12 +241,12 @@ struct TickArgs {
 typedef double tick_d2 __attribute__((ext_vector_type(2)));
 // h0 / h1: (time_cum[i], time_cum[i + 1]), (time_seg[i], i) of slot 0 / 1; ca / cn: the lane's 8 coefficients in slot 0 / 1; tf: (end of the
 // trajectory, the lane's component of final_pt)
-struct TickEarly { double tv; tick_d2 h0[2], h1[2], ca[4], cn[4], tf; int v; };
+struct TickEarly { double tv; tick_d2 h0[2], h1[2], ca[4], cn[4], tf; int v; double own, ownc; };   // own / ownc: word `lane` / constant `lane` of the EGO's record (carried over)
 __device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, int orow, int lane);
 __device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, bool store, double xv[10],
-                                                 double uv[4], double nbv[6], int &refill, double *stamps);
+                                                 double uv[4], double nbv[6], int &refill, double &cfill, double *stamps);
 __device__ __forceinline__ void tick_arrived(TickEarly &te);
-__device__ __forceinline__ void tick_cache_store(const TickArgs &ta, int inst, int lane, int refill, double fill);
+__device__ __forceinline__ void tick_cache_store(const TickArgs &ta, const TickEarly &te, int inst, int lane, int refill, double fill, double cfill);
 __device__ __forceinline__ double tick_estimator(const TickArgs &ta, int inst, int B, int lane);
 
 struct KernArgs {
@@ -412,11 +413,11 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     // TICK: the newest list entry of this vehicle (x_new / u_new) and the position / velocity part of the neighbour's (nb_new).  Row N of
     // both windows is NOT read from the list in this launch (the neighbour's wave writes its entry while this one runs): the ego's goes
     // into the staged window through RtiIo::xrN, the pair into the network's input below.
-    double x_new[10], u_new[4], nb_new[6], seg_fill = 0.0;
+    double x_new[10], u_new[4], nb_new[6], seg_fill = 0.0, seg_cfill = 0.0;
     int seg_refill = 0;
     if (TICK && !(FUSED && wg_nb) && advance) {      // (fused with neighbours: made below, under the weight transfer)
         tick_arrived(te);
-        seg_fill = tick_new_point(ka.ta, te, inst, (int)(threadIdx.x & 63u), active, x_new, u_new, nb_new, seg_refill, io.stamps);
+        seg_fill = tick_new_point(ka.ta, te, inst, (int)(threadIdx.x & 63u), active, x_new, u_new, nb_new, seg_refill, seg_cfill, io.stamps);
 #pragma unroll
         for (int i = 0; i < 10; ++i) io.xrN[i] = x_new[i];
         io.have_xrN = 1;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
                                                   // `advance`: a path around it leaves the values pending in the compiler's books)
         stage_fragments(ma.frag, wl, (int)threadIdx.x, 64 * WAVES);
         if (TICK && advance) {                    // the polynomial work runs while the weights stream into LDS
-            seg_fill = tick_new_point(ka.ta, te, inst, lane, active, x_new, u_new, nb_new, seg_refill, io.stamps);
+            seg_fill = tick_new_point(ka.ta, te, inst, lane, active, x_new, u_new, nb_new, seg_refill, seg_cfill, io.stamps);
 #pragma unroll
             for (int i = 0; i < 10; ++i) io.xrN[i] = x_new[i];
             io.have_xrN = 1;
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
         io.f = nullptr;
         io.f_in_lds = 1;
     }
-    if (TICK && advance && active) tick_cache_store(ka.ta, inst, (int)(threadIdx.x & 63u), seg_refill, seg_fill);   // (requested in the prologue: long there)
+    if (TICK && advance && active) tick_cache_store(ka.ta, te, inst, (int)(threadIdx.x & 63u), seg_refill, seg_fill, seg_cfill);   // (requested in the prologue: long there)
     if (TICK && ka.ta.est && active) io.kthr = tick_estimator(ka.ta, inst, B, (int)(threadIdx.x & 63u));
     const bool deferred = Prog::template run<QMODE == 1, QMODE == 0 || QMODE == 3>(P, io, lds, inb, x0v);
     if (NDP_RARELY(io.stamps && (threadIdx.x & 63u) == 0)) {
@@ -1688,6 +1689,11 @@ __device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, in
             te.ca[k] = s0[o]; te.cn[k] = s0[SEGC_SLOT / 2 + o];
         }
         te.tf = s0[SEGC_SLOT + (c < 3 ? c : 0)];
+    }
+    // the ego's whole record, word `lane` (and constant `lane` in lanes 0..5): carried over into the copy the NEXT tick reads
+    te.own = ta.segc[(size_t)inst * SEGC_PER + lane];
+    te.ownc = ta.segc[(size_t)inst * SEGC_PER + 2 * SEGC_SLOT + (lane < 6 ? lane : 5)];
+    if (lane < 24) {
         // (written as a branch: as a select the compiler picks between two ADDRESSES -- the argument's copy parked in scratch memory
         // for it -- and loads through a flat pointer)
         if (ta.t) te.tv = ta.t[te.v];
@@ -1703,14 +1709,14 @@ __device__ __forceinline__ TickEarly tick_early(const TickArgs &ta, int inst, in
 // transfer costs the transfer a later start (the records' own latency) and takes the polynomial work off the critical path.
 __device__ __forceinline__ void tick_arrived(TickEarly &te)
 {
-    asm volatile("" : "+v"(te.tv), "+v"(te.h0[0]), "+v"(te.h0[1]), "+v"(te.h1[0]), "+v"(te.h1[1]), "+v"(te.tf));
+    asm volatile("" : "+v"(te.tv), "+v"(te.h0[0]), "+v"(te.h0[1]), "+v"(te.h1[0]), "+v"(te.h1[1]), "+v"(te.tf), "+v"(te.own), "+v"(te.ownc));
     asm volatile("" : "+v"(te.ca[0]), "+v"(te.ca[1]), "+v"(te.ca[2]), "+v"(te.ca[3]), "+v"(te.cn[0]), "+v"(te.cn[1]), "+v"(te.cn[2]), "+v"(te.cn[3]));
 }
 
 // returns (in every lane) the value lane l must store into the ego's cache word l behind the MLP phase, valid if refill != 0
 // store: false in the idle waves of a ragged last workgroup (they shadow the last instance for the barriers' sake and must not write)
 __device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickEarly &te, int inst, int lane, bool store, double xv[10],
-                                                 double uv[4], double nbv[6], int &refill, double *stamps)
+                                                 double uv[4], double nbv[6], int &refill, double &cfill, double *stamps)
 {
     // profiling hook (ndp_debug_stamps): slots 17.. = the prologue's own timeline; each stamp waits for the value it names
     auto stamp_after = [&](int idx, double dep) {
@@ -1771,12 +1777,13 @@ __device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickE
     // the ego's cache: re-filled by this wave when its point did not come out of slot 0 (lane 0 belongs to the ego's group)
     refill = __builtin_amdgcn_readlane((in1 || slow) ? 1 : 0, 0);
     double fill = 0.0;
+    cfill = te.ownc;
     if (refill) {
         const int ie = __builtin_amdgcn_readlane(idx, 0);
         const int sl = lane >> 5, f = lane & 31, i = ie + sl < S ? ie + sl : S - 1;
         const KernargLate L;
         const double *tce = NDP_TA_LATE(L, tcum) + (size_t)inst * (S + 1), *fpt = NDP_TA_LATE(L, fpt);
-        if (lane < 6) ta.segc[(size_t)inst * SEGC_PER + 2 * SEGC_SLOT + lane] = (lane & 1) ? fpt[(size_t)inst * 3 + (lane >> 1)] : tce[S];   // (constants of the trajectory)
+        cfill = lane < 6 ? ((lane & 1) ? fpt[(size_t)inst * 3 + (lane >> 1)] : tce[S]) : 0.0;   // (constants of the trajectory; stored by tick_cache_store)
         fill = f == 0 ? tce[i] : (f == 1 ? tce[i + 1] : (f == 2 ? NDP_TA_LATE(L, tseg)[(size_t)inst * S + i] : (f == 3 ? (double)i
                  : NDP_TA_LATE(L, coeff)[((size_t)inst * S + i) * 28 + (f - 4)])));
         if (ie + sl >= S && f == 1) fill = -1.0e300;                  // no segment behind the last one: slot 1 never matches (hi <= any t)
@@ -1821,9 +1828,15 @@ __device__ __forceinline__ double tick_new_point(const TickArgs &ta, const TickE
     return fill;
 }
 
-__device__ __forceinline__ void tick_cache_store(const TickArgs &ta, int inst, int lane, int refill, double fill)
+// The cache has two copies.  A launch READS one (its own record and its neighbour's, at entry) and WRITES the other -- every vehicle's
+// record, every advancing tick: re-filled when the vehicle crossed into its next segment, carried over otherwise -- and the host swaps
+// them between ticks.  (With one copy written in place, the neighbour's wave -- another workgroup, possibly another XCD, possibly a later
+// round of a batch larger than the device -- could read a record while its owner re-filled it in the same launch: old header, new
+// coefficients.  Nothing orders two workgroups of one launch; a kernel boundary orders everything.)
+__device__ __forceinline__ void tick_cache_store(const TickArgs &ta, const TickEarly &te, int inst, int lane, int refill, double fill, double cfill)
 {
-    if (refill) ta.segc[(size_t)inst * SEGC_PER + lane] = fill;
+    ta.segc_wr[(size_t)inst * SEGC_PER + lane] = refill ? fill : te.own;
+    if (lane < 6) ta.segc_wr[(size_t)inst * SEGC_PER + 2 * SEGC_SLOT + lane] = cfill;
 }
 
 // hover_throttle_callback (nmpc_node.py:251-253) of this vehicle, by lane 0; returns k_throttle to every lane
@@ -2078,8 +2091,9 @@ struct ndp_handle {
     int traj_seg = 0;
     double *dRingX = nullptr, *dRingU = nullptr;   // f1: the reference's sliding list of reference points, phase-major (RingGeom), one allocation (first use)
     unsigned long long list_n = 0;                 // absolute index of the list's oldest entry = control ticks since the list was built
+    int segc_par = 0;                              // which copy of the one-launch tick's segment cache the NEXT tick reads (tick_cache_store)
     int list_step = 5;
-    // ndp_tick: the node's control tick on the device (tick_pre_kernel / tick_post_kernel)
+    // ndp_tick: the node's control tick on the device (rti_kernel<..., TICK>; other shapes: tick_pre_kernel + the control step)
     int *dTickIndex = nullptr;       // [B] neighbour instance of every vehicle (< 0: none), or null: no vehicle has one
     double *dTickThrust = nullptr;   // [B] the thrust command of the previous tick (what hover_throttle_callback reads off body_rate_cmd)
     bool tick_gate = true;           // gate the downwash on |neighbour window node 0 xy - ego odometry xy| < r_horiz (ndp_nmpc_leader_node.py:65-74)
@@ -2552,6 +2566,14 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     if (cfg->batch < 1 || cfg->N < 2 || slots_for(cfg->N) > 5 || cfg->n_rti < 1 || cfg->qp_precision < 0 || cfg->qp_precision > 4 ||
         cfg->work_queue < 0 || cfg->work_queue > 2 || !(cfg->ts_nmpc > 0.0) || cfg->dt < cfg->ts_nmpc) {
         g_create_err = "ndp_create: need batch >= 1, 2 <= N <= 46, n_rti >= 1, qp_precision in 0..4, work_queue in 0..2, 0 < ts_nmpc <= dt";
+        return -2;
+    }
+    if (cfg->ipm_refine > 0 && (slots_for(cfg->N) > 3 || cfg->qp_precision != 0)) {
+        // (rounds 4-5 accepted the setting and ignored it -- a getter nobody called said so)
+        g_create_err = "ndp_create: ipm_refine > 0 is not served for this shape: the refinement path (stiff sweeps + second solves while a STATE bound's "
+                       "barrier term exceeds refine_gamma) lives in the three-slot fp64 kernels only (N <= 27, qp_precision 0); the five-slot kernels "
+                       "(N >= 28) sit at the register limit without it.  Set ipm_refine = 0: strongly active state bounds at a tight tolerance then "
+                       "end in status 4 (never a silent answer)";
         return -2;
     }
     {   // the reference list holds one point per control period and the window is every (dt / ts_nmpc)-th entry
@@ -3622,11 +3644,15 @@ int ndp_ref_set_trajectory(ndp_handle *h, int n_seg, const double *coeff_x, cons
     int rc = wait_all(h);
     if (rc) return rc;
     if (h->dTraj) { (void)hipFree(h->dTraj); h->dTraj = nullptr; }
-    // (+ the one-launch tick's segment cache, [B][64] doubles, empty = NaNs: tick_early; + the segment hints, int[B]: ref_point)
-    NDP_HIP(h, hipMalloc((void **)&h->dTraj, total * 8 + B * SEGC_PER * 8 + B * 4));
+    // (+ the one-launch tick's segment cache, [B][SEGC_PER] doubles, empty = NaNs: tick_early; + the segment hints, int[B]: ref_point;
+    //  + the cache's second copy behind them: tick_cache_store)
+    const size_t hint_doubles = (B * 4 + 7) / 8;
+    NDP_HIP(h, hipMalloc((void **)&h->dTraj, (total + 2 * B * SEGC_PER + hint_doubles) * 8));
     NDP_HIP(h, hipMemcpy(h->dTraj, host.data(), total * 8, hipMemcpyHostToDevice));
     NDP_HIP(h, hipMemset(h->dTraj + total, 0xFF, B * SEGC_PER * 8));
-    NDP_HIP(h, hipMemset(h->dTraj + total + B * SEGC_PER, 0, B * 4));
+    NDP_HIP(h, hipMemset(h->dTraj + total + B * SEGC_PER, 0, hint_doubles * 8));
+    NDP_HIP(h, hipMemset(h->dTraj + total + B * SEGC_PER + hint_doubles, 0xFF, B * SEGC_PER * 8));
+    h->segc_par = 0;
     h->traj_seg = n_seg;
     return 0;
 }
@@ -3794,7 +3820,7 @@ int ndp_ref_list_window(ndp_handle *h, const double *t, double *xr, double *ur)
     return 0;
 }
 
-// ---- the node's control tick, end to end on the device (nmpc_node.py:211-231; kernels: tick_pre_kernel, rti_kernel, tick_post_kernel)
+// ---- the node's control tick, end to end on the device (nmpc_node.py:211-231; kernels: rti_kernel<..., TICK>, or tick_pre_kernel + rti_kernel)
 static int ensure_tick(ndp_handle *h)
 {
     if (h->dTickThrust) return 0;
@@ -3867,13 +3893,22 @@ static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, bool
     // configuration's compile-time kernels; any other shape: tick_pre_kernel in front of the control step.  NDP_TICK_FORM=pre forces
     // the two-launch form (A/B measurements).
     static const bool force_pre = [] { const char *e = getenv("NDP_TICK_FORM"); return e && !strcmp(e, "pre"); }();
-    const bool one_launch = !force_pre && h->cfg.N == 20 && h->cfg.n_rti == 1 && h->waves == 4 && h->cfg.qp_precision == 0;
+    // (a neighbour's window node N is made INSIDE the one-launch kernel's fused downwash: without the fused form -- can_fuse -- the
+    // two-launch form serves)
+    const bool one_launch = !force_pre && h->cfg.N == 20 && h->cfg.n_rti == 1 && h->waves == 4 && h->cfg.qp_precision == 0 &&
+                            (!h->dTickIndex || can_fuse(h));
+    // the list position and the cache's copies move on only when the tick's launches have been accepted (below)
+    const unsigned long long n_after = h->list_n + (adv ? 1ull : 0ull);
     TickArgs ta{};
     if (one_launch && (adv || est)) {
         if (adv) {
             const size_t Bs = (size_t)B, S = (size_t)h->traj_seg;
             ta.coeff = h->dTraj; ta.tcum = ta.coeff + Bs * S * 28; ta.tseg = ta.tcum + Bs * (S + 1); ta.fpt = ta.tseg + Bs * S;
-            ta.segc = const_cast<double *>(ta.fpt + Bs * 3);
+            {   // the segment cache's two copies (tick_cache_store): [B][SEGC_PER] behind final_pt, the other behind the segment hints
+                double *c0 = const_cast<double *>(ta.fpt + Bs * 3), *c1 = c0 + Bs * SEGC_PER + (Bs * 4 + 7) / 8;
+                ta.segc = h->segc_par ? c1 : c0;
+                ta.segc_wr = h->segc_par ? c0 : c1;
+            }
             ta.n_seg = h->traj_seg;
         }
         ta.t = t; ta.t_all = t_all; ta.advance = adv ? 1 : 0;
@@ -3886,7 +3921,6 @@ static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, bool
         ta.throttle = throttle ? throttle : h->dTickThrust;
         ta.est = est ? 1 : 0;
         so.tick = &ta;
-        if (adv) ++h->list_n;
     } else if (adv || est) {
         TickPre a{};
         a.cf = ref_cfg(h, h->cfg.N * h->cfg.dt);
@@ -3904,9 +3938,8 @@ static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, bool
         a.est = est ? 1 : 0;
         hipLaunchKernelGGL(tick_pre_kernel, dim3((B + 63) / 64), dim3(64), 0, s, a);
         NDP_HIP(h, hipGetLastError());
-        if (adv) ++h->list_n;
     }
-    const size_t slot = rg.slot(h->list_n);
+    const size_t slot = rg.slot(n_after);
     Neigh nb;
     if (h->dTickIndex) {
         nb.other = h->dRingX + slot * 10; nb.stride = NX; nb.index = h->dTickIndex; nb.pitch = rg.px();
@@ -3916,7 +3949,11 @@ static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, bool
     // nmpc_u_2_att_tgt is the control step's own last store (RtiIo::cmd): no third launch.  k_throttle = row 1 of the estimator's state
     // (k_throttle_init until the estimator has run)
     so.cmd = cmd; so.kthr = h->dThr + (size_t)B; so.thrust_keep = h->dTickThrust;
-    return enqueue_step(h, x_odom, h->dRingX + slot * 10, h->dRingU + slot * 4, nullptr, nb, u0_copy ? u0_copy : h->su0, nullptr, s, &so);
+    rc = enqueue_step(h, x_odom, h->dRingX + slot * 10, h->dRingU + slot * 4, nullptr, nb, u0_copy ? u0_copy : h->su0, nullptr, s, &so);
+    if (rc) return rc;               // (refused: the list stays where it was -- an entry the pre-launch may have written lies beyond every window)
+    h->list_n = n_after;
+    if (adv && so.tick) h->segc_par ^= 1;
+    return 0;
 }
 
 int ndp_tick_device(ndp_handle *h, const void *d_x_odom, const void *d_t, const void *d_vz, const void *d_throttle, int flags,

@@ -65,6 +65,21 @@ def test_no_cpu_fallback():
         NMPCBodyRateController()
 
 
+def test_refinement_setting_is_refused_where_the_kernels_have_no_such_path():
+    """ipm_refine > 0 for a five-slot shape (N >= 28) or a precision study is an error of ndp_create (argument check: no
+    device needed), not a setting that is silently ignored; the Python engine creates such shapes with ipm_refine = 0 itself."""
+    import ndp_nmpc_qd_amd as ndp
+    for kw in (dict(N=40, n_rti=2, ipm_refine=2), dict(N=28, ipm_refine=1), dict(N=20, qp_precision=3, ipm_refine=2)):
+        with pytest.raises(ndp.NdpError, match="ipm_refine > 0 is not served for this shape"):
+            ndp.BatchedNMPC(4, **kw)
+    if not _has_gpu():                       # the same shapes with the engine's own choice pass the argument checks (and then find no device)
+        for kw in (dict(N=40, n_rti=2), dict(N=20, qp_precision=3)):
+            with pytest.raises(ndp.NdpError, match="no usable HIP device"):
+                ndp.BatchedNMPC(4, **kw)
+        with pytest.raises(ndp.NdpError, match="no usable HIP device"):
+            ndp.BatchedNMPC(4, N=27, ipm_refine=2)         # three-slot: served
+
+
 def test_weights_blob():
     w = _lib.load_weights()
     assert w.dtype == np.float32 and w.size == 17859

@@ -13,6 +13,7 @@ import os
 import numpy as np
 import pytest
 
+from ndp_nmpc_qd_amd import synth
 from ndp_nmpc_qd_amd.params import nmpc_params as CP
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -468,3 +469,43 @@ def test_tick_through_every_segment_and_past_the_end_equals_the_composition():
     assert np.array_equal(Xt, Xc) and np.array_equal(Ut, Uc)
     assert np.array_equal(tk.throttle_state(), cp.throttle_state())
     assert n_open > 1000, n_open                                             # gates were open for a fair share of the leader ticks
+
+
+def test_neighbours_in_other_workgroups_at_a_batch_larger_than_the_device():
+    """the one-launch tick reads its NEIGHBOUR's segment-cache record at entry while the neighbour's own wave may
+    re-fill that record in the same launch (it does whenever the neighbour crosses into its next segment) -- with the neighbour in
+    another workgroup nothing orders the two, and at a batch of several rounds of workgroups the reader can start after the writer.
+    The cache now has two copies (read one, write the other, swapped between ticks).  Here: 4096 vehicles (four rounds of 1024 waves),
+    every neighbour 1031 vehicles away (another workgroup, another XCD, usually another round), segments of 0.25 s (a crossing every
+    12.5 ticks), 40 ticks -- the tick against the composition of the stand-alone calls (which never touches the cache), bit for bit."""
+    import torch
+    import ndp_nmpc_qd_amd as ndp
+    dev = torch.device("cuda", 0)
+    B = 4096
+    tr = synth.figure_eight_traj(B, seed=5, n_seg=16, t_seg=0.25)
+    other_index = ((np.arange(B) + 1031) % B).astype(np.int32)
+    tk, cp = ndp.BatchedNMPC(B, disturbance=True), ndp.BatchedNMPC(B, disturbance=True)
+    for e in (tk, cp):
+        e.ref_set_trajectory(tr["coeff_x"], tr["coeff_y"], tr["coeff_z"], tr["coeff_yaw"], tr["time_cum"], tr["time_seg"], tr["final_pt"])
+        e.ref_list_reset()
+    tk.tick_config(other_index, gate=False)               # every gate open: the neighbour's node N feeds the network on every vehicle
+    tk.tick_reset()
+    xr, ur = cp.ref_list_window(None)
+    cp.reset(xr, ur)
+    idx_t = torch.from_numpy(other_index).to(dev)
+    u0_t = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(9)
+    for i in range(40):
+        t = 0.02 * (i + 1)
+        xr, ur = cp.ref_list_window(np.full(B, t))
+        x0 = xr[:, 0, :].copy()
+        x0[:, 0:3] += rng.normal(0.0, 0.03, size=(B, 3))
+        cp.update_device(torch.from_numpy(x0).to(dev), torch.from_numpy(xr).to(dev), torch.from_numpy(ur).to(dev), u0_t,
+                         other=torch.from_numpy(xr).to(dev), other_index=idx_t)
+        cp.synchronize()
+        cmd, u0, st, _ = tk.tick(x0, t=t, estimate=False, full=True, raise_on_status=False)
+        assert np.array_equal(u0, u0_t.cpu().numpy()), (i, float(np.max(np.abs(u0 - u0_t.cpu().numpy()))))
+        assert np.array_equal(tk.device_force().cpu().numpy(), cp.device_force().cpu().numpy()), i
+    xt, ut = tk.ref_list_window(None)
+    xc, uc = cp.ref_list_window(None)
+    assert np.array_equal(xt, xc) and np.array_equal(ut, uc)
