@@ -74,6 +74,8 @@ LEGEND = {
                "sampled across the local order): config2 = batch 1024, no downwash; config4_one_gpu = 4096 formations (12288 instances) and "
                "one rank's share of the 8-GPU run (1536), formation-major (no exchange) and vehicle-major (one-rank RCCL all-gather per step); "
                "config5 = N 40, 2 RTI, batch 4096: sweeps on the f64 / fp32 / bf16 matrix instructions, nominal and perturbed starts; "
+               "condensed_fp32 / condensed_bf16 = configs[4] as worded: every QP's first solve CONDENSED on v_mfma_f32_16x16x4_f32 / v_mfma_f32_16x16x16_bf16 "
+               "+ fp32 Cholesky in LDS (a study mode, csrc/cond_qp.hpp), kept if inside the box in fp64, else the fp64 path (qps_kept_condensed of 2 per step); "
                "err = max rel u0 error vs the fp64 oracle, ipm = fraction of instances in the interior-point loop, bad = status != 0",
     "ipm_always": "qp_mode 1: every instance runs the interior-point loop like HPIPM does",
     "mixed": "perturbed starts (0.5 m / 1 m/s / 0.15): ~20 % of the instances have inputs on their bounds (constrained = the fraction at the last tick); "
@@ -338,16 +340,29 @@ def baseline_configs_block(ndp, ndist, synth, O, torch, dev, stream, local_rank,
         b = synth.make_batch(B, N=N, seed=synth.SEED0 + 5, **kw)
         t = to_dev(b, ("x0", "xr", "ur"))
         res = {}
-        for name, prec, wq in (("fp64_work_list", 0, 1), ("fp64_in_place", 0, 2), ("fp32_mfma", 3, 2), ("bf16_mfma", 4, 2)):
+        for name, prec, wq in (("fp64_work_list", 0, 1), ("fp64_in_place", 0, 2), ("fp32_mfma", 3, 2), ("bf16_mfma", 4, 2),
+                               ("condensed_fp32", 5, 2), ("condensed_bf16", 6, 2)):
             eng = ndp.BatchedNMPC(B, N=N, n_rti=2, qp_precision=prec, work_queue=wq, device=local_rank)
             u0 = torch.empty(B, 4, dtype=torch.float64, device=dev)
             rs = lambda: eng.reset_device(t["xr"], t["ur"], stream=stream)                                            # noqa: E731
             en = lambda i: eng.update_device(t["x0"], t["xr"], t["ur"], u0, stream=stream)                            # noqa: E731
-            ms, mode = run_leg(eng, en, rs, B, graph=False)
+            if prec >= 5:                         # the condensed study: 12-20 ms per step -- three timed steps, not forty
+                rs(); en(0); torch.cuda.synchronize()
+                tq = time.perf_counter()
+                for i in range(3):
+                    en(i)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - tq) / 3 * 1e3
+            else:
+                ms, mode = run_leg(eng, en, rs, B, graph=False)
             rs(); en(0); torch.cuda.synchronize()
             st, it = eng.status()
-            par, _, ok = parity(u0.cpu().numpy(), b, N, 2, False, None, sample(B, NS))
+            par, u_or, ok = parity(u0.cpu().numpy(), b, N, 2, False, None, sample(B, NS))
             res[name] = {"value": B / ms * 1e3, "us": ms * 1e3, "err": par, "bad": int((st != 0).sum()), "ipm": float((it > 0).mean())}
+            if prec >= 5:
+                sel = sample(B, NS)
+                e_ = np.max(np.abs(u0.cpu().numpy()[sel][ok] - u_or[ok]) / np.maximum(1.0, np.abs(u_or[ok])), axis=1)
+                res[name].update({"err_median": float(np.median(e_)), "qps_kept_condensed": float(eng.condensed_kept().mean()), "of": 2})
             del eng
         c5[label] = res
     out["config5"] = c5

@@ -54,6 +54,11 @@ size_t ndp_cfg_size(void);
 #define NDP_PREC_BF16_STUDY 2 /* ... rounded to bf16 */
 #define NDP_PREC_F32_MFMA 3   /* the Riccati sweeps on v_mfma_f32_16x16x4_f32 */
 #define NDP_PREC_BF16_MFMA 4  /* the Riccati sweeps on v_mfma_f32_16x16x16_bf16 (bf16 in, fp32 accumulate) */
+#define NDP_PREC_COND_F32 5   /* BASELINE configs[4] as worded -- "fp32 vs bf16 MFMA on the CONDENSED QP": the first solve of every QP in condensed
+                               * form (prediction matrices, H = R + Gamma' Q Gamma and the gradient as tiled products on v_mfma_f32_16x16x4_f32, fp32
+                               * Cholesky in LDS, csrc/cond_qp.hpp); kept when it passes the fp64 inside-the-box test, else the fp64 Riccati path
+                               * solves the QP.  A STUDY mode (the reference does not condense: qp_solver_cond_N = N): N a multiple of 4, <= 40 */
+#define NDP_PREC_COND_BF16 6  /* ... the products on v_mfma_f32_16x16x16_bf16 (fp32 accumulate, fp32 Cholesky) */
 
 typedef struct ndp_cfg {
     int32_t batch;      /* B: independent OCP instances in this handle            */

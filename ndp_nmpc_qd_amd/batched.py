@@ -373,7 +373,14 @@ class BatchedNMPC:
         sw = np.zeros(self.B, dtype=np.int32)
         act = np.zeros((self.B, self.N, 4), dtype=np.int8)
         self._check(self._lib.ndp_get_active_set(self._h, _lib.ptr(sw), _lib.ptr(act)), "ndp_get_active_set")
-        return sw, act
+        return sw & 0xfff, act
+
+    def condensed_kept(self):
+        """qp_precision 5 / 6 (config 5's condensed study): how many of the last step's QPs per instance kept their condensed solve's
+        result (it passed the fp64 inside-the-box test); the others were solved by the fp64 Riccati path."""
+        sw = np.zeros(self.B, dtype=np.int32)
+        self._check(self._lib.ndp_get_active_set(self._h, _lib.ptr(sw), None), "ndp_get_active_set")
+        return (sw >> 12) & 0xf
 
     # ------------------------------------------------------------------ HBM-resident API (torch CUDA tensors)
     @staticmethod

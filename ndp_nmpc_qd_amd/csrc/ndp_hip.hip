@@ -36,6 +36,7 @@
 
 #include "wave_gfx950.hpp"   // defines the device qualifiers, must precede rti_wave.hpp
 #include "cfg_params.hpp"
+#include "cond_qp.hpp"
 #define NDP_PEER_FN __host__ __device__ inline
 #include "peer_epoch.hpp"
 
@@ -373,7 +374,8 @@ __global__ __launch_bounds__(64 * WAVES) NDP_RTI_ATTR void rti_kernel(KernArgs k
     // PREC 0: the product path (f64 matrix instruction); 1 / 2: operand-rounding studies on it; 3 / 4: the sweeps on the real
     // fp32 / bf16-input matrix instructions (BASELINE config 5)
     using WB = std::conditional_t<PREC == 3, WaveGfx950F32, std::conditional_t<PREC == 4, WaveGfx950BF16, WaveGfx950>>;
-    using Prog = RtiWave<WB, NSLOT, NC, true, NRC, (PREC >= 3 ? 0 : PREC), QMODE == 3>;   // compile-time horizon and iteration count (NC = 0: both at run time)
+    // PREC 5 / 6: config 5's CONDENSED study (cond_qp.hpp) -- the f64 program with every QP's first solve in condensed form on the fp32 / bf16 instructions
+    using Prog = RtiWave<WB, NSLOT, NC, true, NRC, (PREC >= 3 ? 0 : PREC), QMODE == 3, (PREC == 5 ? 1 : (PREC == 6 ? 2 : 0))>;   // compile-time horizon and iteration count (NC = 0: both at run time)
     if (NDP_RARELY(io.stamps && (threadIdx.x & 63u) == 0)) {    // profiling hook: real time (100 MHz) and shader clock at entry -> the clock the launch ran at
         io.stamps[12] = (double)__builtin_amdgcn_s_memrealtime();
         io.stamps[14] = (double)__builtin_amdgcn_s_memtime();
@@ -1956,6 +1958,11 @@ template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = 
 #endif
 struct RtiK { static constexpr auto fn = rti_kernel<3, (WAVES == 2 && NC == 20 ? 2 : 4), (FUSED && NC == 20 && QMODE == 0), 20, 0, 1, NDP_DEV_QMODE, (TICK && NC == 20 && QMODE == 0)>; };
 #define RTI_K(...) (RtiK<__VA_ARGS__>::fn)
+#elif defined(NDP_DEV_COND_ONLY)
+// compile / register studies of the condensed study kernels: every instantiation collapses onto rti_kernel<5, 1, false, 0, 5 or 6>
+template <int NSLOT, int WAVES, bool FUSED, int NC = 0, int PREC = 0, int NRC = (NC ? 1 : 0), int QMODE = 0, bool TICK = false>
+struct RtiK { static constexpr auto fn = rti_kernel<5, 1, false, 0, (PREC == 6 ? 6 : 5)>; };
+#define RTI_K(...) (RtiK<__VA_ARGS__>::fn)
 #elif defined(NDP_DEV_N40_ONLY)
 // register studies of config 5's shape (scripts/dev_regs.sh): every instantiation collapses onto rti_kernel<5, 2, false, 40, 0, 2, NDP_DEV_QMODE>
 #ifndef NDP_DEV_QMODE
@@ -2563,9 +2570,13 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
 {
     if (!cfg || !out) { g_create_err = "ndp_create: null argument"; return -1; }
     *out = nullptr;
-    if (cfg->batch < 1 || cfg->N < 2 || slots_for(cfg->N) > 5 || cfg->n_rti < 1 || cfg->qp_precision < 0 || cfg->qp_precision > 4 ||
+    if (cfg->batch < 1 || cfg->N < 2 || slots_for(cfg->N) > 5 || cfg->n_rti < 1 || cfg->qp_precision < 0 || cfg->qp_precision > 6 ||
         cfg->work_queue < 0 || cfg->work_queue > 2 || !(cfg->ts_nmpc > 0.0) || cfg->dt < cfg->ts_nmpc) {
-        g_create_err = "ndp_create: need batch >= 1, 2 <= N <= 46, n_rti >= 1, qp_precision in 0..4, work_queue in 0..2, 0 < ts_nmpc <= dt";
+        g_create_err = "ndp_create: need batch >= 1, 2 <= N <= 46, n_rti >= 1, qp_precision in 0..6, work_queue in 0..2, 0 < ts_nmpc <= dt";
+        return -2;
+    }
+    if (cfg->qp_precision >= 5 && (cfg->N % 4 != 0 || cfg->N > 40)) {
+        g_create_err = "ndp_create: the condensed study (qp_precision 5 / 6) tiles the 4N x 4N Hessian by 16: N must be a multiple of 4, at most 40";
         return -2;
     }
     if (cfg->ipm_refine > 0 && (slots_for(cfg->N) > 3 || cfg->qp_precision != 0)) {
@@ -2596,6 +2607,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     h->P = to_params(*cfg);
     h->list_step = (int)(cfg->dt / cfg->ts_nmpc + 0.5);      // params/nmpc_params.py:40-43: every 5th list entry is a node
     h->lds_per_wave = (lds_doubles(cfg->N) + 1) & ~1;   // keep 16-byte alignment per wave slice
+    if (cfg->qp_precision >= 5) h->lds_per_wave += (cond_extra_doubles(cfg->N) + 1) & ~1;   // (the condensed study works behind the slice: one wave per workgroup)
     const size_t per_wave_bytes = (size_t)h->lds_per_wave * sizeof(double);
     h->waves = 4;
     while (h->waves > 1 && per_wave_bytes * h->waves > 160 * 1024) h->waves >>= 1;
@@ -2650,7 +2662,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
         if ((e = hipMemcpyAsync(h->dKC, kc, sizeof(kc), hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail("hipMemcpy kc", e);
         ALLOC(h->dTables, TB_WORDS * 4);
         std::vector<int> tb(TB_WORDS);
-        fill_tables(cfg->N, tb.data(), cfg->qp_precision >= 3 ? 1 : 0);   // the fp32 / bf16 instructions keep a different column per lane
+        fill_tables(cfg->N, tb.data(), (cfg->qp_precision == 3 || cfg->qp_precision == 4) ? 1 : 0);   // the fp32 / bf16 sweeps keep a different column per lane
         if ((e = hipMemcpyAsync(h->dTables, tb.data(), TB_WORDS * 4, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail("hipMemcpy tables", e);
         if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
     }
@@ -2699,6 +2711,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
                          (const void *)RTI_K(3, 4, true, 20, 0, 1, 1, true), (const void *)RTI_K(3, 4, false, 20, 0, 1, 1, true),
                          (const void *)RTI_K(5, 1, false, 0, 1), (const void *)RTI_K(5, 1, false, 0, 2),
                          (const void *)RTI_K(5, 1, false, 0, 3), (const void *)RTI_K(5, 1, false, 0, 4),
+                         (const void *)RTI_K(5, 1, false, 0, 5), (const void *)RTI_K(5, 1, false, 0, 6),
                          (const void *)RTI_K(5, 2, false, 40, 3, 2), (const void *)RTI_K(5, 2, false, 40, 4, 2),
                          (const void *)RTI_K(5, 2, false, 40, 0, 2), (const void *)RTI_K(5, 2, false, 40, 0, 2, 1), (const void *)RTI_K(5, 2, false, 40, 0, 2, 2)};
     if ((e = hipFuncSetAttribute((const void *)mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2885,7 +2898,9 @@ static int launch_rti(ndp_handle *h, const double *d_x0, const double *d_xr, con
         } else if (pr == 1) hipLaunchKernelGGL(RTI_K(5, 1, false, 0, 1), dim3(B), dim3(64), shm1, s, ka);   // any horizon: one wave per workgroup
         else if (pr == 2) hipLaunchKernelGGL(RTI_K(5, 1, false, 0, 2), dim3(B), dim3(64), shm1, s, ka);
         else if (pr == 3) hipLaunchKernelGGL(RTI_K(5, 1, false, 0, 3), dim3(B), dim3(64), shm1, s, ka);
-        else hipLaunchKernelGGL(RTI_K(5, 1, false, 0, 4), dim3(B), dim3(64), shm1, s, ka);
+        else if (pr == 4) hipLaunchKernelGGL(RTI_K(5, 1, false, 0, 4), dim3(B), dim3(64), shm1, s, ka);
+        else if (pr == 5) hipLaunchKernelGGL(RTI_K(5, 1, false, 0, 5), dim3(B), dim3(64), shm1, s, ka);     // config 5, condensed: fp32 instruction
+        else hipLaunchKernelGGL(RTI_K(5, 1, false, 0, 6), dim3(B), dim3(64), shm1, s, ka);                   // ... bf16 instruction
         NDP_HIP(h, hipGetLastError());
         if (so && so->done) NDP_HIP(h, hipEventRecord(so->done, s));
         else if (h->track_steps) {          // (a recorded event here: the precision studies are not on the exchange's fast path)

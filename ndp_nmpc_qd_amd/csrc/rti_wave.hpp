@@ -146,8 +146,9 @@ struct RtiIo {            // global-memory views of ONE instance
     signed char *act = nullptr;
 };
 NDP_HD int act_pitch(int N) { return 4 * N; }      // bytes per instance of the active-set record
-// *RtiIo::iters = interior-point iterations of the step (low half) + Riccati sweeps its QP_AUTO solves took before them (high half)
-enum { ITERS_SWEEP_SHIFT = 16, ITERS_IPM_MASK = 0xffff };
+// *RtiIo::iters = interior-point iterations of the step (low half) + Riccati sweeps its QP_AUTO solves took before them (high half);
+// COND_ACCEPTED in the sweep count (config 5's study): a condensed solve's result was kept
+enum { ITERS_SWEEP_SHIFT = 16, ITERS_IPM_MASK = 0xffff, COND_ACCEPTED = 0x1000 };
 
 struct LdsMap {
     int KC, SC, XI, UI, ZX, ZU, CX, CU, ZD, MB, CB, KT, TXR, TUR, TF, AS, total;
@@ -212,7 +213,10 @@ NDP_HD void fill_kc(const RtiParams &P, double *kc)
 // a sweep on v_mfma_f32_16x16x4_f32 / a bf16-input MFMA with fp32 accumulation would see; everything else stays f64.
 // LEAN: no stiff path in the interior-point loop (see ipm(): STIFF).  For the control step that runs BESIDE the downwash launch of the next
 // tick (late force): the two kernels' waves share a SIMD's 512 registers, 184 of them the downwash launch's -- the stiff sweeps cost 80.
-template <class W, int NSLOT, int NC = 0, bool HT = false, int NR = 0, int PREC = 0, bool LEAN = false>
+// COND: BASELINE config 5's study of the CONDENSED QP (cond_qp.hpp; gfx950 backend only): 1 / 2 = the first solve of every QP in condensed
+// form on the fp32 / bf16 matrix instructions; its result is kept when it passes the fp64 inside-the-box test, else the fp64 path below
+// solves the QP.  0 = the product.
+template <class W, int NSLOT, int NC = 0, bool HT = false, int NR = 0, int PREC = 0, bool LEAN = false, int COND = 0>
 struct RtiWave {
     static NDP_D int horizon(const RtiParams &P) { return NC ? NC : P.N; }
     static constexpr int UNROLL_STAGES = NC > 0 ? NC : 1;
@@ -1867,7 +1871,7 @@ struct RtiWave {
         ActSet A;
         if (as_on) as_issue(P, io, A);       // (in flight under the cost / linearisation phases)
         else for (int t = 0; t < RUA; ++t) A.a[t] = vi(0);
-        int sweeps = 0;
+        int sweeps = 0, cond_kept = 0;
         // Several RTI iterations per step at a compile-time count (NR >= 2, config 5): the iteration loop stays a LOOP (its body is
         // 17 k instructions), so inputs requested in front of it and replaced inside it are loop-carried values -- 23 doubles per lane
         // held (in scratch memory, as it turned out) across the first iteration's sweeps and interior-point loop for nothing.  Those
@@ -1945,7 +1949,15 @@ struct RtiWave {
                 const int sweeps0 = sweeps;            // (as_iter_max counts per QP, `sweeps` over the step's RTI iterations)
                 for (;;) {
                     stamp(io, m, 5);
-                    bool ok = riccati_sweep(P, m, T, lds, &io);
+                    bool ok = false, condensed = false;
+                    if constexpr (COND != 0) {
+                        if (!pinned && sweeps == sweeps0) {       // the QP's first solve: condensed, fp32 / bf16 (a failed factorisation: the sweep)
+                            condensed = W::template cond_solve<COND>(P, m, lds, N,
+                                                                     [&](int r, int c) { return m_entry(m, r, c); }, [&](int r, int c) { return c_entry(m, r, c); });
+                            ok = condensed;
+                        }
+                    }
+                    if (!condensed) ok = riccati_sweep(P, m, T, lds, &io);
                     stamp(io, m, 7);
                     ++sweeps;
                     if (NDP_RARELY(!ok)) {
@@ -1957,7 +1969,17 @@ struct RtiWave {
                     // (the constraint slots are built only at the interior-point loop's door: keeping ~90 more registers live across the
                     // sweep forces the MFMA accumulators into AGPRs with copies on every dependency)
                     const int verdict = as_check(P, m, lds, A, as_on ? 0.0 : P.auto_margin, P.auto_margin, as_on, pinned);
-                    if (verdict == 0) { done = true; break; }      // then the step is the sweep's solution, read where it lies (ZX|ZU)
+                    if (verdict == 0) {                            // then the step is the sweep's solution, read where it lies (ZX|ZU)
+                        if (COND != 0 && condensed) cond_kept += COND_ACCEPTED;
+                        done = true;
+                        break;
+                    }
+                    if constexpr (COND != 0) {
+                        if (condensed && verdict != 1) {           // outside the box in a way the active set does not take up: the fp64 solve, then the usual course
+                            pinned = true;                         // (marks "not the first solve": no pins exist, as_check's general part handles that)
+                            continue;
+                        }
+                    }
                     if (!DEFER && NDP_RARELY(as_on && verdict == 1 && sweeps - sweeps0 <= P.as_iter_max)) {
                         as_apply(P, m, lds, A);
                         pinned = true;                 // (an update that only releases may leave no pin: the general test handles an empty set too)
@@ -2028,7 +2050,7 @@ struct RtiWave {
         }
         stamp(io, m, 8);
         W::gsti(io.status, status);
-        W::gsti(io.iters, iters + (sweeps << int(ITERS_SWEEP_SHIFT)));
+        W::gsti(io.iters, iters + ((sweeps + cond_kept) << int(ITERS_SWEEP_SHIFT)));
         // the kept set changed <=> a QP took more than its one sweep (a set that holds reproduces itself in the first one)
         if (NDP_RARELY(as_on && io.act && sweeps != n_rti)) as_store(P, m, lds, io, A);
         if (io.f_late) W::late_publish(late_prev, io.late_gsize, io.late_done_word);

@@ -10,6 +10,9 @@
 
 namespace ndp {
 
+struct RtiParams;
+struct LdsMap;
+
 struct WaveGfx950 {
     using vd = double;
     using vi = int;
@@ -27,6 +30,10 @@ struct WaveGfx950 {
     static NDP_D vi lcol(vi lane) { return lane & 15; }        // the matrix column a lane holds (RtiWave::lane_preds)
     typedef __attribute__((address_space(3))) double *lds_ptr;
     typedef double d4_t __attribute__((ext_vector_type(4)));
+
+    // BASELINE config 5's study: one QP in condensed form on the fp32 / bf16 matrix instructions (cond_qp.hpp)
+    template <int MODE, class ME, class CE>
+    static __device__ bool cond_solve(const RtiParams &P, const LdsMap &m, lds_ptr lds, int N, ME m_entry, CE c_entry);
 
     static NDP_D vi lane() { return (int)(threadIdx.x & 63u); }
     // the lane id as a value the compiler cannot trace back to the thread id: index arithmetic built on it stays WHERE it is written
