@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, datasheet; v_mfma_f64_16x16x4 = 2048 FLOP / 64 clk / SIMD
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 PEER_FORMS = ("peer", "peer_ahead")   # the publish / subscribe forms of the per-tick neighbour exchange (see mode_names)
-PROFILE_TAGS = ("r05", "r04", "r03", "r02")  # newest first: profiles/<tag>_kernel_stats_fused_b1024.csv + <tag>_pmc_rti_kernel.json = the DEFAULT configuration's profile
+PROFILE_TAGS = ("r06", "r05", "r04", "r03", "r02")  # newest first: profiles/<tag>_kernel_stats_fused_b1024.csv + <tag>_pmc_rti_kernel.json = the DEFAULT configuration's profile
 PROFILE_TOLERANCE = 0.25       # a committed profile whose kernel duration is further than this from the live HIP-event duration is refused
 
 

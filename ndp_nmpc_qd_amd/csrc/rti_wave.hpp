@@ -1412,7 +1412,9 @@ struct RtiWave {
     // Velocity bounds are not pinned (a weight on a STATE makes the recursion stiff: see ROBUST): a violated one, a set that does not
     // settle within as_iter_max sweeps, or a failed factorisation hand the QP to the interior-point loop, which starts from the base
     // cost blocks whatever the pins did to them.
-#ifdef NDP_DEV_NO_AS5
+#if defined(NDP_DEV_NO_AS)
+    static constexpr bool ASET = false;
+#elif defined(NDP_DEV_NO_AS5)
     static constexpr bool ASET = NSLOT <= 3;
 #else
     static constexpr bool ASET = true;
