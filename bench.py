@@ -77,6 +77,8 @@ LEGEND = {
                "condensed_fp32 / condensed_bf16 = configs[4] as worded: every QP's first solve CONDENSED on v_mfma_f32_16x16x4_f32 / v_mfma_f32_16x16x16_bf16 "
                "+ fp32 Cholesky in LDS (a study mode, csrc/cond_qp.hpp), kept if inside the box in fp64, else the fp64 path (qps_kept_condensed of 2 per step); "
                "err = max rel u0 error vs the fp64 oracle, ipm = fraction of instances in the interior-point loop, bad = status != 0",
+    "repeat": "REPEATS more passes over the same --steps steps (same graph) behind the timed region, each timed alone: ms_per_step = [min, median, max]; "
+              "value_median = solves/s at the median pass; `value` itself is the contract's one pass",
     "ipm_always": "qp_mode 1: every instance runs the interior-point loop like HPIPM does",
     "mixed": "perturbed starts (0.5 m / 1 m/s / 0.15): ~20 % of the instances have inputs on their bounds (constrained = the fraction at the last tick); "
              "value = the default mode (active-set iterations, sets kept between ticks; ipm = fraction that still needed the interior-point loop), "
@@ -1187,8 +1189,6 @@ def main():
             legend["roofline.kernel_us"] = ("HIP events on the launch stream around the timed region / steps" if one_launch
                                             else "HIP start / stop events on the dispatch packets of host-launched steps")
             legend["roofline.clock_ghz"] = clock_src
-            legend["repeat"] = (f"{REPEATS} more passes over the same {args.steps} steps (same graph) behind the timed region, each timed alone: "
-                                "ms_per_step = [min, median, max]; value_median = solves/s at the median pass; `value` itself is the contract's one pass")
             if partial:
                 out["watchdog"] = {"fired": True, "legs": {m: e[:80] for m, e in form_errors.items()}, "headline_parity_checked": parity is not None}
                 legend["watchdog"] = ("a secondary form did not come back within --leg-timeout-s: this line was built by the watchdog from the forms that had "

@@ -108,7 +108,7 @@ def test_the_line_is_compacted_and_the_legend_covers_its_blocks():
     assert c["value"] == 47191000.0 and c["ms_per_step"] == 0.021699 and c["n"] == 3 and c["ok"] is True and c["none"] is None
     assert c["nan"] != c["nan"] and c["nested"]["a"] == [1.2346e-07, 2, "text"] and c["nested"]["b"] == [0.3]
     assert len(json.dumps(c, separators=(",", ":"))) < len(json.dumps(line))
-    for block in ("roofline", "forms", "scaling_baseline", "configs", "ipm_always", "mixed", "host", "tick", "cpu_baseline", "config1", "rows"):
+    for block in ("roofline", "forms", "scaling_baseline", "configs", "ipm_always", "mixed", "constrained", "repeat", "host", "tick", "cpu_baseline", "config1", "rows"):
         assert block in bench.LEGEND and len(bench.LEGEND[block]) > 40
 
 
@@ -123,3 +123,18 @@ def test_the_committed_line_fits_the_drivers_record():
         assert block in d, block
     assert d["tick"]["launches_per_tick"] == 1 and d["tick"]["parity"] <= 1e-5 and d["tick"]["value_host_inclusive_x0_only"] > 3.0e7
     assert list(d).index("configs") < list(d).index("mixed")
+    # the line says which reading of the metric `value` is and carries SURVEY 8d's host-inclusive readings beside it;
+    # the timed region is backed by repeated passes over the same steps; the host block says what it ran on
+    assert d["metric_variant"] == "device_resident"
+    assert d["value_host_inclusive"] == d["host"]["two"]["value"] and d["value_tick"] == d["tick"]["value_host_inclusive_x0_only"]
+    rp = d["repeat"]
+    assert rp["n"] >= 10 and rp["ms_per_step"][0] <= rp["ms_per_step"][1] <= rp["ms_per_step"][2] and abs(rp["ms_per_step"][1] / d["ms_per_step"] - 1) < 0.1
+    assert d["host"]["pack_threads"] >= 0 and 1 <= d["host"]["usable_cores"] <= d["host"]["hw_threads"]
+    assert d["cpu_baseline"]["per_core"] * d["cpu_baseline"]["cores"] == pytest.approx(d["cpu_baseline"]["value"], rel=1e-3) and 0.1 < d["cpu_baseline"]["mlp_share"] < 0.7
+    # the constrained workloads in the default mode against the interior-point loop on the same inputs
+    assert d["mixed"]["b1024"]["value"] >= 1.6e7 and d["mixed"]["b1024"]["value"] > 2 * d["mixed"]["b1024"]["value_as_off"] and d["mixed"]["b1024"]["bad"] == 0
+    assert d["constrained"]["value"] >= 2.5e7 and d["constrained"]["value_as_off"] < d["constrained"]["value"] and d["constrained"]["bad"] == 0
+    # row +: the condensed study's legs
+    c5 = d["configs"]["config5"]["nominal"]
+    assert c5["condensed_fp32"]["qps_kept_condensed"] == 2.0 and 1e-6 < c5["condensed_fp32"]["err"] < 1e-2 and c5["condensed_fp32"]["value"] < c5["fp64_in_place"]["value"]
+    assert c5["condensed_bf16"]["bad"] == 0
