@@ -2648,7 +2648,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     const size_t B = cfg->batch;
 #define ALLOC(p, n)                                                                      \
     if ((e = hipMalloc((void **)&(p), (n))) != hipSuccess) return fail("hipMalloc " #p, e)
-    ALLOC(h->dForce, nfs(h) * 4); ALLOC(h->dFrag, FR_TOTAL * 4); ALLOC(h->dKC, KC_SC * 8);
+    ALLOC(h->dForce, nfs(h) * 4); ALLOC(h->dFrag, FR_TOTAL * 4); ALLOC(h->dKC, KC_HOST * 8);
     ALLOC(h->dThr, B * 8 * 8); ALLOC(h->sThr, B * 11 * 8);
     ALLOC(h->dRelay, B * 4 * 8);
     ALLOC(h->dQctr, 256); ALLOC(h->dQids, B * 4);
@@ -2657,7 +2657,7 @@ int ndp_create(const ndp_cfg *cfg, ndp_handle **out)
     (void)hipMemsetAsync(h->dRelay, 0, B * 4 * 8, h->stream);
     (void)hipMemsetAsync(h->dQctr, 0, 256, h->stream);
     {
-        double kc[KC_SC];
+        double kc[KC_HOST];
         fill_kc(h->P, kc);
         if ((e = hipMemcpyAsync(h->dKC, kc, sizeof(kc), hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail("hipMemcpy kc", e);
         ALLOC(h->dTables, TB_WORDS * 4);

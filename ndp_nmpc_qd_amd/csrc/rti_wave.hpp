@@ -62,7 +62,11 @@ enum { MB_PV = 0, MB_Q = 48, MB_B = 76, MB_ZERO = 86, MB_ONE = 87, MB_H = 88, MB
 // cost block CB_k: Qq(4x4) | qe(10) | re(4) | dex(6) | constant 0 | qbv(3) | deu(4) | rb(4)
 enum { CB_QQ = 0, CB_QE = 16, CB_RE = 26, CB_DEX = 30, CB_ZERO = 36, CB_QBV = 37, CB_DEU = 40, CB_RB = 44 };
 // constants area
-enum { KC_ZERO = 0, KC_ONE = 1, KC_H = 2, KC_QD = 3, KC_RD = 13, KC_LBV = 17, KC_UBV = 21, KC_LBU = 24, KC_UBU = 28, KC_SC = 32, KC_DUMP = 48, KC_SIZE = 50 };
+enum { KC_ZERO = 0, KC_ONE = 1, KC_H = 2, KC_QD = 3, KC_RD = 13, KC_LBV = 17, KC_UBV = 21, KC_LBU = 24, KC_UBU = 28, KC_SC = 32, KC_DUMP = 48,
+       // the box as QP_AUTO's acceptance test looks at it: every bound moved inwards by its margin (velocities: auto_margin; inputs: auto_margin
+       // with the active set off, 0 with it on) -- made by the host (fill_kc), so that the test behind the sweep needs no scalar parameter
+       // (a scalar load issued in front of the sweep makes the sweep's first LDS wait a wait for it as well: one counter for both)
+       KC_LBVM = 50, KC_UBVM = 53, KC_LBUM = 56, KC_UBUM = 60, KC_SIZE = 64, KC_HOST = 64 };
 // A box constraint (interior-point loop) touches eight LDS places: the step variable, the iterate value, the diagonal / gradient /
 // base-gradient entries of its cost block, its two bounds and its weight.  The two layouts above are arranged so that FIVE of them
 // sit at the same distance from another one for input bounds and velocity bounds alike -- three offsets per constraint slot live in
@@ -108,7 +112,7 @@ struct RtiIo {            // global-memory views of ONE instance
     int *status, *iters;  // per-instance
     double *dbg;          // optional dump area (tests), or null
     int f_in_lds;         // 1: the caller already left f (as doubles) in the LDS staging slot TF (fused downwash)
-    const double *kc;     // [KC_SC] lane-indexable constants block prepared by the host (fill_kc)
+    const double *kc;     // [KC_HOST] lane-indexable constants block prepared by the host (fill_kc)
     double *stamps = nullptr;   // optional [16] per-instance phase stamps (whole-batch profiling), or null
     const int *tables = nullptr;   // [TB_WORDS] host-built index tables (fill_tables), read when RtiWave<..., HT = true>
     double *Xm = nullptr, *Um = nullptr;   // optional second destination of the new iterate (a page-locked host block the caller reads), or null
@@ -194,12 +198,15 @@ NDP_HD void lds_layout(int N, int *out)
 // instead of a 30-way select chain per launch)
 NDP_HD void fill_kc(const RtiParams &P, double *kc)
 {
-    for (int i = 0; i < KC_SC; ++i) kc[i] = 0.0;
+    for (int i = 0; i < KC_HOST; ++i) kc[i] = 0.0;
     kc[KC_ONE] = 1.0;
     kc[KC_H] = P.dt;
     for (int i = 0; i < 10; ++i) kc[KC_QD + i] = P.Qd[i];
     for (int i = 0; i < 4; ++i) { kc[KC_RD + i] = P.Rd[i]; kc[KC_LBU + i] = P.lbu[i]; kc[KC_UBU + i] = P.ubu[i]; }
     for (int i = 0; i < 3; ++i) { kc[KC_LBV + i] = P.lbv[i]; kc[KC_UBV + i] = P.ubv[i]; }
+    const double um = (P.qp_mode == QP_AUTO && P.as_iter_max > 0) ? 0.0 : P.auto_margin;
+    for (int i = 0; i < 4; ++i) { kc[KC_LBUM + i] = P.lbu[i] + um; kc[KC_UBUM + i] = P.ubu[i] - um; }
+    for (int i = 0; i < 3; ++i) { kc[KC_LBVM + i] = P.lbv[i] + P.auto_margin; kc[KC_UBVM + i] = P.ubv[i] - P.auto_margin; }
 }
 
 // NC > 0: the horizon is a compile-time constant (every LDS offset folds into the DS instruction's immediate, every
@@ -509,7 +516,7 @@ struct RtiWave {
             vi i = W::imin(lane + 64 * t, nf - 1);
             b.f[t] = have_f ? (NDP_RARELY(io.f_is_f64 != 0) ? W::gldu(reinterpret_cast<const double *>(io.f), i) : W::gldfu(io.f, i)) : vd(0.0);
         }
-        b.kc = first ? W::gldu(io.kc, W::imin(lane, KC_SC - 1)) : vd(0.0);
+        b.kc = first ? W::gldu(io.kc, W::imin(lane, KC_HOST - 1)) : vd(0.0);
     }
 
     // land them in LDS (first use of the loaded values: the wait sits here)
@@ -540,7 +547,7 @@ struct RtiWave {
             vi i = W::imin(lane + 64 * t, nf - 1);
             W::st(lds, i + m.TF, b.f[t]);
         }
-        if (first) W::st(lds, W::imin(lane, KC_SC - 1) + m.KC, b.kc);   // constants area
+        if (first) W::st(lds, W::imin(lane, KC_HOST - 1) + m.KC, b.kc);   // constants area (the scratch in its middle is dead here)
         W::sync();
     }
 
@@ -1488,11 +1495,11 @@ struct RtiWave {
         W::sync();
     }
     // The sweep's solution (ZX|ZU) against the set it was made with.  Returns 0: the set reproduces itself, every free input and every
-    // velocity is inside its box (velocities by `vmargin`) -- the QP is solved, pinned inputs are set onto their bounds; 1: the set
-    // changed (A updated); 2: a velocity bound is violated or closer than vmargin -- not this method's case.
-    // With as_iter_max = 0 the test is rounds 1-5's: accepted only if inside EVERY bound by umargin = auto_margin -- what keeps the early
+    // velocity is inside its box (velocities by auto_margin) -- the QP is solved, pinned inputs are set onto their bounds; 1: the set
+    // changed (A updated); 2: a velocity bound is violated or closer than auto_margin -- not this method's case.
+    // With as_iter_max = 0 the test is rounds 1-5's: accepted only if inside EVERY bound by auto_margin (the moved bounds of fill_kc) -- what keeps the early
     // exit within ~1e-6 of an interior-point solve stopped at mu <= tol (HPIPM, the oracle's qp_mode 1): at a slack t the barrier leaves a
-    // multiplier mu / t on an INACTIVE bound, which moves the solution by ~mu / (t * weight).  With the active set on, umargin = 0: the
+    // multiplier mu / t on an INACTIVE bound, which moves the solution by ~mu / (t * weight).  With the active set on, the inputs' margin is 0: the
     // answer is the QP's exact solution, and an interior-point answer is compared with it at ITS accuracy (tests: the oracle at a tight
     // tolerance).  The velocity margin stays: a velocity bound that close belongs to the interior-point loop.
     // Evaluated without the constraint slots (which the interior-point loop needs, this does not): the 4N input bounds as they lie in
@@ -1501,7 +1508,7 @@ struct RtiWave {
     // (A NaN makes every comparison false: the QP then goes the interior-point loop's way, which reports it.)
     // pinned = false: the sweep was made with an empty set (the usual case: the caller knows) -- the test is then the handful of
     // comparisons rounds 1-5 made, and everything that deals with pins sits behind a branch the wave almost never takes.
-    static NDP_D int as_check(const RtiParams &P, const LdsMap &m, lp lds, ActSet &A, double umargin, double vmargin, bool update, bool pinned)
+    static NDP_D int as_check(const RtiParams &P, const LdsMap &m, lp lds, ActSet &A, bool update, bool pinned)
     {
         const int N = horizon(P), nzu = N * NU, nv4 = 4 * (N - 1);
         constexpr int RVm = NC ? (4 * (NC - 1) + 63) / 64 : NSLOT;
@@ -1515,20 +1522,20 @@ struct RtiWave {
             vi e = W::imin(lane + 64 * t, nzu - 1);
             vi c = e & 3;
             zu[t] = W::ld(lds, e + m.ZU); cu[t] = W::ld(lds, e + (m.ZU + io));
-            lu[t] = W::ld(lds, c + (m.KC + int(KC_LBU))); hu[t] = W::ld(lds, c + (m.KC + int(KC_UBU)));
+            lu[t] = W::ld(lds, c + (m.KC + int(KC_LBUM))); hu[t] = W::ld(lds, c + (m.KC + int(KC_UBUM)));    // (moved inwards by the margin: fill_kc)
         }
         for (int t = 0; t < RVm; ++t) {
             vi q = W::imin(lane + 64 * t, nv4 - 1);
             vi k = (q >> 2) + 1, c = W::imin(q & 3, 2);           // component 3 repeats component 2
             vi zo = k * int(NX) + c + (m.ZX + 3);
             zv[t] = W::ld(lds, zo); cv[t] = W::ld(lds, zo + io);
-            lv[t] = W::ld(lds, c + (m.KC + int(KC_LBV))); hv[t] = W::ld(lds, c + (m.KC + int(KC_UBV)));
+            lv[t] = W::ld(lds, c + (m.KC + int(KC_LBVM))); hv[t] = W::ld(lds, c + (m.KC + int(KC_UBVM)));
         }
         vb vok = lane >= 0, uok = lane >= 0;
         for (int t = 0; t < RUA; ++t)
-            uok = W::band(uok, W::band(zu[t] > (lu[t] - cu[t]) + umargin, zu[t] < (hu[t] - cu[t]) - umargin));
+            uok = W::band(uok, W::band(zu[t] > lu[t] - cu[t], zu[t] < hu[t] - cu[t]));
         for (int t = 0; t < RVm; ++t)
-            vok = W::band(vok, W::band(zv[t] > (lv[t] - cv[t]) + vmargin, zv[t] < (hv[t] - cv[t]) - vmargin));
+            vok = W::band(vok, W::band(zv[t] > lv[t] - cv[t], zv[t] < hv[t] - cv[t]));
         if (!pinned && W::all(W::band(uok, vok))) return 0;         // empty set, everything inside: the QP's solution
         if (!W::all(vok)) return 2;
         // ---- the rare part: pins in play, or a free input beyond a bound
@@ -1540,13 +1547,13 @@ struct RtiWave {
             const vb up = at[t] > 0, dn = at[t] < 0, on = W::bor(up, dn);
             // pinned: multiplier as_gamma (du - d) for an upper, as_gamma (d - du) for a lower bound; released when negative
             const vb keep = W::band(on, W::sel(up, zu[t] - hi, lo - zu[t]) >= 0.0);
-            // free: beyond a bound (or, as_iter_max = 0, closer to it than umargin) -> pinned there
-            const vb vhi = W::band(!on, !(zu[t] < hi - umargin)), vlo = W::band(!on, !(zu[t] > lo + umargin));
+            // free: beyond a bound (or, as_iter_max = 0, closer to it than auto_margin) -> pinned there
+            const vb vhi = W::band(!on, !(zu[t] < hi)), vlo = W::band(!on, !(zu[t] > lo));
             na[t] = W::sel(keep, at[t], W::sel(vhi, vi(1), W::sel(vlo, vi(-1), vi(0))));
             same = W::band(same, na[t] == at[t]);
         }
         if (W::all(same)) {
-            for (int t = 0; t < RUA; ++t) {
+            for (int t = 0; t < RUA; ++t) {       // (pins exist only with the active set on: the moved input bounds are the bounds)
                 vi e = W::imin(lane + 64 * t, nzu - 1);
                 W::stp(lds, e + m.ZU, W::sel(at[t] > 0, hu[t], lu[t]) - cu[t], !(at[t] == 0));       // onto the bound exactly
             }
@@ -1970,7 +1977,7 @@ struct RtiWave {
                     if (P.qp_mode != QP_AUTO) break;
                     // (the constraint slots are built only at the interior-point loop's door: keeping ~90 more registers live across the
                     // sweep forces the MFMA accumulators into AGPRs with copies on every dependency)
-                    const int verdict = as_check(P, m, lds, A, as_on ? 0.0 : P.auto_margin, P.auto_margin, as_on, pinned);
+                    const int verdict = as_check(P, m, lds, A, as_on, pinned);
                     if (verdict == 0) {                            // then the step is the sweep's solution, read where it lies (ZX|ZU)
                         if (COND != 0 && condensed) cond_kept += COND_ACCEPTED;
                         done = true;

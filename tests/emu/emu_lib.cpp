@@ -34,7 +34,7 @@ int emu_rti_step_act(const ndp_cfg *cfg, const double *x0, const double *xr, con
     std::vector<double> lds((size_t)n, 0.0 / 0.0);   // NaN-poisoned: any read of unwritten LDS shows up
     emu::Wave::lds_limit() = n;
     emu::stats() = emu::Stats();
-    double kc[ndp::KC_SC];
+    double kc[ndp::KC_HOST];
     ndp::fill_kc(P, kc);
     ndp::RtiIo io{x0, xr, ur, f, X, U, u0, status, iters, lds_dump, 0, kc};
     std::vector<int> tb(ndp::TB_WORDS);
@@ -71,7 +71,7 @@ int emu_rti_step_late(const ndp_cfg *cfg, const double *x0, const double *xr, co
     const int n = ndp::lds_doubles(P.N);
     std::vector<double> lds((size_t)n, 0.0 / 0.0);
     emu::Wave::lds_limit() = n;
-    double kc[ndp::KC_SC];
+    double kc[ndp::KC_HOST];
     ndp::fill_kc(P, kc);
     ndp::RtiIo io{x0, xr, ur, nullptr, X, U, u0, status, iters, nullptr, 0, kc};
     std::vector<int> tb(ndp::TB_WORDS);
@@ -101,7 +101,7 @@ int emu_rti_step_defer_act(const ndp_cfg *cfg, const double *x0, const double *x
     const int n = ndp::lds_doubles(P.N);
     std::vector<double> lds((size_t)n, 0.0 / 0.0);
     emu::Wave::lds_limit() = n;
-    double kc[ndp::KC_SC];
+    double kc[ndp::KC_HOST];
     ndp::fill_kc(P, kc);
     ndp::RtiIo io{x0, xr, ur, f, X, U, u0, status, iters, nullptr, 0, kc};
     std::vector<int> tb(ndp::TB_WORDS);
