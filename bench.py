@@ -79,6 +79,8 @@ LEGEND = {
                "err = max rel u0 error vs the fp64 oracle, ipm = fraction of instances in the interior-point loop, bad = status != 0",
     "repeat": "REPEATS more passes over the same --steps steps (same graph) behind the timed region, each timed alone: ms_per_step = [min, median, max]; "
               "value_median = solves/s at the median pass; `value` itself is the contract's one pass",
+    "tick.remote": "ndp_tick with neighbours on OTHER ranks (ndp_tick_config_remote): list advance -> window columns -> [exchange] -> control step, three launches; "
+                   "one rank with its own windows as the gathered buffer, odometry in HBM, host-launched; value_one_launch_device_resident = ndp_tick_device on the same inputs",
     "ipm_always": "qp_mode 1: every instance runs the interior-point loop like HPIPM does",
     "mixed": "perturbed starts (0.5 m / 1 m/s / 0.15): ~20 % of the instances have inputs on their bounds (constrained = the fraction at the last tick); "
              "value = the default mode (active-set iterations, sets kept between ticks; ipm = fraction that still needed the interior-point loop), "
@@ -438,7 +440,42 @@ def tick_block(ndp, synth, B, N, device):
            "t_per_vehicle": res["t_per_vehicle"], "est": res["est"], "one_at_a_time": B / one, "launches_per_tick": 1,
            "parity": par, "cmd_ok": thr_ok, "bad": int((st != 0).sum()), "ipm": float((itn > 0).mean()),
            "gates_open": float(np.any(eng.device_force().cpu().numpy() != 0, axis=(1, 2)).mean())}
+    # ---- the tick when neighbours live on other ranks (ndp_tick_config_remote): advance -> window columns -> [exchange] -> step, three
+    # launches per tick.  One rank, its own windows standing for the gathered buffer (no collective: the wire is not what is measured),
+    # odometry resident in HBM; beside it the one-launch tick on the same device-resident inputs -- the like-for-like pair an N > 1 run's
+    # tick form would be held against.
+    import torch
+    dev = torch.device("cuda", device)
+    xd = [torch.from_numpy(xs[i]).to(dev) for i in range(8)]
+    cmd_t = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    i0 = next(it)
+
+    def rate(fn, n=200):
+        for k in range(20):
+            fn(k)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for k in range(n):
+            fn(20 + k)
+        torch.cuda.synchronize()
+        return B * n / (time.perf_counter() - ta)
+    v_one = rate(lambda k: eng.tick_device(xd[k % 8], cmd_t, t=0.02 * (i0 + k)))
     del eng
+    e2 = ndp.BatchedNMPC(B, N=N, disturbance=True, device=device)
+    e2.ref_set_trajectory(tr["coeff_x"], tr["coeff_y"], tr["coeff_z"], tr["coeff_yaw"], tr["time_cum"], tr["time_seg"], tr["final_pt"])
+    e2.ref_list_reset()
+    own = torch.zeros(B, N + 1, 6, dtype=torch.float64, device=dev)
+    e2.tick_config_remote(own, oi, gate=True)
+    e2.tick_reset()
+
+    def three(k):
+        e2.tick_advance_device(xd[k % 8], t=0.02 * (i0 + k))
+        e2.tick_window_pv_device(own)
+        e2.tick_step_device(xd[k % 8], cmd_t)
+    v_three = rate(three)
+    st2, _ = e2.status()
+    out["remote"] = {"value_three_stage_one_rank": v_three, "value_one_launch_device_resident": v_one, "launches_per_tick": 3, "bad": int((st2 != 0).sum())}
+    del e2
     return out
 
 

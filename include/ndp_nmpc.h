@@ -369,6 +369,18 @@ int ndp_ref_list_window_device(ndp_handle *h, void *d_xr, void *d_ur, void *stre
  *                     d_t: device-accessible [B] doubles -- EXCEPT with NDP_TICK_T_UNIFORM, where d_t is a HOST pointer to one double
  *                     that is read inside the call (before it returns), not by the device.
  *                     The list position is host state baked into the launches: not capturable into a hipGraph. */
+/* The tick with neighbours on OTHER ranks / GPUs: their windows arrive through the caller's exchange (ndp_xchg_*, peer-mapped windows)
+ * in d_windows[rows][N+1][stride] (stride 6: the position / velocity columns the gate and the network read; or 10); other_index[B] = the
+ * row of every vehicle's neighbour (< 0: none).  A tick is then three enqueues on one stream, the exchange between them:
+ *   ndp_tick_advance_device   : list advance (d_t as in ndp_tick_device; NULL: none) + estimator (flags bit 0) -- this rank's window
+ *                               of the tick is complete (node N included);
+ *   ndp_tick_window_pv_device : that window's columns [B][N+1][6] into the exchange's send buffer;      ... the exchange ...
+ *   ndp_tick_step_device      : the control step against the exchanged windows + the actuator command.
+ * Bit-equal with ndp_tick_device on the same vehicles in ONE handle.  ndp_tick_config switches back to neighbours of the same handle. */
+int ndp_tick_config_remote(ndp_handle *h, const void *d_windows, int stride, int64_t rows, const int32_t *other_index, int gate_on_odometry);
+int ndp_tick_advance_device(ndp_handle *h, const void *d_x_odom, const void *d_t, const void *d_vz, const void *d_throttle, int flags, void *stream);
+int ndp_tick_window_pv_device(ndp_handle *h, void *d_pv, void *stream);
+int ndp_tick_step_device(ndp_handle *h, const void *d_x_odom, void *d_cmd, void *d_u0, void *stream);
 #define NDP_TICK_ESTIMATE 1
 #define NDP_TICK_WANT_U0 2
 #define NDP_TICK_T_UNIFORM 4   /* t points at ONE double (host memory, also for ndp_tick_device): the trajectory time of every vehicle

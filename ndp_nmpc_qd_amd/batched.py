@@ -327,6 +327,44 @@ class BatchedNMPC:
             self._dptr(cmd_out, torch.float64, (B, 4)), self._dptr(u0_out, torch.float64, (B, 4)), self._stream(stream)),
             "ndp_tick_device")
 
+    # ---- the tick with neighbours on other ranks: advance -> window columns -> (exchange) -> step
+    def tick_config_remote(self, windows, other_index, gate=True):
+        """Neighbour windows come from `windows` (CUDA tensor [rows, N+1, 6 or 10]: an exchange's gathered / peer-mapped buffer, kept
+        alive by the caller); other_index[B] = the row of every vehicle's neighbour (< 0: none).  ndp_tick_config_remote."""
+        import torch
+        assert isinstance(windows, torch.Tensor) and windows.is_cuda and windows.is_contiguous() and windows.dtype == torch.float64
+        assert windows.dim() == 3 and windows.shape[1] == self.N + 1 and windows.shape[2] in (6, 10)
+        oi = np.ascontiguousarray(other_index, dtype=np.int32).reshape(self.B)
+        self._tick_windows = windows
+        self._check(self._lib.ndp_tick_config_remote(self._h, C.c_void_p(windows.data_ptr()), int(windows.shape[2]), C.c_int64(int(windows.shape[0])),
+                                                     _lib.ptr(oi), 1 if gate else 0), "ndp_tick_config_remote")
+
+    def tick_advance_device(self, x_odom, t=None, vz=None, throttle=None, estimate=False, stream=None):
+        """Stage 1: list advance (t: scalar, CUDA tensor [B] or None) + estimator.  ndp_tick_advance_device."""
+        import torch
+        flags = _lib.TICK_ESTIMATE if estimate else 0
+        if t is not None and not isinstance(t, torch.Tensor):
+            t_host = np.array([float(t)])
+            tp, flags = _lib.ptr(t_host), flags | _lib.TICK_T_UNIFORM
+        else:
+            tp = self._dptr(t, torch.float64, (self.B,))
+        self._check(self._lib.ndp_tick_advance_device(self._h, self._dptr(x_odom, torch.float64, (self.B, 10)), tp,
+                                                      self._dptr(vz, torch.float64, (self.B,)), self._dptr(throttle, torch.float64, (self.B,)),
+                                                      flags, self._stream(stream)), "ndp_tick_advance_device")
+
+    def tick_window_pv_device(self, pv_out, stream=None):
+        """Stage 2: this tick's window, position / velocity columns -> pv_out [B, N+1, 6] (the exchange's send buffer)."""
+        import torch
+        self._check(self._lib.ndp_tick_window_pv_device(self._h, self._dptr(pv_out, torch.float64, (self.B, self.N + 1, 6)), self._stream(stream)),
+                    "ndp_tick_window_pv_device")
+
+    def tick_step_device(self, x_odom, cmd_out, u0_out=None, stream=None):
+        """Stage 3 (behind the exchange): the control step against the exchanged windows + the actuator command."""
+        import torch
+        self._check(self._lib.ndp_tick_step_device(self._h, self._dptr(x_odom, torch.float64, (self.B, 10)),
+                                                   self._dptr(cmd_out, torch.float64, (self.B, 4)), self._dptr(u0_out, torch.float64, (self.B, 4)),
+                                                   self._stream(stream)), "ndp_tick_step_device")
+
     # ------------------------------------------------------------------ f4: plant step (closed-loop rollouts)
     def plant_step(self, x, u, f=None, dt=CP.ts_nmpc, substeps=4):
         x = _lib.f64(x, (self.B, 10)).copy()

@@ -1927,6 +1927,15 @@ __global__ __launch_bounds__(256) void pack_pv_kernel(const double *__restrict__
     reinterpret_cast<double2 *>(pv)[i] = *reinterpret_cast<const double2 *>(xr + r * NX + 2 * p);
 }
 
+// the same for windows that lie in the reference list (ndp_tick): window row k of vehicle b = list row base + b * pitch + k * 10
+__global__ __launch_bounds__(256) void pack_pv_list_kernel(const double *__restrict__ base, size_t pitch, int np1, double *__restrict__ pv, size_t B)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * (size_t)np1 * 3) return;
+    const size_t r = i / 3, p = i - r * 3, b = r / (size_t)np1, k = r - b * (size_t)np1;
+    reinterpret_cast<double2 *>(pv)[i] = *reinterpret_cast<const double2 *>(base + b * pitch + k * NX + 2 * p);
+}
+
 }  // namespace ndp
 
 // ------------------------------------------------------------------------------------------ C-ABI
@@ -2104,6 +2113,8 @@ struct ndp_handle {
     int *dTickIndex = nullptr;       // [B] neighbour instance of every vehicle (< 0: none), or null: no vehicle has one
     double *dTickThrust = nullptr;   // [B] the thrust command of the previous tick (what hover_throttle_callback reads off body_rate_cmd)
     bool tick_gate = true;           // gate the downwash on |neighbour window node 0 xy - ego odometry xy| < r_horiz (ndp_nmpc_leader_node.py:65-74)
+    const double *tick_remote = nullptr;   // ndp_tick_config_remote: the neighbours' windows are rows of the CALLER's buffer (an exchange's gathered /
+    int tick_remote_stride = 6;            // peer-mapped windows, [rows][N+1][stride]) instead of this handle's own list
     struct TickSlot { bool busy = false, want_u0 = false; } tslot[2];
     double *dRelay = nullptr;  // follower relay: [B][4] = filtered offset xyz + initialised flag
     double *sThr = nullptr;    // staging of the f1-f4 host entry points: 11 B doubles
@@ -3870,6 +3881,37 @@ int ndp_tick_config(ndp_handle *h, const int32_t *other_index, int gate_on_odome
         h->dTickIndex = nullptr;
     }
     h->tick_gate = gate_on_odometry != 0;
+    h->tick_remote = nullptr;
+    return 0;
+}
+
+// The control tick with neighbours on OTHER ranks (nmpc_node.py:116-133,229-230 -> ndp_nmpc_leader_node.py:40,60-76: every vehicle
+// publishes its window every tick, the leader consumes its neighbour's): the neighbour rows come from the caller's exchange buffer, and
+// a tick is three enqueues with the exchange between the first two and the last:
+//   ndp_tick_advance_device    list advance (+ estimator): this rank's window of the tick is complete, node N included
+//   ndp_tick_window_pv_device  that window's position / velocity columns [B][N+1][6] -> the exchange's send buffer   ... exchange ...
+//   ndp_tick_step_device       the control step (gate + network + RTI + actuator command), neighbour rows from the gathered windows
+// Same arithmetic as the one-launch tick with the neighbour in the same handle (bit-equal: tests/test_tick.py).
+int ndp_tick_config_remote(ndp_handle *h, const void *d_windows, int stride, int64_t rows, const int32_t *other_index, int gate_on_odometry)
+{
+    if (!h || !d_windows || !other_index) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = wait_all(h);
+    if (rc) return rc;
+    if ((rc = ensure_tick(h))) return rc;
+    if (stride != 6 && stride != NX) { h->err = "ndp_tick_config_remote: stride must be 6 (position / velocity columns) or 10"; return -13; }
+    if (!h->cfg.use_fd) { h->err = "ndp_tick_config_remote: neighbours (downwash) need use_fd = 1 (NDP model)"; return -8; }
+    if (!h->have_mlp) { h->err = "ndp_tick_config_remote: ndp_set_mlp_weights was never called"; return -6; }
+    if (!can_fuse(h)) { h->err = "ndp_tick_config_remote: serves the shapes whose downwash is fused into the control step (N + 1 <= 32, fp64)"; return -12; }
+    const size_t B = h->cfg.batch;
+    for (size_t i = 0; i < B; ++i)
+        if ((int64_t)other_index[i] >= rows) { h->err = "ndp_tick_config_remote: other_index names a row outside the window buffer"; return -2; }
+    if (!h->dTickIndex) NDP_HIP(h, hipMalloc((void **)&h->dTickIndex, B * 4));
+    NDP_HIP(h, hipMemcpy(h->dTickIndex, other_index, B * 4, hipMemcpyHostToDevice));
+    h->tick_gate = gate_on_odometry != 0;
+    h->tick_remote = (const double *)d_windows;
+    h->tick_remote_stride = stride;
     return 0;
 }
 
@@ -3901,6 +3943,7 @@ static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, bool
     if (rc) return rc;
     if (!h->dRingX) { h->err = "ndp_tick: no reference list (ndp_ref_list_fix_pt, or ndp_ref_set_trajectory + ndp_ref_list_reset, first)"; return -11; }
     if (adv && !h->dTraj) { h->err = "ndp_tick: a trajectory time was given but ndp_ref_set_trajectory was never called"; return -11; }
+    if (h->tick_remote) { h->err = "ndp_tick: neighbours come from an exchange buffer (ndp_tick_config_remote): a tick is ndp_tick_advance_device, the exchange, ndp_tick_step_device"; return -17; }
     const int B = h->cfg.batch;
     const RingGeom rg = ring_geom(h);
     const bool est = (flags & TICK_ESTIMATE) != 0;
@@ -3969,6 +4012,77 @@ static int tick_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, bool
     h->list_n = n_after;
     if (adv && so.tick) h->segc_par ^= 1;
     return 0;
+}
+
+int ndp_tick_advance_device(ndp_handle *h, const void *d_x_odom, const void *d_t, const void *d_vz, const void *d_throttle, int flags, void *stream)
+{
+    if (!h || !d_x_odom) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_tick(h);
+    if (rc) return rc;
+    if (!h->dRingX) { h->err = "ndp_tick_advance: no reference list (ndp_ref_list_fix_pt, or ndp_ref_set_trajectory + ndp_ref_list_reset, first)"; return -11; }
+    const bool adv = d_t != nullptr, est = (flags & TICK_ESTIMATE) != 0, uni = adv && (flags & TICK_T_UNIFORM);
+    if (adv && !h->dTraj) { h->err = "ndp_tick_advance: a trajectory time was given but ndp_ref_set_trajectory was never called"; return -11; }
+    if (adv || est) {
+        const int B = h->cfg.batch;
+        const RingGeom rg = ring_geom(h);
+        TickPre a{};
+        a.cf = ref_cfg(h, h->cfg.N * h->cfg.dt);
+        if (adv) {
+            const size_t Bs = (size_t)B, S = (size_t)h->traj_seg;
+            a.coeff = h->dTraj; a.tcum = a.coeff + Bs * S * 28; a.tseg = a.tcum + Bs * (S + 1); a.fpt = a.tseg + Bs * S;
+            a.seg_hint = reinterpret_cast<int *>(const_cast<double *>(a.fpt + Bs * 3 + Bs * SEGC_PER));
+        }
+        a.t = uni ? nullptr : (const double *)d_t; a.t_all = uni ? *(const double *)d_t : 0.0; a.advance = adv ? 1 : 0;
+        a.j_new = h->list_n + (unsigned long long)rg.ring();
+        a.rg = rg; a.rx = h->dRingX; a.ru = h->dRingU;
+        a.thr = thr_cfg(h); a.st = h->dThr;
+        a.vz = d_vz ? (const double *)d_vz : (const double *)d_x_odom + 5; a.vz_pitch = d_vz ? 1 : NX;
+        a.throttle = d_throttle ? (const double *)d_throttle : h->dTickThrust;
+        a.est = est ? 1 : 0;
+        hipLaunchKernelGGL(tick_pre_kernel, dim3((B + 63) / 64), dim3(64), 0, s, a);
+        NDP_HIP(h, hipGetLastError());
+        if (adv) ++h->list_n;
+    }
+    return note_stream(h, s);
+}
+
+int ndp_tick_window_pv_device(ndp_handle *h, void *d_pv, void *stream)
+{
+    if (!h || !d_pv) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    if (!h->dRingX) { h->err = "ndp_tick_window_pv: no reference list"; return -11; }
+    const RingGeom rg = ring_geom(h);
+    const size_t B = h->cfg.batch, n = B * (size_t)(h->cfg.N + 1) * 3;
+    hipLaunchKernelGGL(pack_pv_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dRingX + rg.slot(h->list_n) * 10, rg.px(),
+                       h->cfg.N + 1, (double *)d_pv, B);
+    NDP_HIP(h, hipGetLastError());
+    return note_stream(h, s);
+}
+
+int ndp_tick_step_device(ndp_handle *h, const void *d_x_odom, void *d_cmd, void *d_u0, void *stream)
+{
+    if (!h || !d_x_odom || !d_cmd) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    if (!h->tick_remote) { h->err = "ndp_tick_step: ndp_tick_config_remote first (neighbours in the same handle: ndp_tick_device)"; return -17; }
+    if (!h->dRingX) { h->err = "ndp_tick_step: no reference list"; return -11; }
+    const RingGeom rg = ring_geom(h);
+    const size_t slot = rg.slot(h->list_n), B = h->cfg.batch;
+    const double *x_odom = (const double *)d_x_odom;
+    Neigh nb;
+    nb.other = h->tick_remote; nb.stride = h->tick_remote_stride; nb.index = h->dTickIndex;
+    if (h->tick_gate) { nb.ego_xy = x_odom; nb.ego_pitch = NX; }
+    StepOut so;
+    so.xr_pitch = rg.px(); so.ur_pitch = rg.pu();
+    so.cmd = (double *)d_cmd; so.kthr = h->dThr + B; so.thrust_keep = h->dTickThrust;
+    int rc = enqueue_step(h, x_odom, h->dRingX + slot * 10, h->dRingU + slot * 4, nullptr, nb, d_u0 ? (double *)d_u0 : h->su0, nullptr, s, &so);
+    return rc ? rc : note_stream(h, s);
 }
 
 int ndp_tick_device(ndp_handle *h, const void *d_x_odom, const void *d_t, const void *d_vz, const void *d_throttle, int flags,

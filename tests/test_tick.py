@@ -509,3 +509,83 @@ def test_neighbours_in_other_workgroups_at_a_batch_larger_than_the_device():
     xt, ut = tk.ref_list_window(None)
     xc, uc = cp.ref_list_window(None)
     assert np.array_equal(xt, xc) and np.array_equal(ut, uc)
+
+
+def test_tick_with_neighbours_on_another_rank_equals_the_single_handle_tick():
+    """the control tick when a vehicle's neighbour lives on ANOTHER rank (nmpc_node.py:116-133,229-230 -> the leader's
+    subscriber, ndp_nmpc_leader_node.py:40,60-76).  Two handles of 64 vehicles each stand for two ranks; every vehicle's neighbour is on
+    the other one.  Per tick each "rank": ndp_tick_advance_device -> ndp_tick_window_pv_device into its half of the gathered buffer
+    (= what one all-gather of [B, N+1, 6] delivers) -> ndp_tick_step_device against the gathered windows.  Held bit for bit against ONE
+    handle with all 128 vehicles ticking through the one-launch ndp_tick_device -- u0, actuator command, predicted force, the lists --
+    over 30 ticks with segment crossings, estimator on every other tick; and against the same three-stage form on one handle
+    (one rank, its own windows as the gathered buffer)."""
+    import torch
+    import ndp_nmpc_qd_amd as ndp
+    dev = torch.device("cuda", 0)
+    Bh, B = 64, 128
+    tr = synth.figure_eight_traj(B, seed=6, n_seg=16, t_seg=0.25, pairs=True)
+    oi_all = ((np.arange(B) + Bh) % B).astype(np.int32)              # vehicle i's neighbour: i + 64 (the other "rank")
+    # vehicle i and i + 64 fly close to each other: copy the pair structure of the first half onto the second
+    for k in ("coeff_x", "coeff_y", "coeff_z", "coeff_yaw", "time_cum", "time_seg"):
+        tr[k][Bh:] = tr[k][:Bh]
+    tr["coeff_z"][Bh:, 0::8] += 0.6                                  # 0.6 m above: the gate is open, the force is not zero
+    tr["final_pt"][Bh:] = tr["final_pt"][:Bh] + np.array([0.0, 0.0, 0.6])
+
+    def traj(e, sl):
+        e.ref_set_trajectory(*(tr[k][sl] for k in ("coeff_x", "coeff_y", "coeff_z", "coeff_yaw", "time_cum", "time_seg", "final_pt")))
+        e.ref_list_reset()
+        e.throttle_reset()
+
+    one = ndp.BatchedNMPC(B, disturbance=True)
+    traj(one, slice(None))
+    one.tick_config(oi_all, gate=True)
+    one.tick_reset()
+    ranks = [ndp.BatchedNMPC(Bh, disturbance=True) for _ in range(2)]
+    gathered = torch.zeros(B, 21, 6, dtype=torch.float64, device=dev)
+    for r, e in enumerate(ranks):
+        traj(e, slice(r * Bh, (r + 1) * Bh))
+        e.tick_config_remote(gathered, oi_all[r * Bh:(r + 1) * Bh], gate=True)        # rows of the gathered buffer = global vehicle ids
+        e.tick_reset()
+    solo = ndp.BatchedNMPC(B, disturbance=True)                      # one rank, three stages
+    traj(solo, slice(None))
+    own = torch.zeros(B, 21, 6, dtype=torch.float64, device=dev)
+    solo.tick_config_remote(own, oi_all, gate=True)
+    solo.tick_reset()
+    with pytest.raises(ndp.NdpError, match="ndp_tick_advance_device"):
+        solo.tick(np.zeros((B, 10)), t=0.02)                         # the one-call tick is refused while neighbours are remote
+    rng = np.random.default_rng(4)
+    cmd1, u1 = torch.empty(B, 4, dtype=torch.float64, device=dev), torch.empty(B, 4, dtype=torch.float64, device=dev)
+    cmd2, u2 = torch.empty(B, 4, dtype=torch.float64, device=dev), torch.empty(B, 4, dtype=torch.float64, device=dev)
+    cmd3, u3 = torch.empty(B, 4, dtype=torch.float64, device=dev), torch.empty(B, 4, dtype=torch.float64, device=dev)
+    n_force = 0
+    for i in range(30):
+        t = 0.02 * (i + 1)
+        est = i % 2 == 0
+        xr, _ = one.ref_list_window(None)
+        x0 = xr[:, 1, :].copy()                                      # near the window the tick will use
+        x0[:, 0:3] += rng.normal(0.0, 0.03, size=(B, 3))
+        x0_t = torch.from_numpy(x0).to(dev)
+        one.tick_device(x0_t, cmd1, t=t, estimate=est, u0_out=u1)
+        for r, e in enumerate(ranks):
+            sl = slice(r * Bh, (r + 1) * Bh)
+            e.tick_advance_device(x0_t[sl].contiguous(), t=t, estimate=est)
+            e.tick_window_pv_device(gathered[sl])                    # (each rank writes its rows: the all-gather's result)
+        torch.cuda.synchronize()
+        for r, e in enumerate(ranks):
+            sl = slice(r * Bh, (r + 1) * Bh)
+            e.tick_step_device(x0_t[sl].contiguous(), cmd2[sl], u0_out=u2[sl])
+        solo.tick_advance_device(x0_t, t=t, estimate=est)
+        solo.tick_window_pv_device(own)
+        solo.tick_step_device(x0_t, cmd3, u0_out=u3)
+        torch.cuda.synchronize()
+        for a, b_ in ((u1, u2), (cmd1, cmd2), (u1, u3), (cmd1, cmd3)):
+            assert torch.equal(a, b_), (i, float((a - b_).abs().max()))
+        f1 = one.device_force().cpu().numpy()
+        f2 = np.concatenate([e.device_force().cpu().numpy() for e in ranks])
+        assert np.array_equal(f1, f2)
+        n_force += int(np.any(f1 != 0.0, axis=(1, 2)).sum())
+    assert n_force > 30 * B // 4                                     # the gates were open: the exchanged windows fed the network
+    x1, w1 = one.ref_list_window(None)
+    x2 = np.concatenate([e.ref_list_window(None)[0] for e in ranks])
+    assert np.array_equal(x1, x2)
+    assert np.array_equal(one.throttle_state(), np.concatenate([e.throttle_state() for e in ranks]))
