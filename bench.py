@@ -79,6 +79,9 @@ LEGEND = {
                "err = max rel u0 error vs the fp64 oracle, ipm = fraction of instances in the interior-point loop, bad = status != 0",
     "repeat": "REPEATS more passes over the same --steps steps (same graph) behind the timed region, each timed alone: ms_per_step = [min, median, max]; "
               "value_median = solves/s at the median pass; `value` itself is the contract's one pass",
+    "tick_remote": "N > 1: ndp_tick with every vehicle's neighbour on the NEXT rank (ndp_tick_config_remote): per control period list advance + estimator -> "
+                   "window columns -> all-gather of the [B, N+1, 6] windows -> control step, on one stream; value = whole-job solves/s over the slowest rank; "
+                   "parity = rank 0's u0 against the oracle fed the rows the exchange delivered; rows_ok = those rows are the neighbour rank's windows",
     "tick.remote": "ndp_tick with neighbours on OTHER ranks (ndp_tick_config_remote): list advance -> window columns -> [exchange] -> control step, three launches; "
                    "one rank with its own windows as the gathered buffer, odometry in HBM, host-launched; value_one_launch_device_resident = ndp_tick_device on the same inputs",
     "ipm_always": "qp_mode 1: every instance runs the interior-point loop like HPIPM does",
@@ -389,7 +392,8 @@ def tick_block(ndp, synth, B, N, device):
     eng.tick_reset()
     rng = np.random.default_rng(0)
     n_w, n_1, n_2 = 24, 80, 200
-    nt = n_w + n_1 + 3 * n_2 + 8
+    n_r = 24 + 300                                      # the device-resident legs below: warm-up + timed ticks (both legs tick the same times)
+    nt = n_w + n_1 + 3 * n_2 + 8 + n_r
     xs = []
     for i in range(nt):
         x = eng.ref_window(np.full(B, 0.02 * i))[0][:, 0, :].copy()
@@ -444,22 +448,33 @@ def tick_block(ndp, synth, B, N, device):
     # launches per tick.  One rank, its own windows standing for the gathered buffer (no collective: the wire is not what is measured),
     # odometry resident in HBM; beside it the one-launch tick on the same device-resident inputs -- the like-for-like pair an N > 1 run's
     # tick form would be held against.
+    import ctypes as C
     import torch
     dev = torch.device("cuda", device)
-    xd = [torch.from_numpy(xs[i]).to(dev) for i in range(8)]
-    cmd_t = torch.empty(B, 4, dtype=torch.float64, device=dev)
     i0 = next(it)
+    xd = torch.from_numpy(np.stack(xs[i0:i0 + n_r])).to(dev)            # every tick its own odometry, resident in HBM
+    xp = [C.c_void_p(xd[k].data_ptr()) for k in range(n_r)]
+    cmd_t = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    cp = C.c_void_p(cmd_t.data_ptr())
+    tv = C.c_double(0.0)
+    tp = C.cast(C.pointer(tv), C.c_void_p)
+    UNI = ndp._lib.TICK_T_UNIFORM
 
-    def rate(fn, n=200):
-        for k in range(20):
-            fn(k)
+    def rate(fn, n=300):
+        # (the C entry points called with arguments built once: the rate of the boundary, not of the Python wrapper's checks)
+        for k in range(n_r - n):
+            tv.value = 0.02 * (i0 + k)
+            assert fn(k) == 0
         torch.cuda.synchronize()
         ta = time.perf_counter()
-        for k in range(n):
-            fn(20 + k)
+        for k in range(n_r - n, n_r):
+            tv.value = 0.02 * (i0 + k)
+            fn(k)
         torch.cuda.synchronize()
         return B * n / (time.perf_counter() - ta)
-    v_one = rate(lambda k: eng.tick_device(xd[k % 8], cmd_t, t=0.02 * (i0 + k)))
+    L, h1 = eng._lib, eng._h
+    v_one = rate(lambda k: L.ndp_tick_device(h1, xp[k], tp, None, None, UNI, cp, None, None))
+    st1, _ = eng.status()
     del eng
     e2 = ndp.BatchedNMPC(B, N=N, disturbance=True, device=device)
     e2.ref_set_trajectory(tr["coeff_x"], tr["coeff_y"], tr["coeff_z"], tr["coeff_yaw"], tr["time_cum"], tr["time_seg"], tr["final_pt"])
@@ -467,16 +482,138 @@ def tick_block(ndp, synth, B, N, device):
     own = torch.zeros(B, N + 1, 6, dtype=torch.float64, device=dev)
     e2.tick_config_remote(own, oi, gate=True)
     e2.tick_reset()
+    h2, op = e2._h, C.c_void_p(own.data_ptr())
 
     def three(k):
-        e2.tick_advance_device(xd[k % 8], t=0.02 * (i0 + k))
-        e2.tick_window_pv_device(own)
-        e2.tick_step_device(xd[k % 8], cmd_t)
+        return (L.ndp_tick_advance_device(h2, xp[k], tp, None, None, UNI, None) or L.ndp_tick_window_pv_device(h2, op, None)
+                or L.ndp_tick_step_device(h2, xp[k], cp, None, None))
     v_three = rate(three)
     st2, _ = e2.status()
-    out["remote"] = {"value_three_stage_one_rank": v_three, "value_one_launch_device_resident": v_one, "launches_per_tick": 3, "bad": int((st2 != 0).sum())}
+    out["remote"] = {"value_three_stage_one_rank": v_three, "value_one_launch_device_resident": v_one, "launches_per_tick": 3,
+                     "bad": int((st2 != 0).sum()) + int((st1 != 0).sum())}
     del e2
     return out
+
+
+def tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, dev, cdev, stream, same_dev, n_ticks=120, n_warm=24, xchg=None):
+    """ndp_tick over `world` ranks, every vehicle's neighbour on the NEXT rank (ndp_tick_config_remote): per control period
+        ndp_tick_advance_device -> ndp_tick_window_pv_device -> all-gather of the [B, N+1, 6] windows -> ndp_tick_step_device
+    on `stream`; with xchg (dist.RcclExchange: the library's own communicator) the two middle stages are ONE call, ndp_xchg_tick_windows
+    (pack out of the list + ncclAllGather on `stream`), else torch.distributed's all_gather_into_tensor.  Every rank flies the same B figure-eights (vehicle i's neighbour = vehicle i ^ 1 of rank + 1: the gates of the
+    metric's workload), odometry = node 0 of the tick's window + SURVEY 8d's noise (per-rank noise).  All ranks call this; set-up
+    failures are agreed on by a collective before the first tick, the ticks themselves only launch.  Returns (on every rank) the
+    whole-job rate over the slowest rank's time, a parity tick of rank 0 against the CPU oracle fed the rows the exchange
+    delivered, and whether those rows are the neighbour rank's windows."""
+    import ctypes as C
+    res, ok, e = {}, 1, None
+    try:
+        tr = synth.figure_eight_traj(B, seed=synth.SEED0 + 3, n_seg=80, t_seg=0.25, pairs=True)
+        e = ndp.BatchedNMPC(B, N=N, disturbance=True, device=local_rank)
+        e.ref_set_trajectory(tr["coeff_x"], tr["coeff_y"], tr["coeff_z"], tr["coeff_yaw"], tr["time_cum"], tr["time_seg"], tr["final_pt"])
+        e.ref_list_reset()
+        gathered = torch.zeros(world * B, N + 1, 6, dtype=torch.float64, device=dev)
+        pv = torch.zeros(B, N + 1, 6, dtype=torch.float64, device=dev)
+        nbr = (rank + 1) % world
+        oi = (nbr * B + (np.arange(B, dtype=np.int64) ^ 1)).astype(np.int32)
+        e.tick_config_remote(gathered, oi, gate=True)
+        e.tick_reset()
+        rng = np.random.default_rng(100 + rank)
+        nt = n_warm + n_ticks + 1
+        xs = np.empty((nt, B, 10))
+        for i in range(nt):
+            xs[i] = e.ref_window(np.full(B, 0.02 * i))[0][:, 0, :]
+        xs[:, :, 0:3] += rng.normal(0, 0.1, (nt, B, 3))
+        xs[:, :, 3:6] += rng.normal(0, 0.2, (nt, B, 3))
+        xd = torch.from_numpy(xs).to(dev)
+        cmd = torch.empty(B, 4, dtype=torch.float64, device=dev)
+        u0d = torch.empty(B, 4, dtype=torch.float64, device=dev)
+    except Exception as ex:
+        res["error"], ok = f"{type(ex).__name__}: {ex}"[:200], 0
+    okt = torch.tensor([ok], dtype=torch.int64, device=cdev)
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    if int(okt.item()) == 0:
+        res.setdefault("error", "set-up failed on another rank")
+        return res
+    L, h = e._lib, e._h
+    sp = C.c_void_p(stream.cuda_stream)
+    xp = [C.c_void_p(xd[i].data_ptr()) for i in range(nt)]
+    cp, up, pp = C.c_void_p(cmd.data_ptr()), C.c_void_p(u0d.data_ptr()), C.c_void_p(pv.data_ptr())
+    tv = C.c_double(0.0)
+    tp = C.cast(C.pointer(tv), C.c_void_p)
+    UNI = ndp._lib.TICK_T_UNIFORM
+    rcs = 0
+
+    gp, xh = C.c_void_p(gathered.data_ptr()), (xchg._h if xchg is not None else None)
+
+    def gather():
+        nonlocal rcs
+        if xh is not None:
+            rcs |= L.ndp_xchg_tick_windows(xh, h, gp, sp)
+        elif same_dev:                                # (mechanics check, gloo: through the host)
+            parts = [torch.empty(B, N + 1, 6, dtype=torch.float64) for _ in range(world)]
+            with torch.cuda.stream(stream):
+                mine = pv.cpu()
+            dist.all_gather(parts, mine)
+            with torch.cuda.stream(stream):
+                gathered.copy_(torch.cat(parts, 0))
+        else:
+            with torch.cuda.stream(stream):
+                dist.all_gather_into_tensor(gathered, pv)             # RCCL on torch's current stream = `stream`
+
+    def tick(i):
+        nonlocal rcs
+        tv.value = 0.02 * i
+        rcs |= L.ndp_tick_advance_device(h, xp[i], tp, None, None, UNI, sp)
+        if xh is None:
+            rcs |= L.ndp_tick_window_pv_device(h, pp, sp)
+        gather()
+        rcs |= L.ndp_tick_step_device(h, xp[i], cp, up, sp)
+    for i in range(n_warm):
+        tick(i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    ta = time.perf_counter()
+    for i in range(n_warm, n_warm + n_ticks):
+        tick(i)
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=cdev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    st, _ = e.status()
+    # ---- one more tick, checked: the rows the exchange delivered are the neighbour rank's windows (every rank flies the same
+    # curves: they equal this rank's own), and rank 0's u0 against the oracle fed those rows
+    X, U = e.get_iterate()
+    i = n_warm + n_ticks
+    tick(i)
+    torch.cuda.synchronize()
+    g = gathered.cpu().numpy()
+    rcs |= L.ndp_tick_window_pv_device(h, pp, sp)                   # (this rank's own columns, for the comparison below)
+    torch.cuda.synchronize()
+    rows_ok = bool(np.array_equal(g[nbr * B:(nbr + 1) * B], pv.cpu().numpy())) and bool(np.any(g[nbr * B:(nbr + 1) * B] != 0))
+    par = None
+    if rank == 0:
+        from oracle import oracle as O
+        xr, ur = e.ref_list_window(None)
+        sel = np.unique(np.linspace(0, B - 1, 64).astype(np.int64))
+        other = np.zeros((len(sel), N + 1, 10))
+        other[:, :, 0:6] = g[oi[sel]]
+        other[:, :, 6] = 1.0
+        blob = np.fromfile(os.path.join(ROOT, "ndp_nmpc_qd_amd", "weights", "downwash_sn4.bin"), dtype="<f4")
+        f = O.downwash_batch(blob, other, xr[sel].copy(), xs[i][sel, 0:2].copy())
+        Xo, Uo = X[sel].copy(), U[sel].copy()
+        u_or, st_o, _ = O.step_batch(O.default_cfg(N=N, use_fd=True), xs[i][sel].copy(), xr[sel].copy(), ur[sel].copy(), f, Xo, Uo)
+        good = st_o == 0
+        u0 = u0d.cpu().numpy()
+        par = float(np.max(np.abs(u0[sel][good] - u_or[good]) / np.maximum(1.0, np.abs(u_or[good]))))
+    agg = torch.tensor([int((st != 0).sum()) + (1 if rcs else 0), 0 if rows_ok else 1], dtype=torch.int64, device=cdev)
+    dist.all_reduce(agg)
+    elapsed = float(el.item())
+    res.update({"value": world * B * n_ticks / elapsed, "us": elapsed / n_ticks * 1e6, "unit": "solves/s", "ticks": n_ticks,
+                "launches_per_tick": 3 if xh is None else 2,
+                "gather": ("ndp_xchg_tick_windows (pack + ncclAllGather on the tick's stream)" if xh is not None else
+                           "host-staged (gloo, one device)" if same_dev else "torch.distributed all_gather_into_tensor (RCCL)"),
+                "parity": par, "bad": int(agg[0].item()), "rows_ok": int(agg[1].item()) == 0})
+    del e
+    return res
 
 
 def launch_ranks(n, script, script_args, python=None, out=None, err=None):
@@ -554,6 +691,7 @@ def main():
                     help="mixed: 0.5 m / 1 m/s / 0.15 initial errors, ~20 %% of the instances need the interior-point loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-repeats", action="store_true", help="skip the extra timed passes over the same steps behind the timed region (`repeat`)")
+    ap.add_argument("--no-tick-remote", action="store_true", help="N > 1: skip the `tick_remote` leg (ndp_tick with neighbours on the next rank)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs 2, 4-on-one-GPU, 5 measured in this run)")
     ap.add_argument("--only-timed", action="store_true",
                     help="no parity check, no extra legs: just warm-up + the timed steps (profiling runs: nothing but the kernel)")
@@ -1085,6 +1223,7 @@ def main():
         return res
 
     results, form_errors = {}, {}
+    tick_remote = None                        # (N > 1: filled in behind the forms)
 
     def finish(partial=False):
         """Builds and prints the line (rank 0) from the forms that have finished.  partial: called by the watchdog of a secondary form that
@@ -1269,6 +1408,8 @@ def main():
                         out["exchange"][m] = {"error": peer_err}
                 if world > 1:
                     out["scaling_baseline"] = {"compare_with": "the N = 1 line's scaling_baseline.value", "form": headline}
+                if tick_remote is not None:
+                    out["tick_remote"] = tick_remote
                 if xchg_err and "rccl" in out["exchange"]:
                     out["exchange"]["rccl"]["library_collective_unavailable"] = xchg_err
                 out["exchange"]["headline"] = headline
@@ -1554,6 +1695,22 @@ def main():
             timer.cancel()
         with wd_lock:
             if wd_state["done"]:                   # the timer fired while this leg was being torn down: it prints and exits
+                time.sleep(3600)
+    # ---- N > 1: the node's control tick (ndp_tick) with every neighbour on the next rank -- a secondary leg like the forms above
+    if world > 1 and need_exchange and not cfg4 and N == 20 and args.qp_mode == 0 and not args.only_timed and not args.no_tick_remote:
+        stage["at"] = "tick_remote (ndp_tick with neighbours on the next rank)"
+        timer = threading.Timer(args.leg_timeout_s, watchdog, args=("tick_remote",))
+        timer.daemon = True
+        timer.start()
+        try:
+            tick_remote = tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, dev, cdev, stream, same_dev, xchg=xchg)
+        except Exception as e:
+            tick_remote = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.set_stream(stream)
+        finally:
+            timer.cancel()
+        with wd_lock:
+            if wd_state["done"]:
                 time.sleep(3600)
     for k, (m, r) in enumerate(list(results.items())):     # parity spot checks (CPU oracle, OpenMP): behind every form's timed region
         fn = r.pop("parity_fn", None)

@@ -478,6 +478,12 @@ int ndp_xchg_end(ndp_xchg *x, void *stream);
  * ndp_xchg_begin of the NEXT tick's windows behind the last reader of d_gathered_next -- the completion event of the control step
  * launched last for h when its steps are tracked, else (h NULL, or not tracked) everything `stream` holds so far. */
 int ndp_xchg_tick(ndp_xchg *x, ndp_handle *h, void *stream, const void *d_xr_next, size_t rows, void *d_gathered_next);
+/* ndp_tick with neighbours on other ranks (ndp_tick_config_remote): stage 2 and the exchange in one call -- this tick's window columns
+ * of h's reference list packed into the exchange's send buffer and all-gathered into d_gathered ([world * B][N+1][6] doubles, the
+ * buffer ndp_tick_config_remote was given), both on `stream` (NULL: the handle's), i.e. behind ndp_tick_advance_device and in front of
+ * ndp_tick_step_device by stream order alone.  Replaces, on the reference's side, the publish of PredXU per control period
+ * (nmpc_node.py:229-230) and its subscription in the neighbour's node (ndp_nmpc_leader_node.py:40,60-76). */
+int ndp_xchg_tick_windows(ndp_xchg *x, ndp_handle *h, void *d_gathered, void *stream);
 const char *ndp_xchg_last_error(const ndp_xchg *x);
 int ndp_xchg_destroy(ndp_xchg *x);
 

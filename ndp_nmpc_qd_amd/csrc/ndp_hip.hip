@@ -4064,6 +4064,32 @@ int ndp_tick_window_pv_device(ndp_handle *h, void *d_pv, void *stream)
     return note_stream(h, s);
 }
 
+// Stage 2 and the exchange in one call, on the tick's own stream: this tick's window columns packed out of the list into the
+// exchange's send buffer, then ncclAllGather into d_gathered ([world * B][N+1][6]) -- both on `stream`, behind the list advance and in
+// front of ndp_tick_step_device by stream order alone (no event operation, no second stream: the tick's chain is serial anyway).
+int ndp_xchg_tick_windows(ndp_xchg *x, ndp_handle *h, void *d_gathered, void *stream)
+{
+    if (!x || !h || !d_gathered) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (x->device != h->cfg.device) { h->err = "ndp_xchg_tick_windows: the exchange and the handle live on different devices"; return -1; }
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    if (!h->dRingX) { h->err = "ndp_xchg_tick_windows: no reference list"; return -11; }
+    const RingGeom rg = ring_geom(h);
+    const size_t B = h->cfg.batch, rows = B * (size_t)(h->cfg.N + 1), n = rows * 3;
+    if (x->send_doubles < rows * 6) {
+        if (x->send) { (void)hipStreamSynchronize(x->cs); (void)hipStreamSynchronize(s); (void)hipFree(x->send); x->send = nullptr; }
+        NDP_HIP(h, hipMalloc((void **)&x->send, rows * 6 * sizeof(double)));
+        x->send_doubles = rows * 6;
+    }
+    hipLaunchKernelGGL(pack_pv_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dRingX + rg.slot(h->list_n) * 10, rg.px(),
+                       h->cfg.N + 1, x->send, B);
+    NDP_HIP(h, hipGetLastError());
+    const int r = g_rccl.allgather(x->send, d_gathered, rows * 6, /* ncclFloat64 */ 8, x->comm, s);
+    if (r != 0) { x->err = g_rccl.errstr ? g_rccl.errstr(r) : "ncclAllGather failed"; h->err = "ndp_xchg_tick_windows: " + x->err; return -22; }
+    return note_stream(h, s);
+}
+
 int ndp_tick_step_device(ndp_handle *h, const void *d_x_odom, void *d_cmd, void *d_u0, void *stream)
 {
     if (!h || !d_x_odom || !d_cmd) return -1;

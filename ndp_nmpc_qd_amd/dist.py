@@ -286,6 +286,18 @@ class RcclExchange:
         if rc:
             raise RuntimeError(f"ndp_xchg_tick failed ({rc}): {self._lib.ndp_xchg_last_error(self._h).decode()}")
 
+    def tick_windows(self, eng, gathered, stream=None):
+        """ndp_tick with neighbours on other ranks: the engine's window of this tick (its reference list, behind tick_advance_device)
+        packed and all-gathered into `gathered` [world * B_local, N+1, 6] on `stream` -- between tick_advance_device and tick_step_device
+        (ndp_xchg_tick_windows)."""
+        import ctypes as C
+        if not (gathered.is_contiguous() and gathered.numel() == self.world * self.rows * PV_COLS):
+            raise ValueError("RcclExchange.tick_windows: gathered of the wrong size or not contiguous")
+        rc = self._lib.ndp_xchg_tick_windows(self._h, eng._h, C.c_void_p(gathered.data_ptr()),
+                                             C.c_void_p(stream.cuda_stream) if stream is not None else None)
+        if rc:
+            raise RuntimeError(f"ndp_xchg_tick_windows failed ({rc}): {self._lib.ndp_xchg_last_error(self._h).decode()}")
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.ndp_xchg_destroy(self._h)

@@ -589,3 +589,57 @@ def test_tick_with_neighbours_on_another_rank_equals_the_single_handle_tick():
     x2 = np.concatenate([e.ref_list_window(None)[0] for e in ranks])
     assert np.array_equal(x1, x2)
     assert np.array_equal(one.throttle_state(), np.concatenate([e.throttle_state() for e in ranks]))
+
+
+@pytest.mark.gpu
+def test_tick_windows_through_the_library_collective_equals_the_single_handle_tick():
+    """ndp_xchg_tick_windows: stage 2 of the remote tick and the exchange in one call (pack out of the list + ncclAllGather on the
+    tick's stream), here with a one-rank communicator (a real ncclAllGather, the neighbour "rank" is the rank itself).  Bit-equal
+    with the one-launch tick of one handle over 12 ticks; the gathered rows are the list window's position / velocity columns."""
+    import torch
+    import ndp_nmpc_qd_amd as ndp
+    from ndp_nmpc_qd_amd import dist as ndist
+    dev = torch.device("cuda", 0)
+    B = 128
+    tr = synth.figure_eight_traj(B, seed=9, n_seg=16, t_seg=0.25, pairs=True)
+    oi = (np.arange(B) ^ 1).astype(np.int32)
+
+    def make():
+        e = ndp.BatchedNMPC(B, disturbance=True)
+        e.ref_set_trajectory(*(tr[k] for k in ("coeff_x", "coeff_y", "coeff_z", "coeff_yaw", "time_cum", "time_seg", "final_pt")))
+        e.ref_list_reset()
+        e.throttle_reset()
+        return e
+    one, rem = make(), make()
+    one.tick_config(oi, gate=True)
+    one.tick_reset()
+    gathered = torch.zeros(B, 21, 6, dtype=torch.float64, device=dev)
+    rem.tick_config_remote(gathered, oi, gate=True)
+    rem.tick_reset()
+    try:
+        ex = ndist.RcclExchange(B, 20, 0)
+    except RuntimeError as e:
+        pytest.skip(f"RCCL could not be bound: {e}")
+    stream = torch.cuda.Stream(device=dev)
+    cmd1, u1 = torch.empty(B, 4, dtype=torch.float64, device=dev), torch.empty(B, 4, dtype=torch.float64, device=dev)
+    cmd2, u2 = torch.empty(B, 4, dtype=torch.float64, device=dev), torch.empty(B, 4, dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(5)
+    n_force = 0
+    for i in range(12):
+        t = 0.02 * (i + 1)
+        xr, _ = one.ref_list_window(None)
+        x0 = xr[:, 1, :].copy()
+        x0[:, 0:3] += rng.normal(0.0, 0.03, size=(B, 3))
+        x0_t = torch.from_numpy(x0).to(dev)
+        torch.cuda.synchronize()
+        one.tick_device(x0_t, cmd1, t=t, estimate=True, u0_out=u1)
+        rem.tick_advance_device(x0_t, t=t, estimate=True, stream=stream)
+        ex.tick_windows(rem, gathered, stream)
+        rem.tick_step_device(x0_t, cmd2, u0_out=u2, stream=stream)
+        torch.cuda.synchronize()
+        assert torch.equal(u1, u2) and torch.equal(cmd1, cmd2), i
+        w = rem.ref_list_window(None)[0]
+        assert np.array_equal(gathered.cpu().numpy(), w[:, :, 0:6])
+        n_force += int(np.any(one.device_force().cpu().numpy() != 0.0, axis=(1, 2)).sum())
+    assert n_force > 12 * B // 4
+    ex.close()
