@@ -255,6 +255,10 @@ int ndp_get_status(ndp_handle *h, int32_t *status, int32_t *ipm_iters);
  * loop, if that ran at all (1 = the first solve's set held); act[B][4N] = the set kept for the next step, element 4k + i = input i of
  * stage k: +1 on its upper bound, -1 on its lower, 0 free.  Either pointer may be NULL. */
 int ndp_get_active_set(ndp_handle *h, int32_t *sweeps, int8_t *act);
+/* The kept set handed in (same layout; entries -1, 0, +1): the warm start of the next step's QPs -- an instance that moves to another
+ * handle / rank takes its set along with its iterate (ndp_set_iterate empties the set: call this after it).  A set that does not fit the
+ * next QP costs sweeps, never the answer: the iterations end in a set that reproduces itself or in the interior-point loop. */
+int ndp_set_active_set(ndp_handle *h, const int8_t *act);
 
 /* Device views for callers that keep everything in HBM (bench, multi-GPU driver).  The getters above and
  * ndp_synchronize also wait for the last stream a *_device call was given. */

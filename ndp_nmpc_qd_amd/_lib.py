@@ -51,7 +51,7 @@ EXPORTS = [
     "ndp_track_steps", "ndp_last_step_event",
     "ndp_xchg_unique_id", "ndp_xchg_create", "ndp_xchg_begin", "ndp_xchg_end", "ndp_xchg_tick", "ndp_xchg_last_error", "ndp_xchg_destroy",
     "ndp_abi_version", "ndp_cfg_size",
-    "ndp_step_ex_f64", "ndp_refine_active", "ndp_get_active_set", "ndp_debug_host_info", "ndp_tick_config", "ndp_tick_reset", "ndp_tick_begin", "ndp_tick_end", "ndp_tick", "ndp_tick_device",
+    "ndp_step_ex_f64", "ndp_refine_active", "ndp_get_active_set", "ndp_set_active_set", "ndp_debug_host_info", "ndp_tick_config", "ndp_tick_reset", "ndp_tick_begin", "ndp_tick_end", "ndp_tick", "ndp_tick_device",
     "ndp_tick_config_remote", "ndp_tick_advance_device", "ndp_tick_window_pv_device", "ndp_tick_step_device", "ndp_xchg_tick_windows",
 ]
 
@@ -120,6 +120,7 @@ def load():
     lib.ndp_tick_step_device.argtypes = [vp] * 5
     lib.ndp_xchg_tick_windows.argtypes = [vp] * 4
     lib.ndp_get_active_set.argtypes = [vp] * 3
+    lib.ndp_set_active_set.argtypes = [vp] * 2
     lib.ndp_debug_host_info.argtypes = [vp, vp]
     lib.ndp_ref_list_reset.argtypes = [vp]
     lib.ndp_ref_list_fix_pt.argtypes = [vp, vp, C.c_int]

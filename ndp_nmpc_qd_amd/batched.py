@@ -413,6 +413,12 @@ class BatchedNMPC:
         self._check(self._lib.ndp_get_active_set(self._h, _lib.ptr(sw), _lib.ptr(act)), "ndp_get_active_set")
         return sw & 0xfff, act
 
+    def set_active_set(self, act):
+        """The kept sets handed in (act[B,N,4] int8, entries -1 / 0 / +1): the warm start of the next step's QPs (ndp_set_active_set;
+        after set_iterate, which empties them)."""
+        a = np.ascontiguousarray(act, dtype=np.int8).reshape(self.B, self.N, 4)
+        self._check(self._lib.ndp_set_active_set(self._h, _lib.ptr(a)), "ndp_set_active_set")
+
     def condensed_kept(self):
         """qp_precision 5 / 6 (config 5's condensed study): how many of the last step's QPs per instance kept their condensed solve's
         result (it passed the fp64 inside-the-box test); the others were solved by the fp64 Riccati path."""

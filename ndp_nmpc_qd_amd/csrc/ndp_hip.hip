@@ -741,6 +741,9 @@ __device__ __forceinline__ void mlp_tile(lds_cf32 fr, const float zb[3], int lan
                 accl[r] = 0.0f;
             }
         }
+#ifdef NDP_DEV_HALF_TILE        // (measurement only: half of the tile's matrix instructions, wrong forces -- what a tile shared by two waves would cost at best)
+        if (!(rec & 1))
+#endif
         mm3(wc, l2 ? x1[it][s] : x2[it][s], acc, accl);
         if (last) {
 #pragma unroll
@@ -3456,6 +3459,20 @@ int ndp_get_active_set(ndp_handle *h, int32_t *sweeps, int8_t *act)
         for (size_t i = 0; i < B; ++i) sweeps[i] = (int32_t)((uint32_t)sweeps[i] >> ITERS_SWEEP_SHIFT);
     }
     if (act) NDP_HIP(h, hipMemcpy(act, h->dAct, act_bytes(h), hipMemcpyDefault));
+    return 0;
+}
+
+int ndp_set_active_set(ndp_handle *h, const int8_t *act)
+{
+    if (!h || !act) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = wait_all(h);
+    if (rc) return rc;
+    const size_t n = act_bytes(h);
+    for (size_t i = 0; i < n; ++i)
+        if (act[i] < -1 || act[i] > 1) { h->err = "ndp_set_active_set: entries are -1, 0 or +1"; return -1; }
+    NDP_HIP(h, hipMemcpy(h->dAct, act, n, hipMemcpyDefault));
     return 0;
 }
 

@@ -35,9 +35,11 @@
 #if defined(__clang__)
 #define NDP_UNROLL_STAGES _Pragma("unroll UNROLL_STAGES")
 #define NDP_UNROLL_SWEEP _Pragma("unroll UNROLL_SWEEP")
+#define NDP_KEEP_LOOP _Pragma("unroll 1")            // rare-path loops: a few registers, whatever the trip count
 #else
 #define NDP_UNROLL_STAGES
 #define NDP_UNROLL_SWEEP
+#define NDP_KEEP_LOOP
 #endif
 #ifdef NDP_FINE_STAMPS
 #define NDP_FINE(x) x
@@ -1413,9 +1415,9 @@ struct RtiWave {
     // all at once; a set that reproduces itself satisfies the KKT conditions of the box-constrained QP -- it IS the solution.  One
     // Riccati sweep per iteration (the interior-point loop: ~1.55 per iteration, 5-9 iterations); typically two or three sweeps from
     // an empty set, ONE when the previous control step's set still holds (RtiIo::act: the warm start HPIPM is not given).
-    // A pin is a weight: the stage's R entry + as_gamma and the gradient - as_gamma d, i.e. the term as_gamma/2 (du - d)^2 -- it rides on
-    // the diagonal of Lam exactly where the interior-point loop's barrier terms ride (up to 1e10 in its last iterations), costs the sweep
-    // nothing, leaves du within lambda / as_gamma of d (then set to d exactly) and hands back the multiplier lambda = as_gamma (du - d).
+    // A pin is a weight: the term as_gamma/2 (du - d)^2, solved for delta = du - d (as_apply) -- it rides on the diagonal of Lam exactly
+    // where the interior-point loop's barrier terms ride (up to 1e10 in its last iterations), costs the sweep nothing, leaves du within
+    // lambda / as_gamma of d (then set to d exactly) and hands back the multiplier lambda = as_gamma delta.
     // Velocity bounds are not pinned (a weight on a STATE makes the recursion stiff: see ROBUST): a violated one, a set that does not
     // settle within as_iter_max sweeps, or a failed factorisation hand the QP to the interior-point loop, which starts from the base
     // cost blocks whatever the pins did to them.
@@ -1475,22 +1477,82 @@ struct RtiWave {
         for (int t = 0; t < RUA; ++t) nz = W::bor(nz, !(a_get(A, m, lds, t, a_elem(P, lane, t)) == 0));
         return W::any(nz);
     }
-    // cost blocks of the input rows <- base blocks + the pins of A (every input row is rewritten: released pins disappear)
-    static NDP_D void as_apply(const RtiParams &P, const LdsMap &m, lp lds, const ActSet &A)
+    // The QP's blocks <- base blocks + the pins of A (every input row is rewritten: released pins disappear).  A pinned input is solved
+    // for in RE-CENTRED form: du = d + delta with the pin's weight on delta alone -- cost gradient r + R d, dynamics defect b + B d (d = 0
+    // on free inputs), diagonal R + as_gamma, no as_gamma d term anywhere.  The sweep then returns delta = lambda / as_gamma itself
+    // (|delta| ~ 1e-12 .. 1e-9) to full RELATIVE accuracy, and with it the multiplier's sign.  (Round 6's first form put as_gamma d into
+    // the gradient and read the multiplier off du - d: a difference of two numbers that agree to 12 digits, right to ~1e-3 in lambda --
+    // one closed-loop instance in ~20 000 kept a pin whose multiplier was negative, 1e-4 .. 1e-2 off the QP's solution.)
+    // The defects as the linearisation left them are parked in CX (dead until the interior-point loop, which gets them back: as_restore_b).
+    static NDP_D void as_apply(const RtiParams &P, const LdsMap &m, lp lds, const ActSet &A, bool &pinned)
     {
-        const int nzu = horizon(P) * NU;
+        const int N = horizon(P), nzu = N * NU, nb = N * NX;
         vi lane = W::lane_here();
-        for (int t = 0; t < RUA; ++t) {
+        auto rows = [&](int t) {
             vi e = W::imin(lane + 64 * t, nzu - 1);               // lanes past the end repeat the last element (identical duplicate stores)
             vi c = e & 3;
             vi cbk = (e >> 2) * int(CB_STRIDE) + c + m.CB;
             vd cu = W::ld(lds, e + m.UI);
             const vi at = a_get(A, m, lds, t, e);
             vb up = at > 0, on = !(at == 0);
-            vd d = W::ld(lds, c + (m.KC + int(KC_LBU)) + W::sel(up, vi(int(SL_UB)), vi(0))) - cu;
+            vd d = W::sel(on, W::ld(lds, c + (m.KC + int(KC_LBU)) + W::sel(up, vi(int(SL_UB)), vi(0))) - cu, vd(0.0));
             vd w = W::sel(on, vd(W::late_params(P)->as_gamma), vd(0.0));
-            W::st(lds, cbk + int(CB_DEU), P.dt * W::ld(lds, c + (m.KC + int(KC_RD))) + w);
-            W::st(lds, cbk + int(CB_RE), W::ld(lds, cbk + int(CB_RB)) - w * d);
+            vd rd = P.dt * W::ld(lds, c + (m.KC + int(KC_RD)));
+            W::st(lds, cbk + int(CB_DEU), rd + w);
+            W::st(lds, cbk + int(CB_RE), W::ld(lds, cbk + int(CB_RB)) + rd * d);
+            W::st(lds, e + m.CU, d);
+        };
+        if constexpr (A_LDS) {            // (the set is read from LDS: the loop stays a loop -- those kernels sit at the register limit)
+            NDP_KEEP_LOOP
+            for (int t = 0; t < RUA; ++t) rows(t);
+        } else {
+            for (int t = 0; t < RUA; ++t) rows(t);
+        }
+        W::sync();
+        NDP_KEEP_LOOP
+        for (int t = 0; t * 64 < nb; ++t) {                       // one lane per (stage, state row): b_k[row] = base + B_k[row][:] d_k
+            vi e = W::imin(lane + 64 * t, nb - 1);
+            vi k = (e * 6554) >> 16, row = e - k * 10;             // e / 10, e < 16 384
+            vi mb = k * int(MB_STRIDE) + m.MB;
+            vb pv = row < 6;                                       // rows 0..5: 6x8 block, inputs in columns 4..7; rows 6..9: 4x7 block, columns 4..6 (no thrust column)
+            vi bo = mb + W::sel(pv, row * 8 + (int(MB_PV) + 4), (row - 6) * 7 + (int(MB_Q) + 4));
+            vd base;
+            if (!pinned) {                                         // the first pins of this QP: the defects are still the linearisation's
+                base = W::ld(lds, mb + row + int(MB_B));
+                W::st(lds, e + m.CX, base);
+            } else base = W::ld(lds, e + m.CX);
+            vd s = base;
+            for (int j = 0; j < 4; ++j) {
+                vi off = j < 3 ? bo + j : W::sel(pv, bo + 3, mb + int(MB_ZERO));
+                s = s + W::ld(lds, off) * W::ld(lds, k * 4 + j + m.CU);
+            }
+            W::st(lds, mb + row + int(MB_B), s);
+        }
+        pinned = true;
+        W::sync();
+    }
+    static NDP_D void as_save_b(const RtiParams &P, const LdsMap &m, lp lds)
+    {
+        const int nb = horizon(P) * NX;
+        vi lane = W::lane_here();
+        NDP_KEEP_LOOP
+        for (int t = 0; t * 64 < nb; ++t) {
+            vi e = W::imin(lane + 64 * t, nb - 1);
+            vi k = (e * 6554) >> 16, row = e - k * 10;
+            W::st(lds, e + m.CX, W::ld(lds, k * int(MB_STRIDE) + row + (m.MB + int(MB_B))));
+        }
+        W::sync();
+    }
+    // the defects as the linearisation left them, back from CX (in front of the interior-point loop, which starts from the base blocks)
+    static NDP_D void as_restore_b(const RtiParams &P, const LdsMap &m, lp lds)
+    {
+        const int nb = horizon(P) * NX;
+        vi lane = W::lane_here();
+        NDP_KEEP_LOOP
+        for (int t = 0; t * 64 < nb; ++t) {
+            vi e = W::imin(lane + 64 * t, nb - 1);
+            vi k = (e * 6554) >> 16, row = e - k * 10;
+            W::st(lds, k * int(MB_STRIDE) + row + (m.MB + int(MB_B)), W::ld(lds, e + m.CX));
         }
         W::sync();
     }
@@ -1545,8 +1607,9 @@ struct RtiWave {
             at[t] = a_get(A, m, lds, t, W::imin(lane + 64 * t, nzu - 1));
             const vd lo = lu[t] - cu[t], hi = hu[t] - cu[t];
             const vb up = at[t] > 0, dn = at[t] < 0, on = W::bor(up, dn);
-            // pinned: multiplier as_gamma (du - d) for an upper, as_gamma (d - du) for a lower bound; released when negative
-            const vb keep = W::band(on, W::sel(up, zu[t] - hi, lo - zu[t]) >= 0.0);
+            // pinned (ZU holds delta = du - d, see as_apply): multiplier as_gamma delta for an upper, -as_gamma delta for a lower bound;
+            // released when negative
+            const vb keep = W::band(on, W::sel(up, zu[t], vd(0.0) - zu[t]) >= 0.0);
             // free: beyond a bound (or, as_iter_max = 0, closer to it than auto_margin) -> pinned there
             const vb vhi = W::band(!on, !(zu[t] < hi)), vlo = W::band(!on, !(zu[t] > lo));
             na[t] = W::sel(keep, at[t], W::sel(vhi, vi(1), W::sel(vlo, vi(-1), vi(0))));
@@ -1945,15 +2008,14 @@ struct RtiWave {
                 }
             }
             bool done = false, failed = false;
+            bool pinned = false;                       // does the sweep at hand carry pins?  (then as_apply has moved the defects: their base values are in CX)
             int st = 0;
             if (DEFER || P.qp_mode == QP_AUTO) {
                 // Equality-constrained minimiser inside the box => it IS the QP solution (all multipliers 0).  Otherwise, and when the
                 // previous step left a set: active-set iterations on the input bounds (as_check) -- each one this same sweep again.
-                bool pinned = false;                   // does the sweep at hand carry pins?
                 if (NDP_RARELY(as_on && as_any(P, m, lds, A))) {    // warm start: the kept set's pins
                     if (DEFER && A_LDS) return true;                // (the five-slot producer hands an instance with a kept set straight over: see DEFER)
-                    as_apply(P, m, lds, A);
-                    pinned = true;
+                    as_apply(P, m, lds, A, pinned);
                 }
                 const int sweeps0 = sweeps;            // (as_iter_max counts per QP, `sweeps` over the step's RTI iterations)
                 for (;;) {
@@ -1985,13 +2047,13 @@ struct RtiWave {
                     }
                     if constexpr (COND != 0) {
                         if (condensed && verdict != 1) {           // outside the box in a way the active set does not take up: the fp64 solve, then the usual course
+                            if (!pinned) as_save_b(P, m, lds);     // (keeps `pinned` = "the base defects are in CX")
                             pinned = true;                         // (marks "not the first solve": no pins exist, as_check's general part handles that)
                             continue;
                         }
                     }
                     if (!DEFER && NDP_RARELY(as_on && verdict == 1 && sweeps - sweeps0 <= P.as_iter_max)) {
-                        as_apply(P, m, lds, A);
-                        pinned = true;                 // (an update that only releases may leave no pin: the general test handles an empty set too)
+                        as_apply(P, m, lds, A, pinned);            // (an update that only releases may leave no pin: the general test handles an empty set too)
                         continue;
                     }
                     break;
@@ -2001,6 +2063,7 @@ struct RtiWave {
             if (IPM_RARE ? NDP_RARELY(!done) : !done) {
                 if (DEFER) return true;
                 if (as_on) {                           // the interior-point loop's answer carries no set: the next step starts cold
+                    if (NDP_RARELY(pinned)) as_restore_b(P, m, lds);
                     as_clear(P, m, lds, A);
                     if (io.act) as_store(P, m, lds, io, A);
                 }

@@ -252,7 +252,7 @@ struct WaveGfx950 {
         a = op(a, dpp_quad<0x124>(a));
         a = op(a, dpp_quad<0x128>(a));
         const double r0 = readlane(a, 0), r1 = readlane(a, 16), r2 = readlane(a, 32), r3 = readlane(a, 48);
-        return op(op(r0, r1), op(r2, r3));
+        return uniform(op(op(r0, r1), op(r2, r3)));      // (the same in every lane: told to the compiler -- the result then lives in scalar registers)
     }
     static NDP_D double wave_min(vd a) { return wave_reduce(a, [](double x, double y) { return fmin(x, y); }); }
     static NDP_D double wave_max(vd a) { return wave_reduce(a, [](double x, double y) { return fmax(x, y); }); }

@@ -497,15 +497,23 @@ static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B
         for (int i = 0; i < nu; ++i) a[i] = (as_on && act) ? act[i] : 0;
         for (;;) {
             int any = 0;
+            double *be = w->zb;                 /* the defects with the pinned inputs' step bounds moved into them (see below) */
             memcpy(Re, Rd, sizeof(double) * (size_t)nu);
             memcpy(re, r, sizeof(double) * (size_t)nu);
+            memcpy(be, b, sizeof(double) * (size_t)N * NX);
+            /* a pinned input is solved for in re-centred form, du = d + delta with the weight on delta alone: gradient r + R d,
+             * defect b + B d, diagonal R + as_gamma -- the solve returns delta = lambda / as_gamma itself, to full relative accuracy
+             * (read off du - d, two numbers that agree to 12 digits, the multiplier is right to ~1e-3 only: rti_wave.hpp, as_apply) */
             for (int i = 0; i < nu; ++i)
                 if (a[i]) {
+                    const double d = a[i] > 0 ? cn[i].hi : cn[i].lo;
+                    const int k = i / NU, j = i % NU;
                     Re[i] += c->as_gamma;
-                    re[i] -= c->as_gamma * (a[i] > 0 ? cn[i].hi : cn[i].lo);
+                    re[i] += Rd[i] * d;
+                    for (int row = 0; row < NX; ++row) be[k * NX + row] += B[(size_t)k * NX * NU + row * NU + j] * d;
                     any = 1;
                 }
-            const int rc = riccati_solve(N, A, B, b, Q, q, Re, re, dx0, nx_, nu_, G);
+            const int rc = riccati_solve(N, A, B, any ? be : b, Q, q, Re, re, dx0, nx_, nu_, G);
             ++sweeps;
             if (rc) {
                 if (!any) { status = 4; failed = 1; goto done; }
@@ -519,9 +527,9 @@ static int qp_solve_ws(const orc_cfg *c, int N, const double *A, const double *B
             if (!vok) break;
             for (int i = 0; i < nu; ++i) {
                 const double zn = nu_[i];
-                /* pinned: kept while its multiplier as_gamma (du - d) has the right sign, else released (not re-pinned in this pass);
+                /* pinned: kept while its multiplier as_gamma delta has the right sign, else released (not re-pinned in this pass);
                  * free: beyond a bound -> pinned there */
-                if (a[i]) na[i] = ((a[i] > 0 ? zn - cn[i].hi : cn[i].lo - zn) >= 0.0) ? a[i] : 0;
+                if (a[i]) na[i] = ((a[i] > 0 ? zn : -zn) >= 0.0) ? a[i] : 0;            /* (zn = delta) */
                 else na[i] = zn > cn[i].hi - um ? 1 : (zn < cn[i].lo + um ? -1 : 0);
                 same = same && na[i] == a[i];
             }

@@ -281,3 +281,36 @@ def test_switched_off_is_rounds_1_to_5(oracle):
             assert it == sto.ipm_iters
             np.testing.assert_allclose(u0, uo, rtol=0, atol=1e-7)
     assert n >= 1
+
+
+def test_weak_multipliers_fixture_twin_and_emulator(oracle):
+    """tests/golden/as_weak_multiplier_cases.npz (scripts/make_as_weak_fixture.py): QPs out of closed-loop recoveries with a bound whose
+    multiplier is small (|lambda| ~ 1e-3 .. 1e-1).  Round 6's first form read a pin's multiplier off du - d at as_gamma = 1e12 -- a
+    difference of two numbers that agree to 12 digits, right to ~1e-3 in lambda -- and on five of these eleven kept a pin whose
+    multiplier was negative (status 0, 2.5e-4 .. 1.6e-2 off the QP's solution) or cycled into the interior-point loop.  The
+    re-centred pins (rti_wave.hpp: as_apply; oracle: qp_solve_ws) return delta = lambda / as_gamma itself: oracle twin and wave
+    program on every case to 1e-9 of the exact solution, the exact active set, no interior-point iteration, the same sweeps."""
+    g = np.load("tests/golden/as_weak_multiplier_cases.npz")
+    n = len(g["n_active"])
+    twin = oracle.default_cfg()
+    twin.qp_mode = 0
+    cfg = E.default_cfg()
+    cfgl = oracle.default_cfg()
+    for k in range(n):
+        Xo, Uo, acto = g["X"][k][None].copy(), g["U"][k][None].copy(), g["act"][k][None].copy()
+        uo, sto, ito, swo = oracle.step_batch_as(twin, g["x0"][k][None], g["xr"][k][None], g["ur"][k][None], None, Xo, Uo, acto)
+        assert sto[0] == 0 and ito[0] == 0, k
+        assert np.abs(Uo[0] - g["U_exact"][k]).max() < 1e-9 and np.abs(Xo[0] - g["X_exact"][k]).max() < 1e-9, k
+        assert (acto != 0).sum() == g["n_active"][k], k
+        X, U = g["X"][k].copy(), g["U"][k].copy()
+        act = E.act_record(20)
+        E.act_view(act)[1][:] = g["act"][k]
+        u0, st, it, *_ = E.rti_step(cfg, g["x0"][k], g["xr"][k], g["ur"][k], None, X, U, act=act)
+        sw, aset = E.act_view(act)
+        assert st == 0 and it == 0 and sw == swo[0], (k, st, it, sw, swo[0])
+        assert np.abs(U - g["U_exact"][k]).max() < 1e-9 and np.abs(X - g["X_exact"][k]).max() < 1e-9, k
+        assert np.array_equal(aset, acto[0]), k
+        if k % 4 == 0:                         # the fixture's exact solutions, made again
+            qp = oracle.linearize(cfgl, g["x0"][k], g["xr"][k], g["ur"][k], None, g["X"][k], g["U"][k])
+            dxa, dua, active = R.active_set_solve(qp)
+            assert np.abs(g["U"][k] + dua - g["U_exact"][k]).max() < 1e-12 and len(active) == g["n_active"][k]

@@ -221,3 +221,62 @@ def test_interior_point_always_is_untouched(ndp, oracle):
     assert _rel(u0[st == 0], uo[st == 0]) < 1e-6
     sw, act = eng.active_set()
     assert not act.any() and not sw.any()
+
+
+def test_weak_multipliers_fixture(ndp, oracle):
+    """tests/golden/as_weak_multiplier_cases.npz: QPs with a bound whose multiplier is small, out of closed-loop recoveries, on which
+    round 6's first form of the pins kept a wrongly signed one or cycled (tests/test_active_set.py has the story).  One batch, the kept
+    sets handed in (ndp_set_active_set): every instance to 1e-9 of the exact dense-KKT solution, the exact number of active bounds, no
+    interior-point iteration; the twin agrees on sweeps and sets."""
+    g = np.load("tests/golden/as_weak_multiplier_cases.npz")
+    B = len(g["n_active"])
+    eng = ndp.BatchedNMPC(B)
+    eng.set_iterate(g["X"], g["U"])
+    eng.set_active_set(g["act"])
+    assert np.array_equal(eng.active_set()[1], g["act"])
+    u0, X, U, st, it = eng.update(g["x0"], g["xr"], g["ur"], raise_on_status=False, full=True)
+    sw, act = eng.active_set()
+    assert not st.any() and not it.any()
+    assert np.abs(U - g["U_exact"]).max() < 1e-9 and np.abs(X - g["X_exact"]).max() < 1e-9
+    assert np.array_equal((act != 0).sum(axis=(1, 2)), g["n_active"])
+    Xo, Uo, acto = g["X"].copy(), g["U"].copy(), g["act"].copy()
+    uo, sto, ito, swo = oracle.step_batch_as(_twin_cfg(oracle), g["x0"], g["xr"], g["ur"], None, Xo, Uo, acto)
+    assert np.array_equal(sw, swo) and np.array_equal(act, acto) and not sto.any() and not ito.any()
+    with pytest.raises(ndp.NdpError):
+        eng.set_active_set(np.full((B, 20, 4), 2, dtype=np.int8))
+
+
+def test_closed_loop_recovery_matches_twin_on_every_instance(ndp, oracle):
+    """scripts/stress_active_set.py in small: 1024 vehicles recover from large initial errors over eight control periods, the plant
+    (oracle RK4) driven by the DEVICE's u0, kept sets growing, shrinking and emptying.  Device and oracle twin agree on status,
+    sweeps, interior-point iterations and sets on EVERY instance of every tick and on the iterate to 1e-9 (the first form of the pins
+    differed on ~1 instance in 3000 here: a multiplier's sign decided by rounding noise); against the interior point at tol 1e-11:
+    1e-5 (that answer's own accuracy on nearly degenerate instances, see test_mixed_workload_...)."""
+    B = 1024
+    kw = dict(pos_sigma=1.5, vel_sigma=3.0, quat_sigma=0.2)
+    b = synth.make_batch(B, seed=1002, **kw)
+    eng = ndp.BatchedNMPC(B)
+    eng.reset(b["xr"], b["ur"])
+    twin, tight = _twin_cfg(oracle), oracle.default_cfg()
+    tight.tol = 1e-11
+    Xo, Uo = b["xr"].copy(), b["ur"].copy()
+    acto = np.zeros((B, 20, 4), dtype=np.int8)
+    x = b["x0"].copy()
+    n_con = n_ipm = 0
+    for t in range(8):
+        bt = synth.make_batch(B, seed=1002, t0=0.02 * t, **kw)
+        Xp, Up = Xo.copy(), Uo.copy()
+        u0, X, U, st, it = eng.update(x, bt["xr"], bt["ur"], raise_on_status=False, full=True)
+        sw, act = eng.active_set()
+        uo, sto, ito, swo = oracle.step_batch_as(twin, x, bt["xr"], bt["ur"], None, Xo, Uo, acto)
+        assert not st.any() and np.array_equal(st, sto) and np.array_equal(sw, swo) and np.array_equal(it, ito) and np.array_equal(act, acto), t
+        asv = it == 0                                   # (an interior-point fallback: that loop's device / oracle parity, 1e-8 typical)
+        assert np.abs(U[asv] - Uo[asv]).max() < 1e-9 and np.abs(X[asv] - Xo[asv]).max() < 1e-9 and np.abs(U - Uo).max() < 1e-6, t
+        ui, sti, _ = oracle.step_batch(tight, x, bt["xr"], bt["ur"], None, Xp, Up)
+        ok = sti == 0
+        assert _rel(u0[ok], ui[ok]) < 1e-5, t
+        n_con += int(act.any(axis=(1, 2)).sum())
+        n_ipm += int((it > 0).sum())
+        Xo[:], Uo[:] = X, U
+        x = oracle.plant_step(twin, x.copy(), u0, np.zeros((B, 3)), 0.02)
+    assert n_con > 2 * B and n_ipm <= 8
