@@ -16,6 +16,8 @@ O.build()
 n_seed = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+N = int(sys.argv[4]) if len(sys.argv) > 4 else 20          # 40: the five-slot kernels (config 5's shape), the kept set parked in LDS
+NRTI = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 WORK = {"mixed": dict(pos_sigma=0.5, vel_sigma=1.0, quat_sigma=0.15), "hard": dict(pos_sigma=1.5, vel_sigma=3.0, quat_sigma=0.2),
         "fast": dict(pos_sigma=0.8, vel_sigma=1.5, quat_sigma=0.25, omega_range=(1.5, 2.5))}
 blob = np.fromfile("ndp_nmpc_qd_amd/weights/downwash_sn4.bin", dtype="<f4")
@@ -23,20 +25,20 @@ worst = dict(twin=0.0, tight=0.0, mism=0, bad_dev=0, bad_tight=0, ipm=0, sweeps=
 for seed in range(n_seed):
     for name, kw in WORK.items():
         for dw in (False, True):
-            b = synth.make_batch(B, seed=1000 + seed, downwash=dw, **kw)
-            eng = ndp.BatchedNMPC(B, disturbance=dw)
+            b = synth.make_batch(B, N=N, seed=1000 + seed, downwash=dw, **kw)
+            eng = ndp.BatchedNMPC(B, N=N, n_rti=NRTI, disturbance=dw)
             eng.reset(b["xr"], b["ur"])
-            twin = O.default_cfg(use_fd=dw)
+            twin = O.default_cfg(N=N, n_rti=NRTI, use_fd=dw)
             twin.qp_mode = 0
-            tight = O.default_cfg(use_fd=dw)
+            tight = O.default_cfg(N=N, n_rti=NRTI, use_fd=dw)
             tight.tol = 1e-11
             Xo, Uo = b["xr"].copy(), b["ur"].copy()
-            acto = np.zeros((B, 20, 4), dtype=np.int8)
+            acto = np.zeros((B, N, 4), dtype=np.int8)
             x = b["x0"].copy()
             e_twin = e_tight = 0.0
             mism = bad_dev = bad_tight = n_ipm = sw_max = con = 0
             for t in range(ticks):
-                bt = synth.make_batch(B, seed=1000 + seed, downwash=dw, t0=0.02 * t, **kw)
+                bt = synth.make_batch(B, N=N, seed=1000 + seed, downwash=dw, t0=0.02 * t, **kw)
                 f = None
                 kwu = {}
                 if dw:
