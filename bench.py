@@ -81,7 +81,9 @@ LEGEND = {
               "value_median = solves/s at the median pass; `value` itself is the contract's one pass",
     "tick_remote": "N > 1: ndp_tick with every vehicle's neighbour on the NEXT rank (ndp_tick_config_remote): per control period list advance + estimator -> "
                    "window columns -> all-gather of the [B, N+1, 6] windows -> control step, on one stream; value = whole-job solves/s over the slowest rank; "
-                   "parity = rank 0's u0 against the oracle fed the rows the exchange delivered; rows_ok = those rows are the neighbour rank's windows",
+                   "parity = rank 0's u0 against the oracle fed the rows the exchange delivered; rows_ok = those rows are the neighbour rank's windows; "
+                   "with the library's communicator the headline figures are the form with the exchange ONE CONTROL PERIOD AHEAD (ndp_xchg_tick_step / _begin: advance, "
+                   "columns and all-gather of tick i + 1 on the exchange's stream beside tick i's control step) and `serial` holds the one-stream form's",
     "tick.remote": "ndp_tick with neighbours on OTHER ranks (ndp_tick_config_remote): list advance -> window columns -> [exchange] -> control step, three launches; "
                    "one rank with its own windows as the gathered buffer, odometry in HBM, host-launched; value_one_launch_device_resident = ndp_tick_device on the same inputs",
     "ipm_always": "qp_mode 1: every instance runs the interior-point loop like HPIPM does",
@@ -495,11 +497,14 @@ def tick_block(ndp, synth, B, N, device):
     return out
 
 
-def tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, dev, cdev, stream, same_dev, n_ticks=120, n_warm=24, xchg=None):
+def tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, dev, cdev, stream, same_dev, n_ticks=120, n_warm=24, xchg=None,
+                      ahead=False):
     """ndp_tick over `world` ranks, every vehicle's neighbour on the NEXT rank (ndp_tick_config_remote): per control period
         ndp_tick_advance_device -> ndp_tick_window_pv_device -> all-gather of the [B, N+1, 6] windows -> ndp_tick_step_device
     on `stream`; with xchg (dist.RcclExchange: the library's own communicator) the two middle stages are ONE call, ndp_xchg_tick_windows
-    (pack out of the list + ncclAllGather on `stream`), else torch.distributed's all_gather_into_tensor.  Every rank flies the same B figure-eights (vehicle i's neighbour = vehicle i ^ 1 of rank + 1: the gates of the
+    (pack out of the list + ncclAllGather on `stream`), else torch.distributed's all_gather_into_tensor.  ahead (needs xchg): the
+    exchange one control period ahead -- ndp_xchg_tick_step (tick i) then ndp_xchg_tick_begin (advance, columns, all-gather of tick
+    i + 1 on the exchange's stream beside tick i's control step; two gather buffers).  Every rank flies the same B figure-eights (vehicle i's neighbour = vehicle i ^ 1 of rank + 1: the gates of the
     metric's workload), odometry = node 0 of the tick's window + SURVEY 8d's noise (per-rank noise).  All ranks call this; set-up
     failures are agreed on by a collective before the first tick, the ticks themselves only launch.  Returns (on every rank) the
     whole-job rate over the slowest rank's time, a parity tick of rank 0 against the CPU oracle fed the rows the exchange
@@ -512,6 +517,7 @@ def tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, de
         e.ref_set_trajectory(tr["coeff_x"], tr["coeff_y"], tr["coeff_z"], tr["coeff_yaw"], tr["time_cum"], tr["time_seg"], tr["final_pt"])
         e.ref_list_reset()
         gathered = torch.zeros(world * B, N + 1, 6, dtype=torch.float64, device=dev)
+        gathered_b = torch.zeros(world * B, N + 1, 6, dtype=torch.float64, device=dev)      # (ahead: the second gather buffer)
         pv = torch.zeros(B, N + 1, 6, dtype=torch.float64, device=dev)
         nbr = (rank + 1) % world
         oi = (nbr * B + (np.arange(B, dtype=np.int64) ^ 1)).astype(np.int32)
@@ -560,14 +566,28 @@ def tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, de
             with torch.cuda.stream(stream):
                 dist.all_gather_into_tensor(gathered, pv)             # RCCL on torch's current stream = `stream`
 
-    def tick(i):
+    ahead = bool(ahead and xh is not None)
+    gps = [gp, C.c_void_p(gathered_b.data_ptr())]
+    gts = [gathered, gathered_b]
+
+    def tick(i, last=False):
         nonlocal rcs
+        if ahead:               # tick i's gather was begun one tick ago (the first: below); tick i + 1's is begun behind tick i's step
+            rcs |= L.ndp_xchg_tick_step(xh, h, xp[i], None, None, 0, cp, up, gps[i % 2], sp)
+            if not last:
+                tv.value = 0.02 * (i + 1)
+                rcs |= L.ndp_xchg_tick_begin(xh, h, tp, UNI, gps[(i + 1) % 2])
+            return
         tv.value = 0.02 * i
         rcs |= L.ndp_tick_advance_device(h, xp[i], tp, None, None, UNI, sp)
         if xh is None:
             rcs |= L.ndp_tick_window_pv_device(h, pp, sp)
         gather()
         rcs |= L.ndp_tick_step_device(h, xp[i], cp, up, sp)
+    if ahead:
+        rcs |= L.ndp_track_steps(h, 1)
+        tv.value = 0.0
+        rcs |= L.ndp_xchg_tick_begin(xh, h, tp, UNI, gps[0])
     for i in range(n_warm):
         tick(i)
     torch.cuda.synchronize()
@@ -583,9 +603,9 @@ def tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, de
     # curves: they equal this rank's own), and rank 0's u0 against the oracle fed those rows
     X, U = e.get_iterate()
     i = n_warm + n_ticks
-    tick(i)
+    tick(i, last=True)
     torch.cuda.synchronize()
-    g = gathered.cpu().numpy()
+    g = gts[i % 2 if ahead else 0].cpu().numpy()
     rcs |= L.ndp_tick_window_pv_device(h, pp, sp)                   # (this rank's own columns, for the comparison below)
     torch.cuda.synchronize()
     rows_ok = bool(np.array_equal(g[nbr * B:(nbr + 1) * B], pv.cpu().numpy())) and bool(np.any(g[nbr * B:(nbr + 1) * B] != 0))
@@ -609,7 +629,8 @@ def tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, de
     elapsed = float(el.item())
     res.update({"value": world * B * n_ticks / elapsed, "us": elapsed / n_ticks * 1e6, "unit": "solves/s", "ticks": n_ticks,
                 "launches_per_tick": 3 if xh is None else 2,
-                "gather": ("ndp_xchg_tick_windows (pack + ncclAllGather on the tick's stream)" if xh is not None else
+                "gather": ("ndp_xchg_tick_begin / _step: advance, columns and ncclAllGather of tick i + 1 on the exchange's stream beside tick i's control step" if ahead else
+                           "ndp_xchg_tick_windows (pack + ncclAllGather on the tick's stream)" if xh is not None else
                            "host-staged (gloo, one device)" if same_dev else "torch.distributed all_gather_into_tensor (RCCL)"),
                 "parity": par, "bad": int(agg[0].item()), "rows_ok": int(agg[1].item()) == 0})
     del e
@@ -1704,6 +1725,9 @@ def main():
         timer.start()
         try:
             tick_remote = tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, dev, cdev, stream, same_dev, xchg=xchg)
+            if xchg is not None and "error" not in tick_remote:      # (the same on every rank) ... and with the exchange one period ahead
+                ta_ = tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, dev, cdev, stream, same_dev, xchg=xchg, ahead=True)
+                tick_remote = {**ta_, "serial": {k: tick_remote.get(k) for k in ("value", "us", "parity", "bad", "rows_ok")}}
         except Exception as e:
             tick_remote = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.set_stream(stream)

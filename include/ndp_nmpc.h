@@ -488,6 +488,17 @@ int ndp_xchg_tick(ndp_xchg *x, ndp_handle *h, void *stream, const void *d_xr_nex
  * ndp_tick_step_device by stream order alone.  Replaces, on the reference's side, the publish of PredXU per control period
  * (nmpc_node.py:229-230) and its subscription in the neighbour's node (ndp_nmpc_leader_node.py:40,60-76). */
 int ndp_xchg_tick_windows(ndp_xchg *x, ndp_handle *h, void *d_gathered, void *stream);
+/* The same tick with the exchange ONE CONTROL PERIOD AHEAD: a window is a function of time alone, so the list advance of tick i+1, its
+ * window columns and their all-gather run on the exchange's own stream BESIDE the control step of tick i, into the other one of TWO
+ * gather buffers (both [world * B][N+1][6]; ndp_tick_config_remote names either: the step is told which one it reads).  Per period:
+ *     ndp_xchg_tick_step (tick i: estimator if NDP_TICK_ESTIMATE, device-side wait for gather i, control step + command on `stream`)
+ *     ndp_xchg_tick_begin(tick i+1: d_t / flags as ndp_tick_advance_device takes them -- the NEXT period's trajectory time; NULL: no advance)
+ * and one ndp_xchg_tick_begin in front of the first step.  Ordering is the library's (events on the device, nothing waits on the host);
+ * with ndp_track_steps the gather waits for exactly the control step that read its buffer last.  Needs a list with >= 2 entries per
+ * node spacing (the reference: 5), else -17: the serial form above serves.  Same results as the serial form and the one-handle tick. */
+int ndp_xchg_tick_begin(ndp_xchg *x, ndp_handle *h, const void *d_t, int flags, void *d_gathered_next);
+int ndp_xchg_tick_step(ndp_xchg *x, ndp_handle *h, const void *d_x_odom, const void *d_vz, const void *d_throttle, int flags,
+                       void *d_cmd, void *d_u0, const void *d_gathered, void *stream);
 const char *ndp_xchg_last_error(const ndp_xchg *x);
 int ndp_xchg_destroy(ndp_xchg *x);
 

@@ -1639,6 +1639,10 @@ struct TickPre {
     size_t vz_pitch;
     const double *throttle;            // [B]: the thrust command sent last tick (caller's array, or the one the control step kept)
     int est;                           // run the estimator this tick
+    // ndp_xchg_tick_begin: the advanced window's position / velocity columns -> pv[b][N+1][6] in the same launch (one launch less on a
+    // path that is bound by the host's launches); the window starts at list slot pv_slot, its node N is the point made here
+    double *pv = nullptr;
+    size_t pv_slot = 0;
 };
 
 __global__ __launch_bounds__(64) void tick_pre_kernel(TickPre a)
@@ -1649,8 +1653,21 @@ __global__ __launch_bounds__(64) void tick_pre_kernel(TickPre a)
     if (a.est) { vzv = a.vz[(size_t)b * a.vz_pitch]; th = a.throttle[b]; }      // (requested before the polynomial work)
     if (a.advance) {
         double xv[10], uv[4];
+        const int N = a.rg.np1 - 1;
+        const double2 *src = reinterpret_cast<const double2 *>(a.rx + (size_t)b * a.rg.px() + a.pv_slot * 10);
+        double2 *dst = reinterpret_cast<double2 *>(a.pv) + (size_t)b * a.rg.np1 * 3;
+        if (a.pv) {                    // nodes 0 .. N-1 lie in the list since earlier ticks: copied under the polynomial work
+#pragma unroll 4
+            for (int k = 0; k < N; ++k) {
+                const double2 v0 = src[k * 5], v1 = src[k * 5 + 1], v2 = src[k * 5 + 2];
+                dst[k * 3] = v0; dst[k * 3 + 1] = v1; dst[k * 3 + 2] = v2;
+            }
+        }
         ref_point(a.cf, a.coeff, a.tcum, a.tseg, a.fpt, b, (a.t ? a.t[b] : a.t_all) + a.cf.toff, xv, uv, a.seg_hint);
         ring_store(a.rg, a.rx, a.ru, b, a.j_new, xv, uv);
+        if (a.pv) {                    // node N: the point itself (not read back)
+            dst[N * 3] = make_double2(xv[0], xv[1]); dst[N * 3 + 1] = make_double2(xv[2], xv[3]); dst[N * 3 + 2] = make_double2(xv[4], xv[5]);
+        }
     }
     if (a.est) (void)throttle_update_one(a.thr, a.st, (size_t)a.cf.B, b, vzv, th);
 }
@@ -2158,6 +2175,7 @@ struct ndp_handle {
     // completion signal, hipExtLaunchKernel) -- what another stream orders itself behind (ndp_xchg_begin's after_event)
     bool track_steps = false;
     bool last_step_tracked = false;   // does stepDone[step_seq & 3] belong to the control step launched LAST?
+    bool track_pending = false;       // a tracked step on a caller's stream has not been waited for (wait_all)
     hipEvent_t stepDone[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned step_seq = 0;
     double host_us[4] = {0, 0, 0, 0};   // last host step: packing | enqueue | wait for the results | copy-out  (ndp_debug_host_timing)
@@ -2440,6 +2458,14 @@ struct ndp_xchg {
     hipEvent_t evReady = nullptr, evDone = nullptr;
     double *send = nullptr;                   // packed windows of this rank
     size_t send_doubles = 0;
+    // the remote tick one control period ahead (ndp_xchg_tick_begin / _step): two gather buffers, alternating
+    hipEvent_t evGather[2] = {nullptr, nullptr};     // buffer p's gather is complete
+    unsigned long long win_n[2] = {0, 0};            // the list position its windows belong to
+    unsigned reader_seq[2] = {0, 0};                 // the tracked control step that read buffer p last (ndp_handle::step_seq), 0 = none
+    hipStream_t reader_stream[2] = {nullptr, nullptr};
+    bool has_reader[2] = {false, false};
+    int begin_par = 0, step_par = 0;                 // the buffer the next begin fills / the next step reads
+    int ahead = 0;                                   // gathers begun and not yet stepped on (0 .. 2)
     std::string err;
 };
 
@@ -2472,7 +2498,9 @@ int ndp_xchg_create(int device, int rank, int world, const unsigned char *id128,
     int lo = 0, hi = 0;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&x->cs, hipStreamNonBlocking, hi) != hipSuccess ||
         hipEventCreateWithFlags(&x->evReady, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&x->evDone, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&x->evDone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&x->evGather[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&x->evGather[1], hipEventDisableTiming) != hipSuccess) {
         (void)ndp_xchg_destroy(x.release());      // (releases whatever exists: communicator, stream, events)
         return -3;
     }
@@ -2537,6 +2565,7 @@ int ndp_xchg_destroy(ndp_xchg *x)
     if (x->send) (void)hipFree(x->send);
     if (x->evReady) (void)hipEventDestroy(x->evReady);
     if (x->evDone) (void)hipEventDestroy(x->evDone);
+    for (hipEvent_t e : x->evGather) if (e) (void)hipEventDestroy(e);
     if (x->cs) (void)hipStreamDestroy(x->cs);
     delete x;
     return 0;
@@ -2794,6 +2823,10 @@ static int wait_all(ndp_handle *h)
     if (h->ev_pending) {
         NDP_HIP(h, hipEventSynchronize(h->evLast));
         h->ev_pending = false;
+    }
+    if (h->track_pending) {            // tracked control steps on a caller's stream (ndp_xchg_tick_step): the last one's completion event
+        if (h->stepDone[h->step_seq & 3]) NDP_HIP(h, hipEventSynchronize(h->stepDone[h->step_seq & 3]));
+        h->track_pending = false;
     }
     return 0;
 }
@@ -4107,25 +4140,138 @@ int ndp_xchg_tick_windows(ndp_xchg *x, ndp_handle *h, void *d_gathered, void *st
     return note_stream(h, s);
 }
 
+// stage 3 on `s` (h->mu held): the control step of the window at list position `pos`, neighbour rows out of `windows`
+static int tick_step_enqueue(ndp_handle *h, hipStream_t s, const double *x_odom, double *cmd, double *u0, const double *windows, unsigned long long pos)
+{
+    if (!h->tick_remote) { h->err = "ndp_tick_step: ndp_tick_config_remote first (neighbours in the same handle: ndp_tick_device)"; return -17; }
+    if (!h->dRingX) { h->err = "ndp_tick_step: no reference list"; return -11; }
+    const RingGeom rg = ring_geom(h);
+    const size_t slot = rg.slot(pos), B = h->cfg.batch;
+    Neigh nb;
+    nb.other = windows; nb.stride = h->tick_remote_stride; nb.index = h->dTickIndex;
+    if (h->tick_gate) { nb.ego_xy = x_odom; nb.ego_pitch = NX; }
+    StepOut so;
+    so.xr_pitch = rg.px(); so.ur_pitch = rg.pu();
+    so.cmd = cmd; so.kthr = h->dThr + B; so.thrust_keep = h->dTickThrust;
+    return enqueue_step(h, x_odom, h->dRingX + slot * 10, h->dRingU + slot * 4, nullptr, nb, u0 ? u0 : h->su0, nullptr, s, &so);
+}
+
 int ndp_tick_step_device(ndp_handle *h, const void *d_x_odom, void *d_cmd, void *d_u0, void *stream)
 {
     if (!h || !d_x_odom || !d_cmd) return -1;
     std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     NDP_HIP(h, hipSetDevice(h->cfg.device));
-    if (!h->tick_remote) { h->err = "ndp_tick_step: ndp_tick_config_remote first (neighbours in the same handle: ndp_tick_device)"; return -17; }
-    if (!h->dRingX) { h->err = "ndp_tick_step: no reference list"; return -11; }
-    const RingGeom rg = ring_geom(h);
-    const size_t slot = rg.slot(h->list_n), B = h->cfg.batch;
-    const double *x_odom = (const double *)d_x_odom;
-    Neigh nb;
-    nb.other = h->tick_remote; nb.stride = h->tick_remote_stride; nb.index = h->dTickIndex;
-    if (h->tick_gate) { nb.ego_xy = x_odom; nb.ego_pitch = NX; }
-    StepOut so;
-    so.xr_pitch = rg.px(); so.ur_pitch = rg.pu();
-    so.cmd = (double *)d_cmd; so.kthr = h->dThr + B; so.thrust_keep = h->dTickThrust;
-    int rc = enqueue_step(h, x_odom, h->dRingX + slot * 10, h->dRingU + slot * 4, nullptr, nb, d_u0 ? (double *)d_u0 : h->su0, nullptr, s, &so);
+    int rc = tick_step_enqueue(h, s, (const double *)d_x_odom, (double *)d_cmd, (double *)d_u0, h->tick_remote, h->list_n);
     return rc ? rc : note_stream(h, s);
+}
+
+// ---- the remote tick with the exchange ONE CONTROL PERIOD AHEAD.  A vehicle's window is a function of time alone (the list advance
+// reads the trajectory, not the odometry): the list advance of tick i+1, its window columns and their all-gather run on the exchange's
+// own stream BESIDE the control step of tick i, into the other one of two gather buffers.  Per control period
+//     ndp_xchg_tick_step(tick i: estimator, wait for gather i on the device, control step)   then   ndp_xchg_tick_begin(tick i+1)
+// (one begin in front of the first step).  What orders what:
+//   gather i+1 writes the buffer step i-1 read      -> the exchange stream waits for that step's completion event (ndp_track_steps: it
+//                                                      rides on the step's dispatch packet; untracked: for everything its stream holds)
+//   advance i+1 writes list entries                  -> of another phase row than window i's (RingGeom: entries per node spacing >= 2,
+//                                                      refused otherwise), so it may run beside step i
+//   step i reads window i and gather buffer i        -> its stream waits for evGather[i & 1], recorded behind advance i, pack, gather
+//   the estimator reads the thrust step i-1 commanded -> same stream as the steps, in front of step i
+int ndp_xchg_tick_begin(ndp_xchg *x, ndp_handle *h, const void *d_t, int flags, void *d_gathered)
+{
+    if (!x || !h || !d_gathered) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (x->device != h->cfg.device) { h->err = "ndp_xchg_tick_begin: the exchange and the handle live on different devices"; return -1; }
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_tick(h);
+    if (rc) return rc;
+    if (!h->dRingX) { h->err = "ndp_xchg_tick_begin: no reference list"; return -11; }
+    if (d_t && !h->dTraj) { h->err = "ndp_xchg_tick_begin: a trajectory time was given but ndp_ref_set_trajectory was never called"; return -11; }
+    if (x->ahead >= 2) { h->err = "ndp_xchg_tick_begin: two gathers are already ahead of the control steps (ndp_xchg_tick_step first)"; return -14; }
+    const RingGeom rg = ring_geom(h);
+    if (d_t && rg.step < 2) { h->err = "ndp_xchg_tick_begin: the list's entries are one node spacing apart -- the advance would overwrite the window a control step may be reading (use the serial form: ndp_tick_advance_device, ndp_xchg_tick_windows, ndp_tick_step_device)"; return -17; }
+    const int p = x->begin_par;
+    const size_t B = h->cfg.batch, rows = B * (size_t)(h->cfg.N + 1), n = rows * 3;
+    if (x->send_doubles < rows * 6) {
+        if (x->send) { (void)hipStreamSynchronize(x->cs); (void)hipFree(x->send); x->send = nullptr; }
+        NDP_HIP(h, hipMalloc((void **)&x->send, rows * 6 * sizeof(double)));
+        x->send_doubles = rows * 6;
+    }
+    if (x->has_reader[p]) {
+        const bool precise = h->track_steps && x->reader_seq[p] && h->step_seq - x->reader_seq[p] < 4u;
+        if (precise) NDP_HIP(h, hipStreamWaitEvent(x->cs, h->stepDone[x->reader_seq[p] & 3], 0));
+        else {
+            NDP_HIP(h, hipEventRecord(x->evReady, x->reader_stream[p]));
+            NDP_HIP(h, hipStreamWaitEvent(x->cs, x->evReady, 0));
+        }
+    } else {            // the first gathers: behind whatever made the list (ndp_ref_list_reset / ndp_tick_reset on the handle's stream)
+        NDP_HIP(h, hipEventRecord(x->evReady, h->stream));
+        NDP_HIP(h, hipStreamWaitEvent(x->cs, x->evReady, 0));
+    }
+    if (d_t) {
+        const bool uni = (flags & TICK_T_UNIFORM) != 0;
+        TickPre a{};
+        a.cf = ref_cfg(h, h->cfg.N * h->cfg.dt);
+        const size_t Bs = B, S = (size_t)h->traj_seg;
+        a.coeff = h->dTraj; a.tcum = a.coeff + Bs * S * 28; a.tseg = a.tcum + Bs * (S + 1); a.fpt = a.tseg + Bs * S;
+        a.seg_hint = reinterpret_cast<int *>(const_cast<double *>(a.fpt + Bs * 3 + Bs * SEGC_PER));
+        a.t = uni ? nullptr : (const double *)d_t; a.t_all = uni ? *(const double *)d_t : 0.0; a.advance = 1;
+        a.j_new = h->list_n + (unsigned long long)rg.ring();
+        a.rg = rg; a.rx = h->dRingX; a.ru = h->dRingU;
+        a.thr = thr_cfg(h); a.st = h->dThr;
+        a.vz = h->dTickThrust; a.vz_pitch = 1; a.throttle = h->dTickThrust; a.est = 0;      // (no estimator here: it belongs to the step's side)
+        a.pv = x->send; a.pv_slot = rg.slot(h->list_n + 1);                                 // ... and the advanced window's columns in the same launch
+        hipLaunchKernelGGL(tick_pre_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, x->cs, a);
+        NDP_HIP(h, hipGetLastError());
+        ++h->list_n;
+    } else {
+        hipLaunchKernelGGL(pack_pv_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, x->cs, h->dRingX + rg.slot(h->list_n) * 10, rg.px(),
+                           h->cfg.N + 1, x->send, B);
+        NDP_HIP(h, hipGetLastError());
+    }
+    const int r = g_rccl.allgather(x->send, d_gathered, rows * 6, /* ncclFloat64 */ 8, x->comm, x->cs);
+    if (r != 0) { x->err = g_rccl.errstr ? g_rccl.errstr(r) : "ncclAllGather failed"; h->err = "ndp_xchg_tick_begin: " + x->err; return -22; }
+    NDP_HIP(h, hipEventRecord(x->evGather[p], x->cs));
+    x->win_n[p] = h->list_n;
+    x->begin_par ^= 1;
+    ++x->ahead;
+    return 0;
+}
+
+int ndp_xchg_tick_step(ndp_xchg *x, ndp_handle *h, const void *d_x_odom, const void *d_vz, const void *d_throttle, int flags,
+                       void *d_cmd, void *d_u0, const void *d_gathered, void *stream)
+{
+    if (!x || !h || !d_x_odom || !d_cmd || !d_gathered) return -1;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    NDP_HIP(h, hipSetDevice(h->cfg.device));
+    if (x->ahead < 1) { h->err = "ndp_xchg_tick_step: no gather was begun for this tick (ndp_xchg_tick_begin first)"; return -14; }
+    int rc = ensure_tick(h);
+    if (rc) return rc;
+    const size_t B = h->cfg.batch;
+    const int p = x->step_par;
+    if (flags & TICK_ESTIMATE) {
+        TickPre a{};
+        a.cf = ref_cfg(h, h->cfg.N * h->cfg.dt);
+        a.advance = 0;
+        a.rg = ring_geom(h); a.rx = h->dRingX; a.ru = h->dRingU;
+        a.thr = thr_cfg(h); a.st = h->dThr;
+        a.vz = d_vz ? (const double *)d_vz : (const double *)d_x_odom + 5; a.vz_pitch = d_vz ? 1 : NX;
+        a.throttle = d_throttle ? (const double *)d_throttle : h->dTickThrust;
+        a.est = 1;
+        hipLaunchKernelGGL(tick_pre_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, a);
+        NDP_HIP(h, hipGetLastError());
+    }
+    NDP_HIP(h, hipStreamWaitEvent(s, x->evGather[p], 0));
+    rc = tick_step_enqueue(h, s, (const double *)d_x_odom, (double *)d_cmd, (double *)d_u0, (const double *)d_gathered, x->win_n[p]);
+    if (rc) return rc;
+    x->has_reader[p] = true;
+    x->reader_stream[p] = s;
+    x->reader_seq[p] = (h->track_steps && h->last_step_tracked) ? h->step_seq : 0u;
+    x->step_par ^= 1;
+    --x->ahead;
+    if (x->reader_seq[p]) { h->track_pending = true; return 0; }     // (the getters wait for the step's own completion event: no second one)
+    return note_stream(h, s);
 }
 
 int ndp_tick_device(ndp_handle *h, const void *d_x_odom, const void *d_t, const void *d_vz, const void *d_throttle, int flags,

@@ -298,6 +298,37 @@ class RcclExchange:
         if rc:
             raise RuntimeError(f"ndp_xchg_tick_windows failed ({rc}): {self._lib.ndp_xchg_last_error(self._h).decode()}")
 
+    def tick_begin(self, eng, gathered_next, t=None):
+        """The remote tick one control period ahead: list advance to the NEXT period's trajectory time t (scalar, CUDA tensor [B] or None:
+        no advance), window columns, all-gather into `gathered_next` -- on the exchange's own stream, beside the control step of the
+        current tick (ndp_xchg_tick_begin)."""
+        import ctypes as C
+        import numpy as np
+        import torch
+        from . import _lib
+        flags = 0
+        if t is None:
+            tp = None
+        elif isinstance(t, torch.Tensor):
+            tp = C.c_void_p(t.data_ptr())
+        else:
+            self._t_host = np.array([float(t)])
+            tp, flags = _lib.ptr(self._t_host), _lib.TICK_T_UNIFORM
+        rc = self._lib.ndp_xchg_tick_begin(self._h, eng._h, tp, flags, C.c_void_p(gathered_next.data_ptr()))
+        if rc:
+            raise RuntimeError(f"ndp_xchg_tick_begin failed ({rc}): {eng._lib.ndp_last_error(eng._h).decode()}")
+
+    def tick_step(self, eng, x_odom, cmd_out, gathered, stream=None, estimate=False, u0_out=None):
+        """... and the tick itself: estimator (optional), device-side wait for `gathered`'s all-gather, control step + actuator command on
+        `stream` (ndp_xchg_tick_step)."""
+        import ctypes as C
+        from . import _lib
+        rc = self._lib.ndp_xchg_tick_step(self._h, eng._h, C.c_void_p(x_odom.data_ptr()), None, None, _lib.TICK_ESTIMATE if estimate else 0,
+                                          C.c_void_p(cmd_out.data_ptr()), C.c_void_p(u0_out.data_ptr()) if u0_out is not None else None,
+                                          C.c_void_p(gathered.data_ptr()), C.c_void_p(stream.cuda_stream) if stream is not None else None)
+        if rc:
+            raise RuntimeError(f"ndp_xchg_tick_step failed ({rc}): {eng._lib.ndp_last_error(eng._h).decode()}")
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.ndp_xchg_destroy(self._h)

@@ -25,6 +25,7 @@ from ndp_nmpc_qd_amd import dist as ndist
 out = {"torch_collective": bench.tick_remote_ranks(ndp, synth, dist, torch, 1024, 20, 0, 1, 0, dev, dev, stream, False, n_ticks=300)}
 x = ndist.RcclExchange(1024, 20, 0)
 out["library_collective"] = bench.tick_remote_ranks(ndp, synth, dist, torch, 1024, 20, 0, 1, 0, dev, dev, stream, False, n_ticks=300, xchg=x)
+out["library_collective_one_period_ahead"] = bench.tick_remote_ranks(ndp, synth, dist, torch, 1024, 20, 0, 1, 0, dev, dev, stream, False, n_ticks=300, xchg=x, ahead=True)
 x.close()
 print(json.dumps(bench.compact(out)))
 dist.destroy_process_group()

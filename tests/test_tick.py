@@ -643,3 +643,75 @@ def test_tick_windows_through_the_library_collective_equals_the_single_handle_ti
         n_force += int(np.any(one.device_force().cpu().numpy() != 0.0, axis=(1, 2)).sum())
     assert n_force > 12 * B // 4
     ex.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tracked", [True, False])
+def test_remote_tick_with_the_exchange_one_period_ahead_equals_the_single_handle_tick(tracked):
+    """ndp_xchg_tick_begin / _step: the list advance, window columns and all-gather of tick i+1 on the exchange's stream beside the
+    control step of tick i (two gather buffers), ordered by events on the device -- with tracked steps the gather waits for exactly the
+    step that read its buffer last, without them for that step's stream.  One-rank communicator (a real ncclAllGather).  Bit-equal with
+    the one-launch tick of one handle over 14 ticks, estimator on every tick; the protocol's misuse is refused."""
+    import torch
+    import ndp_nmpc_qd_amd as ndp
+    from ndp_nmpc_qd_amd import dist as ndist
+    dev = torch.device("cuda", 0)
+    B = 128
+    tr = synth.figure_eight_traj(B, seed=11, n_seg=16, t_seg=0.25, pairs=True)
+    oi = (np.arange(B) ^ 1).astype(np.int32)
+
+    def make():
+        e = ndp.BatchedNMPC(B, disturbance=True)
+        e.ref_set_trajectory(*(tr[k] for k in ("coeff_x", "coeff_y", "coeff_z", "coeff_yaw", "time_cum", "time_seg", "final_pt")))
+        e.ref_list_reset()
+        e.throttle_reset()
+        return e
+    one, rem = make(), make()
+    one.tick_config(oi, gate=True)
+    one.tick_reset()
+    gathered = [torch.zeros(B, 21, 6, dtype=torch.float64, device=dev) for _ in range(2)]
+    rem.tick_config_remote(gathered[0], oi, gate=True)
+    rem.tick_reset()
+    if tracked:
+        rem.track_steps(True)
+    try:
+        ex = ndist.RcclExchange(B, 20, 0)
+    except RuntimeError as e:
+        pytest.skip(f"RCCL could not be bound: {e}")
+    stream = torch.cuda.Stream(device=dev)
+    cmd1, u1 = torch.empty(B, 4, dtype=torch.float64, device=dev), torch.empty(B, 4, dtype=torch.float64, device=dev)
+    cmd2 = [torch.empty(B, 4, dtype=torch.float64, device=dev) for _ in range(14)]
+    u2 = [torch.empty(B, 4, dtype=torch.float64, device=dev) for _ in range(14)]
+    rng = np.random.default_rng(6)
+    n = 14
+    with pytest.raises(RuntimeError, match="no gather was begun"):
+        ex.tick_step(rem, torch.zeros(B, 10, dtype=torch.float64, device=dev), cmd1, gathered[0], stream)
+    # the odometry of every tick up front (the one-handle engine's windows: the same list)
+    xs, ref1 = [], []
+    for i in range(n):
+        t = 0.02 * (i + 1)
+        xr, _ = one.ref_list_window(None)
+        x0 = xr[:, 1, :].copy()
+        x0[:, 0:3] += rng.normal(0.0, 0.03, size=(B, 3))
+        x0_t = torch.from_numpy(x0).to(dev)
+        xs.append(x0_t)
+        one.tick_device(x0_t, cmd1, t=t, estimate=True, u0_out=u1)
+        torch.cuda.synchronize()
+        ref1.append((cmd1.clone(), u1.clone(), one.device_force().clone()))
+    # the pipelined remote form: no host synchronisation inside the loop; tick i's trajectory time is 0.02 (i + 1)
+    ex.tick_begin(rem, gathered[0], t=0.02)
+    for i in range(n):
+        ex.tick_step(rem, xs[i], cmd2[i], gathered[i % 2], stream, estimate=True, u0_out=u2[i])
+        if i + 1 < n:
+            ex.tick_begin(rem, gathered[(i + 1) % 2], t=0.02 * (i + 2))
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert torch.equal(cmd2[i], ref1[i][0]) and torch.equal(u2[i], ref1[i][1]), i
+    assert np.array_equal(rem.throttle_state(), one.throttle_state())
+    # two gathers may be ahead of the steps, not three
+    ex.tick_begin(rem, gathered[0], t=None)
+    ex.tick_begin(rem, gathered[1], t=None)
+    with pytest.raises(RuntimeError, match="already ahead"):
+        ex.tick_begin(rem, gathered[0], t=None)
+    torch.cuda.synchronize()
+    ex.close()
