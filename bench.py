@@ -862,7 +862,7 @@ def main():
         # all-gather per step); the N = 1 headline above replays a hipGraph with no exchange at all.  The same steps are therefore
         # ALSO run here in exactly the N > 1 form -- a one-rank communicator, the pack + ncclAllGather on the library's stream per
         # step, host-launched and captured -- and reported as `scaling_baseline`: efficiency = value(N) / (N * scaling_baseline).
-        if not args.only_timed and not same_dev:
+        if not args.only_timed and not same_dev and args.perturb == "nominal":       # (the exchange forms gather the ranks' OWN reference windows: make_formation_shard's workload)
             baseline_modes = ((list(rccl_modes) if args.exchange in ("both", "rccl") else []) + (["peer"] if args.exchange in ("both", "peer") else [])
                               + (["peer_ahead"] if args.exchange == "peer_ahead" else []))
             modes = modes + baseline_modes
