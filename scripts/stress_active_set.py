@@ -18,6 +18,7 @@ ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 N = int(sys.argv[4]) if len(sys.argv) > 4 else 20          # 40: the five-slot kernels (config 5's shape), the kept set parked in LDS
 NRTI = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+WQ = {"auto": None, "on": 1, "off": 2}[sys.argv[6] if len(sys.argv) > 6 else "auto"]      # the work list (producer / consumer launches) forced on / off
 WORK = {"mixed": dict(pos_sigma=0.5, vel_sigma=1.0, quat_sigma=0.15), "hard": dict(pos_sigma=1.5, vel_sigma=3.0, quat_sigma=0.2),
         "fast": dict(pos_sigma=0.8, vel_sigma=1.5, quat_sigma=0.25, omega_range=(1.5, 2.5))}
 blob = np.fromfile("ndp_nmpc_qd_amd/weights/downwash_sn4.bin", dtype="<f4")
@@ -26,7 +27,7 @@ for seed in range(n_seed):
     for name, kw in WORK.items():
         for dw in (False, True):
             b = synth.make_batch(B, N=N, seed=1000 + seed, downwash=dw, **kw)
-            eng = ndp.BatchedNMPC(B, N=N, n_rti=NRTI, disturbance=dw)
+            eng = ndp.BatchedNMPC(B, N=N, n_rti=NRTI, disturbance=dw, **({} if WQ is None else {"work_queue": WQ}))
             eng.reset(b["xr"], b["ur"])
             twin = O.default_cfg(N=N, n_rti=NRTI, use_fd=dw)
             twin.qp_mode = 0
