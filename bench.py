@@ -517,7 +517,8 @@ def tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, de
         e.ref_set_trajectory(tr["coeff_x"], tr["coeff_y"], tr["coeff_z"], tr["coeff_yaw"], tr["time_cum"], tr["time_seg"], tr["final_pt"])
         e.ref_list_reset()
         gathered = torch.zeros(world * B, N + 1, 6, dtype=torch.float64, device=dev)
-        gathered_b = torch.zeros(world * B, N + 1, 6, dtype=torch.float64, device=dev)      # (ahead: the second gather buffer)
+        gathered_b = torch.zeros(world * B, N + 1, 6, dtype=torch.float64, device=dev)      # (ahead: the second and third gather buffers)
+        gathered_c = torch.zeros(world * B, N + 1, 6, dtype=torch.float64, device=dev)
         pv = torch.zeros(B, N + 1, 6, dtype=torch.float64, device=dev)
         nbr = (rank + 1) % world
         oi = (nbr * B + (np.arange(B, dtype=np.int64) ^ 1)).astype(np.int32)
@@ -567,16 +568,17 @@ def tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, de
                 dist.all_gather_into_tensor(gathered, pv)             # RCCL on torch's current stream = `stream`
 
     ahead = bool(ahead and xh is not None)
-    gps = [gp, C.c_void_p(gathered_b.data_ptr())]
-    gts = [gathered, gathered_b]
+    gps = [gp, C.c_void_p(gathered_b.data_ptr()), C.c_void_p(gathered_c.data_ptr())]
+    gts = [gathered, gathered_b, gathered_c]
 
     def tick(i, last=False):
         nonlocal rcs
-        if ahead:               # tick i's gather was begun one tick ago (the first: below); tick i + 1's is begun behind tick i's step
-            rcs |= L.ndp_xchg_tick_step(xh, h, xp[i], None, None, 0, cp, up, gps[i % 2], sp)
-            if not last:
-                tv.value = 0.02 * (i + 1)
-                rcs |= L.ndp_xchg_tick_begin(xh, h, tp, UNI, gps[(i + 1) % 2])
+        if ahead:               # tick i's gather was begun two ticks ago (the first two: below); tick i + 2's is begun behind tick i's step,
+            #                     into the third buffer -- the one step i - 1 read: that gather never waits for a control step
+            rcs |= L.ndp_xchg_tick_step(xh, h, xp[i], None, None, 0, cp, up, gps[i % 3], sp)
+            if i + 2 < nt:
+                tv.value = 0.02 * (i + 2)
+                rcs |= L.ndp_xchg_tick_begin(xh, h, tp, UNI, gps[(i + 2) % 3])
             return
         tv.value = 0.02 * i
         rcs |= L.ndp_tick_advance_device(h, xp[i], tp, None, None, UNI, sp)
@@ -588,6 +590,8 @@ def tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, de
         rcs |= L.ndp_track_steps(h, 1)
         tv.value = 0.0
         rcs |= L.ndp_xchg_tick_begin(xh, h, tp, UNI, gps[0])
+        tv.value = 0.02
+        rcs |= L.ndp_xchg_tick_begin(xh, h, tp, UNI, gps[1])
     for i in range(n_warm):
         tick(i)
     torch.cuda.synchronize()
@@ -605,7 +609,7 @@ def tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, de
     i = n_warm + n_ticks
     tick(i, last=True)
     torch.cuda.synchronize()
-    g = gts[i % 2 if ahead else 0].cpu().numpy()
+    g = gts[i % 3 if ahead else 0].cpu().numpy()
     rcs |= L.ndp_tick_window_pv_device(h, pp, sp)                   # (this rank's own columns, for the comparison below)
     torch.cuda.synchronize()
     rows_ok = bool(np.array_equal(g[nbr * B:(nbr + 1) * B], pv.cpu().numpy())) and bool(np.any(g[nbr * B:(nbr + 1) * B] != 0))
@@ -629,7 +633,7 @@ def tick_remote_ranks(ndp, synth, dist, torch, B, N, rank, world, local_rank, de
     elapsed = float(el.item())
     res.update({"value": world * B * n_ticks / elapsed, "us": elapsed / n_ticks * 1e6, "unit": "solves/s", "ticks": n_ticks,
                 "launches_per_tick": 3 if xh is None else 2,
-                "gather": ("ndp_xchg_tick_begin / _step: advance, columns and ncclAllGather of tick i + 1 on the exchange's stream beside tick i's control step" if ahead else
+                "gather": ("ndp_xchg_tick_begin / _step: advance, columns and ncclAllGather of tick i + 2 on the exchange's stream beside the control steps of ticks i, i + 1; three gather buffers" if ahead else
                            "ndp_xchg_tick_windows (pack + ncclAllGather on the tick's stream)" if xh is not None else
                            "host-staged (gloo, one device)" if same_dev else "torch.distributed all_gather_into_tensor (RCCL)"),
                 "parity": par, "bad": int(agg[0].item()), "rows_ok": int(agg[1].item()) == 0})

@@ -488,15 +488,22 @@ int ndp_xchg_tick(ndp_xchg *x, ndp_handle *h, void *stream, const void *d_xr_nex
  * ndp_tick_step_device by stream order alone.  Replaces, on the reference's side, the publish of PredXU per control period
  * (nmpc_node.py:229-230) and its subscription in the neighbour's node (ndp_nmpc_leader_node.py:40,60-76). */
 int ndp_xchg_tick_windows(ndp_xchg *x, ndp_handle *h, void *d_gathered, void *stream);
-/* The same tick with the exchange ONE CONTROL PERIOD AHEAD: a window is a function of time alone, so the list advance of tick i+1, its
- * window columns and their all-gather run on the exchange's own stream BESIDE the control step of tick i, into the other one of TWO
- * gather buffers (both [world * B][N+1][6]; ndp_tick_config_remote names either: the step is told which one it reads).  Per period:
+/* The same tick with the exchange AHEAD of the control steps: a window is a function of time alone, so the list advance of a later tick,
+ * its window columns and their all-gather run on the exchange's own stream BESIDE the control steps, into one of TWO or THREE gather
+ * buffers the caller cycles through (each [world * B][N+1][6]; ndp_tick_config_remote names any: the step is told which one it reads).
+ * Begins and steps pair up in order (step k reads what begin k gathered); at most two begins may be ahead.  Per period, two buffers:
  *     ndp_xchg_tick_step (tick i: estimator if NDP_TICK_ESTIMATE, device-side wait for gather i, control step + command on `stream`)
- *     ndp_xchg_tick_begin(tick i+1: d_t / flags as ndp_tick_advance_device takes them -- the NEXT period's trajectory time; NULL: no advance)
- * and one ndp_xchg_tick_begin in front of the first step.  Ordering is the library's (events on the device, nothing waits on the host);
+ *     ndp_xchg_tick_begin(tick i+1: d_t / flags as ndp_tick_advance_device takes them -- THAT period's trajectory time; NULL: no advance)
+ * with one begin in front of the first step; three buffers: step(i) then begin(i+2), two begins in front -- the gather then fills a
+ * buffer whose last reader is long over and never waits for a control step (38.3 against 34.9 M solves/s on one rank).  Ordering is the library's (events on the device, nothing waits on the host);
  * with ndp_track_steps the gather waits for exactly the control step that read its buffer last.  Needs a list with >= 2 entries per
  * node spacing (the reference: 5), else -17: the serial form above serves.  Same results as the serial form and the one-handle tick. */
 int ndp_xchg_tick_begin(ndp_xchg *x, ndp_handle *h, const void *d_t, int flags, void *d_gathered_next);
+/* on = 1: a begin's launches on the exchange's stream (event wait, advance + columns, ncclAllGather, event record: ~15 us of host time)
+ * are made by a thread the exchange owns; ndp_xchg_tick_begin then only describes them (~2 us) and ndp_xchg_tick_step waits until its
+ * tick's have been made.  One host thread's launches are what bounds the remote tick one period ahead; with two the device does.  Errors
+ * of that thread surface at the next begin / step.  Switch only with no gather ahead (-14 otherwise); off (the default) = the caller's thread. */
+int ndp_xchg_tick_async(ndp_xchg *x, int on);
 int ndp_xchg_tick_step(ndp_xchg *x, ndp_handle *h, const void *d_x_odom, const void *d_vz, const void *d_throttle, int flags,
                        void *d_cmd, void *d_u0, const void *d_gathered, void *stream);
 const char *ndp_xchg_last_error(const ndp_xchg *x);

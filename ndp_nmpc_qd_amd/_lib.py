@@ -52,7 +52,7 @@ EXPORTS = [
     "ndp_xchg_unique_id", "ndp_xchg_create", "ndp_xchg_begin", "ndp_xchg_end", "ndp_xchg_tick", "ndp_xchg_last_error", "ndp_xchg_destroy",
     "ndp_abi_version", "ndp_cfg_size",
     "ndp_step_ex_f64", "ndp_refine_active", "ndp_get_active_set", "ndp_set_active_set", "ndp_debug_host_info", "ndp_tick_config", "ndp_tick_reset", "ndp_tick_begin", "ndp_tick_end", "ndp_tick", "ndp_tick_device",
-    "ndp_tick_config_remote", "ndp_tick_advance_device", "ndp_tick_window_pv_device", "ndp_tick_step_device", "ndp_xchg_tick_windows", "ndp_xchg_tick_begin", "ndp_xchg_tick_step",
+    "ndp_tick_config_remote", "ndp_tick_advance_device", "ndp_tick_window_pv_device", "ndp_tick_step_device", "ndp_xchg_tick_windows", "ndp_xchg_tick_begin", "ndp_xchg_tick_step", "ndp_xchg_tick_async",
 ]
 
 _lib = None
@@ -120,6 +120,7 @@ def load():
     lib.ndp_tick_step_device.argtypes = [vp] * 5
     lib.ndp_xchg_tick_windows.argtypes = [vp] * 4
     lib.ndp_xchg_tick_begin.argtypes = [vp, vp, vp, C.c_int, vp]
+    lib.ndp_xchg_tick_async.argtypes = [vp, C.c_int]
     lib.ndp_xchg_tick_step.argtypes = [vp] * 5 + [C.c_int] + [vp] * 4
     lib.ndp_get_active_set.argtypes = [vp] * 3
     lib.ndp_set_active_set.argtypes = [vp] * 2

@@ -2458,14 +2458,35 @@ struct ndp_xchg {
     hipEvent_t evReady = nullptr, evDone = nullptr;
     double *send = nullptr;                   // packed windows of this rank
     size_t send_doubles = 0;
-    // the remote tick one control period ahead (ndp_xchg_tick_begin / _step): two gather buffers, alternating
-    hipEvent_t evGather[2] = {nullptr, nullptr};     // buffer p's gather is complete
-    unsigned long long win_n[2] = {0, 0};            // the list position its windows belong to
-    unsigned reader_seq[2] = {0, 0};                 // the tracked control step that read buffer p last (ndp_handle::step_seq), 0 = none
-    hipStream_t reader_stream[2] = {nullptr, nullptr};
-    bool has_reader[2] = {false, false};
-    int begin_par = 0, step_par = 0;                 // the buffer the next begin fills / the next step reads
+    // the remote tick with the exchange ahead of the control steps (ndp_xchg_tick_begin / _step): begins are numbered 1, 2, ...; begin n
+    // lives in slot n % 3 (at most two are ahead of the steps, and step k consumes begin k) and fills whichever gather buffer the
+    // caller names -- two buffers (begin i+1 behind step i) or three (begin i+2 behind step i: the gather then never waits for a step)
+    hipEvent_t evGather[3] = {nullptr, nullptr, nullptr};     // slot's gather is complete
+    unsigned long long win_n[3] = {0, 0, 0};         // the list position its windows belong to
+    const void *buf[3] = {nullptr, nullptr, nullptr};   // the gather buffer it fills
+    struct Reader { const void *ptr = nullptr; unsigned seq = 0; hipStream_t stream = nullptr; unsigned age = 0; };
+    Reader readers[4];                               // per gather buffer: the control step that read it last (seq: its tracked number, 0 = untracked)
+    unsigned steps = 0;                              // control steps taken (step k consumes begin k)
     int ahead = 0;                                   // gathers begun and not yet stepped on (0 .. 2)
+    // ndp_xchg_tick_async: the exchange stream's launches of a begin (wait, advance + columns, ncclAllGather, event record: ~15 us of
+    // host time) are made by a thread of the exchange's own; the caller's begin only describes them (~2 us).  One host thread's
+    // launches are what bounds the remote tick one period ahead; with two the device does.
+    struct Job {
+        bool adv = false;
+        TickPre a{};                                  // adv: the advance (+ columns) launch
+        const double *pack_base = nullptr;            // !adv: the columns of the window that is there
+        size_t pack_pitch = 0, B = 0, rows = 0;
+        int np1 = 0, p = 0;
+        void *gathered = nullptr;
+        hipEvent_t wait_ev = nullptr;
+    };
+    Job job[3];                                      // begin n's launches: job[n % 3]
+    unsigned job_n[3] = {0, 0, 0};                   // ... and n itself
+    std::atomic<unsigned> posted{0}, done{0};
+    std::atomic<int> async_rc{0};
+    std::atomic<bool> stop{false};
+    std::thread worker;
+    bool async = false;
     std::string err;
 };
 
@@ -2500,7 +2521,8 @@ int ndp_xchg_create(int device, int rank, int world, const unsigned char *id128,
         hipEventCreateWithFlags(&x->evReady, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&x->evDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&x->evGather[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&x->evGather[1], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&x->evGather[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&x->evGather[2], hipEventDisableTiming) != hipSuccess) {
         (void)ndp_xchg_destroy(x.release());      // (releases whatever exists: communicator, stream, events)
         return -3;
     }
@@ -2556,9 +2578,20 @@ int ndp_xchg_tick(ndp_xchg *x, ndp_handle *h, void *stream, const void *d_xr_nex
 
 const char *ndp_xchg_last_error(const ndp_xchg *x) { return x ? x->err.c_str() : "null exchange"; }
 
+static void xchg_worker_stop(ndp_xchg *x)
+{
+    if (x->worker.joinable()) {
+        x->stop.store(true, std::memory_order_release);
+        x->worker.join();
+        x->stop.store(false, std::memory_order_release);
+    }
+    x->async = false;
+}
+
 int ndp_xchg_destroy(ndp_xchg *x)
 {
     if (!x) return -1;
+    xchg_worker_stop(x);
     (void)hipSetDevice(x->device);
     if (x->cs) (void)hipStreamSynchronize(x->cs);
     if (x->comm) (void)g_rccl.destroy(x->comm);
@@ -4175,8 +4208,53 @@ int ndp_tick_step_device(ndp_handle *h, const void *d_x_odom, void *d_cmd, void 
 //                                                      rides on the step's dispatch packet; untracked: for everything its stream holds)
 //   advance i+1 writes list entries                  -> of another phase row than window i's (RingGeom: entries per node spacing >= 2,
 //                                                      refused otherwise), so it may run beside step i
-//   step i reads window i and gather buffer i        -> its stream waits for evGather[i & 1], recorded behind advance i, pack, gather
+//   step i reads window i and gather buffer i        -> its stream waits for its begin's event, recorded behind advance i, pack, gather
 //   the estimator reads the thrust step i-1 commanded -> same stream as the steps, in front of step i
+// the exchange stream's launches of one begin; returns 0 or the error code (the caller's thread or the exchange's own)
+static int xchg_job_run(ndp_xchg *x, const ndp_xchg::Job &j)
+{
+    if (j.wait_ev && hipStreamWaitEvent(x->cs, j.wait_ev, 0) != hipSuccess) return -3;
+    if (j.adv) hipLaunchKernelGGL(tick_pre_kernel, dim3((unsigned)((j.B + 63) / 64)), dim3(64), 0, x->cs, j.a);
+    else {
+        const size_t n = j.rows * 3;
+        hipLaunchKernelGGL(pack_pv_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, x->cs, j.pack_base, j.pack_pitch, j.np1, x->send, j.B);
+    }
+    if (hipGetLastError() != hipSuccess) return -3;
+    const int r = g_rccl.allgather(x->send, j.gathered, j.rows * 6, /* ncclFloat64 */ 8, x->comm, x->cs);
+    if (r != 0) { x->err = g_rccl.errstr ? g_rccl.errstr(r) : "ncclAllGather failed"; return -22; }
+    return hipEventRecord(x->evGather[j.p], x->cs) == hipSuccess ? 0 : -3;
+}
+
+static void xchg_worker(ndp_xchg *x)
+{
+    (void)hipSetDevice(x->device);
+    int idle = 0;
+    for (;;) {
+        const unsigned want = x->done.load(std::memory_order_relaxed) + 1;
+        if ((int)(x->posted.load(std::memory_order_acquire) - want) >= 0) {
+            const int rc = xchg_job_run(x, x->job[want % 3]);
+            if (rc) x->async_rc.store(rc, std::memory_order_relaxed);
+            x->done.store(want, std::memory_order_release);
+            idle = 0;
+        } else if (x->stop.load(std::memory_order_acquire)) break;
+        else if (++idle < 200000) __builtin_ia32_pause();                     // (~ a millisecond of spinning behind the last job, then naps)
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+// on: begins are described by the caller and LAUNCHED by a thread of the exchange's own (see ndp_xchg::Job); off: launched by the caller
+int ndp_xchg_tick_async(ndp_xchg *x, int on)
+{
+    if (!x) return -1;
+    if (x->ahead != 0) { x->err = "ndp_xchg_tick_async: gathers are ahead of the control steps (step on them first)"; return -14; }
+    if (on && !x->worker.joinable()) {
+        x->stop.store(false);
+        try { x->worker = std::thread(xchg_worker, x); } catch (...) { x->err = "ndp_xchg_tick_async: no thread"; return -4; }
+        x->async = true;
+    } else if (!on) xchg_worker_stop(x);
+    return 0;
+}
+
 int ndp_xchg_tick_begin(ndp_xchg *x, ndp_handle *h, const void *d_t, int flags, void *d_gathered)
 {
     if (!x || !h || !d_gathered) return -1;
@@ -4188,29 +4266,41 @@ int ndp_xchg_tick_begin(ndp_xchg *x, ndp_handle *h, const void *d_t, int flags, 
     if (!h->dRingX) { h->err = "ndp_xchg_tick_begin: no reference list"; return -11; }
     if (d_t && !h->dTraj) { h->err = "ndp_xchg_tick_begin: a trajectory time was given but ndp_ref_set_trajectory was never called"; return -11; }
     if (x->ahead >= 2) { h->err = "ndp_xchg_tick_begin: two gathers are already ahead of the control steps (ndp_xchg_tick_step first)"; return -14; }
+    if ((rc = x->async_rc.load(std::memory_order_relaxed))) { h->err = "ndp_xchg_tick_begin: an earlier begin failed on the exchange's thread: " + x->err; return rc; }
     const RingGeom rg = ring_geom(h);
     if (d_t && rg.step < 2) { h->err = "ndp_xchg_tick_begin: the list's entries are one node spacing apart -- the advance would overwrite the window a control step may be reading (use the serial form: ndp_tick_advance_device, ndp_xchg_tick_windows, ndp_tick_step_device)"; return -17; }
-    const int p = x->begin_par;
-    const size_t B = h->cfg.batch, rows = B * (size_t)(h->cfg.N + 1), n = rows * 3;
+    const size_t B = h->cfg.batch, rows = B * (size_t)(h->cfg.N + 1);
     if (x->send_doubles < rows * 6) {
+        while (x->done.load(std::memory_order_acquire) != x->posted.load(std::memory_order_relaxed)) __builtin_ia32_pause();
         if (x->send) { (void)hipStreamSynchronize(x->cs); (void)hipFree(x->send); x->send = nullptr; }
         NDP_HIP(h, hipMalloc((void **)&x->send, rows * 6 * sizeof(double)));
         x->send_doubles = rows * 6;
     }
-    if (x->has_reader[p]) {
-        const bool precise = h->track_steps && x->reader_seq[p] && h->step_seq - x->reader_seq[p] < 4u;
-        if (precise) NDP_HIP(h, hipStreamWaitEvent(x->cs, h->stepDone[x->reader_seq[p] & 3], 0));
-        else {
-            NDP_HIP(h, hipEventRecord(x->evReady, x->reader_stream[p]));
-            NDP_HIP(h, hipStreamWaitEvent(x->cs, x->evReady, 0));
+    const unsigned n_job = x->posted.load(std::memory_order_relaxed) + 1;
+    const int p = (int)(n_job % 3u);
+    ndp_xchg::Job &j = x->job[p];                  // (free: at most two are ahead, and a step waits for its begin's launches)
+    j = ndp_xchg::Job{};
+    j.p = p; j.B = B; j.rows = rows; j.np1 = h->cfg.N + 1; j.gathered = d_gathered;
+    // the gather overwrites a buffer: behind the control step that read it last
+    const ndp_xchg::Reader *rd = nullptr;
+    for (const ndp_xchg::Reader &r : x->readers) if (r.ptr == d_gathered) rd = &r;
+    for (int q = 0; q < 3; ++q)                    // (a begin that is still ahead of its step names the same buffer: the caller cycles too few)
+        if (x->buf[q] == d_gathered && (int)(x->job_n[q] - x->steps) > 0) { h->err = "ndp_xchg_tick_begin: this gather buffer holds a tick that has not been stepped on yet"; return -14; }
+    if (rd) {
+        const bool precise = h->track_steps && rd->seq && h->step_seq - rd->seq < 4u;
+        if (precise) {
+            j.wait_ev = h->stepDone[rd->seq & 3];
+        } else {
+            NDP_HIP(h, hipEventRecord(x->evReady, rd->stream));
+            j.wait_ev = x->evReady;
         }
-    } else {            // the first gathers: behind whatever made the list (ndp_ref_list_reset / ndp_tick_reset on the handle's stream)
+    } else if (n_job == 1) {            // the first gather: behind whatever made the list (ndp_ref_list_reset / ndp_tick_reset on the handle's stream)
         NDP_HIP(h, hipEventRecord(x->evReady, h->stream));
-        NDP_HIP(h, hipStreamWaitEvent(x->cs, x->evReady, 0));
+        j.wait_ev = x->evReady;
     }
     if (d_t) {
         const bool uni = (flags & TICK_T_UNIFORM) != 0;
-        TickPre a{};
+        TickPre &a = j.a;
         a.cf = ref_cfg(h, h->cfg.N * h->cfg.dt);
         const size_t Bs = B, S = (size_t)h->traj_seg;
         a.coeff = h->dTraj; a.tcum = a.coeff + Bs * S * 28; a.tseg = a.tcum + Bs * (S + 1); a.fpt = a.tseg + Bs * S;
@@ -4221,19 +4311,21 @@ int ndp_xchg_tick_begin(ndp_xchg *x, ndp_handle *h, const void *d_t, int flags, 
         a.thr = thr_cfg(h); a.st = h->dThr;
         a.vz = h->dTickThrust; a.vz_pitch = 1; a.throttle = h->dTickThrust; a.est = 0;      // (no estimator here: it belongs to the step's side)
         a.pv = x->send; a.pv_slot = rg.slot(h->list_n + 1);                                 // ... and the advanced window's columns in the same launch
-        hipLaunchKernelGGL(tick_pre_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, x->cs, a);
-        NDP_HIP(h, hipGetLastError());
+        j.adv = true;
         ++h->list_n;
     } else {
-        hipLaunchKernelGGL(pack_pv_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, x->cs, h->dRingX + rg.slot(h->list_n) * 10, rg.px(),
-                           h->cfg.N + 1, x->send, B);
-        NDP_HIP(h, hipGetLastError());
+        j.pack_base = h->dRingX + rg.slot(h->list_n) * 10; j.pack_pitch = rg.px();
     }
-    const int r = g_rccl.allgather(x->send, d_gathered, rows * 6, /* ncclFloat64 */ 8, x->comm, x->cs);
-    if (r != 0) { x->err = g_rccl.errstr ? g_rccl.errstr(r) : "ncclAllGather failed"; h->err = "ndp_xchg_tick_begin: " + x->err; return -22; }
-    NDP_HIP(h, hipEventRecord(x->evGather[p], x->cs));
+    x->job_n[p] = n_job;
+    x->buf[p] = d_gathered;
+    if (x->async) x->posted.store(n_job, std::memory_order_release);          // the exchange's thread takes it from here
+    else {
+        rc = xchg_job_run(x, j);
+        x->posted.store(n_job, std::memory_order_relaxed);
+        x->done.store(n_job, std::memory_order_relaxed);
+        if (rc) { h->err = "ndp_xchg_tick_begin: " + (rc == -22 ? x->err : std::string("a HIP call on the exchange's stream failed")); return rc; }
+    }
     x->win_n[p] = h->list_n;
-    x->begin_par ^= 1;
     ++x->ahead;
     return 0;
 }
@@ -4249,7 +4341,9 @@ int ndp_xchg_tick_step(ndp_xchg *x, ndp_handle *h, const void *d_x_odom, const v
     int rc = ensure_tick(h);
     if (rc) return rc;
     const size_t B = h->cfg.batch;
-    const int p = x->step_par;
+    const unsigned k = x->steps + 1;               // this step consumes begin k
+    const int p = (int)(k % 3u);
+    if (x->buf[p] != d_gathered || x->job_n[p] != k) { h->err = "ndp_xchg_tick_step: this tick's gather was begun into another buffer"; return -14; }
     if (flags & TICK_ESTIMATE) {
         TickPre a{};
         a.cf = ref_cfg(h, h->cfg.N * h->cfg.dt);
@@ -4262,15 +4356,20 @@ int ndp_xchg_tick_step(ndp_xchg *x, ndp_handle *h, const void *d_x_odom, const v
         hipLaunchKernelGGL(tick_pre_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, a);
         NDP_HIP(h, hipGetLastError());
     }
+    // (asynchronous begins: the event must have been RECORDED by the exchange's thread before this stream is told to wait for it)
+    while ((int)(x->done.load(std::memory_order_acquire) - k) < 0) __builtin_ia32_pause();
+    if ((rc = x->async_rc.load(std::memory_order_relaxed))) { h->err = "ndp_xchg_tick_step: this tick's begin failed on the exchange's thread: " + x->err; return rc; }
     NDP_HIP(h, hipStreamWaitEvent(s, x->evGather[p], 0));
     rc = tick_step_enqueue(h, s, (const double *)d_x_odom, (double *)d_cmd, (double *)d_u0, (const double *)d_gathered, x->win_n[p]);
     if (rc) return rc;
-    x->has_reader[p] = true;
-    x->reader_stream[p] = s;
-    x->reader_seq[p] = (h->track_steps && h->last_step_tracked) ? h->step_seq : 0u;
-    x->step_par ^= 1;
+    ndp_xchg::Reader *slot = nullptr;              // this buffer's entry, else the one not touched for longest
+    for (ndp_xchg::Reader &r : x->readers) if (r.ptr == d_gathered) slot = &r;
+    if (!slot) { slot = &x->readers[0]; for (ndp_xchg::Reader &r : x->readers) if (r.age < slot->age) slot = &r; }
+    slot->ptr = d_gathered; slot->stream = s; slot->age = k;
+    slot->seq = (h->track_steps && h->last_step_tracked) ? h->step_seq : 0u;
+    x->steps = k;
     --x->ahead;
-    if (x->reader_seq[p]) { h->track_pending = true; return 0; }     // (the getters wait for the step's own completion event: no second one)
+    if (slot->seq) { h->track_pending = true; return 0; }     // (the getters wait for the step's own completion event: no second one)
     return note_stream(h, s);
 }
 

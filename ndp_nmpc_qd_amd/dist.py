@@ -298,6 +298,12 @@ class RcclExchange:
         if rc:
             raise RuntimeError(f"ndp_xchg_tick_windows failed ({rc}): {self._lib.ndp_xchg_last_error(self._h).decode()}")
 
+    def tick_async(self, on=True):
+        """Begins launched by a thread of the exchange's own (ndp_xchg_tick_async): the caller's thread then only launches the steps."""
+        rc = self._lib.ndp_xchg_tick_async(self._h, 1 if on else 0)
+        if rc:
+            raise RuntimeError(f"ndp_xchg_tick_async failed ({rc}): {self._lib.ndp_xchg_last_error(self._h).decode()}")
+
     def tick_begin(self, eng, gathered_next, t=None):
         """The remote tick one control period ahead: list advance to the NEXT period's trajectory time t (scalar, CUDA tensor [B] or None:
         no advance), window columns, all-gather into `gathered_next` -- on the exchange's own stream, beside the control step of the

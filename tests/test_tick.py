@@ -646,12 +646,14 @@ def test_tick_windows_through_the_library_collective_equals_the_single_handle_ti
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tracked", [True, False])
-def test_remote_tick_with_the_exchange_one_period_ahead_equals_the_single_handle_tick(tracked):
+@pytest.mark.parametrize("tracked,asyn,nbuf", [(True, False, 2), (False, False, 2), (True, True, 2), (True, False, 3), (True, True, 3), (False, True, 3)])
+def test_remote_tick_with_the_exchange_one_period_ahead_equals_the_single_handle_tick(tracked, asyn, nbuf):
     """ndp_xchg_tick_begin / _step: the list advance, window columns and all-gather of tick i+1 on the exchange's stream beside the
     control step of tick i (two gather buffers), ordered by events on the device -- with tracked steps the gather waits for exactly the
     step that read its buffer last, without them for that step's stream.  One-rank communicator (a real ncclAllGather).  Bit-equal with
-    the one-launch tick of one handle over 14 ticks, estimator on every tick; the protocol's misuse is refused."""
+    the one-launch tick of one handle over 14 ticks, estimator on every tick; the protocol's misuse is refused.  asyn: the begins'
+    launches made by the exchange's own thread (ndp_xchg_tick_async).  nbuf = 3: the begin of tick i + 2 behind the step of tick i,
+    into a third buffer (the gather then never waits for a control step)."""
     import torch
     import ndp_nmpc_qd_amd as ndp
     from ndp_nmpc_qd_amd import dist as ndist
@@ -669,7 +671,7 @@ def test_remote_tick_with_the_exchange_one_period_ahead_equals_the_single_handle
     one, rem = make(), make()
     one.tick_config(oi, gate=True)
     one.tick_reset()
-    gathered = [torch.zeros(B, 21, 6, dtype=torch.float64, device=dev) for _ in range(2)]
+    gathered = [torch.zeros(B, 21, 6, dtype=torch.float64, device=dev) for _ in range(nbuf)]
     rem.tick_config_remote(gathered[0], oi, gate=True)
     rem.tick_reset()
     if tracked:
@@ -678,6 +680,8 @@ def test_remote_tick_with_the_exchange_one_period_ahead_equals_the_single_handle
         ex = ndist.RcclExchange(B, 20, 0)
     except RuntimeError as e:
         pytest.skip(f"RCCL could not be bound: {e}")
+    if asyn:
+        ex.tick_async(True)
     stream = torch.cuda.Stream(device=dev)
     cmd1, u1 = torch.empty(B, 4, dtype=torch.float64, device=dev), torch.empty(B, 4, dtype=torch.float64, device=dev)
     cmd2 = [torch.empty(B, 4, dtype=torch.float64, device=dev) for _ in range(14)]
@@ -699,20 +703,27 @@ def test_remote_tick_with_the_exchange_one_period_ahead_equals_the_single_handle
         torch.cuda.synchronize()
         ref1.append((cmd1.clone(), u1.clone(), one.device_force().clone()))
     # the pipelined remote form: no host synchronisation inside the loop; tick i's trajectory time is 0.02 (i + 1)
-    ex.tick_begin(rem, gathered[0], t=0.02)
+    la = nbuf - 1                              # begins ahead of the steps: 1 (two buffers) or 2 (three)
+    for i in range(la):
+        ex.tick_begin(rem, gathered[i % nbuf], t=0.02 * (i + 1))
     for i in range(n):
-        ex.tick_step(rem, xs[i], cmd2[i], gathered[i % 2], stream, estimate=True, u0_out=u2[i])
-        if i + 1 < n:
-            ex.tick_begin(rem, gathered[(i + 1) % 2], t=0.02 * (i + 2))
+        ex.tick_step(rem, xs[i], cmd2[i], gathered[i % nbuf], stream, estimate=True, u0_out=u2[i])
+        if i + la < n:
+            ex.tick_begin(rem, gathered[(i + la) % nbuf], t=0.02 * (i + la + 1))
     torch.cuda.synchronize()
     for i in range(n):
         assert torch.equal(cmd2[i], ref1[i][0]) and torch.equal(u2[i], ref1[i][1]), i
     assert np.array_equal(rem.throttle_state(), one.throttle_state())
-    # two gathers may be ahead of the steps, not three
+    # two gathers may be ahead of the steps, not three; and not two into one buffer
     ex.tick_begin(rem, gathered[0], t=None)
+    with pytest.raises(RuntimeError, match="not been stepped on"):
+        ex.tick_begin(rem, gathered[0], t=None)
     ex.tick_begin(rem, gathered[1], t=None)
     with pytest.raises(RuntimeError, match="already ahead"):
         ex.tick_begin(rem, gathered[0], t=None)
+    if asyn:
+        with pytest.raises(RuntimeError, match="ahead of the control steps"):     # (not while gathers are ahead)
+            ex.tick_async(False)
     torch.cuda.synchronize()
     ex.close()
 
